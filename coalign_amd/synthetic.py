@@ -1,0 +1,122 @@
+"""Synthetic OPV2V-shaped frames (SURVEY §8d "Synthetic inputs").
+
+There is no dataset in the build or bench environment, so every test and ``bench.py`` feed the hot
+path with frames generated here.  The output is the batch dict the reference's collate functions
+produce for ``model(batch_data['ego'])`` (intermediate_fusion_dataset.py:441-575 keys only):
+
+    processed_lidar: voxel_features [sum M, 32, 4] f32, voxel_coords [sum M, 4] i32 (agent, z, y, x),
+                     voxel_num_points [sum M] i32
+    record_len [B] int64, pairwise_t_matrix [B, L, L, 4, 4] float64
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .pose import generate_noise, get_pairwise_transformation
+
+
+def make_pillars(rng: np.random.RandomState, agent: int, n_pillars: int, nx: int, ny: int,
+                 voxel_size: Sequence[float], pc_range: Sequence[float], max_points: int = 32,
+                 num_points_mode: str = "geometric"):
+    """One agent's pillars: ``n_pillars`` distinct cells, 1..max_points points each (LiDAR-like skew:
+    ``min(P, 1 + Geometric(0.12))`` or uniform), points jittered around the cell centre, zero padded."""
+    n_pillars = min(n_pillars, nx * ny)
+    cells = rng.choice(nx * ny, size=n_pillars, replace=False)
+    cy, cx = np.divmod(cells, nx)
+    if num_points_mode == "geometric":
+        npts = np.minimum(max_points, rng.geometric(0.12, size=n_pillars)).astype(np.int32)
+    else:
+        npts = rng.randint(1, max_points + 1, size=n_pillars).astype(np.int32)
+    vx, vy = voxel_size[0], voxel_size[1]
+    ctr_x = (cx + 0.5) * vx + pc_range[0]
+    ctr_y = (cy + 0.5) * vy + pc_range[1]
+    pts = np.zeros((n_pillars, max_points, 4), dtype=np.float32)
+    pts[:, :, 0] = ctr_x[:, None] + rng.uniform(-0.5 * vx, 0.5 * vx, size=(n_pillars, max_points))
+    pts[:, :, 1] = ctr_y[:, None] + rng.uniform(-0.5 * vy, 0.5 * vy, size=(n_pillars, max_points))
+    pts[:, :, 2] = rng.uniform(pc_range[2], pc_range[5], size=(n_pillars, max_points))
+    pts[:, :, 3] = rng.uniform(0.0, 1.0, size=(n_pillars, max_points))
+    pts *= (np.arange(max_points)[None, :] < npts[:, None])[:, :, None]
+    coords = np.stack([np.full(n_pillars, agent), np.zeros(n_pillars, dtype=np.int64), cy, cx], axis=1).astype(np.int32)
+    return pts, coords, npts
+
+
+def make_poses(rng: np.random.RandomState, n_agents: int, noise: Optional[Sequence[float]] = None,
+               spread_xy=(20.0, 10.0), spread_yaw=30.0, infra_agent: bool = False) -> List[np.ndarray]:
+    """Ego at the origin; others within +-spread (metres / degrees).  ``infra_agent`` places agent 1 like a
+    DAIR-V2X road-side unit (~30 m ahead, facing back).  Optional Gaussian noise (pos m, rot deg) is
+    added to every agent's pose with the reference's draw order."""
+    poses = [np.zeros(6)]
+    for a in range(1, n_agents):
+        if infra_agent and a == 1:
+            poses.append(np.array([30.0, 5.0, 0.0, 0.0, 170.0, 0.0]))
+        else:
+            poses.append(np.array([rng.uniform(-spread_xy[0], spread_xy[0]), rng.uniform(-spread_xy[1], spread_xy[1]),
+                                   0.0, 0.0, rng.uniform(-spread_yaw, spread_yaw), 0.0]))
+    if noise is not None:
+        poses = [p + generate_noise(noise[0], noise[1], rng=rng) for p in poses]
+    return poses
+
+
+def make_frame(hypes: dict, n_agents: Sequence[int] | int, pillars_per_agent: int = 8000, seed: int = 303,
+               num_points_mode: str = "geometric", noise: Optional[Sequence[float]] = None,
+               infra_agent: bool = False, spread_xy=(20.0, 10.0), spread_yaw=30.0) -> Dict:
+    """Batch dict for ``model.forward``.  ``n_agents`` may be a list (one entry per frame in the batch)."""
+    rng = np.random.RandomState(seed)
+    record = [n_agents] if isinstance(n_agents, int) else list(n_agents)
+    margs = hypes["model"]["args"]
+    nx, ny, _ = [int(v) for v in margs["point_pillar_scatter"]["grid_size"]]
+    L = int(hypes.get("train_params", {}).get("max_cav", 5))
+    L = max(L, max(record))
+    feats, coords, npts, pair = [], [], [], []
+    agent = 0
+    for n in record:
+        for _ in range(n):
+            p, c, k = make_pillars(rng, agent, pillars_per_agent, nx, ny, margs["voxel_size"], margs["lidar_range"],
+                                   num_points_mode=num_points_mode)
+            feats.append(p); coords.append(c); npts.append(k)
+            agent += 1
+        poses = make_poses(rng, n, noise=noise, infra_agent=infra_agent, spread_xy=spread_xy, spread_yaw=spread_yaw)
+        pair.append(get_pairwise_transformation(poses, L))
+    return {
+        "processed_lidar": {
+            "voxel_features": torch.from_numpy(np.concatenate(feats)),
+            "voxel_coords": torch.from_numpy(np.concatenate(coords)),
+            "voxel_num_points": torch.from_numpy(np.concatenate(npts)),
+        },
+        "record_len": torch.tensor(record, dtype=torch.int64),
+        "pairwise_t_matrix": torch.from_numpy(np.stack(pair)),
+    }
+
+
+def fill_parameters_(module: torch.nn.Module, seed: int = 0, cls_bias: float = -2.0) -> None:
+    """Deterministic, name-keyed test weights (independent of module construction order, so two
+    differently written implementations with the same state_dict names get identical values).
+    BN running stats are randomised (mean ~ N(0, .1), var ~ U(.5, 1.5)) so BN folding is exercised."""
+    import zlib
+    sd = module.state_dict()
+    with torch.no_grad():
+        for name in sorted(sd.keys()):
+            t = sd[name]
+            if not t.is_floating_point():
+                continue
+            g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + seed) & 0x7FFFFFFF)
+            shape = tuple(t.shape)
+            if name.endswith("running_var"):
+                v = torch.rand(shape, generator=g) + 0.5
+            elif name.endswith("running_mean"):
+                v = torch.randn(shape, generator=g) * 0.1
+            elif name.endswith("bias"):
+                v = torch.randn(shape, generator=g) * 0.1
+                if name == "cls_head.bias":
+                    v = v + cls_bias
+            elif t.dim() == 1:                       # BN / norm scale
+                v = torch.rand(shape, generator=g) + 0.5
+            else:                                    # conv / linear / deconv weight
+                fan_in = t[0].numel() if t.dim() > 1 else t.numel()
+                if "deblocks" in name and t.dim() == 4:   # ConvTranspose2d weight is [Cin, Cout, k, k]
+                    fan_in = t.shape[0]
+                v = torch.randn(shape, generator=g) * (1.5 / fan_in) ** 0.5
+            t.copy_(v.to(t.dtype))

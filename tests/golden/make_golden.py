@@ -1,0 +1,287 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory by IMPORTING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference; it never travels to the GPU box, the
+``.npz`` files do).  Usage:  python tests/golden/make_golden.py
+
+What is pinned: every function of the hot path that the reference can execute here is
+called unmodified -- ``create_model`` on the unchanged OPV2V CoAlign yaml (only ``cav_lidar_range`` is
+shrunk for the mini cases), ``PillarVFE``, ``PointPillarScatter``, ``normalize_pairwise_tfm``,
+``warp_affine_simple``, ``AttFusion`` / ``MaxFusion``, the ResNet backbone + heads,
+``VoxelPostprocessor.generate_anchor_box`` / ``post_process`` and ``box_utils.nms_rotated``.
+
+Optional third-party modules the reference imports at module scope but that are absent here are
+replaced by inert stubs (icecream, pyquaternion, turtle, cv2, open3d, the un-built Cython
+``box_overlaps``).  ``shapely.geometry.Polygon`` -- the one stub that *computes* something -- is backed
+by the oracle's fp64 clipping routine: this pins the reference's NMS control flow (argsort, top-1000,
+float32 IoU array, strict ``>``) but NOT the GEOS area arithmetic (parity unpinned).
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+from oracle import coalign_oracle as oracle  # noqa: E402
+from coalign_amd.synthetic import fill_parameters_, make_frame  # noqa: E402  (input generators only)
+
+REF = "/root/reference"
+YAML_COALIGN = REF + "/opencood/hypes_yaml/opv2v/lidar_only_with_noise/coalign/pointpillar_coalign.yaml"
+YAML_SINGLE = REF + "/opencood/hypes_yaml/opv2v/lidar_only_with_noise/pointpillar_single.yaml"
+YAML_DAIR = REF + "/opencood/hypes_yaml/dairv2x/lidar_only_with_noise/coalign/pointpillar_coalign.yaml"
+MINI_RANGE = [-12.8, -6.4, -3, 12.8, 6.4, 1]
+
+
+class _OraclePolygon:
+    """Minimal stand-in for shapely.geometry.Polygon (area / intersection / union of convex quads)."""
+
+    def __init__(self, pts=None, area=None):
+        self.pts = None if pts is None else np.asarray(pts, dtype=np.float64)
+        self._area = area
+
+    @property
+    def area(self):
+        if self._area is not None:
+            return self._area
+        x, y = self.pts[:, 0], self.pts[:, 1]
+        return abs(0.5 * float(np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y)))
+
+    def intersection(self, other):
+        return _OraclePolygon(area=oracle.quad_intersection_area(self.pts, other.pts))
+
+    def union(self, other):
+        return _OraclePolygon(area=self.area + other.area - oracle.quad_intersection_area(self.pts, other.pts))
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("icecream", ic=lambda *a, **k: None)
+    mod("pyquaternion", Quaternion=object)
+    sh = mod("shapely")
+    sh.geometry = mod("shapely.geometry", Polygon=_OraclePolygon)
+    mod("turtle", update=None)
+    mod("cv2")
+    mod("open3d")
+    mod("opencood.utils.box_overlaps", bbox_overlaps=None)
+    sys.path.insert(0, REF)
+
+
+def load_hypes(path, lidar_range=None):
+    from opencood.hypes_yaml import yaml_utils
+    h = yaml_utils.load_yaml(path)
+    if lidar_range is not None:
+        h["preprocess"]["cav_lidar_range"][:] = lidar_range      # shared by the yaml anchors
+        h = yaml_utils.load_point_pillar_params(h)
+    return h
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main():
+    install_stubs()
+    from opencood.tools import train_utils
+    from opencood.data_utils.post_processor import build_postprocessor
+    from opencood.models.fuse_modules.fusion_in_one import AttFusion, MaxFusion
+    from opencood.models.sub_modules.torch_transformation_utils import warp_affine_simple
+    from opencood.utils.transformation_utils import normalize_pairwise_tfm, x_to_world, get_pairwise_transformation
+    from opencood.utils import box_utils
+
+    torch.manual_seed(0)
+    np.random.seed(303)
+    torch.set_grad_enabled(False)
+
+    # ------------------------------------------------------------------ mini CoAlign model, end to end
+    h = load_hypes(YAML_COALIGN, MINI_RANGE)
+    model = train_utils.create_model(h).eval()
+    fill_parameters_(model, seed=0, cls_bias=-1.0)
+    frame = make_frame(h, [3, 2], pillars_per_agent=120, seed=11, spread_xy=(4.0, 2.0), spread_yaw=40.0)
+    bd = {"voxel_features": frame["processed_lidar"]["voxel_features"],
+          "voxel_coords": frame["processed_lidar"]["voxel_coords"],
+          "voxel_num_points": frame["processed_lidar"]["voxel_num_points"],
+          "record_len": frame["record_len"]}
+    bd = model.pillar_vfe(bd)
+    bd = model.scatter(bd)
+    canvas = bd["spatial_features"]
+    H0, W0 = canvas.shape[2:]
+    aff = normalize_pairwise_tfm(frame["pairwise_t_matrix"], H0, W0, model.voxel_size[0])
+    feats = model.backbone.get_multiscale_feature(canvas)
+    fused = [m(f, frame["record_len"], aff) for m, f in zip(model.fusion_net, feats)]
+    out = model(frame)
+    sd = model.state_dict()
+    pfx = "pillar_vfe.pfn_layers.0."
+    save("model_mini.npz",
+         voxel_features=bd["voxel_features"], voxel_coords=bd["voxel_coords"], voxel_num_points=bd["voxel_num_points"],
+         record_len=frame["record_len"], pairwise_t_matrix=frame["pairwise_t_matrix"],
+         pfn_weight=sd[pfx + "linear.weight"], pfn_bn_weight=sd[pfx + "norm.weight"], pfn_bn_bias=sd[pfx + "norm.bias"],
+         pfn_bn_mean=sd[pfx + "norm.running_mean"], pfn_bn_var=sd[pfx + "norm.running_var"],
+         pillar_features=bd["pillar_features"], canvas_sample=canvas.reshape(-1)[::7],
+         canvas_nonzero=torch.nonzero(canvas.reshape(-1)).view(-1).int(),
+         normalized_affine=aff,
+         feat0_sample=feats[0].reshape(-1)[::5], feat1_sample=feats[1].reshape(-1)[::5], feat2_sample=feats[2].reshape(-1)[::5],
+         fused0=fused[0], fused1=fused[1], fused2=fused[2],
+         cls_preds=out["cls_preds"], reg_preds=out["reg_preds"], dir_preds=out["dir_preds"],
+         fill_seed=0, cls_bias=-1.0, n_state=len(sd), n_params=sum(p.numel() for p in model.parameters()))
+
+    # ------------------------------------------------------------------ pose algebra
+    poses = [[0, 0, 0, 0, 0, 0], [12.5, -3.25, 0.4, 1.0, 33.0, -2.0], [-7.0, 8.0, 0.1, 0.0, -121.0, 0.5]]
+    worlds = np.stack([x_to_world(p) for p in poses])
+    pair = get_pairwise_transformation({i: {"params": {"lidar_pose": p}} for i, p in enumerate(poses)}, 5, False)
+    pt = torch.from_numpy(pair[None])
+    save("pose.npz", poses=np.array(poses), x_to_world=worlds, pairwise=pair,
+         normalized_200x704=normalize_pairwise_tfm(pt, 200, 704, 0.4), normalized_32x64=normalize_pairwise_tfm(pt, 32, 64, 0.4),
+         pairwise_after=pt)   # pairwise_after == pairwise proves the input is not modified
+
+    # ------------------------------------------------------------------ warp cases
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(6, 8, 16, 32, generator=g)
+    deg = np.radians
+    def rot(th, tx=0.0, ty=0.0, H=16, W=32):
+        c, s = np.cos(th), np.sin(th)
+        return [[c, -s * H / W, tx], [s * W / H, c, ty]]
+    theta = torch.tensor([[[1, 0, 0], [0, 1, 0]],                     # identity
+                          [[1, 0, 2 * 2.3 / 32], [0, 1, -2 * 1.7 / 16]],  # translation by non-integer pixels
+                          rot(deg(90)), rot(deg(37), 0.11, -0.07), rot(deg(-170), 0.4, 0.3),
+                          [[1, 0, 3.0], [0, 1, 0]]], dtype=torch.float64)   # fully out of range -> zeros
+    save("warp.npz", src=src, theta=theta, warped=warp_affine_simple(src, theta, (16, 32)))
+
+    # ------------------------------------------------------------------ fusion at the real channel widths
+    rl = torch.tensor([3, 2])
+    L = 5
+    g = torch.Generator().manual_seed(7)
+    pair = np.stack([get_pairwise_transformation({i: {"params": {"lidar_pose": p}} for i, p in enumerate(ps)}, L, False)
+                     for ps in ([[0, 0, 0, 0, 0, 0], [2.0, -1.0, 0, 0, 25.0, 0], [-3.0, 1.5, 0, 0, -100.0, 0]],
+                                [[0, 0, 0, 0, 0, 0], [1.0, 0.5, 0, 0, 5.0, 0]])])
+    aff_f = normalize_pairwise_tfm(torch.from_numpy(pair), 16, 32, 0.4)
+    fus = {"record_len": rl, "affine": aff_f}
+    for s, (C, H, W) in enumerate(((64, 8, 16), (128, 4, 8), (256, 2, 4))):
+        x = torch.randn(5, C, H, W, generator=g)
+        fus[f"x{s}"] = x
+        fus[f"att{s}"] = AttFusion(C)(x, rl, aff_f)
+        fus[f"max{s}"] = MaxFusion()(x, rl, aff_f)
+    save("fusion.npz", **fus)
+
+    # ------------------------------------------------------------------ anchors for every config
+    anc = {}
+    for tag, path, rng in (("opv2v_coalign", YAML_COALIGN, None), ("opv2v_late", YAML_SINGLE, None),
+                           ("dairv2x_coalign", YAML_DAIR, None), ("mini", YAML_COALIGN, MINI_RANGE)):
+        hh = load_hypes(path, rng)
+        pp = build_postprocessor(hh["postprocess"], False)
+        a = pp.generate_anchor_box()
+        anc[tag + "_shape"] = np.array(a.shape)
+        anc[tag + "_first"] = a.reshape(-1, 7)[0]
+        anc[tag + "_last"] = a.reshape(-1, 7)[-1]
+        anc[tag + "_sha256"] = np.frombuffer(bytes.fromhex(sha(a)), dtype=np.uint8)
+        anc[tag + "_grid_size"] = np.asarray(hh["model"]["args"]["point_pillar_scatter"]["grid_size"])
+        anc[tag + "_WHD"] = np.array([hh["postprocess"]["anchor_args"][k] for k in "WHD"])
+        if tag == "mini":
+            anc["mini_full"] = a
+    save("anchors.npz", **anc)
+
+    # ------------------------------------------------------------------ post-processing (decode + filters + NMS + range)
+    h = load_hypes(YAML_COALIGN, MINI_RANGE)
+    pp = build_postprocessor(h["postprocess"], False)
+    anchors = torch.from_numpy(pp.generate_anchor_box())
+    g = torch.Generator().manual_seed(21)
+    Hh, Ww = anchors.shape[:2]
+
+    def rand_heads(bias):
+        cls = torch.randn(1, 2, Hh, Ww, generator=g) * 1.5 + bias
+        reg = torch.randn(1, 14, Hh, Ww, generator=g) * 0.35
+        reg[:, [2, 9]] = reg[:, [2, 9]] * 0.2                      # keep z inside [-3, 1] for most boxes
+        dirp = torch.randn(1, 4, Hh, Ww, generator=g)
+        return cls, reg, dirp
+
+    post = {"anchors": anchors}
+    # intermediate fusion: one 'ego' entry, identity transform
+    cls, reg, dirp = rand_heads(-1.2)
+    data = {"ego": {"transformation_matrix": torch.eye(4), "anchor_box": anchors}}
+    outd = {"ego": {"cls_preds": cls, "reg_preds": reg, "dir_preds": dirp}}
+    boxes, scores = pp.post_process(data, outd)
+    post.update(i_cls=cls, i_reg=reg, i_dir=dirp, i_boxes=boxes, i_scores=scores,
+                i_delta_boxes=pp.delta_to_boxes3d(reg, anchors))
+    # late fusion: two agents, second one projected with a non-trivial T (float32 like late_fusion_dataset.py:464-466)
+    T1 = torch.from_numpy(np.linalg.solve(x_to_world([0, 0, 0, 0, 0, 0]), x_to_world([3.0, -1.0, 0.0, 0, 12.0, 0]))).float()
+    c0, r0, d0 = rand_heads(-1.6)
+    c1, r1, d1 = rand_heads(-1.6)
+    data = {"a0": {"transformation_matrix": torch.eye(4), "anchor_box": anchors},
+            "a1": {"transformation_matrix": T1, "anchor_box": anchors}}
+    outd = {"a0": {"cls_preds": c0, "reg_preds": r0, "dir_preds": d0}, "a1": {"cls_preds": c1, "reg_preds": r1, "dir_preds": d1}}
+    boxes, scores = pp.post_process(data, outd)
+    post.update(l_cls0=c0, l_reg0=r0, l_dir0=d0, l_cls1=c1, l_reg1=r1, l_dir1=d1, l_T1=T1, l_boxes=boxes, l_scores=scores)
+    # nothing above threshold -> (None, None)
+    cN = torch.full((1, 2, Hh, Ww), -9.0)
+    outd = {"ego": {"cls_preds": cN, "reg_preds": reg, "dir_preds": dirp}}
+    bN, sN = pp.post_process({"ego": {"transformation_matrix": torch.eye(4), "anchor_box": anchors}}, outd)
+    post.update(none_result=np.array([bN is None, sN is None]),
+                score_threshold=h["postprocess"]["target_args"]["score_threshold"], nms_thresh=h["postprocess"]["nms_thresh"],
+                gt_range=np.array(h["postprocess"]["gt_range"], dtype=np.float64))
+    # geometry helpers on a handful of boxes
+    b7 = torch.tensor([[1.0, 2.0, -1.0, 1.56, 1.6, 3.9, 0.3], [-4.0, 0.5, -0.8, 1.4, 1.9, 4.4, -2.0],
+                       [0.0, 0.0, -1.0, 1.5, 7.0, 3.0, 0.0], [2.0, 2.0, -2.9, 2.5, 1.6, 3.9, 1.0]])
+    c8 = box_utils.boxes_to_corners_3d(b7, "hwl")
+    post.update(g_boxes7=b7, g_corners=c8, g_proj=box_utils.project_box3d(c8, T1),
+                g_standup=box_utils.corner_to_standup_box_torch(c8),
+                g_keep_large=box_utils.remove_large_pred_bbx(c8), g_keep_z=box_utils.remove_bbx_abnormal_z(c8))
+    save("postprocess.npz", **post)
+
+    # ------------------------------------------------------------------ rotated NMS through the reference's control flow
+    rs = np.random.RandomState(99)
+    nms = {}
+    for tag, K, spread in (("small", 60, 12.0), ("mid", 400, 40.0), ("over1000", 1500, 60.0)):
+        b7 = np.zeros((K, 7), dtype=np.float32)
+        b7[:, 0] = rs.uniform(-spread, spread, K); b7[:, 1] = rs.uniform(-spread / 3, spread / 3, K); b7[:, 2] = -1
+        b7[:, 3] = 1.56; b7[:, 4] = rs.uniform(1.4, 2.2, K); b7[:, 5] = rs.uniform(3.0, 5.5, K); b7[:, 6] = rs.uniform(-3.2, 3.2, K)
+        corners = box_utils.boxes_to_corners_3d(torch.from_numpy(b7), "hwl")
+        sc = torch.from_numpy(rs.uniform(0.2, 1.0, K).astype(np.float32))
+        keep = box_utils.nms_rotated(corners, sc, 0.15)
+        nms.update({f"{tag}_corners": corners, f"{tag}_scores": sc, f"{tag}_keep": keep})
+    nms["empty_keep"] = box_utils.nms_rotated(torch.zeros(0, 8, 3), torch.zeros(0), 0.15)
+    nms["quad_keep"] = box_utils.nms_rotated(corners[:50, :4, :2], sc[:50], 0.15)   # (N,4,2) input form
+    save("nms.npz", **nms)
+
+    # ------------------------------------------------------------------ full-size pillar path + fusion (samples only)
+    hf = load_hypes(YAML_COALIGN)
+    mf = train_utils.create_model(hf).eval()
+    fill_parameters_(mf, seed=0, cls_bias=-1.0)
+    fr = make_frame(hf, 2, pillars_per_agent=8000, seed=303)
+    bd = {k: fr["processed_lidar"][k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")}
+    bd = mf.scatter(mf.pillar_vfe(bd))
+    cv = bd["spatial_features"]
+    nz = torch.nonzero(cv.reshape(-1)).view(-1)
+    g = torch.Generator().manual_seed(13)
+    full = {"pillar_rows": bd["pillar_features"][::50], "canvas_shape": np.array(cv.shape),
+            "canvas_nonzero_count": nz.numel(), "canvas_nonzero_sha256": np.frombuffer(bytes.fromhex(sha(nz.numpy().astype(np.int64))), dtype=np.uint8),
+            "canvas_sample_idx": nz[::997], "canvas_sample_val": cv.reshape(-1)[nz[::997]],
+            "frame_seed": 303, "pillars_per_agent": 8000}
+    aff = normalize_pairwise_tfm(fr["pairwise_t_matrix"], 200, 704, 0.4)
+    full["affine"] = aff
+    for s, (C, H, W) in enumerate(((64, 100, 352), (128, 50, 176), (256, 25, 88))):
+        x = torch.randn(2, C, H, W, generator=g)
+        y = AttFusion(C)(x, fr["record_len"], aff)
+        full[f"att{s}_sample"] = y.reshape(-1)[::211]
+        full[f"att{s}_shape"] = np.array(y.shape)
+    full["fusion_gen_seed"] = 13
+    save("fullsize.npz", **full)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,174 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only; runs in the build container and on the GPU box."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import coalign_oracle as oracle
+from coalign_amd.config import builtin_config
+
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a, np.asarray(b), rtol=rtol, atol=atol)
+
+
+def test_pillar_vfe_and_scatter(golden):
+    g = golden("model_mini.npz")
+    sd = {"pillar_vfe.pfn_layers.0.linear.weight": T(g["pfn_weight"]), "pillar_vfe.pfn_layers.0.norm.weight": T(g["pfn_bn_weight"]),
+          "pillar_vfe.pfn_layers.0.norm.bias": T(g["pfn_bn_bias"]), "pillar_vfe.pfn_layers.0.norm.running_mean": T(g["pfn_bn_mean"]),
+          "pillar_vfe.pfn_layers.0.norm.running_var": T(g["pfn_bn_var"])}
+    h = builtin_config("mini_coalign")["model"]["args"]
+    pf = oracle.pillar_vfe(T(g["voxel_features"]), T(g["voxel_num_points"]), T(g["voxel_coords"]), sd, h["voxel_size"], h["lidar_range"])
+    close(pf, g["pillar_features"], rtol=1e-5, atol=1e-5)
+    canvas = oracle.scatter(pf, T(g["voxel_coords"]), int(g["record_len"].sum()), 64, 32)
+    close(canvas.reshape(-1)[::7], g["canvas_sample"], rtol=1e-5, atol=1e-5)
+    # integer indexing is bit exact: same set of occupied positions
+    nz = torch.nonzero(oracle.scatter(T(g["pillar_features"]), T(g["voxel_coords"]), 5, 64, 32).reshape(-1)).view(-1).int().numpy()
+    assert np.array_equal(nz, g["canvas_nonzero"])
+
+
+def test_pose_algebra(golden):
+    g = golden("pose.npz")
+    for p, w in zip(g["poses"], g["x_to_world"]):
+        close(oracle.x_to_world(p), w, rtol=0, atol=1e-15)
+    pair = oracle.pairwise_transformation(g["poses"], 5)
+    close(pair, g["pairwise"], rtol=0, atol=1e-13)
+    pt = T(g["pairwise"])[None]
+    close(oracle.normalize_pairwise_tfm(pt, 200, 704, 0.4), g["normalized_200x704"], rtol=0, atol=1e-15)
+    close(oracle.normalize_pairwise_tfm(pt, 32, 64, 0.4), g["normalized_32x64"], rtol=0, atol=1e-15)
+    close(pt, g["pairwise_after"][None] if g["pairwise_after"].ndim == 4 else g["pairwise_after"], rtol=0, atol=0)
+
+
+def test_warp_affine_simple(golden):
+    g = golden("warp.npz")
+    out = oracle.warp_affine_simple(T(g["src"]), T(g["theta"]), (16, 32))
+    close(out, g["warped"], rtol=1e-5, atol=2e-6)
+    assert np.all(g["warped"][5] == 0) and torch.all(out[5] == 0)          # out-of-range case is exactly zero
+
+
+def test_att_and_max_fusion(golden):
+    g = golden("fusion.npz")
+    rl, aff = T(g["record_len"]), T(g["affine"])
+    for s in range(3):
+        x = T(g[f"x{s}"])
+        close(oracle.att_fuse(x, rl, aff), g[f"att{s}"], rtol=1e-5, atol=2e-6)
+        close(oracle.max_fuse(x, rl, aff), g[f"max{s}"], rtol=1e-5, atol=2e-6)
+
+
+def test_anchors(golden):
+    g = golden("anchors.npz")
+    for tag, cfg in (("opv2v_coalign", "opv2v_coalign"), ("opv2v_late", "opv2v_pointpillar_late"),
+                     ("dairv2x_coalign", "dairv2x_coalign"), ("mini", "mini_coalign")):
+        h = builtin_config(cfg)
+        a = oracle.generate_anchor_box(h["postprocess"]["anchor_args"], h["postprocess"]["order"])
+        assert list(a.shape) == list(g[tag + "_shape"]) and a.dtype == np.float64
+        assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest() == g[tag + "_sha256"].tobytes()
+        assert np.array_equal(a.reshape(-1, 7)[0], g[tag + "_first"]) and np.array_equal(a.reshape(-1, 7)[-1], g[tag + "_last"])
+        assert np.array_equal(np.asarray(h["model"]["args"]["point_pillar_scatter"]["grid_size"]), g[tag + "_grid_size"])
+        assert [h["postprocess"]["anchor_args"][k] for k in "WHD"] == list(g[tag + "_WHD"])
+    assert np.array_equal(oracle.generate_anchor_box(builtin_config("mini_coalign")["postprocess"]["anchor_args"]), g["mini_full"])
+
+
+def test_geometry_helpers(golden):
+    g = golden("postprocess.npz")
+    c8 = oracle.boxes_to_corners_3d(T(g["g_boxes7"]), "hwl")
+    close(c8, g["g_corners"], rtol=1e-6, atol=1e-6)
+    close(oracle.project_box3d(c8, T(g["l_T1"])), g["g_proj"], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(oracle.remove_large_pred_bbx(T(g["g_corners"])).numpy(), g["g_keep_large"])
+    assert np.array_equal(oracle.remove_bbx_abnormal_z(T(g["g_corners"])).numpy(), g["g_keep_z"])
+    close(oracle.delta_to_boxes3d(T(g["i_reg"]), T(g["anchors"])), g["i_delta_boxes"], rtol=1e-6, atol=1e-6)
+
+
+def _pp_cfg():
+    return builtin_config("mini_coalign")["postprocess"]
+
+
+def test_post_process_intermediate(golden):
+    g = golden("postprocess.npz")
+    boxes, scores, info = oracle.post_process([dict(cls_preds=T(g["i_cls"]), reg_preds=T(g["i_reg"]), dir_preds=T(g["i_dir"]))],
+                                              T(g["anchors"]), _pp_cfg())
+    assert boxes.shape == g["i_boxes"].shape                               # identical selection
+    close(scores, g["i_scores"], rtol=0, atol=0)
+    close(boxes, g["i_boxes"], rtol=1e-6, atol=1e-5)
+
+
+def test_post_process_late_and_empty(golden):
+    g = golden("postprocess.npz")
+    agents = [dict(cls_preds=T(g["l_cls0"]), reg_preds=T(g["l_reg0"]), dir_preds=T(g["l_dir0"]), transformation_matrix=torch.eye(4)),
+              dict(cls_preds=T(g["l_cls1"]), reg_preds=T(g["l_reg1"]), dir_preds=T(g["l_dir1"]), transformation_matrix=T(g["l_T1"]))]
+    boxes, scores, _ = oracle.post_process(agents, T(g["anchors"]), _pp_cfg())
+    assert boxes.shape == g["l_boxes"].shape
+    close(scores, g["l_scores"], rtol=0, atol=0)
+    close(boxes, g["l_boxes"], rtol=1e-6, atol=1e-5)
+    b, s, _ = oracle.post_process([dict(cls_preds=torch.full((1, 2, 16, 32), -9.0), reg_preds=T(g["i_reg"]), dir_preds=T(g["i_dir"]))],
+                                  T(g["anchors"]), _pp_cfg())
+    assert b is None and s is None and bool(g["none_result"].all())
+
+
+@pytest.mark.parametrize("tag", ["small", "mid", "over1000"])
+def test_nms_control_flow(golden, tag):
+    g = golden("nms.npz")
+    keep = oracle.nms_rotated(g[f"{tag}_corners"], g[f"{tag}_scores"], 0.15)
+    assert keep.dtype == np.int32 and np.array_equal(keep, g[f"{tag}_keep"])
+    if tag == "small":
+        assert np.array_equal(oracle.nms_rotated_numpy(g["small_corners"], g["small_scores"], 0.15), g["small_keep"])
+
+
+def test_nms_edge_cases(golden):
+    g = golden("nms.npz")
+    assert oracle.nms_rotated(np.zeros((0, 8, 3), np.float32), np.zeros(0, np.float32), 0.15).shape == (0,) == g["empty_keep"].shape
+    q = g["over1000_corners"][:50, :4, :2]
+    assert np.array_equal(oracle.nms_rotated(q, g["over1000_scores"][:50], 0.15), g["quad_keep"])
+
+
+def test_iou_known_answers():
+    def rect(cx, cy, l, w, th):
+        c, s = np.cos(th), np.sin(th)
+        t = np.array([[1, -1], [1, 1], [-1, 1], [-1, -1]]) * np.array([l, w]) / 2
+        return t @ np.array([[c, s], [-s, c]]) + np.array([cx, cy])
+    a = rect(0, 0, 3.9, 1.6, 0)
+    assert oracle.quad_iou(a, a) == 1.0
+    assert oracle.quad_iou(a, rect(10, 0, 3.9, 1.6, 0)) == 0.0
+    assert abs(oracle.quad_iou(a, rect(0, 0, 3.9, 1.6, np.pi / 2)) - 1.6 ** 2 / (2 * 3.9 * 1.6 - 1.6 ** 2)) < 1e-14
+    assert abs(oracle.quad_iou(a, rect(3.9 / 2, 0, 3.9, 1.6, 0)) - 1 / 3) < 1e-14
+    assert abs(oracle.quad_iou(a, a[::-1].copy()) - 1.0) < 1e-15                  # orientation independent
+    rng = np.random.default_rng(0)
+    for _ in range(500):                                                          # two independent algorithms agree
+        p = rect(*rng.uniform(-2, 2, 2), *rng.uniform(1, 5, 2), rng.uniform(-4, 4))
+        q = rect(*rng.uniform(-2, 2, 2), *rng.uniform(1, 5, 2), rng.uniform(-4, 4))
+        assert abs(oracle.quad_iou(p, q) - oracle.quad_iou_python(p, q)) < 1e-12
+    assert np.isnan(oracle.quad_iou(np.zeros((4, 2)), np.zeros((4, 2))))           # zero-area union -> NaN, never suppresses
+
+
+def _filled_state_dict(cfg_name):
+    """state_dict with the deterministic name-keyed test weights (built from the product's module classes only to get
+    names and shapes; values come from fill_parameters_)."""
+    from coalign_amd.synthetic import fill_parameters_
+    from coalign_amd.detector import build_model
+    h = builtin_config(cfg_name)
+    m = build_model(h)
+    fill_parameters_(m, seed=0, cls_bias=-1.0)
+    return h, {k: v.clone() for k, v in m.state_dict().items()}
+
+
+def test_full_model_mini(golden):
+    g = golden("model_mini.npz")
+    h, sd = _filled_state_dict("mini_coalign")
+    assert len(sd) == int(g["n_state"])
+    batch = {"processed_lidar": {"voxel_features": T(g["voxel_features"]), "voxel_coords": T(g["voxel_coords"]),
+                                 "voxel_num_points": T(g["voxel_num_points"])},
+             "record_len": T(g["record_len"]), "pairwise_t_matrix": T(g["pairwise_t_matrix"])}
+    out = oracle.coalign_forward(sd, h["model"]["args"], batch, return_intermediate=True)
+    close(out["pillar_features"], g["pillar_features"], rtol=1e-5, atol=1e-5)
+    close(out["affine"], g["normalized_affine"], rtol=0, atol=1e-15)
+    for s in range(3):
+        scale = float(np.abs(g[f"fused{s}"]).max())
+        close(out["feats"][s].reshape(-1)[::5], g[f"feat{s}_sample"], rtol=1e-4, atol=1e-5 * scale)
+        close(out["fused"][s], g[f"fused{s}"], rtol=1e-4, atol=1e-5 * scale)
+    for k in ("cls_preds", "reg_preds", "dir_preds"):
+        close(out[k], g[k], rtol=1e-4, atol=1e-4 * float(np.abs(g[k]).max()))
