@@ -1,0 +1,393 @@
+// Rotated NMS on device: score ranking, float64 convex-clipping IoU bitmask, device-side greedy reduction,
+// in-range gather.  gfx950.
+//
+// Reference semantics (see include/coalign_amd.h): nms_rotated, opencood/utils/box_utils.py:693-738, which
+// copies boxes to the host, builds one Shapely polygon per box and runs a sequential Python loop with two GEOS
+// boolean operations per remaining pair.  Here nothing leaves the device:
+//   rank_kernel    rank-by-counting on the key (score desc, index desc): O(K^2) compares, LDS tiled, no sort
+//                  passes, deterministic; writes the top-`top` order
+//   mask_kernel    one wavefront per 64x64 tile of the (upper-triangular) pair matrix, column polygons staged
+//                  in LDS, each lane builds the 64-bit suppression word of its row; IoU in float64 by
+//                  Sutherland-Hodgman clipping, rounded to float32 before the strict '>' like the reference
+//   reduce_kernel  single wavefront: lane w owns word w of the "removed" set; the inherently sequential part is
+//                  64 scalar steps per 64-row block on the diagonal word, the row ORs are parallel over words
+//   gather_kernel  kept boxes with all 8 corners inside the range (float64 compare), order preserving
+// Compiled with -ffp-contract=off so the float64 arithmetic is bit-identical to the gcc-built CPU oracle.
+#include "common.h"
+
+namespace {
+
+struct P2 { double x, y; };
+
+__device__ __forceinline__ double signed_area(const P2 *p, int n) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const P2 a = p[i], b = p[(i + 1 == n) ? 0 : i + 1];
+        s += a.x * b.y - b.x * a.y;
+    }
+    return 0.5 * s;
+}
+
+__device__ __forceinline__ int clip_halfplane(const P2 *subj, int n, P2 q0, P2 q1, double sgn, P2 *out) {
+    int m = 0;
+    const double ex = q1.x - q0.x, ey = q1.y - q0.y;
+    for (int i = 0; i < n; ++i) {
+        const P2 s = subj[i], e = subj[(i + 1 == n) ? 0 : i + 1];
+        const double ds = sgn * (ex * (s.y - q0.y) - ey * (s.x - q0.x));
+        const double de = sgn * (ex * (e.y - q0.y) - ey * (e.x - q0.x));
+        const bool s_in = ds >= 0.0, e_in = de >= 0.0;
+        if (s_in) out[m++] = s;
+        if (s_in != e_in) {
+            const double t = ds / (ds - de);
+            P2 r;
+            r.x = s.x + t * (e.x - s.x);
+            r.y = s.y + t * (e.y - s.y);
+            out[m++] = r;
+        }
+    }
+    return m;
+}
+
+// IoU of two convex quads; area_a / area_b are |signed areas|.
+__device__ double quad_iou(const P2 *a, double area_a, const P2 *b, double area_b, double sgn_b) {
+    P2 buf0[12], buf1[12];
+    int n = 4;
+    for (int i = 0; i < 4; ++i) buf0[i] = a[i];
+    P2 *src = buf0, *dst = buf1;
+    for (int k = 0; k < 4 && n > 0; ++k) {
+        n = clip_halfplane(src, n, b[k], b[(k + 1) & 3], sgn_b, dst);
+        P2 *t = src; src = dst; dst = t;
+    }
+    const double inter = n < 3 ? 0.0 : fabs(signed_area(src, n));
+    const double uni = area_a + area_b - inter;
+    return inter / uni;
+}
+
+__device__ __forceinline__ int live_k(const int *K_dev, int K) {
+    if (!K_dev) return K;
+    const int k = *K_dev;
+    return k < 0 ? 0 : (k < K ? k : K);
+}
+
+// ------------------------------------------------------------------------------------------------ rank
+__global__ __launch_bounds__(256) void rank_kernel(const float *__restrict__ scores, const uint8_t *__restrict__ valid,
+                                                   int Kcap, const int *K_dev, int top, int *__restrict__ order,
+                                                   int *__restrict__ n_sorted) {
+    __shared__ float tile[256];
+    const int K = live_k(K_dev, Kcap);
+    if ((int)(blockIdx.x * 256) >= K && blockIdx.x != 0) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float nanv = __builtin_nanf("");
+    float si = nanv;
+    if (i < K && (!valid || valid[i])) si = scores[i];
+    const bool vi = si == si;
+    int rank = 0, nvalid = 0;
+    for (int j0 = 0; j0 < K; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        float sj = nanv;
+        if (j < K && (!valid || valid[j])) sj = scores[j];
+        __syncthreads();
+        tile[threadIdx.x] = sj;
+        __syncthreads();
+        const int lim = min(256, K - j0);
+        for (int q = 0; q < lim; ++q) {
+            const float s = tile[q];
+            nvalid += (s == s);
+            rank += (s > si) || (s == si && (j0 + q) > i);
+        }
+    }
+    if (vi && rank < top) order[rank] = i;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_sorted = nvalid < top ? nvalid : top;
+}
+
+// ------------------------------------------------------------------------------------------------ mask
+struct Poly { P2 v[4]; double area, sgn, xmin, xmax, ymin, ymax; };
+
+__device__ __forceinline__ void load_poly(const float *boxes, int rows, int cols, int idx, Poly &p) {
+    const float *b = boxes + (size_t)idx * rows * cols;
+    p.xmin = p.ymin = INFINITY; p.xmax = p.ymax = -INFINITY;
+    for (int c = 0; c < 4; ++c) {
+        p.v[c].x = (double)b[c * cols];
+        p.v[c].y = (double)b[c * cols + 1];
+        p.xmin = fmin(p.xmin, p.v[c].x); p.xmax = fmax(p.xmax, p.v[c].x);
+        p.ymin = fmin(p.ymin, p.v[c].y); p.ymax = fmax(p.ymax, p.v[c].y);
+    }
+    const double sa = signed_area(p.v, 4);
+    p.area = fabs(sa);
+    p.sgn = sa >= 0.0 ? 1.0 : -1.0;
+}
+
+__global__ __launch_bounds__(64) void mask_kernel(const float *__restrict__ boxes, int rows, int cols,
+                                                  const int *__restrict__ order, const int *__restrict__ n_sorted,
+                                                  float thr, int nb, unsigned long long *__restrict__ mask) {
+    const int cb = blockIdx.x, rb = blockIdx.y;
+    if (cb < rb) return;
+    const int n = *n_sorted;
+    if (rb * 64 >= n || cb * 64 >= n) return;
+    __shared__ Poly colp[64];
+    const int lane = threadIdx.x;
+    const int j_own = cb * 64 + lane;
+    if (j_own < n) load_poly(boxes, rows, cols, order[j_own], colp[lane]);
+    __syncthreads();
+    const int i = rb * 64 + lane;
+    if (i >= n) return;
+    Poly row;
+    if (cb == rb) row = colp[lane];
+    else load_poly(boxes, rows, cols, order[i], row);
+    unsigned long long bits = 0;
+    const int lim = min(64, n - cb * 64);
+    for (int q = 0; q < lim; ++q) {
+        const int j = cb * 64 + q;
+        if (j <= i) continue;
+        const Poly &c = colp[q];
+        // disjoint bounding boxes => intersection exactly 0 => IoU 0 (or NaN): never '>' a non-negative thr
+        if (thr >= 0.f && (row.xmax < c.xmin || c.xmax < row.xmin || row.ymax < c.ymin || c.ymax < row.ymin)) continue;
+        const float iou = (float)quad_iou(row.v, row.area, c.v, c.area, c.sgn);
+        if (iou > thr) bits |= 1ull << q;
+    }
+    mask[(size_t)i * nb + cb] = bits;
+}
+
+// ------------------------------------------------------------------------------------------------ reduce
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), l);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(64) void reduce_kernel(const unsigned long long *__restrict__ mask, const int *__restrict__ order,
+                                                    const int *__restrict__ n_sorted, int nb, int *__restrict__ keep,
+                                                    int *__restrict__ keep_count) {
+    const int lane = threadIdx.x;
+    const int n = *n_sorted;
+    const int nblk = (n + 63) / 64;
+    unsigned long long removed = 0;  // lane w: word w of the suppressed set
+    int cnt = 0;
+    for (int b = 0; b < nblk; ++b) {
+        unsigned long long rem = readlane64(removed, b);
+        const int i = b * 64 + lane;
+        const unsigned long long diag = (i < n) ? mask[(size_t)i * nb + b] : 0ull;
+        const int rows = min(64, n - b * 64);
+        unsigned long long keepbits = 0;
+        for (int t = 0; t < rows; ++t) {
+            if (!((rem >> t) & 1ull)) {
+                keepbits |= 1ull << t;
+                rem |= readlane64(diag, t);
+            }
+        }
+        if ((keepbits >> lane) & 1ull) keep[cnt + __popcll(keepbits & ((1ull << lane) - 1ull))] = order[i];
+        cnt += __popcll(keepbits);
+        if (lane > b && lane < nb) {
+            unsigned long long kb = keepbits;
+            while (kb) {
+                const int t = __ffsll((long long)kb) - 1;
+                kb &= kb - 1;
+                removed |= mask[(size_t)(b * 64 + t) * nb + lane];
+            }
+        }
+    }
+    if (lane == 0) *keep_count = cnt;
+}
+
+// ------------------------------------------------------------------------------------------------ gather
+__global__ __launch_bounds__(1024) void gather_kernel(const float *__restrict__ corners, const float *__restrict__ scores,
+                                                      const int *__restrict__ keep, const int *__restrict__ keep_count,
+                                                      int keep_cap, double x0, double y0, double z0, double x1, double y1,
+                                                      double z1, float *__restrict__ out_corners,
+                                                      float *__restrict__ out_scores, int *__restrict__ out_count) {
+    __shared__ int wcnt[16];
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int nk = *keep_count;
+    nk = nk < keep_cap ? nk : keep_cap;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < nk; c0 += 1024) {
+        const int r = c0 + threadIdx.x;
+        bool ok = false;
+        int src = 0;
+        if (r < nk) {
+            src = keep[r];
+            const float *c = corners + (size_t)src * 24;
+            ok = true;
+            for (int k = 0; k < 8; ++k) {
+                const double X = c[3 * k], Y = c[3 * k + 1], Z = c[3 * k + 2];
+                ok = ok && X >= x0 && X <= x1 && Y >= y0 && Y <= y1 && Z >= z0 && Z <= z1;
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) wcnt[wv] = __popcll(m);
+        __syncthreads();
+        int pos = s_base + __popcll(m & ((1ull << lane) - 1ull));
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wv) pos += wcnt[w];
+            tot += wcnt[w];
+        }
+        if (ok) {
+            for (int k = 0; k < 24; ++k) out_corners[(size_t)pos * 24 + k] = corners[(size_t)src * 24 + k];
+            out_scores[pos] = scores[src];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out_count = s_base;
+}
+
+// ------------------------------------------------------------------------------------------------ pcdet fp32 BEV IoU
+struct F2 { float x, y; };
+__device__ __forceinline__ float crs3(F2 p1, F2 p2, F2 p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
+
+__device__ int seg_isect(F2 p1, F2 p0, F2 q1, F2 q0, F2 &ans) {
+    if (!(fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+          fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y)))
+        return 0;
+    const float s1 = crs3(q0, p1, p0), s2 = crs3(p1, q1, p0), s3 = crs3(p0, q1, q0), s4 = crs3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+    const float s5 = crs3(q1, p1, p0);
+    if (fabsf(s5 - s1) > 1e-8f) {
+        ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        const float D = a0 * b1 - a1 * b0;
+        ans.x = (b0 * c1 - b1 * c0) / D;
+        ans.y = (a1 * c0 - a0 * c1) / D;
+    }
+    return 1;
+}
+
+__device__ int in_box_margin(const float *box, F2 p) {
+    const float ca = cosf(-box[6]), sa = sinf(-box[6]);
+    const float rx = (p.x - box[0]) * ca + (p.y - box[1]) * (-sa);
+    const float ry = (p.x - box[0]) * sa + (p.y - box[1]) * ca;
+    return fabsf(rx) < box[3] / 2 + 1e-2f && fabsf(ry) < box[4] / 2 + 1e-2f;
+}
+
+__device__ void box_corners_f32(const float *box, F2 *c) {
+    const float hx = box[3] / 2, hy = box[4] / 2;
+    const float x1 = box[0] - hx, y1 = box[1] - hy, x2 = box[0] + hx, y2 = box[1] + hy;
+    const float ca = cosf(box[6]), sa = sinf(box[6]);
+    const F2 raw[4] = {{x1, y1}, {x2, y1}, {x2, y2}, {x1, y2}};
+    for (int k = 0; k < 4; ++k) {
+        c[k].x = (raw[k].x - box[0]) * ca + (raw[k].y - box[1]) * (-sa) + box[0];
+        c[k].y = (raw[k].x - box[0]) * sa + (raw[k].y - box[1]) * ca + box[1];
+    }
+    c[4] = c[0];
+}
+
+// iou3d_cpu.cpp:128-229 / iou3d_nms_kernel.cu:104-225 (box_overlap), :227-234 (iou_bev)
+__device__ float pcdet_iou(const float *A7, const float *B7) {
+    F2 A[5], B[5], pts[16], ctr = {0.f, 0.f};
+    int cnt = 0;
+    box_corners_f32(A7, A);
+    box_corners_f32(B7, B);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (seg_isect(A[i + 1], A[i], B[j + 1], B[j], pts[cnt])) { ctr.x += pts[cnt].x; ctr.y += pts[cnt].y; ++cnt; }
+    for (int k = 0; k < 4; ++k) {
+        if (in_box_margin(A7, B[k])) { ctr.x += B[k].x; ctr.y += B[k].y; pts[cnt++] = B[k]; }
+        if (in_box_margin(B7, A[k])) { ctr.x += A[k].x; ctr.y += A[k].y; pts[cnt++] = A[k]; }
+    }
+    ctr.x /= cnt; ctr.y /= cnt;
+    for (int j = 0; j < cnt - 1; ++j)
+        for (int i = 0; i < cnt - j - 1; ++i)
+            if (atan2f(pts[i].y - ctr.y, pts[i].x - ctr.x) > atan2f(pts[i + 1].y - ctr.y, pts[i + 1].x - ctr.x)) {
+                const F2 t = pts[i]; pts[i] = pts[i + 1]; pts[i + 1] = t;
+            }
+    float area = 0.f;
+    for (int k = 0; k < cnt - 1; ++k) {
+        const float ux = pts[k].x - pts[0].x, uy = pts[k].y - pts[0].y;
+        const float vx = pts[k + 1].x - pts[0].x, vy = pts[k + 1].y - pts[0].y;
+        area += ux * vy - uy * vx;
+    }
+    const float so = fabsf(area) / 2.0f;
+    const float sa = A7[3] * A7[4], sb = B7[3] * B7[4];
+    return so / fmaxf(sa + sb - so, 1e-8f);
+}
+
+__global__ __launch_bounds__(256) void iou_bev_kernel(const float *__restrict__ a, int Na, const float *__restrict__ b, int Nb,
+                                                      float *__restrict__ iou) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)Na * Nb) return;
+    const int i = (int)(idx / Nb), j = (int)(idx % Nb);
+    iou[idx] = pcdet_iou(a + (size_t)i * 7, b + (size_t)j * 7);
+}
+
+struct NmsWs {
+    int *order, *n_sorted;
+    unsigned long long *mask;
+};
+
+NmsWs carve(void *ws, int top) {
+    NmsWs w;
+    char *p = (char *)ws;
+    const int nb = (top + 63) / 64;
+    w.mask = (unsigned long long *)p; p += coalign::align_up((size_t)top * nb * 8, 256);
+    w.order = (int *)p;               p += coalign::align_up((size_t)top * 4, 256);
+    w.n_sorted = (int *)p;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t coalign_nms_rotated_workspace_bytes(int K, int top) {
+    (void)K;
+    if (top <= 0) return 0;
+    const int nb = (top + 63) / 64;
+    return coalign::align_up((size_t)top * nb * 8, 256) + coalign::align_up((size_t)top * 4, 256) + 256;
+}
+
+int coalign_nms_rotated(const float *boxes, int rows, int cols, const float *scores, const uint8_t *valid, int K,
+                        const int32_t *K_dev, float iou_thr, int top, int32_t *keep, int32_t *keep_count, void *workspace,
+                        size_t workspace_bytes, void *stream_) {
+    using namespace coalign;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (K < 0 || rows < 4 || cols < 2 || top <= 0) return COALIGN_ERR_BAD_SHAPE;
+    if (top > 4096) return COALIGN_ERR_UNSUPPORTED;
+    if (!keep_count || !workspace || !keep) return COALIGN_ERR_NULL_POINTER;
+    if (workspace_bytes < coalign_nms_rotated_workspace_bytes(K, top)) return COALIGN_ERR_WORKSPACE;
+    if (K == 0) return hip_call(hipMemsetAsync(keep_count, 0, sizeof(int), stream));
+    if (!boxes || !scores) return COALIGN_ERR_NULL_POINTER;
+    NmsWs w = carve(workspace, top);
+    const int nb = (top + 63) / 64;
+    hipLaunchKernelGGL(rank_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, scores, valid, K, K_dev, top, w.order, w.n_sorted);
+    int rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(mask_kernel, dim3(nb, nb), dim3(64), 0, stream, boxes, rows, cols, w.order, w.n_sorted, iou_thr, nb, w.mask);
+    if ((rc = check_launch())) return rc;
+    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(64), 0, stream, w.mask, w.order, w.n_sorted, nb, keep, keep_count);
+    return check_launch();
+}
+
+int coalign_gather_in_range(const float *corners, const float *scores, const int32_t *keep, const int32_t *keep_count,
+                            int keep_cap, const double *range6_host, float *out_corners, float *out_scores,
+                            int32_t *out_count, void *stream_) {
+    using namespace coalign;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (keep_cap < 0) return COALIGN_ERR_BAD_SHAPE;
+    if (keep_cap > 4096) return COALIGN_ERR_UNSUPPORTED;
+    if (!keep_count || !range6_host || !out_count) return COALIGN_ERR_NULL_POINTER;
+    if (keep_cap > 0 && (!corners || !scores || !keep || !out_corners || !out_scores)) return COALIGN_ERR_NULL_POINTER;
+    const double *r = range6_host;
+    hipLaunchKernelGGL(gather_kernel, dim3(1), dim3(1024), 0, stream, corners, scores, keep, keep_count, keep_cap, r[0], r[1],
+                       r[2], r[3], r[4], r[5], out_corners, out_scores, out_count);
+    return check_launch();
+}
+
+int coalign_boxes_iou_bev(const float *boxes_a, int Na, const float *boxes_b, int Nb, float *iou, void *stream_) {
+    using namespace coalign;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Na < 0 || Nb < 0) return COALIGN_ERR_BAD_SHAPE;
+    if (Na == 0 || Nb == 0) return COALIGN_OK;
+    if (!boxes_a || !boxes_b || !iou) return COALIGN_ERR_NULL_POINTER;
+    const long total = (long)Na * Nb;
+    hipLaunchKernelGGL(iou_bev_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, boxes_a, Na, boxes_b, Nb, iou);
+    return check_launch();
+}
+
+}  // extern "C"

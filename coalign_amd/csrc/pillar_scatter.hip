@@ -1,0 +1,271 @@
+// Pillar feature encoder (PFN) + scatter to the dense BEV canvas, gfx950.
+//
+// Reference semantics: opencood/models/sub_modules/pillar_vfe.py:31-53,105-155 and
+// opencood/models/sub_modules/point_pillar_scatter.py:15-72 (see include/coalign_amd.h).
+//
+// Three launches on the caller's stream:
+//   memset(cell -> pillar map, -1)
+//   pfn_kernel     one wavefront per pillar.  Phase A: lane = point  (coalesced 16 B/lane read of the pillar,
+//                  xor-butterfly wave reduction for the per-pillar mean, 10-d augmentation computed once per
+//                  point, staged in a wave-private LDS slab).  Phase B: lane = output channel (weights, folded
+//                  BN scale/shift in registers; LDS broadcast reads; running max in a register).  Padded rows
+//                  are never multiplied out: they all contribute relu(BN(0)), folded in as the max's seed.
+//                  Writes pillar_features [M, C] (256 B coalesced per pillar) and atomicMax(cell map, row).
+//   canvas_kernel  streaming writer of the NCHW canvas: every thread owns 4 consecutive cells and a block of
+//                  channels, reads the cell map once (16 B), gathers the (rare, 5-6 % occupancy) pillar rows
+//                  and issues 16 B non-temporal stores, so the dominant traffic -- the dense canvas the
+//                  convolution backbone consumes -- is written exactly once, fully coalesced.
+#include "common.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kFeatStride = 12;  // floats per staged point (<= 11 features), 48 B keeps 16 B alignment
+
+struct PfnArgs {
+    const float4 *pts;
+    const int *npts;
+    const int4 *coords;
+    int M, P;
+    const float *weight, *bias, *bn_w, *bn_b, *bn_m, *bn_v;
+    float eps;
+    int C, Cin, use_abs, with_dist;
+    float vx, vy, vz, xo, yo, zo;
+    int n_agents, ny, nx;
+    float *feats;
+    int *cellmap;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(kWavesPerBlock * 64) void pfn_kernel(PfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    float *slab = smem + (size_t)wib * 64 * kFeatStride;
+    const int gwave = blockIdx.x * kWavesPerBlock + wib;
+    const int nwave = gridDim.x * kWavesPerBlock;
+    const int ncell = a.ny * a.nx;
+
+    for (int cb = 0; cb < a.C; cb += 64) {
+        const int c = cb + lane;
+        const bool c_ok = c < a.C;
+        float w[kFeatStride];
+#pragma unroll
+        for (int k = 0; k < kFeatStride; ++k) w[k] = (c_ok && k < a.Cin) ? a.weight[(size_t)c * a.Cin + k] : 0.f;
+        float alpha = 1.f, shift = 0.f;
+        if (c_ok) {
+            if (a.bn_w) {
+                const float inv_std = 1.0f / sqrtf(a.bn_v[c] + a.eps);
+                alpha = a.bn_w[c] * inv_std;
+                shift = a.bn_b[c] - a.bn_m[c] * alpha;
+            } else if (a.bias) {
+                shift = a.bias[c];
+            }
+        }
+
+        for (int m = gwave; m < a.M; m += nwave) {
+            const int np_raw = a.npts[m];
+            const int4 cd = a.coords[m];  // (agent, z, y, x)
+            const int np_eff = min(max(np_raw, 0), a.P);
+            const float4 *prow = a.pts + (size_t)m * a.P;
+
+            // mean over ALL P slots divided by num_points (pillar_vfe.py:118-120)
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (int p0 = 0; p0 < a.P; p0 += 64) {
+                const int p = p0 + lane;
+                if (p < a.P) {
+                    const float4 q = prow[p];
+                    sx += q.x; sy += q.y; sz += q.z;
+                }
+            }
+            const float npf = (float)np_raw;
+            const float mx = wave_sum(sx) / npf, my = wave_sum(sy) / npf, mz = wave_sum(sz) / npf;
+            const float ctr_x = (float)cd.w * a.vx + a.xo;
+            const float ctr_y = (float)cd.z * a.vy + a.yo;
+            const float ctr_z = (float)cd.y * a.vz + a.zo;
+
+            // rows >= num_points are zeroed before the linear layer: Linear(0) = 0 -> BN -> `shift`
+            float best = (np_eff < a.P) ? shift : -INFINITY;
+
+            for (int p0 = 0; p0 < np_eff; p0 += 64) {
+                const int p = p0 + lane;
+                if (p < np_eff) {
+                    const float4 q = prow[p];
+                    float f[kFeatStride];
+                    int k = 0;
+                    if (a.use_abs) { f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w; k = 4; }
+                    else { f[0] = q.w; k = 1; }
+                    f[k] = q.x - mx; f[k + 1] = q.y - my; f[k + 2] = q.z - mz;
+                    f[k + 3] = q.x - ctr_x; f[k + 4] = q.y - ctr_y; f[k + 5] = q.z - ctr_z;
+                    k += 6;
+                    if (a.with_dist) { f[k] = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z); ++k; }
+                    for (; k < kFeatStride; ++k) f[k] = 0.f;
+                    float4 *dst = reinterpret_cast<float4 *>(slab + lane * kFeatStride);
+                    dst[0] = make_float4(f[0], f[1], f[2], f[3]);
+                    dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+                    dst[2] = make_float4(f[8], f[9], f[10], f[11]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int cnt = min(64, np_eff - p0);
+                for (int j = 0; j < cnt; ++j) {
+                    const float4 *src = reinterpret_cast<const float4 *>(slab + j * kFeatStride);
+                    const float4 u = src[0], v = src[1], t = src[2];
+                    float x = w[0] * u.x;
+                    x = fmaf(w[1], u.y, x); x = fmaf(w[2], u.z, x); x = fmaf(w[3], u.w, x);
+                    x = fmaf(w[4], v.x, x); x = fmaf(w[5], v.y, x); x = fmaf(w[6], v.z, x); x = fmaf(w[7], v.w, x);
+                    x = fmaf(w[8], t.x, x); x = fmaf(w[9], t.y, x); x = fmaf(w[10], t.z, x); x = fmaf(w[11], t.w, x);
+                    best = fmaxf(best, fmaf(x, alpha, shift));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (c_ok) a.feats[(size_t)m * a.C + c] = fmaxf(best, 0.f);
+            if (cb == 0 && lane == 0) {
+                const int cell = cd.y + cd.z * a.nx + cd.w;  // z + y*nx + x (point_pillar_scatter.py:54)
+                if (cd.x >= 0 && cd.x < a.n_agents && cell >= 0 && cell < ncell)
+                    atomicMax(a.cellmap + (size_t)cd.x * ncell + cell, m);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cellmap_kernel(const int4 *__restrict__ coords, int M, int n_agents, int ny, int nx,
+                                                      int *__restrict__ cellmap) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int4 cd = coords[m];
+    const int ncell = ny * nx;
+    const int cell = cd.y + cd.z * nx + cd.w;
+    if (cd.x >= 0 && cd.x < n_agents && cell >= 0 && cell < ncell) atomicMax(cellmap + (size_t)cd.x * ncell + cell, m);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void canvas_kernel(const int *__restrict__ cellmap, const float *__restrict__ feats, int C,
+                                                     int ncell, int ch_per_block, float *__restrict__ canvas) {
+    const long cell0 = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (cell0 >= ncell) return;
+    const int agent = blockIdx.z;
+    const int c0 = blockIdx.y * ch_per_block;
+    const int c1 = min(C, c0 + ch_per_block);
+    int id[VEC];
+    if constexpr (VEC == 4) {
+        const int4 t = *reinterpret_cast<const int4 *>(cellmap + (size_t)agent * ncell + cell0);
+        id[0] = t.x; id[1] = t.y; id[2] = t.z; id[3] = t.w;
+    } else {
+        id[0] = cellmap[(size_t)agent * ncell + cell0];
+    }
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) any |= id[j] >= 0;
+    float *dst = canvas + ((size_t)agent * C + c0) * ncell + cell0;
+    for (int c = c0; c < c1; ++c, dst += ncell) {
+        float v[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = 0.f;
+        if (any) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if (id[j] >= 0) v[j] = feats[(size_t)id[j] * C + c];
+        }
+        if constexpr (VEC == 4) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f o = {v[0], v[1], v[2], v[3]};
+            __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(dst));
+        } else {
+            __builtin_nontemporal_store(v[0], dst);
+        }
+    }
+}
+
+int launch_canvas(const int *cellmap, const float *feats, int C, int ncell, int n_agents, float *canvas, hipStream_t stream) {
+    const int ch_per_block = 16;
+    const int ych = (C + ch_per_block - 1) / ch_per_block;
+    if (ncell % 4 == 0) {
+        dim3 grid((ncell / 4 + 255) / 256, ych, n_agents);
+        hipLaunchKernelGGL(canvas_kernel<4>, grid, dim3(256), 0, stream, cellmap, feats, C, ncell, ch_per_block, canvas);
+    } else {
+        dim3 grid((ncell + 255) / 256, ych, n_agents);
+        hipLaunchKernelGGL(canvas_kernel<1>, grid, dim3(256), 0, stream, cellmap, feats, C, ncell, ch_per_block, canvas);
+    }
+    return coalign::check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t coalign_pillar_scatter_workspace_bytes(int n_agents, int ny, int nx) {
+    if (n_agents <= 0 || ny <= 0 || nx <= 0) return 0;
+    return coalign::align_up((size_t)n_agents * ny * nx * sizeof(int), 256);
+}
+
+int coalign_pillar_vfe_scatter(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords,
+                               int M, int P, const float *pfn_weight, const float *pfn_bias, const float *bn_weight,
+                               const float *bn_bias, const float *bn_mean, const float *bn_var, float bn_eps, int C,
+                               int use_absolute_xyz, int with_distance, const double *voxel_size, const double *range_min,
+                               int n_agents, int ny, int nx, float *pillar_features, float *canvas, void *workspace,
+                               size_t workspace_bytes, void *stream_) {
+    using namespace coalign;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M < 0 || P <= 0 || C <= 0 || n_agents <= 0 || ny <= 0 || nx <= 0) return COALIGN_ERR_BAD_SHAPE;
+    if (!pfn_weight || !voxel_size || !range_min || !canvas || !workspace) return COALIGN_ERR_NULL_POINTER;
+    if (M > 0 && (!voxel_features || !voxel_num_points || !voxel_coords || !pillar_features)) return COALIGN_ERR_NULL_POINTER;
+    const bool has_bn = bn_weight || bn_bias || bn_mean || bn_var;
+    if (has_bn && !(bn_weight && bn_bias && bn_mean && bn_var)) return COALIGN_ERR_NULL_POINTER;
+    if ((size_t)ny * nx > (size_t)INT32_MAX) return COALIGN_ERR_BAD_SHAPE;
+    if (workspace_bytes < coalign_pillar_scatter_workspace_bytes(n_agents, ny, nx)) return COALIGN_ERR_WORKSPACE;
+    const int Cin = (use_absolute_xyz ? 4 : 1) + 6 + (with_distance ? 1 : 0);
+    if (Cin > kFeatStride) return COALIGN_ERR_UNSUPPORTED;
+
+    const int ncell = ny * nx;
+    int *cellmap = (int *)workspace;
+    int rc = hip_call(hipMemsetAsync(cellmap, 0xFF, (size_t)n_agents * ncell * sizeof(int), stream));
+    if (rc) return rc;
+
+    if (M > 0) {
+        PfnArgs a;
+        a.pts = (const float4 *)voxel_features; a.npts = voxel_num_points; a.coords = (const int4 *)voxel_coords;
+        a.M = M; a.P = P;
+        a.weight = pfn_weight; a.bias = pfn_bias; a.bn_w = bn_weight; a.bn_b = bn_bias; a.bn_m = bn_mean; a.bn_v = bn_var;
+        a.eps = bn_eps; a.C = C; a.Cin = Cin; a.use_abs = use_absolute_xyz; a.with_dist = with_distance;
+        a.vx = (float)voxel_size[0]; a.vy = (float)voxel_size[1]; a.vz = (float)voxel_size[2];
+        a.xo = (float)(voxel_size[0] / 2 + range_min[0]);
+        a.yo = (float)(voxel_size[1] / 2 + range_min[1]);
+        a.zo = (float)(voxel_size[2] / 2 + range_min[2]);
+        a.n_agents = n_agents; a.ny = ny; a.nx = nx; a.feats = pillar_features; a.cellmap = cellmap;
+        const int blocks = (int)min((long)(M + kWavesPerBlock - 1) / kWavesPerBlock, (long)256 * 8);
+        const size_t lds = (size_t)kWavesPerBlock * 64 * kFeatStride * sizeof(float);
+        hipLaunchKernelGGL(pfn_kernel, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, a);
+        if ((rc = check_launch())) return rc;
+    }
+
+    return launch_canvas(cellmap, pillar_features, C, ncell, n_agents, canvas, stream);
+}
+
+int coalign_scatter_to_bev(const float *pillar_features, const int32_t *voxel_coords, int M, int C, int n_agents, int ny,
+                           int nx, float *canvas, void *workspace, size_t workspace_bytes, void *stream_) {
+    using namespace coalign;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M < 0 || C <= 0 || n_agents <= 0 || ny <= 0 || nx <= 0) return COALIGN_ERR_BAD_SHAPE;
+    if (!canvas || !workspace || (M > 0 && (!pillar_features || !voxel_coords))) return COALIGN_ERR_NULL_POINTER;
+    if ((size_t)ny * nx > (size_t)INT32_MAX) return COALIGN_ERR_BAD_SHAPE;
+    if (workspace_bytes < coalign_pillar_scatter_workspace_bytes(n_agents, ny, nx)) return COALIGN_ERR_WORKSPACE;
+    const int ncell = ny * nx;
+    int *cellmap = (int *)workspace;
+    int rc = hip_call(hipMemsetAsync(cellmap, 0xFF, (size_t)n_agents * ncell * sizeof(int), stream));
+    if (rc) return rc;
+    if (M > 0) {
+        hipLaunchKernelGGL(cellmap_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, (const int4 *)voxel_coords, M, n_agents,
+                           ny, nx, cellmap);
+        if ((rc = check_launch())) return rc;
+    }
+    return launch_canvas(cellmap, pillar_features, C, ncell, n_agents, canvas, stream);
+}
+
+}  // extern "C"

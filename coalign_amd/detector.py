@@ -1,0 +1,159 @@
+"""Detector classes of the hot path -- the plugin boundary.
+
+``PointPillarBaselineMultiscale`` / ``CoAlign`` / ``PointPillar`` keep the reference's class names, constructor
+(``args`` = ``hypes['model']['args']``), ``forward(data_dict) -> {'cls_preds', 'reg_preds'[, 'dir_preds']}`` and
+``state_dict`` key names (opencood/models/point_pillar_baseline_multiscale.py:17-135,
+opencood/models/point_pillar_coalign.py:9-10, opencood/models/point_pillar.py:16-80), so reference yamls and
+checkpoints drive them unchanged.  Pillar encode + scatter and warp + fusion run in the gfx950 kernels; the
+dense convolutions run on MIOpen through PyTorch-ROCm.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .backbone import BaseBEVBackbone, DownsampleConv, NaiveCompressor, ResNetBEVBackbone
+from .encoder import PillarVFE, PointPillarScatter, host_ints
+from .fusion import AttFusion, MaxFusion
+from .pose import normalize_pairwise_tfm
+
+
+class PointPillarBaselineMultiscale(nn.Module):
+    def __init__(self, args: dict):
+        super().__init__()
+        self.pillar_vfe = PillarVFE(args["pillar_vfe"], num_point_features=4, voxel_size=args["voxel_size"],
+                                    point_cloud_range=args["lidar_range"])
+        self.scatter = PointPillarScatter(args["point_pillar_scatter"])
+        bb = args["base_bev_backbone"]
+        self.backbone = ResNetBEVBackbone(bb, 64) if bb.get("resnet", True) else BaseBEVBackbone(bb, 64)
+        self.voxel_size = args["voxel_size"]
+        self.fusion_net = nn.ModuleList()
+        for i in range(len(bb["layer_nums"])):
+            if args["fusion_method"] == "max":
+                self.fusion_net.append(MaxFusion())
+            elif args["fusion_method"] == "att":
+                self.fusion_net.append(AttFusion(args["att"]["feat_dim"][i]))
+            else:
+                raise NotImplementedError(f"fusion_method '{args['fusion_method']}' is outside the CoAlign hot path (att | max)")
+        self.out_channel = sum(bb["num_upsample_filter"])
+        self.shrink_flag = "shrink_header" in args
+        if self.shrink_flag:
+            self.shrink_conv = DownsampleConv(args["shrink_header"])
+            self.out_channel = args["shrink_header"]["dim"][-1]
+        self.compression = "compression" in args
+        if self.compression:
+            self.naive_compressor = NaiveCompressor(64, args["compression"])
+        self.cls_head = nn.Conv2d(self.out_channel, args["anchor_number"], kernel_size=1)
+        self.reg_head = nn.Conv2d(self.out_channel, 7 * args["anchor_number"], kernel_size=1)
+        self.use_dir = "dir_args" in args
+        if self.use_dir:
+            self.dir_head = nn.Conv2d(self.out_channel, args["dir_args"]["num_bins"] * args["anchor_number"], kernel_size=1)
+        if args.get("backbone_fix"):
+            self.backbone_fix()
+
+    def backbone_fix(self):
+        frozen = [self.pillar_vfe, self.scatter, self.backbone, self.cls_head, self.reg_head]
+        if self.compression:
+            frozen.append(self.naive_compressor)
+        if self.shrink_flag:
+            frozen.append(self.shrink_conv)
+        for m in frozen:
+            for p in m.parameters():
+                p.requires_grad = False
+
+    # -- stages, exposed separately so the sharded runner can place them on different ranks ----------------
+    def encode(self, data_dict: dict):
+        """Per-agent part: pillars -> canvas -> multiscale features.  Returns (feature list, normalised affine)."""
+        pl = data_dict["processed_lidar"]
+        record_len = host_ints(data_dict["record_len"])
+        batch_dict = {"voxel_features": pl["voxel_features"], "voxel_coords": pl["voxel_coords"],
+                      "voxel_num_points": pl["voxel_num_points"], "record_len": record_len}
+        batch_dict = self.scatter(self.pillar_vfe(batch_dict))
+        spatial_features = batch_dict["spatial_features"]
+        H0, W0 = spatial_features.shape[2:]
+        affine = normalize_pairwise_tfm(data_dict["pairwise_t_matrix"], H0, W0, self.voxel_size[0])
+        if self.compression:
+            spatial_features = self.naive_compressor(spatial_features)
+        return self.backbone.get_multiscale_feature(spatial_features), affine
+
+    def fuse_and_head(self, feature_list, record_len, affine) -> dict:
+        """Ego part: per-scale warp + fusion, deblocks, shrink header, heads."""
+        fused = [f(x, record_len, affine) for f, x in zip(self.fusion_net, feature_list)]
+        x = self.backbone.decode_multiscale_feature(fused)
+        if self.shrink_flag:
+            x = self.shrink_conv(x)
+        out = {"cls_preds": self.cls_head(x), "reg_preds": self.reg_head(x)}
+        if self.use_dir:
+            out["dir_preds"] = self.dir_head(x)
+        return out
+
+    def forward(self, data_dict: dict) -> dict:
+        record_len = host_ints(data_dict["record_len"])
+        feats, affine = self.encode(dict(data_dict, record_len=record_len))
+        return self.fuse_and_head(feats, record_len, affine)
+
+
+class CoAlign(PointPillarBaselineMultiscale):
+    pass
+
+
+class PointPillar(nn.Module):
+    """Single-agent PointPillar (late-fusion config)."""
+
+    def __init__(self, args: dict):
+        super().__init__()
+        self.pillar_vfe = PillarVFE(args["pillar_vfe"], num_point_features=4, voxel_size=args["voxel_size"],
+                                    point_cloud_range=args["lidar_range"])
+        self.scatter = PointPillarScatter(args["point_pillar_scatter"])
+        bb = args["base_bev_backbone"]
+        self.backbone = ResNetBEVBackbone(bb, 64) if bb.get("resnet", False) else BaseBEVBackbone(bb, 64)
+        self.out_channel = sum(bb["num_upsample_filter"])
+        self.shrink_flag = "shrink_header" in args
+        if self.shrink_flag:
+            self.shrink_conv = DownsampleConv(args["shrink_header"])
+            self.out_channel = args["shrink_header"]["dim"][-1]
+        self.cls_head = nn.Conv2d(self.out_channel, args["anchor_number"], kernel_size=1)
+        self.reg_head = nn.Conv2d(self.out_channel, 7 * args["anchor_number"], kernel_size=1)
+        self.use_dir = "dir_args" in args
+        if self.use_dir:
+            self.dir_head = nn.Conv2d(self.out_channel, args["dir_args"]["num_bins"] * args["anchor_number"], kernel_size=1)
+
+    def forward(self, data_dict: dict) -> dict:
+        pl = data_dict["processed_lidar"]
+        batch_dict = {"voxel_features": pl["voxel_features"], "voxel_coords": pl["voxel_coords"],
+                      "voxel_num_points": pl["voxel_num_points"]}
+        batch_dict = self.backbone(self.scatter(self.pillar_vfe(batch_dict)))
+        x = batch_dict["spatial_features_2d"]
+        if self.shrink_flag:
+            x = self.shrink_conv(x)
+        out = {"cls_preds": self.cls_head(x), "reg_preds": self.reg_head(x)}
+        if self.use_dir:
+            out["dir_preds"] = self.dir_head(x)
+        return out
+
+
+MODEL_REGISTRY = {
+    "point_pillar_baseline_multiscale": PointPillarBaselineMultiscale,
+    "point_pillar_coalign": CoAlign,
+    "point_pillar": PointPillar,
+}
+
+
+def build_model(hypes: dict) -> nn.Module:
+    """``train_utils.create_model`` for the hot-path model families (opencood/tools/train_utils.py:113-146):
+    ``hypes['model']['core_method']`` names the model, ``hypes['model']['args']`` is its constructor argument."""
+    name = hypes["model"]["core_method"]
+    if name not in MODEL_REGISTRY:
+        raise KeyError(f"model '{name}' is outside the CoAlign hot path (available: {sorted(MODEL_REGISTRY)})")
+    return MODEL_REGISTRY[name](hypes["model"]["args"])
+
+
+def to_device(inputs, device):
+    """Recursive ``.to(device)`` over lists / dicts; non-tensors pass through (opencood/tools/train_utils.py:249-258)."""
+    if isinstance(inputs, list):
+        return [to_device(x, device) for x in inputs]
+    if isinstance(inputs, dict):
+        return {k: to_device(v, device) for k, v in inputs.items()}
+    if isinstance(inputs, (int, float, str)) or inputs is None or not hasattr(inputs, "to"):
+        return inputs
+    return inputs.to(device)

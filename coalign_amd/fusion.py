@@ -1,0 +1,67 @@
+"""Multi-agent feature fusion modules (SURVEY §8a rows G, H, H'), host side.
+
+Class / function names and signatures follow opencood/models/fuse_modules/fusion_in_one.py
+(``regroup`` :21-24, ``warp_feature`` :26-45, ``MaxFusion`` :47-89, ``AttFusion`` :91-136) and
+opencood/models/sub_modules/torch_transformation_utils.py (``warp_affine_simple`` :322-331).  They own no
+parameters; all arithmetic is the fused gfx950 kernel ``coalign_warp_fuse``.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .encoder import host_ints
+
+
+def regroup(x: torch.Tensor, record_len) -> List[torch.Tensor]:
+    """Split the concatenated agent batch into per-frame views."""
+    return list(torch.split(x, host_ints(record_len), dim=0))
+
+
+def _ego_rows(affine: torch.Tensor, groups: Sequence[int]) -> torch.Tensor:
+    """normalized_affine_matrix [B, L, L, 2, 3] -> theta [sum N, 2, 3]: row ``[b, 0, :N_b]`` of every frame
+    (ego coordinates -> agent j; fusion_in_one.py:125-128)."""
+    if affine.shape[0] == 1:
+        return affine[0, 0, : groups[0]]
+    return torch.cat([affine[b, 0, :n] for b, n in enumerate(groups)], dim=0)
+
+
+def warp_affine_simple(src: torch.Tensor, M: torch.Tensor, dsize, mode="bilinear", padding_mode="zeros",
+                       align_corners=False) -> torch.Tensor:
+    """``F.grid_sample(src, F.affine_grid(M, ...).to(src))``, bilinear / zeros / align_corners=False
+    (the extra keyword arguments are accepted and ignored exactly like the reference does)."""
+    n = src.shape[0]
+    return ops.warp_fuse(src, M, [1] * n if n <= 0 else _chunks(n), ops.FUSE_NONE, out_hw=(int(dsize[0]), int(dsize[1])))
+
+
+def _chunks(n: int) -> List[int]:
+    out = []
+    while n > 0:
+        out.append(min(8, n))
+        n -= out[-1]
+    return out
+
+
+def warp_feature(x: torch.Tensor, record_len, pairwise_t_matrix: torch.Tensor) -> torch.Tensor:
+    """Warp every agent of every frame into its ego frame; returns [sum N, C, H, W]."""
+    groups = host_ints(record_len)
+    return ops.warp_fuse(x, _ego_rows(pairwise_t_matrix, groups), groups, ops.FUSE_NONE)
+
+
+class MaxFusion(nn.Module):
+    def forward(self, x: torch.Tensor, record_len, pairwise_t_matrix: torch.Tensor) -> torch.Tensor:
+        groups = host_ints(record_len)
+        return ops.warp_fuse(x, _ego_rows(pairwise_t_matrix, groups), groups, ops.FUSE_MAX)
+
+
+class AttFusion(nn.Module):
+    def __init__(self, feature_dims: int):
+        super().__init__()
+        self.feature_dims = feature_dims
+
+    def forward(self, xx: torch.Tensor, record_len, normalized_affine_matrix: torch.Tensor) -> torch.Tensor:
+        groups = host_ints(record_len)
+        return ops.warp_fuse(xx, _ego_rows(normalized_affine_matrix, groups), groups, ops.FUSE_ATT)

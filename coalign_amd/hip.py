@@ -1,0 +1,76 @@
+"""ctypes binding of ``include/coalign_amd.h`` (the C ABI of the gfx950 kernels).
+
+There is NO fallback: if ``coalign_amd/lib/libcoalign_hip.so`` is missing and cannot be built with hipcc the
+import of this module's ``lib()`` raises, and every op in :mod:`coalign_amd.ops` raises on non-GPU tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_void_p
+
+from . import build as _build
+
+_LIB = None
+
+P = c_void_p  # every device / host buffer crosses the ABI as a plain pointer
+
+# name -> (restype, argtypes); mirrors include/coalign_amd.h one to one
+SIGNATURES = {
+    "coalign_abi_version": (c_int, []),
+    "coalign_status_string": (c_char_p, [c_int]),
+    "coalign_last_hip_error": (c_char_p, []),
+    "coalign_pillar_scatter_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "coalign_pillar_vfe_scatter": (c_int, [P, P, P, c_int, c_int, P, P, P, P, P, P, c_float, c_int, c_int, c_int,
+                                           POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, P, c_size_t, P]),
+    "coalign_scatter_to_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "coalign_warp_fuse": (c_int, [P, c_int, c_int, c_int, c_int, P, POINTER(c_int32), c_int, c_int, P, c_int, c_int, P]),
+    "coalign_anchor_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "coalign_anchor_decode": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P, c_int, P, P, P,
+                                      P, P, P, P, P, P, c_size_t, P]),
+    "coalign_nms_rotated_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "coalign_nms_rotated": (c_int, [P, c_int, c_int, P, P, c_int, P, c_float, c_int, P, P, P, c_size_t, P]),
+    "coalign_gather_in_range": (c_int, [P, P, P, P, c_int, POINTER(c_double), P, P, P, P]),
+    "coalign_boxes_iou_bev": (c_int, [P, c_int, P, c_int, P, P]),
+}
+
+
+class CoalignHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load (building first if needed) the gfx950 library.  Raises if that is impossible."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    import torch  # noqa: F401  -- load PyTorch-ROCm's HIP runtime first so both share one libamdhip64.so.7
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        try:
+            _build.build()
+        except Exception as exc:  # noqa: BLE001
+            raise CoalignHipError(
+                f"{path} is missing and could not be built ({exc}); the CoAlign hot path has no CPU fallback") from exc
+    handle = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError here == header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if handle.coalign_abi_version() != 1:
+        raise CoalignHipError(f"ABI version mismatch: library reports {handle.coalign_abi_version()}, binding expects 1")
+    _LIB = handle
+    return handle
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        L = lib()
+        msg = L.coalign_status_string(status).decode()
+        if status == -5:
+            msg += " [" + L.coalign_last_hip_error().decode() + "]"
+        raise CoalignHipError(f"{what}: {msg}")

@@ -1,0 +1,217 @@
+"""Torch-tensor front end of the C ABI: allocates outputs / workspaces with torch (PyTorch-ROCm owns device
+memory and streams), passes raw ``data_ptr()``s and the current stream to the gfx950 kernels.
+
+Every function requires CUDA(ROCm) tensors and raises otherwise -- the hot path has no CPU implementation
+in this package (the CPU restatement lives in ``oracle/`` and is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import hip
+
+FUSE_ATT, FUSE_MAX, FUSE_NONE = 0, 1, 2
+
+# Optional in-pipeline timing: set to a dict to have every op bracket its launches with HIP events recorded on the
+# stream the kernels are launched on (bench.py reads the pairs after synchronising).  None = no overhead.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e.record()
+            PROFILE.setdefault(self.name, []).append((self.s, self.e))
+        return False
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _need_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise hip.CoalignHipError("coalign_amd ops run on the MI355X only: got a CPU tensor (no CPU fallback exists)")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def _dbl3(v: Sequence[float]):
+    return (ctypes.c_double * 3)(float(v[0]), float(v[1]), float(v[2]))
+
+
+def pillar_vfe_scatter(voxel_features: torch.Tensor, voxel_num_points: torch.Tensor, voxel_coords: torch.Tensor,
+                       weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[Tuple[torch.Tensor, ...]], bn_eps: float,
+                       use_absolute_xyz: bool, with_distance: bool, voxel_size: Sequence[float], range_min: Sequence[float],
+                       n_agents: int, ny: int, nx: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (pillar_features [M, C], canvas [n_agents, C, ny, nx]).  ``bn`` = (weight, bias, running_mean, running_var)."""
+    _need_gpu(voxel_features, voxel_num_points, voxel_coords, weight)
+    L = hip.lib()
+    vf = _f32c(voxel_features)
+    M, P = vf.shape[0], vf.shape[1]
+    if vf.dim() != 3 or vf.shape[2] != 4:
+        raise ValueError(f"voxel_features must be [M, P, 4], got {tuple(vf.shape)}")
+    npts = voxel_num_points.to(torch.int32).contiguous()
+    coords = voxel_coords.to(torch.int32).contiguous()
+    w = _f32c(weight)
+    C = w.shape[0]
+    dev = vf.device
+    feats = torch.empty((M, C), dtype=torch.float32, device=dev)
+    canvas = torch.empty((n_agents, C, ny, nx), dtype=torch.float32, device=dev)
+    ws_bytes = L.coalign_pillar_scatter_workspace_bytes(n_agents, ny, nx)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    bnp = [None] * 4 if bn is None else [_f32c(t) for t in bn]
+    b = None if bias is None else _f32c(bias)
+    with _Timed("pillar_vfe_scatter"):
+      hip.check(L.coalign_pillar_vfe_scatter(_ptr(vf), _ptr(npts), _ptr(coords), M, P, _ptr(w), _ptr(b), _ptr(bnp[0]), _ptr(bnp[1]),
+                                           _ptr(bnp[2]), _ptr(bnp[3]), float(bn_eps), C, int(use_absolute_xyz), int(with_distance),
+                                           _dbl3(voxel_size), _dbl3(range_min), n_agents, ny, nx, _ptr(feats), _ptr(canvas),
+                                           _ptr(ws), ws_bytes, _stream()), "coalign_pillar_vfe_scatter")
+    return feats, canvas
+
+
+def scatter_to_bev(pillar_features: torch.Tensor, voxel_coords: torch.Tensor, n_agents: int, ny: int, nx: int) -> torch.Tensor:
+    """pillar_features [M, C] + coords (agent, z, y, x) -> canvas [n_agents, C, ny, nx]."""
+    _need_gpu(pillar_features, voxel_coords)
+    L = hip.lib()
+    pf = _f32c(pillar_features)
+    coords = voxel_coords.to(torch.int32).contiguous()
+    M, C = pf.shape
+    canvas = torch.empty((n_agents, C, ny, nx), dtype=torch.float32, device=pf.device)
+    ws_bytes = L.coalign_pillar_scatter_workspace_bytes(n_agents, ny, nx)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pf.device)
+    hip.check(L.coalign_scatter_to_bev(_ptr(pf), _ptr(coords), M, C, n_agents, ny, nx, _ptr(canvas), _ptr(ws), ws_bytes, _stream()),
+              "coalign_scatter_to_bev")
+    return canvas
+
+
+def warp_fuse(x: torch.Tensor, theta: torch.Tensor, group_len: Sequence[int], mode: int,
+              out_hw: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """x [n_total, C, H, W] f32, theta [n_total, 2, 3] f64 (device) -> fused [len(group_len), C, Ho, Wo]
+    (or [n_total, C, Ho, Wo] for FUSE_NONE)."""
+    _need_gpu(x, theta)
+    L = hip.lib()
+    xc = _f32c(x)
+    th = theta.to(device=xc.device, dtype=torch.float64).contiguous()
+    n_total, C, H, W = xc.shape
+    Ho, Wo = (H, W) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
+    groups = [int(g) for g in group_len]
+    n_out = n_total if mode == FUSE_NONE else len(groups)
+    out = torch.empty((n_out, C, Ho, Wo), dtype=torch.float32, device=xc.device)
+    gl = (ctypes.c_int32 * max(1, len(groups)))(*groups)
+    with _Timed(f"warp_fuse_C{C}"):
+        hip.check(L.coalign_warp_fuse(_ptr(xc), n_total, C, H, W, _ptr(th), gl, len(groups), mode, _ptr(out), Ho, Wo, _stream()),
+                  "coalign_warp_fuse")
+    return out
+
+
+class DecodeBuffers:
+    """Caller-owned candidate buffers + workspaces of the post-processing kernels (reused across frames)."""
+
+    def __init__(self, capacity: int, A: int, H: int, W: int, top: int, device):
+        L = hip.lib()
+        self.capacity, self.top = capacity, top
+        self.counts = torch.zeros(64, dtype=torch.int32, device=device)       # chained per-agent totals
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self.cand_index = torch.empty(capacity, dtype=torch.int32, device=device)
+        self.cand_score = torch.empty(capacity, dtype=torch.float32, device=device)
+        self.cand_box7 = torch.empty((capacity, 7), dtype=torch.float32, device=device)
+        self.cand_corners = torch.empty((capacity, 8, 3), dtype=torch.float32, device=device)
+        self.cand_keep = torch.empty(capacity, dtype=torch.uint8, device=device)
+        self.dec_ws_bytes = L.coalign_anchor_decode_workspace_bytes(A, H, W)
+        self.dec_ws = torch.empty(max(1, self.dec_ws_bytes), dtype=torch.uint8, device=device)
+        self.nms_ws_bytes = L.coalign_nms_rotated_workspace_bytes(capacity, top)
+        self.nms_ws = torch.empty(max(1, self.nms_ws_bytes), dtype=torch.uint8, device=device)
+        self.keep = torch.empty(top, dtype=torch.int32, device=device)
+        self.keep_count = torch.zeros(1, dtype=torch.int32, device=device)
+        self.out_corners = torch.empty((top, 8, 3), dtype=torch.float32, device=device)
+        self.out_scores = torch.empty(top, dtype=torch.float32, device=device)
+        self.out_count = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def anchor_decode(buf: DecodeBuffers, slot: int, cls: torch.Tensor, reg: torch.Tensor, dir_: Optional[torch.Tensor],
+                  anchors_f32: torch.Tensor, score_thr: float, dir_offset: float, num_bins: int, order: str,
+                  transform: Optional[torch.Tensor]) -> None:
+    """Append one agent's candidates after slot ``slot`` of ``buf.counts`` (slot 0 must hold 0)."""
+    _need_gpu(cls, reg, anchors_f32)
+    L = hip.lib()
+    cls_c, reg_c = _f32c(cls), _f32c(reg)
+    dir_c = None if dir_ is None else _f32c(dir_)
+    if cls_c.dim() == 4:
+        if cls_c.shape[0] != 1:
+            raise ValueError("post-processing handles one frame at a time (batch size 1), like the reference")
+        cls_c, reg_c = cls_c[0], reg_c[0]
+        dir_c = None if dir_c is None else dir_c[0]
+    A, H, W = cls_c.shape
+    T = None if transform is None else _f32c(transform)
+    hip.check(L.coalign_anchor_decode(_ptr(cls_c), _ptr(reg_c), _ptr(dir_c), _ptr(anchors_f32), A, H, W, int(num_bins),
+                                      float(score_thr), float(dir_offset), int(order == "hwl"), _ptr(T), buf.capacity,
+                                      ctypes.c_void_p(buf.counts.data_ptr() + 4 * slot),
+                                      ctypes.c_void_p(buf.counts.data_ptr() + 4 * (slot + 1)),
+                                      _ptr(buf.cand_index), _ptr(buf.cand_score), _ptr(buf.cand_box7), _ptr(buf.cand_corners),
+                                      _ptr(buf.cand_keep), _ptr(buf.status), _ptr(buf.dec_ws), buf.dec_ws_bytes, _stream()),
+              "coalign_anchor_decode")
+
+
+def nms_rotated_device(boxes: torch.Tensor, scores: torch.Tensor, iou_thr: float, top: int = 1000,
+                       valid: Optional[torch.Tensor] = None, k_dev: Optional[torch.Tensor] = None,
+                       keep: Optional[torch.Tensor] = None, keep_count: Optional[torch.Tensor] = None,
+                       ws: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """boxes [K, 8, 3] or [K, 4, 2] -> (keep int32 [top] device, keep_count int32 [1] device); no host sync."""
+    _need_gpu(boxes, scores)
+    L = hip.lib()
+    b = _f32c(boxes)
+    s = _f32c(scores)
+    K = b.shape[0]
+    rows, cols = (b.shape[1], b.shape[2]) if b.dim() == 3 else (4, 2)
+    dev = b.device
+    keep = torch.empty(top, dtype=torch.int32, device=dev) if keep is None else keep
+    keep_count = torch.zeros(1, dtype=torch.int32, device=dev) if keep_count is None else keep_count
+    ws_bytes = L.coalign_nms_rotated_workspace_bytes(K, top)
+    if ws is None:
+        ws = torch.empty(max(1, ws_bytes), dtype=torch.uint8, device=dev)
+    v = None if valid is None else valid.to(torch.uint8).contiguous()
+    hip.check(L.coalign_nms_rotated(_ptr(b), rows, cols, _ptr(s), _ptr(v), K, _ptr(k_dev), float(iou_thr), top, _ptr(keep),
+                                    _ptr(keep_count), _ptr(ws), ws.numel(), _stream()), "coalign_nms_rotated")
+    return keep, keep_count
+
+
+def gather_in_range(corners: torch.Tensor, scores: torch.Tensor, keep: torch.Tensor, keep_count: torch.Tensor,
+                    limit_range: Sequence[float], out_corners: torch.Tensor, out_scores: torch.Tensor,
+                    out_count: torch.Tensor) -> None:
+    _need_gpu(corners, scores, keep)
+    L = hip.lib()
+    r = (ctypes.c_double * 6)(*[float(v) for v in limit_range])
+    hip.check(L.coalign_gather_in_range(_ptr(corners), _ptr(scores), _ptr(keep), _ptr(keep_count), keep.numel(), r,
+                                        _ptr(out_corners), _ptr(out_scores), _ptr(out_count), _stream()), "coalign_gather_in_range")
+
+
+def boxes_iou_bev(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Tensor:
+    """OpenPCDet-semantics fp32 BEV IoU matrix [Na, Nb] of (x, y, z, dx, dy, dz, heading) boxes."""
+    _need_gpu(boxes_a, boxes_b)
+    L = hip.lib()
+    a, b = _f32c(boxes_a), _f32c(boxes_b)
+    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    hip.check(L.coalign_boxes_iou_bev(_ptr(a), a.shape[0], _ptr(b), b.shape[0], _ptr(out), _stream()), "coalign_boxes_iou_bev")
+    return out

@@ -1,0 +1,146 @@
+"""Detection post-processing of the hot path, host side.
+
+``VoxelPostprocessor`` keeps the reference's constructor, ``generate_anchor_box()`` and
+``post_process(data_dict, output_dict)`` contract (opencood/data_utils/post_processor/voxel_postprocessor.py:25-81,
+243-402); ``nms_rotated`` keeps box_utils.nms_rotated's (opencood/utils/box_utils.py:693-738).  Decode, sanity
+filters, rotated NMS and the range filter run in the gfx950 kernels (``coalign_anchor_decode``,
+``coalign_nms_rotated``, ``coalign_gather_in_range``) back to back on one stream; the only device->host traffic is
+the final box count.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+NMS_TOP = 1000  # box_utils.py:719
+
+
+def nms_rotated(boxes: torch.Tensor, scores: torch.Tensor, threshold: float) -> np.ndarray:
+    """boxes [N, 8, 3] or [N, 4, 2] (device), scores [N] -> np.int32 indices of the kept boxes in pick order."""
+    if boxes.shape[0] == 0:
+        return np.array([], dtype=np.int32)
+    keep, cnt = ops.nms_rotated_device(boxes, scores, threshold, NMS_TOP)
+    return keep[: int(cnt.item())].cpu().numpy().astype(np.int32)
+
+
+class VoxelPostprocessor:
+    def __init__(self, anchor_params: dict, train: bool):
+        self.params = anchor_params
+        self.train = train
+        self.bbx_dict = {}
+        self.anchor_num = self.params["anchor_args"]["num"]
+        self._buffers: Dict[tuple, ops.DecodeBuffers] = {}
+        self._anchor_cache: Dict[tuple, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------------------------------ anchors (host)
+    def generate_anchor_box(self) -> np.ndarray:
+        """[H/stride, W/stride, num, 7] float64 anchors; centres are ``linspace(min + v, max - v, n)`` (not cell
+        centres), z = -1, yaw from ``r`` in degrees (voxel_postprocessor.py:30-81)."""
+        aa = self.params["anchor_args"]
+        assert self.anchor_num == len(aa["r"])
+        stride = aa.get("feature_stride", 2)
+        rng = aa["cav_lidar_range"]
+        xs = np.linspace(rng[0] + aa["vw"], rng[3] - aa["vw"], aa["W"] // stride)
+        ys = np.linspace(rng[1] + aa["vh"], rng[4] - aa["vh"], aa["H"] // stride)
+        out = np.empty((len(ys), len(xs), self.anchor_num, 7), dtype=np.float64)
+        out[..., 0] = xs[None, :, None]
+        out[..., 1] = ys[:, None, None]
+        out[..., 2] = -1.0
+        if self.params["order"] == "hwl":
+            dims = (aa["h"], aa["w"], aa["l"])
+        elif self.params["order"] == "lhw":
+            dims = (aa["l"], aa["h"], aa["w"])
+        else:
+            raise ValueError("Unknown bbx order.")
+        for k, v in enumerate(dims):
+            out[..., 3 + k] = v
+        out[..., 6] = np.array([math.radians(r) for r in aa["r"]])[None, None, :]
+        return out
+
+    # ------------------------------------------------------------------------------------------ decode + NMS (device)
+    def _anchors_f32(self, anchor_box, device) -> torch.Tensor:
+        a = anchor_box if torch.is_tensor(anchor_box) else torch.from_numpy(np.asarray(anchor_box))
+        key = (a.data_ptr(), tuple(a.shape), str(a.dtype), str(device))
+        hit = self._anchor_cache.get(key)
+        if hit is None:
+            hit = a.to(device=device).reshape(-1, 7).float().contiguous()   # anchors.view(-1, 7).float(), :431
+            if len(self._anchor_cache) > 8:
+                self._anchor_cache.clear()
+            self._anchor_cache[key] = hit
+        return hit
+
+    def post_process(self, data_dict: dict, output_dict: dict) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+        """-> (pred_box3d [K', 8, 3], scores [K']) on the device, or (None, None) when nothing passes the score
+        threshold.  ``data_dict`` holds one entry per cav (only 'ego' for early / intermediate fusion)."""
+        cavs = list(data_dict.keys())
+        first = output_dict[cavs[0]]
+        cls0 = first["cls_preds"] if "cls_preds" in first else first["psm"]
+        device = cls0.device
+        A, H, W = cls0.shape[-3:]
+        capacity = A * H * W * len(cavs)
+        key = (str(device), A, H, W, capacity)
+        buf = self._buffers.get(key)
+        if buf is None:
+            buf = self._buffers[key] = ops.DecodeBuffers(capacity, A, H, W, NMS_TOP, device)
+        if len(cavs) + 1 > buf.counts.numel():
+            raise ValueError("too many cavs for one post_process call")
+        buf.counts.zero_()
+        buf.status.zero_()
+        thr = self.params["target_args"]["score_threshold"]
+        da = self.params.get("dir_args", {})
+        for slot, cav_id in enumerate(cavs):
+            assert cav_id in output_dict
+            out = output_dict[cav_id]
+            cls = out["cls_preds"] if "cls_preds" in out else out["psm"]
+            reg = out["reg_preds"] if "reg_preds" in out else out["rm"]
+            dirp = out.get("dir_preds", out.get("dm"))
+            if reg.dim() != 4:
+                raise NotImplementedError("anchor-free heads are outside the CoAlign hot path")
+            if "iou_preds" in out:
+                raise NotImplementedError("iou_preds rescoring is outside the CoAlign hot path")
+            content = data_dict[cav_id]
+            T = content["transformation_matrix"]
+            T = torch.as_tensor(T).to(device=device, dtype=torch.float32)
+            anchors = self._anchors_f32(content["anchor_box"], device)
+            ops.anchor_decode(buf, slot, cls, reg, dirp, anchors, thr, da.get("dir_offset", 0.0), da.get("num_bins", 2),
+                              self.params["order"], T)
+        total_dev = buf.counts[len(cavs): len(cavs) + 1]
+        ops.nms_rotated_device(buf.cand_corners, buf.cand_score, self.params["nms_thresh"], NMS_TOP, valid=buf.cand_keep,
+                               k_dev=total_dev, keep=buf.keep, keep_count=buf.keep_count, ws=buf.nms_ws)
+        ops.gather_in_range(buf.cand_corners, buf.cand_score, buf.keep, buf.keep_count, self.params["gt_range"],
+                            buf.out_corners, buf.out_scores, buf.out_count)
+        n_out = int(buf.out_count.item())          # the one host sync of the post-processing
+        n_cand = int(total_dev.item())
+        if int(buf.status.item()) & 1:
+            raise RuntimeError("post_process: candidate buffer overflow")
+        self.last_counts = {"candidates": n_cand, "kept": int(buf.keep_count.item()), "final": n_out}
+        if n_cand == 0:
+            return None, None
+        return buf.out_corners[:n_out].clone(), buf.out_scores[:n_out].clone()
+
+    @staticmethod
+    def delta_to_boxes3d(deltas: torch.Tensor, anchors: torch.Tensor) -> torch.Tensor:
+        """Dense decode of every anchor, [N, 7A, H, W] -> [N, H*W*A, 7] (voxel_postprocessor.py:405-450); plain
+        tensor algebra on whatever device ``deltas`` lives on (the fused kernel decodes only passing anchors)."""
+        N = deltas.shape[0]
+        d = deltas.permute(0, 2, 3, 1).contiguous().view(N, -1, 7)
+        a = anchors.to(d.device).view(-1, 7).float()
+        diag = torch.sqrt(a[:, 4] ** 2 + a[:, 5] ** 2)
+        xy = d[..., 0:2] * diag[None, :, None] + a[None, :, 0:2]
+        z = d[..., 2:3] * a[None, :, 3:4] + a[None, :, 2:3]
+        hwl = torch.exp(d[..., 3:6]) * a[None, :, 3:6]
+        yaw = d[..., 6:7] + a[None, :, 6:7]
+        return torch.cat([xy, z, hwl, yaw], dim=-1)
+
+
+def build_postprocessor(anchor_cfg: dict, train: bool) -> VoxelPostprocessor:
+    """opencood/data_utils/post_processor/__init__.py:build_postprocessor for the hot path's only family."""
+    name = anchor_cfg["core_method"]
+    if name != "VoxelPostprocessor":
+        raise KeyError(f"post-processor '{name}' is outside the CoAlign hot path")
+    return VoxelPostprocessor(anchor_params=anchor_cfg, train=train)

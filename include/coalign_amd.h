@@ -1,0 +1,159 @@
+/*
+ * coalign_amd.h -- C ABI of the MI355X (gfx950) implementation of the CoAlign per-frame detection hot path.
+ *
+ * Drop-in boundary.  The reference (yifanlu0227/CoAlign) is pure Python/PyTorch on this path,
+ * so "what its FFI would bind" is a ctypes stub inside the opencood modules named below; INTEGRATION.md shows
+ * those stubs.  Every entry point
+ *   - takes plain device pointers and sizes (no torch types), all tensors dense row-major, float32 unless noted;
+ *   - never allocates, never synchronises, never exits: outputs and workspaces are caller-allocated,
+ *     kernels are enqueued on the hipStream_t passed as `stream` (NULL = the null stream);
+ *   - returns 0 (COALIGN_OK) or a negative coalign_status; coalign_status_string() names it and
+ *     coalign_last_hip_error() returns the hipError_t string captured by the calling thread's last failure;
+ *   - is re-entrant and keeps no mutable global state (one workspace per stream is the caller's business).
+ *
+ * Paths in comments are relative to the reference repository root.
+ */
+#ifndef COALIGN_AMD_H
+#define COALIGN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COALIGN_ABI_VERSION 1
+
+typedef enum coalign_status {
+    COALIGN_OK = 0,
+    COALIGN_ERR_NULL_POINTER = -1,  /* a required pointer argument is NULL                     */
+    COALIGN_ERR_BAD_SHAPE = -2,     /* negative / inconsistent dimensions                      */
+    COALIGN_ERR_UNSUPPORTED = -3,   /* valid request outside what the kernels implement        */
+    COALIGN_ERR_WORKSPACE = -4,     /* workspace_bytes smaller than the *_workspace_bytes query */
+    COALIGN_ERR_HIP = -5            /* a HIP runtime call failed; see coalign_last_hip_error() */
+} coalign_status;
+
+/* bits of the device-side status word written by the post-processing kernels */
+#define COALIGN_FLAG_CANDIDATE_OVERFLOW 1u /* more candidates passed the score threshold than `capacity` */
+
+int coalign_abi_version(void);
+const char *coalign_status_string(int status);
+const char *coalign_last_hip_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * (1) Pillar feature encoder + scatter to the dense BEV canvas.
+ *     Replaces PillarVFE.forward        opencood/models/sub_modules/pillar_vfe.py:105-155 (PFNLayer :31-53)
+ *          and PointPillarScatter.forward opencood/models/sub_modules/point_pillar_scatter.py:15-72.
+ *
+ * voxel_features  [M, P, 4]  (x, y, z, intensity), rows >= num_points are padding
+ * voxel_num_points[M] int32, voxel_coords [M, 4] int32 = (agent, z, y, x)
+ * pfn_weight      [C, Cin]   Cin = 4*use_absolute_xyz + 1*(!use_absolute_xyz) + 6 + with_distance  (10 by default)
+ * pfn_bias        [C] or NULL (only when the layer was built with use_norm = false)
+ * bn_weight/bn_bias/bn_mean/bn_var [C] or all NULL; bn_eps (1e-3 in the reference, pillar_vfe.py:25), eval mode
+ * voxel_size[3], range_min[3]: HOST float64; pillar centre = coord * voxel + (voxel / 2 + range_min), the offset
+ *                 being evaluated in float64 and rounded to float32 once, like pillar_vfe.py:84-89
+ * pillar_features [M, C] out (required; the reference exposes it as batch_dict['pillar_features'])
+ * canvas          [n_agents, C, ny, nx] out; cell index = z + y * nx + x (point_pillar_scatter.py:54), every
+ *                 element is written (zeros where no pillar).  If two pillars of one agent share a cell the one
+ *                 with the larger row index wins (the reference's sequential CPU indexing semantics).
+ * workspace       coalign_pillar_scatter_workspace_bytes(n_agents, ny, nx) bytes
+ */
+size_t coalign_pillar_scatter_workspace_bytes(int n_agents, int ny, int nx);
+int coalign_pillar_vfe_scatter(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords,
+                               int M, int P, const float *pfn_weight, const float *pfn_bias, const float *bn_weight,
+                               const float *bn_bias, const float *bn_mean, const float *bn_var, float bn_eps, int C,
+                               int use_absolute_xyz, int with_distance, const double *voxel_size, const double *range_min,
+                               int n_agents, int ny, int nx, float *pillar_features, float *canvas, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
+/* Scatter only (PointPillarScatter.forward on already-encoded pillars): pillar_features [M, C] -> canvas.
+ * Same cell rule, duplicate rule and workspace as above. */
+int coalign_scatter_to_bev(const float *pillar_features, const int32_t *voxel_coords, int M, int C, int n_agents, int ny,
+                           int nx, float *canvas, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * (2) Pose-aware affine warp + multi-agent fusion, one launch per feature scale.
+ *     Replaces warp_affine_simple   opencood/models/sub_modules/torch_transformation_utils.py:322-331
+ *              AttFusion.forward    opencood/models/fuse_modules/fusion_in_one.py:96-136
+ *                (ScaledDotProductAttention opencood/models/fuse_modules/att_fuse.py:43-47)
+ *              MaxFusion.forward    opencood/models/fuse_modules/fusion_in_one.py:51-89
+ *              warp_feature         opencood/models/fuse_modules/fusion_in_one.py:26-45
+ *
+ * x          [n_total, C, H, W]   agents of all frames concatenated (record_len order)
+ * theta      [n_total, 2, 3] float64, DEVICE: for agent j of frame b the row normalized_affine[b, 0, j]
+ *            (ego -> agent j in affine_grid's normalised coordinates).  The sampling grid is evaluated in
+ *            float64 and then cast to float32, like F.affine_grid on a float64 theta followed by .to(src).
+ * group_len  [n_groups] HOST int32, agents per frame (record_len); sum == n_total; each 1..8
+ * mode       COALIGN_FUSE_ATT : out [n_groups, C, Ho, Wo]  softmax_j(<X0,Xj>/sqrt(C)) weighted sum, ego row only
+ *            COALIGN_FUSE_MAX : out [n_groups, C, Ho, Wo]  elementwise max over the frame's agents
+ *            COALIGN_FUSE_NONE: out [n_total,  C, Ho, Wo]  the warped maps themselves
+ * Sampling: bilinear, zeros padding, align_corners = False.  C <= 256 for ATT/MAX.
+ */
+enum { COALIGN_FUSE_ATT = 0, COALIGN_FUSE_MAX = 1, COALIGN_FUSE_NONE = 2 };
+int coalign_warp_fuse(const float *x, int n_total, int C, int H, int W, const double *theta, const int32_t *group_len,
+                      int n_groups, int mode, float *out, int Ho, int Wo, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * (3) Anchor decode: sigmoid + score threshold + box decode + direction-bin fix + 8 corners + projection +
+ *     size / z sanity filters, order-preserving compaction.
+ *     Replaces VoxelPostprocessor.post_process opencood/data_utils/post_processor/voxel_postprocessor.py:275-377
+ *              delta_to_boxes3d :405-450, limit_period opencood/utils/common_utils.py:70-79,
+ *              boxes_to_corners_3d / project_box3d / remove_large_pred_bbx / remove_bbx_abnormal_z
+ *              opencood/utils/box_utils.py:152-204, 278-316, 840-869 (including its y-for-z quirk), 872-890.
+ *
+ * cls [A, H, W], reg [7A, H, W], dir [num_bins*A, H, W] or NULL: one agent's head outputs (batch 1)
+ * anchors [H*W*A, 7] float32 (x, y, z, h, w, l, yaw) in flat (h, w, anchor) order
+ * transform [4, 4] float32 DEVICE row-major agent->ego, or NULL for identity
+ * Candidates (score > score_thr) are appended in flat anchor order starting at position *count_in
+ * (count_in == NULL -> 0); *count_out receives the new total, clamped to `capacity`, so several agents
+ * (late fusion) can be chained without a host round trip.
+ * cand_index [capacity] int32 flat anchor index, cand_score [capacity], cand_box7 [capacity, 7] (after the
+ * direction fix), cand_corners [capacity, 8, 3] (projected), cand_keep [capacity] uint8 (passes both sanity
+ * filters).  status: device uint32, COALIGN_FLAG_* bits are OR-ed in.  Any of cand_index/cand_box7 may be NULL.
+ */
+size_t coalign_anchor_decode_workspace_bytes(int A, int H, int W);
+int coalign_anchor_decode(const float *cls, const float *reg, const float *dir, const float *anchors, int A, int H, int W,
+                          int num_bins, float score_thr, float dir_offset, int order_hwl, const float *transform,
+                          int capacity, const int32_t *count_in, int32_t *count_out, int32_t *cand_index,
+                          float *cand_score, float *cand_box7, float *cand_corners, uint8_t *cand_keep, uint32_t *status,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * (4) Rotated NMS.  Replaces nms_rotated opencood/utils/box_utils.py:693-738 (+ compute_iou / convert_format
+ *     opencood/utils/common_utils.py:196-236, i.e. the Shapely polygon loop) and supersedes the bitmask NMS of
+ *     opencood/pcdet_utils/iou3d_nms (src/iou3d_nms_kernel.cu:267-311 + host scan src/iou3d_nms.cpp:90-136).
+ *
+ * boxes  [K, rows, cols] float32, rows >= 4, cols >= 2: corners 0..3, columns (x, y) form the polygon
+ *        ([K, 8, 3] and [K, 4, 2] are the two layouts the reference passes)
+ * scores [K]; valid [K] uint8 or NULL; K_dev: device int32 holding the live K (<= K) or NULL
+ * Semantics: consider valid boxes only, order by score descending (ties: larger index first), keep the first
+ * `top` (1000 in the reference), greedy suppression with float32(IoU) > iou_thr where IoU is evaluated in
+ * float64 (convex clipping, union = |A| + |B| - inter).  keep [top] int32 receives indices into `boxes` in pick
+ * order, *keep_count their number.  top <= 4096.
+ */
+size_t coalign_nms_rotated_workspace_bytes(int K, int top);
+int coalign_nms_rotated(const float *boxes, int rows, int cols, const float *scores, const uint8_t *valid, int K,
+                        const int32_t *K_dev, float iou_thr, int top, int32_t *keep, int32_t *keep_count, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+/* Gather the kept boxes and drop those with a corner outside `range` (xmin, ymin, zmin, xmax, ymax, zmax;
+ * compared in float64 like mask_boxes_outside_range_numpy, opencood/utils/box_utils.py:384-421 with
+ * min_num_corners = 8), preserving pick order (voxel_postprocessor.py:385-397).
+ * corners [*, 8, 3], scores [*], keep [keep_cap] + *keep_count from coalign_nms_rotated
+ * out_corners [keep_cap, 8, 3], out_scores [keep_cap], *out_count.  keep_cap <= 4096. */
+int coalign_gather_in_range(const float *corners, const float *scores, const int32_t *keep, const int32_t *keep_count,
+                            int keep_cap, const double *range6_host, float *out_corners, float *out_scores,
+                            int32_t *out_count, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * (5) OpenPCDet-semantics BEV IoU (fp32 overlap with its 1e-2 corner margin) for callers of
+ *     opencood/pcdet_utils/iou3d_nms/iou3d_nms_utils.py (boxes_iou_bev :47-63, nms_gpu :255-271).
+ * boxes_a [Na, 7], boxes_b [Nb, 7] = (x, y, z, dx, dy, dz, heading) -> iou [Na, Nb]
+ */
+int coalign_boxes_iou_bev(const float *boxes_a, int Na, const float *boxes_b, int Nb, float *iou, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COALIGN_AMD_H */

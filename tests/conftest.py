@@ -10,6 +10,12 @@ if REPO not in sys.path:
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
+# The CPU oracle runs tiny batched matmuls; on a many-core host (the GPU box) torch's default of one thread per
+# core makes them pathologically slow, so cap the intra-op threads for the whole test session.
+import torch  # noqa: E402
+
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
