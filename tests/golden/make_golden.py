@@ -139,7 +139,18 @@ def main():
          feat0_sample=feats[0].reshape(-1)[::5], feat1_sample=feats[1].reshape(-1)[::5], feat2_sample=feats[2].reshape(-1)[::5],
          fused0=fused[0], fused1=fused[1], fused2=fused[2],
          cls_preds=out["cls_preds"], reg_preds=out["reg_preds"], dir_preds=out["dir_preds"],
-         fill_seed=0, cls_bias=-1.0, n_state=len(sd), n_params=sum(p.numel() for p in model.parameters()))
+         fill_seed=0, cls_bias=-1.0, n_state=len(sd), n_params=sum(p.numel() for p in model.parameters()),
+         state_keys=np.array(list(sd.keys())), state_numel=np.array([v.numel() for v in sd.values()]))
+    # single-agent PointPillar (late fusion, cfg 1) on the mini canvas: state_dict names + one forward
+    hl = load_hypes(YAML_SINGLE, MINI_RANGE)
+    ml = train_utils.create_model(hl).eval()
+    fill_parameters_(ml, seed=0, cls_bias=-1.0)
+    fl = make_frame(hl, 1, pillars_per_agent=150, seed=12)
+    ol = ml(fl)
+    sdl = ml.state_dict()
+    save("late_mini.npz", voxel_features=fl["processed_lidar"]["voxel_features"], voxel_coords=fl["processed_lidar"]["voxel_coords"],
+         voxel_num_points=fl["processed_lidar"]["voxel_num_points"], cls_preds=ol["cls_preds"], reg_preds=ol["reg_preds"],
+         dir_preds=ol["dir_preds"], state_keys=np.array(list(sdl.keys())), state_numel=np.array([v.numel() for v in sdl.values()]))
 
     # ------------------------------------------------------------------ pose algebra
     poses = [[0, 0, 0, 0, 0, 0], [12.5, -3.25, 0.4, 1.0, 33.0, -2.0], [-7.0, 8.0, 0.1, 0.0, -121.0, 0.5]]
