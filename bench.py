@@ -39,7 +39,12 @@ def calibrate_cls_bias(model, pp, batch, target=600):
     """Random-init heads give arbitrary logits; shift cls_head.bias so that ~`target` anchors pass the score
     threshold ("head biases shifted so K ~ 300-1000 candidates"), as a trained detector would."""
     with torch.no_grad():
-        logits = model(batch)["cls_preds"].flatten()
+        out = model(batch)
+        # box deltas of a trained detector are small: rescale the random regression head to std 0.1 so that the decoded
+        # boxes stay car sized / inside the z range (they pass the sanity filters) and neighbouring anchors overlap
+        model.reg_head.weight *= 0.1 / float(out["reg_preds"].std())
+        model.reg_head.bias.zero_()
+        logits = out["cls_preds"].flatten()
         k = min(target, logits.numel() - 1)
         v = torch.topk(logits, k + 1).values[-1]
         thr = pp.params["target_args"]["score_threshold"]
@@ -66,11 +71,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # COALIGN_BENCH_BACKEND=gloo + COALIGN_BENCH_ONE_GPU=1: functional test of the multi-rank code path on a single
+    # GPU (ranks share device 0, the exchange is staged through host memory).  Never used for reported numbers.
+    backend = os.environ.get("COALIGN_BENCH_BACKEND", "nccl")
+    if os.environ.get("COALIGN_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     hypes = builtin_config(args.config)
     N = args.agents
@@ -92,17 +105,26 @@ def main():
     calibrate_cls_bias(model, pp, frame)
     if world > 1:   # identical weights everywhere
         for p in model.parameters():
-            dist.broadcast(p.data, 0)
+            if backend == "nccl":
+                dist.broadcast(p.data, 0)
+            else:
+                buf = p.data.cpu()
+                dist.broadcast(buf, 0)
+                p.data.copy_(buf)
 
     record = [N]
 
     def step():
         with torch.no_grad():
-            feats, affine = model.encode(frame)
+            with ops.timed("stage_encode(pillars+backbone)"):
+                feats, affine = model.encode(frame)
             if ring is not None:
-                feats = ring.exchange(feats)
-            out = model.fuse_and_head(feats, record, affine)
-            return pp.post_process(ego_meta, {"ego": out})
+                with ops.timed("stage_exchange(all_to_all)"):
+                    feats = ring.exchange(feats)
+            with ops.timed("stage_fuse_and_heads"):
+                out = model.fuse_and_head(feats, record, affine)
+            with ops.timed("stage_post_process"):
+                return pp.post_process(ego_meta, {"ego": out})
 
     def sync():
         if world > 1:
@@ -120,7 +142,7 @@ def main():
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -151,7 +173,7 @@ def main():
                                    f"geometry): {N} agents/frame, {args.pillars} pillars/agent, canvas {nx}x{ny}, 70400 anchors, "
                                    "full path incl. decode + rotated NMS",
                        "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": world,
-                       "parallelism": "single GPU" if world == 1 else f"agent-sharded frame ring x{world}, RCCL all-to-all",
+                       "parallelism": "single GPU" if world == 1 else f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all",
                        "detections_last_frame": 0 if boxes is None else int(boxes.shape[0]),
                        "candidates_last_frame": pp.last_counts["candidates"]},
             "roofline": roofline, "kernels": kernels,

@@ -21,14 +21,65 @@ Parameter / buffer names are kept identical to the reference so that its
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+# Inference fast path (eval mode, CUDA, float32): eval-mode BatchNorm is a per-channel affine map, so its scale is
+# folded into the convolution weights once (re-folded whenever a parameter / buffer changes) and the remaining
+# per-channel shift + residual add + ReLU run as ONE fused HIP pass (``coalign_bias_act``) after each MIOpen
+# convolution: 2 element-wise passes per BasicBlock instead of the reference's 5.  Training mode and CPU tensors take
+# the plain ``torch.nn`` route below (identical to the reference's op sequence).
+FAST_INFERENCE = True
 
 
 def _bn(ch: int, eps: float) -> nn.BatchNorm2d:
     return nn.BatchNorm2d(ch, eps=eps, momentum=0.01)
+
+
+def _fast_ok(module: nn.Module, x: torch.Tensor) -> bool:
+    return FAST_INFERENCE and (not module.training) and x.is_cuda and x.dtype == torch.float32
+
+
+def fold_bn(weight: torch.Tensor, conv_bias: Optional[torch.Tensor], bn: nn.BatchNorm2d, out_dim: int = 0):
+    """conv/deconv weight + eval BatchNorm -> (scaled weight, per-channel shift).  ``out_dim`` is the weight's
+    output-channel axis (0 for Conv2d, 1 for ConvTranspose2d)."""
+    scale = bn.weight * (1.0 / torch.sqrt(bn.running_var + bn.eps))
+    shift = bn.bias - bn.running_mean * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias * scale
+    shape = [1] * weight.dim()
+    shape[out_dim] = -1
+    return (weight * scale.view(shape)).contiguous(), shift.contiguous()
+
+
+class _FoldCache:
+    """Folded tensors of one module, invalidated when any source tensor is replaced or written in place."""
+
+    def __init__(self):
+        self.sig = None
+        self.data = None
+
+    def get(self, source, builder):
+        """``source``: a module (all its parameters + buffers) or an explicit list of tensors."""
+        tensors = list(source.parameters()) + list(source.buffers()) if isinstance(source, nn.Module) else list(source)
+        sig = tuple((t.data_ptr(), t._version) for t in tensors)
+        if sig != self.sig:
+            with torch.no_grad():
+                self.data = builder()
+            self.sig = sig
+        return self.data
+
+
+def _cache_of(module: nn.Module) -> _FoldCache:
+    c = module.__dict__.get("_coalign_fold_cache")
+    if c is None:
+        c = module.__dict__["_coalign_fold_cache"] = _FoldCache()
+    return c
 
 
 class BasicBlock(nn.Module):
@@ -46,7 +97,25 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
+    def _folded(self):
+        def build():
+            w1, b1 = fold_bn(self.conv1.weight, None, self.bn1)
+            w2, b2 = fold_bn(self.conv2.weight, None, self.bn2)
+            wd = None
+            if self.downsample is not None:
+                wd, bd = fold_bn(self.downsample[0].weight, None, self.downsample[1])
+                b2 = (b2 + bd).contiguous()          # both shifts land on the same sum
+            return w1, b1, w2, b2, wd
+        return _cache_of(self).get(self, build)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _fast_ok(self, x):
+            w1, b1, w2, b2, wd = self._folded()
+            x = x.contiguous()
+            y = ops.bias_act_(F.conv2d(x, w1, None, self.stride, 1), b1, None, True)
+            z = F.conv2d(y, w2, None, 1, 1)
+            skip = x if wd is None else F.conv2d(x, wd, None, self.stride)
+            return ops.bias_act_(z, b2, skip, True)
         skip = x if self.downsample is None else self.downsample(x)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
@@ -108,11 +177,21 @@ def _make_deblocks(num_filters, upsample_strides, num_upsample_filters, num_leve
 class _MultiscaleDecodeMixin:
     """Shared ``decode_multiscale_feature`` / single-pass ``forward`` tail."""
 
+    def _deblock(self, i: int, f: torch.Tensor) -> torch.Tensor:
+        blk = self.deblocks[i]
+        if not _fast_ok(self, f):
+            return blk(f)
+        op, bn = blk[0], blk[1]
+        transposed = isinstance(op, nn.ConvTranspose2d)
+        w, b = _cache_of(blk).get(blk, lambda: fold_bn(op.weight, None, bn, out_dim=1 if transposed else 0))
+        y = F.conv_transpose2d(f, w, None, stride=op.stride) if transposed else F.conv2d(f, w, None, stride=op.stride)
+        return ops.bias_act_(y.contiguous(), b, None, True)
+
     def _upsample_concat(self, feats: Sequence[torch.Tensor]) -> torch.Tensor:
-        ups = [self.deblocks[i](f) if len(self.deblocks) > 0 else f for i, f in enumerate(feats[: self.num_levels])]
+        ups = [self._deblock(i, f) if len(self.deblocks) > 0 else f for i, f in enumerate(feats[: self.num_levels])]
         x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
         if len(self.deblocks) > self.num_levels:
-            x = self.deblocks[-1](x)
+            x = self._deblock(len(self.deblocks) - 1, x)
         return x
 
     def decode_multiscale_feature(self, feats: Sequence[torch.Tensor]) -> torch.Tensor:
@@ -176,10 +255,21 @@ class BaseBEVBackbone(_MultiscaleDecodeMixin, nn.Module):
         self.deblocks = _make_deblocks(num_filters, ups, upf, self.num_levels)
         self.num_bev_features = sum(upf)
 
+    def _block_fast(self, blk: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+        def build():
+            out = []
+            for k in range(1, len(blk), 3):          # (conv, bn, relu) triples after the leading ZeroPad2d
+                out.append(fold_bn(blk[k].weight, None, blk[k + 1]) + (blk[k].stride,))
+            return out
+        for w, b, stride in _cache_of(blk).get(blk, build):
+            x = ops.bias_act_(F.conv2d(x, w, None, stride, 1), b, None, True)   # ZeroPad2d(1)+pad 0 == pad 1
+        return x
+
     def get_multiscale_feature(self, spatial_features: torch.Tensor) -> List[torch.Tensor]:
         feats, x = [], spatial_features
+        fast = _fast_ok(self, x)
         for blk in self.blocks:
-            x = blk(x)
+            x = self._block_fast(blk, x.contiguous()) if fast else blk(x)
             feats.append(x)
         return feats
 
@@ -202,6 +292,10 @@ class DoubleConv(nn.Module):
             nn.Conv2d(cout, cout, 3, padding=1), nn.ReLU(inplace=True))
 
     def forward(self, x):
+        if _fast_ok(self, x):
+            c1, c2 = self.double_conv[0], self.double_conv[2]
+            y = ops.bias_act_(F.conv2d(x, c1.weight, None, c1.stride, c1.padding), c1.bias, None, True)
+            return ops.bias_act_(F.conv2d(y, c2.weight, None, 1, 1), c2.bias, None, True)
         return self.double_conv(x)
 
 
@@ -237,4 +331,11 @@ class NaiveCompressor(nn.Module):
         self.decoder = nn.Sequential(*cbr(mid, input_dim), *cbr(input_dim, input_dim))
 
     def forward(self, x):
+        if _fast_ok(self, x):
+            def build():
+                seqs = [self.encoder, self.decoder[0:3], self.decoder[3:6]]
+                return [fold_bn(q[0].weight, q[0].bias, q[1]) for q in seqs]
+            for w, b in _cache_of(self).get(self, build):
+                x = ops.bias_act_(F.conv2d(x, w, None, 1, 1), b, None, True)
+            return x
         return self.decoder(self.encoder(x))

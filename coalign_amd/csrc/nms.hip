@@ -6,11 +6,14 @@
 // boolean operations per remaining pair.  Here nothing leaves the device:
 //   rank_kernel    rank-by-counting on the key (score desc, index desc): O(K^2) compares, LDS tiled, no sort
 //                  passes, deterministic; writes the top-`top` order
-//   mask_kernel    one wavefront per 64x64 tile of the (upper-triangular) pair matrix, column polygons staged
-//                  in LDS, each lane builds the 64-bit suppression word of its row; IoU in float64 by
-//                  Sutherland-Hodgman clipping, rounded to float32 before the strict '>' like the reference
-//   reduce_kernel  single wavefront: lane w owns word w of the "removed" set; the inherently sequential part is
-//                  64 scalar steps per 64-row block on the diagonal word, the row ORs are parallel over words
+//   mask_kernel    one 16-wave workgroup per 64x64 tile of the (upper-triangular) pair matrix, row and column
+//                  polygons staged in LDS; lanes are the 64 columns, each wave owns 4 rows (row polygon = LDS
+//                  broadcast) and one __ballot IS the row's 64-bit suppression word; IoU in float64 by
+//                  Sutherland-Hodgman clipping, rounded to float32 before the strict '>' like the reference;
+//                  disjoint bounding boxes are rejected without clipping (their IoU is exactly 0)
+//   reduce_kernel  single wavefront: lane w owns word w of the "removed" set; the inherently sequential part walks
+//                  only the still-alive boxes of each 64-row block (scalar find-first-set on the diagonal word),
+//                  the row ORs into the later words are parallel over lanes
 //   gather_kernel  kept boxes with all 8 corners inside the range (float64 compare), order preserving
 // Compiled with -ffp-contract=off so the float64 arithmetic is bit-identical to the gcc-built CPU oracle.
 #include "common.h"
@@ -117,35 +120,44 @@ __device__ __forceinline__ void load_poly(const float *boxes, int rows, int cols
     p.sgn = sa >= 0.0 ? 1.0 : -1.0;
 }
 
-__global__ __launch_bounds__(64) void mask_kernel(const float *__restrict__ boxes, int rows, int cols,
-                                                  const int *__restrict__ order, const int *__restrict__ n_sorted,
-                                                  float thr, int nb, unsigned long long *__restrict__ mask) {
+constexpr int kMaskWaves = 16;   // waves per 64x64 tile: each wave owns 4 rows, lanes are the 64 columns
+
+__global__ __launch_bounds__(kMaskWaves * 64) void mask_kernel(const float *__restrict__ boxes, int rows, int cols,
+                                                               const int *__restrict__ order, const int *__restrict__ n_sorted,
+                                                               float thr, int nb, unsigned long long *__restrict__ mask) {
     const int cb = blockIdx.x, rb = blockIdx.y;
     if (cb < rb) return;
     const int n = *n_sorted;
     if (rb * 64 >= n || cb * 64 >= n) return;
-    __shared__ Poly colp[64];
-    const int lane = threadIdx.x;
-    const int j_own = cb * 64 + lane;
-    if (j_own < n) load_poly(boxes, rows, cols, order[j_own], colp[lane]);
-    __syncthreads();
-    const int i = rb * 64 + lane;
-    if (i >= n) return;
-    Poly row;
-    if (cb == rb) row = colp[lane];
-    else load_poly(boxes, rows, cols, order[i], row);
-    unsigned long long bits = 0;
-    const int lim = min(64, n - cb * 64);
-    for (int q = 0; q < lim; ++q) {
-        const int j = cb * 64 + q;
-        if (j <= i) continue;
-        const Poly &c = colp[q];
-        // disjoint bounding boxes => intersection exactly 0 => IoU 0 (or NaN): never '>' a non-negative thr
-        if (thr >= 0.f && (row.xmax < c.xmin || c.xmax < row.xmin || row.ymax < c.ymin || c.ymax < row.ymin)) continue;
-        const float iou = (float)quad_iou(row.v, row.area, c.v, c.area, c.sgn);
-        if (iou > thr) bits |= 1ull << q;
+    __shared__ Poly colp[64], rowp[64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (wv == 0) {
+        const int j = cb * 64 + lane;
+        if (j < n) load_poly(boxes, rows, cols, order[j], colp[lane]);
+    } else if (wv == 1) {
+        const int i = rb * 64 + lane;
+        if (i < n) load_poly(boxes, rows, cols, order[i], rowp[lane]);
     }
-    mask[(size_t)i * nb + cb] = bits;
+    __syncthreads();
+    const int j = cb * 64 + lane;
+    Poly c;
+    if (j < n) c = colp[lane];
+    constexpr int kRowsPerWave = 64 / kMaskWaves;
+#pragma unroll 1
+    for (int r = 0; r < kRowsPerWave; ++r) {
+        const int il = wv * kRowsPerWave + r;
+        const int i = rb * 64 + il;
+        if (i >= n) break;                                   // wave-uniform
+        const Poly &row = rowp[il];                          // LDS broadcast
+        bool bit = false;
+        if (j < n && j > i) {
+            // disjoint bounding boxes => intersection exactly 0 => IoU 0 (or NaN): never '>' a non-negative thr
+            const bool apart = thr >= 0.f && (row.xmax < c.xmin || c.xmax < row.xmin || row.ymax < c.ymin || c.ymax < row.ymin);
+            if (!apart) bit = (float)quad_iou(row.v, row.area, c.v, c.area, c.sgn) > thr;
+        }
+        const unsigned long long word = __ballot(bit);
+        if (lane == 0) mask[(size_t)i * nb + cb] = word;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ reduce
@@ -158,33 +170,50 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 __global__ __launch_bounds__(64) void reduce_kernel(const unsigned long long *__restrict__ mask, const int *__restrict__ order,
                                                     const int *__restrict__ n_sorted, int nb, int *__restrict__ keep,
                                                     int *__restrict__ keep_count) {
+    extern __shared__ unsigned long long rowsbuf[];   // the 64 mask rows of the current block: [64][nb]
     const int lane = threadIdx.x;
     const int n = *n_sorted;
     const int nblk = (n + 63) / 64;
     unsigned long long removed = 0;  // lane w: word w of the suppressed set
     int cnt = 0;
     for (int b = 0; b < nblk; ++b) {
-        unsigned long long rem = readlane64(removed, b);
-        const int i = b * 64 + lane;
-        const unsigned long long diag = (i < n) ? mask[(size_t)i * nb + b] : 0ull;
         const int rows = min(64, n - b * 64);
-        unsigned long long keepbits = 0;
-        for (int t = 0; t < rows; ++t) {
-            if (!((rem >> t) & 1ull)) {
-                keepbits |= 1ull << t;
-                rem |= readlane64(diag, t);
-            }
+        // one coalesced sweep brings the block's rows (a contiguous rows*nb chunk) into LDS: a single memory round
+        // trip per block instead of one dependent global load per kept box
+        const unsigned long long *chunk = mask + (size_t)b * 64 * nb;
+        for (int e = lane; e < rows * nb; e += 64) {
+            const int w = e % nb;
+            rowsbuf[e] = (w >= b) ? chunk[e] : 0ull;     // words left of the diagonal are never produced nor needed
         }
-        if ((keepbits >> lane) & 1ull) keep[cnt + __popcll(keepbits & ((1ull << lane) - 1ull))] = order[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long diag = (lane < rows) ? rowsbuf[lane * nb + b] : 0ull;
+        const unsigned long long valid = rows == 64 ? ~0ull : ((1ull << rows) - 1ull);
+        // the sequential part: visit only the boxes that are still alive (scalar find-first-set), each kept box
+        // ORs its diagonal word into the removed set
+        unsigned long long rem = readlane64(removed, b);
+        unsigned long long keepbits = 0;
+        unsigned long long alive = ~rem & valid;
+        while (alive) {
+            const int t = __ffsll((long long)alive) - 1;
+            keepbits |= 1ull << t;
+            rem |= readlane64(diag, t);
+            const unsigned long long above = (t == 63) ? 0ull : (~0ull << (t + 1));
+            alive = ~rem & valid & above;
+        }
+        if ((keepbits >> lane) & 1ull) keep[cnt + __popcll(keepbits & ((1ull << lane) - 1ull))] = order[b * 64 + lane];
         cnt += __popcll(keepbits);
-        if (lane > b && lane < nb) {
-            unsigned long long kb = keepbits;
+        if (lane > b && lane < nb) {                     // lane w ORs word w of every kept row (LDS, pipelined)
+            unsigned long long kb = keepbits, acc = 0;
             while (kb) {
                 const int t = __ffsll((long long)kb) - 1;
                 kb &= kb - 1;
-                removed |= mask[(size_t)(b * 64 + t) * nb + lane];
+                acc |= rowsbuf[t * nb + lane];
             }
+            removed |= acc;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) *keep_count = cnt;
 }
@@ -358,9 +387,10 @@ int coalign_nms_rotated(const float *boxes, int rows, int cols, const float *sco
     hipLaunchKernelGGL(rank_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, scores, valid, K, K_dev, top, w.order, w.n_sorted);
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(mask_kernel, dim3(nb, nb), dim3(64), 0, stream, boxes, rows, cols, w.order, w.n_sorted, iou_thr, nb, w.mask);
+    hipLaunchKernelGGL(mask_kernel, dim3(nb, nb), dim3(kMaskWaves * 64), 0, stream, boxes, rows, cols, w.order, w.n_sorted, iou_thr, nb, w.mask);
     if ((rc = check_launch())) return rc;
-    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(64), 0, stream, w.mask, w.order, w.n_sorted, nb, keep, keep_count);
+    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(64), (size_t)64 * nb * sizeof(unsigned long long), stream, w.mask, w.order,
+                       w.n_sorted, nb, keep, keep_count);
     return check_launch();
 }
 

@@ -42,6 +42,132 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Per-lane channel parameters: one row of the linear layer and the folded BatchNorm affine.
+struct ChanParams {
+    float w[kFeatStride];
+    float alpha, shift;
+};
+
+__device__ __forceinline__ ChanParams load_chan(const PfnArgs &a, int c) {
+    ChanParams cp;
+    const bool c_ok = c < a.C;
+#pragma unroll
+    for (int k = 0; k < kFeatStride; ++k) cp.w[k] = (c_ok && k < a.Cin) ? a.weight[(size_t)c * a.Cin + k] : 0.f;
+    cp.alpha = 1.f; cp.shift = 0.f;
+    if (c_ok) {
+        if (a.bn_w) {
+            const float inv_std = 1.0f / sqrtf(a.bn_v[c] + a.eps);
+            cp.alpha = a.bn_w[c] * inv_std;
+            cp.shift = a.bn_b[c] - a.bn_m[c] * cp.alpha;
+        } else if (a.bias) {
+            cp.shift = a.bias[c];
+        }
+    }
+    return cp;
+}
+
+// 10/11-d augmentation of one point (pillar_vfe.py:118-141), written to the wave's LDS slab row `row`.
+// Compile-time feature layout (all indices static, so the staging array lives in registers).
+template <bool ABS, bool DIST>
+__device__ __forceinline__ void stage_point_t(float *slab, int row, float4 q, float mx, float my, float mz, float ctr_x,
+                                              float ctr_y, float ctr_z) {
+    float f[kFeatStride];
+#pragma unroll
+    for (int k = 0; k < kFeatStride; ++k) f[k] = 0.f;
+    constexpr int B = ABS ? 4 : 1;
+    if constexpr (ABS) { f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w; }
+    else { f[0] = q.w; }
+    f[B] = q.x - mx; f[B + 1] = q.y - my; f[B + 2] = q.z - mz;
+    f[B + 3] = q.x - ctr_x; f[B + 4] = q.y - ctr_y; f[B + 5] = q.z - ctr_z;
+    if constexpr (DIST) f[B + 6] = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);
+    float4 *dst = reinterpret_cast<float4 *>(slab + row * kFeatStride);
+    dst[0] = make_float4(f[0], f[1], f[2], f[3]);
+    dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+    dst[2] = make_float4(f[8], f[9], f[10], f[11]);
+}
+
+__device__ __forceinline__ void stage_point(const PfnArgs &a, float *slab, int row, float4 q, float mx, float my, float mz,
+                                            float ctr_x, float ctr_y, float ctr_z) {
+    if (a.use_abs) {
+        if (a.with_dist) stage_point_t<true, true>(slab, row, q, mx, my, mz, ctr_x, ctr_y, ctr_z);
+        else stage_point_t<true, false>(slab, row, q, mx, my, mz, ctr_x, ctr_y, ctr_z);
+    } else {
+        if (a.with_dist) stage_point_t<false, true>(slab, row, q, mx, my, mz, ctr_x, ctr_y, ctr_z);
+        else stage_point_t<false, false>(slab, row, q, mx, my, mz, ctr_x, ctr_y, ctr_z);
+    }
+}
+
+__device__ __forceinline__ float point_response(const ChanParams &cp, const float *slab, int j) {
+    const float4 *src = reinterpret_cast<const float4 *>(slab + j * kFeatStride);
+    const float4 u = src[0], v = src[1], t = src[2];
+    float x = cp.w[0] * u.x;
+    x = fmaf(cp.w[1], u.y, x); x = fmaf(cp.w[2], u.z, x); x = fmaf(cp.w[3], u.w, x);
+    x = fmaf(cp.w[4], v.x, x); x = fmaf(cp.w[5], v.y, x); x = fmaf(cp.w[6], v.z, x); x = fmaf(cp.w[7], v.w, x);
+    x = fmaf(cp.w[8], t.x, x); x = fmaf(cp.w[9], t.y, x); x = fmaf(cp.w[10], t.z, x); x = fmaf(cp.w[11], t.w, x);
+    return fmaf(x, cp.alpha, cp.shift);
+}
+
+// Fast path, P <= 64 and C <= 64: the pillar is read exactly once (lane = point), the NEXT pillar's loads are issued
+// before the current one is processed (one HBM round trip per pillar, hidden behind compute), phase B walks the
+// staged points four at a time with independent FMA chains.
+__global__ __launch_bounds__(kWavesPerBlock * 64) void pfn_kernel_p64(PfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    float *slab = smem + (size_t)wib * 64 * kFeatStride;
+    const int gwave = blockIdx.x * kWavesPerBlock + wib;
+    const int nwave = gridDim.x * kWavesPerBlock;
+    const int ncell = a.ny * a.nx;
+    const ChanParams cp = load_chan(a, lane);
+    const bool c_ok = lane < a.C;
+
+    int m = gwave;
+    float4 q_nx = make_float4(0.f, 0.f, 0.f, 0.f); int np_nx = 0; int4 cd_nx = make_int4(0, 0, 0, 0);
+    if (m < a.M) {
+        if (lane < a.P) q_nx = a.pts[(size_t)m * a.P + lane];
+        np_nx = a.npts[m];
+        cd_nx = a.coords[m];
+    }
+    for (; m < a.M; m += nwave) {
+        const float4 q = q_nx;
+        const int np_raw = np_nx;
+        const int4 cd = cd_nx;
+        const int mn = m + nwave;
+        if (mn < a.M) {  // prefetch
+            q_nx = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < a.P) q_nx = a.pts[(size_t)mn * a.P + lane];
+            np_nx = a.npts[mn];
+            cd_nx = a.coords[mn];
+        }
+        const int np_eff = min(max(np_raw, 0), a.P);
+        const float npf = (float)np_raw;
+        const float mx = wave_sum(q.x) / npf, my = wave_sum(q.y) / npf, mz = wave_sum(q.z) / npf;
+        const float ctr_x = (float)cd.w * a.vx + a.xo;
+        const float ctr_y = (float)cd.z * a.vy + a.yo;
+        const float ctr_z = (float)cd.y * a.vz + a.zo;
+        if (lane < np_eff) stage_point(a, slab, lane, q, mx, my, mz, ctr_x, ctr_y, ctr_z);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float best = (np_eff < a.P) ? cp.shift : -INFINITY;
+        int j = 0;
+        for (; j + 4 <= np_eff; j += 4) {
+            const float y0 = point_response(cp, slab, j), y1 = point_response(cp, slab, j + 1);
+            const float y2 = point_response(cp, slab, j + 2), y3 = point_response(cp, slab, j + 3);
+            best = fmaxf(fmaxf(best, fmaxf(y0, y1)), fmaxf(y2, y3));
+        }
+        for (; j < np_eff; ++j) best = fmaxf(best, point_response(cp, slab, j));
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (c_ok) a.feats[(size_t)m * a.C + lane] = fmaxf(best, 0.f);
+        if (lane == 0) {
+            const int cell = cd.y + cd.z * a.nx + cd.w;  // z + y*nx + x (point_pillar_scatter.py:54)
+            if (cd.x >= 0 && cd.x < a.n_agents && cell >= 0 && cell < ncell)
+                atomicMax(a.cellmap + (size_t)cd.x * ncell + cell, m);
+        }
+    }
+}
+
+// Generic path (any P, any C): channel blocks of 64, point chunks of 64.
 __global__ __launch_bounds__(kWavesPerBlock * 64) void pfn_kernel(PfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -54,26 +180,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pfn_kernel(PfnArgs a) {
     for (int cb = 0; cb < a.C; cb += 64) {
         const int c = cb + lane;
         const bool c_ok = c < a.C;
-        float w[kFeatStride];
-#pragma unroll
-        for (int k = 0; k < kFeatStride; ++k) w[k] = (c_ok && k < a.Cin) ? a.weight[(size_t)c * a.Cin + k] : 0.f;
-        float alpha = 1.f, shift = 0.f;
-        if (c_ok) {
-            if (a.bn_w) {
-                const float inv_std = 1.0f / sqrtf(a.bn_v[c] + a.eps);
-                alpha = a.bn_w[c] * inv_std;
-                shift = a.bn_b[c] - a.bn_m[c] * alpha;
-            } else if (a.bias) {
-                shift = a.bias[c];
-            }
-        }
-
+        const ChanParams cp = load_chan(a, c);
         for (int m = gwave; m < a.M; m += nwave) {
             const int np_raw = a.npts[m];
             const int4 cd = a.coords[m];  // (agent, z, y, x)
             const int np_eff = min(max(np_raw, 0), a.P);
             const float4 *prow = a.pts + (size_t)m * a.P;
-
             // mean over ALL P slots divided by num_points (pillar_vfe.py:118-120)
             float sx = 0.f, sy = 0.f, sz = 0.f;
             for (int p0 = 0; p0 < a.P; p0 += 64) {
@@ -88,40 +200,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pfn_kernel(PfnArgs a) {
             const float ctr_x = (float)cd.w * a.vx + a.xo;
             const float ctr_y = (float)cd.z * a.vy + a.yo;
             const float ctr_z = (float)cd.y * a.vz + a.zo;
-
             // rows >= num_points are zeroed before the linear layer: Linear(0) = 0 -> BN -> `shift`
-            float best = (np_eff < a.P) ? shift : -INFINITY;
-
+            float best = (np_eff < a.P) ? cp.shift : -INFINITY;
             for (int p0 = 0; p0 < np_eff; p0 += 64) {
                 const int p = p0 + lane;
-                if (p < np_eff) {
-                    const float4 q = prow[p];
-                    float f[kFeatStride];
-                    int k = 0;
-                    if (a.use_abs) { f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w; k = 4; }
-                    else { f[0] = q.w; k = 1; }
-                    f[k] = q.x - mx; f[k + 1] = q.y - my; f[k + 2] = q.z - mz;
-                    f[k + 3] = q.x - ctr_x; f[k + 4] = q.y - ctr_y; f[k + 5] = q.z - ctr_z;
-                    k += 6;
-                    if (a.with_dist) { f[k] = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z); ++k; }
-                    for (; k < kFeatStride; ++k) f[k] = 0.f;
-                    float4 *dst = reinterpret_cast<float4 *>(slab + lane * kFeatStride);
-                    dst[0] = make_float4(f[0], f[1], f[2], f[3]);
-                    dst[1] = make_float4(f[4], f[5], f[6], f[7]);
-                    dst[2] = make_float4(f[8], f[9], f[10], f[11]);
-                }
+                if (p < np_eff) stage_point(a, slab, lane, prow[p], mx, my, mz, ctr_x, ctr_y, ctr_z);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const int cnt = min(64, np_eff - p0);
-                for (int j = 0; j < cnt; ++j) {
-                    const float4 *src = reinterpret_cast<const float4 *>(slab + j * kFeatStride);
-                    const float4 u = src[0], v = src[1], t = src[2];
-                    float x = w[0] * u.x;
-                    x = fmaf(w[1], u.y, x); x = fmaf(w[2], u.z, x); x = fmaf(w[3], u.w, x);
-                    x = fmaf(w[4], v.x, x); x = fmaf(w[5], v.y, x); x = fmaf(w[6], v.z, x); x = fmaf(w[7], v.w, x);
-                    x = fmaf(w[8], t.x, x); x = fmaf(w[9], t.y, x); x = fmaf(w[10], t.z, x); x = fmaf(w[11], t.w, x);
-                    best = fmaxf(best, fmaf(x, alpha, shift));
-                }
+                for (int j = 0; j < cnt; ++j) best = fmaxf(best, point_response(cp, slab, j));
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -239,9 +326,14 @@ int coalign_pillar_vfe_scatter(const float *voxel_features, const int32_t *voxel
         a.yo = (float)(voxel_size[1] / 2 + range_min[1]);
         a.zo = (float)(voxel_size[2] / 2 + range_min[2]);
         a.n_agents = n_agents; a.ny = ny; a.nx = nx; a.feats = pillar_features; a.cellmap = cellmap;
-        const int blocks = (int)min((long)(M + kWavesPerBlock - 1) / kWavesPerBlock, (long)256 * 8);
         const size_t lds = (size_t)kWavesPerBlock * 64 * kFeatStride * sizeof(float);
-        hipLaunchKernelGGL(pfn_kernel, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, a);
+        if (P <= 64 && C <= 64) {   // ~4 pillars per wave: enough to amortise the parameter load, prefetch hides the rest
+            const int blocks = (int)min((long)(M + 4 * kWavesPerBlock - 1) / (4 * kWavesPerBlock), (long)256 * 16);
+            hipLaunchKernelGGL(pfn_kernel_p64, dim3(max(blocks, 1)), dim3(kWavesPerBlock * 64), lds, stream, a);
+        } else {
+            const int blocks = (int)min((long)(M + kWavesPerBlock - 1) / kWavesPerBlock, (long)256 * 8);
+            hipLaunchKernelGGL(pfn_kernel, dim3(blocks), dim3(kWavesPerBlock * 64), lds, stream, a);
+        }
         if ((rc = check_launch())) return rc;
     }
 

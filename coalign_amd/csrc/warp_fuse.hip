@@ -5,147 +5,99 @@
 // (opencood/models/fuse_modules/fusion_in_one.py:51-136).  The reference materialises the warped copy of every
 // agent, permutes it to (H*W, N, C), runs two bmm + softmax over all N rows and throws N-1 of them away.
 //
-// This kernel fuses everything and computes the ego row only.  One workgroup owns an 8x8 tile of output pixels
-// and ALL channels of ALL agents of the frame:
-//     thread = (pixel = tid & 63, channel group g = tid >> 6), each thread owns CPT consecutive channels;
-//     a wavefront therefore gathers a compact 8x8 footprint of one channel plane per load (bounded by a
-//     ~13x13 source patch for any yaw), served by L1/L2;
-//     the sampling geometry (float64 grid -> float32, 4 taps, zero padding) is computed once per (pixel, agent)
-//     and reused for every channel;
-//     the warped values stay in REGISTERS (KEEP variant), the only cross-wave traffic is the partial
-//     <X0, Xn> dot products (G x N x 64 floats of LDS), then softmax and the weighted sum are per-thread.
-// The QK^T / AV contractions are per-pixel dot products of *different* vectors for every pixel (no operand is
-// shared between pixels), i.e. a batch of 1xC . CxN GEMVs with N <= 8 -- there is no tile to feed an MFMA
-// with, and the f32 MFMA rate equals the f32 VALU rate on gfx950 anyway; the kernel is bound by the gather.
-// Workgroup -> tile mapping is XCD-aware so horizontally adjacent tiles (which share 128-B source lines) hit
-// the same L2.
+// This kernel fuses everything and computes the ego row only.  One workgroup owns an 8x8 tile of output pixels and
+// ALL channels of ALL agents of the frame; thread = (pixel = tid & 63, channel group g = tid >> 6), CPT channels each.
+//
+//  phase 0  the sampling geometry (float64 grid -> float32 coords -> top-left tap + 4 bilinear weights) is computed
+//           ONCE per (pixel, agent) -- the waves split the agents -- and parked in LDS together with the bounding box
+//           of the tile's footprint in the source plane (wave min/max reduction).
+//  phase 1  LDS-staged gather.  For a rigid pose (rotation + translation at unit scale, what normalize_pairwise_tfm
+//           produces) the footprint of an 8x8 tile fits a 16x16 source patch for ANY yaw.  Per (agent, channel) a wave
+//           loads that patch with ONE coalesced 16 B/lane load (lane -> row = lane>>2, 4 floats at col 4*(lane&3);
+//           out-of-image lanes contribute zeros = grid_sample's zero padding), writes it to a wave-private LDS slab
+//           (row stride 24 floats: conflict-free for axis-aligned reads) and every pixel fetches its 4 taps with two
+//           ds_read2_b32.  v1 issued four dword gathers per value through the texture-address path (4 lanes/clk);
+//           this is one 16 B/lane load per 64 values.  The warped values stay in REGISTERS (X[NA][CPT]).
+//  phase 2  <X0, Xn> partials cross the waves through LDS (G x N x 64 floats), softmax over the agents and the
+//           weighted sum are per-thread; max / none modes skip the reduction.
+//  fallback non-rigid theta (footprint larger than the patch), W % 4 != 0 or unaligned planes: the same workgroup
+//           takes a generic two-pass direct-gather route (no register-resident X, clamped taps).
+//
+// The QK^T / AV contractions are per-pixel dot products of *different* vectors for every pixel (a batch of 1xC . CxN
+// GEMVs, N <= 8, no operand shared between pixels): there is no tile to feed an MFMA with and the f32 MFMA rate equals
+// the f32 VALU rate on gfx950, so they are lane-local FMAs on registers; the kernel is bound by the gather.
+// Workgroup -> tile order is XCD-aware so neighbouring tiles (which share source lines) share an L2.
 #include "common.h"
 
 namespace {
 
+constexpr int kPatchRows = 16;
+constexpr int kPatchStride = 24;                        // floats per patch row (16 used), keeps 16 B alignment
+constexpr int kPatchFloats = kPatchRows * kPatchStride;  // 384 floats = 1.5 KB per wave
+
 struct WarpArgs {
-    const float *x;       // [NA, C, H, W] of this frame
-    const double *theta;  // [NA, 2, 3]
-    float *out;           // ATT/MAX: [C, Ho, Wo]; NONE: [NA, C, Ho, Wo]
-    int n, C, H, W, Ho, Wo, tiles_x, ntiles, mode;
+    const float *x;       // [n, C, H, W] of this frame
+    const double *theta;  // [n, 2, 3]
+    float *out;           // ATT/MAX: [C, Ho, Wo]; NONE: [n, C, Ho, Wo]
+    int n, C, H, W, Ho, Wo, tiles_x, ntiles, mode, vec_ok;
     float sqrt_dim;
 };
 
-template <int NA>
-struct Taps {
-    int o00[NA], dx[NA], dy[NA];  // clamped top-left offset and the +x / +y steps (0 when clamped)
-    float w00[NA], w01[NA], w10[NA], w11[NA];
+struct Tap {       // per (agent, pixel), parked in LDS
+    int idx;       // staged: patch-relative index of the top-left tap
+    float w00, w01, w10, w11;
 };
 
-template <int NA>
-__device__ __forceinline__ void setup_taps(const WarpArgs &a, int ox, int oy, bool pix_ok, Taps<NA> &t) {
-    // F.affine_grid(theta_f64, align_corners=False): x_n = (2j+1)/W - 1 evaluated in float64, then .to(float32)
+struct Origin {    // per agent, wave-uniform
+    int ax0, py0, fit;
+};
+
+// grid_sample coordinates of output pixel (ox, oy) in agent n's plane, reference arithmetic:
+// F.affine_grid on a float64 theta (x_n = (2j+1)/W - 1 in float64) -> .to(float32) -> (g + 1) * (size / 2) - 0.5
+__device__ __forceinline__ void sample_coords(const WarpArgs &a, int n, int ox, int oy, float &ix, float &iy) {
     const double xn = (2.0 * ox + 1.0) / a.Wo - 1.0;
     const double yn = (2.0 * oy + 1.0) / a.Ho - 1.0;
-    const float half_w = (float)a.W / 2, half_h = (float)a.H / 2;
+    const double *th = a.theta + n * 6;
+    const float gx = (float)(th[0] * xn + th[1] * yn + th[2]);
+    const float gy = (float)(th[3] * xn + th[4] * yn + th[5]);
+    ix = (gx + 1.f) * ((float)a.W / 2) - 0.5f;
+    iy = (gy + 1.f) * ((float)a.H / 2) - 0.5f;
+}
+
+__device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
-    for (int n = 0; n < NA; ++n) {
-        t.o00[n] = 0; t.dx[n] = 0; t.dy[n] = 0;
-        t.w00[n] = t.w01[n] = t.w10[n] = t.w11[n] = 0.f;
-        if (n < a.n && pix_ok) {
-            const double *th = a.theta + n * 6;
-            const float gx = (float)(th[0] * xn + th[1] * yn + th[2]);
-            const float gy = (float)(th[3] * xn + th[4] * yn + th[5]);
-            // grid_sample un-normalisation, align_corners=False (CPU kernel form)
-            const float ix = (gx + 1.f) * half_w - 0.5f;
-            const float iy = (gy + 1.f) * half_h - 0.5f;
-            if (ix > -1.f && ix < (float)a.W && iy > -1.f && iy < (float)a.H) {
-                const float x0f = floorf(ix), y0f = floorf(iy);
-                const float tx = ix - x0f, ty = iy - y0f;
-                const float ex = 1.f - tx, ey = 1.f - ty;
-                const int x0 = (int)x0f, y0 = (int)y0f;
-                const bool vx0 = x0 >= 0, vx1 = x0 + 1 <= a.W - 1, vy0 = y0 >= 0, vy1 = y0 + 1 <= a.H - 1;
-                t.w00[n] = (vx0 && vy0) ? ey * ex : 0.f;
-                t.w01[n] = (vx1 && vy0) ? ey * tx : 0.f;
-                t.w10[n] = (vx0 && vy1) ? ty * ex : 0.f;
-                t.w11[n] = (vx1 && vy1) ? ty * tx : 0.f;
-                const int xc0 = vx0 ? x0 : 0, yc0 = vy0 ? y0 : 0;
-                const int xc1 = vx1 ? x0 + 1 : a.W - 1, yc1 = vy1 ? y0 + 1 : a.H - 1;
-                t.o00[n] = yc0 * a.W + xc0;
-                t.dx[n] = xc1 - xc0;
-                t.dy[n] = (yc1 - yc0) * a.W;
-            }
-        }
-    }
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+// direct (un-staged) bilinear sample with clamped addresses and masked weights -- the generic fallback
+__device__ __forceinline__ float sample_direct(const WarpArgs &a, const float *__restrict__ plane, float ix, float iy) {
+    if (!(ix > -1.f && ix < (float)a.W && iy > -1.f && iy < (float)a.H)) return 0.f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float tx = ix - x0f, ty = iy - y0f, ex = 1.f - tx, ey = 1.f - ty;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const bool vx0 = x0 >= 0, vx1 = x0 + 1 <= a.W - 1, vy0 = y0 >= 0, vy1 = y0 + 1 <= a.H - 1;
+    const int xc0 = vx0 ? x0 : 0, yc0 = vy0 ? y0 : 0, xc1 = vx1 ? x0 + 1 : a.W - 1, yc1 = vy1 ? y0 + 1 : a.H - 1;
+    const float v00 = plane[yc0 * a.W + xc0], v01 = plane[yc0 * a.W + xc1];
+    const float v10 = plane[yc1 * a.W + xc0], v11 = plane[yc1 * a.W + xc1];
+    const float w00 = (vx0 && vy0) ? ey * ex : 0.f, w01 = (vx1 && vy0) ? ey * tx : 0.f;
+    const float w10 = (vx0 && vy1) ? ty * ex : 0.f, w11 = (vx1 && vy1) ? ty * tx : 0.f;
+    return v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
 }
 
 template <int NA>
-__device__ __forceinline__ float sample(const float *__restrict__ plane, const Taps<NA> &t, int n) {
-    const float *p = plane + t.o00[n];
-    const float v00 = p[0], v01 = p[t.dx[n]], v10 = p[t.dy[n]], v11 = p[t.dy[n] + t.dx[n]];
-    return v00 * t.w00[n] + v01 * t.w01[n] + v10 * t.w10[n] + v11 * t.w11[n];
-}
-
-template <int NA, int CPT, bool KEEP, int MAXT>
-__global__ __launch_bounds__(MAXT) void warp_fuse_kernel(WarpArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [G][NA][64]
-    const int tile = coalign::xcd_remap(blockIdx.x, a.ntiles);
-    const int px = threadIdx.x & 63, g = threadIdx.x >> 6, G = blockDim.x >> 6;
-    const int oy = (tile / a.tiles_x) * 8 + (px >> 3), ox = (tile % a.tiles_x) * 8 + (px & 7);
-    const bool pix_ok = oy < a.Ho && ox < a.Wo;
-    const int HW = a.H * a.W;
-    const size_t HWo = (size_t)a.Ho * a.Wo;
-    const int c_base = g * CPT;
-
-    Taps<NA> t;
-    setup_taps<NA>(a, ox, oy, pix_ok, t);
-
-    if (a.mode != COALIGN_FUSE_ATT) {  // max / none: no cross-channel dependency -> stream the channels
-        for (int k = 0; k < CPT; ++k) {
-            const int c = c_base + k;
-            if (c >= a.C) break;
-            float m = -INFINITY;
-#pragma unroll
-            for (int n = 0; n < NA; ++n) {
-                if (n < a.n) {
-                    const float v = sample<NA>(a.x + ((size_t)n * a.C + c) * HW, t, n);
-                    if (a.mode == COALIGN_FUSE_NONE) {
-                        if (pix_ok) a.out[((size_t)n * a.C + c) * HWo + (size_t)oy * a.Wo + ox] = v;
-                    } else {
-                        m = fmaxf(m, v);
-                    }
-                }
-            }
-            if (a.mode == COALIGN_FUSE_MAX && pix_ok) a.out[(size_t)c * HWo + (size_t)oy * a.Wo + ox] = m;
-        }
-        return;
-    }
-
-    float X[KEEP ? NA : 1][KEEP ? CPT : 1];
-    float part[NA];
-#pragma unroll
-    for (int n = 0; n < NA; ++n) part[n] = 0.f;
-
-#pragma unroll(KEEP ? CPT : 1)
-    for (int k = 0; k < CPT; ++k) {
-        const int c = c_base + k;
-        float v[NA];
-#pragma unroll
-        for (int n = 0; n < NA; ++n) {
-            v[n] = 0.f;
-            if (n < a.n && c < a.C) v[n] = sample<NA>(a.x + ((size_t)n * a.C + c) * HW, t, n);
-            if constexpr (KEEP) X[n][k] = v[n];
-        }
-#pragma unroll
-        for (int n = 0; n < NA; ++n) part[n] = fmaf(v[0], v[n], part[n]);
-    }
-
-#pragma unroll
-    for (int n = 0; n < NA; ++n) red[(g * NA + n) * 64 + px] = part[n];
-    __syncthreads();
-
-    // scores of the ego row, softmax over the frame's agents (att_fuse.py:43-47)
-    float s[NA], smax = -INFINITY;
+__device__ __forceinline__ void softmax_weights(const WarpArgs &a, const float *red, int G, int px, float (&s)[NA]) {
+    float smax = -INFINITY;
 #pragma unroll
     for (int n = 0; n < NA; ++n) {
         float acc = 0.f;
         for (int gg = 0; gg < G; ++gg) acc += red[(gg * NA + n) * 64 + px];
-        s[n] = acc / a.sqrt_dim;
+        s[n] = acc / a.sqrt_dim;                      // score / np.sqrt(C)   (att_fuse.py:44)
         if (n < a.n) smax = fmaxf(smax, s[n]);
     }
     float den = 0.f;
@@ -156,44 +108,285 @@ __global__ __launch_bounds__(MAXT) void warp_fuse_kernel(WarpArgs a) {
     }
 #pragma unroll
     for (int n = 0; n < NA; ++n) s[n] = s[n] / den;
+}
 
-#pragma unroll(KEEP ? CPT : 1)
-    for (int k = 0; k < CPT; ++k) {
-        const int c = c_base + k;
-        float o = 0.f;
+template <int NA, int CPT, bool KEEP, int MAXT, int PD>
+__global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && NA <= 5 && MAXT <= 512) ? 5 : 4)) void warp_fuse_kernel(WarpArgs a) {   // waves / SIMD the register allocation must allow
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int px = threadIdx.x & 63, g = threadIdx.x >> 6, G = blockDim.x >> 6;
+    // LDS carve: [G][kPatchFloats] patches | [G][NA][64] score partials | [NA][64] taps | [NA] origins
+    float *patch = smem + (size_t)g * kPatchFloats;
+    float *red = smem + (size_t)G * kPatchFloats;
+    Tap *taps = reinterpret_cast<Tap *>(red + (size_t)G * NA * 64);
+    Origin *origins = reinterpret_cast<Origin *>(taps + NA * 64);
+
+    const int tile = coalign::xcd_remap(blockIdx.x, a.ntiles);
+    const int oy = (tile / a.tiles_x) * 8 + (px >> 3), ox = (tile % a.tiles_x) * 8 + (px & 7);
+    const bool pix_ok = oy < a.Ho && ox < a.Wo;
+    const int HW = a.H * a.W;
+    const size_t HWo = (size_t)a.Ho * a.Wo;
+    const int c_base = g * CPT;
+    const size_t opix = (size_t)oy * a.Wo + ox;
+
+    // ---------------------------------------------------------------- phase 0: taps + footprint per agent
+    for (int n = g; n < a.n; n += G) {
+        Tap t;
+        t.idx = 0; t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
+        int x0 = 0, y0 = 0;
+        bool live = false;
+        if (pix_ok) {
+            float ix, iy;
+            sample_coords(a, n, ox, oy, ix, iy);
+            if (ix > -1.f && ix < (float)a.W && iy > -1.f && iy < (float)a.H) {
+                const float x0f = floorf(ix), y0f = floorf(iy);
+                const float tx = ix - x0f, ty = iy - y0f, ex = 1.f - tx, ey = 1.f - ty;
+                x0 = (int)x0f; y0 = (int)y0f;
+                t.w00 = ey * ex; t.w01 = ey * tx; t.w10 = ty * ex; t.w11 = ty * tx;
+                live = true;
+            }
+        }
+        const int big = 1 << 28;
+        const int xmin = wave_min(live ? x0 : big), xmax = wave_max(live ? x0 + 1 : -big);
+        const int ymin = wave_min(live ? y0 : big), ymax = wave_max(live ? y0 + 1 : -big);
+        Origin o;
+        o.ax0 = 0; o.py0 = 0; o.fit = 1;
+        if (xmin != big) {
+            o.ax0 = (xmin >> 2) << 2;                  // floor to a multiple of 4 (also for -1)
+            o.py0 = ymin;
+            o.fit = (xmax - o.ax0 < 16) && (ymax - ymin < kPatchRows);
+        }
+        if (live && o.fit) t.idx = (y0 - o.py0) * kPatchStride + (x0 - o.ax0);   // else: weights 0 or fallback route
+        taps[n * 64 + px] = t;
+        if (px == 0) origins[n] = o;
+    }
+    __syncthreads();
+    bool fast = a.vec_ok != 0;
+    for (int n = 0; n < a.n; ++n) fast = fast && origins[n].fit;
+
+    if (fast) {
+        // ------------------------------------------------------------ phase 1: LDS-staged gather
+        // Work items j = (agent n, channel k) are walked in order with a rolling prefetch ring: the 16 B/lane patch
+        // load of item j + D is issued when item j is consumed, so every wave keeps D loads (D KB) in flight -- the
+        // kernel is latency bound otherwise (PMC: 79 % of wave cycles waiting on vmcnt with 4 loads in flight).
+        constexpr int D = PD;                             // prefetch distance (patch loads in flight per wave)
+        constexpr int ITEMS = NA * CPT;
+        const int prow = px >> 2, pc4 = (px & 3) << 2;   // this lane's slot of the 16x16 patch
+        float4 *pw = reinterpret_cast<float4 *>(patch + prow * kPatchStride + pc4);
+        int goff[NA];                                     // global offset of this lane's patch slot, -1: outside the image
 #pragma unroll
         for (int n = 0; n < NA; ++n) {
-            float v;
-            if constexpr (KEEP) v = X[n][k];
-            else v = (n < a.n && c < a.C) ? sample<NA>(a.x + ((size_t)n * a.C + c) * HW, t, n) : 0.f;
-            o = fmaf(s[n], v, o);
+            goff[n] = -1;
+            if (n < a.n) {
+                const Origin o = origins[n];
+                const int gy = o.py0 + prow, gx = o.ax0 + pc4;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx + 3 < a.W) goff[n] = gy * a.W + gx;
+            }
         }
-        if (pix_ok && c < a.C) a.out[(size_t)c * HWo + (size_t)oy * a.Wo + ox] = o;
+        auto fetch = [&](int n, int k) -> float4 {       // n, k are compile-time after unrolling
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c = c_base + k;
+            if (n < a.n && c < a.C && goff[n] >= 0)
+                v = *reinterpret_cast<const float4 *>(a.x + ((size_t)n * a.C + c) * HW + goff[n]);
+            return v;
+        };
+        auto resample = [&](float4 v, const Tap &t) -> float {   // patch slice -> LDS slab -> this pixel's 4 taps
+            *pw = v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float *pr = patch + t.idx;
+            const float v00 = pr[0], v01 = pr[1], v10 = pr[kPatchStride], v11 = pr[kPatchStride + 1];
+            const float r = v00 * t.w00 + v01 * t.w01 + v10 * t.w10 + v11 * t.w11;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            return r;
+        };
+
+        if constexpr (KEEP) {
+            float X[NA][CPT];                              // warped values stay in registers
+            float4 ring[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) ring[j] = fetch(j / CPT, j % CPT);
+            Tap t = taps[px];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int n = j / CPT, k = j % CPT;
+                if (k == 0 && n > 0 && n < a.n) t = taps[n * 64 + px];
+                const float4 v = ring[j % D];
+                if (j + D < ITEMS) ring[j % D] = fetch((j + D) / CPT, (j + D) % CPT);
+                X[n][k] = (n < a.n && c_base + k < a.C) ? resample(v, t) : 0.f;
+                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch of item j + D inside iteration j
+            }
+            if (a.mode == COALIGN_FUSE_ATT) {
+#pragma unroll
+                for (int n = 0; n < NA; ++n) {
+                    float p = 0.f;
+#pragma unroll
+                    for (int k = 0; k < CPT; ++k) p = fmaf(X[0][k], X[n][k], p);
+                    red[(g * NA + n) * 64 + px] = p;
+                }
+                __syncthreads();
+                float s[NA];
+                softmax_weights<NA>(a, red, G, px, s);
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    const int c = c_base + k;
+                    float o = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NA; ++n) o = fmaf(s[n], X[n][k], o);
+                    if (pix_ok && c < a.C) a.out[(size_t)c * HWo + opix] = o;
+                }
+            } else if (a.mode == COALIGN_FUSE_MAX) {
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    const int c = c_base + k;
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int n = 0; n < NA; ++n)
+                        if (n < a.n) m = fmaxf(m, X[n][k]);
+                    if (pix_ok && c < a.C) a.out[(size_t)c * HWo + opix] = m;
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < NA; ++n)
+#pragma unroll
+                    for (int k = 0; k < CPT; ++k) {
+                        const int c = c_base + k;
+                        if (pix_ok && n < a.n && c < a.C) a.out[((size_t)n * a.C + c) * HWo + opix] = X[n][k];
+                    }
+            }
+        } else {
+            // register-light variant for many agents x many channels: only the ego values and the output
+            // accumulators are resident (2 x CPT registers); the staged gather runs twice for the attention mode.
+            float X0[CPT], acc[CPT];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) { X0[k] = 0.f; acc[k] = (a.mode == COALIGN_FUSE_MAX) ? -INFINITY : 0.f; }
+            float s[NA];
+#pragma unroll
+            for (int n = 0; n < NA; ++n) s[n] = 0.f;
+            float4 ring[D];
+            Tap t = taps[px];
+            if (a.mode == COALIGN_FUSE_ATT) {
+                float p = 0.f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) ring[j] = fetch(j / CPT, j % CPT);
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) {
+                    const int n = j / CPT, k = j % CPT;
+                    if (k == 0) { p = 0.f; if (n > 0 && n < a.n) t = taps[n * 64 + px]; }
+                    const float4 v4 = ring[j % D];
+                    if (j + D < ITEMS) ring[j % D] = fetch((j + D) / CPT, (j + D) % CPT);
+                    const float v = (n < a.n && c_base + k < a.C) ? resample(v4, t) : 0.f;
+                    if (n == 0) X0[k] = v;
+                    p = fmaf(X0[k], v, p);
+                    if (k == CPT - 1) red[(g * NA + n) * 64 + px] = p;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();
+                softmax_weights<NA>(a, red, G, px, s);
+                t = taps[px];
+            }
+#pragma unroll
+            for (int j = 0; j < D; ++j) ring[j] = fetch(j / CPT, j % CPT);
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int n = j / CPT, k = j % CPT;
+                if (k == 0 && n > 0 && n < a.n) t = taps[n * 64 + px];
+                const float4 v4 = ring[j % D];
+                if (j + D < ITEMS) ring[j % D] = fetch((j + D) / CPT, (j + D) % CPT);
+                const int c = c_base + k;
+                if (n < a.n && c < a.C) {
+                    const float v = resample(v4, t);
+                    if (a.mode == COALIGN_FUSE_ATT) acc[k] = fmaf(s[n], v, acc[k]);
+                    else if (a.mode == COALIGN_FUSE_MAX) acc[k] = fmaxf(acc[k], v);
+                    else if (pix_ok) a.out[((size_t)n * a.C + c) * HWo + opix] = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (a.mode != COALIGN_FUSE_NONE) {
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    const int c = c_base + k;
+                    if (pix_ok && c < a.C) a.out[(size_t)c * HWo + opix] = acc[k];
+                }
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- generic fallback: direct gather, two passes
+    float ixs[NA], iys[NA];
+#pragma unroll
+    for (int n = 0; n < NA; ++n) {
+        ixs[n] = -2.f; iys[n] = -2.f;
+        if (n < a.n && pix_ok) sample_coords(a, n, ox, oy, ixs[n], iys[n]);
+    }
+    float s[NA];
+    if (a.mode == COALIGN_FUSE_ATT) {
+        float part[NA];
+#pragma unroll
+        for (int n = 0; n < NA; ++n) part[n] = 0.f;
+        for (int k = 0; k < CPT; ++k) {
+            const int c = c_base + k;
+            if (c >= a.C) break;
+            const float v0 = sample_direct(a, a.x + (size_t)c * HW, ixs[0], iys[0]);
+#pragma unroll
+            for (int n = 0; n < NA; ++n) {
+                if (n < a.n) {
+                    const float v = n == 0 ? v0 : sample_direct(a, a.x + ((size_t)n * a.C + c) * HW, ixs[n], iys[n]);
+                    part[n] = fmaf(v0, v, part[n]);
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NA; ++n) red[(g * NA + n) * 64 + px] = part[n];
+        __syncthreads();
+        softmax_weights<NA>(a, red, G, px, s);
+    }
+    for (int k = 0; k < CPT; ++k) {
+        const int c = c_base + k;
+        if (c >= a.C) break;
+        float o = 0.f, m = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < NA; ++n) {
+            if (n < a.n) {
+                const float v = sample_direct(a, a.x + ((size_t)n * a.C + c) * HW, ixs[n], iys[n]);
+                if (a.mode == COALIGN_FUSE_ATT) o = fmaf(s[n], v, o);
+                else if (a.mode == COALIGN_FUSE_MAX) m = fmaxf(m, v);
+                else if (pix_ok) a.out[((size_t)n * a.C + c) * HWo + opix] = v;
+            }
+        }
+        if (pix_ok && a.mode == COALIGN_FUSE_ATT) a.out[(size_t)c * HWo + opix] = o;
+        if (pix_ok && a.mode == COALIGN_FUSE_MAX) a.out[(size_t)c * HWo + opix] = m;
     }
 }
 
-template <int NA, int CPT, bool KEEP, int MAXT>
+template <int NA, int CPT, bool KEEP, int MAXT, int PD>
 int launch(const WarpArgs &a, int G, hipStream_t stream) {
-    const size_t lds = (size_t)G * NA * 64 * sizeof(float);
-    hipLaunchKernelGGL((warp_fuse_kernel<NA, CPT, KEEP, MAXT>), dim3(a.ntiles), dim3(G * 64), lds, stream, a);
+    const size_t lds = ((size_t)G * kPatchFloats + (size_t)G * NA * 64) * sizeof(float) + (size_t)NA * 64 * sizeof(Tap) +
+                       (size_t)NA * sizeof(Origin);
+    hipLaunchKernelGGL((warp_fuse_kernel<NA, CPT, KEEP, MAXT, PD>), dim3(a.ntiles), dim3(G * 64), lds, stream, a);
     return coalign::check_launch();
 }
 
-// Channels-per-thread / register residency are picked from the register budget the block size leaves per
-// thread (512-entry file per SIMD lane / waves per SIMD): 4 waves -> 512, 8 -> 256, 16 -> 128.
+// Channels per thread: 8 while that keeps the block within 16 waves (more, smaller waves = more loads in flight and a
+// finer spread over the 256 CUs), 16 above.  The register-resident variant (KEEP) needs NA * CPT registers for the
+// warped values plus the prefetch ring, so it is used while that fits the per-thread budget the block size leaves
+// (512-entry file per SIMD lane / waves per SIMD: <= 4 waves -> 512, 8 -> 256, 16 -> 128); otherwise two-pass.
 template <int NA>
 int dispatch(const WarpArgs &a, hipStream_t stream) {
-    const int G16 = (a.C + 15) / 16;
-    if (G16 <= 4) return launch<NA, 16, true, 256>(a, G16, stream);
-    if (G16 <= 8) return launch<NA, 16, true, 512>(a, G16, stream);
+    const int G8 = (a.C + 7) / 8, G16 = (a.C + 15) / 16;
     if (G16 > 16) return COALIGN_ERR_UNSUPPORTED;
-    if constexpr (NA <= 3) {
-        return launch<NA, 16, true, 1024>(a, G16, stream);
-    } else if constexpr (NA <= 5) {
-        return launch<NA, 32, true, 512>(a, (a.C + 31) / 32, stream);
-    } else {
-        return launch<NA, 32, false, 512>(a, (a.C + 31) / 32, stream);  // two-pass: scores first, recompute for the output
+    if (G8 <= 8) {
+        if constexpr (NA <= 5) return launch<NA, 8, true, 512, 8>(a, G8, stream);
+        else return launch<NA, 8, true, 512, 4>(a, G8, stream);
     }
+    if (G8 <= 16) {
+        if constexpr (NA <= 5) return launch<NA, 8, true, 1024, 8>(a, G8, stream);
+        else return launch<NA, 8, true, 1024, 4>(a, G8, stream);
+    }
+    if constexpr (NA <= 3) return launch<NA, 16, true, 1024, 8>(a, G16, stream);
+    else if constexpr (NA <= 5) return launch<NA, 16, true, 1024, 4>(a, G16, stream);
+    else return launch<NA, 16, false, 1024, 4>(a, G16, stream);
 }
 
 }  // namespace
@@ -221,6 +414,7 @@ extern "C" int coalign_warp_fuse(const float *x, int n_total, int C, int H, int 
     a.tiles_x = (Wo + 7) / 8;
     a.ntiles = a.tiles_x * ((Ho + 7) / 8);
     a.sqrt_dim = (float)sqrt((double)C);
+    a.vec_ok = (W % 4 == 0) && (((uintptr_t)x & 15) == 0);   // 16 B patch loads need aligned rows
     int off = 0;
     for (int b = 0; b < n_groups; ++b) {
         const int n = group_len[b];

@@ -12,10 +12,33 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .backbone import BaseBEVBackbone, DownsampleConv, NaiveCompressor, ResNetBEVBackbone
+import torch.nn.functional as F
+
+from . import ops
+from .backbone import BaseBEVBackbone, DownsampleConv, NaiveCompressor, ResNetBEVBackbone, _cache_of, _fast_ok
 from .encoder import PillarVFE, PointPillarScatter, host_ints
 from .fusion import AttFusion, MaxFusion
 from .pose import normalize_pairwise_tfm
+
+
+def _run_heads(model: nn.Module, x: torch.Tensor) -> dict:
+    """cls / reg / dir 1x1 heads.  Inference fast path: one convolution with the concatenated head weights (+ one fused
+    bias pass) instead of three convolutions and three bias kernels; the outputs are channel slices of one tensor."""
+    heads = [("cls_preds", model.cls_head), ("reg_preds", model.reg_head)]
+    if model.use_dir:
+        heads.append(("dir_preds", model.dir_head))
+    if not _fast_ok(model, x):
+        return {k: h(x) for k, h in heads}
+
+    def build():
+        return (torch.cat([h.weight for _, h in heads]).contiguous(), torch.cat([h.bias for _, h in heads]).contiguous())
+    w, b = _cache_of(model.cls_head).get([t for _, h in heads for t in (h.weight, h.bias)], build)
+    y = ops.bias_act_(F.conv2d(x, w, None), b, None, False)
+    out, c0 = {}, 0
+    for k, h in heads:
+        out[k] = y[:, c0:c0 + h.out_channels]
+        c0 += h.out_channels
+    return out
 
 
 class PointPillarBaselineMultiscale(nn.Module):
@@ -82,10 +105,7 @@ class PointPillarBaselineMultiscale(nn.Module):
         x = self.backbone.decode_multiscale_feature(fused)
         if self.shrink_flag:
             x = self.shrink_conv(x)
-        out = {"cls_preds": self.cls_head(x), "reg_preds": self.reg_head(x)}
-        if self.use_dir:
-            out["dir_preds"] = self.dir_head(x)
-        return out
+        return _run_heads(self, x)
 
     def forward(self, data_dict: dict) -> dict:
         record_len = host_ints(data_dict["record_len"])
@@ -126,10 +146,7 @@ class PointPillar(nn.Module):
         x = batch_dict["spatial_features_2d"]
         if self.shrink_flag:
             x = self.shrink_conv(x)
-        out = {"cls_preds": self.cls_head(x), "reg_preds": self.reg_head(x)}
-        if self.use_dir:
-            out["dir_preds"] = self.dir_head(x)
-        return out
+        return _run_heads(self, x)
 
 
 MODEL_REGISTRY = {

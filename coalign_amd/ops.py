@@ -21,6 +21,11 @@ FUSE_ATT, FUSE_MAX, FUSE_NONE = 0, 1, 2
 PROFILE = None
 
 
+def timed(name: str):
+    """Bracket a region with HIP events when ``PROFILE`` is active (used by bench.py for the per-stage breakdown)."""
+    return _Timed(name)
+
+
 class _Timed:
     def __init__(self, name: str):
         self.name = name
@@ -215,3 +220,16 @@ def boxes_iou_bev(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Tensor:
     out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
     hip.check(L.coalign_boxes_iou_bev(_ptr(a), a.shape[0], _ptr(b), b.shape[0], _ptr(out), _stream()), "coalign_boxes_iou_bev")
     return out
+
+
+def bias_act_(y: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None, relu: bool = True) -> torch.Tensor:
+    """In place ``y = act(y + bias[c] (+ residual))`` on a contiguous NCHW float32 tensor (fused conv epilogue)."""
+    _need_gpu(y, bias, residual)
+    if y.dtype != torch.float32 or not y.is_contiguous():
+        raise ValueError("bias_act_ needs a contiguous float32 NCHW tensor")
+    if residual is not None and (residual.shape != y.shape or not residual.is_contiguous() or residual.dtype != torch.float32):
+        raise ValueError("residual must match y (contiguous float32)")
+    N, C = y.shape[0], y.shape[1]
+    HW = y.numel() // max(1, N * C)
+    hip.check(hip.lib().coalign_bias_act(_ptr(y), _ptr(bias), _ptr(residual), N, C, HW, int(relu), _stream()), "coalign_bias_act")
+    return y

@@ -75,8 +75,15 @@ class FrameRing:
         for f, sz in zip(feats, sizes):          # pack: destination-major rows, scales side by side
             self._send[:, off:off + sz] = f.reshape(self.n, sz).index_select(0, idx)
             off += sz
-        dist.all_to_all_single(self._recv, self._send, output_split_sizes=self.recv_counts,
-                               input_split_sizes=self.send_counts, group=self.group)
+        if self._send.is_cuda and dist.get_backend(self.group) == "gloo":
+            # functional-test route only (two ranks sharing one GPU cannot use RCCL): stage through host memory
+            recv = torch.empty(self._recv.shape, dtype=dt)
+            dist.all_to_all_single(recv, self._send.cpu(), output_split_sizes=self.recv_counts,
+                                   input_split_sizes=self.send_counts, group=self.group)
+            self._recv.copy_(recv)
+        else:
+            dist.all_to_all_single(self._recv, self._send, output_split_sizes=self.recv_counts,
+                                   input_split_sizes=self.send_counts, group=self.group)
         inv = torch.empty(self.n, dtype=torch.long)
         for slot, a in enumerate(self.recv_agents):
             inv[a] = slot

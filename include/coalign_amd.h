@@ -153,6 +153,15 @@ int coalign_gather_in_range(const float *corners, const float *scores, const int
  */
 int coalign_boxes_iou_bev(const float *boxes_a, int Na, const float *boxes_b, int Nb, float *iou, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * (6) Fused convolution epilogue for the dense stages (rows E / I): in place  y = act(y + bias[c] (+ residual)).
+ *     With eval-mode BatchNorm folded into the convolution weights on the host, this one pass replaces the
+ *     BatchNorm2d / ReLU / residual-add kernels of BasicBlock.forward (opencood/models/sub_modules/resblock.py:53-69),
+ *     of the deblocks (base_bev_backbone_resnet.py:121-138) and the bias + ReLU of DoubleConv (downsample_conv.py:7-27).
+ * y [N, C, HW] in/out, bias [C] or NULL, residual [N, C, HW] or NULL, relu 0/1.
+ */
+int coalign_bias_act(float *y, const float *bias, const float *residual, int N, int C, int HW, int relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
