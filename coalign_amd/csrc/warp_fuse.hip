@@ -48,8 +48,8 @@ struct Tap {       // per (agent, pixel), parked in LDS
     float w00, w01, w10, w11;
 };
 
-struct Origin {    // per agent, wave-uniform
-    int ax0, py0, fit;
+struct Origin {    // per agent, wave-uniform: patch origin (x aligned to 4), used extent, fits-the-slab flag
+    int ax0, py0, nc4, nrows, fit;
 };
 
 // grid_sample coordinates of output pixel (ox, oy) in agent n's plane, reference arithmetic:
@@ -149,11 +149,13 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
         const int xmin = wave_min(live ? x0 : big), xmax = wave_max(live ? x0 + 1 : -big);
         const int ymin = wave_min(live ? y0 : big), ymax = wave_max(live ? y0 + 1 : -big);
         Origin o;
-        o.ax0 = 0; o.py0 = 0; o.fit = 1;
+        o.ax0 = 0; o.py0 = 0; o.nc4 = 1; o.nrows = 0; o.fit = 1;
         if (xmin != big) {
             o.ax0 = (xmin >> 2) << 2;                  // floor to a multiple of 4 (also for -1)
             o.py0 = ymin;
-            o.fit = (xmax - o.ax0 < 16) && (ymax - ymin < kPatchRows);
+            o.nc4 = ((xmax - o.ax0) >> 2) + 1;         // float4 columns actually touched (1..4 when it fits)
+            o.nrows = ymax - ymin + 1;
+            o.fit = (o.nc4 <= 4) && (o.nrows <= kPatchRows);
         }
         if (live && o.fit) t.idx = (y0 - o.py0) * kPatchStride + (x0 - o.ax0);   // else: weights 0 or fallback route
         taps[n * 64 + px] = t;
@@ -170,16 +172,22 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
         // kernel is latency bound otherwise (PMC: 79 % of wave cycles waiting on vmcnt with 4 loads in flight).
         constexpr int D = PD;                             // prefetch distance (patch loads in flight per wave)
         constexpr int ITEMS = NA * CPT;
-        const int prow = px >> 2, pc4 = (px & 3) << 2;   // this lane's slot of the 16x16 patch
-        float4 *pw = reinterpret_cast<float4 *>(patch + prow * kPatchStride + pc4);
-        int goff[NA];                                     // global offset of this lane's patch slot, -1: outside the image
+        // Only the bounding box of the tile's footprint is fetched: the lanes are laid over it row-major with nc4
+        // float4 per row (nc4 * nrows <= 64 lanes), the rest of the wave issues nothing.
+        int goff[NA];   // global offset of this lane's patch slot; -1: inside the box but outside the image (zeros)
+        int loff[NA];   // LDS offset (floats) of the slot; -1: lane not part of this agent's box
 #pragma unroll
         for (int n = 0; n < NA; ++n) {
-            goff[n] = -1;
+            goff[n] = -1; loff[n] = -1;
             if (n < a.n) {
                 const Origin o = origins[n];
-                const int gy = o.py0 + prow, gx = o.ax0 + pc4;
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx + 3 < a.W) goff[n] = gy * a.W + gx;
+                const int prow = (o.nc4 == 4) ? (px >> 2) : (o.nc4 == 3) ? (px * 43 >> 7) : (o.nc4 == 2) ? (px >> 1) : px;
+                const int pc4 = (px - prow * o.nc4) << 2;
+                if (prow < o.nrows) {
+                    loff[n] = prow * kPatchStride + pc4;
+                    const int gy = o.py0 + prow, gx = o.ax0 + pc4;
+                    if (gy >= 0 && gy < a.H && gx >= 0 && gx + 3 < a.W) goff[n] = gy * a.W + gx;
+                }
             }
         }
         auto fetch = [&](int n, int k) -> float4 {       // n, k are compile-time after unrolling
@@ -189,8 +197,8 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
                 v = *reinterpret_cast<const float4 *>(a.x + ((size_t)n * a.C + c) * HW + goff[n]);
             return v;
         };
-        auto resample = [&](float4 v, const Tap &t) -> float {   // patch slice -> LDS slab -> this pixel's 4 taps
-            *pw = v;
+        auto resample = [&](float4 v, const Tap &t, int lo) -> float {   // patch slice -> LDS slab -> this pixel's 4 taps
+            if (lo >= 0) *reinterpret_cast<float4 *>(patch + lo) = v;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const float *pr = patch + t.idx;
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
                 if (k == 0 && n > 0 && n < a.n) t = taps[n * 64 + px];
                 const float4 v = ring[j % D];
                 if (j + D < ITEMS) ring[j % D] = fetch((j + D) / CPT, (j + D) % CPT);
-                X[n][k] = (n < a.n && c_base + k < a.C) ? resample(v, t) : 0.f;
+                X[n][k] = (n < a.n && c_base + k < a.C) ? resample(v, t, loff[n]) : 0.f;
                 __builtin_amdgcn_sched_barrier(0);   // keep the prefetch of item j + D inside iteration j
             }
             if (a.mode == COALIGN_FUSE_ATT) {
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
                     if (k == 0) { p = 0.f; if (n > 0 && n < a.n) t = taps[n * 64 + px]; }
                     const float4 v4 = ring[j % D];
                     if (j + D < ITEMS) ring[j % D] = fetch((j + D) / CPT, (j + D) % CPT);
-                    const float v = (n < a.n && c_base + k < a.C) ? resample(v4, t) : 0.f;
+                    const float v = (n < a.n && c_base + k < a.C) ? resample(v4, t, loff[n]) : 0.f;
                     if (n == 0) X0[k] = v;
                     p = fmaf(X0[k], v, p);
                     if (k == CPT - 1) red[(g * NA + n) * 64 + px] = p;
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
                 if (j + D < ITEMS) ring[j % D] = fetch((j + D) / CPT, (j + D) % CPT);
                 const int c = c_base + k;
                 if (n < a.n && c < a.C) {
-                    const float v = resample(v4, t);
+                    const float v = resample(v4, t, loff[n]);
                     if (a.mode == COALIGN_FUSE_ATT) acc[k] = fmaf(s[n], v, acc[k]);
                     else if (a.mode == COALIGN_FUSE_MAX) acc[k] = fmaxf(acc[k], v);
                     else if (pix_ok) a.out[((size_t)n * a.C + c) * HWo + opix] = v;

@@ -153,6 +153,7 @@ class DecodeBuffers:
         self.out_corners = torch.empty((top, 8, 3), dtype=torch.float32, device=device)
         self.out_scores = torch.empty(top, dtype=torch.float32, device=device)
         self.out_count = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(4, dtype=torch.int32).pin_memory()   # (final, candidates, kept, status) of the last frame
 
 
 def anchor_decode(buf: DecodeBuffers, slot: int, cls: torch.Tensor, reg: torch.Tensor, dir_: Optional[torch.Tensor],

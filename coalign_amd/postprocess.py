@@ -34,7 +34,7 @@ class VoxelPostprocessor:
         self.train = train
         self.bbx_dict = {}
         self.anchor_num = self.params["anchor_args"]["num"]
-        self._buffers: Dict[tuple, ops.DecodeBuffers] = {}
+        self._buffers: Dict[tuple, list] = {}
         self._anchor_cache: Dict[tuple, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------------ anchors (host)
@@ -77,6 +77,13 @@ class VoxelPostprocessor:
     def post_process(self, data_dict: dict, output_dict: dict) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
         """-> (pred_box3d [K', 8, 3], scores [K']) on the device, or (None, None) when nothing passes the score
         threshold.  ``data_dict`` holds one entry per cav (only 'ego' for early / intermediate fusion)."""
+        return self.post_process_async(data_dict, output_dict, side_stream=False).result()
+
+    def post_process_async(self, data_dict: dict, output_dict: dict, side_stream: bool = True) -> "PostProcessHandle":
+        """Enqueue decode + NMS + range filter and return immediately.  With ``side_stream`` the kernels run on a
+        second HIP stream (ordered after the head outputs), so the next frame's encoder overlaps these small,
+        latency-bound launches; ``handle.result()`` waits for this frame only.  Two buffer sets rotate, i.e. at most
+        two frames may be in flight."""
         cavs = list(data_dict.keys())
         first = output_dict[cavs[0]]
         cls0 = first["cls_preds"] if "cls_preds" in first else first["psm"]
@@ -84,44 +91,57 @@ class VoxelPostprocessor:
         A, H, W = cls0.shape[-3:]
         capacity = A * H * W * len(cavs)
         key = (str(device), A, H, W, capacity)
-        buf = self._buffers.get(key)
-        if buf is None:
-            buf = self._buffers[key] = ops.DecodeBuffers(capacity, A, H, W, NMS_TOP, device)
+        ring = self._buffers.get(key)
+        if ring is None:
+            ring = self._buffers[key] = [ops.DecodeBuffers(capacity, A, H, W, NMS_TOP, device) for _ in range(2)]
+        self._turn = getattr(self, "_turn", 0) + 1
+        buf = ring[self._turn % 2]
         if len(cavs) + 1 > buf.counts.numel():
             raise ValueError("too many cavs for one post_process call")
-        buf.counts.zero_()
-        buf.status.zero_()
+        main = torch.cuda.current_stream(device)
+        stream = main
+        if side_stream:
+            if getattr(self, "_side", None) is None or self._side.device != device:
+                self._side = torch.cuda.Stream(device=device)
+            stream = self._side
+            stream.wait_stream(main)
         thr = self.params["target_args"]["score_threshold"]
         da = self.params.get("dir_args", {})
-        for slot, cav_id in enumerate(cavs):
-            assert cav_id in output_dict
-            out = output_dict[cav_id]
-            cls = out["cls_preds"] if "cls_preds" in out else out["psm"]
-            reg = out["reg_preds"] if "reg_preds" in out else out["rm"]
-            dirp = out.get("dir_preds", out.get("dm"))
-            if reg.dim() != 4:
-                raise NotImplementedError("anchor-free heads are outside the CoAlign hot path")
-            if "iou_preds" in out:
-                raise NotImplementedError("iou_preds rescoring is outside the CoAlign hot path")
-            content = data_dict[cav_id]
-            T = content["transformation_matrix"]
-            T = torch.as_tensor(T).to(device=device, dtype=torch.float32)
-            anchors = self._anchors_f32(content["anchor_box"], device)
-            ops.anchor_decode(buf, slot, cls, reg, dirp, anchors, thr, da.get("dir_offset", 0.0), da.get("num_bins", 2),
-                              self.params["order"], T)
-        total_dev = buf.counts[len(cavs): len(cavs) + 1]
-        ops.nms_rotated_device(buf.cand_corners, buf.cand_score, self.params["nms_thresh"], NMS_TOP, valid=buf.cand_keep,
-                               k_dev=total_dev, keep=buf.keep, keep_count=buf.keep_count, ws=buf.nms_ws)
-        ops.gather_in_range(buf.cand_corners, buf.cand_score, buf.keep, buf.keep_count, self.params["gt_range"],
-                            buf.out_corners, buf.out_scores, buf.out_count)
-        n_out = int(buf.out_count.item())          # the one host sync of the post-processing
-        n_cand = int(total_dev.item())
-        if int(buf.status.item()) & 1:
-            raise RuntimeError("post_process: candidate buffer overflow")
-        self.last_counts = {"candidates": n_cand, "kept": int(buf.keep_count.item()), "final": n_out}
-        if n_cand == 0:
-            return None, None
-        return buf.out_corners[:n_out].clone(), buf.out_scores[:n_out].clone()
+        with torch.cuda.stream(stream):
+            buf.counts.zero_()
+            buf.status.zero_()
+            for slot, cav_id in enumerate(cavs):
+                assert cav_id in output_dict
+                out = output_dict[cav_id]
+                cls = out["cls_preds"] if "cls_preds" in out else out["psm"]
+                reg = out["reg_preds"] if "reg_preds" in out else out["rm"]
+                dirp = out.get("dir_preds", out.get("dm"))
+                if reg.dim() != 4:
+                    raise NotImplementedError("anchor-free heads are outside the CoAlign hot path")
+                if "iou_preds" in out:
+                    raise NotImplementedError("iou_preds rescoring is outside the CoAlign hot path")
+                content = data_dict[cav_id]
+                T = torch.as_tensor(content["transformation_matrix"]).to(device=device, dtype=torch.float32)
+                anchors = self._anchors_f32(content["anchor_box"], device)
+                if side_stream:                     # keep the head outputs alive until the side stream is done
+                    for t in (cls, reg, dirp):
+                        if t is not None:
+                            t.record_stream(stream)
+                ops.anchor_decode(buf, slot, cls, reg, dirp, anchors, thr, da.get("dir_offset", 0.0), da.get("num_bins", 2),
+                                  self.params["order"], T)
+            total_dev = buf.counts[len(cavs): len(cavs) + 1]
+            ops.nms_rotated_device(buf.cand_corners, buf.cand_score, self.params["nms_thresh"], NMS_TOP, valid=buf.cand_keep,
+                                   k_dev=total_dev, keep=buf.keep, keep_count=buf.keep_count, ws=buf.nms_ws)
+            ops.gather_in_range(buf.cand_corners, buf.cand_score, buf.keep, buf.keep_count, self.params["gt_range"],
+                                buf.out_corners, buf.out_scores, buf.out_count)
+            # the frame's three scalars travel to pinned host memory behind the kernels: one small async copy each
+            buf.host[0:1].copy_(buf.out_count, non_blocking=True)
+            buf.host[1:2].copy_(total_dev, non_blocking=True)
+            buf.host[2:3].copy_(buf.keep_count, non_blocking=True)
+            buf.host[3:4].copy_(buf.status, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(stream)
+        return PostProcessHandle(self, buf, done)
 
     @staticmethod
     def delta_to_boxes3d(deltas: torch.Tensor, anchors: torch.Tensor) -> torch.Tensor:
@@ -136,6 +156,23 @@ class VoxelPostprocessor:
         hwl = torch.exp(d[..., 3:6]) * a[None, :, 3:6]
         yaw = d[..., 6:7] + a[None, :, 6:7]
         return torch.cat([xy, z, hwl, yaw], dim=-1)
+
+
+class PostProcessHandle:
+    """Result of :meth:`VoxelPostprocessor.post_process_async`; ``result()`` performs the frame's only host sync."""
+
+    def __init__(self, owner: VoxelPostprocessor, buf: ops.DecodeBuffers, done: torch.cuda.Event):
+        self.owner, self.buf, self.done = owner, buf, done
+
+    def result(self) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+        self.done.synchronize()
+        n_out, n_cand, n_keep, status = [int(v) for v in self.buf.host.tolist()]
+        if status & 1:
+            raise RuntimeError("post_process: candidate buffer overflow")
+        self.owner.last_counts = {"candidates": n_cand, "kept": n_keep, "final": n_out}
+        if n_cand == 0:
+            return None, None
+        return self.buf.out_corners[:n_out].clone(), self.buf.out_scores[:n_out].clone()
 
 
 def build_postprocessor(anchor_cfg: dict, train: bool) -> VoxelPostprocessor:
