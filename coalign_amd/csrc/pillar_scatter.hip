@@ -15,6 +15,8 @@
 //                  channels, reads the cell map once (16 B), gathers the (rare, 5-6 % occupancy) pillar rows
 //                  and issues 16 B non-temporal stores, so the dominant traffic -- the dense canvas the
 //                  convolution backbone consumes -- is written exactly once, fully coalesced.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -270,6 +272,157 @@ __global__ __launch_bounds__(256) void canvas_kernel(const int *__restrict__ cel
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused encoder + canvas writer (P <= 64, C <= 64): one workgroup owns a strip of 256 consecutive cells of one agent.
+// It looks the strip up in the cell map, runs the PFN for the (few: ~5-6 % occupancy) pillars that live there -- phase A
+// lane = point, phase B lane = channel, exactly as pfn_kernel_p64 -- keeps their 64-float feature rows in LDS and streams
+// the strip's 64 channel rows to the NCHW canvas with 16 B non-temporal stores.  The feature rows never make an HBM
+// round trip, the PFN arithmetic of one workgroup hides behind the stores of the others, and the encoder + scatter is
+// two launches (cell map, this) instead of four.  Pillars that lost their cell (duplicates) or lie outside the canvas
+// still get their pillar_features row: every workgroup also checks a slice of the pillar list for such orphans.
+constexpr int kStrip = 256;      // cells per workgroup
+constexpr int kMaxLds = 64;      // feature rows kept in LDS (a 256-cell strip holds ~15 at LiDAR occupancy); denser strips read the rest back from L2
+
+struct FusedArgs {
+    PfnArgs p;
+    float *canvas;
+    int strips_per_agent, pillars_per_wg;
+};
+
+struct PillarIn { float4 q; int np; int4 cd; };
+
+__device__ __forceinline__ PillarIn pillar_load(const PfnArgs &a, int lane, int m) {
+    PillarIn in;
+    in.q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < a.P) in.q = a.pts[(size_t)m * a.P + lane];
+    in.np = a.npts[m];
+    in.cd = a.coords[m];
+    return in;
+}
+
+__device__ __forceinline__ float pfn_compute(const PfnArgs &a, const ChanParams &cp, float *slab, int lane, const PillarIn &in) {
+    const float4 q = in.q;
+    const int np_raw = in.np;
+    const int4 cd = in.cd;
+    const int np_eff = min(max(np_raw, 0), a.P);
+    const float npf = (float)np_raw;
+    const float mx = wave_sum(q.x) / npf, my = wave_sum(q.y) / npf, mz = wave_sum(q.z) / npf;
+    const float ctr_x = (float)cd.w * a.vx + a.xo;
+    const float ctr_y = (float)cd.z * a.vy + a.yo;
+    const float ctr_z = (float)cd.y * a.vz + a.zo;
+    if (lane < np_eff) stage_point(a, slab, lane, q, mx, my, mz, ctr_x, ctr_y, ctr_z);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float best = (np_eff < a.P) ? cp.shift : -INFINITY;
+    int j = 0;
+    for (; j + 4 <= np_eff; j += 4) {
+        const float y0 = point_response(cp, slab, j), y1 = point_response(cp, slab, j + 1);
+        const float y2 = point_response(cp, slab, j + 2), y3 = point_response(cp, slab, j + 3);
+        best = fmaxf(fmaxf(best, fmaxf(y0, y1)), fmaxf(y2, y3));
+    }
+    for (; j < np_eff; ++j) best = fmaxf(best, point_response(cp, slab, j));
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return fmaxf(best, 0.f);
+}
+
+__device__ __forceinline__ float pfn_one_pillar(const PfnArgs &a, const ChanParams &cp, float *slab, int lane, int m) {
+    return pfn_compute(a, cp, slab, lane, pillar_load(a, lane, m));
+}
+
+__global__ __launch_bounds__(256) void pillar_canvas_kernel(FusedArgs f) {
+    const PfnArgs &a = f.p;
+    __shared__ __attribute__((aligned(16))) float slabs[4 * 64 * kFeatStride];
+    __shared__ __attribute__((aligned(16))) float featbuf[kMaxLds * 64];
+    __shared__ int work_m[kStrip + 64];      // pillar rows to encode: occupied cells first, then orphans
+    __shared__ int slot_of_cell[kStrip];     // cell -> index into work_m / featbuf, -1 = empty
+    __shared__ int n_occ, n_work;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ncell = a.ny * a.nx;
+    const int agent = blockIdx.y;
+    const int cell0 = blockIdx.x * kStrip;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (tid == 0) { n_occ = 0; n_work = 0; }
+    __syncthreads();
+    // ---- occupied cells of the strip (order inside the list is irrelevant: every cell remembers its slot)
+    const int cell = cell0 + tid;
+    const int id = (cell < ncell) ? a.cellmap[(size_t)agent * ncell + cell] : -1;
+    int slot = -1;
+    if (id >= 0) { slot = atomicAdd(&n_occ, 1); work_m[slot] = id; }
+    slot_of_cell[tid] = slot;
+    __syncthreads();
+    const int nocc = n_occ;
+    // ---- PFN for the strip's pillars, wave-strided
+    const ChanParams cp = load_chan(a, lane);
+    float *slab = slabs + wv * 64 * kFeatStride;
+    for (int w = wv; w < nocc; w += 4) {
+        const int m = work_m[w];
+        const float v = pfn_one_pillar(a, cp, slab, lane, m);
+        if (lane < a.C) {
+            a.feats[(size_t)m * a.C + lane] = v;
+            if (w < kMaxLds) featbuf[w * 64 + lane] = v;
+        }
+    }
+    // ---- orphans (duplicate-cell losers, out-of-canvas pillars) in this workgroup's slice of the pillar list,
+    //      64 candidates per round; with well-formed input every round finds none
+    for (int r0 = 0; r0 < f.pillars_per_wg; r0 += 64) {
+        __syncthreads();
+        if (tid == 0) n_work = 0;
+        __syncthreads();
+        if (tid < 64 && r0 + tid < f.pillars_per_wg) {
+            const int m = wg * f.pillars_per_wg + r0 + tid;
+            if (m < a.M) {
+                const int4 cd = a.coords[m];
+                const int c = cd.y + cd.z * a.nx + cd.w;
+                const bool placed = cd.x >= 0 && cd.x < a.n_agents && c >= 0 && c < ncell && a.cellmap[(size_t)cd.x * ncell + c] == m;
+                if (!placed) work_m[kStrip + atomicAdd(&n_work, 1)] = m;
+            }
+        }
+        __syncthreads();
+        const int nw = n_work;
+        for (int w = wv; w < nw; w += 4) {
+            const int m = work_m[kStrip + w];
+            const float v = pfn_one_pillar(a, cp, slab, lane, m);
+            if (lane < a.C) a.feats[(size_t)m * a.C + lane] = v;
+        }
+    }
+    if (nocc > kMaxLds) __threadfence();     // overflow rows are read back from L2 below
+    __syncthreads();
+    // ---- stream the strip: thread = 4 consecutive cells x (C/4) channels, 16 B stores
+    const int q4 = lane * 4;                 // first of this thread's 4 cells inside the strip
+    const int cpw = (a.C + 3) / 4;           // channels per wave
+    const int c_lo = wv * cpw, c_hi = min(a.C, c_lo + cpw);
+    int sl[4];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sl[j] = slot_of_cell[q4 + j]; any |= sl[j] >= 0; }
+    const int gcell = cell0 + q4;
+    if (gcell >= ncell) return;
+    const bool vec = (ncell % 4 == 0);
+    float *dst = f.canvas + ((size_t)agent * a.C + c_lo) * ncell + gcell;
+    for (int c = c_lo; c < c_hi; ++c, dst += ncell) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (any) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (sl[j] >= 0) {
+                    if (sl[j] < kMaxLds) v[j] = featbuf[sl[j] * 64 + c];
+                    else v[j] = __hip_atomic_load(a.feats + (size_t)work_m[sl[j]] * a.C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (vec) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f o = {v[0], v[1], v[2], v[3]};
+            __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(dst));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (gcell + j < ncell) dst[j] = v[j];
+        }
+    }
+}
+
 int launch_canvas(const int *cellmap, const float *feats, int C, int ncell, int n_agents, float *canvas, hipStream_t stream) {
     const int ch_per_block = 16;
     const int ych = (C + ch_per_block - 1) / ch_per_block;
@@ -327,7 +480,19 @@ int coalign_pillar_vfe_scatter(const float *voxel_features, const int32_t *voxel
         a.zo = (float)(voxel_size[2] / 2 + range_min[2]);
         a.n_agents = n_agents; a.ny = ny; a.nx = nx; a.feats = pillar_features; a.cellmap = cellmap;
         const size_t lds = (size_t)kWavesPerBlock * 64 * kFeatStride * sizeof(float);
-        if (P <= 64 && C <= 64) {   // ~4 pillars per wave: enough to amortise the parameter load, prefetch hides the rest
+        if (P <= 64 && C <= 64 && !getenv("COALIGN_UNFUSED_PILLARS")) {
+            // cell map first, then ONE fused encoder + canvas pass
+            hipLaunchKernelGGL(cellmap_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, (const int4 *)voxel_coords, M, n_agents,
+                               ny, nx, cellmap);
+            if ((rc = check_launch())) return rc;
+            FusedArgs f;
+            f.p = a; f.canvas = canvas;
+            f.strips_per_agent = (ncell + kStrip - 1) / kStrip;
+            const long nwg = (long)f.strips_per_agent * n_agents;
+            f.pillars_per_wg = (int)((M + nwg - 1) / nwg);
+            hipLaunchKernelGGL(pillar_canvas_kernel, dim3(f.strips_per_agent, n_agents), dim3(256), 0, stream, f);
+            return check_launch();
+        } else if (P <= 64 && C <= 64) {   // ~4 pillars per wave: enough to amortise the parameter load, prefetch hides the rest
             const int blocks = (int)min((long)(M + 4 * kWavesPerBlock - 1) / (4 * kWavesPerBlock), (long)256 * 16);
             hipLaunchKernelGGL(pfn_kernel_p64, dim3(max(blocks, 1)), dim3(kWavesPerBlock * 64), lds, stream, a);
         } else {

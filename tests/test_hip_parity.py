@@ -109,6 +109,33 @@ def test_pillar_edge_cases():
     assert torch.equal(ops.scatter_to_bev(feats, pl["voxel_coords"].to(DEV), 2, 32, 64), canvas)
 
 
+def test_pillar_dense_duplicates_and_unfused_route(monkeypatch):
+    """Dense canvas (strips hold far more pillars than the LDS feature buffer), duplicate cells, out-of-canvas pillars:
+    every pillar_features row is still produced, the canvas follows the 'larger row wins' rule, and the separate-kernel
+    route gives bit-identical results."""
+    h = builtin_config("mini_coalign")
+    margs = h["model"]["args"]
+    model = build_model(h)
+    fill_parameters_(model, seed=4)
+    sd = model.state_dict()
+    fr = make_frame(h, 2, pillars_per_agent=1500, seed=6, num_points_mode="uniform")     # 1500 / 2048 cells occupied
+    pl = fr["processed_lidar"]
+    c = pl["voxel_coords"]
+    c[10] = c[700]; c[11] = c[700]                      # three pillars in one cell: row 700 wins
+    c[20, 3] = 64                                       # x == nx: outside the canvas
+    c[21, 0] = 7                                        # agent index out of range
+    feats, canvas = run_pillar(pl["voxel_features"], pl["voxel_num_points"], c, sd, margs, 2)
+    ref = oracle.pillar_vfe(pl["voxel_features"], pl["voxel_num_points"], c, sd, margs["voxel_size"], margs["lidar_range"])
+    feat_close(feats, ref, what="dense pillars, every row")
+    keep = torch.ones(len(c), dtype=torch.bool)
+    keep[[20, 21]] = False
+    ref_canvas = oracle.scatter(feats.cpu()[keep], c[keep], 2, 64, 32)     # sequential indexing: last duplicate wins
+    assert torch.equal(canvas.cpu(), ref_canvas)
+    monkeypatch.setenv("COALIGN_UNFUSED_PILLARS", "1")
+    feats2, canvas2 = run_pillar(pl["voxel_features"], pl["voxel_num_points"], c, sd, margs, 2)
+    assert torch.equal(feats2, feats) and torch.equal(canvas2, canvas)
+
+
 # ------------------------------------------------------------------------------------------------ warp + fusion
 def test_warp_golden(golden):
     g = golden("warp.npz")
