@@ -101,11 +101,13 @@ __device__ __forceinline__ void stage_point(const PfnArgs &a, float *slab, int r
 
 __device__ __forceinline__ float point_response(const ChanParams &cp, const float *slab, int j) {
     const float4 *src = reinterpret_cast<const float4 *>(slab + j * kFeatStride);
-    const float4 u = src[0], v = src[1], t = src[2];
+    const float4 u = src[0], v = src[1];
+    const float2 t = *reinterpret_cast<const float2 *>(slab + j * kFeatStride + 8);
+    const float2 t2 = *reinterpret_cast<const float2 *>(slab + j * kFeatStride + 10);   // zeros (times zero weights) unless Cin > 10
     float x = cp.w[0] * u.x;
     x = fmaf(cp.w[1], u.y, x); x = fmaf(cp.w[2], u.z, x); x = fmaf(cp.w[3], u.w, x);
     x = fmaf(cp.w[4], v.x, x); x = fmaf(cp.w[5], v.y, x); x = fmaf(cp.w[6], v.z, x); x = fmaf(cp.w[7], v.w, x);
-    x = fmaf(cp.w[8], t.x, x); x = fmaf(cp.w[9], t.y, x); x = fmaf(cp.w[10], t.z, x); x = fmaf(cp.w[11], t.w, x);
+    x = fmaf(cp.w[8], t.x, x); x = fmaf(cp.w[9], t.y, x); x = fmaf(cp.w[10], t2.x, x); x = fmaf(cp.w[11], t2.y, x);
     return fmaf(x, cp.alpha, cp.shift);
 }
 
@@ -330,75 +332,160 @@ __device__ __forceinline__ float pfn_one_pillar(const PfnArgs &a, const ChanPara
     return pfn_compute(a, cp, slab, lane, pillar_load(a, lane, m));
 }
 
+// Two pillars per wavefront in phase A (P <= 32): lanes 0-31 hold pillar A's points, lanes 32-63 pillar B's.  The mean
+// reduction (xor butterfly inside each 32-lane half via ds_swizzle: LDS crossbar, no memory access), the three IEEE
+// divisions and the 10-d augmentation are issued once for both pillars; phase B (lane = channel) then walks A's rows
+// 0.. and B's rows 32.. of the slab.  Returns relu(max) for A in `va`, for B in `vb` (mB < 0: no second pillar).
+__device__ __forceinline__ float half_sum(float v) {
+    // BitMode swizzle: lane' = ((lane & and_mask) | or_mask) ^ xor_mask inside each group of 32; pattern = xor<<10 | or<<5 | and
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (16 << 10) | 0x1f));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (8 << 10) | 0x1f));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (4 << 10) | 0x1f));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (2 << 10) | 0x1f));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (1 << 10) | 0x1f));
+    return v;
+}
+
+__device__ __forceinline__ float rows_max(const ChanParams &cp, const float *slab, int row0, int np_eff, int P) {
+    float best = (np_eff < P) ? cp.shift : -INFINITY;
+    int j = 0;
+    for (; j + 4 <= np_eff; j += 4) {
+        const float y0 = point_response(cp, slab, row0 + j), y1 = point_response(cp, slab, row0 + j + 1);
+        const float y2 = point_response(cp, slab, row0 + j + 2), y3 = point_response(cp, slab, row0 + j + 3);
+        best = fmaxf(fmaxf(best, fmaxf(y0, y1)), fmaxf(y2, y3));
+    }
+    for (; j < np_eff; ++j) best = fmaxf(best, point_response(cp, slab, row0 + j));
+    return fmaxf(best, 0.f);
+}
+
+__device__ __forceinline__ void pfn_pair(const PfnArgs &a, const ChanParams &cp, float *slab, int lane, int mA, int mB,
+                                         float &va, float &vb) {
+    const int half = lane >> 5, pl = lane & 31;
+    const int m = half ? mB : mA;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    int np_raw = 0;
+    int4 cd = make_int4(0, 0, 0, 0);
+    if (m >= 0) {
+        if (pl < a.P) q = a.pts[(size_t)m * a.P + pl];
+        np_raw = a.npts[m];
+        cd = a.coords[m];
+    }
+    const int np_eff = min(max(np_raw, 0), a.P);
+    const float npf = (float)np_raw;
+    const float mx = half_sum(q.x) / npf, my = half_sum(q.y) / npf, mz = half_sum(q.z) / npf;
+    const float ctr_x = (float)cd.w * a.vx + a.xo;
+    const float ctr_y = (float)cd.z * a.vy + a.yo;
+    const float ctr_z = (float)cd.y * a.vz + a.zo;
+    if (pl < np_eff) stage_point(a, slab, lane, q, mx, my, mz, ctr_x, ctr_y, ctr_z);   // row = lane: A -> 0.., B -> 32..
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int npA = __builtin_amdgcn_readlane(np_eff, 0), npB = __builtin_amdgcn_readlane(np_eff, 32);
+    va = rows_max(cp, slab, 0, npA, a.P);
+    vb = (mB >= 0) ? rows_max(cp, slab, 32, npB, a.P) : 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(256) void pillar_canvas_kernel(FusedArgs f) {
     const PfnArgs &a = f.p;
     __shared__ __attribute__((aligned(16))) float slabs[4 * 64 * kFeatStride];
     __shared__ __attribute__((aligned(16))) float featbuf[kMaxLds * 64];
-    __shared__ int work_m[kStrip + 64];      // pillar rows to encode: occupied cells first, then orphans
+    __shared__ int work_m[kStrip];           // pillar rows living in this strip
+    __shared__ int orphan_m[256];            // orphans found in this workgroup's slice of the pillar list (normally none)
     __shared__ int slot_of_cell[kStrip];     // cell -> index into work_m / featbuf, -1 = empty
-    __shared__ int n_occ, n_work;
+    __shared__ int n_occ, n_orph;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ncell = a.ny * a.nx;
     const int agent = blockIdx.y;
     const int cell0 = blockIdx.x * kStrip;
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-    if (tid == 0) { n_occ = 0; n_work = 0; }
-    __syncthreads();
-    // ---- occupied cells of the strip (order inside the list is irrelevant: every cell remembers its slot)
+    if (tid == 0) { n_occ = 0; n_orph = 0; }
+    // ---- issue both independent loads first: this thread's cell of the strip, and one pillar of this workgroup's slice of
+    //      the pillar list (orphan check: duplicate-cell losers and out-of-canvas pillars still need their feature row)
     const int cell = cell0 + tid;
     const int id = (cell < ncell) ? a.cellmap[(size_t)agent * ncell + cell] : -1;
+    const int m_o = (tid < f.pillars_per_wg) ? wg * f.pillars_per_wg + tid : a.M;
+    int4 cd_o = make_int4(-1, 0, 0, 0);
+    if (m_o < a.M) cd_o = a.coords[m_o];
+    __syncthreads();
     int slot = -1;
-    if (id >= 0) { slot = atomicAdd(&n_occ, 1); work_m[slot] = id; }
+    if (id >= 0) { slot = atomicAdd(&n_occ, 1); work_m[slot] = id; }   // order inside the list is irrelevant
     slot_of_cell[tid] = slot;
+    int winner = -2;                                                   // second hop of the orphan check, overlaps the PFN below
+    if (m_o < a.M) {
+        const int c = cd_o.y + cd_o.z * a.nx + cd_o.w;
+        winner = (cd_o.x >= 0 && cd_o.x < a.n_agents && c >= 0 && c < ncell) ? a.cellmap[(size_t)cd_o.x * ncell + c] : -1;
+    }
     __syncthreads();
     const int nocc = n_occ;
-    // ---- PFN for the strip's pillars, wave-strided
+    // ---- PFN for the strip's pillars
     const ChanParams cp = load_chan(a, lane);
     float *slab = slabs + wv * 64 * kFeatStride;
-    for (int w = wv; w < nocc; w += 4) {
-        const int m = work_m[w];
-        const float v = pfn_one_pillar(a, cp, slab, lane, m);
-        if (lane < a.C) {
-            a.feats[(size_t)m * a.C + lane] = v;
-            if (w < kMaxLds) featbuf[w * 64 + lane] = v;
-        }
-    }
-    // ---- orphans (duplicate-cell losers, out-of-canvas pillars) in this workgroup's slice of the pillar list,
-    //      64 candidates per round; with well-formed input every round finds none
-    for (int r0 = 0; r0 < f.pillars_per_wg; r0 += 64) {
-        __syncthreads();
-        if (tid == 0) n_work = 0;
-        __syncthreads();
-        if (tid < 64 && r0 + tid < f.pillars_per_wg) {
-            const int m = wg * f.pillars_per_wg + r0 + tid;
-            if (m < a.M) {
-                const int4 cd = a.coords[m];
-                const int c = cd.y + cd.z * a.nx + cd.w;
-                const bool placed = cd.x >= 0 && cd.x < a.n_agents && c >= 0 && c < ncell && a.cellmap[(size_t)cd.x * ncell + c] == m;
-                if (!placed) work_m[kStrip + atomicAdd(&n_work, 1)] = m;
+    if (a.P <= 32) {
+        for (int w = 2 * wv; w < nocc; w += 8) {          // two pillars per wave and pass
+            const int mA = work_m[w], mB = (w + 1 < nocc) ? work_m[w + 1] : -1;
+            float va, vb;
+            pfn_pair(a, cp, slab, lane, mA, mB, va, vb);
+            if (lane < a.C) {
+                a.feats[(size_t)mA * a.C + lane] = va;
+                if (w < kMaxLds) featbuf[w * 64 + lane] = va;
+                if (mB >= 0) {
+                    a.feats[(size_t)mB * a.C + lane] = vb;
+                    if (w + 1 < kMaxLds) featbuf[(w + 1) * 64 + lane] = vb;
+                }
             }
         }
-        __syncthreads();
-        const int nw = n_work;
-        for (int w = wv; w < nw; w += 4) {
-            const int m = work_m[kStrip + w];
+    } else {
+        for (int w = wv; w < nocc; w += 4) {
+            const int m = work_m[w];
             const float v = pfn_one_pillar(a, cp, slab, lane, m);
-            if (lane < a.C) a.feats[(size_t)m * a.C + lane] = v;
+            if (lane < a.C) {
+                a.feats[(size_t)m * a.C + lane] = v;
+                if (w < kMaxLds) featbuf[w * 64 + lane] = v;
+            }
         }
     }
     if (nocc > kMaxLds) __threadfence();     // overflow rows are read back from L2 below
-    __syncthreads();
-    // ---- stream the strip: thread = 4 consecutive cells x (C/4) channels, 16 B stores
+    // ---- one barrier publishes featbuf AND tells whether anybody found an orphan (well-formed input: nobody)
+    const bool orphan = (m_o < a.M) && (winner != m_o);
+    if (__syncthreads_or(orphan || f.pillars_per_wg > 256)) {
+        if (orphan) orphan_m[atomicAdd(&n_orph, 1)] = m_o;
+        __syncthreads();
+        for (int w = wv; w < n_orph; w += 4) {
+            const float v = pfn_one_pillar(a, cp, slab, lane, orphan_m[w]);
+            if (lane < a.C) a.feats[(size_t)orphan_m[w] * a.C + lane] = v;
+        }
+        for (int r0 = 256; r0 < f.pillars_per_wg; r0 += 256) {        // slices longer than the block (huge M, tiny canvas)
+            __syncthreads();
+            if (tid == 0) n_orph = 0;
+            __syncthreads();
+            const int m = wg * f.pillars_per_wg + r0 + tid;
+            if (r0 + tid < f.pillars_per_wg && m < a.M) {
+                const int4 cd = a.coords[m];
+                const int c = cd.y + cd.z * a.nx + cd.w;
+                const bool placed = cd.x >= 0 && cd.x < a.n_agents && c >= 0 && c < ncell && a.cellmap[(size_t)cd.x * ncell + c] == m;
+                if (!placed) orphan_m[atomicAdd(&n_orph, 1)] = m;
+            }
+            __syncthreads();
+            for (int w = wv; w < n_orph; w += 4) {
+                const float v = pfn_one_pillar(a, cp, slab, lane, orphan_m[w]);
+                if (lane < a.C) a.feats[(size_t)orphan_m[w] * a.C + lane] = v;
+            }
+        }
+    }
+    // ---- the occupied groups: thread = 4 consecutive cells x (C/4) channels, 16 B stores of LDS-resident feature rows
+    // (stores are issued only now: a wave that stores and then loads stalls -- vmcnt retires in order and counts stores --
+    //  and an early zero-writer wave measured 2x slower, so the whole strip goes out after the encoder)
     const int q4 = lane * 4;                 // first of this thread's 4 cells inside the strip
     const int cpw = (a.C + 3) / 4;           // channels per wave
     const int c_lo = wv * cpw, c_hi = min(a.C, c_lo + cpw);
+    const int gcell = cell0 + q4;
+    const bool vec = (ncell % 4 == 0);
     int sl[4];
     bool any = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { sl[j] = slot_of_cell[q4 + j]; any |= sl[j] >= 0; }
-    const int gcell = cell0 + q4;
     if (gcell >= ncell) return;
-    const bool vec = (ncell % 4 == 0);
     float *dst = f.canvas + ((size_t)agent * a.C + c_lo) * ncell + gcell;
     for (int c = c_lo; c < c_hi; ++c, dst += ncell) {
         float v[4] = {0.f, 0.f, 0.f, 0.f};
