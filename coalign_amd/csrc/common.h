@@ -38,4 +38,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return base + slot;
 }
 
+// Order a wavefront's own LDS traffic: write by some lanes, read by others of the SAME wave.  The LDS unit executes one
+// wave's DS instructions in issue order, so no hardware wait is needed -- only the compiler must not reorder across this
+// point.  (A __builtin_amdgcn_fence here can also drain vmcnt, i.e. wait for every prefetched global load.)
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace coalign

@@ -185,8 +185,7 @@ __global__ __launch_bounds__(64) void reduce_kernel(const unsigned long long *__
             const int w = e % nb;
             rowsbuf[e] = (w >= b) ? chunk[e] : 0ull;     // words left of the diagonal are never produced nor needed
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        coalign::wave_lds_sync();
         const unsigned long long diag = (lane < rows) ? rowsbuf[lane * nb + b] : 0ull;
         const unsigned long long valid = rows == 64 ? ~0ull : ((1ull << rows) - 1ull);
         // the sequential part: visit only the boxes that are still alive (scalar find-first-set), each kept box
@@ -212,8 +211,7 @@ __global__ __launch_bounds__(64) void reduce_kernel(const unsigned long long *__
             }
             removed |= acc;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        coalign::wave_lds_sync();
     }
     if (lane == 0) *keep_count = cnt;
 }

@@ -150,8 +150,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pfn_kernel_p64(PfnArgs a)
         const float ctr_y = (float)cd.z * a.vy + a.yo;
         const float ctr_z = (float)cd.y * a.vz + a.zo;
         if (lane < np_eff) stage_point(a, slab, lane, q, mx, my, mz, ctr_x, ctr_y, ctr_z);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        coalign::wave_lds_sync();
         float best = (np_eff < a.P) ? cp.shift : -INFINITY;
         int j = 0;
         for (; j + 4 <= np_eff; j += 4) {
@@ -160,8 +159,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pfn_kernel_p64(PfnArgs a)
             best = fmaxf(fmaxf(best, fmaxf(y0, y1)), fmaxf(y2, y3));
         }
         for (; j < np_eff; ++j) best = fmaxf(best, point_response(cp, slab, j));
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        coalign::wave_lds_sync();
         if (c_ok) a.feats[(size_t)m * a.C + lane] = fmaxf(best, 0.f);
         if (lane == 0) {
             const int cell = cd.y + cd.z * a.nx + cd.w;  // z + y*nx + x (point_pillar_scatter.py:54)
@@ -209,12 +207,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pfn_kernel(PfnArgs a) {
             for (int p0 = 0; p0 < np_eff; p0 += 64) {
                 const int p = p0 + lane;
                 if (p < np_eff) stage_point(a, slab, lane, prow[p], mx, my, mz, ctr_x, ctr_y, ctr_z);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                coalign::wave_lds_sync();
                 const int cnt = min(64, np_eff - p0);
                 for (int j = 0; j < cnt; ++j) best = fmaxf(best, point_response(cp, slab, j));
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                coalign::wave_lds_sync();
             }
             if (c_ok) a.feats[(size_t)m * a.C + c] = fmaxf(best, 0.f);
             if (cb == 0 && lane == 0) {
@@ -313,8 +309,7 @@ __device__ __forceinline__ float pfn_compute(const PfnArgs &a, const ChanParams 
     const float ctr_y = (float)cd.z * a.vy + a.yo;
     const float ctr_z = (float)cd.y * a.vz + a.zo;
     if (lane < np_eff) stage_point(a, slab, lane, q, mx, my, mz, ctr_x, ctr_y, ctr_z);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    coalign::wave_lds_sync();
     float best = (np_eff < a.P) ? cp.shift : -INFINITY;
     int j = 0;
     for (; j + 4 <= np_eff; j += 4) {
@@ -323,8 +318,7 @@ __device__ __forceinline__ float pfn_compute(const PfnArgs &a, const ChanParams 
         best = fmaxf(fmaxf(best, fmaxf(y0, y1)), fmaxf(y2, y3));
     }
     for (; j < np_eff; ++j) best = fmaxf(best, point_response(cp, slab, j));
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    coalign::wave_lds_sync();
     return fmaxf(best, 0.f);
 }
 
@@ -377,13 +371,11 @@ __device__ __forceinline__ void pfn_pair(const PfnArgs &a, const ChanParams &cp,
     const float ctr_y = (float)cd.z * a.vy + a.yo;
     const float ctr_z = (float)cd.y * a.vz + a.zo;
     if (pl < np_eff) stage_point(a, slab, lane, q, mx, my, mz, ctr_x, ctr_y, ctr_z);   // row = lane: A -> 0.., B -> 32..
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    coalign::wave_lds_sync();
     const int npA = __builtin_amdgcn_readlane(np_eff, 0), npB = __builtin_amdgcn_readlane(np_eff, 32);
     va = rows_max(cp, slab, 0, npA, a.P);
     vb = (mB >= 0) ? rows_max(cp, slab, 32, npB, a.P) : 0.f;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    coalign::wave_lds_sync();
 }
 
 __global__ __launch_bounds__(256) void pillar_canvas_kernel(FusedArgs f) {

@@ -113,7 +113,8 @@ __device__ __forceinline__ void softmax_weights(const WarpArgs &a, const float *
 template <int NA, int CPT, bool KEEP, int MAXT, int PD>
 __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && NA <= 5 && MAXT <= 512) ? 5 : 4)) void warp_fuse_kernel(WarpArgs a) {   // waves / SIMD the register allocation must allow
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int px = threadIdx.x & 63, g = threadIdx.x >> 6, G = blockDim.x >> 6;
+    const int px = threadIdx.x & 63, G = blockDim.x >> 6;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id: provably uniform -> scalar plane addresses
     // LDS carve: [G][kPatchFloats] patches | [G][NA][64] score partials | [NA][64] taps | [NA] origins
     float *patch = smem + (size_t)g * kPatchFloats;
     float *red = smem + (size_t)G * kPatchFloats;
@@ -141,7 +142,11 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
                 const float x0f = floorf(ix), y0f = floorf(iy);
                 const float tx = ix - x0f, ty = iy - y0f, ex = 1.f - tx, ey = 1.f - ty;
                 x0 = (int)x0f; y0 = (int)y0f;
-                t.w00 = ey * ex; t.w01 = ey * tx; t.w10 = ty * ex; t.w11 = ty * tx;
+                const bool vx0 = x0 >= 0, vx1 = x0 + 1 <= a.W - 1, vy0 = y0 >= 0, vy1 = y0 + 1 <= a.H - 1;
+                t.w00 = (vx0 && vy0) ? ey * ex : 0.f;      // zero padding: out-of-image taps weigh nothing, so the patch
+                t.w01 = (vx1 && vy0) ? ey * tx : 0.f;      // may hold anything at those positions (clamped loads below)
+                t.w10 = (vx0 && vy1) ? ty * ex : 0.f;
+                t.w11 = (vx1 && vy1) ? ty * tx : 0.f;
                 live = true;
             }
         }
@@ -172,45 +177,79 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
         // kernel is latency bound otherwise (PMC: 79 % of wave cycles waiting on vmcnt with 4 loads in flight).
         constexpr int D = PD;                             // prefetch distance (patch loads in flight per wave)
         constexpr int ITEMS = NA * CPT;
-        // Only the bounding box of the tile's footprint is fetched: the lanes are laid over it row-major with nc4
-        // float4 per row (nc4 * nrows <= 64 lanes), the rest of the wave issues nothing.
-        int goff[NA];   // global offset of this lane's patch slot; -1: inside the box but outside the image (zeros)
-        int loff[NA];   // LDS offset (floats) of the slot; -1: lane not part of this agent's box
+        // Only the bounding box of the tile's footprint is fetched: the lanes are laid over it row-major with nc4 float4 per
+        // row (nc4 * nrows <= 64).  Every lane issues the load -- box lanes at their (clamped into the image) position,
+        // the others at byte 0 of the plane (one broadcast line) -- and writes LDS, the others into the unused columns
+        // 16..23 of the slab: no per-lane branch anywhere in the item loop.
+        unsigned voff[NA];   // byte offset of this lane's patch slot inside a channel plane
+        int loff[NA];        // LDS offset (floats) of the slot
 #pragma unroll
         for (int n = 0; n < NA; ++n) {
-            goff[n] = -1; loff[n] = -1;
+            voff[n] = 0u; loff[n] = (px & 15) * kPatchStride + 16 + ((px >> 4) & 1) * 4;
             if (n < a.n) {
                 const Origin o = origins[n];
                 const int prow = (o.nc4 == 4) ? (px >> 2) : (o.nc4 == 3) ? (px * 43 >> 7) : (o.nc4 == 2) ? (px >> 1) : px;
                 const int pc4 = (px - prow * o.nc4) << 2;
                 if (prow < o.nrows) {
                     loff[n] = prow * kPatchStride + pc4;
-                    const int gy = o.py0 + prow, gx = o.ax0 + pc4;
-                    if (gy >= 0 && gy < a.H && gx >= 0 && gx + 3 < a.W) goff[n] = gy * a.W + gx;
+                    const int gy = min(max(o.py0 + prow, 0), a.H - 1), gx = min(max(o.ax0 + pc4, 0), a.W - 4);
+                    voff[n] = (unsigned)(gy * a.W + gx) * 4u;
                 }
             }
         }
+        const char *xb = reinterpret_cast<const char *>(a.x);
         auto fetch = [&](int n, int k) -> float4 {       // n, k are compile-time after unrolling
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int c = c_base + k;
-            if (n < a.n && c < a.C && goff[n] >= 0)
-                v = *reinterpret_cast<const float4 *>(a.x + ((size_t)n * a.C + c) * HW + goff[n]);
+            if (n < a.n && c < a.C) {                      // wave-uniform: scalar branch, scalar plane address
+                const char *plane = xb + ((size_t)n * a.C + c) * HW * sizeof(float);
+                v = *reinterpret_cast<const float4 *>(plane + voff[n]);
+            }
             return v;
         };
         auto resample = [&](float4 v, const Tap &t, int lo) -> float {   // patch slice -> LDS slab -> this pixel's 4 taps
-            if (lo >= 0) *reinterpret_cast<float4 *>(patch + lo) = v;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<float4 *>(patch + lo) = v;
+            coalign::wave_lds_sync();
             const float *pr = patch + t.idx;
             const float v00 = pr[0], v01 = pr[1], v10 = pr[kPatchStride], v11 = pr[kPatchStride + 1];
             const float r = v00 * t.w00 + v01 * t.w01 + v10 * t.w10 + v11 * t.w11;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            coalign::wave_lds_sync();
             return r;
         };
 
         if constexpr (KEEP) {
             float X[NA][CPT];                              // warped values stay in registers
+            if (a.n == NA && c_base + CPT <= a.C) {
+                // Every (agent, channel) slot of the template exists for this wave: a straight-line stream of
+                // ITEMS x {16 B/lane load, ds_write, 2 ds_read2, 7 VALU}.  The kernel is instruction-issue bound (removing
+                // every load AND the LDS round trip only took it from 31 to 18 us), so the per-item overhead is stripped:
+                // no per-item conditions, the plane pointer advances by a scalar add.  The empty asm pins program order --
+                // without it hipcc hoists dozens of the (now unconditional) loads to the top and spills.
+                const size_t stride = (size_t)HW * sizeof(float);
+                const char *agent0 = xb + (size_t)c_base * stride;
+                const size_t agent_stride = (size_t)a.C * stride;
+                const char *pf = agent0;                   // plane of the next item to prefetch (uniform)
+                float4 ring[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    ring[j] = *reinterpret_cast<const float4 *>(pf + voff[j / CPT]);
+                    pf = ((j + 1) % CPT == 0) ? agent0 + (size_t)((j + 1) / CPT) * agent_stride : pf + stride;
+                }
+                Tap t = taps[px];
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) {
+                    const int n = j / CPT, k = j % CPT;
+                    if (k == 0 && n > 0) t = taps[n * 64 + px];
+                    const float4 v = ring[j % D];
+                    if (j + D < ITEMS) {
+                        ring[j % D] = *reinterpret_cast<const float4 *>(pf + voff[(j + D) / CPT]);
+                        pf = ((j + D + 1) % CPT == 0) ? agent0 + (size_t)((j + D + 1) / CPT) * agent_stride : pf + stride;
+                    }
+                    X[n][k] = resample(v, t, loff[n]);
+#pragma unroll
+                    for (int q = 0; q < NA; ++q) asm volatile("" : "+v"(voff[q]));   // later loads may not move above here
+                }
+            } else {
             float4 ring[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) ring[j] = fetch(j / CPT, j % CPT);
@@ -223,6 +262,7 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
                 if (j + D < ITEMS) ring[j % D] = fetch((j + D) / CPT, (j + D) % CPT);
                 X[n][k] = (n < a.n && c_base + k < a.C) ? resample(v, t, loff[n]) : 0.f;
                 __builtin_amdgcn_sched_barrier(0);   // keep the prefetch of item j + D inside iteration j
+            }
             }
             if (a.mode == COALIGN_FUSE_ATT) {
 #pragma unroll
