@@ -343,6 +343,23 @@ __global__ __launch_bounds__(256) void iou_bev_kernel(const float *__restrict__ 
     iou[idx] = pcdet_iou(a + (size_t)i * 7, b + (size_t)j * 7);
 }
 
+// ------------------------------------------------------------------------------------------------ float64 IoU matrix
+// (evaluation: TP / FP matching, opencood/utils/eval_utils.py:45-96 builds the same numbers with one Shapely call per pair)
+__global__ __launch_bounds__(256) void iou_matrix_kernel(const float *__restrict__ a, int rows_a, int cols_a, int Na,
+                                                         const float *__restrict__ b, int rows_b, int cols_b, int Nb,
+                                                         float *__restrict__ iou) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)Na * Nb) return;
+    const int i = (int)(idx / Nb), j = (int)(idx % Nb);
+    Poly pa, pb;
+    load_poly(a, rows_a, cols_a, i, pa);
+    load_poly(b, rows_b, cols_b, j, pb);
+    float r = 0.f;
+    const bool apart = pa.xmax < pb.xmin || pb.xmax < pa.xmin || pa.ymax < pb.ymin || pb.ymax < pa.ymin;
+    if (!apart || pa.area + pb.area == 0.0) r = (float)quad_iou(pa.v, pa.area, pb.v, pb.area, pb.sgn);
+    iou[idx] = r;
+}
+
 struct NmsWs {
     int *order, *n_sorted;
     unsigned long long *mask;
@@ -404,6 +421,19 @@ int coalign_gather_in_range(const float *corners, const float *scores, const int
     const double *r = range6_host;
     hipLaunchKernelGGL(gather_kernel, dim3(1), dim3(1024), 0, stream, corners, scores, keep, keep_count, keep_cap, r[0], r[1],
                        r[2], r[3], r[4], r[5], out_corners, out_scores, out_count);
+    return check_launch();
+}
+
+int coalign_iou_rotated_matrix(const float *boxes_a, int rows_a, int cols_a, int Na, const float *boxes_b, int rows_b, int cols_b,
+                               int Nb, float *iou, void *stream_) {
+    using namespace coalign;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Na < 0 || Nb < 0 || rows_a < 4 || cols_a < 2 || rows_b < 4 || cols_b < 2) return COALIGN_ERR_BAD_SHAPE;
+    if (Na == 0 || Nb == 0) return COALIGN_OK;
+    if (!boxes_a || !boxes_b || !iou) return COALIGN_ERR_NULL_POINTER;
+    const long total = (long)Na * Nb;
+    hipLaunchKernelGGL(iou_matrix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, boxes_a, rows_a, cols_a, Na,
+                       boxes_b, rows_b, cols_b, Nb, iou);
     return check_launch();
 }
 

@@ -213,6 +213,18 @@ def gather_in_range(corners: torch.Tensor, scores: torch.Tensor, keep: torch.Ten
                                         _ptr(out_corners), _ptr(out_scores), _ptr(out_count), _stream()), "coalign_gather_in_range")
 
 
+def iou_rotated_matrix(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Tensor:
+    """[Na, 8, 3] / [Na, 4, 2] corners x [Nb, ...] corners -> float32 IoU matrix [Na, Nb] (float64 clipping inside)."""
+    _need_gpu(boxes_a, boxes_b)
+    L = hip.lib()
+    a, b = _f32c(boxes_a), _f32c(boxes_b)
+    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    if a.shape[0] and b.shape[0]:
+        hip.check(L.coalign_iou_rotated_matrix(_ptr(a), a.shape[1], a.shape[2], a.shape[0], _ptr(b), b.shape[1], b.shape[2], b.shape[0],
+                                               _ptr(out), _stream()), "coalign_iou_rotated_matrix")
+    return out
+
+
 def boxes_iou_bev(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Tensor:
     """OpenPCDet-semantics fp32 BEV IoU matrix [Na, Nb] of (x, y, z, dx, dy, dz, heading) boxes."""
     _need_gpu(boxes_a, boxes_b)

@@ -146,6 +146,13 @@ int coalign_gather_in_range(const float *corners, const float *scores, const int
                             int keep_cap, const double *range6_host, float *out_corners, float *out_scores,
                             int32_t *out_count, void *stream);
 
+/* Rotated IoU matrix with the same float64 clipping as the NMS (union = |A| + |B| - inter, result rounded to float32):
+ * the numbers opencood/utils/eval_utils.py:45-96 (caluclate_tp_fp) obtains from common_utils.compute_iou, one Shapely
+ * call per (detection, ground truth) pair.  boxes_a [Na, rows_a, cols_a], boxes_b [Nb, rows_b, cols_b] as in (4)
+ * -> iou [Na, Nb]. */
+int coalign_iou_rotated_matrix(const float *boxes_a, int rows_a, int cols_a, int Na, const float *boxes_b, int rows_b, int cols_b,
+                               int Nb, float *iou, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * (5) OpenPCDet-semantics BEV IoU (fp32 overlap with its 1e-2 corner margin) for callers of
  *     opencood/pcdet_utils/iou3d_nms/iou3d_nms_utils.py (boxes_iou_bev :47-63, nms_gpu :255-271).

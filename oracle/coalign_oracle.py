@@ -668,3 +668,64 @@ def pcdet_nms(boxes7: np.ndarray, scores: np.ndarray, thr: float, pre_max: Optio
     keep = np.empty(len(order), dtype=np.int32)
     n = _nms_lib().oracle_pcdet_nms(b.ctypes.data, len(order), ctypes.c_float(thr), keep.ctypes.data)
     return order[keep[:n]]
+
+
+# --------------------------------------------------------------------------------------
+# Evaluation: opencood/utils/eval_utils.py:19-169
+# --------------------------------------------------------------------------------------
+
+
+def iou_matrix(det: np.ndarray, gt: np.ndarray) -> np.ndarray:
+    """float32 IoU of every (detection, ground truth) pair, corners 0..3 (x, y) as polygons (common_utils.py:196-236)."""
+    out = np.zeros((len(det), len(gt)), dtype=np.float32)
+    for i, a in enumerate(det):
+        for j, b in enumerate(gt):
+            out[i, j] = np.float32(quad_iou(a[:4, :2], b[:4, :2]))
+    return out
+
+
+def caluclate_tp_fp(det_boxes, det_score, gt_boxes, result_stat, iou_thresh):
+    """eval_utils.py:45-96: detections in descending score order; TP if the best IoU against the remaining ground truths
+    is >= the threshold, the matched ground truth is removed."""
+    fp, tp = [], []
+    gt = gt_boxes.shape[0]
+    if det_boxes is not None:
+        det_boxes, det_score, gt_np = np.asarray(det_boxes), np.asarray(det_score), np.asarray(gt_boxes)
+        order = np.argsort(-det_score, kind="stable")
+        det_score = det_score[order]
+        remaining = list(range(gt))
+        for i in range(len(order)):
+            ious = np.array([quad_iou(det_boxes[order[i]][:4, :2], gt_np[g][:4, :2]) for g in remaining], dtype=np.float32)
+            if len(remaining) == 0 or np.max(ious) < iou_thresh:
+                fp.append(1); tp.append(0)
+                continue
+            fp.append(0); tp.append(1)
+            remaining.pop(int(np.argmax(ious)))
+        result_stat[iou_thresh]["score"] += det_score.tolist()
+    result_stat[iou_thresh]["fp"] += fp
+    result_stat[iou_thresh]["tp"] += tp
+    result_stat[iou_thresh]["gt"] += gt
+
+
+def voc_ap(rec, prec):
+    """eval_utils.py:19-42."""
+    mrec = [0.0] + list(rec) + [1.0]
+    mpre = [0.0] + list(prec) + [0.0]
+    for i in range(len(mpre) - 2, -1, -1):
+        mpre[i] = max(mpre[i], mpre[i + 1])
+    ap = 0.0
+    for i in range(1, len(mrec)):
+        if mrec[i] != mrec[i - 1]:
+            ap += (mrec[i] - mrec[i - 1]) * mpre[i]
+    return ap, mrec, mpre
+
+
+def calculate_ap(result_stat, iou):
+    """eval_utils.py:100-142."""
+    st = result_stat[iou]
+    fp, tp, score = np.array(st["fp"]), np.array(st["tp"]), np.array(st["score"])
+    order = np.argsort(-score, kind="stable")
+    fp, tp = np.cumsum(fp[order]), np.cumsum(tp[order])
+    rec = [float(t) / st["gt"] for t in tp]
+    prec = [float(t) / (f + t) for t, f in zip(tp, fp)]
+    return voc_ap(rec, prec)

@@ -269,6 +269,33 @@ def main():
     nms["quad_keep"] = box_utils.nms_rotated(corners[:50, :4, :2], sc[:50], 0.15)   # (N,4,2) input form
     save("nms.npz", **nms)
 
+    # ------------------------------------------------------------------ evaluation: the reference's TP/FP matching + AP
+    from opencood.utils import eval_utils
+    rs = np.random.RandomState(31)
+    ev = {}
+    stat = {0.3: {"tp": [], "fp": [], "gt": 0, "score": []}, 0.5: {"tp": [], "fp": [], "gt": 0, "score": []},
+            0.7: {"tp": [], "fp": [], "gt": 0, "score": []}}
+    for f in range(3):
+        G = 25 + 5 * f
+        g7 = np.zeros((G, 7), dtype=np.float32)
+        g7[:, 0] = rs.uniform(-60, 60, G); g7[:, 1] = rs.uniform(-30, 30, G); g7[:, 2] = -1; g7[:, 3] = 1.56
+        g7[:, 4] = rs.uniform(1.5, 2.1, G); g7[:, 5] = rs.uniform(3.5, 5.0, G); g7[:, 6] = rs.uniform(-3.1, 3.1, G)
+        d7 = np.concatenate([g7[: G - 5] + rs.normal(0, [0.35, 0.25, 0, 0, 0.1, 0.25, 0.08], (G - 5, 7)).astype(np.float32),
+                             g7[:8] + np.array([9.0, 7.0, 0, 0, 0, 0, 0.5], dtype=np.float32)])        # jittered hits + false alarms
+        gt_c = box_utils.boxes_to_corners_3d(torch.from_numpy(g7), "hwl")
+        det_c = box_utils.boxes_to_corners_3d(torch.from_numpy(d7), "hwl")
+        det_s = torch.from_numpy(rs.uniform(0.2, 1.0, len(d7)).astype(np.float32))
+        for thr in (0.3, 0.5, 0.7):
+            eval_utils.caluclate_tp_fp(det_c, det_s, gt_c, stat, thr)
+        ev.update({f"gt{f}": gt_c, f"det{f}": det_c, f"score{f}": det_s})
+    eval_utils.caluclate_tp_fp(None, None, gt_c, stat, 0.7)          # a frame without detections only adds ground truths
+    for thr in (0.3, 0.5, 0.7):
+        ap, mrec, mpre = eval_utils.calculate_ap(stat, thr)
+        tag = str(int(thr * 100))
+        ev.update({f"tp{tag}": np.array(stat[thr]["tp"]), f"fp{tag}": np.array(stat[thr]["fp"]), f"gtn{tag}": stat[thr]["gt"],
+                   f"scores{tag}": np.array(stat[thr]["score"]), f"ap{tag}": ap, f"mrec{tag}": np.array(mrec), f"mpre{tag}": np.array(mpre)})
+    save("eval.npz", **ev)
+
     # ------------------------------------------------------------------ full-size pillar path + fusion (samples only)
     hf = load_hypes(YAML_COALIGN)
     mf = train_utils.create_model(hf).eval()

@@ -466,3 +466,20 @@ def test_api_level_functions(golden):
         finally:
             bb.FAST_INFERENCE = True
     feat_close(fast, plain.cpu(), what="NaiveCompressor folded vs plain")
+
+
+def test_evaluation_on_device_vs_reference(golden):
+    """next-2: AP through the device IoU matrix == the reference's eval_utils numbers; IoU matrix bit-equal to the oracle's."""
+    from coalign_amd import evaluation as ev
+    g = golden("eval.npz")
+    stat = ev.new_result_stat()
+    for f in range(3):
+        det, sc, gt = T(g[f"det{f}"]).to(DEV), T(g[f"score{f}"]).to(DEV), T(g[f"gt{f}"]).to(DEV)
+        assert np.array_equal(ops.iou_rotated_matrix(det, gt).cpu().numpy(), oracle.iou_matrix(g[f"det{f}"], g[f"gt{f}"]))
+        for thr in (0.3, 0.5, 0.7):
+            ev.caluclate_tp_fp(det, sc, gt, stat, thr)
+    ev.caluclate_tp_fp(None, None, T(g["gt2"]), stat, 0.7)
+    for thr in (0.3, 0.5, 0.7):
+        tag = str(int(thr * 100))
+        assert stat[thr]["tp"] == list(g[f"tp{tag}"]) and stat[thr]["fp"] == list(g[f"fp{tag}"]) and stat[thr]["gt"] == int(g[f"gtn{tag}"])
+        assert abs(ev.calculate_ap(stat, thr)[0] - float(g[f"ap{tag}"])) < 1e-12

@@ -172,3 +172,41 @@ def test_full_model_mini(golden):
         close(out["fused"][s], g[f"fused{s}"], rtol=1e-4, atol=1e-5 * scale)
     for k in ("cls_preds", "reg_preds", "dir_preds"):
         close(out[k], g[k], rtol=1e-4, atol=1e-4 * float(np.abs(g[k]).max()))
+
+
+def test_evaluation_matches_reference(golden):
+    """TP/FP matching + VOC AP (next-2): the oracle restatement reproduces the reference's eval_utils on 3 frames
+    (IoU through the stand-in polygon, see make_golden.py) at IoU 0.3 / 0.5 / 0.7."""
+    g = golden("eval.npz")
+    stat = {t: {"tp": [], "fp": [], "gt": 0, "score": []} for t in (0.3, 0.5, 0.7)}
+    for f in range(3):
+        for thr in (0.3, 0.5, 0.7):
+            oracle.caluclate_tp_fp(g[f"det{f}"], g[f"score{f}"], g[f"gt{f}"], stat, thr)
+    oracle.caluclate_tp_fp(None, None, g["gt2"], stat, 0.7)
+    for thr in (0.3, 0.5, 0.7):
+        tag = str(int(thr * 100))
+        assert stat[thr]["tp"] == list(g[f"tp{tag}"]) and stat[thr]["fp"] == list(g[f"fp{tag}"]) and stat[thr]["gt"] == int(g[f"gtn{tag}"])
+        ap, mrec, mpre = oracle.calculate_ap(stat, thr)
+        assert abs(ap - float(g[f"ap{tag}"])) < 1e-12
+        np.testing.assert_allclose(mrec, g[f"mrec{tag}"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(mpre, g[f"mpre{tag}"], rtol=0, atol=1e-12)
+
+
+def test_evaluation_host_logic_matches_reference(golden):
+    """The product's host-side matching / AP code (coalign_amd.evaluation) fed with the oracle's IoU matrix."""
+    from coalign_amd import evaluation as ev
+    g = golden("eval.npz")
+    stat = ev.new_result_stat()
+    for f in range(3):
+        iou = oracle.iou_matrix(g[f"det{f}"], g[f"gt{f}"])
+        for thr in (0.3, 0.5, 0.7):
+            tp, fp, sc = ev.match_tp_fp(iou, g[f"score{f}"], thr)
+            stat[thr]["tp"] += tp; stat[thr]["fp"] += fp; stat[thr]["score"] += sc.tolist(); stat[thr]["gt"] += len(g[f"gt{f}"])
+    stat[0.7]["gt"] += len(g["gt2"])
+    for thr in (0.3, 0.5, 0.7):
+        tag = str(int(thr * 100))
+        assert stat[thr]["tp"] == list(g[f"tp{tag}"]) and stat[thr]["fp"] == list(g[f"fp{tag}"])
+        ap, mrec, mpre = ev.calculate_ap(stat, thr)
+        assert abs(ap - float(g[f"ap{tag}"])) < 1e-12
+        np.testing.assert_allclose(mrec, g[f"mrec{tag}"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(mpre, g[f"mpre{tag}"], rtol=0, atol=1e-12)
