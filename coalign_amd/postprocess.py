@@ -143,6 +143,35 @@ class VoxelPostprocessor:
             done.record(stream)
         return PostProcessHandle(self, buf, done)
 
+    # ------------------------------------------------------------------------------------------ ground truth (host)
+    def generate_gt_bbx(self, data_dict: dict) -> torch.Tensor:
+        """Ground-truth corners [G, 8, 3] for evaluation (base_postprocessor.py:46-106): every agent's masked object
+        centres become corners, are projected with ``transformation_matrix_clean``, de-duplicated by object id (first
+        occurrence wins) and kept only when all eight corners -- z included -- fall inside ``gt_range``.  At most a few
+        hundred boxes per frame, once per frame, outside the timed path: plain torch on whatever device the labels are on."""
+        order = self.params["order"]
+        boxes, ids = [], []
+        for cav in data_dict.values():
+            centre = cav["object_bbx_center"][cav["object_bbx_mask"] == 1].float()
+            T = cav["transformation_matrix_clean"].to(centre.device, torch.float32)
+            b = centre[:, [0, 1, 2, 5, 4, 3, 6]] if order == "hwl" else centre
+            signs = centre.new_tensor([[1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, -1],
+                                       [1, -1, 1], [1, 1, 1], [-1, 1, 1], [-1, -1, 1]]) / 2
+            local = b[:, None, 3:6] * signs[None]
+            c, s = torch.cos(b[:, 6])[:, None], torch.sin(b[:, 6])[:, None]
+            x = local[..., 0] * c - local[..., 1] * s + b[:, None, 0]
+            y = local[..., 0] * s + local[..., 1] * c + b[:, None, 1]
+            z = local[..., 2] + b[:, None, 2]
+            homo = torch.stack((x, y, z, torch.ones_like(x)), dim=1)               # [n, 4, 8]
+            boxes.append(torch.matmul(T, homo)[:, :3, :].transpose(1, 2))
+            ids += list(cav["object_ids"])
+        boxes = torch.vstack(boxes)
+        boxes = boxes[[ids.index(i) for i in set(ids)]]
+        lo = torch.tensor(self.params["gt_range"][0:3], dtype=torch.float64, device=boxes.device)
+        hi = torch.tensor(self.params["gt_range"][3:6], dtype=torch.float64, device=boxes.device)
+        b64 = boxes.double()
+        return boxes[((b64 >= lo) & (b64 <= hi)).all(dim=2).all(dim=1)]
+
     @staticmethod
     def delta_to_boxes3d(deltas: torch.Tensor, anchors: torch.Tensor) -> torch.Tensor:
         """Dense decode of every anchor, [N, 7A, H, W] -> [N, H*W*A, 7] (voxel_postprocessor.py:405-450); plain

@@ -729,3 +729,20 @@ def calculate_ap(result_stat, iou):
     rec = [float(t) / st["gt"] for t in tp]
     prec = [float(t) / (f + t) for t, f in zip(tp, fp)]
     return voc_ap(rec, prec)
+
+
+def generate_gt_bbx(data_dict: dict, order: str, gt_range) -> torch.Tensor:
+    """opencood/data_utils/post_processor/base_postprocessor.py:46-106: per agent, masked object centres -> corners ->
+    projected with the clean transform; duplicates removed by object id (first occurrence, ids visited in ``set`` order);
+    kept only if all 8 corners lie inside ``gt_range`` including z (box_utils.py:384-421, compared in float64 after numpy
+    promotes the float32 corners against the Python-float range)."""
+    boxes, ids = [], []
+    for cav in data_dict.values():
+        centre = cav["object_bbx_center"][cav["object_bbx_mask"] == 1]
+        boxes.append(project_box3d(boxes_to_corners_3d(centre, order).float(), cav["transformation_matrix_clean"]))
+        ids += list(cav["object_ids"])
+    boxes = torch.vstack(boxes)
+    boxes = boxes[[ids.index(x) for x in set(ids)]].numpy()
+    lo, hi = np.asarray(gt_range[0:3]), np.asarray(gt_range[3:6])
+    inside = ((boxes >= lo) & (boxes <= hi)).all(axis=2).sum(axis=1) >= 8
+    return torch.from_numpy(boxes[inside])

@@ -294,6 +294,24 @@ def main():
         tag = str(int(thr * 100))
         ev.update({f"tp{tag}": np.array(stat[thr]["tp"]), f"fp{tag}": np.array(stat[thr]["fp"]), f"gtn{tag}": stat[thr]["gt"],
                    f"scores{tag}": np.array(stat[thr]["score"]), f"ap{tag}": ap, f"mrec{tag}": np.array(mrec), f"mpre{tag}": np.array(mpre)})
+    # ground-truth boxes the way the inference loop builds them (base_postprocessor.py:46-106): two agents, shared ids
+    from opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor as RefPost
+    hg = load_hypes(YAML_COALIGN)
+    rp = RefPost(hg["postprocess"], train=False)
+    gt_in = {}
+    for c, (ids, T) in enumerate((([3, 7, 11, 20, 21, 40], np.eye(4)),
+                                  ([7, 50, 3, 60, 61], x_to_world([6.0, -2.0, 0.1, 0.0, 35.0, 0.0])))):
+        M = 100
+        centre = np.zeros((M, 7), dtype=np.float32)
+        mask = np.zeros(M, dtype=np.float32)
+        mask[: len(ids)] = 1
+        centre[: len(ids), 0] = rs.uniform(-150, 150, len(ids)); centre[: len(ids), 1] = rs.uniform(-45, 45, len(ids))
+        centre[: len(ids), 2] = rs.uniform(-2.5, 0.5, len(ids)); centre[: len(ids), 3] = 1.56
+        centre[: len(ids), 4] = 2.0; centre[: len(ids), 5] = 4.5; centre[: len(ids), 6] = rs.uniform(-3.1, 3.1, len(ids))
+        gt_in[c] = {"transformation_matrix_clean": torch.from_numpy(T.astype(np.float32)), "object_bbx_center": torch.from_numpy(centre),
+                    "object_bbx_mask": torch.from_numpy(mask), "object_ids": list(ids)}
+        ev.update({f"gtgen_centre{c}": centre, f"gtgen_mask{c}": mask, f"gtgen_ids{c}": np.array(ids), f"gtgen_T{c}": T.astype(np.float32)})
+    ev["gtgen_out"] = rp.generate_gt_bbx(gt_in)
     save("eval.npz", **ev)
 
     # ------------------------------------------------------------------ full-size pillar path + fusion (samples only)

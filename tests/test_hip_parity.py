@@ -483,3 +483,19 @@ def test_evaluation_on_device_vs_reference(golden):
         tag = str(int(thr * 100))
         assert stat[thr]["tp"] == list(g[f"tp{tag}"]) and stat[thr]["fp"] == list(g[f"fp{tag}"]) and stat[thr]["gt"] == int(g[f"gtn{tag}"])
         assert abs(ev.calculate_ap(stat, thr)[0] - float(g[f"ap{tag}"])) < 1e-12
+
+
+def test_synthetic_inference_loop_ap_vs_oracle():
+    """The reference's inference loop on seeded frames with planted ground truth (tools/inference_synthetic.py): the
+    gfx950 path and the CPU oracle give the same TP/FP sequence and the same AP at every IoU threshold."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("inference_synthetic", os.path.join(os.path.dirname(__file__), "..", "tools", "inference_synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rep = mod.run("mini_coalign", frames=4, agents=3, pillars=150, check_oracle=True)
+    assert rep["detections"] > 8, rep
+    assert rep["tp_fp_identical"], rep
+    for k, v in rep["hip"].items():
+        assert abs(v - rep["oracle"][k]) < 1e-12, rep
+    assert 0.0 < rep["hip"]["ap30"] <= 1.0

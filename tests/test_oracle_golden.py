@@ -210,3 +210,22 @@ def test_evaluation_host_logic_matches_reference(golden):
         assert abs(ap - float(g[f"ap{tag}"])) < 1e-12
         np.testing.assert_allclose(mrec, g[f"mrec{tag}"], rtol=0, atol=1e-12)
         np.testing.assert_allclose(mpre, g[f"mpre{tag}"], rtol=0, atol=1e-12)
+
+
+def _gt_inputs(g):
+    return {c: {"transformation_matrix_clean": T(g[f"gtgen_T{c}"]), "object_bbx_center": T(g[f"gtgen_centre{c}"]),
+                "object_bbx_mask": T(g[f"gtgen_mask{c}"]), "object_ids": g[f"gtgen_ids{c}"].tolist()} for c in (0, 1)}
+
+
+def test_generate_gt_bbx_matches_reference(golden):
+    g = golden("eval.npz")
+    rng = [-140.8, -40, -3, 140.8, 40, 1]
+    got = oracle.generate_gt_bbx(_gt_inputs(g), "hwl", rng)
+    assert np.array_equal(got.numpy(), g["gtgen_out"])
+    assert 0 < len(got) < 9          # 9 distinct ids, some outside the range: both the de-dup and the filter fired
+    from coalign_amd.config import builtin_config
+    from coalign_amd.postprocess import build_postprocessor
+    post = build_postprocessor(builtin_config("opv2v_coalign")["postprocess"], train=False)
+    mine = post.generate_gt_bbx(_gt_inputs(g))
+    assert mine.shape == got.shape
+    np.testing.assert_allclose(mine.numpy(), g["gtgen_out"], rtol=0, atol=2e-5)
