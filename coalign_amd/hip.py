@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_uint32, c_void_p
 
 from . import build as _build
 
@@ -34,6 +34,10 @@ SIGNATURES = {
     "coalign_iou_rotated_matrix": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P]),
     "coalign_boxes_iou_bev": (c_int, [P, c_int, P, c_int, P, P]),
     "coalign_bias_act": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "coalign_voxelize_capacity": (c_int64, [c_int64, c_int, POINTER(c_double), POINTER(c_double), c_int]),
+    "coalign_voxelize_workspace_bytes": (c_size_t, [POINTER(c_int64), c_int, POINTER(c_double), POINTER(c_double), c_int]),
+    "coalign_voxelize": (c_int, [P, POINTER(c_int64), c_int, POINTER(c_double), POINTER(c_double), c_int, c_int, c_int,
+                                 POINTER(c_double), P, P, P, c_int64, P, P, c_size_t, P]),
 }
 
 

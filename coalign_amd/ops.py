@@ -246,3 +246,39 @@ def bias_act_(y: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[
     HW = y.numel() // max(1, N * C)
     hip.check(hip.lib().coalign_bias_act(_ptr(y), _ptr(bias), _ptr(residual), N, C, HW, int(relu), _stream()), "coalign_bias_act")
     return y
+
+
+VOX_FILTER_EGO, VOX_FILTER_RANGE = 1, 2   # COALIGN_VOX_FILTER_* of include/coalign_amd.h
+
+
+def voxelize(points: torch.Tensor, cloud_offsets: Sequence[int], voxel_size: Sequence[float], lidar_range: Sequence[float],
+             max_points: int, max_voxels: int, ego_filter: bool = False, filter_range: Optional[Sequence[float]] = None):
+    """points [N, 4] (the clouds of a batch concatenated; ``cloud_offsets`` = host ints [n_clouds + 1]) ->
+    (voxels [cap, max_points, 4], coords [cap, 4] int32 (cloud, z, y, x), num_points [cap] int32, counts [n_clouds + 1] int32).
+    Only the first ``counts[-1]`` rows are meaningful; nothing here synchronises -- the caller slices after reading counts."""
+    _need_gpu(points)
+    L = hip.lib()
+    pts = _f32c(points)
+    if pts.dim() != 2 or pts.shape[1] != 4:
+        raise ValueError(f"points must be [N, 4], got {tuple(pts.shape)}")
+    n_clouds = len(cloud_offsets) - 1
+    if int(cloud_offsets[-1]) != pts.shape[0]:
+        raise ValueError("cloud_offsets[-1] must equal the number of points")
+    off = (ctypes.c_int64 * (n_clouds + 1))(*[int(o) for o in cloud_offsets])
+    vs, rg = _dbl3(voxel_size), (ctypes.c_double * 6)(*[float(v) for v in lidar_range])
+    fr = None if filter_range is None else (ctypes.c_double * 6)(*[float(v) for v in filter_range])
+    flags = (VOX_FILTER_EGO if ego_filter else 0) | (VOX_FILTER_RANGE if filter_range is not None else 0)
+    cap = L.coalign_voxelize_capacity(pts.shape[0], n_clouds, vs, rg, int(max_voxels))
+    if cap < 0:
+        raise ValueError("invalid voxel grid / max_voxels")
+    dev = pts.device
+    voxels = torch.empty((cap, max_points, 4), dtype=torch.float32, device=dev)
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    num = torch.empty((cap,), dtype=torch.int32, device=dev)
+    counts = torch.empty((n_clouds + 1,), dtype=torch.int32, device=dev)
+    ws_bytes = L.coalign_voxelize_workspace_bytes(off, n_clouds, vs, rg, int(max_voxels))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    with _Timed("voxelize"):
+        hip.check(L.coalign_voxelize(_ptr(pts), off, n_clouds, vs, rg, int(max_points), int(max_voxels), flags, fr, _ptr(voxels),
+                                     _ptr(coords), _ptr(num), cap, _ptr(counts), _ptr(ws), ws_bytes, _stream()), "coalign_voxelize")
+    return voxels, coords, num, counts

@@ -120,3 +120,41 @@ def fill_parameters_(module: torch.nn.Module, seed: int = 0, cls_bias: float = -
                     fan_in = t.shape[0]
                 v = torch.randn(shape, generator=g) * (1.5 / fan_in) ** 0.5
             t.copy_(v.to(t.dtype))
+
+
+def make_point_cloud(seed: int, beams: int = 64, azimuth_steps: int = 1800, sensor_height: float = 1.9, max_range: float = 120.0,
+                     n_boxes: int = 30, dropout: float = 0.3) -> np.ndarray:
+    """A spinning-lidar sweep [N, 4] float32 (x, y, z, intensity) in the sensor frame, N ~ 60-70 k like one OPV2V cav
+    (64 beams x 0.2 deg): flat ground, a street canyon of two walls, and axis-aligned vehicle-sized boxes -- so that, like
+    real data, pillars near the sensor and on vertical surfaces hold far more than 32 points while most hold a handful.
+    The point order is the sensor's firing order (azimuth major), i.e. spatially coherent, not shuffled."""
+    rs = np.random.RandomState(seed)
+    pitch = np.radians(np.linspace(-24.8, 2.0, beams))
+    az = np.radians(np.arange(azimuth_steps) * (360.0 / azimuth_steps))
+    dx, dy, dz = (np.cos(pitch)[None] * np.cos(az)[:, None]), (np.cos(pitch)[None] * np.sin(az)[:, None]), np.broadcast_to(np.sin(pitch)[None], (azimuth_steps, beams))
+    t = np.full(dx.shape, np.inf)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tg = np.where(dz < 0, -sensor_height / dz, np.inf)                       # ground
+        t = np.minimum(t, tg)
+        for wall_y in (rs.uniform(12, 30), -rs.uniform(12, 30)):                 # building fronts, 6 m high, with gaps
+            tw = wall_y / dy
+            zw, xw = tw * dz, tw * dx
+            solid = np.sin(xw / rs.uniform(6, 14) + rs.uniform(0, 6)) > -0.2
+            t = np.minimum(t, np.where((tw > 0) & (zw < 6.0 - sensor_height) & solid, tw, np.inf))
+        for _ in range(n_boxes):                                                 # vehicles: slab test against an AABB
+            cx, cy = rs.uniform(-90, 90), rs.uniform(-8, 8)
+            lo = np.array([cx - 2.3, cy - 1.0, -sensor_height])
+            hi = np.array([cx + 2.3, cy + 1.0, -sensor_height + 1.6])
+            if lo[0] < 3 and hi[0] > -3 and lo[1] < 1.5 and hi[1] > -1.5:
+                continue                                                          # not on top of the sensor
+            t1, t2 = lo[0] / dx, hi[0] / dx
+            tn, tf = np.minimum(t1, t2), np.maximum(t1, t2)
+            t1, t2 = lo[1] / dy, hi[1] / dy
+            tn, tf = np.maximum(tn, np.minimum(t1, t2)), np.minimum(tf, np.maximum(t1, t2))
+            t1, t2 = lo[2] / dz, hi[2] / dz
+            tn, tf = np.maximum(tn, np.minimum(t1, t2)), np.minimum(tf, np.maximum(t1, t2))
+            t = np.minimum(t, np.where((tn <= tf) & (tn > 0), tn, np.inf))
+    hit = np.isfinite(t) & (t < max_range) & (rs.uniform(0, 1, t.shape) > dropout)
+    t = np.where(hit, t, 0.0) + rs.normal(0, 0.02, t.shape)
+    pts = np.stack([t * dx, t * dy, t * dz, rs.uniform(0, 1, t.shape)], axis=-1)[hit]
+    return np.ascontiguousarray(pts, dtype=np.float32)

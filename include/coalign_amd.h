@@ -169,6 +169,40 @@ int coalign_boxes_iou_bev(const float *boxes_a, int Na, const float *boxes_b, in
  */
 int coalign_bias_act(float *y, const float *bias, const float *residual, int N, int C, int HW, int relu, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * (7) Points -> pillars voxeliser, the step in front of (1).
+ *     Replaces SpVoxelPreprocessor.preprocess + collate_batch
+ *     (opencood/data_utils/pre_processor/sp_voxel_preprocessor.py:62-85, 107-174), i.e. spconv's CPU
+ *     VoxelGeneratorV2 / Point2VoxelCPU3d run per cav in the DataLoader workers, and optionally the two point filters in
+ *     front of it (opencood/utils/pcd_utils.py:41-66 mask_points_by_range, :69-88 mask_ego_points; call sites
+ *     intermediate_fusion_dataset.py:96-117, late_fusion_dataset.py:157-170).  shuffle_points (a random permutation) stays
+ *     with the caller: the output is a deterministic function of the point ORDER, exactly like the sequential CPU loop.
+ *
+ * points         [N, 4] float32 (x, y, z, intensity), the clouds of one batch concatenated; 16-byte aligned
+ * cloud_offsets  HOST int64 [n_clouds + 1], cloud c = points[cloud_offsets[c] : cloud_offsets[c + 1]], n_clouds <= 16
+ * voxel_size[3], range[6] (xmin ymin zmin xmax ymax zmax): HOST float64, used as float32 like spconv does;
+ *                grid = round((max - min) / voxel); a point is kept iff 0 <= floor((p - min) / voxel) < grid on all axes
+ * max_points     points kept per voxel (first come, point order), <= 64;  max_voxels  voxels opened per cloud (cells met
+ *                after that are dropped, points of already open cells are still taken)
+ * flags          COALIGN_VOX_FILTER_EGO and / or COALIGN_VOX_FILTER_RANGE (filter_range: HOST float64 [6], strict
+ *                inequalities evaluated in float32); a filtered point is skipped, which equals filtering first
+ * voxels         [capacity, max_points, 4] out, rows past a voxel's count are zero     (`voxel_features`)
+ * coords         [capacity, 4] int32 out = (cloud, z, y, x)                           (`voxel_coords` after collate)
+ * num_points     [capacity] int32 out                                                 (`voxel_num_points`)
+ * voxel_counts   [n_clouds + 1] int32 out (device): voxels of each cloud, then their sum M; cloud c owns the rows
+ *                [sum(counts[:c]), sum(counts[:c + 1])), numbered by first appearance in point order.  Rows >= M are
+ *                not written.  capacity >= coalign_voxelize_capacity(...) = min(N, n_clouds * min(cells, max_voxels)).
+ */
+#define COALIGN_VOX_FILTER_EGO 1
+#define COALIGN_VOX_FILTER_RANGE 2
+int64_t coalign_voxelize_capacity(int64_t n_points, int n_clouds, const double *voxel_size, const double *range, int max_voxels);
+size_t coalign_voxelize_workspace_bytes(const int64_t *cloud_offsets, int n_clouds, const double *voxel_size,
+                                        const double *range, int max_voxels);
+int coalign_voxelize(const float *points, const int64_t *cloud_offsets, int n_clouds, const double *voxel_size,
+                     const double *range, int max_points, int max_voxels, int flags, const double *filter_range,
+                     float *voxels, int32_t *coords, int32_t *num_points, int64_t capacity, int32_t *voxel_counts,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -519,13 +519,13 @@ _NMS_LIB = None
 
 
 def build_c(force: bool = False) -> str:
-    """Compile oracle/rotated_nms.c -> oracle/_build/librotated_nms.so with gcc."""
+    """Compile oracle/rotated_nms.c + oracle/voxelize.c -> oracle/_build/librotated_nms.so with gcc."""
     out_dir = os.path.join(_HERE, "_build")
     so = os.path.join(out_dir, "librotated_nms.so")
-    src = os.path.join(_HERE, "rotated_nms.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "rotated_nms.c"), os.path.join(_HERE, "voxelize.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         os.makedirs(out_dir, exist_ok=True)
-        subprocess.check_call(["gcc", "-O2", "-std=c99", "-ffp-contract=off", "-shared", "-fPIC", src, "-o", so, "-lm"])
+        subprocess.check_call(["gcc", "-O2", "-std=c99", "-ffp-contract=off", "-shared", "-fPIC", *srcs, "-o", so, "-lm"])
     return so
 
 
@@ -544,6 +544,10 @@ def _nms_lib():
         lib.oracle_pcdet_overlap.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.oracle_pcdet_nms.restype = ctypes.c_int
         lib.oracle_pcdet_nms.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+        lib.oracle_points_to_voxel.restype = ctypes.c_int
+        lib.oracle_points_to_voxel.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p]
         _NMS_LIB = lib
     return _NMS_LIB
 
@@ -746,3 +750,79 @@ def generate_gt_bbx(data_dict: dict, order: str, gt_range) -> torch.Tensor:
     lo, hi = np.asarray(gt_range[0:3]), np.asarray(gt_range[3:6])
     inside = ((boxes >= lo) & (boxes <= hi)).all(axis=2).sum(axis=1) >= 8
     return torch.from_numpy(boxes[inside])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# points -> pillars.  spconv is a third-party dependency absent from /root/reference and from this
+# image: PARITY UNPINNED for the voxel generator itself (see oracle/voxelize.c); the two point filters are the reference's
+# own numpy code and are pinned by tests/golden/points.npz.
+
+def mask_points_by_range(points: np.ndarray, limit_range) -> np.ndarray:
+    """opencood/utils/pcd_utils.py:41-66: strict inequalities on x, y, z; float32 points against Python floats compare in
+    float32 (NumPy weak-scalar promotion)."""
+    lo, hi = np.asarray(limit_range[0:3], dtype=np.float32), np.asarray(limit_range[3:6], dtype=np.float32)
+    m = np.ones(len(points), dtype=bool)
+    for j in range(3):
+        m &= (points[:, j] > lo[j]) & (points[:, j] < hi[j])
+    return points[m]
+
+
+def mask_ego_points(points: np.ndarray) -> np.ndarray:
+    """pcd_utils.py:69-88: drop the returns from the ego vehicle's own body (closed box in x, y)."""
+    f = np.float32
+    m = (points[:, 0] >= f(-1.95)) & (points[:, 0] <= f(2.95)) & (points[:, 1] >= f(-1.1)) & (points[:, 1] <= f(1.1))
+    return points[~m]
+
+
+def voxel_grid_size(voxel_size, lidar_range) -> np.ndarray:
+    """sp_voxel_preprocessor.py:40-42 / spconv: round((max - min) / voxel) in float32, (x, y, z)."""
+    r, v = np.asarray(lidar_range, dtype=np.float32), np.asarray(voxel_size, dtype=np.float32)
+    return np.round((r[3:6] - r[0:3]) / v).astype(np.int32)
+
+
+def points_to_voxel(points: np.ndarray, voxel_size, lidar_range, max_points: int, max_voxels: int):
+    """C restatement of spconv's sequential generator -> (voxels [M, max_points, 4], coords [M, 3] zyx int32, num [M] int32)."""
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    assert pts.ndim == 2 and pts.shape[1] == 4
+    vs, rg = np.asarray(voxel_size, dtype=np.float32), np.asarray(lidar_range, dtype=np.float32)
+    grid = voxel_grid_size(voxel_size, lidar_range)
+    cap = min(len(pts), max_voxels)
+    voxels = np.zeros((cap, max_points, 4), dtype=np.float32)
+    coors = np.zeros((cap, 3), dtype=np.int32)
+    num = np.zeros(cap, dtype=np.int32)
+    scratch = np.empty(int(grid[0]) * int(grid[1]) * int(grid[2]), dtype=np.int32)
+    m = _nms_lib().oracle_points_to_voxel(pts.ctypes.data, len(pts), vs.ctypes.data, rg.ctypes.data, grid.ctypes.data, max_points,
+                                          max_voxels, voxels.ctypes.data, coors.ctypes.data, num.ctypes.data, scratch.ctypes.data)
+    return voxels[:m], coors[:m], num[:m]
+
+
+def points_to_voxel_python(points: np.ndarray, voxel_size, lidar_range, max_points: int, max_voxels: int):
+    """The same loop in plain Python (small inputs only) -- cross-checks the C build."""
+    vs, rg = np.asarray(voxel_size, dtype=np.float32), np.asarray(lidar_range, dtype=np.float32)
+    grid = voxel_grid_size(voxel_size, lidar_range)
+    table, voxels, coors, num = {}, [], [], []
+    for p in np.asarray(points, dtype=np.float32):
+        c = np.floor((p[:3] - rg[:3]) / vs)
+        if not np.all((c >= 0) & (c < grid)):
+            continue
+        key = (int(c[2]), int(c[1]), int(c[0]))
+        v = table.get(key)
+        if v is None:
+            if len(voxels) >= max_voxels:
+                continue
+            v = table[key] = len(voxels)
+            voxels.append(np.zeros((max_points, 4), dtype=np.float32)); coors.append(key); num.append(0)
+        if num[v] < max_points:
+            voxels[v][num[v]] = p
+            num[v] += 1
+    if not voxels:
+        return np.zeros((0, max_points, 4), np.float32), np.zeros((0, 3), np.int32), np.zeros(0, np.int32)
+    return np.stack(voxels), np.asarray(coors, dtype=np.int32), np.asarray(num, dtype=np.int32)
+
+
+def collate_voxels(per_cloud):
+    """SpVoxelPreprocessor.collate_batch_list (sp_voxel_preprocessor.py:107-147): concatenate and prefix the cloud index."""
+    feats = np.concatenate([v for v, _, _ in per_cloud])
+    num = np.concatenate([n for _, _, n in per_cloud])
+    coords = np.concatenate([np.pad(c, ((0, 0), (1, 0)), mode="constant", constant_values=i) for i, (_, c, _) in enumerate(per_cloud)])
+    return feats, coords, num

@@ -12,7 +12,7 @@ shrunk for the mini cases), ``PillarVFE``, ``PointPillarScatter``, ``normalize_p
 
 Optional third-party modules the reference imports at module scope but that are absent here are
 replaced by inert stubs (icecream, pyquaternion, turtle, cv2, open3d, the un-built Cython
-``box_overlaps``).  ``shapely.geometry.Polygon`` -- the one stub that *computes* something -- is backed
+``box_overlaps``, pypcd).  ``shapely.geometry.Polygon`` -- the one stub that *computes* something -- is backed
 by the oracle's fp64 clipping routine: this pins the reference's NMS control flow (argsort, top-1000,
 float32 IoU array, strict ``>``) but NOT the GEOS area arithmetic (parity unpinned).
 """
@@ -73,6 +73,7 @@ def install_stubs():
     mod("turtle", update=None)
     mod("cv2")
     mod("open3d")
+    mod("pypcd").pypcd = mod("pypcd.pypcd")
     mod("opencood.utils.box_overlaps", bbox_overlaps=None)
     sys.path.insert(0, REF)
 
@@ -313,6 +314,19 @@ def main():
         ev.update({f"gtgen_centre{c}": centre, f"gtgen_mask{c}": mask, f"gtgen_ids{c}": np.array(ids), f"gtgen_T{c}": T.astype(np.float32)})
     ev["gtgen_out"] = rp.generate_gt_bbx(gt_in)
     save("eval.npz", **ev)
+
+    # ------------------------------------------------------------------ point filters in front of the voxeliser (next-1)
+    from opencood.utils import pcd_utils
+    rs = np.random.RandomState(41)
+    cloud = rs.uniform([-150, -45, -4, 0], [150, 45, 2, 1], (1500, 4)).astype(np.float32)
+    cloud[:200, :2] = rs.uniform([-3, -2], [4, 2], (200, 2))                                   # around the ego body
+    edge = np.float32([-140.8, -40, -3, 140.8, 40, 1, -1.95, 2.95, -1.1, 1.1])
+    cloud[200:210, 0] = [edge[0], edge[3], np.nextafter(edge[0], np.float32(0)), np.nextafter(edge[3], np.float32(0)), edge[6], edge[7],
+                         np.nextafter(edge[6], np.float32(-9)), np.nextafter(edge[7], np.float32(9)), 0.5, 0.5]
+    cloud[200:210, 1] = [0, 0, 0, 0, 0.3, 0.3, 0.3, 0.3, edge[8], np.nextafter(edge[9], np.float32(9))]
+    cloud[200:210, 2] = -1
+    save("points.npz", cloud=cloud, range_masked=pcd_utils.mask_points_by_range(cloud, [-140.8, -40, -3, 140.8, 40, 1]),
+         ego_masked=pcd_utils.mask_ego_points(cloud))
 
     # ------------------------------------------------------------------ full-size pillar path + fusion (samples only)
     hf = load_hypes(YAML_COALIGN)

@@ -499,3 +499,116 @@ def test_synthetic_inference_loop_ap_vs_oracle():
     for k, v in rep["hip"].items():
         assert abs(v - rep["oracle"][k]) < 1e-12, rep
     assert 0.0 < rep["hip"]["ap30"] <= 1.0
+
+
+# ------------------------------------------------------------------------------------------------ points -> pillars (next-1)
+OPV2V_RANGE, OPV2V_VOXEL = [-140.8, -40, -3, 140.8, 40, 1], [0.4, 0.4, 4]
+
+
+def _voxelize_ref(clouds, max_points, max_voxels, ego=False, frange=None, rng=OPV2V_RANGE, vs=OPV2V_VOXEL):
+    per = []
+    for c in clouds:
+        if frange is not None:
+            c = oracle.mask_points_by_range(c, frange)
+        if ego:
+            c = oracle.mask_ego_points(c)
+        per.append(oracle.points_to_voxel(c, vs, rng, max_points, max_voxels))
+    return oracle.collate_voxels(per), [len(p[0]) for p in per]
+
+
+def _voxelize_hip(clouds, max_points, max_voxels, ego=False, frange=None, rng=OPV2V_RANGE, vs=OPV2V_VOXEL):
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).tolist()
+    pts = T(np.concatenate(clouds).astype(np.float32)).to(DEV)
+    v, c, n, counts = ops.voxelize(pts, off, vs, rng, max_points, max_voxels, ego_filter=ego, filter_range=frange)
+    counts = counts.cpu().tolist()
+    m = counts[-1]
+    return (v[:m].cpu().numpy(), c[:m].cpu().numpy(), n[:m].cpu().numpy()), counts[:-1]
+
+
+def _same_voxels(got, ref):
+    (gv, gc, gn), gcounts = got
+    (rv, rc, rn), rcounts = ref
+    assert gcounts == rcounts
+    assert np.array_equal(gc, rc) and np.array_equal(gn, rn)
+    assert np.array_equal(gv.view(np.uint32), rv.view(np.uint32))       # bit-exact copies, zero padding included
+
+
+def test_voxelize_full_sweeps_vs_oracle():
+    """Five synthetic 64-beam sweeps (~75 k points each, pillars holding from 1 to several hundred points) in one call:
+    voxel numbering, the first-32-in-point-order selection, coords and counts are bit-identical to the sequential CPU loop;
+    shuffled order (what the reference feeds) likewise; and the run is repeatable."""
+    from coalign_amd.synthetic import make_point_cloud
+    clouds = [make_point_cloud(40 + i) for i in range(5)]
+    ref = _voxelize_ref(clouds, 32, 70000, ego=True)
+    got = _voxelize_hip(clouds, 32, 70000, ego=True)
+    _same_voxels(got, ref)
+    assert max(ref[0][2]) == 32 and sum(ref[1]) > 20000
+    _same_voxels(_voxelize_hip(clouds, 32, 70000, ego=True), got)
+    rs = np.random.RandomState(0)
+    shuffled = [c[rs.permutation(len(c))] for c in clouds[:2]]
+    _same_voxels(_voxelize_hip(shuffled, 32, 70000, ego=True), _voxelize_ref(shuffled, 32, 70000, ego=True))
+    # late-fusion order of filters (range mask, then ego mask; late_fusion_dataset.py:157-170) and a tighter filter range
+    fr = [-70.4, -40, -3, 70.4, 40, 1]
+    _same_voxels(_voxelize_hip(clouds[:2], 32, 70000, ego=True, frange=fr, rng=fr), _voxelize_ref(clouds[:2], 32, 70000, ego=True, frange=fr, rng=fr))
+
+
+def test_voxelize_edge_cases(golden):
+    g = golden("points.npz")
+    cloud = g["cloud"]
+    rs = np.random.RandomState(5)
+    blob = rs.normal([5, 3, -1, 0.5], [0.5, 0.5, 0.3, 0.1], (6000, 4)).astype(np.float32)       # cells with 100s of points
+    spike = np.tile(np.float32([[20.1, 10.1, -1, 0.5]]), (5000, 1)) + rs.uniform(0, 0.1, (5000, 4)).astype(np.float32)  # one cell, 5000 points
+    # (a) boundary points, the reference's own filters pinned through golden masks
+    (gv, gc, gn), _ = _voxelize_hip([cloud], 32, 70000, ego=True)
+    (rv, rc, rn) = oracle.points_to_voxel(g["ego_masked"], OPV2V_VOXEL, OPV2V_RANGE, 32, 70000)
+    assert np.array_equal(gv, rv) and np.array_equal(gc[:, 1:], rc) and np.array_equal(gn, rn)
+    (gv, gc, gn), _ = _voxelize_hip([cloud], 32, 70000, frange=OPV2V_RANGE)
+    (rv, rc, rn) = oracle.points_to_voxel(g["range_masked"], OPV2V_VOXEL, OPV2V_RANGE, 32, 70000)
+    assert np.array_equal(gv, rv) and np.array_equal(gc[:, 1:], rc) and np.array_equal(gn, rn)
+    # (b) max_voxels reached: later cells dropped, later points of open cells still taken; small max_points; ragged clouds incl. empty
+    mixed = np.concatenate([cloud, blob, spike])[rs.permutation(len(cloud) + 11000)]
+    for max_points, max_voxels in ((32, 70000), (5, 300), (1, 7), (64, 50)):
+        clouds = [mixed, mixed[:0], spike, mixed[:1], blob[:1025]]
+        _same_voxels(_voxelize_hip(clouds, max_points, max_voxels), _voxelize_ref(clouds, max_points, max_voxels))
+    # (c) 3-D grid (SECOND-style voxels, nz > 1) and an all-outside cloud
+    vs3, rng3 = [0.1, 0.1, 0.1], [-12.8, -6.4, -3, 12.8, 6.4, 1]
+    near = np.concatenate([blob, cloud[:300]])
+    _same_voxels(_voxelize_hip([near, blob], 5, 16000, rng=rng3, vs=vs3), _voxelize_ref([near, blob], 5, 16000, rng=rng3, vs=vs3))
+    far = cloud.copy(); far[:, 0] += 1000
+    (gv, gc, gn), counts = _voxelize_hip([far, far], 32, 70000)
+    assert counts == [0, 0] and len(gv) == 0
+    # (d) argument errors are reported, not executed
+    from coalign_amd import hip
+    with pytest.raises(hip.CoalignHipError):
+        ops.voxelize(T(cloud).to(DEV), [0, len(cloud)], OPV2V_VOXEL, OPV2V_RANGE, 65, 70000)
+    with pytest.raises(hip.CoalignHipError):
+        ops.voxelize(T(cloud), [0, len(cloud)], OPV2V_VOXEL, OPV2V_RANGE, 32, 70000)
+
+
+def test_voxelize_feeds_the_detector():
+    """points -> pillars -> PillarVFE -> canvas on the device equals the oracle chain on the CPU."""
+    from coalign_amd.preprocess import build_preprocessor
+    from coalign_amd.synthetic import make_point_cloud
+    h = builtin_config("opv2v_coalign")
+    pre = build_preprocessor(h["preprocess"], train=False)
+    clouds = [make_point_cloud(60 + i) for i in range(2)]
+    out = pre.preprocess_clouds(clouds, ego_filter=True)
+    (rv, rc, rn), counts = _voxelize_ref(clouds, 32, 70000, ego=True)
+    assert out["voxel_counts"] == counts
+    assert np.array_equal(out["voxel_features"].cpu().numpy(), rv) and np.array_equal(out["voxel_coords"].cpu().numpy(), rc)
+    single = pre.preprocess(clouds[0])
+    assert single["voxel_coords"].shape[1] == 3 and single["voxel_features"].shape[0] >= counts[0]   # no ego filter here
+    coll = pre.collate_batch([single, single])
+    assert coll["voxel_coords"].shape[1] == 4 and int(coll["voxel_coords"][:, 0].max()) == 1
+    model = build_model(h)
+    fill_parameters_(model, seed=0)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    bd = {"voxel_features": out["voxel_features"], "voxel_coords": out["voxel_coords"], "voxel_num_points": out["voxel_num_points"],
+          "record_len": torch.tensor([2])}
+    with torch.no_grad():
+        canvas = model.scatter(model.pillar_vfe(bd))["spatial_features"]
+    margs = h["model"]["args"]
+    pf = oracle.pillar_vfe(T(rv), T(rn), T(rc), sd, margs["voxel_size"], margs["lidar_range"])
+    ref_canvas = oracle.scatter(pf, T(rc), 2, 704, 200)
+    feat_close(canvas, ref_canvas, what="canvas from device voxels")

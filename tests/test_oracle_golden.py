@@ -229,3 +229,32 @@ def test_generate_gt_bbx_matches_reference(golden):
     mine = post.generate_gt_bbx(_gt_inputs(g))
     assert mine.shape == got.shape
     np.testing.assert_allclose(mine.numpy(), g["gtgen_out"], rtol=0, atol=2e-5)
+
+
+def test_point_filters_match_reference(golden):
+    """mask_points_by_range / mask_ego_points (pcd_utils.py:41-88) incl. points exactly on and one ulp off every boundary."""
+    g = golden("points.npz")
+    assert np.array_equal(oracle.mask_points_by_range(g["cloud"], [-140.8, -40, -3, 140.8, 40, 1]), g["range_masked"])
+    assert np.array_equal(oracle.mask_ego_points(g["cloud"]), g["ego_masked"])
+    assert len(g["ego_masked"]) < len(g["cloud"]) and len(g["range_masked"]) < len(g["cloud"])
+
+
+def test_voxel_generator_restatement_is_self_consistent(golden):
+    """spconv is absent (parity unpinned): the C loop is cross-checked against the plain-Python transcription of the same
+    published loop and against the invariants of the output contract."""
+    cloud = golden("points.npz")["cloud"]
+    rs = np.random.RandomState(3)
+    dense = np.concatenate([cloud, rs.normal([5, 3, -1, 0.5], [0.6, 0.6, 0.3, 0.1], (1500, 4)).astype(np.float32)])
+    for max_points, max_voxels in ((32, 70000), (5, 16000), (3, 40)):
+        v, c, n = oracle.points_to_voxel(dense, [0.4, 0.4, 4], [-140.8, -40, -3, 140.8, 40, 1], max_points, max_voxels)
+        pv, pc, pn = oracle.points_to_voxel_python(dense, [0.4, 0.4, 4], [-140.8, -40, -3, 140.8, 40, 1], max_points, max_voxels)
+        assert np.array_equal(v, pv) and np.array_equal(c, pc) and np.array_equal(n, pn)
+        assert len(v) <= max_voxels and n.min() >= 1 and n.max() <= max_points
+        assert len(np.unique(c, axis=0)) == len(c)                                   # one voxel per cell
+        assert c[:, 0].max() == 0 and c[:, 1].max() < 200 and c[:, 2].max() < 704    # (z, y, x)
+        for i in (0, len(v) // 2, len(v) - 1):                                       # points sit in their cell, padding is zero
+            cell = np.floor((v[i, : n[i], :3] - np.float32([-140.8, -40, -3])) / np.float32([0.4, 0.4, 4])).astype(int)
+            assert np.all(cell[:, ::-1] == c[i]) and not v[i, n[i]:].any()
+    assert n.max() == 3 and len(v) == 40
+    feats, coords, num = oracle.collate_voxels([(v, c, n), (pv, pc, pn)])
+    assert feats.shape[0] == 80 and coords.shape == (80, 4) and list(np.unique(coords[:, 0])) == [0, 1]
