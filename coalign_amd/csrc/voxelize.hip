@@ -7,12 +7,15 @@
 // bit-identical to the CPU loop and run-to-run deterministic.  No global atomics anywhere (device-scope atomics cost
 // ~100 us per 400 k points on this part, measured): every cell of the dense grid has exactly one owner workgroup.
 //
-//   cell_kernel    per point: filters, float32 cell coordinate (IEEE divide + floor, like the CPU loop) -> cell_of_point.
-//   owner_kernel   grid (owners, clouds); an owner holds 7168 cells (runs of 32 dealt round-robin, see cell_code()).  The workgroup scans its cloud's cell ids (L2 resident) and, for the
-//                  cells it owns, builds in LDS the per-cell point count and smallest point index; counts the points
-//                  that sort below its range (= base of its slice of the bucket array); scans the counts into per-cell
-//                  segment offsets; writes count / first index / segment start per cell; rescans the points and drops
-//                  each index into its cell's segment (LDS ticket; the order inside a segment is arbitrary scratch).
+//   split_kernel   per 1024-point block: filters, float32 cell coordinate (IEEE divide + floor, like the CPU loop) ->
+//                  cell code per point, and the block's points grouped by owner (an LDS counting sort over the owners;
+//                  per block a row of owner offsets).  This is the first level of a two-level bucket sort by cell.
+//   owner_kernel   grid (owners, clouds); an owner holds 5120 cells (dealt round-robin, see cell_code()).
+//                  It walks only its own slices of the split array -- a few thousand points -- and builds in LDS the
+//                  per-cell point count and smallest point index, scans the counts into per-cell segment offsets (its
+//                  slice of the bucket array starts where the lower owners' points end), writes (count, first index,
+//                  segment start) of every occupied cell, walks its points again and drops each index into its cell's
+//                  segment (LDS ticket; the order inside a segment is arbitrary scratch, sorted later).
 //   head_kernel    a point is a voxel "head" iff it is its cell's smallest index; heads per 1024-point block.
 //   scan_kernel    one workgroup: exclusive prefix of the block head counts per cloud, per-cloud voxel totals clamped to
 //                  max_voxels, base row of every cloud in the concatenated output.
@@ -35,7 +38,9 @@ constexpr int kBlock = 256;
 constexpr int kPerThread = 4;
 constexpr int kChunk = kBlock * kPerThread;   // points per workgroup in the per-point kernels
 constexpr int kOwner = 1024;                  // threads of an owner workgroup
-constexpr int kRange = 7 * kOwner;            // cells per owner (2 x 28 KB of LDS, under the 64 KB static limit)
+constexpr int kRange = 5 * kOwner;            // cells per owner (2 x 20 KB of LDS)
+constexpr int kMaxOwners = 4096;              // LDS histogram of the split
+constexpr int kMaxBlocks = 2048;              // 1024-point blocks per cloud (2 M points) the owner can index in LDS
 constexpr int kSegLds = 1024;                 // per-wave LDS copy of a large voxel's segment (ints)
 constexpr int kIntMax = 0x7fffffff;
 
@@ -43,31 +48,33 @@ struct VoxArgs {
     const float4 *pts;
     int n_clouds, max_blocks;
     int off[kMaxClouds + 1];      // first point of each cloud
-    int coff[kMaxClouds + 1];     // first cell_of_point slot of each cloud (padded to multiples of 4: int4 reads)
     float lo[3], vs[3];
     int grid[3], ncell;
     int ranges, ncode;            // owner workgroups per cloud, ranges * kRange >= ncell cell codes per cloud
     int max_points, max_voxels, capacity;
     int flags;
     float flo[3], fhi[3];
-    int *cell_of_point, *count, *first, *cell_start, *blocksum, *base, *bucket;
+    int *cell_of_point, *table, *blocksum, *base, *bucket;
+    int *biglist, *big_count;     // flat cellinfo indices of the cells holding > 16 points, and how many there are
+    int2 *split;                  // per block: (cell code, point index in cloud) grouped by owner
+    int4 *cellinfo;               // per cell code: (point count, smallest point index, segment start, voxel row or -1)
     int2 *seg;
     float4 *voxels;
     int4 *coords;
     int *num_points, *voxel_counts;
 };
 
-// Cell -> code: runs of 32 consecutive cells are dealt round-robin to the owner workgroups, so that the densely hit cells
-// around the sensor (contiguous rows of the canvas) spread evenly over all owners instead of landing on one or two.
+// Cell -> code: consecutive cells are dealt round-robin to the owner workgroups, so that the densely hit cells around the
+// sensor spread evenly over all owners (measured with contiguous ownership: one owner got 40 % of the points).
 // code = owner * kRange + slot; bijective on [0, ncell).
 __device__ __forceinline__ int cell_code(const VoxArgs &a, int cell) {
-    const int run = cell >> 5, q = run / a.ranges, owner = run - q * a.ranges;
-    return owner * kRange + (q << 5 | (cell & 31));
+    const int slot = cell / a.ranges;
+    return (cell - slot * a.ranges) * kRange + slot;
 }
 
 __device__ __forceinline__ int code_cell(const VoxArgs &a, int code) {
-    const int owner = code / kRange, slot = code - owner * kRange;
-    return ((slot >> 5) * a.ranges + owner) << 5 | (slot & 31);
+    const int owner = code / kRange;
+    return (code - owner * kRange) * a.ranges + owner;
 }
 
 __device__ __forceinline__ int cell_of(const VoxArgs &a, const float4 p) {
@@ -85,61 +92,36 @@ __device__ __forceinline__ int cell_of(const VoxArgs &a, const float4 p) {
     return cell_code(a, ((int)cz * a.grid[1] + (int)cy) * a.grid[0] + (int)cx);
 }
 
-__global__ __launch_bounds__(kBlock) void cell_kernel(const VoxArgs a) {
-    const int cloud = blockIdx.y;
-    const int begin = a.off[cloud], n = a.off[cloud + 1] - begin, npad = a.coff[cloud + 1] - a.coff[cloud];
-    int *cells = a.cell_of_point + a.coff[cloud];
+__global__ __launch_bounds__(kBlock) void split_kernel(const VoxArgs a) {
+    __shared__ int hist[kMaxOwners + 1];
+    __shared__ int wave_tmp[kBlock / 64];
+    const int cloud = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int begin = a.off[cloud], n = a.off[cloud + 1] - begin;
+    if (blockIdx.x * kChunk >= n) return;
+    const int R = a.ranges;
+    for (int r = tid; r <= R; r += kBlock) hist[r] = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.big_count = 0;      // appended to by owner_kernel, next in the stream
+    __syncthreads();
+    int *cells = a.cell_of_point + begin;
+    int code[kPerThread], ticket[kPerThread];
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
-        const int i = blockIdx.x * kChunk + k * kBlock + threadIdx.x;
-        if (i < npad) cells[i] = i < n ? cell_of(a, a.pts[begin + i]) : -1;
-    }
-}
-
-__global__ __launch_bounds__(kOwner) void owner_kernel(const VoxArgs a) {
-    __shared__ int cnt[kRange];      // point count, later the exclusive segment offset of the cell
-    __shared__ int aux[kRange];      // kIntMax - smallest point index, later the fill ticket of the cell
-    __shared__ int wave_tmp[kOwner / 64];
-    __shared__ int below_total;
-    constexpr int kUnroll = 4;       // int4 loads in flight per thread: the scans are L2-latency bound otherwise
-    const int cloud = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int begin = a.off[cloud], n4 = (a.coff[cloud + 1] - a.coff[cloud]) >> 2;
-    const int lo = blockIdx.x * kRange, hi = lo + kRange;
-    for (int c = tid; c < kRange; c += kOwner) { cnt[c] = 0; aux[c] = 0; }
-    if (tid == 0) below_total = 0;
-    __syncthreads();
-    const int4 *cells4 = reinterpret_cast<const int4 *>(a.cell_of_point + a.coff[cloud]);
-    int below = 0;
-    for (int q0 = tid; q0 < n4; q0 += kOwner * kUnroll) {
-        int4 c4[kUnroll];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int q = q0 + u * kOwner;
-            c4[u] = q < n4 ? cells4[q] : make_int4(-1, -1, -1, -1);
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int i = (q0 + u * kOwner) * 4;
-            const int c[4] = {c4[u].x, c4[u].y, c4[u].z, c4[u].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                below += (c[k] >= 0 && c[k] < lo) ? 1 : 0;
-                if (c[k] >= lo && c[k] < hi) {
-                    atomicAdd(&cnt[c[k] - lo], 1);
-                    atomicMax(&aux[c[k] - lo], kIntMax - (i + k));
-                }
-            }
+        const int i = blockIdx.x * kChunk + k * kBlock + tid;
+        code[k] = -1;
+        if (i < n) {
+            code[k] = cell_of(a, a.pts[begin + i]);
+            cells[i] = code[k];
+            if (code[k] >= 0) ticket[k] = atomicAdd(&hist[code[k] / kRange], 1);
         }
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) below += __shfl_xor(below, d);
-    if (lane == 0) atomicAdd(&below_total, below);
     __syncthreads();
-    // exclusive scan of the counts: 7 consecutive cells per thread, wave scan, wave totals
-    constexpr int kPer = kRange / kOwner;
-    int local[kPer], sum = 0;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) { local[k] = cnt[tid * kPer + k]; sum += local[k]; }
+    // exclusive scan of the R owner counts (R <= 4096: up to 16 consecutive bins per thread)
+    const int per = (R + kBlock - 1) / kBlock;
+    int sum = 0;
+    for (int k = 0; k < per; ++k) {
+        const int r = tid * per + k;
+        if (r < R) sum += hist[r];
+    }
     int incl = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -148,50 +130,169 @@ __global__ __launch_bounds__(kOwner) void owner_kernel(const VoxArgs a) {
     }
     if (lane == 63) wave_tmp[wave] = incl;
     __syncthreads();
-    int run = below_total + incl - sum;
+    int run = incl - sum;
     for (int w = 0; w < wave; ++w) run += wave_tmp[w];
-    int *count = a.count + (size_t)cloud * a.ncode, *first = a.first + (size_t)cloud * a.ncode, *cell_start = a.cell_start + (size_t)cloud * a.ncode;
+    for (int k = 0; k < per; ++k) {
+        const int r = tid * per + k;
+        if (r < R) {
+            const int c = hist[r];
+            hist[r] = run;
+            run += c;
+        }
+    }
+    if (tid == kBlock - 1) hist[R] = run;
+    __syncthreads();
+    int *row = a.table + ((size_t)cloud * a.max_blocks + blockIdx.x) * (R + 1);
+    for (int r = tid; r <= R; r += kBlock) row[r] = hist[r];
+    int2 *out = a.split + begin + blockIdx.x * kChunk;
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k)
+        if (code[k] >= 0) out[hist[code[k] / kRange] + ticket[k]] = make_int2(code[k], blockIdx.x * kChunk + k * kBlock + tid);
+}
+
+__global__ __launch_bounds__(kOwner) void owner_kernel(const VoxArgs a) {
+    __shared__ int cnt[kRange];            // point count, later the exclusive segment offset of the cell
+    __shared__ int aux[kRange];            // kIntMax - smallest point index, later the fill ticket of the cell
+    __shared__ int pre[kMaxBlocks + 1];    // elements of this owner in the blocks before b
+    __shared__ int from[kMaxBlocks];       // where this owner's slice starts inside block b
+    __shared__ int wave_tmp[kOwner / 64], wave_big[kOwner / 64];
+    __shared__ int below_total, big_base;
+    const int cloud = blockIdx.y, owner = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int begin = a.off[cloud], n = a.off[cloud + 1] - begin, nb = (n + kChunk - 1) / kChunk;
+    const int R = a.ranges, lo = owner * kRange;
+    for (int c = tid; c < kRange; c += kOwner) { cnt[c] = 0; aux[c] = 0; }
+    if (tid == 0) below_total = 0;
+    // slices: block b holds this owner's points at [from[b], from[b] + size_b) of its 1024 split slots
+    const int *table = a.table + (size_t)cloud * a.max_blocks * (R + 1);
+    constexpr int kPerB = kMaxBlocks / kOwner;
+    int size[kPerB], ssum = 0, below = 0;
+#pragma unroll
+    for (int k = 0; k < kPerB; ++k) {
+        const int b = tid * kPerB + k;
+        size[k] = 0;
+        if (b < nb) {
+            const int s = table[(size_t)b * (R + 1) + owner], e = table[(size_t)b * (R + 1) + owner + 1];
+            from[b] = s;
+            size[k] = e - s;
+            below += s;
+        }
+        ssum += size[k];
+    }
+    __syncthreads();                  // below_total = 0 visible
+    int incl = ssum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wave_tmp[wave] = incl;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) below += __shfl_xor(below, d);
+    if (lane == 0) atomicAdd(&below_total, below);
+    __syncthreads();
+    {
+        int run = incl - ssum;
+        for (int w = 0; w < wave; ++w) run += wave_tmp[w];
+#pragma unroll
+        for (int k = 0; k < kPerB; ++k) {
+            const int b = tid * kPerB + k;
+            pre[b] = run;            // blocks past nb are empty: pre[nb] = total
+            run += size[k];
+        }
+        if (tid == kOwner - 1) pre[kMaxBlocks] = run;
+    }
+    __syncthreads();
+    const int total = pre[nb];
+    const int2 *split = a.split + begin;
+    auto element = [&](int e) {       // e-th point of this owner: binary search for its block
+        int l = 0, h = nb;            // invariant: pre[l] <= e < pre[h]
+        while (h - l > 1) {
+            const int m = (l + h) >> 1;
+            if (pre[m] <= e) l = m; else h = m;
+        }
+        return split[l * kChunk + from[l] + (e - pre[l])];
+    };
+    // a thread's first kKeep points stay in registers for both walks (a balanced owner has ~3 per thread): their
+    // searches and loads are independent and overlap; the atomics follow in one burst
+    constexpr int kKeep = 4;
+    int2 mine[kKeep];
+#pragma unroll
+    for (int u = 0; u < kKeep; ++u) {
+        const int e = tid + u * kOwner;
+        mine[u] = e < total ? element(e) : make_int2(-1, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < kKeep; ++u)
+        if (mine[u].x >= 0) {
+            atomicAdd(&cnt[mine[u].x - lo], 1);
+            atomicMax(&aux[mine[u].x - lo], kIntMax - mine[u].y);
+        }
+    for (int e = tid + kKeep * kOwner; e < total; e += kOwner) {
+        const int2 p = element(e);
+        atomicAdd(&cnt[p.x - lo], 1);
+        atomicMax(&aux[p.x - lo], kIntMax - p.y);
+    }
+    __syncthreads();
+    // exclusive scan of the counts: 5 consecutive cells per thread, wave scan, wave totals
+    constexpr int kPer = kRange / kOwner;
+    int local[kPer], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) { local[k] = cnt[tid * kPer + k]; sum += local[k]; }
+    incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    int nbig = 0;                     // cells of > 16 points go onto a work list: gather_kernel gives each a whole wavefront
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) nbig += local[k] > 16 ? 1 : 0;
+    int bincl = nbig;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(bincl, d);
+        if (lane >= d) bincl += t;
+    }
+    if (lane == 63) { wave_tmp[wave] = incl; wave_big[wave] = bincl; }
+    __syncthreads();
+    int run = below_total + incl - sum, brun = bincl - nbig;
+    for (int w = 0; w < wave; ++w) { run += wave_tmp[w]; brun += wave_big[w]; }
+    if (tid == kOwner - 1) big_base = (brun + nbig) ? atomicAdd(a.big_count, brun + nbig) : 0;   // one global atomic per owner
+    const int flat0 = cloud * a.ncode + lo;
+    int4 *cellinfo = a.cellinfo + flat0;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const int c = tid * kPer + k;
-        count[lo + c] = local[k];
-        first[lo + c] = kIntMax - aux[c];
-        cell_start[lo + c] = begin + run;
+        if (local[k] > 0) cellinfo[c] = make_int4(local[k], kIntMax - aux[c], begin + run, -1);   // empty cells are never looked up
         cnt[c] = run;
         aux[c] = 0;
         run += local[k];
     }
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+        if (local[k] > 16) a.biglist[big_base + brun++] = flat0 + tid * kPer + k;
     int *bucket = a.bucket + begin;
-    for (int q0 = tid; q0 < n4; q0 += kOwner * kUnroll) {
-        int4 c4[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int q = q0 + u * kOwner;
-            c4[u] = q < n4 ? cells4[q] : make_int4(-1, -1, -1, -1);
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int i = (q0 + u * kOwner) * 4;
-            const int c[4] = {c4[u].x, c4[u].y, c4[u].z, c4[u].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (c[k] >= lo && c[k] < hi) bucket[cnt[c[k] - lo] + atomicAdd(&aux[c[k] - lo], 1)] = begin + i + k;
-        }
+    for (int u = 0; u < kKeep; ++u)
+        if (mine[u].x >= 0) bucket[cnt[mine[u].x - lo] + atomicAdd(&aux[mine[u].x - lo], 1)] = begin + mine[u].y;
+    for (int e = tid + kKeep * kOwner; e < total; e += kOwner) {
+        const int2 p = element(e);
+        bucket[cnt[p.x - lo] + atomicAdd(&aux[p.x - lo], 1)] = begin + p.y;
     }
 }
 
 // head flags of this thread's kPerThread consecutive points (bit k) and their cells
 __device__ __forceinline__ unsigned head_flags(const VoxArgs &a, int cloud, int begin, int n, int i0, int (&cells)[kPerThread]) {
-    const int *first = a.first + (size_t)cloud * a.ncode;
+    const int4 *cellinfo = a.cellinfo + (size_t)cloud * a.ncode;
     unsigned h = 0;
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
         const int i = i0 + k;
         int c = -1;
-        if (i < n) c = a.cell_of_point[a.coff[cloud] + i];
+        if (i < n) c = a.cell_of_point[begin + i];
         cells[k] = c;
-        if (c >= 0 && first[c] == i) h |= 1u << k;
+        if (c >= 0 && cellinfo[c].y == i) h |= 1u << k;
     }
     return h;
 }
@@ -264,17 +365,20 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const VoxArgs a) {
     for (int w = 0; w < wave; ++w) rank += wave_sum[w];
     if (!h) return;
     const int base = a.base[cloud];
-    const int *count = a.count + (size_t)cloud * a.ncode, *cell_start = a.cell_start + (size_t)cloud * a.ncode;
+    int4 *cellinfo = a.cellinfo + (size_t)cloud * a.ncode;
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
         if (!(h >> k & 1)) continue;
         if (rank < a.max_voxels) {     // a cell that would open voxel number >= max_voxels is dropped with all its points
-            const int code = cells[k], v = base + rank, cnt = count[code];
+            const int code = cells[k], v = base + rank;
+            const int4 info = cellinfo[code];
+            const int cnt = info.x;
             const int c = code_cell(a, code);
             const int x = c % a.grid[0], yz = c / a.grid[0];
             a.coords[v] = make_int4(cloud, yz / a.grid[1], yz % a.grid[1], x);
             a.num_points[v] = cnt < a.max_points ? cnt : a.max_points;
-            a.seg[v] = make_int2(cell_start[code], cnt);
+            a.seg[v] = make_int2(info.z, cnt);
+            cellinfo[code].w = v;
         }
         ++rank;
     }
@@ -302,93 +406,133 @@ __device__ __forceinline__ int rank_in_row(int idx) {   // # of the other 15 lan
     }
 }
 
-__global__ __launch_bounds__(kBlock) void gather_kernel(const VoxArgs a) {
+// gather_kernel, two kinds of workgroups in one launch (both grid-stride: the counts are only known on the device):
+//   blockIdx.x <  big_blocks    one wavefront per entry of the big-cell list (> 16 points) -- first in the grid, they run longest;
+//   blockIdx.x >= big_blocks    16 lanes per voxel (16 voxels per workgroup step): zero fill of every voxel's unused slots and
+//                               the complete job for voxels of <= 16 points (rank by DPP row rotation, float4 gather).
+// A big cell's segment holds its point indices in arbitrary order; wanted are the `keep` smallest, ascending.  Up to 64
+// entries: one per lane, rank = number of smaller entries (readlane sweep).  Beyond: every lane's minimum over its strided
+// share gives 64 distinct candidates, the keep-th smallest of which bounds the keep smallest of the whole segment; the
+// entries <= that bound (keep..~64 of them unless the order is adversarial) are compacted into LDS and ranked as before.
+__global__ __launch_bounds__(kBlock) void gather_kernel(const VoxArgs a, const int big_blocks, const int list_cap) {
     __shared__ int stage[kBlock / 64][kSegLds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, group = lane >> 4, gl = lane & 15;
-    const int total = a.voxel_counts[a.n_clouds];
-    const int v0 = (blockIdx.x * (kBlock / 64) + wave) * 4;
-    if (v0 >= total) return;
-    const int v = v0 + group;
-    const int2 seg = v < total ? a.seg[v] : make_int2(0, 0);
-    const int cnt = seg.y;
-    {   // every voxel: zero fill of the slots past its points; voxels of <= 16 points: rank by row rotation, gather
-        const int keep = cnt < a.max_points ? cnt : a.max_points;
-        float4 *row = a.voxels + (size_t)v * a.max_points;
-        const bool small = v < total && cnt <= 16;
-        const int idx = (small && gl < cnt) ? a.bucket[seg.x + gl] : kIntMax;
-        const int rank = rank_in_row<15>(idx);
-        if (small && gl < cnt && rank < keep) row[rank] = a.pts[idx];
-        if (v < total)
-            for (int slot = keep + gl; slot < a.max_points; slot += 16) row[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= big_blocks) {
+        const int group = lane >> 4, gl = lane & 15, small_blocks = gridDim.x - big_blocks;
+        const int total = a.voxel_counts[a.n_clouds];
+        for (int v = (((int)blockIdx.x - big_blocks) * (kBlock / 64) + wave) * 4 + group; v < ((total + 3) & ~3); v += small_blocks * 16) {
+            const bool live = v < total;
+            const int2 seg = live ? a.seg[v] : make_int2(0, 0);
+            const int cnt = seg.y;
+            const int keep = cnt < a.max_points ? cnt : a.max_points;
+            float4 *row = a.voxels + (size_t)v * a.max_points;
+            const bool small = live && cnt <= 16;
+            const int idx = (small && gl < cnt) ? a.bucket[seg.x + gl] : kIntMax;
+            const int rank = rank_in_row<15>(idx);          // all 64 lanes take part: the loop bound is wave-uniform
+            if (small && gl < cnt && rank < keep) row[rank] = a.pts[idx];
+            if (live)
+                for (int slot = keep + gl; slot < a.max_points; slot += 16) row[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
     }
-    for (int g = 0; g < 4; ++g) {     // larger voxels, one at a time with the whole wavefront
-        const int gcnt = __builtin_amdgcn_readlane(cnt, g * 16), gstart = __builtin_amdgcn_readlane(seg.x, g * 16);
-        if (v0 + g >= total || gcnt <= 16) continue;
+    const int waves = big_blocks * (kBlock / 64);
+    int item = blockIdx.x * (kBlock / 64) + wave;
+    int entry = item < list_cap ? a.biglist[item] : 0;       // fetched beside the count, garbage past it
+    const int nbig = *a.big_count;
+    int *st = stage[wave];
+    for (; item < nbig; item += waves, entry = item < nbig ? a.biglist[item] : 0) {
+        const int4 info = a.cellinfo[entry];
+        const int gcnt = info.x, gstart = info.z, v = info.w;
+        if (v < 0) continue;                                 // cell dropped by max_voxels
         const int keep = gcnt < a.max_points ? gcnt : a.max_points;
-        float4 *row = a.voxels + (size_t)(v0 + g) * a.max_points;
+        float4 *row = a.voxels + (size_t)v * a.max_points;
+        int cand = gcnt;                                     // candidates to rank, wave-uniform
+        int idx = kIntMax;
         if (gcnt <= 64) {
-            const int idx = lane < gcnt ? a.bucket[gstart + lane] : kIntMax;
-            int rank = 0;
-            for (int j = 0; j < gcnt; ++j) rank += __builtin_amdgcn_readlane(idx, j) < idx ? 1 : 0;
-            if (lane < gcnt && rank < keep) row[rank] = a.pts[idx];
+            if (lane < gcnt) idx = a.bucket[gstart + lane];
         } else {
-            // > 64 points.  Every lane's minimum over its strided share gives 64 distinct candidates; the keep-th
-            // smallest of them bounds the keep smallest of the whole segment, so only entries <= that bound matter
-            // (a few dozen for the arbitrary ticket order the owner leaves): compact them into LDS, select there.
-            int mine = kIntMax;
-            for (int e = lane; e < gcnt; e += 64) {
-                const int t = a.bucket[gstart + e];
-                mine = t < mine ? t : mine;
+            constexpr int kRegs = kSegLds / 64;
+            const bool inreg = gcnt <= kSegLds;
+            int vals[kRegs], mine = kIntMax;
+            if (inreg) {
+#pragma unroll
+                for (int u = 0; u < kRegs; ++u) {
+                    const int e = lane + u * 64;
+                    vals[u] = e < gcnt ? a.bucket[gstart + e] : kIntMax;
+                }
+#pragma unroll
+                for (int u = 0; u < kRegs; ++u) mine = vals[u] < mine ? vals[u] : mine;
+            } else {
+                for (int e = lane; e < gcnt; e += 64) {
+                    const int t = a.bucket[gstart + e];
+                    mine = t < mine ? t : mine;
+                }
             }
             int mrank = 0;
             for (int j = 0; j < 64; ++j) mrank += __builtin_amdgcn_readlane(mine, j) < mine ? 1 : 0;
             const int bound = wave_min(mrank == keep - 1 ? mine : kIntMax);
-            int *st = stage[wave];
-            int filled = 0;                              // wave-uniform
-            for (int e0 = 0; e0 < gcnt; e0 += 64) {
-                const int e = e0 + lane;
-                const int t = e < gcnt ? a.bucket[gstart + e] : kIntMax;
+            int filled = 0;
+            auto push = [&](int t) {
                 const unsigned long long take = __ballot(t <= bound);
                 const int pos = filled + __popcll(take & ((1ull << lane) - 1ull));
                 if (t <= bound && pos < kSegLds) st[pos] = t;
                 filled += __popcll(take);
+            };
+            if (inreg) {
+#pragma unroll
+                for (int u = 0; u < kRegs; ++u) push(vals[u]);
+            } else {
+                for (int e0 = 0; e0 < gcnt; e0 += 64) push(e0 + lane < gcnt ? a.bucket[gstart + e0 + lane] : kIntMax);
             }
             coalign::wave_lds_sync();
-            const bool staged = filled <= kSegLds;       // else (adversarial ticket order only): select from global memory
-            const int m_cnt = staged ? filled : gcnt;
-            int last = -1, chosen = -1;                  // lane r ends up with the r-th smallest point index of the voxel
-            for (int r = 0; r < keep; ++r) {
-                int m = kIntMax;
-                for (int e = lane; e < m_cnt; e += 64) {
-                    const int t = staged ? st[e] : a.bucket[gstart + e];
-                    m = (t > last && t < m) ? t : m;
+            cand = filled;
+            if (cand <= 64) {
+                if (lane < cand) idx = st[lane];
+            } else {
+                // more than 64 candidates (adversarial segment order): selection rounds, over the LDS copy if it was complete
+                const bool staged = cand <= kSegLds;
+                const int m_cnt = staged ? cand : gcnt;
+                int last = -1, chosen = -1;                  // lane r ends up with the r-th smallest point index
+                for (int r = 0; r < keep; ++r) {
+                    int m = kIntMax;
+                    for (int e = lane; e < m_cnt; e += 64) {
+                        const int t = staged ? st[e] : a.bucket[gstart + e];
+                        m = (t > last && t < m) ? t : m;
+                    }
+                    last = wave_min(m);
+                    if (lane == r) chosen = last;
                 }
-                last = wave_min(m);
-                if (lane == r) chosen = last;
+                if (lane < keep) row[lane] = a.pts[chosen];
+                coalign::wave_lds_sync();
+                continue;
             }
-            if (lane < keep) row[lane] = a.pts[chosen];
-            coalign::wave_lds_sync();
         }
+        int rank = 0;
+        for (int j = 0; j < cand; ++j) rank += __builtin_amdgcn_readlane(idx, j) < idx ? 1 : 0;
+        if (lane < cand && rank < keep) row[rank] = a.pts[idx];
+        coalign::wave_lds_sync();                            // the next item reuses the stage
     }
 }
 
 struct Workspace {
-    size_t count, first, cell_start, cell_of_point, bucket, blocksum, base, seg, total;
+    size_t cellinfo, cell_of_point, split, table, bucket, blocksum, base, seg, biglist, big_count, total;
 };
 
 Workspace layout(int n_clouds, int64_t n_points, int64_t ncell, int64_t capacity, int max_blocks) {
     Workspace w;
-    ncell = (ncell + kRange - 1) / kRange * kRange;     // cell codes, see cell_code()
+    const int64_t ranges = (ncell + kRange - 1) / kRange;      // cell codes: ranges * kRange per cloud, see cell_code()
     size_t o = 0;
     auto take = [&](size_t ints) { size_t at = o; o = coalign::align_up(o + ints * sizeof(int), 256); return at; };
-    w.count = take((size_t)n_clouds * ncell);
-    w.first = take((size_t)n_clouds * ncell);
-    w.cell_start = take((size_t)n_clouds * ncell);
-    w.cell_of_point = take((size_t)n_points + 4 * kMaxClouds);
+    w.cellinfo = take((size_t)n_clouds * ranges * kRange * 4);
+    w.cell_of_point = take((size_t)n_points);
+    w.split = take((size_t)n_points * 2);
+    w.table = take((size_t)n_clouds * max_blocks * (ranges + 1));
     w.bucket = take((size_t)n_points);
     w.blocksum = take((size_t)n_clouds * max_blocks);
     w.base = take(kMaxClouds + 1);
     w.seg = take((size_t)capacity * 2);
+    w.biglist = take((size_t)n_points / 17 + 1);
+    w.big_count = take(1);
     w.total = o;
     return w;
 }
@@ -399,7 +543,7 @@ int grid_of(const double *voxel_size, const double *range, int g[3]) {
         if (!(q >= 0.5f && q < 65536.0f)) return COALIGN_ERR_BAD_SHAPE;
         g[j] = (int)nearbyintf(q);
     }
-    if ((int64_t)g[0] * g[1] * g[2] > (int64_t)1 << 28) return COALIGN_ERR_UNSUPPORTED;
+    if ((int64_t)g[0] * g[1] * g[2] > (int64_t)kMaxOwners * kRange) return COALIGN_ERR_UNSUPPORTED;   // 21 M cells
     return COALIGN_OK;
 }
 
@@ -453,6 +597,7 @@ extern "C" int coalign_voxelize(const float *points, const int64_t *cloud_offset
     if (n == 0) return hip_call(hipMemsetAsync(voxel_counts, 0, sizeof(int32_t) * (n_clouds + 1), s));
     if (!points || !voxels || !coords || !num_points || !workspace) return COALIGN_ERR_NULL_POINTER;
     a.max_blocks = max_blocks_of(cloud_offsets, n_clouds);
+    if (a.max_blocks > kMaxBlocks) return COALIGN_ERR_UNSUPPORTED;     // > 2 M points in one cloud
     const Workspace w = layout(n_clouds, n, ncell, need, a.max_blocks);
     if (workspace_bytes < w.total) return COALIGN_ERR_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(voxels) | reinterpret_cast<uintptr_t>(coords)) & 15)
@@ -461,7 +606,6 @@ extern "C" int coalign_voxelize(const float *points, const int64_t *cloud_offset
     a.pts = reinterpret_cast<const float4 *>(points);
     a.n_clouds = n_clouds;
     for (int c = 0; c <= n_clouds; ++c) a.off[c] = (int)cloud_offsets[c];
-    for (int c = 0; c < n_clouds; ++c) a.coff[c + 1] = a.coff[c] + (a.off[c + 1] - a.off[c] + 3) / 4 * 4;
     for (int j = 0; j < 3; ++j) {
         a.lo[j] = (float)range[j];
         a.vs[j] = (float)voxel_size[j];
@@ -477,25 +621,30 @@ extern "C" int coalign_voxelize(const float *points, const int64_t *cloud_offset
     a.max_voxels = max_voxels;
     a.capacity = (int)need;
     a.flags = flags;
-    a.count = reinterpret_cast<int *>(ws + w.count);
-    a.first = reinterpret_cast<int *>(ws + w.first);
-    a.cell_start = reinterpret_cast<int *>(ws + w.cell_start);
+    a.cellinfo = reinterpret_cast<int4 *>(ws + w.cellinfo);
+    a.split = reinterpret_cast<int2 *>(ws + w.split);
+    a.table = reinterpret_cast<int *>(ws + w.table);
     a.cell_of_point = reinterpret_cast<int *>(ws + w.cell_of_point);
     a.bucket = reinterpret_cast<int *>(ws + w.bucket);
     a.blocksum = reinterpret_cast<int *>(ws + w.blocksum);
     a.base = reinterpret_cast<int *>(ws + w.base);
     a.seg = reinterpret_cast<int2 *>(ws + w.seg);
+    a.biglist = reinterpret_cast<int *>(ws + w.biglist);
+    a.big_count = reinterpret_cast<int *>(ws + w.big_count);
     a.voxels = reinterpret_cast<float4 *>(voxels);
     a.coords = reinterpret_cast<int4 *>(coords);
     a.num_points = num_points;
     a.voxel_counts = voxel_counts;
     const dim3 per_point(a.max_blocks, n_clouds);
-    const unsigned groups = (unsigned)((need + 15) / 16);
-    hipLaunchKernelGGL(cell_kernel, per_point, dim3(kBlock), 0, s, a);
+    // gather grid: enough workgroups for the worst case, capped -- both kinds of workgroup stride over the device-side counts
+    const unsigned small_blocks = (unsigned)std::min<int64_t>((need + 15) / 16, 8192);
+    const int64_t list_cap = n / 17 + 1;
+    const unsigned big_blocks = (unsigned)std::min<int64_t>((list_cap + 3) / 4, 8192);
+    hipLaunchKernelGGL(split_kernel, per_point, dim3(kBlock), 0, s, a);
     hipLaunchKernelGGL(owner_kernel, dim3(a.ranges, n_clouds), dim3(kOwner), 0, s, a);
     hipLaunchKernelGGL(head_kernel, per_point, dim3(kBlock), 0, s, a);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, a);
     hipLaunchKernelGGL(assign_kernel, per_point, dim3(kBlock), 0, s, a);
-    hipLaunchKernelGGL(gather_kernel, dim3(groups), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(gather_kernel, dim3(big_blocks + small_blocks), dim3(kBlock), 0, s, a, (int)big_blocks, (int)list_cap);
     return check_launch();
 }
