@@ -4,8 +4,8 @@
 // (opencood/data_utils/pre_processor/sp_voxel_preprocessor.py:62-147) around spconv's sequential point-to-voxel loop, and
 // the two point filters of opencood/utils/pcd_utils.py:41-88.  The sequential loop numbers voxels by first appearance
 // and keeps each voxel's first `max_points` points *in point order*; both orders are reproduced exactly, so the output is
-// bit-identical to the CPU loop and run-to-run deterministic.  No global atomics anywhere (device-scope atomics cost
-// ~100 us per 400 k points on this part, measured): every cell of the dense grid has exactly one owner workgroup.
+// bit-identical to the CPU loop and run-to-run deterministic.  Per-point global atomics are avoided (device-scope atomics
+// cost ~100 us per 400 k points on this part, measured): every cell of the dense grid has exactly one owner workgroup.
 //
 //   split_kernel   per 1024-point block: filters, float32 cell coordinate (IEEE divide + floor, like the CPU loop) ->
 //                  cell code per point, and the block's points grouped by owner (an LDS counting sort over the owners;
@@ -16,15 +16,15 @@
 //                  slice of the bucket array starts where the lower owners' points end), writes (count, first index,
 //                  segment start) of every occupied cell, walks its points again and drops each index into its cell's
 //                  segment (LDS ticket; the order inside a segment is arbitrary scratch, sorted later).
-//   head_kernel    a point is a voxel "head" iff it is its cell's smallest index; heads per 1024-point block.
-//   scan_kernel    one workgroup: exclusive prefix of the block head counts per cloud, per-cloud voxel totals clamped to
-//                  max_voxels, base row of every cloud in the concatenated output.
-//   assign_kernel  head rank in point order = voxel number; writes coords (cloud, z, y, x), num_points, and the voxel's
-//                  (segment start, point count).
+//                  Finally it adds its cells' heads (a cell's smallest point index opens the voxel) to the per-1024-point-
+//                  block head counts -- the only global atomics of the pipeline, one per (owner, block).
+//   assign_kernel  per 1024-point block: a point is a head iff it is its cell's smallest index; head rank in point order
+//                  (heads in earlier blocks + scan inside the block) = voxel number, clamped to max_voxels per cloud; writes
+//                  coords (cloud, z, y, x), num_points, the voxel's (segment start, point count), and the voxel counts.
 //   gather_kernel  the max_points smallest indices of each voxel's segment in ascending order: 16 lanes per voxel with
-//                  DPP row rotations for the common <= 16-point voxels, a whole wavefront for larger ones (cross-lane
-//                  rank up to 64 points, selection rounds over an LDS copy beyond); float4 gather of those points, zero
-//                  fill of the remaining slots.
+//                  DPP row rotations for the common <= 16-point voxels, a whole wavefront per entry of the big-cell list
+//                  (cross-lane rank up to 64 points, candidate bound + LDS compaction beyond); float4 gather of those
+//                  points, zero fill of the remaining slots.
 //
 // Everything is integer / index work plus copies: HBM-bound by the [M, max_points, 4] output it must write.
 #include <algorithm>
@@ -54,7 +54,7 @@ struct VoxArgs {
     int max_points, max_voxels, capacity;
     int flags;
     float flo[3], fhi[3];
-    int *cell_of_point, *table, *blocksum, *base, *bucket;
+    int *cell_of_point, *table, *blocksum, *bucket;
     int *biglist, *big_count;     // flat cellinfo indices of the cells holding > 16 points, and how many there are
     int2 *split;                  // per block: (cell code, point index in cloud) grouped by owner
     int4 *cellinfo;               // per cell code: (point count, smallest point index, segment start, voxel row or -1)
@@ -97,10 +97,13 @@ __global__ __launch_bounds__(kBlock) void split_kernel(const VoxArgs a) {
     __shared__ int wave_tmp[kBlock / 64];
     const int cloud = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int begin = a.off[cloud], n = a.off[cloud + 1] - begin;
+    if (tid == 0) {                   // accumulated by owner_kernel, next in the stream
+        a.blocksum[cloud * a.max_blocks + blockIdx.x] = 0;
+        if (blockIdx.x == 0 && blockIdx.y == 0) *a.big_count = 0;
+    }
     if (blockIdx.x * kChunk >= n) return;
     const int R = a.ranges;
     for (int r = tid; r <= R; r += kBlock) hist[r] = 0;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.big_count = 0;      // appended to by owner_kernel, next in the stream
     __syncthreads();
     int *cells = a.cell_of_point + begin;
     int code[kPerThread], ticket[kPerThread];
@@ -260,10 +263,12 @@ __global__ __launch_bounds__(kOwner) void owner_kernel(const VoxArgs a) {
     if (tid == kOwner - 1) big_base = (brun + nbig) ? atomicAdd(a.big_count, brun + nbig) : 0;   // one global atomic per owner
     const int flat0 = cloud * a.ncode + lo;
     int4 *cellinfo = a.cellinfo + flat0;
+    int firsts[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const int c = tid * kPer + k;
-        if (local[k] > 0) cellinfo[c] = make_int4(local[k], kIntMax - aux[c], begin + run, -1);   // empty cells are never looked up
+        firsts[k] = kIntMax - aux[c];
+        if (local[k] > 0) cellinfo[c] = make_int4(local[k], firsts[k], begin + run, -1);   // empty cells are never looked up
         cnt[c] = run;
         aux[c] = 0;
         run += local[k];
@@ -280,6 +285,18 @@ __global__ __launch_bounds__(kOwner) void owner_kernel(const VoxArgs a) {
         const int2 p = element(e);
         bucket[cnt[p.x - lo] + atomicAdd(&aux[p.x - lo], 1)] = begin + p.y;
     }
+    // voxel heads (= occupied cells, at their smallest point index) per 1024-point block, summed over the owners in
+    // blocksum: assign_kernel ranks the heads in point order from it
+    __syncthreads();
+    int *heads = pre;
+    for (int b = tid; b < nb; b += kOwner) heads[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+        if (local[k] > 0) atomicAdd(&heads[firsts[k] / kChunk], 1);
+    __syncthreads();
+    for (int b = tid; b < nb; b += kOwner)
+        if (heads[b]) atomicAdd(&a.blocksum[cloud * a.max_blocks + b], heads[b]);
 }
 
 // head flags of this thread's kPerThread consecutive points (bit k) and their cells
@@ -297,59 +314,37 @@ __device__ __forceinline__ unsigned head_flags(const VoxArgs &a, int cloud, int 
     return h;
 }
 
-__global__ __launch_bounds__(kBlock) void head_kernel(const VoxArgs a) {
-    __shared__ int wave_sum[kBlock / 64];
-    const int cloud = blockIdx.y;
-    const int begin = a.off[cloud], n = a.off[cloud + 1] - begin;
-    if (blockIdx.x * kChunk >= n) return;
-    int cells[kPerThread];
-    const int mine = __popc(head_flags(a, cloud, begin, n, blockIdx.x * kChunk + threadIdx.x * kPerThread, cells));
-    int s = mine;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
-    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) a.blocksum[cloud * a.max_blocks + blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
-}
-
-__global__ __launch_bounds__(kBlock) void scan_kernel(const VoxArgs a) {
-    __shared__ int total[kMaxClouds];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int cloud = wave; cloud < a.n_clouds; cloud += kBlock / 64) {
-        const int nb = (a.off[cloud + 1] - a.off[cloud] + kChunk - 1) / kChunk;
-        int carry = 0;
-        for (int b0 = 0; b0 < nb; b0 += 64) {
-            const int b = b0 + lane;
-            const int v = b < nb ? a.blocksum[cloud * a.max_blocks + b] : 0;
-            int incl = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl_up(incl, d);
-                if (lane >= d) incl += t;
-            }
-            if (b < nb) a.blocksum[cloud * a.max_blocks + b] = carry + incl - v;
-            carry += __shfl(incl, 63);
-        }
-        if (lane == 0) total[cloud] = carry < a.max_voxels ? carry : a.max_voxels;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int base = 0;
-        for (int c = 0; c < a.n_clouds; ++c) {
-            a.base[c] = base;
-            a.voxel_counts[c] = total[c];
-            base += total[c];
-        }
-        a.voxel_counts[a.n_clouds] = base;
-    }
-}
-
 __global__ __launch_bounds__(kBlock) void assign_kernel(const VoxArgs a) {
     __shared__ int wave_sum[kBlock / 64];
-    const int cloud = blockIdx.y;
+    __shared__ int heads_of[kMaxClouds], before_me;
+    const int cloud = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // every workgroup sums the per-block head counts itself (a few hundred ints): the heads of each cloud -> its voxel total
+    // and base row, the heads in the blocks before this one -> the rank of this block's first head
+    for (int c = wave; c < a.n_clouds; c += kBlock / 64) {
+        const int nb = (a.off[c + 1] - a.off[c] + kChunk - 1) / kChunk;
+        int all = 0, before = 0;
+        for (int b = lane; b < nb; b += 64) {
+            const int h = a.blocksum[c * a.max_blocks + b];
+            all += h;
+            before += (c == cloud && b < (int)blockIdx.x) ? h : 0;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { all += __shfl_xor(all, d); before += __shfl_xor(before, d); }
+        if (lane == 0) {
+            heads_of[c] = all < a.max_voxels ? all : a.max_voxels;
+            if (c == cloud) before_me = before;
+        }
+    }
+    __syncthreads();
+    int base = 0;
+    for (int c = 0; c < cloud; ++c) base += heads_of[c];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        int sum = 0;
+        for (int c = 0; c < a.n_clouds; ++c) { a.voxel_counts[c] = heads_of[c]; sum += heads_of[c]; }
+        a.voxel_counts[a.n_clouds] = sum;
+    }
     const int begin = a.off[cloud], n = a.off[cloud + 1] - begin;
     if (blockIdx.x * kChunk >= n) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int cells[kPerThread];
     const unsigned h = head_flags(a, cloud, begin, n, blockIdx.x * kChunk + threadIdx.x * kPerThread, cells);
     const int mine = __popc(h);
@@ -361,10 +356,9 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const VoxArgs a) {
     }
     if (lane == 63) wave_sum[wave] = incl;
     __syncthreads();
-    int rank = a.blocksum[cloud * a.max_blocks + blockIdx.x] + incl - mine;
+    int rank = before_me + incl - mine;
     for (int w = 0; w < wave; ++w) rank += wave_sum[w];
     if (!h) return;
-    const int base = a.base[cloud];
     int4 *cellinfo = a.cellinfo + (size_t)cloud * a.ncode;
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
@@ -515,7 +509,7 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const VoxArgs a, const i
 }
 
 struct Workspace {
-    size_t cellinfo, cell_of_point, split, table, bucket, blocksum, base, seg, biglist, big_count, total;
+    size_t cellinfo, cell_of_point, split, table, bucket, blocksum, seg, biglist, big_count, total;
 };
 
 Workspace layout(int n_clouds, int64_t n_points, int64_t ncell, int64_t capacity, int max_blocks) {
@@ -529,7 +523,6 @@ Workspace layout(int n_clouds, int64_t n_points, int64_t ncell, int64_t capacity
     w.table = take((size_t)n_clouds * max_blocks * (ranges + 1));
     w.bucket = take((size_t)n_points);
     w.blocksum = take((size_t)n_clouds * max_blocks);
-    w.base = take(kMaxClouds + 1);
     w.seg = take((size_t)capacity * 2);
     w.biglist = take((size_t)n_points / 17 + 1);
     w.big_count = take(1);
@@ -627,7 +620,6 @@ extern "C" int coalign_voxelize(const float *points, const int64_t *cloud_offset
     a.cell_of_point = reinterpret_cast<int *>(ws + w.cell_of_point);
     a.bucket = reinterpret_cast<int *>(ws + w.bucket);
     a.blocksum = reinterpret_cast<int *>(ws + w.blocksum);
-    a.base = reinterpret_cast<int *>(ws + w.base);
     a.seg = reinterpret_cast<int2 *>(ws + w.seg);
     a.biglist = reinterpret_cast<int *>(ws + w.biglist);
     a.big_count = reinterpret_cast<int *>(ws + w.big_count);
@@ -642,8 +634,6 @@ extern "C" int coalign_voxelize(const float *points, const int64_t *cloud_offset
     const unsigned big_blocks = (unsigned)std::min<int64_t>((list_cap + 3) / 4, 8192);
     hipLaunchKernelGGL(split_kernel, per_point, dim3(kBlock), 0, s, a);
     hipLaunchKernelGGL(owner_kernel, dim3(a.ranges, n_clouds), dim3(kOwner), 0, s, a);
-    hipLaunchKernelGGL(head_kernel, per_point, dim3(kBlock), 0, s, a);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, s, a);
     hipLaunchKernelGGL(assign_kernel, per_point, dim3(kBlock), 0, s, a);
     hipLaunchKernelGGL(gather_kernel, dim3(big_blocks + small_blocks), dim3(kBlock), 0, s, a, (int)big_blocks, (int)list_cap);
     return check_launch();

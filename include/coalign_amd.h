@@ -192,6 +192,8 @@ int coalign_bias_act(float *y, const float *bias, const float *residual, int N, 
  * voxel_counts   [n_clouds + 1] int32 out (device): voxels of each cloud, then their sum M; cloud c owns the rows
  *                [sum(counts[:c]), sum(counts[:c + 1])), numbered by first appearance in point order.  Rows >= M are
  *                not written.  capacity >= coalign_voxelize_capacity(...) = min(N, n_clouds * min(cells, max_voxels)).
+ * Limits (COALIGN_ERR_UNSUPPORTED beyond): 16 clouds, 2 M points per cloud, 20 971 520 grid cells, max_points 64.
+ * workspace      coalign_voxelize_workspace_bytes(...) bytes (dense per-cell table 16 B x cells x clouds + 20 B per point).
  */
 #define COALIGN_VOX_FILTER_EGO 1
 #define COALIGN_VOX_FILTER_RANGE 2
