@@ -282,3 +282,24 @@ def voxelize(points: torch.Tensor, cloud_offsets: Sequence[int], voxel_size: Seq
         hip.check(L.coalign_voxelize(_ptr(pts), off, n_clouds, vs, rg, int(max_points), int(max_voxels), flags, fr, _ptr(voxels),
                                      _ptr(coords), _ptr(num), cap, _ptr(counts), _ptr(ws), ws_bytes, _stream()), "coalign_voxelize")
     return voxels, coords, num, counts
+
+
+def pose_graph_optimize(vertex_offsets: torch.Tensor, edge_offsets: torch.Tensor, n_agents: torch.Tensor, vertices: torch.Tensor,
+                        kinds: torch.Tensor, edge_agent: torch.Tensor, edge_landmark: torch.Tensor, edge_meas: torch.Tensor,
+                        edge_info: torch.Tensor, max_iterations: int = 1000) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Batched Levenberg-Marquardt over agent-object pose graphs (see include/coalign_amd.h (8)); all tensors on the device,
+    offsets / indices int32, values float64.  -> (optimised vertices [V, 3], stats [G, 4])."""
+    _need_gpu(vertex_offsets, edge_offsets, n_agents, vertices, kinds, edge_agent, edge_landmark, edge_meas, edge_info)
+    L = hip.lib()
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    f64 = lambda t: t.to(torch.float64).contiguous()
+    vo, eo, na, kd, ea, el = (i32(t) for t in (vertex_offsets, edge_offsets, n_agents, kinds, edge_agent, edge_landmark))
+    out, em, ew = f64(vertices).clone(), f64(edge_meas), f64(edge_info)
+    G, V = na.shape[0], out.shape[0]
+    stats = torch.zeros((G, 4), dtype=torch.float64, device=out.device)
+    ws_bytes = L.coalign_pose_graph_workspace_bytes(V)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=out.device)
+    with _Timed("pose_graph_optimize"):
+        hip.check(L.coalign_pose_graph_optimize(G, _ptr(vo), _ptr(eo), _ptr(na), V, _ptr(out), _ptr(kd), _ptr(ea), _ptr(el), _ptr(em), _ptr(ew),
+                                                int(max_iterations), _ptr(stats), _ptr(ws), ws_bytes, _stream()), "coalign_pose_graph_optimize")
+    return out, stats

@@ -205,6 +205,32 @@ int coalign_voxelize(const float *points, const int64_t *cloud_offsets, int n_cl
                      float *voxels, int32_t *coords, int32_t *num_points, int64_t capacity, int32_t *voxel_counts,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * (8) Agent-object pose-graph optimisation, the solver inside CoAlign's box alignment.
+ *     Replaces PoseGraphOptimization2D.optimize (opencood/models/sub_modules/pose_graph_optim.py:11-60: g2o SparseOptimizer,
+ *     Levenberg-Marquardt, dense SE2 block solver) as called by box_alignment_relative_sample_np
+ *     (opencood/models/sub_modules/box_align_v2.py:287-372; hook intermediate_fusion_dataset.py:301-328).
+ *     A batch of independent graphs (one per frame) is solved in one launch, float64.
+ *
+ * Graph g owns vertices [vertex_offsets[g], vertex_offsets[g+1]) and edges [edge_offsets[g], edge_offsets[g+1]) (device int32).
+ * Its first n_agents[g] (<= 8) vertices are the agents, the rest (<= 256) the landmarks; every edge joins an agent to a
+ * landmark (g2o EdgeSE2 / EdgeSE2PointXY) and the edges of one landmark are contiguous (the reference adds them that way).
+ * vertices   [V, 3] float64 in/out: (x, y, theta in radians); point landmarks use (x, y, -)
+ * kinds      [V] int32: 0 = fixed SE2 (the ego), 1 = free SE2, 2 = free point (landmarks only)
+ * edge_agent / edge_landmark  [E] int32, vertex numbers LOCAL to the graph
+ * edge_meas  [E, 3] float64: the landmark in the agent's frame (x, y, theta; theta ignored for point landmarks)
+ * edge_info  [E, 3] float64: diagonal of the information matrix (the reference only ever builds diagonal ones)
+ * stats      [n_graphs, 4] float64 out: LM iterations run (-1: graph outside the limits above, left untouched),
+ *            chi2 before, chi2 after, final lambda
+ * Damping schedule, update rule (X <- X * dx), termination (rho == 0, ten rejected trials, max_iterations) follow g2o's
+ * OptimizationAlgorithmLevenberg; vertices without edges are not moved.
+ */
+size_t coalign_pose_graph_workspace_bytes(int total_vertices);
+int coalign_pose_graph_optimize(int n_graphs, const int32_t *vertex_offsets, const int32_t *edge_offsets, const int32_t *n_agents,
+                                int total_vertices, double *vertices, const int32_t *kinds, const int32_t *edge_agent,
+                                const int32_t *edge_landmark, const double *edge_meas, const double *edge_info,
+                                int max_iterations, double *stats, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

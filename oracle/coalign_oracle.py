@@ -826,3 +826,285 @@ def collate_voxels(per_cloud):
     num = np.concatenate([n for _, _, n in per_cloud])
     coords = np.concatenate([np.pad(c, ((0, 0), (1, 0)), mode="constant", constant_values=i) for i, (_, c, _) in enumerate(per_cloud)])
     return feats, coords, num
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Pose correction by box alignment: agent-object pose graph built from every agent's stage-1 boxes,
+# solved with Levenberg-Marquardt.  The solver in the reference is g2o (python binding `g2o`, C++; absent from
+# /root/reference and from this image, no version pinned): PARITY UNPINNED for the optimiser -- restated below from
+# g2o's published OptimizationAlgorithmLevenberg / EdgeSE2 / EdgeSE2PointXY, and cross-checked in the tests against an
+# independent solver (scipy.optimize.least_squares) on the same residuals.  Everything in front of and behind the solver
+# (box clustering, landmark choice, information matrices, hard-case rules, degree/radian handling) is the reference's own
+# Python and IS pinned: tests/golden/box_align.npz comes from the reference's function running with a recording g2o stand-in.
+
+def pose_to_tfm(pose) -> np.ndarray:
+    """opencood/utils/transformation_utils.py:93-160.  numpy input is cast to **float32** first (common_utils.py:82-85)."""
+    p = torch.from_numpy(np.asarray(pose)).float()
+    n = p.shape[0]
+    tfm = torch.eye(4).view(1, 4, 4).repeat(n, 1, 1)
+    if p.shape[1] == 3:
+        yaw = torch.deg2rad(p[:, 2])
+        tfm[:, 0, 0], tfm[:, 0, 1], tfm[:, 1, 0], tfm[:, 1, 1] = torch.cos(yaw), -torch.sin(yaw), torch.sin(yaw), torch.cos(yaw)
+        tfm[:, 0, 3], tfm[:, 1, 3] = p[:, 0], p[:, 1]
+        return tfm.numpy()
+    cy, sy = torch.cos(torch.deg2rad(p[:, 4])), torch.sin(torch.deg2rad(p[:, 4]))
+    cr, sr = torch.cos(torch.deg2rad(p[:, 3])), torch.sin(torch.deg2rad(p[:, 3]))
+    cp, sp = torch.cos(torch.deg2rad(p[:, 5])), torch.sin(torch.deg2rad(p[:, 5]))
+    tfm[:, 0, 3], tfm[:, 1, 3], tfm[:, 2, 3] = p[:, 0], p[:, 1], p[:, 2]
+    tfm[:, 0, 0], tfm[:, 0, 1], tfm[:, 0, 2] = cp * cy, cy * sp * sr - sy * cr, -cy * sp * cr - sy * sr
+    tfm[:, 1, 0], tfm[:, 1, 1], tfm[:, 1, 2] = sy * cp, sy * sp * sr + cy * cr, -sy * sp * cr + cy * sr
+    tfm[:, 2, 0], tfm[:, 2, 1], tfm[:, 2, 2] = sp, -cp * sr, cp * cr
+    return tfm.numpy()
+
+
+def corner_to_center(corner3d: np.ndarray, order: str = "lwh") -> np.ndarray:
+    """opencood/utils/box_utils.py:25-85: centre = mean of corners 0, 3, 5, 6; edge lengths and heading averaged over 4 edges."""
+    c = np.asarray(corner3d)
+    xyz = np.mean(c[:, [0, 3, 5, 6], :], axis=1)
+    h = abs(np.mean(c[:, 4:, 2] - c[:, :4, 2], axis=1, keepdims=True))
+    d = lambda i, j: np.sqrt(np.sum((c[:, i, [0, 1]] - c[:, j, [0, 1]]) ** 2, axis=1, keepdims=True))
+    l = (d(0, 3) + d(2, 1) + d(4, 7) + d(5, 6)) / 4
+    w = (d(0, 1) + d(2, 3) + d(4, 5) + d(6, 7)) / 4
+    a = lambda i, j: np.arctan2(c[:, i, 1] - c[:, j, 1], c[:, i, 0] - c[:, j, 0])
+    theta = (a(1, 2) + a(0, 3) + a(5, 6) + a(4, 7))[:, np.newaxis] / 4
+    parts = [xyz, l, w, h, theta] if order == "lwh" else [xyz, h, w, l, theta]
+    return np.concatenate(parts, axis=1).reshape(c.shape[0], 7)
+
+
+def project_box3d_np(box3d: np.ndarray, T: np.ndarray) -> np.ndarray:
+    """box_utils.project_box3d on numpy input: both operands are cast to float32 (common_utils.py:82-85)."""
+    return project_box3d(torch.from_numpy(np.asarray(box3d)).float(), torch.from_numpy(np.asarray(T)).float()).numpy()
+
+
+def all_pair_l2(A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """box_align_v2.py:79-96, in the dtype of its inputs (float32 on this path)."""
+    two_ab = 2 * A @ B.T
+    with np.errstate(invalid="ignore"):          # rounding can push a zero distance slightly negative -> NaN, like the reference
+        return np.sqrt(np.sum(A * A, 1, keepdims=True).repeat(two_ab.shape[1], axis=1)
+                       + np.sum(B * B, 1, keepdims=True).T.repeat(two_ab.shape[0], axis=0) - two_ab)
+
+
+def build_pose_graph(pred_corners_list, noisy_lidar_pose, uncertainty_list=None, landmark_SE2=True, adaptive_landmark=False,
+                     normalize_uncertainty=False, abandon_hard_cases=False, drop_hard_boxes=False, drop_unsure_edge=False,
+                     use_uncertainty=True, thres=1.5, yaw_var_thres=0.2):
+    """box_align_v2.py:150-372 up to (not including) the optimiser call.  Returns None when the hard-case rules say "keep the
+    noisy poses", else a dict: vertices [V, 3] float64 (agents first: x, y, yaw in radians; landmarks: x, y, yaw or x, y, 0),
+    kinds [V] (0 fixed SE2, 1 free SE2, 2 free XY), edges = (agent [E], landmark [E], measurement [E, 3], information [E, 3]),
+    clusters (list of box-index lists, seed first)."""
+    if not use_uncertainty:
+        uncertainty_list = None
+    noisy_lidar_pose = np.asarray(noisy_lidar_pose)
+    N = noisy_lidar_pose.shape[0]
+    tfm = pose_to_tfm(noisy_lidar_pose)
+    nonempty = [i for i, c in enumerate(pred_corners_list) if len(c) != 0]
+    world_corners = [project_box3d_np(pred_corners_list[i], tfm[i]) for i in nonempty]
+    box_local = np.concatenate([corner_to_center(c, "lwh") for c in pred_corners_list if len(c) != 0], axis=0)
+    box_world = [corner_to_center(c, "lwh") for c in world_corners]
+    center_world = np.concatenate([b[:, :3] for b in box_world], axis=0)
+    yaw_world = np.concatenate([b[:, 6] for b in box_world], axis=0)
+    pred_len = [len(c) for c in pred_corners_list]
+    box_to_agent = [i for i in range(N) for _ in range(pred_len[i])]
+    certainty = None
+    if uncertainty_list is not None:
+        certainty = np.exp(-np.concatenate([u for u in uncertainty_list if len(u) != 0], axis=0))
+        certainty[:, :2] /= 1.6 ** 2 + 3.9 ** 2                      # anchor diagonal squared (:187-202)
+        if normalize_uncertainty:
+            certainty = np.sqrt(certainty)
+    dist = all_pair_l2(center_world, center_world)
+    cum = 0
+    for i in range(N):
+        dist[cum: cum + pred_len[i], cum: cum + pred_len[i]] = 10000  # boxes of one agent never pair up
+        cum += pred_len[i]
+    remain = set(range(cum))
+    clusters, landmarks, varies = [], [], []
+    for box_idx in range(cum):
+        if box_idx not in remain:
+            continue
+        near = (dist[box_idx] < thres).nonzero()[0].tolist()
+        if len(near) == 0:
+            continue                                              # stays in `remain` (it has no neighbours anyway)
+        # the reference's growth loop re-reads the SEED's row (:247), so a cluster is the seed plus its free neighbours
+        members = [box_idx] + [j for j in near if j in remain]
+        if len(members) == 1:
+            remain.remove(box_idx)
+            continue
+        yaw_var = np.var([yaw_world[j] for j in members])
+        if landmark_SE2 and not (adaptive_landmark and yaw_var > yaw_var_thres):
+            lm = center_world[box_idx].copy()
+            lm[2] = yaw_world[box_idx]
+        else:
+            lm = center_world[box_idx][:2]
+            if landmark_SE2:
+                for j in members:
+                    certainty[j] *= 2
+        clusters.append(members)
+        landmarks.append(lm)
+        varies.append(bool(yaw_var > yaw_var_thres))
+        for j in members:
+            remain.remove(j)
+    L = len(clusters)
+    if abandon_hard_cases and (L <= 3 or sum(varies) >= 0.5 * L):
+        return None
+    vertices = np.zeros((N + L, 3), dtype=np.float64)
+    kinds = np.ones(N + L, dtype=np.int32)
+    vertices[:N] = noisy_lidar_pose[:, [0, 1, 4]]
+    vertices[:N, 2] = np.deg2rad(vertices[:N, 2])
+    kinds[0] = 0
+    e_agent, e_lm, e_meas, e_info = [], [], [], []
+    for k, (members, lm) in enumerate(zip(clusters, landmarks)):
+        se2 = lm.shape[0] == 3
+        vertices[N + k, : lm.shape[0]] = lm
+        kinds[N + k] = 1 if se2 else 2
+        if drop_hard_boxes and varies[k]:
+            continue
+        for j in members:
+            info = np.ones(3)
+            if certainty is not None:
+                if drop_unsure_edge and sum(certainty[j]) < 100:
+                    continue
+                info[: 3 if se2 else 2] = certainty[j][: 3 if se2 else 2]
+            meas = box_local[j][[0, 1, 6]].astype(np.float64)
+            if not se2:
+                meas[2], info[2] = 0.0, 0.0
+            e_agent.append(box_to_agent[j]); e_lm.append(N + k); e_meas.append(meas); e_info.append(info)
+    edges = (np.asarray(e_agent, dtype=np.int32), np.asarray(e_lm, dtype=np.int32),
+             np.asarray(e_meas, dtype=np.float64).reshape(-1, 3), np.asarray(e_info, dtype=np.float64).reshape(-1, 3))
+    return {"vertices": vertices, "kinds": kinds, "edges": edges, "clusters": clusters, "n_agents": N}
+
+
+def _normalize_theta(t):
+    return np.arctan2(np.sin(t), np.cos(t))
+
+
+def pose_graph_residuals(vertices, kinds, edges):
+    """g2o EdgeSE2::computeError (e = toVector(M^-1 * (X1^-1 * X2))) / EdgeSE2PointXY (e = X1^-1 * l - m), stacked [E, 3]
+    (third component 0 for point landmarks)."""
+    ea, el, meas, _ = edges
+    a, l = vertices[ea], vertices[el]
+    c1, s1 = np.cos(a[:, 2]), np.sin(a[:, 2])
+    dx, dy = l[:, 0] - a[:, 0], l[:, 1] - a[:, 1]
+    rx, ry = c1 * dx + s1 * dy, -s1 * dx + c1 * dy                  # R1^T (t2 - t1)
+    se2 = kinds[el] == 1
+    cm, sm = np.where(se2, np.cos(meas[:, 2]), 1.0), np.where(se2, np.sin(meas[:, 2]), 0.0)
+    ux, uy = rx - meas[:, 0], ry - meas[:, 1]
+    e = np.zeros((len(ea), 3))
+    e[:, 0], e[:, 1] = cm * ux + sm * uy, -sm * ux + cm * uy
+    e[:, 2] = np.where(se2, _normalize_theta(l[:, 2] - a[:, 2] - meas[:, 2]), 0.0)
+    return e
+
+
+def pose_graph_chi2(vertices, kinds, edges):
+    e = pose_graph_residuals(vertices, kinds, edges)
+    return float(np.sum(e * e * edges[3]))
+
+
+def pose_graph_lm(vertices, kinds, edges, max_iterations: int = 1000):
+    """g2o's SparseOptimizer::optimize with OptimizationAlgorithmLevenberg over a dense solve, restated:
+    lambda0 = 1e-5 * max diag(H); each iteration tries up to 10 damped steps  (H + lambda I) dx = b,  applies
+    X <- X * dx for SE2 vertices (t += R dt, theta += dtheta, normalised) and l += dl for points,
+    rho = (chi2 - chi2_new) / (dx . (lambda dx + b) + 1e-3); accepted steps scale lambda by
+    clamp(1 - (2 rho - 1)^3, 1/3, 2/3), rejected ones multiply it by ni = 2, 4, 8...; stop on rho == 0, ten rejections in
+    a row or max_iterations.  Vertices without edges are left untouched (g2o's active set).  Returns (vertices, stats)."""
+    x = np.array(vertices, dtype=np.float64)
+    ea, el, meas, info = edges
+    E, V = len(ea), len(x)
+    active = np.zeros(V, dtype=bool)
+    active[ea] = True; active[el] = True
+    free = np.nonzero(active & (kinds != 0))[0]
+    if E == 0 or len(free) == 0:
+        return x, {"iterations": 0, "chi2": 0.0, "chi2_initial": 0.0}
+    dim = np.where(kinds[free] == 2, 2, 3)
+    start = np.concatenate([[0], np.cumsum(dim)])
+    col = {int(v): int(s) for v, s in zip(free, start[:-1])}
+    n = int(start[-1])
+
+    def linearize(x):
+        H, b = np.zeros((n, n)), np.zeros(n)
+        e = pose_graph_residuals(x, kinds, edges)
+        for k in range(E):
+            a, l = x[ea[k]], x[el[k]]
+            se2 = kinds[el[k]] == 1
+            c1, s1 = np.cos(a[2]), np.sin(a[2])
+            cm, sm = (np.cos(meas[k, 2]), np.sin(meas[k, 2])) if se2 else (1.0, 0.0)
+            RmT = np.array([[cm, sm], [-sm, cm]])
+            dRT1 = np.array([[-s1, c1], [-c1, -s1]])
+            d = l[:2] - a[:2]
+            A = np.zeros((3, 3)); B = np.zeros((3, 3))
+            A[:2, :2] = -RmT
+            A[:2, 2] = RmT @ dRT1 @ d
+            R1T = np.array([[c1, s1], [-s1, c1]])
+            if se2:
+                c2, s2 = np.cos(l[2]), np.sin(l[2])
+                B[:2, :2] = RmT @ R1T @ np.array([[c2, -s2], [s2, c2]])
+                A[2, 2], B[2, 2] = -1.0, 1.0
+            else:
+                B[:2, :2] = R1T
+            W = np.diag(info[k])
+            blocks = [(ea[k], A, 3), (el[k], B, 3 if se2 else 2)]
+            for vi, Ji, di in blocks:
+                if kinds[vi] == 0:
+                    continue
+                ci = col[int(vi)]
+                b[ci: ci + di] -= (Ji.T @ W @ e[k])[:di]
+                for vj, Jj, dj in blocks:
+                    if kinds[vj] == 0:
+                        continue
+                    cj = col[int(vj)]
+                    H[ci: ci + di, cj: cj + dj] += (Ji.T @ W @ Jj)[:di, :dj]
+        return H, b, float(np.sum(e * e * info))
+
+    def apply(x, dx):
+        y = x.copy()
+        for v, s, d in zip(free, start[:-1], dim):
+            if d == 3:
+                c, s_ = np.cos(y[v, 2]), np.sin(y[v, 2])
+                y[v, 0] += c * dx[s] - s_ * dx[s + 1]
+                y[v, 1] += s_ * dx[s] + c * dx[s + 1]
+                y[v, 2] = _normalize_theta(y[v, 2] + dx[s + 2])
+            else:
+                y[v, :2] += dx[s: s + 2]
+        return y
+
+    lam, it = 0.0, 0
+    chi0 = None
+    for it in range(max_iterations):
+        H, b, chi = linearize(x)
+        if it == 0:
+            lam, chi0 = 1e-5 * float(np.max(np.diag(H))), chi
+        ni, rho, qmax = 2.0, 0.0, 0
+        while True:
+            try:
+                dx = np.linalg.solve(H + lam * np.eye(n), b)
+                y = apply(x, dx)
+                new = pose_graph_chi2(y, kinds, edges)
+                ok = np.all(np.isfinite(dx))
+            except np.linalg.LinAlgError:
+                ok, new, dx, y = False, np.inf, np.zeros(n), x
+            rho = (chi - new) / ((float(dx @ (lam * dx + b)) + 1e-3) if ok else 1.0)
+            if rho > 0 and np.isfinite(new) and ok:
+                alpha = min(1.0 - (2 * rho - 1) ** 3, 2.0 / 3.0)
+                lam *= max(1.0 / 3.0, alpha)
+                ni, x, chi = 2.0, y, new
+            else:
+                lam *= ni
+                ni *= 2
+                if not np.isfinite(lam):
+                    break
+            qmax += 1
+            if not (rho < 0 and qmax < 10):
+                break
+        if qmax == 10 or rho == 0 or not np.isfinite(lam):
+            break
+    return x, {"iterations": it + 1, "chi2": pose_graph_chi2(x, kinds, edges), "chi2_initial": chi0}
+
+
+def box_alignment_relative_sample_np(pred_corners_list, noisy_lidar_pose, uncertainty_list=None, max_iterations=1000, **flags):
+    """box_align_v2.py:101-396 -> refined [N, 3] (x, y, yaw in degrees)."""
+    noisy_lidar_pose = np.asarray(noisy_lidar_pose)
+    g = build_pose_graph(pred_corners_list, noisy_lidar_pose, uncertainty_list, **flags)
+    if g is None:
+        return noisy_lidar_pose[:, [0, 1, 4]]
+    x, _ = pose_graph_lm(g["vertices"], g["kinds"], g["edges"], max_iterations)
+    refined = x[: g["n_agents"]].copy()
+    refined[:, 2] = np.rad2deg(refined[:, 2])
+    return refined

@@ -12,7 +12,7 @@ shrunk for the mini cases), ``PillarVFE``, ``PointPillarScatter``, ``normalize_p
 
 Optional third-party modules the reference imports at module scope but that are absent here are
 replaced by inert stubs (icecream, pyquaternion, turtle, cv2, open3d, the un-built Cython
-``box_overlaps``, pypcd).  ``shapely.geometry.Polygon`` -- the one stub that *computes* something -- is backed
+``box_overlaps``, pypcd).  ``g2o`` (pose-graph solver, absent) is a recording stand-in, see ``_G2O``.  ``shapely.geometry.Polygon`` -- the one stub that *computes* something -- is backed
 by the oracle's fp64 clipping routine: this pins the reference's NMS control flow (argsort, top-1000,
 float32 IoU array, strict ``>``) but NOT the GEOS area arithmetic (parity unpinned).
 """
@@ -59,6 +59,82 @@ class _OraclePolygon:
         return _OraclePolygon(area=self.area + other.area - oracle.quad_intersection_area(self.pts, other.pts))
 
 
+class _G2O:
+    """Recording stand-in for the python `g2o` binding (absent here): keeps the vertices / edges the reference adds and, in
+    optimize(), hands them to the oracle's restatement of g2o's Levenberg-Marquardt.  Pins everything of box_align_v2 except
+    the optimiser's own arithmetic."""
+    recorded = []
+
+    class SE2:
+        def __init__(self, *a):
+            self.v = np.asarray(a[0] if len(a) == 1 else a, dtype=np.float64).reshape(3).copy()
+
+        def vector(self):
+            return self.v
+
+    class _Vertex:
+        kind = 1
+
+        def set_estimate(self, e): self.e = e
+        def set_id(self, i): self.i = i
+        def set_fixed(self, f): self.f = f
+        def estimate(self): return self.e
+
+    class VertexSE2(_Vertex):
+        kind = 1
+
+    class VertexPointXY(_Vertex):
+        kind = 2
+
+    class _Edge:
+        def __init__(self): self.vs = [None, None]; self.rk = None
+        def set_vertex(self, i, v): self.vs[i] = v
+        def set_measurement(self, m): self.m = m
+        def set_information(self, w): self.w = np.asarray(w, dtype=np.float64)
+        def set_robust_kernel(self, k): self.rk = k
+
+    class EdgeSE2(_Edge):
+        pass
+
+    class EdgeSE2PointXY(_Edge):
+        pass
+
+    class SparseOptimizer:
+        def __init__(self): self.V, self.E = {}, []
+        def set_algorithm(self, a): pass
+        def set_verbose(self, v): pass
+        def add_vertex(self, v): self.V[v.i] = v
+        def add_edge(self, e): self.E.append(e)
+        def vertex(self, i): return self.V[i]
+        def initialize_optimization(self): pass
+
+        def optimize(self, n):
+            ids = sorted(self.V)
+            assert ids == list(range(len(ids)))
+            vert = np.zeros((len(ids), 3)); kinds = np.zeros(len(ids), dtype=np.int32)
+            for i in ids:
+                v = self.V[i]
+                est = v.e.vector() if isinstance(v.e, _G2O.SE2) else np.asarray(v.e, dtype=np.float64)
+                vert[i, : len(est)] = est
+                kinds[i] = 0 if v.f else v.kind
+            ea = np.array([e.vs[0].i for e in self.E], dtype=np.int32); el = np.array([e.vs[1].i for e in self.E], dtype=np.int32)
+            meas = np.zeros((len(self.E), 3)); info = np.zeros((len(self.E), 3))
+            for k, e in enumerate(self.E):
+                m = e.m.vector() if isinstance(e.m, _G2O.SE2) else np.asarray(e.m, dtype=np.float64)
+                meas[k, : len(m)] = m
+                assert np.array_equal(e.w, np.diag(np.diag(e.w))) and e.rk is None
+                info[k, : len(m)] = np.diag(e.w)
+            edges = (ea, el, meas, info)
+            x, stats = oracle.pose_graph_lm(vert, kinds, edges, n)
+            _G2O.recorded.append({"vertices": vert, "kinds": kinds, "edges": edges, "solution": x, "iterations": stats["iterations"]})
+            for i in ids:
+                v = self.V[i]
+                v.e = _G2O.SE2(x[i]) if isinstance(v.e, _G2O.SE2) else x[i, :2].copy()
+
+    BlockSolverSE2 = LinearSolverDenseSE2 = OptimizationAlgorithmLevenberg = staticmethod(lambda *a: None)
+    BlockSolverSE3 = LinearSolverCholmodSE3 = staticmethod(lambda *a: None)
+
+
 def install_stubs():
     def mod(name, **attrs):
         m = types.ModuleType(name)
@@ -74,6 +150,7 @@ def install_stubs():
     mod("cv2")
     mod("open3d")
     mod("pypcd").pypcd = mod("pypcd.pypcd")
+    mod("g2o", **{k: getattr(_G2O, k) for k in dir(_G2O) if not k.startswith("__")})
     mod("opencood.utils.box_overlaps", bbox_overlaps=None)
     sys.path.insert(0, REF)
 
@@ -327,6 +404,57 @@ def main():
     cloud[200:210, 2] = -1
     save("points.npz", cloud=cloud, range_masked=pcd_utils.mask_points_by_range(cloud, [-140.8, -40, -3, 140.8, 40, 1]),
          ego_masked=pcd_utils.mask_ego_points(cloud))
+
+    # ------------------------------------------------------------------ pose correction by box alignment (next-3)
+    from opencood.models.sub_modules.box_align_v2 import box_alignment_relative_sample_np
+
+    def align_scene(seed, N, K, pos_noise, rot_noise, detect=0.6, jitter=0.05, yaw_flip=0.0):
+        """K vehicles in the world, N agents each detecting a random subset in its own (true) frame with box noise; the
+        agents' reported poses carry (pos_noise m, rot_noise deg) errors -- what box alignment is there to correct."""
+        rs = np.random.RandomState(seed)
+        obj = np.zeros((K, 7)); obj[:, 0] = rs.uniform(-60, 60, K); obj[:, 1] = rs.uniform(-30, 30, K); obj[:, 2] = -1
+        obj[:, 3:6] = [4.5, 2.0, 1.6]; obj[:, 6] = rs.uniform(-3.1, 3.1, K)
+        pose = np.zeros((N, 6)); pose[:, 0] = rs.uniform(-20, 20, N); pose[:, 1] = rs.uniform(-10, 10, N); pose[:, 4] = rs.uniform(-180, 180, N)
+        noisy = pose.copy()
+        noisy[1:, 0] += rs.normal(0, pos_noise, N - 1); noisy[1:, 1] += rs.normal(0, pos_noise, N - 1); noisy[1:, 4] += rs.normal(0, rot_noise, N - 1)
+        corners, unc = [], []
+        for i in range(N):
+            Ti = np.linalg.inv(x_to_world(pose[i].tolist()))
+            b = obj[rs.uniform(size=K) < detect].copy()
+            b[rs.uniform(size=len(b)) < yaw_flip, 6] += np.pi / 2          # heading disagreements -> "yaw varies" clusters
+            c = box_utils.boxes_to_corners_3d(torch.from_numpy(b), "lwh").numpy()
+            c = (Ti[:3, :3] @ c.transpose(0, 2, 1)).transpose(0, 2, 1) + Ti[:3, 3]
+            c[:, :, :2] += rs.normal(0, jitter, (len(c), 1, 2))
+            corners.append(c.astype(np.float64)); unc.append(rs.uniform(-3, 0, (len(c), 3)))
+        return corners, noisy, unc
+
+    ba = {}
+    cases = [("default", dict(seed=1, N=4, K=30, pos_noise=0.3, rot_noise=0.4), dict(use_uncertainty=True, landmark_SE2=True, adaptive_landmark=False, normalize_uncertainty=False, abandon_hard_cases=True, drop_hard_boxes=True)),
+             ("five_agents", dict(seed=2, N=5, K=60, pos_noise=0.4, rot_noise=0.8), dict(use_uncertainty=True, landmark_SE2=True, adaptive_landmark=False, normalize_uncertainty=False, abandon_hard_cases=True, drop_hard_boxes=True)),
+             ("no_uncertainty", dict(seed=3, N=3, K=40, pos_noise=0.2, rot_noise=0.2), dict(use_uncertainty=False)),
+             ("points", dict(seed=4, N=3, K=40, pos_noise=0.2, rot_noise=0.2), dict(landmark_SE2=False, normalize_uncertainty=True)),
+             ("adaptive", dict(seed=5, N=4, K=50, pos_noise=0.3, rot_noise=0.3, yaw_flip=0.3), dict(adaptive_landmark=True, drop_unsure_edge=True)),
+             ("hard_boxes", dict(seed=6, N=4, K=50, pos_noise=0.3, rot_noise=0.3, yaw_flip=0.15), dict(abandon_hard_cases=True, drop_hard_boxes=True)),
+             ("abandoned_few", dict(seed=7, N=2, K=4, pos_noise=0.3, rot_noise=0.3, detect=0.9), dict(abandon_hard_cases=True)),
+             ("abandoned_yaw", dict(seed=8, N=3, K=30, pos_noise=0.3, rot_noise=0.3, yaw_flip=0.8), dict(abandon_hard_cases=True)),
+             ("empty_agent", dict(seed=9, N=3, K=30, pos_noise=0.3, rot_noise=0.3), dict())]
+    for tag, sc, flags in cases:
+        corners, noisy, unc = align_scene(**sc)
+        if tag == "empty_agent":
+            corners[1], unc[1] = np.zeros((0, 8, 3)), np.zeros((0, 3))
+        if tag == "adaptive":
+            unc = [u - 3.5 for u in unc]                 # certain enough that drop_unsure_edge keeps most edges, not all
+        _G2O.recorded.clear()
+        refined = box_alignment_relative_sample_np([c.copy() for c in corners], noisy.copy(), uncertainty_list=[u.copy() for u in unc], **flags)
+        ba.update({f"{tag}_corners": np.concatenate(corners), f"{tag}_len": np.array([len(c) for c in corners]), f"{tag}_unc": np.concatenate(unc),
+                   f"{tag}_noisy": noisy, f"{tag}_refined": refined, f"{tag}_flags": np.array(sorted(f"{k}={v}" for k, v in flags.items())),
+                   f"{tag}_solved": len(_G2O.recorded)})
+        if _G2O.recorded:
+            g = _G2O.recorded[0]
+            ba.update({f"{tag}_vertices": g["vertices"], f"{tag}_kinds": g["kinds"], f"{tag}_edge_agent": g["edges"][0], f"{tag}_edge_landmark": g["edges"][1],
+                       f"{tag}_edge_meas": g["edges"][2], f"{tag}_edge_info": g["edges"][3], f"{tag}_solution": g["solution"]})
+        print(f"  box_align {tag}: solved={len(_G2O.recorded)} moved={np.abs(refined - noisy[:, [0, 1, 4]]).max():.3f}")
+    save("box_align.npz", **ba)
 
     # ------------------------------------------------------------------ full-size pillar path + fusion (samples only)
     hf = load_hypes(YAML_COALIGN)

@@ -612,3 +612,65 @@ def test_voxelize_feeds_the_detector():
     pf = oracle.pillar_vfe(T(rv), T(rn), T(rc), sd, margs["voxel_size"], margs["lidar_range"])
     ref_canvas = oracle.scatter(pf, T(rc), 2, 704, 200)
     feat_close(canvas, ref_canvas, what="canvas from device voxels")
+
+
+# ------------------------------------------------------------------------------------------------ box alignment (next-3)
+def test_pose_graph_solver_vs_reference_graphs_and_oracle(golden):
+    """coalign_pose_graph_optimize on the graphs the reference built (recorded from its g2o calls): agents end at the oracle
+    LM's solution -- which the CPU suite checks against scipy's independent least-squares optimum -- for SE2 and point
+    landmarks, with / without information matrices, dropped clusters, an agent without boxes; all nine in ONE launch."""
+    from coalign_amd import box_align
+    from tests.test_oracle_golden import BOX_ALIGN_CASES
+    g = golden("box_align.npz")
+    tags = [t for t in BOX_ALIGN_CASES if int(g[f"{t}_solved"])]
+    graphs = [box_align.PoseGraph(g[f"{t}_vertices"], g[f"{t}_kinds"], g[f"{t}_edge_agent"], g[f"{t}_edge_landmark"], g[f"{t}_edge_meas"],
+                                  g[f"{t}_edge_info"], int(g[f"{t}_len"].shape[0])) for t in tags]
+    solved, stats = box_align.optimize_pose_graphs(graphs)
+    again, _ = box_align.optimize_pose_graphs(graphs)
+    for t, graph, x, y, st in zip(tags, graphs, solved, again, stats):
+        ref = g[f"{t}_solution"]
+        n = graph.n_agents
+        edges = (graph.edge_agent, graph.edge_landmark, graph.edge_meas, graph.edge_info)
+        assert np.array_equal(x, y), t                                              # deterministic
+        assert np.array_equal(x[0], graph.vertices[0]), t                           # ego fixed
+        np.testing.assert_allclose(x[:n, :2], ref[:n, :2], rtol=0, atol=1e-6, err_msg=t)
+        assert np.abs(oracle._normalize_theta(x[:n, 2] - ref[:n, 2])).max() < 1e-7, t
+        chi_ref = oracle.pose_graph_chi2(ref, graph.kinds, edges)
+        assert abs(oracle.pose_graph_chi2(x, graph.kinds, edges) - chi_ref) <= 1e-9 * max(1.0, chi_ref), t
+        assert abs(st[2] - chi_ref) <= 1e-9 * max(1.0, chi_ref) and 0 < st[0] < 200 and st[2] <= st[1], (t, st)
+        untouched = np.ones(len(x), dtype=bool); untouched[graph.edge_agent] = False; untouched[graph.edge_landmark] = False
+        assert np.array_equal(x[untouched], graph.vertices[untouched]), t           # vertices without edges do not move
+
+
+def test_box_alignment_end_to_end_vs_reference(golden):
+    """box_alignment_relative_sample_np (host graph construction + device solve) returns the reference's refined poses; the
+    batched entry point and the g2o-shaped PoseGraphOptimization2D wrapper agree with it."""
+    from coalign_amd import box_align
+    from tests.test_oracle_golden import BOX_ALIGN_CASES, box_align_inputs
+    g = golden("box_align.npz")
+    samples = []
+    for tag in BOX_ALIGN_CASES:
+        corners, noisy, unc, flags = box_align_inputs(g, tag)
+        refined = box_align.box_alignment_relative_sample_np(corners, noisy.copy(), uncertainty_list=unc, **flags)
+        np.testing.assert_allclose(refined[:, :2], g[f"{tag}_refined"][:, :2], rtol=0, atol=2e-5, err_msg=tag)
+        assert np.abs((refined[:, 2] - g[f"{tag}_refined"][:, 2] + 180) % 360 - 180).max() < 1e-4, tag
+        if tag in ("default", "five_agents", "hard_boxes"):
+            samples.append({"pred_corners_list": corners, "noisy_lidar_pose": noisy, "uncertainty_list": unc})
+    batch = box_align.box_alignment_batch(samples, use_uncertainty=True, landmark_SE2=True, abandon_hard_cases=True, drop_hard_boxes=True)
+    for tag, out in zip(("default", "five_agents", "hard_boxes"), batch):
+        np.testing.assert_allclose(out, g[f"{tag}_refined"], rtol=0, atol=1e-4, err_msg=tag)
+    # the reference's own call sequence against the g2o-shaped wrapper
+    t = "points"
+    pgo = box_align.PoseGraphOptimization2D()
+    vert, kinds = g[f"{t}_vertices"], g[f"{t}_kinds"]
+    for i in range(len(vert)):
+        if kinds[i] == 2:
+            pgo.add_vertex(i, vert[i, :2], fixed=False, SE2=False)
+        else:
+            pgo.add_vertex(i, box_align.SE2(vert[i]), fixed=kinds[i] == 0)
+    for a, l, m, w in zip(g[f"{t}_edge_agent"], g[f"{t}_edge_landmark"], g[f"{t}_edge_meas"], g[f"{t}_edge_info"]):
+        pgo.add_edge([int(a), int(l)], m[:2], np.diag(w[:2]), SE2=False)
+    pgo.optimize(1000)
+    n = int(g[f"{t}_len"].shape[0])
+    got = np.array([pgo.get_pose(i).vector() for i in range(n)])
+    np.testing.assert_allclose(got[:, :2], g[f"{t}_solution"][:n, :2], rtol=0, atol=1e-6)

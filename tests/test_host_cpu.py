@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(REPO, "include", "coalign_amd.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(coalign_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) == 18
+    assert len(declared) == 20
     lib = hip.lib()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/coalign_amd.h but not exported"
@@ -154,3 +154,27 @@ def test_synthetic_frame_contract():
     pad = torch.arange(32)[None, :] >= pl["voxel_num_points"][:, None]
     assert float(pl["voxel_features"][pad].abs().sum()) == 0.0               # zero padded
     assert int(pl["voxel_num_points"].min()) >= 1 and int(pl["voxel_num_points"].max()) <= 32
+
+
+def test_box_alignment_graph_construction_matches_reference(golden):
+    """Host half of next-3 (coalign_amd/box_align.py, no GPU needed): clusters, landmarks, edges and information matrices equal
+    the graph the reference hands to g2o; the hard-case rules return None where the reference returns the noisy poses."""
+    import numpy as np
+    from coalign_amd import box_align
+    from tests.test_oracle_golden import BOX_ALIGN_CASES, box_align_inputs
+    g = golden("box_align.npz")
+    for tag in BOX_ALIGN_CASES:
+        corners, noisy, unc, flags = box_align_inputs(g, tag)
+        graph = box_align.build_pose_graph(corners, noisy, unc, **flags)
+        if int(g[f"{tag}_solved"]) == 0:
+            assert graph is None
+            assert np.array_equal(box_align._refined(None, None, noisy), g[f"{tag}_refined"])
+            continue
+        graph.check()
+        n = graph.n_agents
+        assert np.array_equal(graph.kinds, g[f"{tag}_kinds"])
+        assert np.array_equal(graph.edge_agent, g[f"{tag}_edge_agent"]) and np.array_equal(graph.edge_landmark, g[f"{tag}_edge_landmark"])
+        assert np.array_equal(graph.vertices[:n], g[f"{tag}_vertices"][:n])                       # agents: exact
+        np.testing.assert_allclose(graph.vertices[n:], g[f"{tag}_vertices"][n:], rtol=0, atol=1e-4)  # landmarks: float32 world frame
+        np.testing.assert_allclose(graph.edge_meas, g[f"{tag}_edge_meas"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(graph.edge_info, g[f"{tag}_edge_info"], rtol=1e-12, atol=0)

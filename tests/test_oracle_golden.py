@@ -258,3 +258,63 @@ def test_voxel_generator_restatement_is_self_consistent(golden):
     assert n.max() == 3 and len(v) == 40
     feats, coords, num = oracle.collate_voxels([(v, c, n), (pv, pc, pn)])
     assert feats.shape[0] == 80 and coords.shape == (80, 4) and list(np.unique(coords[:, 0])) == [0, 1]
+
+
+BOX_ALIGN_CASES = ("default", "five_agents", "no_uncertainty", "points", "adaptive", "hard_boxes", "abandoned_few", "abandoned_yaw", "empty_agent")
+
+
+def box_align_inputs(g, tag):
+    lens = g[f"{tag}_len"]
+    cuts = np.cumsum(lens)[:-1]
+    flags = {}
+    for item in g[f"{tag}_flags"]:
+        k, v = str(item).split("=")
+        flags[k] = v == "True"
+    return np.split(g[f"{tag}_corners"], cuts), g[f"{tag}_noisy"], np.split(g[f"{tag}_unc"], cuts), flags
+
+
+@pytest.mark.parametrize("tag", BOX_ALIGN_CASES)
+def test_box_alignment_matches_reference(golden, tag):
+    """next-3: the pose graph the reference hands to g2o (vertices, kinds, edges, information) and the refined poses it returns
+    (solver = the oracle's LM behind a recording g2o stand-in, see make_golden.py) are reproduced by the restatement."""
+    g = golden("box_align.npz")
+    corners, noisy, unc, flags = box_align_inputs(g, tag)
+    graph = oracle.build_pose_graph(corners, noisy, unc, **flags)
+    if int(g[f"{tag}_solved"]) == 0:
+        assert graph is None
+    else:
+        assert np.array_equal(graph["kinds"], g[f"{tag}_kinds"])
+        assert np.array_equal(graph["edges"][0], g[f"{tag}_edge_agent"]) and np.array_equal(graph["edges"][1], g[f"{tag}_edge_landmark"])
+        np.testing.assert_allclose(graph["vertices"], g[f"{tag}_vertices"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(graph["edges"][2], g[f"{tag}_edge_meas"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(graph["edges"][3], g[f"{tag}_edge_info"], rtol=1e-12, atol=0)
+    refined = oracle.box_alignment_relative_sample_np(corners, noisy, unc, **flags)
+    np.testing.assert_allclose(refined, g[f"{tag}_refined"], rtol=0, atol=1e-7)
+
+
+def test_pose_graph_lm_reaches_the_least_squares_optimum(golden):
+    """g2o is absent (parity unpinned): the restated Levenberg-Marquardt is checked against an independent solver
+    (scipy.optimize.least_squares, trust-region) on the same residuals, and against the defining properties of the problem."""
+    from scipy.optimize import least_squares
+    g = golden("box_align.npz")
+    for tag in ("default", "five_agents", "points", "adaptive"):
+        kinds = g[f"{tag}_kinds"]
+        edges = (g[f"{tag}_edge_agent"], g[f"{tag}_edge_landmark"], g[f"{tag}_edge_meas"], g[f"{tag}_edge_info"])
+        x, stats = oracle.pose_graph_lm(g[f"{tag}_vertices"], kinds, edges)
+        assert stats["chi2"] < stats["chi2_initial"] and stats["iterations"] < 200
+        assert np.array_equal(x[0], g[f"{tag}_vertices"][0])                      # the ego vertex is fixed
+        active = np.zeros(len(kinds), dtype=bool); active[edges[0]] = True; active[edges[1]] = True
+        free = np.nonzero(active & (kinds != 0))[0]
+        assert np.array_equal(x[~active], g[f"{tag}_vertices"][~active])          # vertices without edges do not move
+        cols = np.concatenate([[3 * i, 3 * i + 1] + ([3 * i + 2] if kinds[v] == 1 else []) for i, v in enumerate(free)]).astype(int)
+
+        def fun(p):
+            v = g[f"{tag}_vertices"].copy()
+            flat = v[free].ravel(); flat[cols] = p; v[free] = flat.reshape(-1, 3)
+            return (oracle.pose_graph_residuals(v, kinds, edges) * np.sqrt(edges[3])).ravel()
+        sol = least_squares(fun, g[f"{tag}_vertices"][free].ravel()[cols], xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        assert abs(2 * sol.cost - stats["chi2"]) <= 1e-9 * max(1.0, stats["chi2"])
+        n_agents = int(np.sum(edges[0].max() + 1))
+        best = g[f"{tag}_vertices"].copy(); flat = best[free].ravel(); flat[cols] = sol.x; best[free] = flat.reshape(-1, 3)
+        np.testing.assert_allclose(x[:n_agents, :2], best[:n_agents, :2], rtol=0, atol=1e-6)
+        assert np.abs(oracle._normalize_theta(x[:n_agents, 2] - best[:n_agents, 2])).max() < 1e-7
