@@ -25,6 +25,8 @@ def _run_heads(model: nn.Module, x: torch.Tensor) -> dict:
     """cls / reg / dir 1x1 heads.  Inference fast path: one convolution with the concatenated head weights (+ one fused
     bias pass) instead of three convolutions and three bias kernels; the outputs are channel slices of one tensor."""
     heads = [("cls_preds", model.cls_head), ("reg_preds", model.reg_head)]
+    if getattr(model, "unc_head", None) is not None:
+        heads.append(("unc_preds", model.unc_head))
     if model.use_dir:
         heads.append(("dir_preds", model.dir_head))
     if not _fast_ok(model, x):
@@ -174,10 +176,38 @@ class PointPillar(nn.Module):
         return _run_heads(self, x)
 
 
+class PointPillarUncertainty(nn.Module):
+    """Stage-1 single-agent detector of CoAlign's box alignment (opencood/models/point_pillar_uncertainty.py:15-84): PointPillar
+    with a fourth 1x1 head ``unc_head`` predicting ``uncertainty_dim`` log-variances (x, y[, yaw]) per anchor."""
+
+    def __init__(self, args: dict):
+        super().__init__()
+        self.pillar_vfe = PillarVFE(args["pillar_vfe"], num_point_features=4, voxel_size=args["voxel_size"],
+                                    point_cloud_range=args["lidar_range"])
+        self.scatter = PointPillarScatter(args["point_pillar_scatter"])
+        self.backbone = BaseBEVBackbone(args["base_bev_backbone"], 64)
+        self.uncertainty_dim = args["uncertainty_dim"]
+        width = 128 * 3                                          # hard-coded in the reference (:26-37)
+        self.cls_head = nn.Conv2d(width, args["anchor_number"], kernel_size=1)
+        self.reg_head = nn.Conv2d(width, 7 * args["anchor_number"], kernel_size=1)
+        self.unc_head = nn.Conv2d(width, self.uncertainty_dim * args["anchor_number"], kernel_size=1)
+        self.use_dir = "dir_args" in args
+        if self.use_dir:
+            self.dir_head = nn.Conv2d(width, args["dir_args"]["num_bins"] * args["anchor_number"], kernel_size=1)
+
+    def forward(self, data_dict: dict) -> dict:
+        pl = data_dict["processed_lidar"]
+        batch_dict = {"voxel_features": pl["voxel_features"], "voxel_coords": pl["voxel_coords"],
+                      "voxel_num_points": pl["voxel_num_points"]}
+        batch_dict = self.backbone(self.scatter(self.pillar_vfe(batch_dict)))
+        return _run_heads(self, batch_dict["spatial_features_2d"])
+
+
 MODEL_REGISTRY = {
     "point_pillar_baseline_multiscale": PointPillarBaselineMultiscale,
     "point_pillar_coalign": CoAlign,
     "point_pillar": PointPillar,
+    "point_pillar_uncertainty": PointPillarUncertainty,
 }
 
 

@@ -204,9 +204,57 @@ class PostProcessHandle:
         return self.buf.out_corners[:n_out].clone(), self.buf.out_scores[:n_out].clone()
 
 
+class UncertaintyVoxelPostprocessor(VoxelPostprocessor):
+    """opencood/data_utils/post_processor/uncertainty_voxel_postprocessor.py:26-112: the post-processor of the stage-1 models."""
+
+    def post_process_stage1(self, stage1_output_dict: dict, anchor_box):
+        """Per-agent detections *in each agent's own frame* for box alignment: score threshold, box decode, direction fix,
+        corners, rotated NMS per agent -- no projection, no size / z / range filters.  Returns three lists with one entry per
+        agent: corners [K_i, 8, 3], boxes [K_i, 7], uncertainty [K_i, uncertainty_dim] (raw ``unc_preds`` of the kept anchors);
+        ``(None, None, None)`` when no anchor of any agent passes the threshold.  Same kernels as ``post_process``: the decode
+        kernel with an identity transform, the NMS without the sanity mask."""
+        cls, reg, unc = stage1_output_dict["cls_preds"], stage1_output_dict["reg_preds"], stage1_output_dict["unc_preds"]
+        dirp = stage1_output_dict.get("dir_preds")
+        device = cls.device
+        n_agents, A, H, W = cls.shape
+        udim = unc.shape[1] // A
+        anchors = self._anchors_f32(anchor_box, device)
+        key = ("stage1", str(device), A, H, W)
+        ring = self._buffers.get(key)
+        if ring is None:
+            ring = self._buffers[key] = [ops.DecodeBuffers(A * H * W, A, H, W, NMS_TOP, device)]
+        buf = ring[0]
+        thr = self.params["target_args"]["score_threshold"]
+        da = self.params.get("dir_args", {})
+        corners, boxes, uncertainty, any_box = [], [], [], False
+        for i in range(n_agents):
+            buf.counts.zero_()
+            buf.status.zero_()
+            ops.anchor_decode(buf, 0, cls[i], reg[i], None if dirp is None else dirp[i], anchors, thr, da.get("dir_offset", 0.0),
+                              da.get("num_bins", 2), self.params["order"], None)
+            k_dev = buf.counts[1:2]
+            ops.nms_rotated_device(buf.cand_corners, buf.cand_score, self.params["nms_thresh"], NMS_TOP, valid=None, k_dev=k_dev,
+                                   keep=buf.keep, keep_count=buf.keep_count, ws=buf.nms_ws)
+            n_keep, n_cand = int(buf.keep_count.item()), int(k_dev.item())
+            any_box = any_box or n_cand > 0
+            keep = buf.keep[:n_keep].long()
+            flat = buf.cand_index[keep].long()                        # (h, w, anchor) order, like the reference's mask
+            hw, an = torch.div(flat, A, rounding_mode="floor"), flat % A
+            u = unc[i].reshape(A, udim, H * W)[an, :, hw]              # unc_preds.permute(0, 2, 3, 1).view(-1, udim)[mask]
+            corners.append(buf.cand_corners[keep].clone())
+            boxes.append(buf.cand_box7[keep].clone())
+            uncertainty.append(u.reshape(-1, udim))
+        if not any_box:
+            return None, None, None
+        return corners, boxes, uncertainty
+
+
+POSTPROCESSORS = {"VoxelPostprocessor": VoxelPostprocessor, "UncertaintyVoxelPostprocessor": UncertaintyVoxelPostprocessor}
+
+
 def build_postprocessor(anchor_cfg: dict, train: bool) -> VoxelPostprocessor:
-    """opencood/data_utils/post_processor/__init__.py:build_postprocessor for the hot path's only family."""
+    """opencood/data_utils/post_processor/__init__.py:build_postprocessor for the families on the hot path and its stage 1."""
     name = anchor_cfg["core_method"]
-    if name != "VoxelPostprocessor":
-        raise KeyError(f"post-processor '{name}' is outside the CoAlign hot path")
-    return VoxelPostprocessor(anchor_params=anchor_cfg, train=train)
+    if name not in POSTPROCESSORS:
+        raise KeyError(f"post-processor '{name}' is outside the CoAlign hot path (available: {sorted(POSTPROCESSORS)})")
+    return POSTPROCESSORS[name](anchor_params=anchor_cfg, train=train)

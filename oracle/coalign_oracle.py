@@ -310,6 +310,8 @@ def shrink_and_heads(x: torch.Tensor, sd, use_dir=True) -> Dict[str, torch.Tenso
         x = torch.relu(F.conv2d(x, sd[p + "2.weight"], sd[p + "2.bias"], padding=1))
     out = {"cls_preds": F.conv2d(x, sd["cls_head.weight"], sd["cls_head.bias"]),
            "reg_preds": F.conv2d(x, sd["reg_head.weight"], sd["reg_head.bias"])}
+    if "unc_head.weight" in sd:                     # stage-1 models, point_pillar_uncertainty.py:36-37,71
+        out["unc_preds"] = F.conv2d(x, sd["unc_head.weight"], sd["unc_head.bias"])
     if use_dir and "dir_head.weight" in sd:
         out["dir_preds"] = F.conv2d(x, sd["dir_head.weight"], sd["dir_head.bias"])
     return out
@@ -1108,3 +1110,24 @@ def box_alignment_relative_sample_np(pred_corners_list, noisy_lidar_pose, uncert
     refined = x[: g["n_agents"]].copy()
     refined[:, 2] = np.rad2deg(refined[:, 2])
     return refined
+
+
+def post_process_stage1(out: Dict[str, torch.Tensor], anchors: torch.Tensor, pp_cfg: dict):
+    """UncertaintyVoxelPostprocessor.post_process_stage1 (uncertainty_voxel_postprocessor.py:30-112): per agent -- score
+    threshold, decode + direction fix, corners in the agent's own frame (no projection, no size / z / range filters), rotated
+    NMS -> lists of corners [K_i, 8, 3], boxes [K_i, 7], uncertainty [K_i, dim]; (None, None, None) without any candidate."""
+    thr, order, da = pp_cfg["target_args"]["score_threshold"], pp_cfg["order"], pp_cfg.get("dir_args", {})
+    cls, reg, unc, dirp = out["cls_preds"], out["reg_preds"], out["unc_preds"], out.get("dir_preds")
+    A = cls.shape[1]
+    udim = unc.shape[1] // A
+    corners_l, boxes_l, unc_l, total = [], [], [], 0
+    for i in range(cls.shape[0]):
+        idx, boxes3d, scores, corners = decode_candidates(cls[i: i + 1], reg[i: i + 1], None if dirp is None else dirp[i: i + 1], anchors, thr,
+                                                          order, da.get("dir_offset", 0.7853), da.get("num_bins", 2), None)
+        total += len(idx)
+        u = unc[i].permute(1, 2, 0).reshape(-1, udim)[idx]
+        keep = torch.from_numpy(nms_rotated(corners, scores, pp_cfg["nms_thresh"]).astype(np.int64)) if len(idx) else torch.zeros(0, dtype=torch.long)
+        corners_l.append(corners[keep]); boxes_l.append(boxes3d[keep]); unc_l.append(u[keep])
+    if total == 0:
+        return None, None, None
+    return corners_l, boxes_l, unc_l

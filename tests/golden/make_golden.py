@@ -34,6 +34,7 @@ from coalign_amd.synthetic import fill_parameters_, make_frame  # noqa: E402  (i
 REF = "/root/reference"
 YAML_COALIGN = REF + "/opencood/hypes_yaml/opv2v/lidar_only_with_noise/coalign/pointpillar_coalign.yaml"
 YAML_SINGLE = REF + "/opencood/hypes_yaml/opv2v/lidar_only_with_noise/pointpillar_single.yaml"
+YAML_UNC = REF + "/opencood/hypes_yaml/opv2v/lidar_only_with_noise/coalign/pointpillar_uncertainty.yaml"
 YAML_DAIR = REF + "/opencood/hypes_yaml/dairv2x/lidar_only_with_noise/coalign/pointpillar_coalign.yaml"
 MINI_RANGE = [-12.8, -6.4, -3, 12.8, 6.4, 1]
 
@@ -404,6 +405,29 @@ def main():
     cloud[200:210, 2] = -1
     save("points.npz", cloud=cloud, range_masked=pcd_utils.mask_points_by_range(cloud, [-140.8, -40, -3, 140.8, 40, 1]),
          ego_masked=pcd_utils.mask_ego_points(cloud))
+
+    # ------------------------------------------------------------------ stage-1 detector with uncertainty head + its post-process (next-3)
+    from opencood.data_utils.post_processor.uncertainty_voxel_postprocessor import UncertaintyVoxelPostprocessor as RefUncPost
+    hu = load_hypes(YAML_UNC, MINI_RANGE)
+    mu = train_utils.create_model(hu).eval()
+    fill_parameters_(mu, seed=0, cls_bias=-1.0)
+    with torch.no_grad():                      # small box deltas / moderate logits so that real detections come out
+        mu.reg_head.weight.mul_(0.01); mu.reg_head.bias.zero_(); mu.cls_head.weight.mul_(0.05)
+    fu = make_frame(hu, 3, pillars_per_agent=150, seed=21)
+    with torch.no_grad():
+        ou = mu(fu)
+    pu = RefUncPost(hu["postprocess"], train=False)
+    anchors_u = torch.from_numpy(pu.generate_anchor_box())
+    c_list, b_list, u_list = pu.post_process_stage1({k: v.clone() for k, v in ou.items()}, anchors_u)
+    sdu = mu.state_dict()
+    st1 = {"voxel_features": fu["processed_lidar"]["voxel_features"], "voxel_coords": fu["processed_lidar"]["voxel_coords"],
+           "voxel_num_points": fu["processed_lidar"]["voxel_num_points"], "cls_preds": ou["cls_preds"], "reg_preds": ou["reg_preds"],
+           "unc_preds": ou["unc_preds"], "dir_preds": ou["dir_preds"], "state_keys": np.array(list(sdu.keys())),
+           "state_numel": np.array([v.numel() for v in sdu.values()]), "n_boxes": np.array([len(c) for c in c_list])}
+    for i, (c, b, u) in enumerate(zip(c_list, b_list, u_list)):
+        st1.update({f"corners{i}": c, f"boxes{i}": b, f"unc{i}": u})
+    print("  stage1 boxes per agent:", [len(c) for c in c_list])
+    save("stage1_mini.npz", **st1)
 
     # ------------------------------------------------------------------ pose correction by box alignment (next-3)
     from opencood.models.sub_modules.box_align_v2 import box_alignment_relative_sample_np

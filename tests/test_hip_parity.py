@@ -674,3 +674,42 @@ def test_box_alignment_end_to_end_vs_reference(golden):
     n = int(g[f"{t}_len"].shape[0])
     got = np.array([pgo.get_pose(i).vector() for i in range(n)])
     np.testing.assert_allclose(got[:, :2], g[f"{t}_solution"][:n, :2], rtol=0, atol=1e-6)
+
+
+def test_stage1_model_and_post_process_vs_reference(golden):
+    """Stage 1 of box alignment on the device: PointPillarUncertainty (pillar kernel + MIOpen + merged 1x1 heads incl. unc_head)
+    and UncertaintyVoxelPostprocessor.post_process_stage1 (decode with identity transform, per-agent NMS without the sanity
+    mask, uncertainty gather) -- same kept anchors in the same order as the reference, boxes within float32 rounding."""
+    g = golden("stage1_mini.npz")
+    h = builtin_config("mini_pointpillar_uncertainty")
+    model = build_model(h)
+    fill_parameters_(model, seed=0, cls_bias=-1.0)
+    with torch.no_grad():
+        model.reg_head.weight.mul_(0.01); model.reg_head.bias.zero_(); model.cls_head.weight.mul_(0.05)
+    model = model.to(DEV).eval()
+    batch = {"processed_lidar": {"voxel_features": T(g["voxel_features"]).to(DEV), "voxel_coords": T(g["voxel_coords"]).to(DEV),
+                                 "voxel_num_points": T(g["voxel_num_points"]).to(DEV)}}
+    with torch.no_grad():
+        out = model(batch)
+    for k in ("cls_preds", "reg_preds", "unc_preds", "dir_preds"):
+        feat_close(out[k], g[k], what=k)
+    post = build_postprocessor(h["postprocess"], train=False)
+    anchors = T(post.generate_anchor_box())
+    # (a) the reference's own head outputs through the device post-process: selection is bit-exact
+    ref_out = {k: T(g[k]).to(DEV) for k in ("cls_preds", "reg_preds", "unc_preds", "dir_preds")}
+    corners, boxes, unc = post.post_process_stage1(ref_out, anchors)
+    assert [len(c) for c in corners] == list(g["n_boxes"])
+    for i in range(3):
+        assert np.array_equal(unc[i].cpu().numpy(), g[f"unc{i}"])
+        np.testing.assert_allclose(corners[i].cpu().numpy(), g[f"corners{i}"], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(boxes[i].cpu().numpy(), g[f"boxes{i}"], rtol=1e-5, atol=1e-4)
+    # (b) nothing above the threshold -> (None, None, None)
+    quiet = dict(ref_out, cls_preds=torch.full_like(ref_out["cls_preds"], -9.0))
+    assert post.post_process_stage1(quiet, anchors) == (None, None, None)
+    # (c) stage 1 -> box alignment: the device detections of the three agents drive a pose-graph solve end to end
+    from coalign_amd import box_align
+    c2, _, u2 = post.post_process_stage1(out, anchors)
+    poses = np.zeros((3, 6))
+    refined = box_align.box_alignment_relative_sample_np([c.cpu().numpy().astype(np.float64) for c in c2], poses,
+                                                         uncertainty_list=[u.cpu().numpy().astype(np.float64) for u in u2])
+    assert refined.shape == (3, 3) and np.all(np.isfinite(refined)) and np.array_equal(refined[0], [0, 0, 0])

@@ -318,3 +318,33 @@ def test_pose_graph_lm_reaches_the_least_squares_optimum(golden):
         best = g[f"{tag}_vertices"].copy(); flat = best[free].ravel(); flat[cols] = sol.x; best[free] = flat.reshape(-1, 3)
         np.testing.assert_allclose(x[:n_agents, :2], best[:n_agents, :2], rtol=0, atol=1e-6)
         assert np.abs(oracle._normalize_theta(x[:n_agents, 2] - best[:n_agents, 2])).max() < 1e-7
+
+
+def test_stage1_uncertainty_model_and_post_process_match_reference(golden):
+    """next-3 stage 1: PointPillarUncertainty forward (incl. the unc head) and post_process_stage1 (per-agent boxes in the
+    agent frame + the kept anchors' log-variances) against the reference on a 3-agent mini frame."""
+    from coalign_amd.detector import build_model
+    from coalign_amd.synthetic import fill_parameters_
+    g = golden("stage1_mini.npz")
+    h = builtin_config("mini_pointpillar_uncertainty")
+    model = build_model(h)
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["state_keys"]] and [v.numel() for v in sd.values()] == list(g["state_numel"])
+    fill_parameters_(model, seed=0, cls_bias=-1.0)
+    with torch.no_grad():
+        model.reg_head.weight.mul_(0.01); model.reg_head.bias.zero_(); model.cls_head.weight.mul_(0.05)
+    sd = model.state_dict()
+    batch = {"processed_lidar": {"voxel_features": T(g["voxel_features"]), "voxel_coords": T(g["voxel_coords"]), "voxel_num_points": T(g["voxel_num_points"])}}
+    with torch.no_grad():
+        out = oracle.pointpillar_forward(sd, h["model"]["args"], batch)
+    for k in ("cls_preds", "reg_preds", "unc_preds", "dir_preds"):
+        ref = T(g[k])
+        assert float((out[k] - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), k
+    anchors = T(oracle.generate_anchor_box(h["postprocess"]["anchor_args"], h["postprocess"]["order"]))
+    ref_out = {k: T(g[k]) for k in ("cls_preds", "reg_preds", "unc_preds", "dir_preds")}
+    corners, boxes, unc = oracle.post_process_stage1(ref_out, anchors, h["postprocess"])
+    assert [len(c) for c in corners] == list(g["n_boxes"]) and min(g["n_boxes"]) > 10
+    for i in range(3):
+        assert np.array_equal(unc[i].numpy(), g[f"unc{i}"])                      # same anchors kept, same order
+        np.testing.assert_allclose(corners[i].numpy(), g[f"corners{i}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(boxes[i].numpy(), g[f"boxes{i}"], rtol=1e-5, atol=1e-5)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Time the batched pose-graph solve (coalign_pose_graph_optimize) on G copies-with-jitter of the golden graphs, beside the
+oracle's numpy LM on the host.   python tools/bench_box_align.py [--graphs 2048]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from coalign_amd import box_align       # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--graphs", type=int, default=2048)
+ap.add_argument("--cpu-graphs", type=int, default=16)
+a = ap.parse_args()
+g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "box_align.npz"), allow_pickle=True)
+tags = ("default", "five_agents", "hard_boxes", "no_uncertainty")
+rs = np.random.RandomState(0)
+graphs = []
+for i in range(a.graphs):
+    t = tags[i % len(tags)]
+    v = g[f"{t}_vertices"].copy()
+    n = len(g[f"{t}_len"])
+    v[1:n, :2] += rs.normal(0, 0.2, (n - 1, 2)); v[1:n, 2] += rs.normal(0, 0.005, n - 1)      # a different noisy pose per frame
+    graphs.append(box_align.PoseGraph(v, g[f"{t}_kinds"], g[f"{t}_edge_agent"], g[f"{t}_edge_landmark"], g[f"{t}_edge_meas"], g[f"{t}_edge_info"], n))
+box_align.optimize_pose_graphs(graphs[:8])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+solved, stats = box_align.optimize_pose_graphs(graphs)
+torch.cuda.synchronize()
+wall = time.perf_counter() - t0
+rep = {"graphs": a.graphs, "wall_ms_incl_h2d_d2h": round(wall * 1e3, 2), "us_per_graph": round(wall * 1e6 / a.graphs, 2),
+       "mean_lm_iterations": float(stats[:, 0].mean()), "vertices": int(sum(len(x.vertices) for x in graphs)), "edges": int(sum(len(x.edge_agent) for x in graphs))}
+from oracle import coalign_oracle as oracle
+t0 = time.perf_counter()
+for x in graphs[: a.cpu_graphs]:
+    oracle.pose_graph_lm(x.vertices, x.kinds, (x.edge_agent, x.edge_landmark, x.edge_meas, x.edge_info))
+rep["cpu_oracle_ms_per_graph"] = round((time.perf_counter() - t0) * 1e3 / a.cpu_graphs, 2)
+print(json.dumps(rep))
