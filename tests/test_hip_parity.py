@@ -713,3 +713,38 @@ def test_stage1_model_and_post_process_vs_reference(golden):
     refined = box_align.box_alignment_relative_sample_np([c.cpu().numpy().astype(np.float64) for c in c2], poses,
                                                          uncertainty_list=[u.cpu().numpy().astype(np.float64) for u in u2])
     assert refined.shape == (3, 3) and np.all(np.isfinite(refined)) and np.array_equal(refined[0], [0, 0, 0])
+
+
+def test_full_frame_vs_stock_pytorch_ops_on_the_gpu():
+    """The whole path at the OPV2V size against the same path written with stock eager PyTorch ops on the GPU (nn.Linear /
+    BatchNorm, index scatter, Conv2d+BN+ReLU modules, F.affine_grid + F.grid_sample, bmm + softmax attention, tensor-op box
+    decode; tools/eager_torch_baseline.py): head outputs within 1e-4 relative, identical detections."""
+    import importlib.util
+    import os
+    from coalign_amd import backbone as bb_mod
+    from coalign_amd.detector import to_device
+    spec = importlib.util.spec_from_file_location("eager_torch_baseline", os.path.join(os.path.dirname(__file__), "..", "tools", "eager_torch_baseline.py"))
+    eb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(eb)
+    h = builtin_config("opv2v_coalign")
+    model = build_model(h)
+    fill_parameters_(model, seed=0, cls_bias=-2.0)
+    with torch.no_grad():
+        model.reg_head.weight.mul_(0.02); model.cls_head.weight.mul_(0.3)
+    model = model.to(DEV).eval()
+    post = build_postprocessor(h["postprocess"], False)
+    anchors = T(post.generate_anchor_box()).to(DEV)
+    frame = to_device(make_frame(h, 3, pillars_per_agent=6000, seed=77), DEV)
+    with torch.no_grad():
+        try:
+            bb_mod.FAST_INFERENCE = False
+            ref = eb.eager_forward(model, frame)
+            ref_boxes, ref_scores = eb.eager_post_process(ref, anchors, h["postprocess"])
+        finally:
+            bb_mod.FAST_INFERENCE = True
+        out = model(frame)
+        boxes, scores = post.post_process({"ego": {"transformation_matrix": torch.eye(4, device=DEV), "anchor_box": anchors}}, {"ego": out})
+    for k in ref:
+        assert float((out[k] - ref[k]).abs().max()) <= 1e-4 * float(ref[k].abs().max()), k
+    assert ref_boxes is not None and boxes is not None and boxes.shape == ref_boxes.shape and boxes.shape[0] > 5
+    assert float((boxes - ref_boxes).abs().max()) < 1e-3 and float((scores - ref_scores).abs().max()) < 1e-5
