@@ -303,3 +303,32 @@ def pose_graph_optimize(vertex_offsets: torch.Tensor, edge_offsets: torch.Tensor
         hip.check(L.coalign_pose_graph_optimize(G, _ptr(vo), _ptr(eo), _ptr(na), V, _ptr(out), _ptr(kd), _ptr(ea), _ptr(el), _ptr(em), _ptr(ew),
                                                 int(max_iterations), _ptr(stats), _ptr(ws), ws_bytes, _stream()), "coalign_pose_graph_optimize")
     return out, stats
+
+
+def pack_conv3x3_weight(weight: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> [Cout / 64, Cin, 9, 64] (the layout coalign_conv3x3_bias_act streams through LDS)."""
+    co, ci, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or co % 64 or ci % 8:
+        raise ValueError(f"conv3x3 kernel needs 3x3 weights with Cout % 64 == 0 and Cin % 8 == 0, got {tuple(weight.shape)}")
+    return weight.detach().float().reshape(co // 64, 64, ci, 9).permute(0, 2, 3, 1).contiguous()
+
+
+def conv3x3_bias_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None,
+                     relu: bool = True) -> torch.Tensor:
+    """y = act(conv3x3(x, w) + bias (+ residual)), stride 1, padding 1, NCHW float32, on the fp32 matrix cores."""
+    _need_gpu(x, w_packed, bias, residual)
+    L = hip.lib()
+    xc = _f32c(x)
+    N, Cin, H, W = xc.shape
+    G, Cin_w, _, _ = w_packed.shape
+    if Cin_w != Cin:
+        raise ValueError(f"input has {Cin} channels, packed weight expects {Cin_w}")
+    Cout = G * 64
+    y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=xc.device)
+    res = None if residual is None else _f32c(residual)
+    if res is not None and res.shape != y.shape:
+        raise ValueError("residual shape mismatch")
+    with _Timed("conv3x3_bias_act"):
+        hip.check(L.coalign_conv3x3_bias_act(_ptr(xc), _ptr(w_packed), _ptr(None if bias is None else _f32c(bias)), _ptr(res), _ptr(y),
+                                             N, Cin, Cout, H, W, int(relu), _stream()), "coalign_conv3x3_bias_act")
+    return y

@@ -748,3 +748,27 @@ def test_full_frame_vs_stock_pytorch_ops_on_the_gpu():
         assert float((out[k] - ref[k]).abs().max()) <= 1e-4 * float(ref[k].abs().max()), k
     assert ref_boxes is not None and boxes is not None and boxes.shape == ref_boxes.shape and boxes.shape[0] > 5
     assert float((boxes - ref_boxes).abs().max()) < 1e-3 and float((scores - ref_scores).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 100, 352), (3, 128, 128, 50, 176), (2, 256, 256, 25, 88), (1, 384, 256, 36, 96), (2, 64, 128, 37, 50), (1, 8, 64, 5, 3)])
+def test_conv3x3_bias_act_vs_torch(shape):
+    """The fp32 matrix-core 3x3 convolution (experimental entry point (9), not yet on the product path) against torch's
+    convolution: with / without residual and ReLU, map sizes that do not divide the tile, one-chunk inputs."""
+    import torch.nn.functional as F
+    N, Ci, Co, H, W = shape
+    gen = torch.Generator(device="cpu").manual_seed(sum(shape))
+    x = torch.randn(N, Ci, H, W, generator=gen).to(DEV)
+    w = (torch.randn(Co, Ci, 3, 3, generator=gen) / (Ci * 9) ** 0.5).to(DEV)
+    b = torch.randn(Co, generator=gen).to(DEV)
+    r = torch.randn(N, Co, H, W, generator=gen).to(DEV)
+    wp = ops.pack_conv3x3_weight(w)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    for res, relu in ((None, False), (r, True), (None, True)):
+        want = ref if res is None else ref + res.double()
+        want = torch.relu(want) if relu else want
+        got = ops.conv3x3_bias_act(x, wp, b, res, relu)
+        assert got.shape == want.shape
+        assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()), (shape, res is not None, relu)
+    assert torch.equal(ops.conv3x3_bias_act(x, wp, b, r, True), ops.conv3x3_bias_act(x, wp, b, r, True))     # deterministic
+    got = ops.conv3x3_bias_act(x, wp, None, None, False)
+    assert float((got.double() - (ref - b.double().view(1, -1, 1, 1))).abs().max()) <= 2e-5 * float(ref.abs().max())

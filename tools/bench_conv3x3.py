@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""coalign_conv3x3_bias_act vs MIOpen (F.conv2d) + the separate fused epilogue, at the backbone / shrink-header shapes."""
+import json, os, sys
+import torch, torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from coalign_amd import ops
+
+def timed(fn, n=20, warm=5):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+torch.manual_seed(0)
+rows = []
+for (N, Ci, Co, H, W, res) in ((5, 64, 64, 100, 352, True), (5, 128, 128, 50, 176, True), (5, 256, 256, 25, 88, True),
+                               (1, 384, 256, 100, 352, False), (1, 256, 256, 100, 352, False), (2, 64, 64, 37, 50, True)):
+    x = torch.randn(N, Ci, H, W, device="cuda"); w = torch.randn(Co, Ci, 3, 3, device="cuda") / (Ci * 9) ** 0.5
+    b = torch.randn(Co, device="cuda"); r = torch.randn(N, Co, H, W, device="cuda") if res else None
+    wp = ops.pack_conv3x3_weight(w)
+    ref = F.conv2d(x, w, b, padding=1)
+    if r is not None: ref = ref + r
+    ref = torch.relu(ref)
+    got = ops.conv3x3_bias_act(x, wp, b, r, True)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    t_new = timed(lambda: ops.conv3x3_bias_act(x, wp, b, r, True))
+    t_old = timed(lambda: ops.bias_act_(F.conv2d(x, w, None, padding=1), b, r, True))
+    gf = 2 * N * Co * H * W * Ci * 9 / 1e9
+    rows.append({"shape": [N, Ci, Co, H, W], "rel_err": err, "us_hip": round(t_new, 1), "us_miopen_plus_epilogue": round(t_old, 1),
+                 "TFLOPs_hip": round(gf / t_new * 1e3, 1), "TFLOPs_miopen": round(gf / t_old * 1e3, 1)})
+    print(json.dumps(rows[-1]), flush=True)
