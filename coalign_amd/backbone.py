@@ -45,6 +45,12 @@ def _fast_ok(module: nn.Module, x: torch.Tensor) -> bool:
     return FAST_INFERENCE and (not module.training) and x.is_cuda and x.dtype == torch.float32
 
 
+def hip_conv3x3_wins(x: torch.Tensor, cin: int, cout: int) -> bool:
+    """Shapes on which coalign_conv3x3_bias_act beats MIOpen's Winograd + separate epilogue (measured,
+    profiles/round1/conv3x3_bench.json): the wide 64-channel stage.  Everything else stays on MIOpen."""
+    return cin <= 64 and cin % 8 == 0 and cout % 64 == 0 and x.shape[3] % 32 == 0 and x.shape[2] >= 64
+
+
 def fold_bn(weight: torch.Tensor, conv_bias: Optional[torch.Tensor], bn: nn.BatchNorm2d, out_dim: int = 0):
     """conv/deconv weight + eval BatchNorm -> (scaled weight, per-channel shift).  ``out_dim`` is the weight's
     output-channel axis (0 for Conv2d, 1 for ConvTranspose2d)."""
@@ -105,17 +111,24 @@ class BasicBlock(nn.Module):
             if self.downsample is not None:
                 wd, bd = fold_bn(self.downsample[0].weight, None, self.downsample[1])
                 b2 = (b2 + bd).contiguous()          # both shifts land on the same sum
-            return w1, b1, w2, b2, wd
+            packable = lambda w: w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0
+            p1 = ops.pack_conv3x3_weight(w1) if self.stride == 1 and packable(w1) else None
+            p2 = ops.pack_conv3x3_weight(w2) if packable(w2) else None
+            return w1, b1, w2, b2, wd, p1, p2
         return _cache_of(self).get(self, build)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if _fast_ok(self, x):
-            w1, b1, w2, b2, wd = self._folded()
+            w1, b1, w2, b2, wd, p1, p2 = self._folded()
             x = x.contiguous()
-            y = ops.bias_act_(F.conv2d(x, w1, None, self.stride, 1), b1, None, True)
-            z = F.conv2d(y, w2, None, 1, 1)
+            if p1 is not None and hip_conv3x3_wins(x, w1.shape[1], w1.shape[0]):
+                y = ops.conv3x3_bias_act(x, p1, b1, None, True)
+            else:
+                y = ops.bias_act_(F.conv2d(x, w1, None, self.stride, 1), b1, None, True)
             skip = x if wd is None else F.conv2d(x, wd, None, self.stride)
-            return ops.bias_act_(z, b2, skip, True)
+            if p2 is not None and hip_conv3x3_wins(y, w2.shape[1], w2.shape[0]):
+                return ops.conv3x3_bias_act(y, p2, b2, skip, True)
+            return ops.bias_act_(F.conv2d(y, w2, None, 1, 1), b2, skip, True)
         skip = x if self.downsample is None else self.downsample(x)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))

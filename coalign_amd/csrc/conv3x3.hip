@@ -8,19 +8,22 @@
 // v_mfma_f32_32x32x2_f32 -- exact fp32 products and accumulation, the same rounding model as an fmaf chain -- with the epilogue
 // in registers.
 //
-// STATUS (round 1): bit-for-bit deterministic and correct to 4e-6 of torch's conv on every tested shape, but NOT yet faster than
-// MIOpen (73-97 TFLOP/s real against MIOpen's 79-113 effective, profiles/round1/conv3x3_bench.json), so the detector still calls
-// MIOpen; the entry point is exported and tested as the starting point of the round-2 work.
+// STATUS (round 1): deterministic and correct to 4e-6 of torch's conv on every tested shape; 72-100 TFLOP/s of real work against
+// MIOpen's 78-108 effective (profiles/round1/conv3x3_bench.json).  It wins where the input-channel count is small (the 64-channel
+// stage: 141 vs 166 us) and the detector uses it there; the other stages stay on MIOpen.
 //
 // GEMM view per image:  D[cout, pixel] = sum_{cin, tap} W[cout, cin, tap] * X[cin, pixel + tap].
 //   A operand (32 x 2)  weights: 32 output channels x 2 input channels of one tap      (from LDS, [cin][tap][cout])
 //   B operand (2 x 32)  input:   2 input channels x 32 pixels shifted by the tap        (from LDS, halo patch [cin][y][x])
 //   D (32 x 32)         16 accumulators per lane: lane % 32 = pixel (coalesced NCHW stores), 16 output channels.
-// A workgroup owns WAVES vertically stacked pixel blocks (BH x BW = 32 pixels each) and 64 output channels; every wavefront
-// keeps two 32 x 32 accumulator tiles (its pixel block x the two channel halves).  The input channels stream through LDS in
-// chunks of 8: the next chunk's halo patch and weights are fetched into registers while the matrix cores work on the
-// current one.  f32 MFMA issues one instruction per 64 cycles per SIMD, so three LDS reads per two MFMAs is far from the LDS
-// limit: the kernel is bound by the matrix pipe as long as two or more wavefronts share each SIMD.
+// A workgroup (4 wavefronts) owns NPB vertically stacked pixel blocks (BH x BW = 32 pixels each) and 64 output channels.  The
+// input channels stream through a double-buffered LDS image in chunks of 8 with the gfx950 LDS-DMA (global_load_lds): while the
+// matrix cores work on chunk c out of one buffer, chunk c + 1 lands in the other -- no staging registers, no ds_write pass, one
+// barrier per chunk.  LDS-DMA writes lane-linearly (wave-uniform base + lane x size), so the LDS image IS the layout: the packed
+// weights carry their bank padding in global memory, and every float of the halo patch (padding slots and out-of-image taps
+// included) is fetched by the lane that owns its LDS slot, pointed at a zero word when there is nothing to fetch.
+// f32 MFMA issues one instruction per 64 cycles per SIMD, so two LDS reads per MFMA is far from the LDS limit: the kernel is
+// bound by the matrix pipe as long as the staging stays out of the wavefronts' way.
 #include "common.h"
 
 namespace {
@@ -31,52 +34,57 @@ constexpr int kKC = 8;               // input channels per LDS chunk
 constexpr int kCoutTile = 64;        // output channels per workgroup
 constexpr int kWStride = 9 * kCoutTile + 32;   // floats between input channels of the weight chunk (+32: the two k-halves of a wave hit different banks)
 
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
 struct ConvArgs {
     const float *__restrict__ x, *__restrict__ wt, *__restrict__ bias, *__restrict__ residual;
     float *__restrict__ y;
     int N, Cin, Cout, H, W, relu, tiles_x, tiles_per_img, total_tiles;
 };
 
-constexpr int pick_stride(int pw, int bh, int bw) {      // smallest row stride >= pw whose BH row segments tile the 32 banks
-    if (bh == 1) return pw;
-    int s = pw;
-    while (s % 32 != bw % 32) ++s;
+constexpr int pick_stride(int pw, int bh, int bw) {      // smallest row stride >= pw (multiple of 4) whose BH row segments tile the 32 banks
+    int s = (pw + 3) / 4 * 4;
+    if (bh == 1) return s;
+    while (s % 32 != bw % 32) s += 4;
     return s;
 }
 
-// BH x BW = 32 pixels per block; a workgroup (4 wavefronts, 64 output channels) stacks NPB blocks vertically:
+constexpr int kWChunk = kKC * kWStride;                   // floats of one packed weight chunk (4864 = 19 x 256)
+constexpr int kWInstr = kWChunk * 4 / 1024;               // dwordx4 LDS-DMA instructions per chunk (64 lanes x 16 B each)
+static_assert(kWChunk * 4 % 1024 == 0, "weight chunk must be a whole number of dwordx4 wave transfers");
+
+// BH x BW = 32 pixels per block; the workgroup stacks NPB blocks vertically:
 //   NPB = 4: wave w owns pixel block w and both 32-channel halves (two accumulator tiles),
 //   NPB = 2: wave w owns pixel block w % 2 and the 32-channel half w / 2 (one tile) -- smaller work units for small maps.
 template <int BH, int BW, int NPB>
 struct Geo {
-    static constexpr int NCO = NPB / 2;                                       // accumulator tiles per wave
-    static constexpr int TH = BH * NPB, TW = BW, PH = TH + 2, PW = TW + 2;
+    static constexpr int NCO = NPB >= 4 ? 2 : 1;                              // accumulator tiles per wave
+    static constexpr int WAVES = NPB >= 4 ? NPB : 2 * NPB;                    // wavefronts per workgroup
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int TH = BH * NPB, TW = BW, PH = TH + 2, PW = TW + 8;  // rows cover x0 - 4 .. x0 + TW + 3: whole 16-byte groups
     static constexpr int STR = pick_stride(PW, BH, BW);
+    static_assert(STR % 4 == 0, "row stride must keep the 16-byte groups row-aligned");
     static constexpr int CS_RAW = PH * STR;
-    static constexpr int CS = CS_RAW + ((32 - CS_RAW % 64) + 64) % 64;       // channel stride == 32 (mod 64)
-    static constexpr int THREADS = 256;
-    static constexpr int PATCH = kKC * PH * PW;                               // floats fetched per chunk
-    static constexpr int PER_THREAD = (PATCH + THREADS - 1) / THREADS;
-    static constexpr int WCHUNK4 = kKC * 9 * kCoutTile / 4;                   // float4s of weights per chunk
-    static constexpr int WPER_THREAD = (WCHUNK4 + THREADS - 1) / THREADS;
+    static constexpr int CS = CS_RAW;                                         // channel stride (multiple of 4)
+    static constexpr int PGROUPS = kKC * CS / 4;                              // 16-byte groups of the patch image
+    static constexpr int PINSTR = (PGROUPS + 63) / 64;                        // dwordx4 LDS-DMA instructions (the last may be partial)
+    static constexpr int PLDS = PGROUPS * 4;                                  // floats of the patch image
+    static constexpr int BUF = PLDS + kWChunk;                                // floats of one LDS buffer (patch | weights)
 };
 
 struct Tile {
     int n, cg, y0, x0;
 };
 
-// Persistent workgroups: each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The (tile, chunk) steps form one software
-// pipeline -- while the matrix cores work on a chunk, the next chunk (of this tile or the first of the next tile) is on its way
-// from L2 into registers, and a tile's bias / residual values arrive during its last chunk -- so neither the prologue nor the
-// epilogue of a tile leaves the MFMA pipe idle (measured before: 30-40 % of a workgroup's life went into them).
 template <int BH, int BW, int NPB>
-__global__ __launch_bounds__(256, 3) void conv3x3_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_kernel(const ConvArgs a) {
     using G = Geo<BH, BW, NPB>;
-    __shared__ float patch[kKC * G::CS];
-    __shared__ float wlds[kKC * kWStride];
+    __shared__ __attribute__((aligned(1024))) float lds[2 * G::BUF];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, p = lane & 31;
     const size_t plane = (size_t)a.H * a.W;
     const int groups = a.Cout / kCoutTile, chunks = a.Cin / kKC;
+    const float *zero = a.wt + 9 * kCoutTile;            // first padding word of the packed weights: always 0
     auto decode = [&](int t) {
         Tile c;
         c.cg = t % groups;
@@ -89,45 +97,33 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(const ConvArgs a) {
     };
 
     // this lane's pixel inside the tile, channel half, LDS read bases
-    const int pb = wave % NPB, cb = (NPB == 4 ? 0 : wave / NPB) * 32;
+    const int pb = wave % NPB, cb = (G::NCO == 2 ? 0 : wave / NPB) * 32;
     const int py = pb * BH + p / BW, px = p % BW;
-    const int pbase = half * G::CS + py * G::STR + px;
-    const int wbase = half * kWStride + cb + p;
+    const int pbase = half * G::CS + py * G::STR + px + 3;      // tap (dy, dx) of pixel (py, px) sits at row py + dy, column px + 3 + dx
+    const int wbase = G::PLDS + half * kWStride + cb + p;
 
-    float pre[G::PER_THREAD];
-    float4 wpre[G::WPER_THREAD];
-    auto fetch = [&](const Tile &t, int cin0) {
-        const float *xin = a.x + (size_t)t.n * a.Cin * plane;
+    // LDS-DMA of one chunk into buffer `buf`: wave w issues transfers w, w + 4, ...
+    auto issue = [&](const Tile &t, int chunk, int buf) {
+        float *dst = lds + buf * G::BUF;
+        const float *xin = a.x + ((size_t)t.n * a.Cin + (size_t)chunk * kKC) * plane;
 #pragma unroll
-        for (int i = 0; i < G::PER_THREAD; ++i) {
-            const int e = tid + i * G::THREADS;
-            const int c = e / (G::PH * G::PW), rem = e - c * (G::PH * G::PW), r = rem / G::PW, xx = rem - r * G::PW;
-            const int gy = t.y0 - 1 + r, gx = t.x0 - 1 + xx;
-            float v = 0.f;
-            if (e < G::PATCH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = xin[(size_t)(cin0 + c) * plane + (size_t)gy * a.W + gx];
-            pre[i] = v;
-        }
-        const float4 *w4 = reinterpret_cast<const float4 *>(a.wt + ((size_t)t.cg * a.Cin + cin0) * 9 * kCoutTile);
-#pragma unroll
-        for (int i = 0; i < G::WPER_THREAD; ++i) {
-            const int e = tid + i * G::THREADS;
-            wpre[i] = e < G::WCHUNK4 ? w4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto stage = [&]() {
-#pragma unroll
-        for (int i = 0; i < G::PER_THREAD; ++i) {
-            const int e = tid + i * G::THREADS;
-            const int c = e / (G::PH * G::PW), rem = e - c * (G::PH * G::PW), r = rem / G::PW, xx = rem - r * G::PW;
-            if (e < G::PATCH) patch[c * G::CS + r * G::STR + xx] = pre[i];
-        }
-#pragma unroll
-        for (int i = 0; i < G::WPER_THREAD; ++i) {
-            const int e = tid + i * G::THREADS;
-            if (e < G::WCHUNK4) {
-                const int f = e * 4, c = f / (9 * kCoutTile), rem = f - c * (9 * kCoutTile);
-                *reinterpret_cast<float4 *>(&wlds[c * kWStride + rem]) = wpre[i];
+        for (int j = 0; j < (G::PINSTR + G::WAVES - 1) / G::WAVES; ++j) {
+            const int ins = wave + G::WAVES * j;
+            if (ins < G::PINSTR) {
+                if (ins * 64 + lane >= G::PGROUPS) continue;               // partial last transfer: masked lanes write nothing
+                const int e = (ins * 64 + lane) * 4;                       // first float of this lane's 16-byte group
+                const int c = e / G::CS, rem = e - c * G::CS, r = rem / G::STR, xx = rem - r * G::STR;
+                const int gy = t.y0 - 1 + r, gx = t.x0 - 4 + xx;           // gx % 4 == 0: the group is inside the row or outside
+                const bool ok = c < kKC && r < G::PH && xx < G::PW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const float *src = ok ? xin + (size_t)c * plane + (size_t)gy * a.W + gx : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + ins * 256), 16, 0, 0);
             }
+        }
+        const float *wsrc = a.wt + ((size_t)t.cg * chunks + chunk) * kWChunk;
+#pragma unroll
+        for (int j = 0; j < (kWInstr + G::WAVES - 1) / G::WAVES; ++j) {
+            const int ins = wave + G::WAVES * j;
+            if (ins < kWInstr) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ins * 256 + lane * 4), (lptr_t)(dst + G::PLDS + ins * 256), 16, 0, 0);
         }
     };
 
@@ -135,45 +131,49 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(const ConvArgs a) {
     if (tile >= a.total_tiles) return;
     Tile cur = decode(tile), nxt = cur;
     floatx16 acc[G::NCO];
-    fetch(cur, 0);
+    int buf = 0;
+    issue(cur, 0, 0);
     while (true) {
         const bool more = tile + (int)gridDim.x < a.total_tiles;
+        if (more) nxt = decode(tile + gridDim.x);
         const int gy = cur.y0 + py, gx = cur.x0 + px;
         const bool live = gy < a.H && gx < a.W;
-        // accumulator r of lane l is output channel 8 * (r / 4) + 4 * (l / 32) + r % 4 of its 32-block, pixel l % 32.
-        // The accumulators start from bias (+ residual): those loads are issued here, behind the previous tile's stores, and
-        // are only waited for by the first MFMA -- after the barrier / LDS staging below.
-        const size_t obase = ((size_t)cur.n * a.Cout + cur.cg * kCoutTile + cb + 4 * half) * plane + (size_t)gy * a.W + gx;
+        // accumulator r of lane l is output channel 8 * (r / 4) + 4 * (l / 32) + r % 4 of its 32-block, pixel l % 32; the
+        // accumulators start from bias (+ residual); dead lanes read (and never write) pixel 0 of their plane
+        const size_t obase = ((size_t)cur.n * a.Cout + cur.cg * kCoutTile + cb + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
+        const float *bias = a.bias + cur.cg * kCoutTile + cb + 4 * half;
+        if (a.residual) {
 #pragma unroll
-        for (int q = 0; q < 16 * G::NCO; ++q) {
-            const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
-            float v = a.bias ? a.bias[cur.cg * kCoutTile + cb + 4 * half + c] : 0.f;
-            if (a.residual && live) v += a.residual[obase + (size_t)c * plane];
-            acc[q / 16][q % 16] = v;
+            for (int q = 0; q < 16 * G::NCO; ++q) {
+                const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
+                acc[q / 16][q % 16] = a.residual[obase + (size_t)c * plane] + bias[c];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16 * G::NCO; ++q) acc[q / 16][q % 16] = bias[(q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4)];
         }
         for (int chunk = 0; chunk < chunks; ++chunk) {
-            __syncthreads();                      // everyone is done reading the previous chunk
-            stage();
+            // chunk `chunk` was issued into `buf` one step ago: wait for my transfers, then for everyone's (which also means
+            // everyone has finished reading the other buffer), then start the next transfer into that other buffer
+            __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
-            if (chunk + 1 < chunks) {
-                fetch(cur, (chunk + 1) * kKC);
-            } else if (more) {
-                nxt = decode(tile + gridDim.x);
-                fetch(nxt, 0);
-            }
+            if (chunk + 1 < chunks) issue(cur, chunk + 1, buf ^ 1);
+            else if (more) issue(nxt, 0, buf ^ 1);
+            const float *pl = lds + buf * G::BUF;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
                 for (int kp = 0; kp < kKC / 2; ++kp) {
-                    const float b = patch[pbase + 2 * kp * G::CS + dy * G::STR + dx];
+                    const float b = pl[pbase + 2 * kp * G::CS + dy * G::STR + dx];
 #pragma unroll
                     for (int q = 0; q < G::NCO; ++q) {
-                        const float w = wlds[wbase + 2 * kp * kWStride + tap * kCoutTile + q * 32];
+                        const float w = pl[wbase + 2 * kp * kWStride + tap * kCoutTile + q * 32];
                         acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b, acc[q], 0, 0, 0);
                     }
                 }
             }
+            buf ^= 1;
         }
         if (live) {
 #pragma unroll
@@ -216,15 +216,16 @@ void launch(const ConvArgs &a0, hipStream_t s) {
 extern "C" int coalign_conv3x3_bias_act(const float *x, const float *w_packed, const float *bias, const float *residual, float *y,
                                         int N, int Cin, int Cout, int H, int W, int relu, void *stream) {
     using namespace coalign;
-    if (!x || !w_packed || !y) return COALIGN_ERR_NULL_POINTER;
+    if (!x || !w_packed || !y || !bias) return COALIGN_ERR_NULL_POINTER;
     if (N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return COALIGN_ERR_BAD_SHAPE;
-    if (Cin % kKC || Cout % kCoutTile || (reinterpret_cast<uintptr_t>(w_packed) & 15)) return COALIGN_ERR_UNSUPPORTED;
+    if (Cin % kKC || Cout % kCoutTile || W % 4 || ((reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(x)) & 15)) return COALIGN_ERR_UNSUPPORTED;
     if ((int64_t)N * Cout * H * W > (int64_t)1 << 40) return COALIGN_ERR_UNSUPPORTED;
     if (N == 0) return COALIGN_OK;
     const ConvArgs a{x, w_packed, bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // pixel-block shape by map size: 32-pixel row segments on wide maps, 2 x 16 blocks in pairs on the middle ones
-    if (W % 32 == 0 || W >= 256) launch<1, 32, 2>(a, s);
+    // pixel-block shape by map size: 32-pixel row segments on wide maps, 2 x 16 blocks on the middle ones
+    if ((W % 32 == 0 || W >= 256) && H >= 64) launch<1, 32, 8>(a, s);       // 8 wavefronts share one weight image
+    else if (W % 32 == 0 || W >= 256) launch<1, 32, 4>(a, s);
     else if (W % 16 == 0) launch<2, 16, 2>(a, s);
     else launch<1, 32, 2>(a, s);
     return check_launch();

@@ -305,12 +305,19 @@ def pose_graph_optimize(vertex_offsets: torch.Tensor, edge_offsets: torch.Tensor
     return out, stats
 
 
+CONV_KC, CONV_WSTRIDE = 8, 9 * 64 + 32      # kKC / kWStride of csrc/conv3x3.hip
+
+
 def pack_conv3x3_weight(weight: torch.Tensor) -> torch.Tensor:
-    """[Cout, Cin, 3, 3] -> [Cout / 64, Cin, 9, 64] (the layout coalign_conv3x3_bias_act streams through LDS)."""
+    """[Cout, Cin, 3, 3] -> [Cout / 64, Cin / 8, 8, 608]: per 64-channel group and 8-input-channel chunk the exact LDS image
+    coalign_conv3x3_bias_act streams in ([ci][tap][64 couts] + 32 zero floats of bank padding per input channel)."""
     co, ci, kh, kw = weight.shape
-    if (kh, kw) != (3, 3) or co % 64 or ci % 8:
+    if (kh, kw) != (3, 3) or co % 64 or ci % CONV_KC:
         raise ValueError(f"conv3x3 kernel needs 3x3 weights with Cout % 64 == 0 and Cin % 8 == 0, got {tuple(weight.shape)}")
-    return weight.detach().float().reshape(co // 64, 64, ci, 9).permute(0, 2, 3, 1).contiguous()
+    w = weight.detach().float().reshape(co // 64, 64, ci // CONV_KC, CONV_KC, 9).permute(0, 2, 3, 4, 1)   # [g, chunk, k, tap, 64]
+    out = torch.zeros((co // 64, ci // CONV_KC, CONV_KC, CONV_WSTRIDE), dtype=torch.float32, device=weight.device)
+    out[..., : 9 * 64] = w.reshape(co // 64, ci // CONV_KC, CONV_KC, 9 * 64)
+    return out.contiguous()
 
 
 def conv3x3_bias_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None,
@@ -320,7 +327,8 @@ def conv3x3_bias_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[tor
     L = hip.lib()
     xc = _f32c(x)
     N, Cin, H, W = xc.shape
-    G, Cin_w, _, _ = w_packed.shape
+    G, n_chunks, _, _ = w_packed.shape
+    Cin_w = n_chunks * CONV_KC
     if Cin_w != Cin:
         raise ValueError(f"input has {Cin} channels, packed weight expects {Cin_w}")
     Cout = G * 64
@@ -329,6 +337,7 @@ def conv3x3_bias_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[tor
     if res is not None and res.shape != y.shape:
         raise ValueError("residual shape mismatch")
     with _Timed("conv3x3_bias_act"):
-        hip.check(L.coalign_conv3x3_bias_act(_ptr(xc), _ptr(w_packed), _ptr(None if bias is None else _f32c(bias)), _ptr(res), _ptr(y),
+        b = torch.zeros(Cout, dtype=torch.float32, device=xc.device) if bias is None else _f32c(bias)
+        hip.check(L.coalign_conv3x3_bias_act(_ptr(xc), _ptr(w_packed), _ptr(b), _ptr(res), _ptr(y),
                                              N, Cin, Cout, H, W, int(relu), _stream()), "coalign_conv3x3_bias_act")
     return y

@@ -236,8 +236,10 @@ int coalign_pose_graph_optimize(int n_graphs, const int32_t *vertex_offsets, con
  *     y = act(conv3x3(x, w) + bias[c] (+ residual)): Conv2d + eval BatchNorm2d (folded into w, bias on the host) + ReLU of
  *     BasicBlock.forward (opencood/models/sub_modules/resblock.py:53-69), the ResNet stages
  *     (base_bev_backbone_resnet.py:59-119) and DoubleConv of the shrink header (downsample_conv.py:7-50).
- * x [N, Cin, H, W], y / residual [N, Cout, H, W] float32 NCHW, Cin % 8 == 0, Cout % 64 == 0, x and y distinct buffers.
- * w_packed [Cout / 64][Cin][9][64] float32, 16-byte aligned: w_packed[g][ci][ky * 3 + kx][j] = w[g * 64 + j][ci][ky][kx].
+ * x [N, Cin, H, W], y / residual [N, Cout, H, W] float32 NCHW, Cin % 8 == 0, Cout % 64 == 0, x and y distinct buffers;
+ * bias [Cout] required (zeros for none), residual may be NULL.
+ * w_packed [Cout / 64][Cin / 8][8][608] float32, 16-byte aligned: the LDS image of one 8-input-channel chunk,
+ *   w_packed[g][ci / 8][ci % 8][(ky * 3 + kx) * 64 + j] = w[g * 64 + j][ci][ky][kx],  entries [..][576..607] = 0.
  * Products and sums are exact float32 (v_mfma_f32_32x32x2_f32); the summation order differs from a sequential loop.
  */
 int coalign_conv3x3_bias_act(const float *x, const float *w_packed, const float *bias, const float *residual, float *y,

@@ -747,7 +747,7 @@ def test_full_frame_vs_stock_pytorch_ops_on_the_gpu():
     for k in ref:
         assert float((out[k] - ref[k]).abs().max()) <= 1e-4 * float(ref[k].abs().max()), k
     assert ref_boxes is not None and boxes is not None and boxes.shape == ref_boxes.shape and boxes.shape[0] > 5
-    assert float((boxes - ref_boxes).abs().max()) < 1e-3 and float((scores - ref_scores).abs().max()) < 1e-5
+    assert float((boxes - ref_boxes).abs().max()) < 1e-3 and float((scores - ref_scores).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 64, 100, 352), (3, 128, 128, 50, 176), (2, 256, 256, 25, 88), (1, 384, 256, 36, 96), (2, 64, 128, 37, 50), (1, 8, 64, 5, 3)])

@@ -17,7 +17,7 @@ def timed(fn, n=20, warm=5):
 torch.manual_seed(0)
 rows = []
 for (N, Ci, Co, H, W, res) in ((5, 64, 64, 100, 352, True), (5, 128, 128, 50, 176, True), (5, 256, 256, 25, 88, True),
-                               (1, 384, 256, 100, 352, False), (1, 256, 256, 100, 352, False), (2, 64, 64, 37, 50, True)):
+                               (1, 384, 256, 100, 352, False), (1, 256, 256, 100, 352, False), (2, 64, 64, 37, 52, True)):
     x = torch.randn(N, Ci, H, W, device="cuda"); w = torch.randn(Co, Ci, 3, 3, device="cuda") / (Ci * 9) ** 0.5
     b = torch.randn(Co, device="cuda"); r = torch.randn(N, Co, H, W, device="cuda") if res else None
     wp = ops.pack_conv3x3_weight(w)
