@@ -36,4 +36,8 @@ res = {}
 res["pillar_vfe_scatter_us"] = timed(lambda: ops.pillar_vfe_scatter(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], pfn.linear.weight, None, bn, 1e-3, True, False, h["model"]["args"]["voxel_size"], h["model"]["args"]["lidar_range"][:3], N, 200, 704), iters)
 for x in xs:
     res[f"warp_fuse_att_C{x.shape[1]}_us"] = timed(lambda: ops.warp_fuse(x, theta, [N], ops.FUSE_ATT), iters)
+# the matrix-core convolution at the stage-1 shape (64 -> 64 channels, 100 x 352, N agents), with residual + ReLU
+wconv = torch.randn(64, 64, 3, 3, generator=g).to(dev) / 24.0
+wp, bconv, rconv = ops.pack_conv3x3_weight(wconv), torch.randn(64, generator=g).to(dev), torch.randn(N, 64, 100, 352, generator=g).to(dev)
+res["conv3x3_bias_act_64ch_us"] = timed(lambda: ops.conv3x3_bias_act(xs[0], wp, bconv, rconv, True), iters)
 print(json.dumps(res))
