@@ -23,6 +23,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -45,10 +47,21 @@ def _fast_ok(module: nn.Module, x: torch.Tensor) -> bool:
     return FAST_INFERENCE and (not module.training) and x.is_cuda and x.dtype == torch.float32
 
 
+HIP_CONV_POLICY = os.environ.get("COALIGN_HIP_CONV", "stage1")      # measurement switch: none | stage1 | stage12 | stage1tail | all
+
+
 def hip_conv3x3_wins(x: torch.Tensor, cin: int, cout: int) -> bool:
-    """Shapes on which coalign_conv3x3_bias_act beats MIOpen's Winograd + separate epilogue (measured,
-    profiles/round1/conv3x3_bench.json): the wide 64-channel stage.  Everything else stays on MIOpen."""
-    return cin <= 64 and cin % 8 == 0 and cout % 64 == 0 and x.shape[3] % 32 == 0 and x.shape[2] >= 64
+    """Shapes routed to coalign_conv3x3_bias_act instead of MIOpen's Winograd + separate epilogue."""
+    if cin % 8 or cout % 64 or x.shape[3] % 4 or HIP_CONV_POLICY == "none":
+        return False
+    wide = x.shape[3] % 32 == 0 and x.shape[2] >= 64
+    if HIP_CONV_POLICY == "stage1":
+        return wide and cin <= 64
+    if HIP_CONV_POLICY == "stage12":
+        return (wide and cin <= 64) or (cin == 128 and x.shape[3] % 16 == 0)
+    if HIP_CONV_POLICY == "stage1tail":
+        return wide
+    return True
 
 
 def fold_bn(weight: torch.Tensor, conv_bias: Optional[torch.Tensor], bn: nn.BatchNorm2d, out_dim: int = 0):
@@ -307,7 +320,18 @@ class DoubleConv(nn.Module):
     def forward(self, x):
         if _fast_ok(self, x):
             c1, c2 = self.double_conv[0], self.double_conv[2]
-            y = ops.bias_act_(F.conv2d(x, c1.weight, None, c1.stride, c1.padding), c1.bias, None, True)
+
+            def build():
+                ok = lambda c: c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.out_channels % 64 == 0 and c.in_channels % 8 == 0
+                return (ops.pack_conv3x3_weight(c1.weight) if ok(c1) else None, ops.pack_conv3x3_weight(c2.weight) if ok(c2) else None)
+            p1, p2 = _cache_of(self).get([c1.weight, c2.weight], build)
+            x = x.contiguous()
+            if p1 is not None and hip_conv3x3_wins(x, c1.in_channels, c1.out_channels):
+                y = ops.conv3x3_bias_act(x, p1, c1.bias, None, True)
+            else:
+                y = ops.bias_act_(F.conv2d(x, c1.weight, None, c1.stride, c1.padding), c1.bias, None, True)
+            if p2 is not None and hip_conv3x3_wins(y, c2.in_channels, c2.out_channels):
+                return ops.conv3x3_bias_act(y, p2, c2.bias, None, True)
             return ops.bias_act_(F.conv2d(y, c2.weight, None, 1, 1), c2.bias, None, True)
         return self.double_conv(x)
 

@@ -41,6 +41,8 @@ struct ConvArgs {
     const float *__restrict__ x, *__restrict__ wt, *__restrict__ bias, *__restrict__ residual;
     float *__restrict__ y;
     int N, Cin, Cout, H, W, relu, tiles_x, tiles_per_img, total_tiles;
+    float *__restrict__ partial;      // [grid][16 * NCO][threads]: accumulators of a tile whose chunks are split over two workgroups
+    int *flags;                       // [grid], zeroed per launch: flags[g] = 1 once workgroup g has published its partial tile
 };
 
 constexpr int pick_stride(int pw, int bh, int bw) {      // smallest row stride >= pw (multiple of 4) whose BH row segments tile the 32 banks
@@ -50,6 +52,7 @@ constexpr int pick_stride(int pw, int bh, int bw) {      // smallest row stride 
     return s;
 }
 
+constexpr int kSplitChunks = 32;                          // tiles with at least this many chunks are load-balanced by splitting
 constexpr int kWChunk = kKC * kWStride;                   // floats of one packed weight chunk (4864 = 19 x 256)
 constexpr int kWInstr = kWChunk * 4 / 1024;               // dwordx4 LDS-DMA instructions per chunk (64 lanes x 16 B each)
 static_assert(kWChunk * 4 % 1024 == 0, "weight chunk must be a whole number of dwordx4 wave transfers");
@@ -77,8 +80,9 @@ struct Tile {
     int n, cg, y0, x0;
 };
 
-template <int BH, int BW, int NPB>
-__global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_kernel(const ConvArgs a) {
+template <int BH, int BW, int NPB, bool SPLIT>
+__global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) __attribute__((amdgpu_waves_per_eu(NPB == 8 ? 4 : 3, NPB == 8 ? 4 : 3)))
+void conv3x3_kernel(const ConvArgs a) {
     using G = Geo<BH, BW, NPB>;
     __shared__ __attribute__((aligned(1024))) float lds[2 * G::BUF];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, p = lane & 31;
@@ -127,22 +131,47 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_kerne
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile >= a.total_tiles) return;
-    Tile cur = decode(tile), nxt = cur;
+    // Work = total_tiles x chunks (tile, chunk) steps, cut into gridDim.x equal contiguous ranges (stream-K): every persistent
+    // workgroup runs the same number of MFMAs (+-1 chunk) whatever the tile count -- with whole tiles per workgroup, 715 tiles
+    // on 512 resident workgroups meant two rounds at 70 % fill.  A range may start in the middle of a tile (then this
+    // workgroup computes the tile's last chunks from zero accumulators and publishes them) and may end in the middle of a tile
+    // (then it owns that tile: bias / residual start, its own first chunks, plus the partial the next workgroup published at the
+    // very beginning of its range, long before it is needed here).  Ranges are at least one tile long, so a tile has at most two
+    // contributors and the split -- hence the summation order -- is a pure function of the shape: results stay deterministic.
+    // Splitting pays when a tile is long (>= 32 chunks: the 256-channel layers and the shrink header, 13-27 % faster); short tiles
+    // (64 / 128 input channels) would be split almost every time and the hand-over costs more than the imbalance.
+    const long long S = (long long)a.total_tiles * chunks;
+    const int g = blockIdx.x, n_wg = gridDim.x;
+    constexpr bool split = SPLIT;            // decided on the host from the chunk count (kSplitChunks)
+    // local step L of this workgroup -> global step: a contiguous range when splitting; whole tiles g, g + n_wg, ... otherwise
+    // (strided: the workgroups resident at the same time then work on neighbouring tiles and share halos / weights in L2)
+    const int s0 = split ? (int)(S * g / n_wg) : 0;
+    const int n_local = split ? (int)(S * (g + 1) / n_wg) - s0 : ((a.total_tiles - g + n_wg - 1) / n_wg) * chunks;
+    auto global_step = [&](int L) { return split ? s0 + L : (g + (L / chunks) * n_wg) * chunks + L % chunks; };
+    if (n_local <= 0) return;
+    int L = 0;
     floatx16 acc[G::NCO];
     int buf = 0;
-    issue(cur, 0, 0);
-    while (true) {
-        const bool more = tile + (int)gridDim.x < a.total_tiles;
-        if (more) nxt = decode(tile + gridDim.x);
+    {
+        const int gs = global_step(0);
+        issue(decode(gs / chunks), gs % chunks, 0);
+    }
+    while (L < n_local) {
+        const int gs0 = global_step(L);
+        const int tile = gs0 / chunks, c_begin = gs0 - tile * chunks;
+        const int c_end = (n_local - L) < (chunks - c_begin) ? c_begin + (n_local - L) : chunks;
+        const bool head = c_begin == 0, complete = c_end == chunks;
+        const Tile cur = decode(tile);
         const int gy = cur.y0 + py, gx = cur.x0 + px;
         const bool live = gy < a.H && gx < a.W;
-        // accumulator r of lane l is output channel 8 * (r / 4) + 4 * (l / 32) + r % 4 of its 32-block, pixel l % 32; the
-        // accumulators start from bias (+ residual); dead lanes read (and never write) pixel 0 of their plane
+        // accumulator r of lane l is output channel 8 * (r / 4) + 4 * (l / 32) + r % 4 of its 32-block, pixel l % 32; dead lanes
+        // read (and never write) pixel 0 of their plane
         const size_t obase = ((size_t)cur.n * a.Cout + cur.cg * kCoutTile + cb + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
         const float *bias = a.bias + cur.cg * kCoutTile + cb + 4 * half;
-        if (a.residual) {
+        if (SPLIT && !head) {
+#pragma unroll
+            for (int q = 0; q < G::NCO; ++q) acc[q] = floatx16{0};
+        } else if (a.residual) {
 #pragma unroll
             for (int q = 0; q < 16 * G::NCO; ++q) {
                 const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
@@ -152,13 +181,15 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_kerne
 #pragma unroll
             for (int q = 0; q < 16 * G::NCO; ++q) acc[q / 16][q % 16] = bias[(q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4)];
         }
-        for (int chunk = 0; chunk < chunks; ++chunk) {
-            // chunk `chunk` was issued into `buf` one step ago: wait for my transfers, then for everyone's (which also means
-            // everyone has finished reading the other buffer), then start the next transfer into that other buffer
+        for (int chunk = c_begin; chunk < c_end; ++chunk, ++L) {
+            // this step's image was issued into `buf` one step ago: wait for my transfers, then for everyone's (which also means
+            // everyone has finished reading the other buffer), then start the next step's transfer into that other buffer
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
-            if (chunk + 1 < chunks) issue(cur, chunk + 1, buf ^ 1);
-            else if (more) issue(nxt, 0, buf ^ 1);
+            if (L + 1 < n_local) {
+                const int ns = global_step(L + 1), nt = ns / chunks;
+                issue(decode(nt), ns - nt * chunks, buf ^ 1);
+            }
             const float *pl = lds + buf * G::BUF;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -175,6 +206,28 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_kerne
             }
             buf ^= 1;
         }
+        // The hand-over of a split tile uses agent-scope *write-through* stores / L2-bypassing loads (relaxed atomics) and no
+        // fences: an agent-scope release / acquire fence writes back and invalidates the whole L2 of the XCD -- with hundreds of
+        // workgroups doing that, the weights and patches of everybody else kept being evicted (measured: 141 -> 382 us).
+        if (SPLIT && !head) {              // contributor: publish the partial sums of the tile's last chunks (slot g)
+            float *slot = a.partial + (size_t)g * (16 * G::NCO * G::THREADS);
+#pragma unroll
+            for (int q = 0; q < 16 * G::NCO; ++q)
+                __hip_atomic_store(slot + q * G::THREADS + tid, acc[q / 16][q % 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);     // my write-throughs are acknowledged ...
+            __syncthreads();                   // ... and so are everyone's
+            if (tid == 0) __hip_atomic_store(a.flags + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (SPLIT && !complete) {          // owner of a split tile: add what workgroup g + 1 published
+            if (tid == 0)
+                while (__hip_atomic_load(a.flags + g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+            __syncthreads();
+            const float *slot = a.partial + (size_t)(g + 1) * (16 * G::NCO * G::THREADS);
+#pragma unroll
+            for (int q = 0; q < 16 * G::NCO; ++q)
+                acc[q / 16][q % 16] += __hip_atomic_load(slot + q * G::THREADS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (live) {
 #pragma unroll
             for (int q = 0; q < 16 * G::NCO; ++q) {
@@ -183,14 +236,11 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_kerne
                 a.y[obase + (size_t)c * plane] = a.relu ? fmaxf(v, 0.f) : v;
             }
         }
-        if (!more) break;
-        tile += gridDim.x;
-        cur = nxt;
     }
 }
 
 template <int BH, int BW, int NPB>
-void launch(const ConvArgs &a0, hipStream_t s) {
+int plan(const ConvArgs &a0, ConvArgs *out, size_t *ws_bytes) {          // grid size; fills the tiling fields and the workspace size
     using G = Geo<BH, BW, NPB>;
     static int resident = 0;                    // workgroups one CU holds at once (occupancy query, once per shape family)
     static int cus = 0;
@@ -200,33 +250,71 @@ void launch(const ConvArgs &a0, hipStream_t s) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
         cus = prop.multiProcessorCount;
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_kernel<BH, BW, NPB>, G::THREADS, 0) != hipSuccess || n < 1) n = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_kernel<BH, BW, NPB, true>, G::THREADS, 0) != hipSuccess || n < 1) n = 1;
         resident = n;
     }
     ConvArgs a = a0;
     a.tiles_x = (a.W + G::TW - 1) / G::TW;
     a.tiles_per_img = a.tiles_x * ((a.H + G::TH - 1) / G::TH);
     a.total_tiles = a.tiles_per_img * (a.Cout / kCoutTile) * a.N;
-    const int grid = a.total_tiles < cus * resident ? a.total_tiles : cus * resident;
-    hipLaunchKernelGGL((conv3x3_kernel<BH, BW, NPB>), dim3(grid), dim3(G::THREADS), 0, s, a);
+    const int grid = a.total_tiles < cus * resident ? a.total_tiles : cus * resident;     // every range >= one tile; all resident
+    if (out) *out = a;
+    if (ws_bytes) *ws_bytes = coalign::align_up((size_t)(grid + 1) * sizeof(int), 256) + (size_t)(grid + 1) * 16 * G::NCO * G::THREADS * sizeof(float);
+    return grid;
+}
+
+template <int BH, int BW, int NPB>
+int launch(const ConvArgs &a0, void *workspace, size_t workspace_bytes, hipStream_t s) {
+    using G = Geo<BH, BW, NPB>;
+    ConvArgs a;
+    size_t need = 0;
+    const int grid = plan<BH, BW, NPB>(a0, &a, &need);
+    if (!workspace) return COALIGN_ERR_NULL_POINTER;
+    if (workspace_bytes < need) return COALIGN_ERR_WORKSPACE;
+    const size_t flag_bytes = coalign::align_up((size_t)(grid + 1) * sizeof(int), 256);
+    a.flags = static_cast<int *>(workspace);
+    a.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + flag_bytes);
+    const int rc = coalign::hip_call(hipMemsetAsync(workspace, 0, flag_bytes, s));
+    if (rc != COALIGN_OK) return rc;
+    if (a.Cin / kKC >= kSplitChunks) hipLaunchKernelGGL((conv3x3_kernel<BH, BW, NPB, true>), dim3(grid), dim3(G::THREADS), 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<BH, BW, NPB, false>), dim3(grid), dim3(G::THREADS), 0, s, a);
+    return COALIGN_OK;
 }
 
 }  // namespace
 
-extern "C" int coalign_conv3x3_bias_act(const float *x, const float *w_packed, const float *bias, const float *residual, float *y,
-                                        int N, int Cin, int Cout, int H, int W, int relu, void *stream) {
-    using namespace coalign;
-    if (!x || !w_packed || !y || !bias) return COALIGN_ERR_NULL_POINTER;
+static int check_conv_args(const float *x, const float *w_packed, int N, int Cin, int Cout, int H, int W) {
     if (N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return COALIGN_ERR_BAD_SHAPE;
     if (Cin % kKC || Cout % kCoutTile || W % 4 || ((reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(x)) & 15)) return COALIGN_ERR_UNSUPPORTED;
-    if ((int64_t)N * Cout * H * W > (int64_t)1 << 40) return COALIGN_ERR_UNSUPPORTED;
+    if ((int64_t)N * Cout * H * W > (int64_t)1 << 40 || (int64_t)N * Cout * H * W * (Cin / kKC) > (int64_t)1 << 40) return COALIGN_ERR_UNSUPPORTED;
+    return COALIGN_OK;
+}
+
+extern "C" size_t coalign_conv3x3_workspace_bytes(int N, int Cin, int Cout, int H, int W) {
+    if (check_conv_args(nullptr, nullptr, N, Cin, Cout, H, W) != COALIGN_OK || N == 0) return 0;
+    const ConvArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, N, Cin, Cout, H, W, 0, 0, 0, 0, nullptr, nullptr};
+    size_t need = 0;
+    if ((W % 32 == 0 || W >= 256) && H >= 64) plan<1, 32, 8>(a, nullptr, &need);
+    else if (W % 32 == 0 || W >= 256) plan<1, 32, 4>(a, nullptr, &need);
+    else if (W % 16 == 0) plan<2, 16, 2>(a, nullptr, &need);
+    else plan<1, 32, 2>(a, nullptr, &need);
+    return need;
+}
+
+extern "C" int coalign_conv3x3_bias_act(const float *x, const float *w_packed, const float *bias, const float *residual, float *y,
+                                        int N, int Cin, int Cout, int H, int W, int relu, void *workspace, size_t workspace_bytes,
+                                        void *stream) {
+    using namespace coalign;
+    if (!x || !w_packed || !y || !bias) return COALIGN_ERR_NULL_POINTER;
+    int rc = check_conv_args(x, w_packed, N, Cin, Cout, H, W);
+    if (rc != COALIGN_OK) return rc;
     if (N == 0) return COALIGN_OK;
-    const ConvArgs a{x, w_packed, bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0};
+    const ConvArgs a{x, w_packed, bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, nullptr, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
     // pixel-block shape by map size: 32-pixel row segments on wide maps, 2 x 16 blocks on the middle ones
-    if ((W % 32 == 0 || W >= 256) && H >= 64) launch<1, 32, 8>(a, s);       // 8 wavefronts share one weight image
-    else if (W % 32 == 0 || W >= 256) launch<1, 32, 4>(a, s);
-    else if (W % 16 == 0) launch<2, 16, 2>(a, s);
-    else launch<1, 32, 2>(a, s);
-    return check_launch();
+    if ((W % 32 == 0 || W >= 256) && H >= 64) rc = launch<1, 32, 8>(a, workspace, workspace_bytes, s);       // 8 wavefronts share one weight image
+    else if (W % 32 == 0 || W >= 256) rc = launch<1, 32, 4>(a, workspace, workspace_bytes, s);
+    else if (W % 16 == 0) rc = launch<2, 16, 2>(a, workspace, workspace_bytes, s);
+    else rc = launch<1, 32, 2>(a, workspace, workspace_bytes, s);
+    return rc != COALIGN_OK ? rc : check_launch();
 }

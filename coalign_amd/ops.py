@@ -306,6 +306,7 @@ def pose_graph_optimize(vertex_offsets: torch.Tensor, edge_offsets: torch.Tensor
 
 
 CONV_KC, CONV_WSTRIDE = 8, 9 * 64 + 32      # kKC / kWStride of csrc/conv3x3.hip
+_CONV_WS: dict = {}
 
 
 def pack_conv3x3_weight(weight: torch.Tensor) -> torch.Tensor:
@@ -336,8 +337,13 @@ def conv3x3_bias_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[tor
     res = None if residual is None else _f32c(residual)
     if res is not None and res.shape != y.shape:
         raise ValueError("residual shape mismatch")
+    ws_bytes = L.coalign_conv3x3_workspace_bytes(N, Cin, Cout, H, W)
+    key = (xc.device, torch.cuda.current_stream(xc.device).cuda_stream)
+    ws = _CONV_WS.get(key)
+    if ws is None or ws.numel() < ws_bytes:        # one workspace per (device, stream): launches on a stream are ordered
+        ws = _CONV_WS[key] = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=xc.device)
+    b = torch.zeros(Cout, dtype=torch.float32, device=xc.device) if bias is None else _f32c(bias)
     with _Timed("conv3x3_bias_act"):
-        b = torch.zeros(Cout, dtype=torch.float32, device=xc.device) if bias is None else _f32c(bias)
         hip.check(L.coalign_conv3x3_bias_act(_ptr(xc), _ptr(w_packed), _ptr(b), _ptr(res), _ptr(y),
-                                             N, Cin, Cout, H, W, int(relu), _stream()), "coalign_conv3x3_bias_act")
+                                             N, Cin, Cout, H, W, int(relu), _ptr(ws), ws.numel(), _stream()), "coalign_conv3x3_bias_act")
     return y

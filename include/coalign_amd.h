@@ -240,10 +240,14 @@ int coalign_pose_graph_optimize(int n_graphs, const int32_t *vertex_offsets, con
  * bias [Cout] required (zeros for none), residual may be NULL.
  * w_packed [Cout / 64][Cin / 8][8][608] float32, 16-byte aligned: the LDS image of one 8-input-channel chunk,
  *   w_packed[g][ci / 8][ci % 8][(ky * 3 + kx) * 64 + j] = w[g * 64 + j][ci][ky][kx],  entries [..][576..607] = 0.
- * Products and sums are exact float32 (v_mfma_f32_32x32x2_f32); the summation order differs from a sequential loop.
+ * workspace: coalign_conv3x3_workspace_bytes(...) bytes (flags + partial tiles of the stream-K work split; flags are
+ * cleared by the call itself).  W % 4 == 0.
+ * Products and sums are exact float32 (v_mfma_f32_32x32x2_f32); the summation order differs from a sequential loop but is a
+ * pure function of the shape (deterministic).
  */
+size_t coalign_conv3x3_workspace_bytes(int N, int Cin, int Cout, int H, int W);
 int coalign_conv3x3_bias_act(const float *x, const float *w_packed, const float *bias, const float *residual, float *y,
-                             int N, int Cin, int Cout, int H, int W, int relu, void *stream);
+                             int N, int Cin, int Cout, int H, int W, int relu, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

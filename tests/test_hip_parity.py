@@ -750,10 +750,11 @@ def test_full_frame_vs_stock_pytorch_ops_on_the_gpu():
     assert float((boxes - ref_boxes).abs().max()) < 1e-3 and float((scores - ref_scores).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 64, 100, 352), (3, 128, 128, 50, 176), (2, 256, 256, 25, 88), (1, 384, 256, 36, 96), (2, 64, 128, 37, 50), (1, 8, 64, 5, 3)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 100, 352), (3, 128, 128, 50, 176), (2, 256, 256, 25, 88), (1, 384, 256, 36, 96), (2, 64, 128, 37, 52), (1, 8, 64, 5, 4), (1, 256, 64, 100, 352)])
 def test_conv3x3_bias_act_vs_torch(shape):
     """The fp32 matrix-core 3x3 convolution (experimental entry point (9), not yet on the product path) against torch's
-    convolution: with / without residual and ReLU, map sizes that do not divide the tile, one-chunk inputs."""
+    convolution: with / without residual and ReLU, map sizes that do not divide the tile, one-chunk inputs, long-K shapes whose tiles
+    are split between workgroups (stream-K hand-over)."""
     import torch.nn.functional as F
     N, Ci, Co, H, W = shape
     gen = torch.Generator(device="cpu").manual_seed(sum(shape))
