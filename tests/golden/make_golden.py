@@ -12,7 +12,9 @@ shrunk for the mini cases), ``PillarVFE``, ``PointPillarScatter``, ``normalize_p
 
 Optional third-party modules the reference imports at module scope but that are absent here are
 replaced by inert stubs (icecream, pyquaternion, turtle, cv2, open3d, the un-built Cython
-``box_overlaps``, pypcd).  ``g2o`` (pose-graph solver, absent) is a recording stand-in, see ``_G2O``.  ``shapely.geometry.Polygon`` -- the one stub that *computes* something -- is backed
+``box_overlaps``, pypcd).  ``g2o`` (pose-graph solver, absent) is a recording stand-in, see ``_G2O``;
+torchvision / pypcd are inert and ``opencood.data_utils.datasets`` is registered as a bare package so that only the
+intermediate-fusion dataset module is imported.  ``shapely.geometry.Polygon`` -- the one stub that *computes* something -- is backed
 by the oracle's fp64 clipping routine: this pins the reference's NMS control flow (argsort, top-1000,
 float32 IoU array, strict ``>``) but NOT the GEOS area arithmetic (parity unpinned).
 """
@@ -146,7 +148,13 @@ def install_stubs():
     mod("icecream", ic=lambda *a, **k: None)
     mod("pyquaternion", Quaternion=object)
     sh = mod("shapely")
-    sh.geometry = mod("shapely.geometry", Polygon=_OraclePolygon)
+    sh.geometry = mod("shapely.geometry", Polygon=_OraclePolygon, Point=object, MultiPoint=object)
+    tv = mod("torchvision")
+    _inert = type("Inert", (), {"__init__": lambda self, *a, **k: None, "__call__": lambda self, x: x})
+    tv.transforms = mod("torchvision.transforms", Normalize=_inert, Compose=_inert, ToTensor=_inert, ToPILImage=_inert)
+    # the datasets package __init__ pulls every dataset family (and their dependencies): expose the directory only
+    dsets = mod("opencood.data_utils.datasets")
+    dsets.__path__ = [REF + "/opencood/data_utils/datasets"]
     mod("turtle", update=None)
     mod("cv2")
     mod("open3d")
@@ -405,6 +413,86 @@ def main():
     cloud[200:210, 2] = -1
     save("points.npz", cloud=cloud, range_masked=pcd_utils.mask_points_by_range(cloud, [-140.8, -40, -3, 140.8, 40, 1]),
          ego_masked=pcd_utils.mask_ego_points(cloud))
+
+    # ------------------------------------------------------------------ batch-dict producer (next-4): the reference's dataset class
+    import copy
+    import json
+    from collections import OrderedDict
+    from opencood.data_utils.datasets.intermediate_fusion_dataset import getIntermediateFusionDataset
+    from opencood.data_utils.post_processor import build_postprocessor as ref_build_post
+    from opencood.data_utils.pre_processor.sp_voxel_preprocessor import SpVoxelPreprocessor as RefSpVox
+    from coalign_amd.synthetic import make_point_cloud
+
+    class _VoxStub(RefSpVox):
+        """The reference's pre-processor with spconv's generator (absent) replaced by the oracle's restatement of it; the
+        collate functions are the reference's own."""
+        def __init__(self, params, train):                         # noqa: super().__init__ imports spconv
+            self.params, self.train = params, train
+            self.lidar_range, self.voxel_size = params["cav_lidar_range"], params["args"]["voxel_size"]
+            self.max_points, self.max_voxels = params["args"]["max_points_per_voxel"], params["args"]["max_voxel_test"]
+
+        def preprocess(self, pcd_np):
+            v, c, n = oracle.points_to_voxel(pcd_np, self.voxel_size, self.lidar_range, self.max_points, self.max_voxels)
+            return {"voxel_features": v, "voxel_coords": c, "voxel_num_points": n}
+
+    class _MemoryBase:
+        """Stands in for basedataset (disk readers): serves one in-memory scenario."""
+        def __init__(self, params, visualize, train=True):
+            self.params, self.visualize, self.train = params, visualize, train
+            self.pre_processor = _VoxStub(params["preprocess"], train)
+            self.post_processor = ref_build_post(params["postprocess"], train)
+            self.post_processor.generate_label = lambda **kw: {}       # anchor targets: training only (needs the Cython overlaps)
+            self.post_processor.collate_batch = lambda lst: {}
+            self.max_cav = params["train_params"]["max_cav"]
+            self.load_lidar_file, self.load_camera_file, self.load_depth_file = True, False, False
+            self.scenario = None
+
+        def retrieve_base_data(self, idx):
+            return copy.deepcopy(self.scenario)
+
+        def generate_object_center(self, cav_contents, reference_lidar_pose):
+            return self.post_processor.generate_object_center(cav_contents, reference_lidar_pose)
+
+    def memory_scenario(seed, n_cav=3, n_obj=40, far=True):
+        rs = np.random.RandomState(seed)
+        vehicles = OrderedDict()
+        for k in range(n_obj):
+            vehicles[100 + k] = {"location": [float(rs.uniform(-120, 120)), float(rs.uniform(-38, 38)), float(rs.uniform(-0.2, 0.2))],
+                                 "angle": [0.0, float(rs.uniform(-180, 180)), 0.0], "extent": [float(rs.uniform(1.8, 2.6)), float(rs.uniform(0.8, 1.1)), float(rs.uniform(0.7, 0.9))],
+                                 "center": [0.0, 0.0, float(rs.uniform(0.6, 0.9))]}
+        sc = OrderedDict()
+        for c in range(n_cav):
+            pose = [float(rs.uniform(-25, 25)), float(rs.uniform(-8, 8)), 1.9, 0.0, float(rs.uniform(-180, 180)), 0.0]
+            if far and c == n_cav - 1:
+                pose[0] += 200.0                                       # beyond comm_range: must be dropped
+            seen = OrderedDict((k, v) for k, v in vehicles.items() if rs.uniform() < 0.7)
+            sc[str(c * 7 + 1)] = {"ego": c == 0, "params": {"lidar_pose": pose, "vehicles": seen},
+                                  "lidar_np": make_point_cloud(seed * 10 + c, beams=16, azimuth_steps=450)}
+        return sc
+
+    IFD = getIntermediateFusionDataset(_MemoryBase)
+    hd = load_hypes(YAML_COALIGN)
+    hd.pop("box_align", None)
+    ds = IFD(hd, visualize=False, train=False)
+    dsg = {}
+    for tag, seed, n_cav in (("a", 3, 4), ("b", 4, 2)):
+        ds.scenario = memory_scenario(seed, n_cav)
+        np.random.seed(1000 + seed)
+        batch = ds.collate_batch_test([ds[0]])["ego"]
+        for c, (cid, cav) in enumerate(ds.scenario.items()):
+            dsg.update({f"{tag}_lidar{c}": cav["lidar_np"], f"{tag}_pose{c}": np.array(cav["params"]["lidar_pose"]),
+                        f"{tag}_veh_ids{c}": np.array(list(cav["params"]["vehicles"].keys())),
+                        f"{tag}_veh{c}": np.array([v["location"] + v["angle"] + v["extent"] + v["center"] for v in cav["params"]["vehicles"].values()]).reshape(-1, 12)})
+        dsg.update({f"{tag}_n_cav": n_cav, f"{tag}_cav_ids": np.array(list(ds.scenario.keys())), f"{tag}_np_seed": 1000 + seed,
+                    f"{tag}_voxel_features": batch["processed_lidar"]["voxel_features"], f"{tag}_voxel_coords": batch["processed_lidar"]["voxel_coords"],
+                    f"{tag}_voxel_num_points": batch["processed_lidar"]["voxel_num_points"], f"{tag}_record_len": batch["record_len"],
+                    f"{tag}_pairwise_t_matrix": batch["pairwise_t_matrix"], f"{tag}_object_bbx_center": batch["object_bbx_center"],
+                    f"{tag}_object_bbx_mask": batch["object_bbx_mask"], f"{tag}_object_ids": np.array(batch["object_ids"]),
+                    f"{tag}_lidar_pose": batch["lidar_pose"], f"{tag}_lidar_pose_clean": batch["lidar_pose_clean"],
+                    f"{tag}_cav_id_list": np.array(batch["cav_id_list"]), f"{tag}_transformation_matrix": batch["transformation_matrix"]})
+        print(f"  dataset {tag}: cavs kept {batch['cav_id_list']}, voxels {tuple(batch['processed_lidar']['voxel_features'].shape)}, objects {int(batch['object_bbx_mask'].sum())}")
+    np.savez_compressed(os.path.join(HERE, "dataset.npz"), **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in dsg.items()})
+    print(f"wrote dataset.npz: {os.path.getsize(os.path.join(HERE, 'dataset.npz')) // 1024} KiB")
 
     # ------------------------------------------------------------------ stage-1 detector with uncertainty head + its post-process (next-3)
     from opencood.data_utils.post_processor.uncertainty_voxel_postprocessor import UncertaintyVoxelPostprocessor as RefUncPost

@@ -773,3 +773,36 @@ def test_conv3x3_bias_act_vs_torch(shape):
     assert torch.equal(ops.conv3x3_bias_act(x, wp, b, r, True), ops.conv3x3_bias_act(x, wp, b, r, True))     # deterministic
     got = ops.conv3x3_bias_act(x, wp, None, None, False)
     assert float((got.double() - (ref - b.double().view(1, -1, 1, 1))).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_batch_dict_producer_on_device_vs_reference_dataset(golden):
+    """next-4 end to end: raw per-cav records -> IntermediateFusionBatcher with the device voxeliser -> the batch the reference's
+    dataset + collate produce (bit-identical pillars, poses, transforms, ground truth), and the detector + post-process +
+    evaluation run straight off that batch."""
+    from coalign_amd import evaluation as ev
+    from coalign_amd.dataset import IntermediateFusionBatcher
+    from coalign_amd.detector import to_device
+    from tests.test_host_cpu import check_batch_against_reference, dataset_scenario
+    g = golden("dataset.npz")
+    h = builtin_config("opv2v_coalign")
+    h.pop("box_align", None)
+    batcher = IntermediateFusionBatcher(h, train=False, device=DEV)
+    batches = {}
+    for tag in ("a", "b"):
+        np.random.seed(int(g[f"{tag}_np_seed"]))
+        batches[tag] = batcher(dataset_scenario(g, tag))
+        check_batch_against_reference(batches[tag], g, tag)
+    model = build_model(h)
+    fill_parameters_(model, seed=0, cls_bias=-2.0)
+    with torch.no_grad():
+        model.reg_head.weight.mul_(0.02); model.cls_head.weight.mul_(0.3)
+    model = model.to(DEV).eval()
+    batch = to_device(batches["a"], DEV)
+    with torch.no_grad():
+        out = model(batch["ego"])
+    boxes, scores, gt = batcher.post_process(batch, {"ego": out})
+    assert gt.shape == (int(g["a_object_bbx_mask"].sum()), 8, 3) or gt.shape[0] <= int(g["a_object_bbx_mask"].sum())
+    stat = ev.new_result_stat()
+    for thr in ev.IOU_THRESHOLDS:
+        ev.caluclate_tp_fp(boxes, scores, gt.to(DEV), stat, thr)
+    assert stat[0.7]["gt"] == gt.shape[0]

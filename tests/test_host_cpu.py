@@ -178,3 +178,63 @@ def test_box_alignment_graph_construction_matches_reference(golden):
         np.testing.assert_allclose(graph.vertices[n:], g[f"{tag}_vertices"][n:], rtol=0, atol=1e-4)  # landmarks: float32 world frame
         np.testing.assert_allclose(graph.edge_meas, g[f"{tag}_edge_meas"], rtol=0, atol=1e-12)
         np.testing.assert_allclose(graph.edge_info, g[f"{tag}_edge_info"], rtol=1e-12, atol=0)
+
+
+def dataset_scenario(g, tag):
+    """Rebuild the in-memory scenario of tests/golden/dataset.npz (see make_golden.py: memory_scenario)."""
+    from collections import OrderedDict
+    sc = OrderedDict()
+    for c, cid in enumerate(g[f"{tag}_cav_ids"]):
+        veh = OrderedDict()
+        for vid, row in zip(g[f"{tag}_veh_ids{c}"], g[f"{tag}_veh{c}"]):
+            veh[int(vid)] = {"location": row[0:3].tolist(), "angle": row[3:6].tolist(), "extent": row[6:9].tolist(), "center": row[9:12].tolist()}
+        sc[str(cid)] = {"ego": c == 0, "params": {"lidar_pose": g[f"{tag}_pose{c}"].tolist(), "vehicles": veh}, "lidar_np": g[f"{tag}_lidar{c}"]}
+    return sc
+
+
+def check_batch_against_reference(batch, g, tag, exact_voxels=True):
+    import numpy as np
+    ego = batch["ego"]
+    assert [str(c) for c in ego["cav_id_list"]] == [str(c) for c in g[f"{tag}_cav_id_list"]]
+    assert ego["record_len"].tolist() == g[f"{tag}_record_len"].tolist()
+    np.testing.assert_allclose(ego["lidar_pose"].numpy(), g[f"{tag}_lidar_pose"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(ego["lidar_pose_clean"].numpy(), g[f"{tag}_lidar_pose_clean"], rtol=0, atol=0)
+    np.testing.assert_allclose(ego["pairwise_t_matrix"].numpy(), g[f"{tag}_pairwise_t_matrix"], rtol=0, atol=1e-9)
+    assert [int(i) for i in ego["object_ids"]] == g[f"{tag}_object_ids"].tolist()
+    assert np.array_equal(ego["object_bbx_mask"].numpy(), g[f"{tag}_object_bbx_mask"])
+    np.testing.assert_allclose(ego["object_bbx_center"].numpy(), g[f"{tag}_object_bbx_center"], rtol=0, atol=1e-9)
+    assert np.array_equal(ego["transformation_matrix"].numpy(), g[f"{tag}_transformation_matrix"])
+    pl = {k: v.cpu().numpy() for k, v in ego["processed_lidar"].items()}
+    assert np.array_equal(pl["voxel_coords"], g[f"{tag}_voxel_coords"]) and np.array_equal(pl["voxel_num_points"], g[f"{tag}_voxel_num_points"])
+    assert np.array_equal(pl["voxel_features"], g[f"{tag}_voxel_features"])
+
+
+def test_batch_dict_producer_matches_reference_dataset(golden):
+    """next-4 on the host: IntermediateFusionBatcher (pose noise, comm-range cut, pairwise transforms, ground-truth boxes, id de-dup,
+    collate) against the reference's IntermediateFusionDataset.__getitem__ + collate_batch_test run on the same in-memory scenario;
+    the voxeliser is injected (oracle here, the device kernel in the GPU twin of this test)."""
+    import numpy as np
+    import torch
+    from oracle import coalign_oracle as oracle
+    from coalign_amd.config import builtin_config
+    from coalign_amd.dataset import IntermediateFusionBatcher
+
+    class OracleVoxels:
+        def __init__(self, p):
+            self.p = p
+
+        def preprocess_clouds(self, clouds, ego_filter=False, filter_range=None):
+            a = self.p["args"]
+            per = [oracle.points_to_voxel(oracle.mask_ego_points(c) if ego_filter else c, a["voxel_size"], self.p["cav_lidar_range"],
+                                          a["max_points_per_voxel"], a["max_voxel_test"]) for c in clouds]
+            f, c, n = oracle.collate_voxels(per)
+            return {"voxel_features": torch.from_numpy(f), "voxel_coords": torch.from_numpy(c), "voxel_num_points": torch.from_numpy(n)}
+
+    g = golden("dataset.npz")
+    h = builtin_config("opv2v_coalign")
+    h.pop("box_align", None)
+    batcher = IntermediateFusionBatcher(h, train=False, device="cpu", preprocessor=OracleVoxels(h["preprocess"]))
+    for tag in ("a", "b"):
+        np.random.seed(int(g[f"{tag}_np_seed"]))
+        check_batch_against_reference(batcher(dataset_scenario(g, tag)), g, tag)
+    assert len(g["a_cav_id_list"]) == 3 and int(g["a_n_cav"]) == 4          # one cav was beyond comm_range
