@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--agents", type=int, default=5)
     ap.add_argument("--pillars", type=int, default=8000)
     ap.add_argument("--config", default="opv2v_coalign")
-    ap.add_argument("--lanes", type=int, default=4, help="frames in flight on separate HIP streams (single-GPU runs; the multi-rank ring keeps one)")
+    ap.add_argument("--lanes", type=int, default=4, help="frames in flight on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch CPU threads for the oracle (tiny batched matmuls "
@@ -103,7 +103,6 @@ def main():
     frame_cpu = make_frame(hypes, N, pillars_per_agent=args.pillars, seed=303 + rank, noise=(0.2, 0.2))
     frame = to_device(frame_cpu, dev)
     frame["record_len"] = frame_cpu["record_len"]        # host-side agent counts: no device->host sync per frame
-    ring = FrameRing(N) if world > 1 else None
     calibrate_cls_bias(model, pp, frame)
     if world > 1:   # identical weights everywhere
         for p in model.parameters():
@@ -124,19 +123,23 @@ def main():
     # Frames are independent, so consecutive frames go to alternating HIP streams ("lanes"): the tail of one frame's kernels
     # (partial last waves of every convolution launch, the small latency-bound fusion / head kernels) overlaps the other
     # frame's work.  Throughput device; every frame still completes inside the timed bracket (device-wide synchronise).
-    n_lanes = args.lanes if world == 1 else 1      # one communicator: keep the ring's collectives on one stream
+    n_lanes = max(1, args.lanes)
     lanes = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)] if n_lanes > 1 else [None]
+    # one exchange buffer set per lane (a lane's all-to-all may still be in flight when the next lane packs); the collectives of
+    # all lanes go to the one communicator in frame order on every rank, ProcessGroupNCCL serialises them on its own stream
+    rings = [FrameRing(N) for _ in range(n_lanes)] if world > 1 else None
     counter = [0]
 
     def step():
-        lane = lanes[counter[0] % len(lanes)]
+        k = counter[0] % len(lanes)
         counter[0] += 1
-        if lane is None:
-            return _step()
-        with torch.cuda.stream(lane):
-            return _step()
+        if lanes[k] is None:
+            return _step(k)
+        with torch.cuda.stream(lanes[k]):
+            return _step(k)
 
-    def _step():
+    def _step(k):
+        ring = rings[k] if rings is not None else None
         with torch.no_grad():
             with ops.timed("stage_encode(pillars+backbone)"):
                 feats, affine = model.encode(frame)
