@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Synthetic-ground-truth AP harness: the reference's inference loop
+"""Test infrastructure (lives under tests/ because it may call the CPU oracle).
+
+Synthetic-ground-truth AP harness: the reference's inference loop
 (opencood/tools/inference.py:100-160) on seeded synthetic frames -- model -> post-process -> TP/FP at IoU 0.3/0.5/0.7 ->
 VOC AP -- once through the gfx950 path and, with ``--check-oracle``, once through the CPU oracle on the same inputs.
 
@@ -8,7 +10,7 @@ rigid jitter of a subset of the oracle-independent HIP detections plus a few unm
 says nothing about detection quality; what the harness shows is that both pipelines produce the same TP/FP sequence and
 the same AP ("AP@0.7 vs ref" of BASELINE.json's metric) on identical inputs.
 
-    python tools/inference_synthetic.py --config mini_coalign --frames 6 --agents 3 --pillars 150 --check-oracle
+    python tests/inference_synthetic.py --config mini_coalign --frames 6 --agents 3 --pillars 150 --check-oracle
 """
 import argparse
 import json

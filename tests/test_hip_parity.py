@@ -486,11 +486,11 @@ def test_evaluation_on_device_vs_reference(golden):
 
 
 def test_synthetic_inference_loop_ap_vs_oracle():
-    """The reference's inference loop on seeded frames with planted ground truth (tools/inference_synthetic.py): the
+    """The reference's inference loop on seeded frames with planted ground truth (tests/inference_synthetic.py): the
     gfx950 path and the CPU oracle give the same TP/FP sequence and the same AP at every IoU threshold."""
     import importlib.util
     import os
-    spec = importlib.util.spec_from_file_location("inference_synthetic", os.path.join(os.path.dirname(__file__), "..", "tools", "inference_synthetic.py"))
+    spec = importlib.util.spec_from_file_location("inference_synthetic", os.path.join(os.path.dirname(__file__), "inference_synthetic.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     rep = mod.run("mini_coalign", frames=4, agents=3, pillars=150, check_oracle=True)

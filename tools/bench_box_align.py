@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Time the batched pose-graph solve (coalign_pose_graph_optimize) on G copies-with-jitter of the golden graphs, beside the
-oracle's numpy LM on the host.   python tools/bench_box_align.py [--graphs 2048]"""
+"""Time the batched pose-graph solve (coalign_pose_graph_optimize) on G copies-with-jitter of the golden graphs.
+python tools/bench_box_align.py [--graphs 2048]   (host-side reference timing: tests/cpu_reference_timings.py)"""
 import argparse
 import json
 import os
@@ -15,7 +15,6 @@ from coalign_amd import box_align       # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--graphs", type=int, default=2048)
-ap.add_argument("--cpu-graphs", type=int, default=16)
 a = ap.parse_args()
 g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "box_align.npz"), allow_pickle=True)
 tags = ("default", "five_agents", "hard_boxes", "no_uncertainty")
@@ -35,9 +34,4 @@ torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 rep = {"graphs": a.graphs, "wall_ms_incl_h2d_d2h": round(wall * 1e3, 2), "us_per_graph": round(wall * 1e6 / a.graphs, 2),
        "mean_lm_iterations": float(stats[:, 0].mean()), "vertices": int(sum(len(x.vertices) for x in graphs)), "edges": int(sum(len(x.edge_agent) for x in graphs))}
-from oracle import coalign_oracle as oracle
-t0 = time.perf_counter()
-for x in graphs[: a.cpu_graphs]:
-    oracle.pose_graph_lm(x.vertices, x.kinds, (x.edge_agent, x.edge_landmark, x.edge_meas, x.edge_info))
-rep["cpu_oracle_ms_per_graph"] = round((time.perf_counter() - t0) * 1e3 / a.cpu_graphs, 2)
 print(json.dumps(rep))

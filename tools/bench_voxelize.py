@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Time coalign_voxelize on a frame of synthetic 64-beam sweeps (inputs resident in HBM) and, beside it, the oracle's C
-loop on the host.   python tools/bench_voxelize.py [--clouds 5] [--iters 50] [--shuffle]"""
+"""Time coalign_voxelize on a frame of synthetic 64-beam sweeps (inputs resident in HBM).
+python tools/bench_voxelize.py [--clouds 5] [--iters 50] [--shuffle]   (host-side reference timing: tests/cpu_reference_timings.py)"""
 import argparse
 import json
 import os
@@ -18,7 +18,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--clouds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--shuffle", action="store_true")
-ap.add_argument("--cpu", action="store_true")
 a = ap.parse_args()
 rs = np.random.RandomState(0)
 clouds = [make_point_cloud(40 + i) for i in range(a.clouds)]
@@ -41,10 +40,4 @@ m = int(out[3][-1])
 alg = pts.numel() * 4 + m * (32 * 16 + 16 + 4)
 rep = {"clouds": a.clouds, "points": int(pts.shape[0]), "voxels": m, "us_per_call": round(us, 2), "algorithmic_bytes": alg,
        "GBps": round(alg / us / 1e3, 1), "shuffled": a.shuffle}
-if a.cpu:
-    from oracle import coalign_oracle as oracle
-    t = time.perf_counter()
-    for c in clouds:
-        oracle.points_to_voxel(oracle.mask_ego_points(c), VOXEL, RANGE, 32, 70000)
-    rep["cpu_oracle_us"] = round((time.perf_counter() - t) * 1e6, 1)
 print(json.dumps(rep))
