@@ -94,6 +94,13 @@ class _FoldCache:
         return self.data
 
 
+def _pw_cache_of(module: nn.Module) -> _FoldCache:
+    c = module.__dict__.get("_coalign_pw_cache")
+    if c is None:
+        c = module.__dict__["_coalign_pw_cache"] = _FoldCache()
+    return c
+
+
 def _cache_of(module: nn.Module) -> _FoldCache:
     c = module.__dict__.get("_coalign_fold_cache")
     if c is None:
@@ -127,18 +134,26 @@ class BasicBlock(nn.Module):
             packable = lambda w: w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0
             p1 = ops.pack_conv3x3_weight(w1) if self.stride == 1 and packable(w1) else None
             p2 = ops.pack_conv3x3_weight(w2) if packable(w2) else None
-            return w1, b1, w2, b2, wd, p1, p2
+            pd = None                                    # 1x1 / stride-2 skip convolution through the pointwise kernel
+            if wd is not None and self.stride == 2 and wd.shape[1] % 2 == 0 and wd.shape[1] <= 256:
+                pd = (ops.pack_pointwise_weight(wd, False), torch.zeros(wd.shape[0], dtype=torch.float32, device=wd.device))
+            return w1, b1, w2, b2, wd, p1, p2, pd
         return _cache_of(self).get(self, build)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if _fast_ok(self, x):
-            w1, b1, w2, b2, wd, p1, p2 = self._folded()
+            w1, b1, w2, b2, wd, p1, p2, pd = self._folded()
             x = x.contiguous()
             if p1 is not None and hip_conv3x3_wins(x, w1.shape[1], w1.shape[0]):
                 y = ops.conv3x3_bias_act(x, p1, b1, None, True)
             else:
                 y = ops.bias_act_(F.conv2d(x, w1, None, self.stride, 1), b1, None, True)
-            skip = x if wd is None else F.conv2d(x, wd, None, self.stride)
+            if wd is None:
+                skip = x
+            elif pd is not None:
+                skip = ops.pointwise_conv(x, pd[0], pd[1], wd.shape[0], in_stride=2, relu=False)      # its BN shift already sits in b2
+            else:
+                skip = F.conv2d(x, wd, None, self.stride)
             if p2 is not None and hip_conv3x3_wins(y, w2.shape[1], w2.shape[0]):
                 return ops.conv3x3_bias_act(y, p2, b2, skip, True)
             return ops.bias_act_(F.conv2d(y, w2, None, 1, 1), b2, skip, True)
@@ -213,7 +228,38 @@ class _MultiscaleDecodeMixin:
         y = F.conv_transpose2d(f, w, None, stride=op.stride) if transposed else F.conv2d(f, w, None, stride=op.stride)
         return ops.bias_act_(y.contiguous(), b, None, True)
 
+    def _pointwise_ok(self, feats: Sequence[torch.Tensor]) -> bool:
+        """All per-level heads are non-overlapping transposed convolutions the pointwise kernel serves (kernel = stride in
+        {1, 2, 4}, Cin even and <= 256) and they all land on one output resolution."""
+        if not len(self.deblocks) or not _fast_ok(self, feats[0]):
+            return False
+        sizes = set()
+        for i, f in enumerate(feats[: self.num_levels]):
+            op = self.deblocks[i][0]
+            if not isinstance(op, nn.ConvTranspose2d) or op.kernel_size != op.stride or op.stride[0] != op.stride[1] or op.stride[0] not in (1, 2, 4):
+                return False
+            if op.in_channels > 256 or op.in_channels % 2 or f.shape[0] != feats[0].shape[0]:
+                return False
+            sizes.add((f.shape[2] * op.stride[0], f.shape[3] * op.stride[0]))
+        return len(sizes) == 1
+
     def _upsample_concat(self, feats: Sequence[torch.Tensor]) -> torch.Tensor:
+        if self._pointwise_ok(feats):
+            # every head writes its channel slice of the concatenated tensor directly (one GEMM launch each, bias + ReLU fused)
+            ops_, c_tot = [], 0
+            for i, f in enumerate(feats[: self.num_levels]):
+                blk = self.deblocks[i]
+                op, bn = blk[0], blk[1]
+                w, b = _pw_cache_of(blk).get(blk, lambda op=op, bn=bn: (lambda wf, bf: (ops.pack_pointwise_weight(wf, True), bf))(*fold_bn(op.weight, None, bn, out_dim=1)))
+                ops_.append((f, w, b, op.out_channels, op.stride[0], c_tot))
+                c_tot += op.out_channels
+            f0, s0 = feats[0], self.deblocks[0][0].stride[0]
+            x = torch.empty((f0.shape[0], c_tot, f0.shape[2] * s0, f0.shape[3] * s0), dtype=torch.float32, device=f0.device)
+            for f, w, b, cout, up, off in ops_:
+                ops.pointwise_conv(f, w, b, cout, up=up, relu=True, out=x, c_off=off)
+            if len(self.deblocks) > self.num_levels:
+                x = self._deblock(len(self.deblocks) - 1, x)
+            return x
         ups = [self._deblock(i, f) if len(self.deblocks) > 0 else f for i, f in enumerate(feats[: self.num_levels])]
         x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
         if len(self.deblocks) > self.num_levels:

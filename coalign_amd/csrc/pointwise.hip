@@ -1,0 +1,134 @@
+// Pointwise (per-pixel GEMM) layers of the BEV backbone on the fp32 matrix cores, NCHW, gfx950:
+//   * the up-sampling heads  ConvTranspose2d(kernel = stride = k in {1, 2, 4}) + BatchNorm + ReLU  whose outputs are
+//     concatenated along the channels (opencood/models/sub_modules/base_bev_backbone_resnet.py:47-87, 121-138): every input
+//     pixel produces a k x k patch of every output channel and nothing overlaps, so the layer is one GEMM
+//     D[(co, ky, kx), pixel] = sum_ci W[ci, co, ky, kx] * X[ci, pixel]; the result is written straight into its channel slice
+//     of the concatenated tensor (no torch.cat pass);
+//   * the 1 x 1 / stride-2 down-sampling convolution + BatchNorm on the skip path of the first block of a ResNet stage
+//     (opencood/models/sub_modules/resblock.py:53-69, 165-174): the same GEMM reading every second pixel of every second row.
+// MIOpen serves these through NHWC implicit-GEMM / rocBLAS kernels wrapped in NCHW<->NHWC transposes, a col2im pass and a
+// separate bias / ReLU pass (profiles/round1: ~0.4 ms per frame for 5.3 GFLOP); here each is a single launch.
+//
+// A workgroup (4 wavefronts) owns 32 GEMM pixels and up to 256 GEMM rows (m = co * k * k + ky * k + kx); it stages the X tile
+// [Cin x 32 pixels] in LDS once, each wavefront keeps two 32 x 32 accumulator tiles and streams its weight rows from L2
+// (the weight layout [Cin][M] of ConvTranspose2d is already the A operand: 32 consecutive m for one input channel).
+#include "common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMaxCin = 256;
+constexpr int kRowsPerWg = 256;       // GEMM rows per workgroup: 8 tiles of 32, two per wavefront
+
+struct PwArgs {
+    const float *__restrict__ x, *__restrict__ w, *__restrict__ bias;
+    float *__restrict__ y;
+    int N, Cin, Hin, Win, in_stride, Hp, Wp, M, up, Cout, Ctot, c_off, relu;
+};
+
+template <int UP>
+__global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
+    __shared__ float xt[kMaxCin * 32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, p = lane & 31;
+    const int pixels = a.Hp * a.Wp;
+    const int p0 = blockIdx.x * 32, n = blockIdx.z;
+    const int m_base = blockIdx.y * kRowsPerWg;
+    const size_t in_plane = (size_t)a.Hin * a.Win;
+    const float *xin = a.x + (size_t)n * a.Cin * in_plane;
+    // stage X[ci][32 pixels]: thread t loads pixel t % 32 of channels t / 32, t / 32 + 8, ...
+    {
+        const int px = p0 + (tid & 31);
+        const bool ok = px < pixels;
+        const int hp = ok ? px / a.Wp : 0, wp = ok ? px - hp * a.Wp : 0;
+        const size_t off = (size_t)(hp * a.in_stride) * a.Win + (size_t)wp * a.in_stride;
+        for (int ci = tid >> 5; ci < a.Cin; ci += 8) {
+            const float v = xin[(size_t)ci * in_plane + off];
+            xt[ci * 32 + (tid & 31)] = ok ? v : 0.f;
+        }
+    }
+    __syncthreads();
+    // this wavefront's two m-tiles
+    const int m0 = m_base + wave * 64;
+    if (m0 >= a.M) return;
+    const bool second = m0 + 32 < a.M;
+    floatx16 acc0 = {0}, acc1 = {0};
+    const float *w0 = a.w + m0 + p;
+#pragma unroll 8
+    for (int k0 = 0; k0 < a.Cin; k0 += 2) {
+        const float b = xt[(k0 + half) * 32 + p];
+        const float a0 = w0[(size_t)(k0 + half) * a.M];
+        const float a1 = second ? w0[(size_t)(k0 + half) * a.M + 32] : 0.f;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+    }
+    // epilogue: accumulator r of lane l is GEMM row 8 * (r / 4) + 4 * (l / 32) + r % 4 of its tile, pixel l % 32
+    const int px = p0 + p;
+    if (px >= pixels) return;
+    const int hp = px / a.Wp, wp = px - hp * a.Wp;
+    const int Ho = a.Hp * UP, Wo = a.Wp * UP;
+    const size_t out_plane = (size_t)Ho * Wo;
+    float *yout = a.y + ((size_t)n * a.Ctot + a.c_off) * out_plane;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t == 1 && !second) break;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int m = m0 + t * 32 + 8 * r4 + 4 * half;            // rows m .. m + 3 are accumulators 4 * r4 .. 4 * r4 + 3
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = t == 0 ? acc0[4 * r4 + j] : acc1[4 * r4 + j];
+            if (UP == 4) {                 // m % 16 = ky * 4 + kx: the four rows are kx = 0..3 of one (co, ky): one 16-byte store
+                const int co = m >> 4, ky = (m >> 2) & 3;
+                const float bb = a.bias[co];
+                float4 o;
+                o.x = v[0] + bb; o.y = v[1] + bb; o.z = v[2] + bb; o.w = v[3] + bb;
+                if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                *reinterpret_cast<float4 *>(yout + (size_t)co * out_plane + (size_t)(hp * 4 + ky) * Wo + wp * 4) = o;
+            } else if (UP == 2) {          // m % 4 = ky * 2 + kx: the four rows are the 2 x 2 patch of one co: two 8-byte stores
+                const int co = m >> 2;
+                const float bb = a.bias[co];
+#pragma unroll
+                for (int ky = 0; ky < 2; ++ky) {
+                    float2 o;
+                    o.x = v[ky * 2] + bb; o.y = v[ky * 2 + 1] + bb;
+                    if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); }
+                    *reinterpret_cast<float2 *>(yout + (size_t)co * out_plane + (size_t)(hp * 2 + ky) * Wo + wp * 2) = o;
+                }
+            } else {                       // four consecutive output channels
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (m + j < a.Cout) {
+                        const float o = v[j] + a.bias[m + j];
+                        yout[(size_t)(m + j) * out_plane + (size_t)hp * Wo + wp] = a.relu ? fmaxf(o, 0.f) : o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int coalign_pointwise_conv(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
+                                      int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, void *stream) {
+    using namespace coalign;
+    if (!x || !w || !bias || !y) return COALIGN_ERR_NULL_POINTER;
+    if (N < 0 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1 || Ctot < Cout || c_off < 0 || c_off + Cout > Ctot) return COALIGN_ERR_BAD_SHAPE;
+    if (Cin > kMaxCin || (Cin & 1) || (up != 1 && up != 2 && up != 4) || (in_stride != 1 && in_stride != 2) || (up != 1 && in_stride != 1))
+        return COALIGN_ERR_UNSUPPORTED;
+    const int M = Cout * up * up;
+    if (M_padded < M || M_padded % 32 || (up != 1 && M_padded != M)) return COALIGN_ERR_BAD_SHAPE;
+    if (N == 0) return COALIGN_OK;
+    PwArgs a{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu};
+    if (N > 65535) return COALIGN_ERR_UNSUPPORTED;
+    const int pixels = a.Hp * a.Wp;
+    if (up == 4 && ((a.Wp * 4) % 4 || (reinterpret_cast<uintptr_t>(y) & 15))) return COALIGN_ERR_UNSUPPORTED;
+    if (up == 2 && (reinterpret_cast<uintptr_t>(y) & 7)) return COALIGN_ERR_UNSUPPORTED;
+    const dim3 grid((pixels + 31) / 32, (M_padded + kRowsPerWg - 1) / kRowsPerWg, N);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (up == 4) hipLaunchKernelGGL(pointwise_kernel<4>, grid, dim3(256), 0, s, a);
+    else if (up == 2) hipLaunchKernelGGL(pointwise_kernel<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pointwise_kernel<1>, grid, dim3(256), 0, s, a);
+    return check_launch();
+}

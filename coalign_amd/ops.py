@@ -347,3 +347,34 @@ def conv3x3_bias_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[tor
         hip.check(L.coalign_conv3x3_bias_act(_ptr(xc), _ptr(w_packed), _ptr(b), _ptr(res), _ptr(y),
                                              N, Cin, Cout, H, W, int(relu), _ptr(ws), ws.numel(), _stream()), "coalign_conv3x3_bias_act")
     return y
+
+
+def pack_pointwise_weight(weight: torch.Tensor, transposed: bool) -> torch.Tensor:
+    """ConvTranspose2d weight [Cin, Cout, k, k] -> [Cin, Cout * k * k] (a view of the same layout); Conv2d 1x1 weight
+    [Cout, Cin, 1, 1] -> [Cin, Cout padded to a multiple of 32] (zero columns)."""
+    w = weight.detach().float()
+    if transposed:
+        return w.reshape(w.shape[0], -1).contiguous()
+    co, ci = w.shape[0], w.shape[1]
+    out = torch.zeros((ci, (co + 31) // 32 * 32), dtype=torch.float32, device=w.device)
+    out[:, :co] = w.reshape(co, ci).t()
+    return out
+
+
+def pointwise_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, up: int = 1, in_stride: int = 1, relu: bool = True,
+                   out: Optional[torch.Tensor] = None, c_off: int = 0) -> torch.Tensor:
+    """One-launch pointwise layer (include/coalign_amd.h (10)): ``up`` > 1 = non-overlapping transposed convolution, ``in_stride`` 2 =
+    1x1 stride-2 convolution.  ``out`` [N, Ctot, H', W'] + ``c_off`` select a channel slice of a larger (concatenated) tensor."""
+    _need_gpu(x, w_packed, bias)
+    L = hip.lib()
+    xc = _f32c(x)
+    N, Cin, Hin, Win = xc.shape
+    Ho, Wo = (Hin + in_stride - 1) // in_stride * up, (Win + in_stride - 1) // in_stride * up
+    if out is None:
+        out = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=xc.device)
+    if tuple(out.shape[2:]) != (Ho, Wo) or out.shape[0] != N or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("output buffer shape / layout mismatch")
+    with _Timed("pointwise_conv"):
+        hip.check(L.coalign_pointwise_conv(_ptr(xc), _ptr(w_packed), _ptr(_f32c(bias)), _ptr(out), N, Cin, Hin, Win, in_stride, cout, up,
+                                           w_packed.shape[1], out.shape[1], c_off, int(relu), _stream()), "coalign_pointwise_conv")
+    return out

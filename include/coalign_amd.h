@@ -249,6 +249,21 @@ size_t coalign_conv3x3_workspace_bytes(int N, int Cin, int Cout, int H, int W);
 int coalign_conv3x3_bias_act(const float *x, const float *w_packed, const float *bias, const float *residual, float *y,
                              int N, int Cin, int Cout, int H, int W, int relu, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * (10) Pointwise layers of the BEV backbone as one GEMM launch each, bias (+ ReLU) fused, NCHW float32:
+ *   up in {1, 2, 4}, in_stride = 1:  ConvTranspose2d(kernel = stride = up) + eval BatchNorm (folded) + ReLU of the up-sampling heads
+ *        (opencood/models/sub_modules/base_bev_backbone_resnet.py:47-87, 121-138), written into channels
+ *        [c_off, c_off + Cout) of a [N, Ctot, Hin * up, Win * up] tensor -- the concatenation of :134-138 without a copy;
+ *   up = 1, in_stride = 2:           the 1 x 1 / stride-2 down-sampling convolution + BatchNorm of a ResNet stage's first block
+ *        (opencood/models/sub_modules/resblock.py:53-69, 165-174), output [N, Ctot, ceil(Hin / 2), ceil(Win / 2)].
+ * x [N, Cin, Hin, Win], Cin even and <= 256.
+ * w [Cin, M_padded]: row ci holds the GEMM rows m = co * up * up + ky * up + kx, i.e. ConvTranspose2d's [Cin, Cout, k, k] weight
+ *   as it is (M_padded = Cout * up * up) or, for up = 1, the transposed Conv2d weight zero-padded to a multiple of 32 columns.
+ * bias [Cout].  y must be 16-byte aligned for up = 4, 8-byte for up = 2.
+ */
+int coalign_pointwise_conv(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
+                           int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

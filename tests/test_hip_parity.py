@@ -806,3 +806,39 @@ def test_batch_dict_producer_on_device_vs_reference_dataset(golden):
     for thr in ev.IOU_THRESHOLDS:
         ev.caluclate_tp_fp(boxes, scores, gt.to(DEV), stat, thr)
     assert stat[0.7]["gt"] == gt.shape[0]
+
+
+@pytest.mark.parametrize("case", [(1, 64, 128, 100, 352, 1, 1), (2, 128, 128, 50, 176, 2, 1), (1, 256, 128, 25, 88, 4, 1), (3, 64, 128, 101, 353, 1, 2),
+                                  (2, 128, 256, 50, 176, 1, 2), (1, 6, 20, 7, 9, 1, 1), (1, 10, 8, 5, 3, 2, 1)])
+def test_pointwise_conv_vs_torch(case):
+    """coalign_pointwise_conv (non-overlapping transposed convolutions written into a channel slice of a larger tensor, 1x1 stride-2
+    convolutions) against torch, incl. odd map sizes, channel counts that do not fill a 32-row tile, and an offset slice."""
+    import torch.nn.functional as F
+    N, Ci, Co, H, W, up, st = case
+    gen = torch.Generator(device="cpu").manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=gen).to(DEV)
+    b = torch.randn(Co, generator=gen).to(DEV)
+    if st == 1:
+        w = (torch.randn(Ci, Co, up, up, generator=gen) / Ci ** 0.5).to(DEV)
+        ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=up)
+        wp = ops.pack_pointwise_weight(w, True) if (Co * up * up) % 32 == 0 else None
+        if wp is None:          # rows that do not fill a tile: the 1x1 form with zero-padded columns
+            assert up == 1 or Co * up * up % 32, case
+            if up != 1:
+                with pytest.raises(Exception):
+                    ops.pointwise_conv(x, w.reshape(Ci, -1).contiguous(), b, Co, up=up)
+                return
+            wp = ops.pack_pointwise_weight(w.reshape(Ci, Co).t().reshape(Co, Ci, 1, 1).contiguous(), False)
+    else:
+        w = (torch.randn(Co, Ci, 1, 1, generator=gen) / Ci ** 0.5).to(DEV)
+        ref = F.conv2d(x.double(), w.double(), b.double(), stride=st)
+        wp = ops.pack_pointwise_weight(w, False)
+    for relu in (True, False):
+        want = torch.relu(ref) if relu else ref
+        got = ops.pointwise_conv(x, wp, b, Co, up=up, in_stride=st, relu=relu)
+        assert got.shape == want.shape
+        assert float((got.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), (case, relu)
+    big = torch.full((N, Co + 40, ref.shape[2], ref.shape[3]), 7.0, device=DEV)
+    ops.pointwise_conv(x, wp, b, Co, up=up, in_stride=st, relu=True, out=big, c_off=24)
+    assert float((big[:, 24:24 + Co].double() - torch.relu(ref)).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert bool((big[:, :24] == 7.0).all()) and bool((big[:, 24 + Co:] == 7.0).all())        # neighbours of the slice untouched
