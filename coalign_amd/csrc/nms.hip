@@ -306,6 +306,7 @@ __device__ void box_corners_f32(const float *box, F2 *c) {
 }
 
 // iou3d_cpu.cpp:128-229 / iou3d_nms_kernel.cu:104-225 (box_overlap), :227-234 (iou_bev)
+template <bool AREA>
 __device__ float pcdet_iou(const float *A7, const float *B7) {
     F2 A[5], B[5], pts[16], ctr = {0.f, 0.f};
     int cnt = 0;
@@ -331,16 +332,18 @@ __device__ float pcdet_iou(const float *A7, const float *B7) {
         area += ux * vy - uy * vx;
     }
     const float so = fabsf(area) / 2.0f;
+    if (AREA) return so;                   // boxes_overlap_bev_gpu: the overlap area itself
     const float sa = A7[3] * A7[4], sb = B7[3] * B7[4];
     return so / fmaxf(sa + sb - so, 1e-8f);
 }
 
+template <bool AREA>
 __global__ __launch_bounds__(256) void iou_bev_kernel(const float *__restrict__ a, int Na, const float *__restrict__ b, int Nb,
                                                       float *__restrict__ iou) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)Na * Nb) return;
     const int i = (int)(idx / Nb), j = (int)(idx % Nb);
-    iou[idx] = pcdet_iou(a + (size_t)i * 7, b + (size_t)j * 7);
+    iou[idx] = pcdet_iou<AREA>(a + (size_t)i * 7, b + (size_t)j * 7);
 }
 
 // ------------------------------------------------------------------------------------------------ float64 IoU matrix
@@ -437,15 +440,25 @@ int coalign_iou_rotated_matrix(const float *boxes_a, int rows_a, int cols_a, int
     return check_launch();
 }
 
-int coalign_boxes_iou_bev(const float *boxes_a, int Na, const float *boxes_b, int Nb, float *iou, void *stream_) {
+static int launch_iou_bev(bool area, const float *boxes_a, int Na, const float *boxes_b, int Nb, float *out, void *stream_) {
     using namespace coalign;
     hipStream_t stream = (hipStream_t)stream_;
     if (Na < 0 || Nb < 0) return COALIGN_ERR_BAD_SHAPE;
     if (Na == 0 || Nb == 0) return COALIGN_OK;
-    if (!boxes_a || !boxes_b || !iou) return COALIGN_ERR_NULL_POINTER;
+    if (!boxes_a || !boxes_b || !out) return COALIGN_ERR_NULL_POINTER;
     const long total = (long)Na * Nb;
-    hipLaunchKernelGGL(iou_bev_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, boxes_a, Na, boxes_b, Nb, iou);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (area) hipLaunchKernelGGL(iou_bev_kernel<true>, grid, dim3(256), 0, stream, boxes_a, Na, boxes_b, Nb, out);
+    else hipLaunchKernelGGL(iou_bev_kernel<false>, grid, dim3(256), 0, stream, boxes_a, Na, boxes_b, Nb, out);
     return check_launch();
+}
+
+int coalign_boxes_iou_bev(const float *boxes_a, int Na, const float *boxes_b, int Nb, float *iou, void *stream) {
+    return launch_iou_bev(false, boxes_a, Na, boxes_b, Nb, iou, stream);
+}
+
+int coalign_boxes_overlap_bev(const float *boxes_a, int Na, const float *boxes_b, int Nb, float *overlap, void *stream) {
+    return launch_iou_bev(true, boxes_a, Na, boxes_b, Nb, overlap, stream);
 }
 
 }  // extern "C"

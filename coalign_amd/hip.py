@@ -33,6 +33,7 @@ SIGNATURES = {
     "coalign_gather_in_range": (c_int, [P, P, P, P, c_int, POINTER(c_double), P, P, P, P]),
     "coalign_iou_rotated_matrix": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P]),
     "coalign_boxes_iou_bev": (c_int, [P, c_int, P, c_int, P, P]),
+    "coalign_boxes_overlap_bev": (c_int, [P, c_int, P, c_int, P, P]),
     "coalign_bias_act": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "coalign_voxelize_capacity": (c_int64, [c_int64, c_int, POINTER(c_double), POINTER(c_double), c_int]),
     "coalign_voxelize_workspace_bytes": (c_size_t, [POINTER(c_int64), c_int, POINTER(c_double), POINTER(c_double), c_int]),

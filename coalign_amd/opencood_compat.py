@@ -16,7 +16,7 @@ import sys
 import types
 from typing import Dict
 
-from . import backbone, config, detector, encoder, fusion, pose, postprocess
+from . import backbone, box_align, config, detector, encoder, evaluation, fusion, pcdet, pose, postprocess, preprocess
 
 # dotted module name -> {attribute: object}
 _EXPORTS: Dict[str, Dict[str, object]] = {
@@ -42,6 +42,18 @@ _EXPORTS: Dict[str, Dict[str, object]] = {
                                            "VoxelPostprocessor": postprocess.VoxelPostprocessor},
     "opencood.hypes_yaml.yaml_utils": {"load_yaml": config.load_yaml, "load_point_pillar_params": config.load_point_pillar_params},
     "opencood.tools.train_utils": {"create_model": detector.build_model, "to_device": detector.to_device},
+    # rows N and the "next" rows of SURVEY section 8
+    "opencood.pcdet_utils.iou3d_nms.iou3d_nms_utils": {"nms_gpu": pcdet.nms_gpu, "boxes_iou_bev": pcdet.boxes_iou_bev,
+                                                       "boxes_iou3d_gpu": pcdet.boxes_iou3d_gpu},
+    "opencood.models.point_pillar_uncertainty": {"PointPillarUncertainty": detector.PointPillarUncertainty},
+    "opencood.data_utils.post_processor.uncertainty_voxel_postprocessor": {"UncertaintyVoxelPostprocessor": postprocess.UncertaintyVoxelPostprocessor},
+    "opencood.data_utils.pre_processor.sp_voxel_preprocessor": {"SpVoxelPreprocessor": preprocess.SpVoxelPreprocessor},
+    "opencood.data_utils.pre_processor": {"build_preprocessor": preprocess.build_preprocessor, "SpVoxelPreprocessor": preprocess.SpVoxelPreprocessor},
+    "opencood.models.sub_modules.box_align_v2": {"box_alignment_relative_sample_np": box_align.box_alignment_relative_sample_np,
+                                                 "box_alignment_relative_np": box_align.box_alignment_relative_np},
+    "opencood.models.sub_modules.pose_graph_optim": {"PoseGraphOptimization2D": box_align.PoseGraphOptimization2D},
+    "opencood.utils.eval_utils": {"caluclate_tp_fp": evaluation.caluclate_tp_fp, "calculate_ap": evaluation.calculate_ap, "voc_ap": evaluation.voc_ap,
+                                  "eval_final_results": evaluation.eval_final_results},
 }
 
 

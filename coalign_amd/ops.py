@@ -378,3 +378,13 @@ def pointwise_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
         hip.check(L.coalign_pointwise_conv(_ptr(xc), _ptr(w_packed), _ptr(_f32c(bias)), _ptr(out), N, Cin, Hin, Win, in_stride, cout, up,
                                            w_packed.shape[1], out.shape[1], c_off, int(relu), _stream()), "coalign_pointwise_conv")
     return out
+
+
+def boxes_overlap_bev(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Tensor:
+    """OpenPCDet-semantics fp32 BEV overlap AREA matrix [Na, Nb] of (x, y, z, dx, dy, dz, heading) boxes."""
+    _need_gpu(boxes_a, boxes_b)
+    L = hip.lib()
+    a, b = _f32c(boxes_a), _f32c(boxes_b)
+    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    hip.check(L.coalign_boxes_overlap_bev(_ptr(a), a.shape[0], _ptr(b), b.shape[0], _ptr(out), _stream()), "coalign_boxes_overlap_bev")
+    return out

@@ -159,6 +159,8 @@ int coalign_iou_rotated_matrix(const float *boxes_a, int rows_a, int cols_a, int
  * boxes_a [Na, 7], boxes_b [Nb, 7] = (x, y, z, dx, dy, dz, heading) -> iou [Na, Nb]
  */
 int coalign_boxes_iou_bev(const float *boxes_a, int Na, const float *boxes_b, int Nb, float *iou, void *stream);
+/* same pairing, the overlap AREA instead of the IoU (iou3d_nms_cuda.boxes_overlap_bev_gpu, used by boxes_iou3d_gpu :66-98) */
+int coalign_boxes_overlap_bev(const float *boxes_a, int Na, const float *boxes_b, int Nb, float *overlap, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * (6) Fused convolution epilogue for the dense stages (rows E / I): in place  y = act(y + bias[c] (+ residual)).

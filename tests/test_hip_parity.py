@@ -842,3 +842,29 @@ def test_pointwise_conv_vs_torch(case):
     ops.pointwise_conv(x, wp, b, Co, up=up, in_stride=st, relu=True, out=big, c_off=24)
     assert float((big[:, 24:24 + Co].double() - torch.relu(ref)).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
     assert bool((big[:, :24] == 7.0).all()) and bool((big[:, 24 + Co:] == 7.0).all())        # neighbours of the slice untouched
+
+
+def test_pcdet_iou3d_and_nms_vs_oracle():
+    """Row N: the OpenPCDet-semantics API (boxes_iou3d_gpu, nms_gpu) against the oracle's restatement of the CUDA extension."""
+    from coalign_amd import pcdet
+    rs = np.random.RandomState(17)
+    n = 300
+    boxes = np.zeros((n, 7), dtype=np.float32)
+    boxes[:, 0] = rs.uniform(-20, 20, n); boxes[:, 1] = rs.uniform(-10, 10, n); boxes[:, 2] = rs.uniform(-1.2, -0.8, n)
+    boxes[:, 3] = rs.uniform(3.5, 5, n); boxes[:, 4] = rs.uniform(1.6, 2.1, n); boxes[:, 5] = rs.uniform(1.4, 1.8, n); boxes[:, 6] = rs.uniform(-3.1, 3.1, n)
+    scores = rs.uniform(0, 1, n).astype(np.float32)
+    bd, sd = T(boxes).to(DEV), T(scores).to(DEV)
+    for thr, pre in ((0.01, None), (0.3, 200)):
+        keep, _ = pcdet.nms_gpu(bd, sd, thr, pre_maxsize=pre)
+        assert keep.cpu().numpy().tolist() == oracle.pcdet_nms(boxes, scores, thr, pre).tolist()
+    a, b = boxes[:40], boxes[40:90]
+    got = pcdet.boxes_iou3d_gpu(T(a).to(DEV), T(b).to(DEV)).cpu().numpy()
+    ov = np.array([[oracle.pcdet_overlap(x, y) for y in b] for x in a], dtype=np.float32)        # fp32 BEV overlap areas
+    np.testing.assert_allclose(ops.boxes_overlap_bev(T(a).to(DEV), T(b).to(DEV)).cpu().numpy(), ov, rtol=1e-5, atol=1e-6)
+    top = np.minimum((a[:, 2] + a[:, 5] / 2)[:, None], (b[:, 2] + b[:, 5] / 2)[None])
+    bottom = np.maximum((a[:, 2] - a[:, 5] / 2)[:, None], (b[:, 2] - b[:, 5] / 2)[None])
+    h = np.clip(top - bottom, 0, None)
+    o3 = ov * h
+    want = o3 / np.clip((a[:, 3] * a[:, 4] * a[:, 5])[:, None] + (b[:, 3] * b[:, 4] * b[:, 5])[None] - o3, 1e-6, None)
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-5)
+    assert (got > 0.05).sum() > 5
