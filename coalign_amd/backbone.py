@@ -50,6 +50,38 @@ def _fast_ok(module: nn.Module, x: torch.Tensor) -> bool:
 HIP_CONV_POLICY = os.environ.get("COALIGN_HIP_CONV", "stage1")      # measurement switch: none | stage1 | stage12 | stage1tail | all
 
 
+# OPT-IN: 0 (default) keeps every product of the 3x3 convolutions in native fp32 (MIOpen / coalign_conv3x3_bias_act);
+# 2 or 3 routes every packable 3x3 convolution to coalign_conv3x3_emu_bias_act: fp32 products evaluated as 2- / 3-way split bf16
+# products on the bf16 matrix cores with fp32 accumulation (csrc/conv3x3_emu.hip).  Read at call time.
+CONV_EMU_TERMS = int(os.environ.get("COALIGN_CONV_EMU", "0"))
+
+
+class Conv3x3Pack:
+    """Device images of one folded 3x3 weight: the fp32 LDS image always, the split-bf16 images on first use."""
+
+    def __init__(self, weight: torch.Tensor):
+        self.weight = weight
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.f32 = ops.pack_conv3x3_weight(weight)
+        self._emu = {}
+
+    def emu(self, terms: int) -> torch.Tensor:
+        if terms not in self._emu:
+            self._emu[terms] = ops.pack_conv3x3_emu_weight(self.weight, terms)
+        return self._emu[terms]
+
+
+def conv3x3_fused(x: torch.Tensor, pack: Optional["Conv3x3Pack"], weight: torch.Tensor, bias: torch.Tensor,
+                  residual: Optional[torch.Tensor], stride=1) -> torch.Tensor:
+    """relu(conv3x3(x) + bias (+ residual)) through the kernel the policy selects."""
+    if pack is not None and x.shape[3] % 4 == 0:
+        if CONV_EMU_TERMS in (2, 3):
+            return ops.conv3x3_emu_bias_act(x, pack.emu(CONV_EMU_TERMS), bias, pack.cout, residual, True, CONV_EMU_TERMS)
+        if hip_conv3x3_wins(x, pack.cin, pack.cout):
+            return ops.conv3x3_bias_act(x, pack.f32, bias, residual, True)
+    return ops.bias_act_(F.conv2d(x, weight, None, stride, 1), bias, residual, True)
+
+
 def hip_conv3x3_wins(x: torch.Tensor, cin: int, cout: int) -> bool:
     """Shapes routed to coalign_conv3x3_bias_act instead of MIOpen's Winograd + separate epilogue."""
     if cin % 8 or cout % 64 or x.shape[3] % 4 or HIP_CONV_POLICY == "none":
@@ -132,8 +164,8 @@ class BasicBlock(nn.Module):
                 wd, bd = fold_bn(self.downsample[0].weight, None, self.downsample[1])
                 b2 = (b2 + bd).contiguous()          # both shifts land on the same sum
             packable = lambda w: w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0
-            p1 = ops.pack_conv3x3_weight(w1) if self.stride == 1 and packable(w1) else None
-            p2 = ops.pack_conv3x3_weight(w2) if packable(w2) else None
+            p1 = Conv3x3Pack(w1) if self.stride == 1 and packable(w1) else None
+            p2 = Conv3x3Pack(w2) if packable(w2) else None
             pd = None                                    # 1x1 / stride-2 skip convolution through the pointwise kernel
             if wd is not None and self.stride == 2 and wd.shape[1] % 2 == 0 and wd.shape[1] <= 256:
                 pd = (ops.pack_pointwise_weight(wd, False), torch.zeros(wd.shape[0], dtype=torch.float32, device=wd.device))
@@ -144,19 +176,14 @@ class BasicBlock(nn.Module):
         if _fast_ok(self, x):
             w1, b1, w2, b2, wd, p1, p2, pd = self._folded()
             x = x.contiguous()
-            if p1 is not None and hip_conv3x3_wins(x, w1.shape[1], w1.shape[0]):
-                y = ops.conv3x3_bias_act(x, p1, b1, None, True)
-            else:
-                y = ops.bias_act_(F.conv2d(x, w1, None, self.stride, 1), b1, None, True)
+            y = conv3x3_fused(x, p1, w1, b1, None, self.stride)
             if wd is None:
                 skip = x
             elif pd is not None:
                 skip = ops.pointwise_conv(x, pd[0], pd[1], wd.shape[0], in_stride=2, relu=False)      # its BN shift already sits in b2
             else:
                 skip = F.conv2d(x, wd, None, self.stride)
-            if p2 is not None and hip_conv3x3_wins(y, w2.shape[1], w2.shape[0]):
-                return ops.conv3x3_bias_act(y, p2, b2, skip, True)
-            return ops.bias_act_(F.conv2d(y, w2, None, 1, 1), b2, skip, True)
+            return conv3x3_fused(y, p2, w2, b2, skip)
         skip = x if self.downsample is None else self.downsample(x)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
@@ -369,16 +396,14 @@ class DoubleConv(nn.Module):
 
             def build():
                 ok = lambda c: c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.out_channels % 64 == 0 and c.in_channels % 8 == 0
-                return (ops.pack_conv3x3_weight(c1.weight) if ok(c1) else None, ops.pack_conv3x3_weight(c2.weight) if ok(c2) else None)
+                return (Conv3x3Pack(c1.weight.detach()) if ok(c1) else None, Conv3x3Pack(c2.weight.detach()) if ok(c2) else None)
             p1, p2 = _cache_of(self).get([c1.weight, c2.weight], build)
             x = x.contiguous()
-            if p1 is not None and hip_conv3x3_wins(x, c1.in_channels, c1.out_channels):
-                y = ops.conv3x3_bias_act(x, p1, c1.bias, None, True)
+            if p1 is not None:
+                y = conv3x3_fused(x, p1, c1.weight, c1.bias, None)
             else:
                 y = ops.bias_act_(F.conv2d(x, c1.weight, None, c1.stride, c1.padding), c1.bias, None, True)
-            if p2 is not None and hip_conv3x3_wins(y, c2.in_channels, c2.out_channels):
-                return ops.conv3x3_bias_act(y, p2, c2.bias, None, True)
-            return ops.bias_act_(F.conv2d(y, c2.weight, None, 1, 1), c2.bias, None, True)
+            return conv3x3_fused(y, p2, c2.weight, c2.bias, None)
         return self.double_conv(x)
 
 

@@ -349,6 +349,48 @@ def conv3x3_bias_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[tor
     return y
 
 
+def pack_conv3x3_emu_weight(weight: torch.Tensor, terms: int = 3) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] fp32 -> the split-bf16 LDS image of csrc/conv3x3_emu.hip, as uint8:
+    [Cout / 64][Cin / 8][5 steps][terms][2 k-groups][64 cout][8 cin] bf16 (tap = 2 * step + k-group, the tenth tap is zero;
+    term 0 = bf16(w), term 1 = bf16(w - term 0), term 2 = bf16(w - term 0 - term 1)) followed by 16 zero bytes."""
+    co, ci, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or co % 64 or ci % CONV_KC or terms not in (2, 3):
+        raise ValueError(f"conv3x3_emu needs 3x3 weights with Cout % 64 == 0, Cin % 8 == 0 and terms in (2, 3), got {tuple(weight.shape)}, {terms}")
+    w = weight.detach().float().reshape(co // 64, 64, ci // CONV_KC, CONV_KC, 9)
+    w = torch.cat([w, torch.zeros_like(w[..., :1])], dim=-1).reshape(co // 64, 64, ci // CONV_KC, CONV_KC, 5, 2)
+    w = w.permute(0, 2, 4, 5, 1, 3)                                        # [g, chunk, step, k-group, cout, cin]
+    parts, rest = [], w
+    for _ in range(terms):
+        t = rest.bfloat16()
+        parts.append(t)
+        rest = rest - t.float()
+    img = torch.stack(parts, dim=3).contiguous()                           # [g, chunk, step, term, k-group, cout, cin]
+    flat = img.view(torch.uint8).reshape(-1)
+    out = torch.cat([flat, torch.zeros(16, dtype=torch.uint8, device=flat.device)])
+    assert out.numel() == hip.lib().coalign_conv3x3_emu_weight_bytes(ci, co, terms)
+    return out
+
+
+def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Tensor, cout: int, residual: Optional[torch.Tensor] = None,
+                         relu: bool = True, terms: int = 3) -> torch.Tensor:
+    """y = act(conv3x3(x, w) + bias (+ residual)) with every fp32 product evaluated as `terms`-way split bf16 products on the
+    bf16 matrix cores, fp32 accumulation (csrc/conv3x3_emu.hip)."""
+    _need_gpu(x, w_split, bias, residual)
+    L = hip.lib()
+    xc = _f32c(x)
+    N, Cin, H, W = xc.shape
+    if w_split.numel() != L.coalign_conv3x3_emu_weight_bytes(Cin, cout, terms):
+        raise ValueError("split weight image does not match (Cin, Cout, terms)")
+    y = torch.empty((N, cout, H, W), dtype=torch.float32, device=xc.device)
+    res = None if residual is None else _f32c(residual)
+    if res is not None and res.shape != y.shape:
+        raise ValueError("residual shape mismatch")
+    with _Timed("conv3x3_emu_bias_act"):
+        hip.check(L.coalign_conv3x3_emu_bias_act(_ptr(xc), _ptr(w_split), _ptr(_f32c(bias)), _ptr(res), _ptr(y),
+                                                 N, Cin, cout, H, W, int(relu), terms, _stream()), "coalign_conv3x3_emu_bias_act")
+    return y
+
+
 def pack_pointwise_weight(weight: torch.Tensor, transposed: bool) -> torch.Tensor:
     """ConvTranspose2d weight [Cin, Cout, k, k] -> [Cin, Cout * k * k] (a view of the same layout); Conv2d 1x1 weight
     [Cout, Cin, 1, 1] -> [Cin, Cout padded to a multiple of 32] (zero columns)."""

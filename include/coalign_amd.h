@@ -251,6 +251,20 @@ size_t coalign_conv3x3_workspace_bytes(int N, int Cin, int Cout, int H, int W);
 int coalign_conv3x3_bias_act(const float *x, const float *w_packed, const float *bias, const float *residual, float *y,
                              int N, int Cin, int Cout, int H, int W, int relu, void *workspace, size_t workspace_bytes, void *stream);
 
+/* (9b) OPT-IN variant of (9): the same layers, fp32 in / fp32 out, with every fp32 product evaluated on the bf16 matrix cores by
+ * error-free operand splitting (x = x_h + x_m + x_l, bf16 each; cross terms accumulated in fp32, smallest first).
+ *   terms = 3: six bf16 products per fp32 product, dropped terms <= 2^-24 |w x| -- fp32-level accuracy;
+ *   terms = 2: three products, dropped terms <= 2^-16 |w x|.
+ * w_split: coalign_conv3x3_emu_weight_bytes(Cin, Cout, terms) bytes, 16-byte aligned:
+ *   [Cout / 64][Cin / 8][5 steps][terms][2 k-groups][64 cout][8 cin] bf16 with tap = 2 * step + k-group (the tenth tap zero),
+ *   term 0 = bf16(w), term 1 = bf16(w - term 0), term 2 = bf16(w - term 0 - term 1), followed by 16 zero bytes.
+ * Other arguments, limits and the fused epilogue as in (9); no workspace.  Not used by the default detector path (which keeps
+ * native fp32 products); selected with COALIGN_CONV_EMU (coalign_amd/backbone.py).
+ */
+size_t coalign_conv3x3_emu_weight_bytes(int Cin, int Cout, int terms);
+int coalign_conv3x3_emu_bias_act(const float *x, const void *w_split, const float *bias, const float *residual, float *y,
+                                 int N, int Cin, int Cout, int H, int W, int relu, int terms, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * (10) Pointwise layers of the BEV backbone as one GEMM launch each, bias (+ ReLU) fused, NCHW float32:
  *   up in {1, 2, 4}, in_stride = 1:  ConvTranspose2d(kernel = stride = up) + eval BatchNorm (folded) + ReLU of the up-sampling heads

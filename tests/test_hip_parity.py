@@ -715,10 +715,12 @@ def test_stage1_model_and_post_process_vs_reference(golden):
     assert refined.shape == (3, 3) and np.all(np.isfinite(refined)) and np.array_equal(refined[0], [0, 0, 0])
 
 
-def test_full_frame_vs_stock_pytorch_ops_on_the_gpu():
+@pytest.mark.parametrize("emu_terms,tol", [(0, 1e-4), (3, 1e-4), (2, 1e-3)])
+def test_full_frame_vs_stock_pytorch_ops_on_the_gpu(emu_terms, tol):
     """The whole path at the OPV2V size against the same path written with stock eager PyTorch ops on the GPU (nn.Linear /
     BatchNorm, index scatter, Conv2d+BN+ReLU modules, F.affine_grid + F.grid_sample, bmm + softmax attention, tensor-op box
-    decode; tools/eager_torch_baseline.py): head outputs within 1e-4 relative, identical detections."""
+    decode; tools/eager_torch_baseline.py): head outputs within 1e-4 relative, identical detections.  emu_terms 3 / 2 = the
+    opt-in split-bf16 3x3 convolutions (COALIGN_CONV_EMU): 3-way split holds the same 1e-4, 2-way split the north star's 1e-3."""
     import importlib.util
     import os
     from coalign_amd import backbone as bb_mod
@@ -742,12 +744,19 @@ def test_full_frame_vs_stock_pytorch_ops_on_the_gpu():
             ref_boxes, ref_scores = eb.eager_post_process(ref, anchors, h["postprocess"])
         finally:
             bb_mod.FAST_INFERENCE = True
-        out = model(frame)
+        saved = bb_mod.CONV_EMU_TERMS
+        try:
+            bb_mod.CONV_EMU_TERMS = emu_terms
+            out = model(frame)
+        finally:
+            bb_mod.CONV_EMU_TERMS = saved
         boxes, scores = post.post_process({"ego": {"transformation_matrix": torch.eye(4, device=DEV), "anchor_box": anchors}}, {"ego": out})
     for k in ref:
-        assert float((out[k] - ref[k]).abs().max()) <= 1e-4 * float(ref[k].abs().max()), k
+        err = float((out[k] - ref[k]).abs().max()) / float(ref[k].abs().max())
+        print(f"emu_terms {emu_terms} {k}: max |diff| / max |ref| = {err:.2e}")
+        assert err <= tol, k
     assert ref_boxes is not None and boxes is not None and boxes.shape == ref_boxes.shape and boxes.shape[0] > 5
-    assert float((boxes - ref_boxes).abs().max()) < 1e-3 and float((scores - ref_scores).abs().max()) < 1e-4
+    assert float((boxes - ref_boxes).abs().max()) < 10 * tol and float((scores - ref_scores).abs().max()) < tol
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 64, 100, 352), (3, 128, 128, 50, 176), (2, 256, 256, 25, 88), (1, 384, 256, 36, 96), (2, 64, 128, 37, 52), (1, 8, 64, 5, 4), (1, 256, 64, 100, 352)])
@@ -773,6 +782,37 @@ def test_conv3x3_bias_act_vs_torch(shape):
     assert torch.equal(ops.conv3x3_bias_act(x, wp, b, r, True), ops.conv3x3_bias_act(x, wp, b, r, True))     # deterministic
     got = ops.conv3x3_bias_act(x, wp, None, None, False)
     assert float((got.double() - (ref - b.double().view(1, -1, 1, 1))).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("terms,tol", [(3, 5e-6), (2, 2e-5)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 100, 352), (3, 128, 128, 50, 176), (2, 256, 256, 25, 88), (1, 384, 256, 36, 96), (2, 64, 128, 37, 52), (1, 8, 64, 5, 4)])
+def test_conv3x3_emu_bias_act_vs_fp64(shape, terms, tol):
+    """The opt-in split-bf16 3x3 convolution (entry point (9b)) against the fp64 convolution: the 3-way split must be as accurate
+    as a native fp32 convolution (5e-6 of the output scale; torch's own fp32 kernels land at 2e-7 .. 4e-6 on these shapes), the
+    2-way split within 2e-5; with / without residual and ReLU, ragged map sizes, one-chunk inputs, inputs spanning 12 orders of
+    magnitude (the split is exponent-agnostic), determinism."""
+    import torch.nn.functional as F
+    N, Ci, Co, H, W = shape
+    gen = torch.Generator(device="cpu").manual_seed(sum(shape) + terms)
+    x = torch.randn(N, Ci, H, W, generator=gen).to(DEV)
+    w = (torch.randn(Co, Ci, 3, 3, generator=gen) / (Ci * 9) ** 0.5).to(DEV)
+    b = torch.randn(Co, generator=gen).to(DEV)
+    r = torch.randn(N, Co, H, W, generator=gen).to(DEV)
+    ws = ops.pack_conv3x3_emu_weight(w, terms)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    for res, relu in ((None, False), (r, True)):
+        want = ref if res is None else ref + res.double()
+        want = torch.relu(want) if relu else want
+        got = ops.conv3x3_emu_bias_act(x, ws, b, Co, res, relu, terms)
+        assert got.shape == want.shape
+        assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max()), (shape, res is not None, relu)
+    assert torch.equal(ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, terms), ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, terms))
+    # scale invariance: per-channel input scales from 1e-6 to 1e6 (no fixed-point assumptions in the split)
+    scale = (10.0 ** torch.linspace(-6, 6, Ci)).view(1, -1, 1, 1).to(DEV)
+    xs, wsc = x * scale, w / scale
+    got = ops.conv3x3_emu_bias_act(xs, ops.pack_conv3x3_emu_weight(wsc, terms), b, Co, None, False, terms)
+    want = F.conv2d(xs.double(), wsc.double(), b.double(), padding=1)
+    assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max())
 
 
 def test_batch_dict_producer_on_device_vs_reference_dataset(golden):
