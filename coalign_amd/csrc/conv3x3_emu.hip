@@ -16,6 +16,7 @@
 // x the 8 input channels of the LDS chunk: lanes 0-31 (k 0..7) carry tap 2s, lanes 32-63 (k 8..15) tap 2s + 1, s = 0..4 (the
 // tenth tap is zero weights).  Tiling, persistent workgroups, LDS-DMA double buffering and the epilogue are those of conv3x3.hip.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -133,27 +134,43 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_emu_k
     }
     const int wlane = half * kCoutTile + cb + p;          // 16-byte group of this lane inside one (step, term) weight block
 
-    auto issue = [&](const Tile &t, int chunk, int buf) {
+    // LDS-DMA plan of a tile: transfer j of this wave fills 16-byte group (wave + WAVES * j) * 64 + lane of the patch image; its
+    // source offset inside the chunk's 8 input planes (or "nothing to fetch": zero word) depends on the tile only, so it is
+    // computed once per tile, not per chunk
+    constexpr int PJ = (G::PINSTR + G::WAVES - 1) / G::WAVES, WJ = (G::WINSTR + G::WAVES - 1) / G::WAVES;
+    struct Plan {
+        int off[PJ];           // float offset from the chunk's first plane; < 0: out of the image / padding slot
+    };
+    auto make_plan = [&](const Tile &t) {
+        Plan pl;
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+            const int ins = wave + G::WAVES * j;
+            const int e = (ins * 64 + lane) * 4;
+            const int c = e / G::CS, rem = e - c * G::CS, r = rem / G::STR, xx = rem - r * G::STR;
+            const int gy = t.y0 - 1 + r, gx = t.x0 - 4 + xx;           // gx % 4 == 0: the group is inside the row or outside
+            const bool ok = c < kKC && r < G::PH && xx < G::PW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            pl.off[j] = ok ? c * (int)plane + gy * a.W + gx : -1;
+        }
+        return pl;
+    };
+    auto issue = [&](const Tile &t, const Plan &pl, int chunk, int buf) {
         float *dst = lds + buf * G::BUF;
         const float *xin = a.x + ((size_t)t.n * a.Cin + (size_t)chunk * kKC) * plane;
 #pragma unroll
-        for (int j = 0; j < (G::PINSTR + G::WAVES - 1) / G::WAVES; ++j) {
+        for (int j = 0; j < PJ; ++j) {
             const int ins = wave + G::WAVES * j;
             if (ins < G::PINSTR) {
-                if (ins * 64 + lane >= G::PGROUPS) continue;
-                const int e = (ins * 64 + lane) * 4;
-                const int c = e / G::CS, rem = e - c * G::CS, r = rem / G::STR, xx = rem - r * G::STR;
-                const int gy = t.y0 - 1 + r, gx = t.x0 - 4 + xx;
-                const bool ok = c < kKC && r < G::PH && xx < G::PW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                const float *src = ok ? xin + (size_t)c * plane + (size_t)gy * a.W + gx : a.zero;
+                if (ins * 64 + lane >= G::PGROUPS) continue;               // partial last transfer: masked lanes write nothing
+                const float *src = pl.off[j] >= 0 ? xin + pl.off[j] : a.zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + ins * 256), 16, 0, 0);
             }
         }
-        const uint4 *wsrc = a.wt + ((size_t)t.cg * chunks + chunk) * G::WQ;
+        const uint4 *wsrc = a.wt + ((size_t)t.cg * chunks + chunk) * G::WQ + lane;
 #pragma unroll
-        for (int j = 0; j < (G::WINSTR + G::WAVES - 1) / G::WAVES; ++j) {
+        for (int j = 0; j < WJ; ++j) {
             const int ins = wave + G::WAVES * j;
-            if (ins < G::WINSTR) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ins * 64 + lane), (lptr_t)(dst + G::PLDS + ins * 256), 16, 0, 0);
+            if (ins < G::WINSTR) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ins * 64), (lptr_t)(dst + G::PLDS + ins * 256), 16, 0, 0);
         }
     };
 
@@ -165,15 +182,18 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_emu_k
 #endif
     const int n_local = my_tiles * chunks;
     int L = 0, buf = 0;
-    issue(decode(g), 0, 0);
+    Tile cur = decode(g);
+    Plan plan = make_plan(cur);
+    issue(cur, plan, 0, 0);
+    if (wave >= G::WAVES / 2) __builtin_amdgcn_s_setprio(1);           // the later-dispatched half loses every arbitration otherwise
     for (int ti = 0; ti < my_tiles; ++ti) {
         const int tile = g + ti * n_wg;
-        const Tile cur = decode(tile);
         const int gy = cur.y0 + py, gx = cur.x0 + px;
         const bool live = gy < a.H && gx < a.W;
         const size_t obase = ((size_t)cur.n * a.Cout + cur.cg * kCoutTile + cb + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
         const float *bias = a.bias + cur.cg * kCoutTile + cb + 4 * half;
         floatx16 acc[G::NCO];
+        Tile next = cur;
         if (a.residual) {
 #pragma unroll
             for (int q = 0; q < 16 * G::NCO; ++q) {
@@ -189,9 +209,12 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_emu_k
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
             EMU_STAMP(1);
-            if (L + 1 < n_local) {
-                const bool same = chunk + 1 < chunks;
-                issue(same ? cur : decode(tile + n_wg), same ? chunk + 1 : 0, buf ^ 1);
+            if (chunk + 1 < chunks) {
+                issue(cur, plan, chunk + 1, buf ^ 1);
+            } else if (L + 1 < n_local) {                              // first chunk of this workgroup's next tile
+                next = decode(tile + n_wg);
+                plan = make_plan(next);
+                issue(next, plan, 0, buf ^ 1);
             }
             EMU_STAMP(2);
             const float *pl = lds + buf * G::BUF;
@@ -272,6 +295,7 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_emu_k
                 a.y[obase + (size_t)c * plane] = a.relu ? fmaxf(v, 0.f) : v;
             }
         }
+        cur = next;
     }
 #ifdef EMU_TRACE
     if (tid == 0) a.trace[2 * 16 * 64 * 5 + 2 * g + 1] = wall_clock64();
@@ -305,10 +329,19 @@ int launch(const EmuArgs &a0, hipStream_t s) {
 
 template <int TERMS>
 int dispatch(const EmuArgs &a, hipStream_t s) {
-    if ((a.W % 32 == 0 || a.W >= 256) && a.H >= 64) return launch<1, 32, 8, TERMS>(a, s);
-    if (a.W % 32 == 0 || a.W >= 256) return launch<1, 32, 4, TERMS>(a, s);
-    if (a.W % 16 == 0) return launch<2, 16, 2, TERMS>(a, s);
-    return launch<1, 32, 2, TERMS>(a, s);
+    static const int force = getenv("COALIGN_EMU_GEO") ? atoi(getenv("COALIGN_EMU_GEO")) : -1;      // experiments only
+    // measured on the backbone shapes (tools/bench_conv_emu_geo.py): 8 row segments of 32 pixels per workgroup win or tie on every
+    // map size -- the weight image is shared by 8 wavefronts and both accumulator tiles amortise the operand split; the 3-way split
+    // with long K prefers 4 segments (its 53 KB buffers leave room for two such workgroups per CU)
+    int geo = (TERMS == 3 && a.Cin / kKC >= 32 && a.H >= 64) ? 1 : 0;
+    if (force >= 0) geo = force;
+    switch (geo) {
+        case 0: return launch<1, 32, 8, TERMS>(a, s);
+        case 1: return launch<1, 32, 4, TERMS>(a, s);
+        case 2: return launch<2, 16, 4, TERMS>(a, s);
+        case 3: return launch<2, 16, 2, TERMS>(a, s);
+        default: return launch<1, 32, 2, TERMS>(a, s);
+    }
 }
 
 }  // namespace
