@@ -69,41 +69,27 @@ struct Geo {
     static constexpr int PLDS = (PGROUPS * 4 + 255) / 256 * 256;             // floats of the patch image (whole wave transfers)
     static constexpr int WQ = kSteps * TERMS * 2 * kCoutTile;                 // 16-byte groups of one weight chunk
     static constexpr int WINSTR = WQ / 64;
-    static constexpr int BUF = PLDS + WQ * 4;                                 // floats of one LDS buffer
-    static constexpr size_t LDS_BYTES = 2 * (size_t)BUF * 4;
+    static constexpr int PIX = PH * PW;                                       // pixel slots of the patch
+    // LDS map (floats): three weight images | two fp32 staging patches | two split patches [term][y][x][8 cin] bf16
+    static constexpr int W_OFF = 0, S_OFF = 3 * WQ * 4, B_OFF = S_OFF + 2 * PLDS, BSZ = TERMS * PIX * 4;
+    static constexpr size_t LDS_BYTES = ((size_t)B_OFF + 2 * (size_t)BSZ) * 4;
 };
 
 struct Tile {
     int n, cg, y0, x0;
 };
 
+// error-free split of the 8 input channels of one pixel: out[t] = term t of each channel, 8 bf16 = one MFMA operand
 template <int TERMS>
-__device__ __forceinline__ void split(const float (&v)[8], bf16x8 (&out)[TERMS]) {
+__device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[TERMS]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const __bf16 h = (__bf16)v[i];
         const float r = v[i] - (float)h;
         out[0][i] = h;
-        if (TERMS == 2) {
-            out[1][i] = (__bf16)r;
-        } else {
-            const __bf16 m = (__bf16)r;
-            out[1][i] = m;
-            out[TERMS - 1][i] = (__bf16)(r - (float)m);
-        }
-    }
-}
-
-template <int TERMS>
-__device__ __forceinline__ void split_pair(float v0, float v1, bf16x8 (&out)[TERMS], int pr) {
-    const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
-    const float r0 = v0 - (float)h0, r1 = v1 - (float)h1;
-    out[0][2 * pr] = h0; out[0][2 * pr + 1] = h1;
-    const __bf16 m0 = (__bf16)r0, m1 = (__bf16)r1;
-    out[1][2 * pr] = m0; out[1][2 * pr + 1] = m1;
-    if (TERMS == 3) {
-        out[TERMS - 1][2 * pr] = (__bf16)(r0 - (float)m0);
-        out[TERMS - 1][2 * pr + 1] = (__bf16)(r1 - (float)m1);
+        const __bf16 m = (__bf16)r;
+        out[1][i] = m;
+        if (TERMS == 3) out[TERMS - 1][i] = (__bf16)(r - (float)m);
     }
 }
 
@@ -111,7 +97,7 @@ template <int BH, int BW, int NPB, int TERMS>
 __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_emu_kernel(const EmuArgs a) {
     using G = Geo<BH, BW, NPB, TERMS>;
     extern __shared__ __attribute__((aligned(1024))) float lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, p = lane & 31;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;      // wave: scalar
     const size_t plane = (size_t)a.H * a.W;
     const int groups = a.Cout / kCoutTile, chunks = a.Cin / kKC;
     auto decode = [&](int t) {
@@ -126,11 +112,11 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_emu_k
     };
     const int pb = wave % NPB, cb = (G::NCO == 2 ? 0 : wave / NPB) * 32;
     const int py = pb * BH + p / BW, px = p % BW;
-    int boff[kSteps];                                     // LDS offset of this lane's tap in step s (tap 9 -> tap 8, zeroed below)
+    int boff[kSteps];                                     // pixel slot of this lane's tap in step s (tap 9 -> tap 8, zeroed below)
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) {
         const int t = 2 * s + half < 9 ? 2 * s + half : 8;
-        boff[s] = (py + t / 3) * G::STR + px + 3 + t % 3;
+        boff[s] = (py + t / 3) * G::PW + px + 3 + t % 3;
     }
     const int wlane = half * kCoutTile + cb + p;          // 16-byte group of this lane inside one (step, term) weight block
 
@@ -139,10 +125,13 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_emu_k
     // computed once per tile, not per chunk
     constexpr int PJ = (G::PINSTR + G::WAVES - 1) / G::WAVES, WJ = (G::WINSTR + G::WAVES - 1) / G::WAVES;
     struct Plan {
-        int off[PJ];           // float offset from the chunk's first plane; < 0: out of the image / padding slot
+        const float *src[PJ];  // this lane's source of patch transfer j for the NEXT chunk to issue (the zero word: nothing to fetch)
+        size_t step[PJ];       // floats to advance per chunk (0 for the zero word)
+        const uint4 *wsrc;     // this lane's source inside the next weight chunk
     };
     auto make_plan = [&](const Tile &t) {
         Plan pl;
+        const float *xin = a.x + (size_t)t.n * a.Cin * plane;
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
             const int ins = wave + G::WAVES * j;
@@ -150,28 +139,30 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_emu_k
             const int c = e / G::CS, rem = e - c * G::CS, r = rem / G::STR, xx = rem - r * G::STR;
             const int gy = t.y0 - 1 + r, gx = t.x0 - 4 + xx;           // gx % 4 == 0: the group is inside the row or outside
             const bool ok = c < kKC && r < G::PH && xx < G::PW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            pl.off[j] = ok ? c * (int)plane + gy * a.W + gx : -1;
+            pl.src[j] = ok ? xin + (size_t)c * plane + (size_t)gy * a.W + gx : a.zero;
+            pl.step[j] = ok ? (size_t)kKC * plane : 0;
         }
+        pl.wsrc = a.wt + (size_t)t.cg * chunks * G::WQ + lane;
         return pl;
     };
-    auto issue = [&](const Tile &t, const Plan &pl, int chunk, int buf) {
-        float *dst = lds + buf * G::BUF;
-        const float *xin = a.x + ((size_t)t.n * a.Cin + (size_t)chunk * kKC) * plane;
-#pragma unroll
-        for (int j = 0; j < PJ; ++j) {
-            const int ins = wave + G::WAVES * j;
-            if (ins < G::PINSTR) {
-                if (ins * 64 + lane >= G::PGROUPS) continue;               // partial last transfer: masked lanes write nothing
-                const float *src = pl.off[j] >= 0 ? xin + pl.off[j] : a.zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + ins * 256), 16, 0, 0);
-            }
+    // transfer k (patch transfers first, then weight transfers) of chunk `step` of this workgroup (S slot step % 2, W slot
+    // step % 3); every lane of every transfer is active (the staging image is padded to whole 1 KiB transfers), the LDS
+    // addresses are scalar
+    constexpr int NPART = PJ + WJ;
+    auto issue_part = [&](const Plan &pl, int step, int k) {
+        float *dst = lds + G::S_OFF + (step & 1) * G::PLDS, *wdst = lds + G::W_OFF + (step % 3) * (G::WQ * 4);
+        if (k < PJ) {
+            const int ins = wave + G::WAVES * k;
+            if (ins < G::PINSTR) __builtin_amdgcn_global_load_lds((gptr_t)pl.src[k < PJ ? k : 0], (lptr_t)(dst + ins * 256), 16, 0, 0);
+        } else {
+            const int ins = wave + G::WAVES * (k - PJ);
+            if (ins < G::WINSTR) __builtin_amdgcn_global_load_lds((gptr_t)(pl.wsrc + ins * 64), (lptr_t)(wdst + ins * 256), 16, 0, 0);
         }
-        const uint4 *wsrc = a.wt + ((size_t)t.cg * chunks + chunk) * G::WQ + lane;
+    };
+    auto advance = [&](Plan &pl) {                 // to the tile's next chunk
 #pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-            const int ins = wave + G::WAVES * j;
-            if (ins < G::WINSTR) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ins * 64), (lptr_t)(dst + G::PLDS + ins * 256), 16, 0, 0);
-        }
+        for (int j = 0; j < PJ; ++j) pl.src[j] += pl.step[j];
+        pl.wsrc += G::WQ;
     };
 
     const int g = blockIdx.x, n_wg = gridDim.x;
@@ -181,50 +172,111 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_emu_k
     if (tid == 0) a.trace[2 * 16 * 64 * 5 + 2 * g] = wall_clock64();   // 100 MHz wall clock: start / end of every workgroup
 #endif
     const int n_local = my_tiles * chunks;
-    int L = 0, buf = 0;
-    Tile cur = decode(g);
-    Plan plan = make_plan(cur);
-    issue(cur, plan, 0, 0);
+
+    // Chunk-level software pipeline (one barrier per chunk).  In iteration L a wavefront
+    //   * issues the LDS-DMA of chunk L + 2          (staging slot L % 2, weight slot (L + 2) % 3),
+    //   * splits the staged fp32 patch of chunk L + 1 into bf16 operands        (split-patch slot (L + 1) % 2),
+    //   * runs the MFMA steps of chunk L             (split-patch slot L % 2, weight slot L % 3),
+    // all in one instruction stream, so the matrix pipe works while the VALU splits and the DMA lands.  The barrier at the top of
+    // iteration L + 1 (with vmcnt / lgkmcnt 0) closes all three: every slot written in iteration L had its last reader in
+    // iteration L - 1.
+    int it = 0, ic = 0, li = 0;                    // issue cursor: tile ordinal, chunk, chunk number of this workgroup
+    Tile itile = decode(g);
+    Plan iplan = make_plan(itile);
+    // take the next chunk to issue off the cursor: its plan and chunk number are returned, the cursor moves on
+    auto take_next = [&](Plan &pl, int &step) {
+        if (it >= my_tiles) return false;
+        pl = iplan;
+        step = li++;
+        if (++ic == chunks) {
+            ic = 0;
+            if (++it < my_tiles) {
+                itile = decode(g + it * n_wg);
+                iplan = make_plan(itile);
+            }
+        } else {
+            advance(iplan);
+        }
+        return true;
+    };
+    // the pixel slot this lane splits (slots beyond the patch: none)
+    const bool cv_on = tid < G::PIX || G::PIX > G::THREADS;
+    auto cv_load = [&](int step, int i, float (&v)[8]) {
+        const float *st = lds + G::S_OFF + (step & 1) * G::PLDS;
+        const int y = i / G::PW, xq = i - y * G::PW;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = st[c * G::CS + y * G::STR + xq];
+    };
+    auto cv_store = [&](int step, int i, const bf16x8 (&o)[TERMS]) {
+        uint4 *bt = reinterpret_cast<uint4 *>(lds + G::B_OFF + (step & 1) * G::BSZ);
+#pragma unroll
+        for (int t = 0; t < TERMS; ++t) bt[t * G::PIX + i] = __builtin_bit_cast(uint4, o[t]);
+    };
+    auto convert_all = [&](int step) {             // whole split pass (prologue, and patches larger than the workgroup)
+        for (int i = tid; i < G::PIX; i += G::THREADS) {
+            float v[8];
+            bf16x8 o[TERMS];
+            cv_load(step, i, v);
+            split_pixel<TERMS>(v, o);
+            cv_store(step, i, o);
+        }
+    };
+
+    for (int k = 0; k < 2; ++k) {
+        Plan pl;
+        int step;
+        if (take_next(pl, step)) {
+#pragma unroll
+            for (int q = 0; q < NPART; ++q) issue_part(pl, step, q);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    convert_all(0);
     if (wave >= G::WAVES / 2) __builtin_amdgcn_s_setprio(1);           // the later-dispatched half loses every arbitration otherwise
+    int L = 0;
+    Tile cur = decode(g);
     for (int ti = 0; ti < my_tiles; ++ti) {
-        const int tile = g + ti * n_wg;
         const int gy = cur.y0 + py, gx = cur.x0 + px;
         const bool live = gy < a.H && gx < a.W;
         const size_t obase = ((size_t)cur.n * a.Cout + cur.cg * kCoutTile + cb + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
         const float *bias = a.bias + cur.cg * kCoutTile + cb + 4 * half;
         floatx16 acc[G::NCO];
-        Tile next = cur;
-        if (a.residual) {
+        float res[16 * G::NCO];                    // residual, fetched at the start of the tile and added in the epilogue
 #pragma unroll
-            for (int q = 0; q < 16 * G::NCO; ++q) {
-                const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
-                acc[q / 16][q % 16] = a.residual[obase + (size_t)c * plane] + bias[c];
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16 * G::NCO; ++q) acc[q / 16][q % 16] = bias[(q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4)];
+        for (int q = 0; q < 16 * G::NCO; ++q) {
+            const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
+            acc[q / 16][q % 16] = bias[c];
+            res[q] = a.residual ? a.residual[obase + (size_t)c * plane] : 0.f;
         }
         for (int chunk = 0; chunk < chunks; ++chunk, ++L) {
             EMU_STAMP(0);
             __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
             EMU_STAMP(1);
-            if (chunk + 1 < chunks) {
-                issue(cur, plan, chunk + 1, buf ^ 1);
-            } else if (L + 1 < n_local) {                              // first chunk of this workgroup's next tile
-                next = decode(tile + n_wg);
-                plan = make_plan(next);
-                issue(next, plan, 0, buf ^ 1);
-            }
+            __syncthreads();
             EMU_STAMP(2);
-            const float *pl = lds + buf * G::BUF;
-            const uint4 *wq = reinterpret_cast<const uint4 *>(pl + G::PLDS) + wlane;
-            // software pipeline over the five steps: the LDS reads and the operand split of step s + 1 are issued beside the
-            // matrix instructions of step s (hipcc alone schedules read -> split -> MFMA strictly one step at a time and the
-            // matrix pipe idles through every LDS round trip and split)
-            auto load_b = [&](int s, float (&v)[8]) {
+            Plan dpl;
+            int dstep = 0;
+            // LDS-DMA of chunk L + 2, all transfers up front (spread between the MFMA steps they were measured 10 % slower: each
+            // transfer stalls the wavefront's MFMA stream)
+            if (take_next(dpl, dstep)) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = pl[boff[s] + c * G::CS];
+                for (int q = 0; q < NPART; ++q) issue_part(dpl, dstep, q);
+            }
+            EMU_STAMP(3);
+            const bool more = L + 1 < n_local;
+            float cv[8];
+            const bool cv_inline = G::PIX <= G::THREADS && more && cv_on;
+            if (cv_inline) cv_load(L + 1, tid, cv);
+            const uint4 *bq = reinterpret_cast<const uint4 *>(lds + G::B_OFF + (L & 1) * G::BSZ);
+            const uint4 *wq = reinterpret_cast<const uint4 *>(lds + G::W_OFF + (L % 3) * (G::WQ * 4)) + wlane;
+            auto load_b = [&](int s, bf16x8 (&b)[TERMS]) {
+#pragma unroll
+                for (int t = 0; t < TERMS; ++t) {
+                    uint4 v = bq[t * G::PIX + boff[s]];
+                    if (s == kSteps - 1 && half) v = uint4{0, 0, 0, 0};       // the tenth tap does not exist
+                    b[t] = __builtin_bit_cast(bf16x8, v);
+                }
             };
             auto load_w = [&](int s, bf16x8 (&w)[G::NCO][TERMS]) {
 #pragma unroll
@@ -232,70 +284,46 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_emu_k
 #pragma unroll
                     for (int t = 0; t < TERMS; ++t) w[q][t] = __builtin_bit_cast(bf16x8, wq[((s * TERMS + t) * 2) * kCoutTile + q * 32]);
             };
-            float vn[8];
-            bf16x8 bc[TERMS], wc[G::NCO][TERMS];
-            load_b(0, vn);
+            bf16x8 bc[TERMS], wc[G::NCO][TERMS], cvo[TERMS];
+            load_b(0, bc);
             load_w(0, wc);
-            split<TERMS>(vn, bc);
-            EMU_STAMP(3);
 #pragma unroll
             for (int s = 0; s < kSteps; ++s) {
                 bf16x8 wn[G::NCO][TERMS], bn[TERMS];
                 constexpr int NT = TERMS == 3 ? 6 : 3;
                 constexpr int wi[6] = {0, 1, TERMS == 3 ? 2 : 0, 0, 1, 0};                       // weight term of product i
                 constexpr int bi[6] = {TERMS == 3 ? 2 : 1, TERMS == 3 ? 1 : 0, 0, 1, 0, 0};      // pixel term of product i
-                constexpr int n_mfma = NT * G::NCO, lead = n_mfma >= 8 ? 4 : (n_mfma >= 6 ? 2 : 1), rest = n_mfma - lead;
-                auto mfma = [&](int j) {                                                          // product j / NCO on accumulator j % NCO
-                    const int i = j / G::NCO, q = j % G::NCO;
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[q][wi[i]], bc[bi[i]], acc[q], 0, 0, 0);
-                };
-                if (s + 1 < kSteps) {
-                    // exact issue order (sched_barrier fences): every LDS read of step s + 1, `lead` bare MFMAs to cover their
-                    // latency, then the split of one pixel pair at a time between the remaining MFMAs
-                    load_b(s + 1, vn);
+                if (s + 1 < kSteps) {                  // operands of the next step are in flight while this step's MFMAs issue
+                    load_b(s + 1, bn);
                     load_w(s + 1, wn);
-                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
-                    for (int j = 0; j < lead; ++j) mfma(j);
-                    __builtin_amdgcn_sched_barrier(0);
-                    int done = lead;
+                for (int i = 0; i < NT; ++i)
 #pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) {
-                        if (s + 1 == kSteps - 1) {
-                            vn[2 * pr] = half ? 0.f : vn[2 * pr];
-                            vn[2 * pr + 1] = half ? 0.f : vn[2 * pr + 1];
-                        }
-                        split_pair<TERMS>(vn[2 * pr], vn[2 * pr + 1], bn, pr);
-                        const int upto = lead + (pr + 1) * rest / 4;
-#pragma unroll
-                        for (int j = lead + pr * rest / 4; j < upto; ++j) mfma(j);
-                        done = upto;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    (void)done;
+                    for (int q = 0; q < G::NCO; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[q][wi[i]], bc[bi[i]], acc[q], 0, 0, 0);
+                if (s == 1 && cv_inline) split_pixel<TERMS>(cv, cvo);          // VALU work of the split beside the MFMAs
+                if (s == 3 && cv_inline) cv_store(L + 1, tid, cvo);
+                if (s + 1 < kSteps) {
 #pragma unroll
                     for (int t = 0; t < TERMS; ++t) {
                         bc[t] = bn[t];
 #pragma unroll
                         for (int q = 0; q < G::NCO; ++q) wc[q][t] = wn[q][t];
                     }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < n_mfma; ++j) mfma(j);
                 }
             }
+            if (G::PIX > G::THREADS && more) convert_all(L + 1);
             EMU_STAMP(4);
-            buf ^= 1;
         }
         if (live) {
 #pragma unroll
             for (int q = 0; q < 16 * G::NCO; ++q) {
                 const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
-                const float v = acc[q / 16][q % 16];
+                const float v = acc[q / 16][q % 16] + res[q];
                 a.y[obase + (size_t)c * plane] = a.relu ? fmaxf(v, 0.f) : v;
             }
         }
-        cur = next;
+        if (ti + 1 < my_tiles) cur = decode(g + (ti + 1) * n_wg);
     }
 #ifdef EMU_TRACE
     if (tid == 0) a.trace[2 * 16 * 64 * 5 + 2 * g + 1] = wall_clock64();
@@ -333,13 +361,16 @@ int dispatch(const EmuArgs &a, hipStream_t s) {
     // measured on the backbone shapes (tools/bench_conv_emu_geo.py): 8 row segments of 32 pixels per workgroup win or tie on every
     // map size -- the weight image is shared by 8 wavefronts and both accumulator tiles amortise the operand split; the 3-way split
     // with long K prefers 4 segments (its 53 KB buffers leave room for two such workgroups per CU)
-    int geo = (TERMS == 3 && a.Cin / kKC >= 32 && a.H >= 64) ? 1 : 0;
+    // measured (tools/bench_conv_emu_geo.py): 12 row segments per workgroup (3 wavefronts per SIMD) on the large maps when the
+    // LDS holds them (2-way split), 8 otherwise
+    int geo = (TERMS == 2 && a.H >= 64) ? 5 : 0;
     if (force >= 0) geo = force;
     switch (geo) {
         case 0: return launch<1, 32, 8, TERMS>(a, s);
         case 1: return launch<1, 32, 4, TERMS>(a, s);
         case 2: return launch<2, 16, 4, TERMS>(a, s);
         case 3: return launch<2, 16, 2, TERMS>(a, s);
+        case 5: return launch<1, 32, 12, TERMS>(a, s);
         default: return launch<1, 32, 2, TERMS>(a, s);
     }
 }

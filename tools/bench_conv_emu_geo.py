@@ -18,17 +18,20 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     for (N, Ci, Co, H, W) in ((5, 64, 64, 100, 352), (5, 128, 128, 50, 176), (5, 256, 256, 25, 88), (1, 384, 256, 100, 352), (1, 256, 256, 100, 352)):
         x = torch.randn(N, Ci, H, W, device="cuda"); w = torch.randn(Co, Ci, 3, 3, device="cuda") / (Ci * 9) ** 0.5
         b = torch.randn(Co, device="cuda"); r = torch.randn(N, Co, H, W, device="cuda")
-        for terms in (2, 3):
+        for terms in [int(v) for v in os.environ.get("TERMS", "2,3").split(",")]:
             ws = ops.pack_conv3x3_emu_weight(w, terms)
-            out[f"{N}x{Ci}x{Co}x{H}x{W} x{terms}"] = round(timed(lambda: ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, terms)), 1)
+            try:
+                out[f"{N}x{Ci}x{Co}x{H}x{W} x{terms}"] = round(timed(lambda: ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, terms)), 1)
+            except Exception as e:
+                out[f"{N}x{Ci}x{Co}x{H}x{W} x{terms}"] = "fail"
     print(json.dumps(out))
 else:
     rows = {}
-    for geo in range(5):
+    for geo in [int(v) for v in os.environ.get('GEOS', '0,1,5,6').split(',')]:
         env = dict(os.environ, COALIGN_EMU_GEO=str(geo))
         r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True, timeout=200)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         rows[geo] = json.loads(line[0]) if line else r.stderr[-300:]
-    names = ["1x32x8", "1x32x4", "2x16x4", "2x16x2", "1x32x2"]
-    for k in rows[0]:
+    names = {0: "1x32x8", 1: "1x32x4", 2: "2x16x4", 3: "2x16x2", 4: "1x32x2", 5: "1x32x12", 6: "1x32x16"}
+    for k in next(r for r in rows.values() if isinstance(r, dict)):
         print(k, {names[g]: (rows[g][k] if isinstance(rows[g], dict) else "fail") for g in rows})

@@ -40,7 +40,7 @@ t = tr.cpu()[: 2 * waves * 64 * 5].view(2, -1)
 t = torch.stack([t[0, : nw * 64 * 5], tr.cpu()[nw * 64 * 5: 2 * nw * 64 * 5]]).reshape(2, nw, 64, 5)
 for g in (0, 1):
     for wv in (0, nw - 1):
-        print(f"workgroup {'0' if g == 0 else '100'} wave {wv}: chunk  wait+barrier  issue  prologue  steps  | total")
+        print(f"workgroup {'0' if g == 0 else '100'} wave {wv}: chunk  own-DMA-wait  barrier  issue  steps  | total")
         for c in range(24):
             s = t[g, wv, c]
             if s[4] == 0: break
