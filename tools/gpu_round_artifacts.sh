@@ -10,6 +10,10 @@ timeout 300 python bench.py 2> $OUT/bench.err | tee $OUT/bench_n1.json | cut -c1
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cp $(find $OUT/stats -name "*domain_stats.csv" | head -1) $OUT/domain_stats.csv
 grep -h '"metric"' $OUT/stats.log > $OUT/bench_n1_under_rocprof.json
+timeout 200 python tools/bench_conv3x3.py 2>/dev/null | grep '^{' > $OUT/conv3x3_bench.json
+( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/emu_stats -- python $ROOT/bench.py --conv-emu 2 --no-cpu-baseline --no-opt-in > $OUT/emu_stats.log 2>&1 )
+cp $(find $OUT/emu_stats -name "*kernel_stats.csv" | head -1) $OUT/emu_kernel_stats.csv
+grep -h '"metric"' $OUT/emu_stats.log > $OUT/emu_bench_n1.json
 i=0
 for ctrs in "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA"; do
   i=$((i+1))
@@ -24,6 +28,7 @@ for f in glob.glob(out+"/pmc*/**/*counter_collection.csv", recursive=True):
         k=r["Kernel_Name"]
         if "anonymous" not in k: continue
         short=k.split("(anonymous namespace)::")[1].split("(")[0]
+        if short.startswith("conv3x3_emu_kernel"): short = "conv3x3_emu_kernel_bf16x" + short.rstrip(">").split(",")[-1].strip()
         agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res={k:{c:sum(v)/len(v) for c,v in d.items()} for k,d in agg.items()}
 for k,d in res.items():

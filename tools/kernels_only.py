@@ -40,6 +40,10 @@ for x in xs:
 wconv = torch.randn(64, 64, 3, 3, generator=g).to(dev) / 24.0
 wp, bconv, rconv = ops.pack_conv3x3_weight(wconv), torch.randn(64, generator=g).to(dev), torch.randn(N, 64, 100, 352, generator=g).to(dev)
 res["conv3x3_bias_act_64ch_us"] = timed(lambda: ops.conv3x3_bias_act(xs[0], wp, bconv, rconv, True), iters)
+# the opt-in split-bf16 convolution at the same shape (3-way and 2-way split)
+for terms in (3, 2):
+    wsplit = ops.pack_conv3x3_emu_weight(wconv, terms)
+    res[f"conv3x3_emu_bf16x{terms}_64ch_us"] = timed(lambda: ops.conv3x3_emu_bias_act(xs[0], wsplit, bconv, 64, rconv, True, terms), iters)
 # the pointwise kernel at the 4x4 up-sampling head shape (256 -> 128 channels, 25 x 88 -> 100 x 352, ego only)
 wt = torch.randn(256, 128, 4, 4, generator=g).to(dev) / 16.0
 res["pointwise_up4_us"] = timed(lambda: ops.pointwise_conv(xs[2][:1], ops.pack_pointwise_weight(wt, True), bconv.repeat(2), 128, up=4), iters)
