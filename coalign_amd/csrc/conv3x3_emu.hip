@@ -341,7 +341,10 @@ int launch(const EmuArgs &a0, hipStream_t s) {
         cus = prop.multiProcessorCount;
         const int rc = coalign::hip_call(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS>),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
-        if (rc != COALIGN_OK) return rc;
+        if (rc != COALIGN_OK) {                    // geometry does not fit this device's LDS: report, leave no sticky error behind
+            (void)hipGetLastError();
+            return rc;
+        }
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_emu_kernel<BH, BW, NPB, TERMS>, G::THREADS, G::LDS_BYTES) != hipSuccess || n < 1) n = 1;
         resident = n;

@@ -238,3 +238,28 @@ def test_batch_dict_producer_matches_reference_dataset(golden):
         np.random.seed(int(g[f"{tag}_np_seed"]))
         check_batch_against_reference(batcher(dataset_scenario(g, tag)), g, tag)
     assert len(g["a_cav_id_list"]) == 3 and int(g["a_n_cav"]) == 4          # one cav was beyond comm_range
+
+
+def test_split_bf16_weight_image_layout_and_exactness():
+    """ops.pack_conv3x3_emu_weight (entry point (9b)): the image is [Cout/64][Cin/8][5 steps][terms][2 k-groups][64][8] bf16 + 16 zero
+    bytes, tap = 2 * step + k-group with a zero tenth tap; the three terms of the 3-way split add up to the fp32 weight EXACTLY, the
+    two terms of the 2-way split to within 2^-16 relative."""
+    from coalign_amd import hip, ops
+    gen = torch.Generator().manual_seed(5)
+    w = torch.randn(128, 16, 3, 3, generator=gen) * torch.logspace(-3, 3, 128).view(-1, 1, 1, 1)
+    for terms in (3, 2):
+        img = ops.pack_conv3x3_emu_weight(w, terms)
+        assert img.dtype == torch.uint8 and img.numel() == hip.lib().coalign_conv3x3_emu_weight_bytes(16, 128, terms)
+        assert int(img[-16:].sum()) == 0
+        t = img[:-16].view(torch.bfloat16).reshape(2, 2, 5, terms, 2, 64, 8).double()          # [g, chunk, step, term, kgroup, cout, cin]
+        total = t.sum(dim=3)                                                                    # [g, chunk, step, kgroup, cout, cin]
+        taps = total.permute(0, 4, 1, 5, 2, 3).reshape(128, 16, 10)                             # [cout, cin, tap = 2 * step + kgroup]
+        assert float(taps[..., 9].abs().max()) == 0.0
+        want = w.reshape(128, 16, 9).double()
+        if terms == 3:
+            assert torch.equal(taps[..., :9], want)
+        else:
+            assert float(((taps[..., :9] - want).abs() / want.abs().clamp_min(1e-30)).max()) <= 2.0 ** -16
+    with pytest.raises(ValueError):
+        ops.pack_conv3x3_emu_weight(torch.zeros(60, 16, 3, 3), 3)
+    assert hip.lib().coalign_conv3x3_emu_weight_bytes(16, 128, 4) == 0
