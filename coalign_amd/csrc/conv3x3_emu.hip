@@ -10,11 +10,15 @@
 //   TERMS = 3:  w_h x_l + w_m x_m + w_l x_h + w_h x_m + w_m x_h + w_h x_h     dropped terms <= 2^-24 |w x|: fp32-level accuracy
 //   TERMS = 2:  w_h x_l + w_l x_h + w_h x_h   (x_l = bf16(x - x_h))           dropped terms <= 2^-16 |w x|
 // i.e. 6 (or 3) bf16 MFMAs replace 8 fp32 MFMAs of the same K: 2.7x (5.3x) less matrix-pipe time.  The weights are split on the
-// host once; the input pixels are split in registers right after their LDS read (v_cvt_pk_bf16_f32 + exact subtractions).
+// host once; the input pixels are split in registers, once per pixel and chunk (v_cvt_pk_bf16_f32 + exact subtractions).
 //
 // GEMM view per image:  D[cout, pixel] = sum_{cin, tap} W[cout, cin, tap] * X[cin, pixel + tap].  One MFMA has K = 16 = two taps
-// x the 8 input channels of the LDS chunk: lanes 0-31 (k 0..7) carry tap 2s, lanes 32-63 (k 8..15) tap 2s + 1, s = 0..4 (the
-// tenth tap is zero weights).  Tiling, persistent workgroups, LDS-DMA double buffering and the epilogue are those of conv3x3.hip.
+// x the 8 input channels of a chunk: lanes 0-31 (k 0..7) carry tap 2s, lanes 32-63 (k 8..15) tap 2s + 1, s = 0..4 (the tenth tap
+// is zero weights).  A workgroup (8 or 12 wavefronts) owns 8 / 12 row segments of 32 pixels and 64 output channels; persistent
+// workgroups, one barrier per 8-channel chunk, everything one chunk ahead: the split weights of chunk L + 1 arrive by LDS-DMA, the
+// fp32 halo pixels of chunk L + 1 are loaded into registers (one lane = one pixel, coalesced along the patch rows), split ONCE per
+// pixel after the MFMA steps of chunk L and written to LDS as [term][pixel][8 cin] bf16 -- a B operand is then one ds_read_b128
+// and the MFMA stream carries no VALU work.  Long tiles are load-balanced stream-K style (see the kernel).
 #include "common.h"
 #include <cstdlib>
 
@@ -33,9 +37,11 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 struct EmuArgs {
     const float *__restrict__ x;
     const uint4 *__restrict__ wt;     // [Cout / 64][Cin / 8][5 steps][TERMS][2 k-groups][64 cout][8 bf16]
-    const float *__restrict__ bias, *__restrict__ residual, *__restrict__ zero;
+    const float *__restrict__ bias, *__restrict__ residual;
     float *__restrict__ y;
     int N, Cin, Cout, H, W, relu, tiles_x, tiles_per_img, total_tiles;
+    float *__restrict__ partial;      // [grid][16 * NCO][threads]: accumulators of a tile whose chunks are split over two workgroups
+    int *flags;                       // [grid], zeroed per launch: flags[g] = 1 once workgroup g has published its partial tile
 #ifdef EMU_TRACE
     long long *trace;                 // profiling aid (tools/trace_conv_emu.py): [2 workgroups][waves][64 chunks][5 stamps]
 #endif
@@ -49,29 +55,19 @@ struct EmuArgs {
 #define EMU_STAMP(k)
 #endif
 
-constexpr int pick_stride(int pw, int bh, int bw) {
-    int s = (pw + 3) / 4 * 4;
-    if (bh == 1) return s;
-    while (s % 32 != bw % 32) s += 4;
-    return s;
-}
-
-template <int BH, int BW, int NPB, int TERMS>
+template <int BH, int BW, int NPB, int TERMS, int KCH>
 struct Geo {
-    static constexpr int NCO = NPB >= 4 ? 2 : 1;
+    static constexpr int NCO = NPB >= 4 ? 2 : 1;                              // accumulator tiles (32 output channels each) per wave
     static constexpr int WAVES = NPB >= 4 ? NPB : 2 * NPB;
     static constexpr int THREADS = 64 * WAVES;
-    static constexpr int TH = BH * NPB, TW = BW, PH = TH + 2, PW = TW + 8;
-    static constexpr int STR = pick_stride(PW, BH, BW);
-    static constexpr int CS = PH * STR;
-    static constexpr int PGROUPS = kKC * CS / 4;
-    static constexpr int PINSTR = (PGROUPS + 63) / 64;
-    static constexpr int PLDS = (PGROUPS * 4 + 255) / 256 * 256;             // floats of the patch image (whole wave transfers)
+    static constexpr int TH = BH * NPB, TW = BW, PH = TH + 2, PW = TW + 2;    // halo patch: rows y0 - 1 .., columns x0 - 1 ..
+    static constexpr int PIX = PH * PW;                                       // pixel slots of the patch
+    static constexpr int SLOTS = (PIX + THREADS - 1) / THREADS;               // pixel slots one thread splits per chunk
     static constexpr int WQ = kSteps * TERMS * 2 * kCoutTile;                 // 16-byte groups of one weight chunk
     static constexpr int WINSTR = WQ / 64;
-    static constexpr int PIX = PH * PW;                                       // pixel slots of the patch
-    // LDS map (floats): three weight images | two fp32 staging patches | two split patches [term][y][x][8 cin] bf16
-    static constexpr int W_OFF = 0, S_OFF = 3 * WQ * 4, B_OFF = S_OFF + 2 * PLDS, BSZ = TERMS * PIX * 4;
+    // KCH 8-channel chunks are processed per barrier.  LDS map (floats): two weight images of KCH chunks | two split patches
+    // [chunk][term][y][x][8 cin] bf16
+    static constexpr int W_OFF = 0, WSZ = KCH * WQ * 4, B_OFF = 2 * WSZ, BSZ1 = TERMS * PIX * 4, BSZ = KCH * BSZ1;
     static constexpr size_t LDS_BYTES = ((size_t)B_OFF + 2 * (size_t)BSZ) * 4;
 };
 
@@ -93,13 +89,18 @@ __device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[T
     }
 }
 
-template <int BH, int BW, int NPB, int TERMS>
-__global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_emu_kernel(const EmuArgs a) {
-    using G = Geo<BH, BW, NPB, TERMS>;
+// The split variant's occupancy is pinned (registers capped): its hand-over code, executed once per split tile, would otherwise
+// cost a resident workgroup -- the spills it causes sit outside the chunk loop.  8 wavefronts x 2 workgroups = 4 per SIMD, 12
+// wavefronts = 3 per SIMD.  (Pinning the plain variant as well changes hipcc's scheduling and was measured 5-20 % slower.)
+template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT>
+__global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB))
+__attribute__((amdgpu_waves_per_eu(SPLIT ? (NPB == 12 ? 3 : 4) : 1, SPLIT ? (NPB == 12 ? 3 : 4) : 8)))
+void conv3x3_emu_kernel(const EmuArgs a) {
+    using G = Geo<BH, BW, NPB, TERMS, KCH>;
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;      // wave: scalar
     const size_t plane = (size_t)a.H * a.W;
-    const int groups = a.Cout / kCoutTile, chunks = a.Cin / kKC;
+    const int groups = a.Cout / kCoutTile, chunks = a.Cin / (kKC * KCH);       // `chunks`: barrier intervals per tile, KCH x 8 channels each
     auto decode = [&](int t) {
         Tile c;
         c.cg = t % groups;
@@ -116,194 +117,188 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_emu_k
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) {
         const int t = 2 * s + half < 9 ? 2 * s + half : 8;
-        boff[s] = (py + t / 3) * G::PW + px + 3 + t % 3;
+        boff[s] = (py + t / 3) * G::PW + px + t % 3;
     }
     const int wlane = half * kCoutTile + cb + p;          // 16-byte group of this lane inside one (step, term) weight block
 
-    // LDS-DMA plan of a tile: transfer j of this wave fills 16-byte group (wave + WAVES * j) * 64 + lane of the patch image; its
-    // source offset inside the chunk's 8 input planes (or "nothing to fetch": zero word) depends on the tile only, so it is
-    // computed once per tile, not per chunk
-    constexpr int PJ = (G::PINSTR + G::WAVES - 1) / G::WAVES, WJ = (G::WINSTR + G::WAVES - 1) / G::WAVES;
+    // Patch plan of a tile: thread t owns pixel slots t, t + THREADS, ... of the halo patch; per slot the offset of that pixel
+    // inside an input plane, or -1 for the zero padding outside the image.  Computed once per tile.
     struct Plan {
-        const float *src[PJ];  // this lane's source of patch transfer j for the NEXT chunk to issue (the zero word: nothing to fetch)
-        size_t step[PJ];       // floats to advance per chunk (0 for the zero word)
-        const uint4 *wsrc;     // this lane's source inside the next weight chunk
+        const float *base;     // first input plane of the tile's image
+        const uint4 *wsrc;     // this lane inside the tile's first weight chunk
+        int off[G::SLOTS];
     };
     auto make_plan = [&](const Tile &t) {
         Plan pl;
-        const float *xin = a.x + (size_t)t.n * a.Cin * plane;
+        pl.base = a.x + (size_t)t.n * a.Cin * plane;
+        pl.wsrc = a.wt + (size_t)t.cg * chunks * (KCH * G::WQ) + lane;
 #pragma unroll
-        for (int j = 0; j < PJ; ++j) {
-            const int ins = wave + G::WAVES * j;
-            const int e = (ins * 64 + lane) * 4;
-            const int c = e / G::CS, rem = e - c * G::CS, r = rem / G::STR, xx = rem - r * G::STR;
-            const int gy = t.y0 - 1 + r, gx = t.x0 - 4 + xx;           // gx % 4 == 0: the group is inside the row or outside
-            const bool ok = c < kKC && r < G::PH && xx < G::PW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            pl.src[j] = ok ? xin + (size_t)c * plane + (size_t)gy * a.W + gx : a.zero;
-            pl.step[j] = ok ? (size_t)kKC * plane : 0;
+        for (int j = 0; j < G::SLOTS; ++j) {
+            const int i = tid + j * G::THREADS;
+            const int y = i / G::PW, xq = i - y * G::PW;
+            const int gy = t.y0 - 1 + y, gx = t.x0 - 1 + xq;
+            pl.off[j] = (i < G::PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? gy * a.W + gx : -1;
         }
-        pl.wsrc = a.wt + (size_t)t.cg * chunks * G::WQ + lane;
         return pl;
     };
-    // transfer k (patch transfers first, then weight transfers) of chunk `step` of this workgroup (S slot step % 2, W slot
-    // step % 3); every lane of every transfer is active (the staging image is padded to whole 1 KiB transfers), the LDS
-    // addresses are scalar
-    constexpr int NPART = PJ + WJ;
-    auto issue_part = [&](const Plan &pl, int step, int k) {
-        float *dst = lds + G::S_OFF + (step & 1) * G::PLDS, *wdst = lds + G::W_OFF + (step % 3) * (G::WQ * 4);
-        if (k < PJ) {
-            const int ins = wave + G::WAVES * k;
-            if (ins < G::PINSTR) __builtin_amdgcn_global_load_lds((gptr_t)pl.src[k < PJ ? k : 0], (lptr_t)(dst + ins * 256), 16, 0, 0);
-        } else {
-            const int ins = wave + G::WAVES * (k - PJ);
-            if (ins < G::WINSTR) __builtin_amdgcn_global_load_lds((gptr_t)(pl.wsrc + ins * 64), (lptr_t)(wdst + ins * 256), 16, 0, 0);
+    // chunk c of the tile: the 8 input channels of this thread's pixel slots -> registers (plain coalesced loads: consecutive
+    // lanes = consecutive pixels of a patch row; clamped address + zero select, no divergent branch around the loads)
+    auto load_patch = [&](const Plan &pl, int c, float (&v)[G::SLOTS][8 * KCH]) {
+        const float *src = pl.base + (size_t)c * (kKC * KCH) * plane;
+#pragma unroll
+        for (int j = 0; j < G::SLOTS; ++j) {
+            const int o = pl.off[j] < 0 ? 0 : pl.off[j];
+#pragma unroll
+            for (int k = 0; k < 8 * KCH; ++k) v[j][k] = src[(size_t)k * plane + o];
         }
     };
-    auto advance = [&](Plan &pl) {                 // to the tile's next chunk
+    // ... split into bf16 terms and written as [term][pixel slot][8 cin] into split-patch buffer `slot`
+    auto store_patch = [&](const Plan &pl, int slot, float (&v)[G::SLOTS][8 * KCH]) {
+        uint4 *bt = reinterpret_cast<uint4 *>(lds + G::B_OFF + slot * G::BSZ);
 #pragma unroll
-        for (int j = 0; j < PJ; ++j) pl.src[j] += pl.step[j];
-        pl.wsrc += G::WQ;
+        for (int j = 0; j < G::SLOTS; ++j) {
+            const int i = tid + j * G::THREADS;
+            if (i < G::PIX) {
+#pragma unroll
+                for (int h = 0; h < KCH; ++h) {
+                    float u[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) u[k] = pl.off[j] < 0 ? 0.f : v[j][8 * h + k];
+                    bf16x8 o[TERMS];
+                    split_pixel<TERMS>(u, o);
+#pragma unroll
+                    for (int t = 0; t < TERMS; ++t) bt[(h * TERMS + t) * G::PIX + i] = __builtin_bit_cast(uint4, o[t]);
+                }
+            }
+        }
+    };
+    // LDS-DMA of weight chunk c of the tile into weight buffer `slot` (scalar LDS addresses, every lane active)
+    constexpr int WJ = (KCH * G::WINSTR + G::WAVES - 1) / G::WAVES;
+    auto issue_weights = [&](const Plan &pl, int c, int slot) {
+        float *wdst = lds + G::W_OFF + slot * G::WSZ;
+        const uint4 *wsrc = pl.wsrc + (size_t)c * (KCH * G::WQ);
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int ins = wave + G::WAVES * j;
+            if (ins < KCH * G::WINSTR) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ins * 64), (lptr_t)(wdst + ins * 256), 16, 0, 0);
+        }
     };
 
+    // Work = total_tiles x chunks (tile, chunk) steps.  SPLIT (stream-K): cut into gridDim.x equal contiguous ranges, so every
+    // persistent workgroup runs the same number of MFMAs (+-1 chunk) whatever the tile count -- with whole tiles per workgroup,
+    // 715 tiles on 512 resident workgroups are two rounds at 70 % fill.  A range may start in the middle of a tile (then this
+    // workgroup computes the tile's last chunks from zero accumulators and publishes them) and may end in the middle of a tile
+    // (then it owns that tile: bias / residual start, its own first chunks, plus the partial the next workgroup published at the
+    // very beginning of its range).  Ranges are at least one tile long, so a tile has at most two contributors and the split --
+    // hence the summation order -- is a pure function of the shape: results stay deterministic.  !SPLIT: whole tiles g, g + n, ...
     const int g = blockIdx.x, n_wg = gridDim.x;
-    const int my_tiles = (a.total_tiles - g + n_wg - 1) / n_wg;        // tiles g, g + n_wg, ...
-    if (my_tiles <= 0) return;
+    const long long S = (long long)a.total_tiles * chunks;
+    const int s0 = SPLIT ? (int)(S * g / n_wg) : 0;
+    const int n_local = SPLIT ? (int)(S * (g + 1) / n_wg) - s0 : ((a.total_tiles - g + n_wg - 1) / n_wg) * chunks;
+    auto global_step = [&](int l) { return SPLIT ? s0 + l : (g + (l / chunks) * n_wg) * chunks + l % chunks; };
+    if (n_local <= 0) return;
 #ifdef EMU_TRACE
     if (tid == 0) a.trace[2 * 16 * 64 * 5 + 2 * g] = wall_clock64();   // 100 MHz wall clock: start / end of every workgroup
 #endif
-    const int n_local = my_tiles * chunks;
 
-    // Chunk-level software pipeline (one barrier per chunk).  In iteration L a wavefront
-    //   * issues the LDS-DMA of chunk L + 2          (staging slot L % 2, weight slot (L + 2) % 3),
-    //   * splits the staged fp32 patch of chunk L + 1 into bf16 operands        (split-patch slot (L + 1) % 2),
-    //   * runs the MFMA steps of chunk L             (split-patch slot L % 2, weight slot L % 3),
-    // all in one instruction stream, so the matrix pipe works while the VALU splits and the DMA lands.  The barrier at the top of
-    // iteration L + 1 (with vmcnt / lgkmcnt 0) closes all three: every slot written in iteration L had its last reader in
-    // iteration L - 1.
-    int it = 0, ic = 0, li = 0;                    // issue cursor: tile ordinal, chunk, chunk number of this workgroup
-    Tile itile = decode(g);
-    Plan iplan = make_plan(itile);
-    // take the next chunk to issue off the cursor: its plan and chunk number are returned, the cursor moves on
-    auto take_next = [&](Plan &pl, int &step) {
-        if (it >= my_tiles) return false;
-        pl = iplan;
-        step = li++;
-        if (++ic == chunks) {
-            ic = 0;
-            if (++it < my_tiles) {
-                itile = decode(g + it * n_wg);
-                iplan = make_plan(itile);
-            }
-        } else {
-            advance(iplan);
-        }
-        return true;
-    };
-    // the pixel slot this lane splits (slots beyond the patch: none)
-    const bool cv_on = tid < G::PIX || G::PIX > G::THREADS;
-    auto cv_load = [&](int step, int i, float (&v)[8]) {
-        const float *st = lds + G::S_OFF + (step & 1) * G::PLDS;
-        const int y = i / G::PW, xq = i - y * G::PW;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = st[c * G::CS + y * G::STR + xq];
-    };
-    auto cv_store = [&](int step, int i, const bf16x8 (&o)[TERMS]) {
-        uint4 *bt = reinterpret_cast<uint4 *>(lds + G::B_OFF + (step & 1) * G::BSZ);
-#pragma unroll
-        for (int t = 0; t < TERMS; ++t) bt[t * G::PIX + i] = __builtin_bit_cast(uint4, o[t]);
-    };
-    auto convert_all = [&](int step) {             // whole split pass (prologue, and patches larger than the workgroup)
-        for (int i = tid; i < G::PIX; i += G::THREADS) {
-            float v[8];
-            bf16x8 o[TERMS];
-            cv_load(step, i, v);
-            split_pixel<TERMS>(v, o);
-            cv_store(step, i, o);
-        }
-    };
-
-    for (int k = 0; k < 2; ++k) {
-        Plan pl;
-        int step;
-        if (take_next(pl, step)) {
-#pragma unroll
-            for (int q = 0; q < NPART; ++q) issue_part(pl, step, q);
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    convert_all(0);
+    // Chunk-level software pipeline, one barrier per chunk, everything one chunk ahead.  In iteration L a wavefront
+    //   * issues the LDS-DMA of the split weights of chunk L + 1 (weight buffer (L + 1) % 2) and loads the fp32 halo pixels of
+    //     chunk L + 1 into registers,
+    //   * runs the MFMA steps of chunk L out of split-patch buffer L % 2 and weight buffer L % 2,
+    //   * then splits the loaded pixels ONCE (its 8 channels -> TERMS operands of 8 bf16) into split-patch buffer (L + 1) % 2.
+    // The barrier at the top of iteration L + 1 (vmcnt / lgkmcnt 0) closes all three; what iteration L writes was last read in
+    // iteration L - 1.  The MFMA stream carries no VALU work: a B operand is one ds_read_b128.
+    int tile = global_step(0) / chunks;
+    Tile cur = decode(tile);
+    Plan plan = make_plan(cur);
+    float pv[G::SLOTS][8 * KCH];
+    load_patch(plan, global_step(0) - tile * chunks, pv);
+    issue_weights(plan, global_step(0) - tile * chunks, 0);
+    store_patch(plan, 0, pv);
     if (wave >= G::WAVES / 2) __builtin_amdgcn_s_setprio(1);           // the later-dispatched half loses every arbitration otherwise
     int L = 0;
-    Tile cur = decode(g);
-    for (int ti = 0; ti < my_tiles; ++ti) {
+    while (L < n_local) {
+        const int gs0 = global_step(L);
+        const int c_begin = gs0 - tile * chunks;
+        const int c_end = (n_local - L) < (chunks - c_begin) ? c_begin + (n_local - L) : chunks;
+        const bool head = c_begin == 0, complete = c_end == chunks;
         const int gy = cur.y0 + py, gx = cur.x0 + px;
         const bool live = gy < a.H && gx < a.W;
         const size_t obase = ((size_t)cur.n * a.Cout + cur.cg * kCoutTile + cb + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
         const float *bias = a.bias + cur.cg * kCoutTile + cb + 4 * half;
         floatx16 acc[G::NCO];
-        float res[16 * G::NCO];                    // residual, fetched at the start of the tile and added in the epilogue
+        if (SPLIT && !head) {
 #pragma unroll
-        for (int q = 0; q < 16 * G::NCO; ++q) {
-            const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
-            acc[q / 16][q % 16] = bias[c];
-            res[q] = a.residual ? a.residual[obase + (size_t)c * plane] : 0.f;
+            for (int q = 0; q < G::NCO; ++q) acc[q] = floatx16{0};
+        } else if (a.residual) {
+#pragma unroll
+            for (int q = 0; q < 16 * G::NCO; ++q) {
+                const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
+                acc[q / 16][q % 16] = a.residual[obase + (size_t)c * plane] + bias[c];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16 * G::NCO; ++q) acc[q / 16][q % 16] = bias[(q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4)];
         }
-        for (int chunk = 0; chunk < chunks; ++chunk, ++L) {
+        Tile next = cur;
+        Plan nplan = plan;
+        int ntile = tile;
+        for (int chunk = c_begin; chunk < c_end; ++chunk, ++L) {
             EMU_STAMP(0);
             __builtin_amdgcn_s_waitcnt(0);
             EMU_STAMP(1);
             __syncthreads();
             EMU_STAMP(2);
-            Plan dpl;
-            int dstep = 0;
-            // LDS-DMA of chunk L + 2, all transfers up front (spread between the MFMA steps they were measured 10 % slower: each
-            // transfer stalls the wavefront's MFMA stream)
-            if (take_next(dpl, dstep)) {
-#pragma unroll
-                for (int q = 0; q < NPART; ++q) issue_part(dpl, dstep, q);
+            const bool more = L + 1 < n_local;
+            if (more) {
+                const int ns = global_step(L + 1);
+                const int nt = ns / chunks;
+                if (nt != tile) {                                      // the next chunk opens this workgroup's next tile
+                    ntile = nt;
+                    next = decode(nt);
+                    nplan = make_plan(next);
+                }
+                issue_weights(nplan, ns - nt * chunks, (L + 1) & 1);
+                load_patch(nplan, ns - nt * chunks, pv);
             }
             EMU_STAMP(3);
-            const bool more = L + 1 < n_local;
-            float cv[8];
-            const bool cv_inline = G::PIX <= G::THREADS && more && cv_on;
-            if (cv_inline) cv_load(L + 1, tid, cv);
             const uint4 *bq = reinterpret_cast<const uint4 *>(lds + G::B_OFF + (L & 1) * G::BSZ);
-            const uint4 *wq = reinterpret_cast<const uint4 *>(lds + G::W_OFF + (L % 3) * (G::WQ * 4)) + wlane;
-            auto load_b = [&](int s, bf16x8 (&b)[TERMS]) {
+            const uint4 *wq = reinterpret_cast<const uint4 *>(lds + G::W_OFF + (L & 1) * G::WSZ) + wlane;
+            constexpr int NS = kSteps * KCH;           // MFMA steps of this interval: step = (8-channel chunk h, tap pair s)
+            auto load_b = [&](int st, bf16x8 (&b)[TERMS]) {
+                const int h = st / kSteps, s = st % kSteps;
 #pragma unroll
                 for (int t = 0; t < TERMS; ++t) {
-                    uint4 v = bq[t * G::PIX + boff[s]];
+                    uint4 v = bq[(h * TERMS + t) * G::PIX + boff[s]];
                     if (s == kSteps - 1 && half) v = uint4{0, 0, 0, 0};       // the tenth tap does not exist
                     b[t] = __builtin_bit_cast(bf16x8, v);
                 }
             };
-            auto load_w = [&](int s, bf16x8 (&w)[G::NCO][TERMS]) {
+            auto load_w = [&](int st, bf16x8 (&w)[G::NCO][TERMS]) {
+                const int h = st / kSteps, s = st % kSteps;
 #pragma unroll
                 for (int q = 0; q < G::NCO; ++q)
 #pragma unroll
-                    for (int t = 0; t < TERMS; ++t) w[q][t] = __builtin_bit_cast(bf16x8, wq[((s * TERMS + t) * 2) * kCoutTile + q * 32]);
+                    for (int t = 0; t < TERMS; ++t) w[q][t] = __builtin_bit_cast(bf16x8, wq[h * G::WQ + ((s * TERMS + t) * 2) * kCoutTile + q * 32]);
             };
-            bf16x8 bc[TERMS], wc[G::NCO][TERMS], cvo[TERMS];
+            bf16x8 bc[TERMS], wc[G::NCO][TERMS];
             load_b(0, bc);
             load_w(0, wc);
 #pragma unroll
-            for (int s = 0; s < kSteps; ++s) {
+            for (int st = 0; st < NS; ++st) {
                 bf16x8 wn[G::NCO][TERMS], bn[TERMS];
                 constexpr int NT = TERMS == 3 ? 6 : 3;
                 constexpr int wi[6] = {0, 1, TERMS == 3 ? 2 : 0, 0, 1, 0};                       // weight term of product i
                 constexpr int bi[6] = {TERMS == 3 ? 2 : 1, TERMS == 3 ? 1 : 0, 0, 1, 0, 0};      // pixel term of product i
-                if (s + 1 < kSteps) {                  // operands of the next step are in flight while this step's MFMAs issue
-                    load_b(s + 1, bn);
-                    load_w(s + 1, wn);
+                if (st + 1 < NS) {                     // operands of the next step are in flight while this step's MFMAs issue
+                    load_b(st + 1, bn);
+                    load_w(st + 1, wn);
                 }
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
                     for (int q = 0; q < G::NCO; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[q][wi[i]], bc[bi[i]], acc[q], 0, 0, 0);
-                if (s == 1 && cv_inline) split_pixel<TERMS>(cv, cvo);          // VALU work of the split beside the MFMAs
-                if (s == 3 && cv_inline) cv_store(L + 1, tid, cvo);
-                if (s + 1 < kSteps) {
+                if (st + 1 < NS) {
 #pragma unroll
                     for (int t = 0; t < TERMS; ++t) {
                         bc[t] = bn[t];
@@ -312,69 +307,141 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) void conv3x3_emu_k
                     }
                 }
             }
-            if (G::PIX > G::THREADS && more) convert_all(L + 1);
+            if (more) store_patch(nplan, (L + 1) & 1, pv);
             EMU_STAMP(4);
         }
-        if (live) {
+        // The hand-over of a split tile uses agent-scope *write-through* stores / L2-bypassing loads (relaxed atomics) and no
+        // fences (an agent-scope fence writes back and invalidates the XCD's whole L2; see conv3x3.hip).
+        // slot layout [wave][q][lane]: one base pointer per 16 values + immediate offsets (q x 256 B), so the 32 addresses cost
+        // four registers, not sixty-four
+        if (SPLIT && !head) {              // contributor: publish the partial sums of the tile's last chunks (slot g)
+            float *slot = a.partial + (size_t)g * (16 * G::NCO * G::THREADS) + (size_t)wave * (16 * G::NCO * 64) + lane;
 #pragma unroll
-            for (int q = 0; q < 16 * G::NCO; ++q) {
-                const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
-                const float v = acc[q / 16][q % 16] + res[q];
-                a.y[obase + (size_t)c * plane] = a.relu ? fmaxf(v, 0.f) : v;
+            for (int q = 0; q < 16 * G::NCO; ++q)
+                __hip_atomic_store(slot + (q / 16) * 1024 + (q % 16) * 64, acc[q / 16][q % 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);     // my write-throughs are acknowledged ...
+            __syncthreads();                   // ... and so are everyone's
+            if (tid == 0) __hip_atomic_store(a.flags + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (SPLIT && !complete) {      // owner of a split tile: add what workgroup g + 1 published
+                if (tid == 0)
+                    while (__hip_atomic_load(a.flags + g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+                __syncthreads();
+                const float *slot = a.partial + (size_t)(g + 1) * (16 * G::NCO * G::THREADS) + (size_t)wave * (16 * G::NCO * 64) + lane;
+#pragma unroll
+                for (int q = 0; q < 16 * G::NCO; ++q)
+                    acc[q / 16][q % 16] += __hip_atomic_load(slot + (q / 16) * 1024 + (q % 16) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < 16 * G::NCO; ++q) {
+                    const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
+                    const float v = acc[q / 16][q % 16];
+                    a.y[obase + (size_t)c * plane] = a.relu ? fmaxf(v, 0.f) : v;
+                }
             }
         }
-        if (ti + 1 < my_tiles) cur = decode(g + (ti + 1) * n_wg);
+        cur = next;
+        plan = nplan;
+        tile = ntile;
     }
 #ifdef EMU_TRACE
     if (tid == 0) a.trace[2 * 16 * 64 * 5 + 2 * g + 1] = wall_clock64();
 #endif
 }
 
-template <int BH, int BW, int NPB, int TERMS>
-int launch(const EmuArgs &a0, hipStream_t s) {
-    using G = Geo<BH, BW, NPB, TERMS>;
+struct Launch {                    // what the host needs to know about one (shape, geometry) pair
+    int grid;
+    size_t flag_bytes, ws_bytes;
+    bool split;
+};
+
+// stream-K pays when the whole-tile schedule leaves the last round badly filled; a tile must have at least two chunks to split
+inline bool want_split(int total_tiles, int slots, int chunks) {
+    static const int force = getenv("COALIGN_EMU_SPLIT") ? atoi(getenv("COALIGN_EMU_SPLIT")) : -1;     // experiments only
+    if (chunks < 2) return false;
+    if (force >= 0) return force != 0;
+    // measured (tools/bench_conv_emu_geo.py with COALIGN_EMU_SPLIT=0|1): as for the fp32 kernel, splitting pays on long tiles
+    // (>= 32 chunks: the shrink header, 4-11 %) whose last round is under-filled; short tiles would nearly all be split and the
+    // extra tile starts (residual fetch, epilogue) cost more than the imbalance
+    if (chunks < 32 || total_tiles <= slots) return false;
+    const int rounds = (total_tiles + slots - 1) / slots;
+    return total_tiles * 10 < rounds * slots * 9;
+}
+
+template <int BH, int BW, int NPB, int TERMS, int KCH>
+int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream_t s, Launch *query) {
+    using G = Geo<BH, BW, NPB, TERMS, KCH>;
     static int resident = 0, cus = 0;
     if (!resident) {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
         cus = prop.multiProcessorCount;
-        const int rc = coalign::hip_call(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS>),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
-        if (rc != COALIGN_OK) {                    // geometry does not fit this device's LDS: report, leave no sticky error behind
-            (void)hipGetLastError();
-            return rc;
+        for (int sp = 0; sp < 2; ++sp) {
+            const void *fn = sp ? reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true>)
+                                : reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false>);
+            const int rc = coalign::hip_call(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+            if (rc != COALIGN_OK) {                // geometry does not fit this device's LDS: report, leave no sticky error behind
+                (void)hipGetLastError();
+                return rc;
+            }
         }
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_emu_kernel<BH, BW, NPB, TERMS>, G::THREADS, G::LDS_BYTES) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true>, G::THREADS, G::LDS_BYTES) != hipSuccess || n < 1) n = 1;
         resident = n;
     }
     EmuArgs a = a0;
     a.tiles_x = (a.W + G::TW - 1) / G::TW;
     a.tiles_per_img = a.tiles_x * ((a.H + G::TH - 1) / G::TH);
     a.total_tiles = a.tiles_per_img * (a.Cout / kCoutTile) * a.N;
-    const int grid = a.total_tiles < cus * resident ? a.total_tiles : cus * resident;
-    hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+    const int slots = cus * resident, chunks = a.Cin / (kKC * KCH);
+    Launch l;
+    l.split = want_split(a.total_tiles, slots, chunks);
+    l.grid = a.total_tiles < slots ? a.total_tiles : slots;
+    if (l.split && a.total_tiles < slots) {
+        // fewer tiles than slots: an exact two-way split of every tile (ranges of chunks / 2 steps: range 2t opens tile t,
+        // range 2t + 1 finishes it) when that fits; otherwise whole tiles
+        if (2 * a.total_tiles <= slots && chunks % 2 == 0) l.grid = 2 * a.total_tiles;
+        else l.split = false;
+    }
+    l.flag_bytes = coalign::align_up((size_t)(l.grid + 1) * sizeof(int), 256);
+    l.ws_bytes = l.flag_bytes + (size_t)(l.grid + 1) * 16 * G::NCO * G::THREADS * sizeof(float);
+    if (query) {
+        *query = l;
+        return COALIGN_OK;
+    }
+    if (l.split) {
+        if (!workspace) return COALIGN_ERR_NULL_POINTER;
+        if (workspace_bytes < l.ws_bytes) return COALIGN_ERR_WORKSPACE;
+        a.flags = static_cast<int *>(workspace);
+        a.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + l.flag_bytes);
+        const int rc = coalign::hip_call(hipMemsetAsync(workspace, 0, l.flag_bytes, s));
+        if (rc != COALIGN_OK) return rc;
+        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+    } else {
+        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+    }
     return COALIGN_OK;
 }
 
 template <int TERMS>
-int dispatch(const EmuArgs &a, hipStream_t s) {
+int dispatch(const EmuArgs &a, void *ws, size_t ws_bytes, hipStream_t s, Launch *query) {
     static const int force = getenv("COALIGN_EMU_GEO") ? atoi(getenv("COALIGN_EMU_GEO")) : -1;      // experiments only
-    // measured on the backbone shapes (tools/bench_conv_emu_geo.py): 8 row segments of 32 pixels per workgroup win or tie on every
-    // map size -- the weight image is shared by 8 wavefronts and both accumulator tiles amortise the operand split; the 3-way split
-    // with long K prefers 4 segments (its 53 KB buffers leave room for two such workgroups per CU)
-    // measured (tools/bench_conv_emu_geo.py): 12 row segments per workgroup (3 wavefronts per SIMD) on the large maps when the
-    // LDS holds them (2-way split), 8 otherwise
-    int geo = (TERMS == 2 && a.H >= 64) ? 5 : 0;
+    // geometry code = 10 * (wavefronts per workgroup) + (8-channel chunks per barrier)
+    const bool even = (a.Cin / kKC) % 2 == 0;
+    // measured: 8 wavefronts (two workgroups per CU with the 2-way split) everywhere, except the 3-way split on the large maps,
+    // whose single resident workgroup does better with 12
+    int geo = (TERMS == 3 && a.H >= 64) ? 121 : 81;
     if (force >= 0) geo = force;
+    if (!even && geo % 10 == 2) geo -= 1;
     switch (geo) {
-        case 0: return launch<1, 32, 8, TERMS>(a, s);
-        case 1: return launch<1, 32, 4, TERMS>(a, s);
-        case 2: return launch<2, 16, 4, TERMS>(a, s);
-        case 3: return launch<2, 16, 2, TERMS>(a, s);
-        case 5: return launch<1, 32, 12, TERMS>(a, s);
-        default: return launch<1, 32, 2, TERMS>(a, s);
+        case 81: return launch<1, 32, 8, TERMS, 1>(a, ws, ws_bytes, s, query);
+        case 82: return launch<1, 32, 8, TERMS, 2>(a, ws, ws_bytes, s, query);
+        case 121: return launch<1, 32, 12, TERMS, 1>(a, ws, ws_bytes, s, query);
+        case 122: return launch<1, 32, 12, TERMS, 2>(a, ws, ws_bytes, s, query);
+        case 41: return launch<1, 32, 4, TERMS, 1>(a, ws, ws_bytes, s, query);
+        default: return COALIGN_ERR_UNSUPPORTED;
     }
 }
 
@@ -390,23 +457,35 @@ extern "C" size_t coalign_conv3x3_emu_weight_bytes(int Cin, int Cout, int terms)
     return (size_t)(Cout / kCoutTile) * (Cin / kKC) * kSteps * terms * 2 * kCoutTile * 16 + 16;      // + one zero group
 }
 
+static int check_emu_args(int N, int Cin, int Cout, int H, int W, int terms) {
+    if (N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return COALIGN_ERR_BAD_SHAPE;
+    if (Cin % kKC || Cout % kCoutTile || (terms != 2 && terms != 3)) return COALIGN_ERR_UNSUPPORTED;
+    if ((int64_t)N * Cout * H * W > (int64_t)1 << 40 || (int64_t)Cin * H * W > (int64_t)1 << 30) return COALIGN_ERR_UNSUPPORTED;
+    return COALIGN_OK;
+}
+
+extern "C" size_t coalign_conv3x3_emu_workspace_bytes(int N, int Cin, int Cout, int H, int W, int terms) {
+    if (check_emu_args(N, Cin, Cout, H, W, terms) != COALIGN_OK || N == 0) return 0;
+    EmuArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, N, Cin, Cout, H, W, 0, 0, 0, 0, nullptr, nullptr};
+    Launch l{};
+    const int rc = terms == 3 ? dispatch<3>(a, nullptr, 0, nullptr, &l) : dispatch<2>(a, nullptr, 0, nullptr, &l);
+    return rc == COALIGN_OK && l.split ? l.ws_bytes : 0;
+}
+
 extern "C" int coalign_conv3x3_emu_bias_act(const float *x, const void *w_split, const float *bias, const float *residual, float *y,
-                                            int N, int Cin, int Cout, int H, int W, int relu, int terms, void *stream) {
+                                            int N, int Cin, int Cout, int H, int W, int relu, int terms, void *workspace,
+                                            size_t workspace_bytes, void *stream) {
     using namespace coalign;
     if (!x || !w_split || !y || !bias) return COALIGN_ERR_NULL_POINTER;
-    if (N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return COALIGN_ERR_BAD_SHAPE;
-    if (Cin % kKC || Cout % kCoutTile || W % 4 || (terms != 2 && terms != 3) ||
-        ((reinterpret_cast<uintptr_t>(w_split) | reinterpret_cast<uintptr_t>(x)) & 15))
-        return COALIGN_ERR_UNSUPPORTED;
-    if ((int64_t)N * Cout * H * W > (int64_t)1 << 40) return COALIGN_ERR_UNSUPPORTED;
+    int rc = check_emu_args(N, Cin, Cout, H, W, terms);
+    if (rc != COALIGN_OK) return rc;
+    if (reinterpret_cast<uintptr_t>(w_split) & 15) return COALIGN_ERR_UNSUPPORTED;
     if (N == 0) return COALIGN_OK;
-    EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, nullptr, y, N, Cin, Cout, H, W, relu, 0, 0, 0};
+    EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, nullptr, nullptr};
 #ifdef EMU_TRACE
     a.trace = g_emu_trace;
 #endif
-    // the 16 zero bytes appended to the packed weights: source of every out-of-image / padding group of the halo patch
-    a.zero = reinterpret_cast<const float *>(static_cast<const char *>(w_split) + coalign_conv3x3_emu_weight_bytes(Cin, Cout, terms) - 16);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rc = terms == 3 ? dispatch<3>(a, s) : dispatch<2>(a, s);
+    rc = terms == 3 ? dispatch<3>(a, workspace, workspace_bytes, s, nullptr) : dispatch<2>(a, workspace, workspace_bytes, s, nullptr);
     return rc != COALIGN_OK ? rc : check_launch();
 }

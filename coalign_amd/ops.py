@@ -385,9 +385,17 @@ def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Ten
     res = None if residual is None else _f32c(residual)
     if res is not None and res.shape != y.shape:
         raise ValueError("residual shape mismatch")
+    ws_bytes = L.coalign_conv3x3_emu_workspace_bytes(N, Cin, cout, H, W, terms)
+    ws = None
+    if ws_bytes:
+        key = (xc.device, torch.cuda.current_stream(xc.device).cuda_stream, "emu")
+        ws = _CONV_WS.get(key)
+        if ws is None or ws.numel() < ws_bytes:        # one workspace per (device, stream): launches on a stream are ordered
+            ws = _CONV_WS[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=xc.device)
     with _Timed("conv3x3_emu_bias_act"):
         hip.check(L.coalign_conv3x3_emu_bias_act(_ptr(xc), _ptr(w_split), _ptr(_f32c(bias)), _ptr(res), _ptr(y),
-                                                 N, Cin, cout, H, W, int(relu), terms, _stream()), "coalign_conv3x3_emu_bias_act")
+                                                 N, Cin, cout, H, W, int(relu), terms, _ptr(ws), 0 if ws is None else ws.numel(), _stream()),
+                  "coalign_conv3x3_emu_bias_act")
     return y
 
 

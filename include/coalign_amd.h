@@ -258,12 +258,17 @@ int coalign_conv3x3_bias_act(const float *x, const float *w_packed, const float 
  * w_split: coalign_conv3x3_emu_weight_bytes(Cin, Cout, terms) bytes, 16-byte aligned:
  *   [Cout / 64][Cin / 8][5 steps][terms][2 k-groups][64 cout][8 cin] bf16 with tap = 2 * step + k-group (the tenth tap zero),
  *   term 0 = bf16(w), term 1 = bf16(w - term 0), term 2 = bf16(w - term 0 - term 1), followed by 16 zero bytes.
- * Other arguments, limits and the fused epilogue as in (9); no workspace.  Not used by the default detector path (which keeps
- * native fp32 products); selected with COALIGN_CONV_EMU (coalign_amd/backbone.py).
+ * Cin % 8 == 0, Cout % 64 == 0, any H, W (no alignment requirement on x).  bias is required; residual may be NULL.
+ * workspace: coalign_conv3x3_emu_workspace_bytes(...) bytes of device scratch (0 = none needed for that shape) for the stream-K
+ * hand-over of tiles split between two workgroups; one workspace per stream, not shared between concurrent launches.  The split is a
+ * pure function of the shape (deterministic).
+ * Not used by the default detector path (which keeps native fp32 products); selected with COALIGN_CONV_EMU (coalign_amd/backbone.py).
  */
 size_t coalign_conv3x3_emu_weight_bytes(int Cin, int Cout, int terms);
+size_t coalign_conv3x3_emu_workspace_bytes(int N, int Cin, int Cout, int H, int W, int terms);
 int coalign_conv3x3_emu_bias_act(const float *x, const void *w_split, const float *bias, const float *residual, float *y,
-                                 int N, int Cin, int Cout, int H, int W, int relu, int terms, void *stream);
+                                 int N, int Cin, int Cout, int H, int W, int relu, int terms, void *workspace, size_t workspace_bytes,
+                                 void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * (10) Pointwise layers of the BEV backbone as one GEMM launch each, bias (+ ReLU) fused, NCHW float32:

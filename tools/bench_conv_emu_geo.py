@@ -27,11 +27,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(out))
 else:
     rows = {}
-    for geo in [int(v) for v in os.environ.get('GEOS', '0,1,5,6').split(',')]:
+    for geo in [int(v) for v in os.environ.get('GEOS', '81,82,121,122').split(',')]:
         env = dict(os.environ, COALIGN_EMU_GEO=str(geo))
         r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True, timeout=200)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         rows[geo] = json.loads(line[0]) if line else r.stderr[-300:]
-    names = {0: "1x32x8", 1: "1x32x4", 2: "2x16x4", 3: "2x16x2", 4: "1x32x2", 5: "1x32x12", 6: "1x32x16"}
+    names = {g: f"{g // 10}w/k{8 * (g % 10)}" for g in rows}
     for k in next(r for r in rows.values() if isinstance(r, dict)):
         print(k, {names[g]: (rows[g][k] if isinstance(rows[g], dict) else "fail") for g in rows})

@@ -17,16 +17,19 @@ from coalign_amd import ops
 terms = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 N, Ci, Co, H, W = [int(v) for v in sys.argv[2:7]] if len(sys.argv) > 6 else (5, 64, 64, 100, 352)
 L = ctypes.CDLL(lib)
-L.coalign_conv3x3_emu_bias_act.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+L.coalign_conv3x3_emu_bias_act.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+L.coalign_conv3x3_emu_workspace_bytes.restype = ctypes.c_size_t
+L.coalign_conv3x3_emu_workspace_bytes.argtypes = [ctypes.c_int] * 6
 x = torch.randn(N, Ci, H, W, device="cuda"); w = torch.randn(Co, Ci, 3, 3, device="cuda") / (Ci * 9) ** 0.5
 b = torch.randn(Co, device="cuda"); y = torch.empty(N, Co, H, W, device="cuda")
 ws = ops.pack_conv3x3_emu_weight(w, terms)
 waves = 16
 tr = torch.zeros(2 * waves * 64 * 5 + 2 * 4096, dtype=torch.int64, device="cuda")
 L.coalign_conv3x3_emu_set_trace(ctypes.c_void_p(tr.data_ptr()))
+scratch = torch.empty(max(1, L.coalign_conv3x3_emu_workspace_bytes(N, Ci, Co, H, W, terms)), dtype=torch.uint8, device="cuda")
 for _ in range(3):
     tr.zero_()
-    rc = L.coalign_conv3x3_emu_bias_act(x.data_ptr(), ws.data_ptr(), b.data_ptr(), None, y.data_ptr(), N, Ci, Co, H, W, 1, terms, None)
+    rc = L.coalign_conv3x3_emu_bias_act(x.data_ptr(), ws.data_ptr(), b.data_ptr(), None, y.data_ptr(), N, Ci, Co, H, W, 1, terms, scratch.data_ptr(), scratch.numel(), None)
     torch.cuda.synchronize()
 assert rc == 0
 nw = int(os.environ.get("WAVES", 8))
