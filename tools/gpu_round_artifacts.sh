@@ -28,7 +28,7 @@ for f in glob.glob(out+"/pmc*/**/*counter_collection.csv", recursive=True):
         k=r["Kernel_Name"]
         if "anonymous" not in k: continue
         short=k.split("(anonymous namespace)::")[1].split("(")[0]
-        if short.startswith("conv3x3_emu_kernel"): short = "conv3x3_emu_kernel_bf16x" + short.rstrip(">").split(",")[-1].strip()
+        if short.startswith("conv3x3_emu_kernel"): short = "conv3x3_emu_kernel_bf16x" + short.split("<")[1].split(",")[3].strip()
         agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res={k:{c:sum(v)/len(v) for c,v in d.items()} for k,d in agg.items()}
 for k,d in res.items():
