@@ -214,7 +214,7 @@ def main():
         backbone_mod.CONV_EMU_TERMS = 0
         opt_in["note"] = ("COALIGN_CONV_EMU=3|2: every 3x3 convolution through coalign_conv3x3_emu_bias_act -- fp32 operands split "
                           "error-free into 3 (2) bf16 terms, 6 (3) cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; "
-                          "conv error vs fp64 1.1e-6..2.6e-6 (x3) / 2.7e-6..3.7e-6 (x2) of the output scale against 1.8e-6..3.6e-6 for "
+                          "conv error vs fp64 1.1e-6..2.4e-6 (x3) / 2.7e-6..3.6e-6 (x2) of the output scale against 1.8e-6..3.6e-6 for "
                           "the native fp32-MFMA kernel; end-to-end head outputs within 5.7e-6 (x3) / 3.8e-5 (x2) of eager PyTorch "
                           "(north-star tolerance 1e-3).  Not the default: `value` keeps native fp32 products.")
     if world > 1:
