@@ -74,10 +74,10 @@ class Conv3x3Pack:
 def conv3x3_fused(x: torch.Tensor, pack: Optional["Conv3x3Pack"], weight: torch.Tensor, bias: torch.Tensor,
                   residual: Optional[torch.Tensor], stride=1) -> torch.Tensor:
     """relu(conv3x3(x) + bias (+ residual)) through the kernel the policy selects."""
-    if pack is not None and x.shape[3] % 4 == 0:
-        if CONV_EMU_TERMS in (2, 3):
+    if pack is not None:
+        if CONV_EMU_TERMS in (2, 3):                                   # any map size
             return ops.conv3x3_emu_bias_act(x, pack.emu(CONV_EMU_TERMS), bias, pack.cout, residual, True, CONV_EMU_TERMS)
-        if hip_conv3x3_wins(x, pack.cin, pack.cout):
+        if x.shape[3] % 4 == 0 and hip_conv3x3_wins(x, pack.cin, pack.cout):
             return ops.conv3x3_bias_act(x, pack.f32, bias, residual, True)
     return ops.bias_act_(F.conv2d(x, weight, None, stride, 1), bias, residual, True)
 

@@ -761,7 +761,7 @@ def test_full_frame_vs_stock_pytorch_ops_on_the_gpu(emu_terms, tol):
 
 @pytest.mark.parametrize("shape", [(2, 64, 64, 100, 352), (3, 128, 128, 50, 176), (2, 256, 256, 25, 88), (1, 384, 256, 36, 96), (2, 64, 128, 37, 52), (1, 8, 64, 5, 4), (1, 256, 64, 100, 352)])
 def test_conv3x3_bias_act_vs_torch(shape):
-    """The fp32 matrix-core 3x3 convolution (experimental entry point (9), not yet on the product path) against torch's
+    """The fp32 matrix-core 3x3 convolution (entry point (9); the detector routes the 64-channel stage through it) against torch's
     convolution: with / without residual and ReLU, map sizes that do not divide the tile, one-chunk inputs, long-K shapes whose tiles
     are split between workgroups (stream-K hand-over)."""
     import torch.nn.functional as F
@@ -785,12 +785,14 @@ def test_conv3x3_bias_act_vs_torch(shape):
 
 
 @pytest.mark.parametrize("terms,tol", [(3, 5e-6), (2, 2e-5)])
-@pytest.mark.parametrize("shape", [(2, 64, 64, 100, 352), (3, 128, 128, 50, 176), (2, 256, 256, 25, 88), (1, 384, 256, 36, 96), (2, 64, 128, 37, 52), (1, 8, 64, 5, 4)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 100, 352), (3, 128, 128, 50, 176), (2, 256, 256, 25, 88), (1, 384, 256, 36, 96), (2, 64, 128, 37, 52), (1, 8, 64, 5, 4),
+                                   (1, 16, 64, 9, 63), (1, 256, 256, 100, 352)])
 def test_conv3x3_emu_bias_act_vs_fp64(shape, terms, tol):
     """The opt-in split-bf16 3x3 convolution (entry point (9b)) against the fp64 convolution: the 3-way split must be as accurate
     as a native fp32 convolution (5e-6 of the output scale; torch's own fp32 kernels land at 2e-7 .. 4e-6 on these shapes), the
-    2-way split within 2e-5; with / without residual and ReLU, ragged map sizes, one-chunk inputs, inputs spanning 12 orders of
-    magnitude (the split is exponent-agnostic), determinism."""
+    2-way split within 2e-5; with / without residual and ReLU, ragged map sizes (odd widths: no alignment requirement), one-chunk
+    inputs, the shrink-header shape whose 572 long tiles are split between workgroups (stream-K hand-over), inputs spanning 12
+    orders of magnitude (the split is exponent-agnostic), determinism."""
     import torch.nn.functional as F
     N, Ci, Co, H, W = shape
     gen = torch.Generator(device="cpu").manual_seed(sum(shape) + terms)
