@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB)) __attribute__((amd
 void conv3x3_kernel(const ConvArgs a) {
     using G = Geo<BH, BW, NPB>;
     __shared__ __attribute__((aligned(1024))) float lds[2 * G::BUF];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, p = lane & 31;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;   // wave: scalar
     const size_t plane = (size_t)a.H * a.W;
     const int groups = a.Cout / kCoutTile, chunks = a.Cin / kKC;
     const float *zero = a.wt + 9 * kCoutTile;            // first padding word of the packed weights: always 0
@@ -106,28 +106,46 @@ void conv3x3_kernel(const ConvArgs a) {
     const int pbase = half * G::CS + py * G::STR + px + 3;      // tap (dy, dx) of pixel (py, px) sits at row py + dy, column px + 3 + dx
     const int wbase = G::PLDS + half * kWStride + cb + p;
 
-    // LDS-DMA of one chunk into buffer `buf`: wave w issues transfers w, w + 4, ...
-    auto issue = [&](const Tile &t, int chunk, int buf) {
-        float *dst = lds + buf * G::BUF;
-        const float *xin = a.x + ((size_t)t.n * a.Cin + (size_t)chunk * kKC) * plane;
+    // LDS-DMA of one chunk into buffer `buf`: wave w issues transfers w, w + WAVES, ...  The source of every lane's 16-byte group
+    // of the halo patch (or the zero word: padding slot / outside the image) depends on the tile only: it is computed once per
+    // tile (`Plan`), a chunk adds its plane offset.  `wave` is scalar, so the LDS destinations are scalar too.
+    constexpr int PJ = (G::PINSTR + G::WAVES - 1) / G::WAVES, WJ = (kWInstr + G::WAVES - 1) / G::WAVES;
+    struct Plan {
+        int off[PJ];           // float offset from the chunk's first input plane; < 0: nothing to fetch
+        int n, cg;
+    };
+    auto make_plan = [&](const Tile &t) {
+        Plan pl;
+        pl.n = t.n;
+        pl.cg = t.cg;
 #pragma unroll
-        for (int j = 0; j < (G::PINSTR + G::WAVES - 1) / G::WAVES; ++j) {
+        for (int j = 0; j < PJ; ++j) {
+            const int ins = wave + G::WAVES * j;
+            const int e = (ins * 64 + lane) * 4;                       // first float of this lane's 16-byte group
+            const int c = e / G::CS, rem = e - c * G::CS, r = rem / G::STR, xx = rem - r * G::STR;
+            const int gy = t.y0 - 1 + r, gx = t.x0 - 4 + xx;           // gx % 4 == 0: the group is inside the row or outside
+            const bool ok = ins * 64 + lane < G::PGROUPS && c < kKC && r < G::PH && xx < G::PW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            pl.off[j] = ok ? c * (int)plane + gy * a.W + gx : -1;
+        }
+        return pl;
+    };
+    auto issue = [&](const Plan &pl, int chunk, int buf) {
+        float *dst = lds + buf * G::BUF;
+        const float *xin = a.x + ((size_t)pl.n * a.Cin + (size_t)chunk * kKC) * plane;
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
             const int ins = wave + G::WAVES * j;
             if (ins < G::PINSTR) {
                 if (ins * 64 + lane >= G::PGROUPS) continue;               // partial last transfer: masked lanes write nothing
-                const int e = (ins * 64 + lane) * 4;                       // first float of this lane's 16-byte group
-                const int c = e / G::CS, rem = e - c * G::CS, r = rem / G::STR, xx = rem - r * G::STR;
-                const int gy = t.y0 - 1 + r, gx = t.x0 - 4 + xx;           // gx % 4 == 0: the group is inside the row or outside
-                const bool ok = c < kKC && r < G::PH && xx < G::PW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                const float *src = ok ? xin + (size_t)c * plane + (size_t)gy * a.W + gx : zero;
+                const float *src = pl.off[j] >= 0 ? xin + pl.off[j] : zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + ins * 256), 16, 0, 0);
             }
         }
-        const float *wsrc = a.wt + ((size_t)t.cg * chunks + chunk) * kWChunk;
+        const float *wsrc = a.wt + ((size_t)pl.cg * chunks + chunk) * kWChunk + lane * 4;
 #pragma unroll
-        for (int j = 0; j < (kWInstr + G::WAVES - 1) / G::WAVES; ++j) {
+        for (int j = 0; j < WJ; ++j) {
             const int ins = wave + G::WAVES * j;
-            if (ins < kWInstr) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ins * 256 + lane * 4), (lptr_t)(dst + G::PLDS + ins * 256), 16, 0, 0);
+            if (ins < kWInstr) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ins * 256), (lptr_t)(dst + G::PLDS + ins * 256), 16, 0, 0);
         }
     };
 
@@ -152,10 +170,9 @@ void conv3x3_kernel(const ConvArgs a) {
     int L = 0;
     floatx16 acc[G::NCO];
     int buf = 0;
-    {
-        const int gs = global_step(0);
-        issue(decode(gs / chunks), gs % chunks, 0);
-    }
+    int plan_tile = global_step(0) / chunks;
+    Plan plan = make_plan(decode(plan_tile));                         // plan of the tile the next issue belongs to
+    issue(plan, global_step(0) - plan_tile * chunks, 0);
     while (L < n_local) {
         const int gs0 = global_step(L);
         const int tile = gs0 / chunks, c_begin = gs0 - tile * chunks;
@@ -188,7 +205,11 @@ void conv3x3_kernel(const ConvArgs a) {
             __syncthreads();
             if (L + 1 < n_local) {
                 const int ns = global_step(L + 1), nt = ns / chunks;
-                issue(decode(nt), ns - nt * chunks, buf ^ 1);
+                if (nt != plan_tile) {
+                    plan_tile = nt;
+                    plan = make_plan(decode(nt));
+                }
+                issue(plan, ns - nt * chunks, buf ^ 1);
             }
             const float *pl = lds + buf * G::BUF;
 #pragma unroll
@@ -209,11 +230,12 @@ void conv3x3_kernel(const ConvArgs a) {
         // The hand-over of a split tile uses agent-scope *write-through* stores / L2-bypassing loads (relaxed atomics) and no
         // fences: an agent-scope release / acquire fence writes back and invalidates the whole L2 of the XCD -- with hundreds of
         // workgroups doing that, the weights and patches of everybody else kept being evicted (measured: 141 -> 382 us).
+        // (slot layout [wave][q][lane]: one base pointer per 16 values + immediate offsets, so the addresses cost four registers)
         if (SPLIT && !head) {              // contributor: publish the partial sums of the tile's last chunks (slot g)
-            float *slot = a.partial + (size_t)g * (16 * G::NCO * G::THREADS);
+            float *slot = a.partial + (size_t)g * (16 * G::NCO * G::THREADS) + (size_t)wave * (16 * G::NCO * 64) + lane;
 #pragma unroll
             for (int q = 0; q < 16 * G::NCO; ++q)
-                __hip_atomic_store(slot + q * G::THREADS + tid, acc[q / 16][q % 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(slot + (q / 16) * 1024 + (q % 16) * 64, acc[q / 16][q % 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_s_waitcnt(0);     // my write-throughs are acknowledged ...
             __syncthreads();                   // ... and so are everyone's
             if (tid == 0) __hip_atomic_store(a.flags + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -223,10 +245,10 @@ void conv3x3_kernel(const ConvArgs a) {
             if (tid == 0)
                 while (__hip_atomic_load(a.flags + g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
             __syncthreads();
-            const float *slot = a.partial + (size_t)(g + 1) * (16 * G::NCO * G::THREADS);
+            const float *slot = a.partial + (size_t)(g + 1) * (16 * G::NCO * G::THREADS) + (size_t)wave * (16 * G::NCO * 64) + lane;
 #pragma unroll
             for (int q = 0; q < 16 * G::NCO; ++q)
-                acc[q / 16][q % 16] += __hip_atomic_load(slot + q * G::THREADS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc[q / 16][q % 16] += __hip_atomic_load(slot + (q / 16) * 1024 + (q % 16) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (live) {
 #pragma unroll
