@@ -8,9 +8,10 @@
 // v_mfma_f32_32x32x2_f32 -- exact fp32 products and accumulation, the same rounding model as an fmaf chain -- with the epilogue
 // in registers.
 //
-// STATUS (round 1): deterministic and correct to 4e-6 of torch's conv on every tested shape; 72-100 TFLOP/s of real work against
-// MIOpen's 78-108 effective (profiles/round1/conv3x3_bench.json).  It wins where the input-channel count is small (the 64-channel
-// stage: 141 vs 166 us) and the detector uses it there; the other stages stay on MIOpen.
+// STATUS (round 1): deterministic and correct to 4e-6 of torch's conv on every tested shape; 87-117 TFLOP/s of real work, 0.87-1.01x
+// MIOpen's time (Winograd + separate epilogue pass) per layer (profiles/round1/conv3x3_bench.json).  It wins clearly where the
+// input-channel count is small (the 64-channel stage: 144 vs 165 us) and the detector uses it there; the other stages stay on
+// MIOpen.
 //
 // GEMM view per image:  D[cout, pixel] = sum_{cin, tap} W[cout, cin, tap] * X[cin, pixel + tap].
 //   A operand (32 x 2)  weights: 32 output channels x 2 input channels of one tap      (from LDS, [cin][tap][cout])
