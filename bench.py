@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--pillars", type=int, default=8000)
     ap.add_argument("--config", default="opv2v_coalign")
     ap.add_argument("--lanes", type=int, default=4, help="frames in flight on separate HIP streams")
+    ap.add_argument("--result-lag", type=int, default=1, help="frames between enqueueing a frame and collecting its detections on the host "
+                    "(1 = collect the previous frame's; deeper lags were measured no faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-emu", type=int, default=0, choices=(0, 2, 3),
                     help="measure with the opt-in split-bf16 3x3 convolutions (COALIGN_CONV_EMU) instead of the native-fp32 default")
@@ -117,16 +119,21 @@ def main():
                 p.data.copy_(buf)
 
     record = [N]
-    pending = [None]
+    import collections
+    pending = collections.deque()          # post-process handles whose results have not been collected yet
+    last = [(None, None)]
 
     def flush():
-        prev, pending[0] = pending[0], None
-        return prev.result() if prev is not None else (None, None)
+        while pending:
+            last[0] = pending.popleft().result()
+        return last[0]
 
     # Frames are independent, so consecutive frames go to alternating HIP streams ("lanes"): the tail of one frame's kernels
     # (partial last waves of every convolution launch, the small latency-bound fusion / head kernels) overlaps the other
     # frame's work.  Throughput device; every frame still completes inside the timed bracket (device-wide synchronise).
     n_lanes = max(1, args.lanes)
+    result_lag = max(0, args.result_lag)
+    pp.buffer_sets = result_lag + 2        # decode / NMS buffer sets: one per uncollected frame + the one being filled
     lanes = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)] if n_lanes > 1 else [None]
     # one exchange buffer set per lane (a lane's all-to-all may still be in flight when the next lane packs); the collectives of
     # all lanes go to the one communicator in frame order on every rank, ProcessGroupNCCL serialises them on its own stream
@@ -153,10 +160,12 @@ def main():
                 out = model.fuse_and_head(feats, record, affine)
             with ops.timed("stage_post_process(enqueue)"):
                 # decode + NMS run on a side stream and overlap the next frame's encoder; the previous frame's
-                # result is collected here (software pipeline of depth 1, flushed before the timed region closes)
+                # results are collected `result_lag` frames later (software pipeline, flushed before the timed region closes)
                 handle = pp.post_process_async(ego_meta, {"ego": out})
-            prev, pending[0] = pending[0], handle
-            return prev.result() if prev is not None else (None, None)
+            pending.append(handle)
+            while len(pending) > result_lag:       # collect the oldest frame's detections (host wait for that frame only)
+                last[0] = pending.popleft().result()
+            return last[0]
 
     def sync():
         if world > 1:
@@ -171,7 +180,7 @@ def main():
     sync()
     # the roofline kernel alone on the GPU (outside the timed region): with several frames in flight the live launch durations
     # below include time-sharing with the other lanes' kernels, so both figures are reported
-    iso_ms = iso_pillar_ms = None
+    iso_ms = iso_pillar_ms = iso_fuse_ms = None
     if rank == 0:
         with torch.no_grad():
             gx = torch.randn(N, 64, ny // 2, nx // 2, device=dev)
@@ -197,11 +206,24 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             iso_pillar_ms = e0.elapsed_time(e1) / 10
+            # ... and the warp + attention fusion of all three scales (launched as the model launches them), same bracket
+            feats_iso, affine_iso = model.encode(frame)
+            for _ in range(3):
+                model._fuse_scales(feats_iso, record, affine_iso)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                model._fuse_scales(feats_iso, record, affine_iso)
+            e1.record()
+            torch.cuda.synchronize()
+            iso_fuse_ms = e0.elapsed_time(e1) / 10
+            del feats_iso, affine_iso
     sync()
     ops.PROFILE = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_issue = time.perf_counter() - t0   # host time to enqueue the K frames (the GPU may still be working)
     boxes, scores = flush()          # the last frame's detections: all K frames are complete inside the bracket
     sync()
     dt = time.perf_counter() - t0
@@ -218,9 +240,11 @@ def main():
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 step()
+            ti = time.perf_counter() - t1
             flush(); sync()
             d = time.perf_counter() - t1
-            opt_in[f"bf16x{terms}"] = {"value": round(args.steps / d, 3), "unit": "frames/s", "ms_per_step": round(d / args.steps * 1e3, 4)}
+            opt_in[f"bf16x{terms}"] = {"value": round(args.steps / d, 3), "unit": "frames/s", "ms_per_step": round(d / args.steps * 1e3, 4),
+                                       "host_enqueue_ms_per_step": round(ti / args.steps * 1e3, 4)}
         backbone_mod.CONV_EMU_TERMS = 0
         opt_in["note"] = ("COALIGN_CONV_EMU=3|2: every 3x3 convolution through coalign_conv3x3_emu_bias_act -- fp32 operands split "
                           "error-free into 3 (2) bf16 terms, 6 (3) cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; "
@@ -274,6 +298,16 @@ def main():
                     "note": "avg_launch_ms / achieved: HIP events around 10 calls of the op alone on the GPU right before the timed region (the "
                             "figure comparable to the committed rocprofv3 kernel trace); in_timed_region: the same op inside the timed steps, "
                             "where it shares the GPU with the other frames in flight and the previous frame's decode + NMS"}
+        if iso_fuse_ms and iso_pillar_ms and dom["name"] == "pillar_vfe_scatter":
+            fuse_bytes = sum(alg_bytes[f"warp_fuse_C{C}"] for C, _, _ in scales)
+            roofline_hbm["pillar_plus_warp_path"] = {
+                "warp_fuse_all_scales": {"algorithmic_bytes": fuse_bytes, "ms": round(iso_fuse_ms, 5), "achieved": round(fuse_bytes / iso_fuse_ms / 1e6, 1),
+                                         "frac": round(fuse_bytes / iso_fuse_ms / 1e6 / HBM_PEAK_GBPS, 4)},
+                "combined": {"algorithmic_bytes": dom["algorithmic_bytes"] + fuse_bytes, "ms": round(iso_pillar_ms + iso_fuse_ms, 5),
+                             "achieved": round((dom["algorithmic_bytes"] + fuse_bytes) / (iso_pillar_ms + iso_fuse_ms) / 1e6, 1),
+                             "frac": round((dom["algorithmic_bytes"] + fuse_bytes) / (iso_pillar_ms + iso_fuse_ms) / 1e6 / HBM_PEAK_GBPS, 4)},
+                "note": "north_star's pillar-scatter + warp path, each part alone on the GPU (HIP events around 10 calls before the timed region); "
+                        "the three fusion scales are launched the way the model launches them"}
         conv_traffic = None
         if os.path.exists(pmc_path) and N == 5 and args.config == "opv2v_coalign":
             for k, v in json.load(open(pmc_path)).items():
@@ -308,11 +342,12 @@ def main():
             "config": {"workload": f"OPV2V PointPillar + CoAlign multiscale attention fusion ({args.config}.yaml, BASELINE configs[2] "
                                    f"geometry): {N} agents/frame, {args.pillars} pillars/agent, canvas {nx}x{ny}, 70400 anchors, "
                                    "full path incl. decode + rotated NMS",
-                       "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": world, "frames_in_flight": n_lanes,
+                       "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": world, "frames_in_flight": n_lanes, "result_lag_frames": result_lag,
                        "parallelism": "single GPU" if world == 1 else f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all",
                        "detections_last_frame": 0 if boxes is None else int(boxes.shape[0]),
                        "candidates_last_frame": pp.last_counts["candidates"]},
             "roofline": roofline, "kernels": kernels,
+            "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
         }
         if opt_in is not None:
             result["opt_in_conv_emu"] = opt_in

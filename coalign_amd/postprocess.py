@@ -82,8 +82,8 @@ class VoxelPostprocessor:
     def post_process_async(self, data_dict: dict, output_dict: dict, side_stream: bool = True) -> "PostProcessHandle":
         """Enqueue decode + NMS + range filter and return immediately.  With ``side_stream`` the kernels run on a
         second HIP stream (ordered after the head outputs), so the next frame's encoder overlaps these small,
-        latency-bound launches; ``handle.result()`` waits for this frame only.  Two buffer sets rotate, i.e. at most
-        two frames may be in flight."""
+        latency-bound launches; ``handle.result()`` waits for this frame only.  ``self.buffer_sets`` (default 2) buffer sets
+        rotate, i.e. at most that many frames may be in flight (set it before the first call)."""
         cavs = list(data_dict.keys())
         first = output_dict[cavs[0]]
         cls0 = first["cls_preds"] if "cls_preds" in first else first["psm"]
@@ -93,9 +93,9 @@ class VoxelPostprocessor:
         key = (str(device), A, H, W, capacity)
         ring = self._buffers.get(key)
         if ring is None:
-            ring = self._buffers[key] = [ops.DecodeBuffers(capacity, A, H, W, NMS_TOP, device) for _ in range(2)]
+            ring = self._buffers[key] = [ops.DecodeBuffers(capacity, A, H, W, NMS_TOP, device) for _ in range(max(2, int(getattr(self, "buffer_sets", 2))))]
         self._turn = getattr(self, "_turn", 0) + 1
-        buf = ring[self._turn % 2]
+        buf = ring[self._turn % len(ring)]
         if len(cavs) + 1 > buf.counts.numel():
             raise ValueError("too many cavs for one post_process call")
         main = torch.cuda.current_stream(device)
