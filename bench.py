@@ -7,10 +7,13 @@
 
 Metric (BASELINE.json): frames/s on synthetic 5-agent OPV2V-shaped scenes.  A step is one pass of the whole hot
 path (pillar encode + scatter -> BEV backbone -> pose-aware warp + attention fusion at 3 scales -> heads ->
-decode + rotated NMS) over one frame per rank; inputs are resident in HBM before the timed region.  With R ranks
-a step processes R frames in the agent-sharded "frame ring" schedule of coalign_amd/sharded.py (weak scaling).
-Rank 0 prints ONE JSON line; it also carries the roofline of the dominant hand-written kernel (the fp32 matrix-core
-convolution; the HBM-bound pillar encoder rides along as `hbm_bound_kernel`; both timed with HIP events inside the timed steps) and, at N=1, the CPU oracle timed on the host cores.
+decode + rotated NMS) over one frame per rank; inputs are resident in HBM before the timed region and the timed loop
+ROTATES over a pool of distinct frames.  The loop is ``coalign_amd.pipeline.FramePipeline`` -- the product's frame runner
+(4 frames in flight, one HIP graph replay per frame), the same object the parity tests drive.  With R ranks a step
+processes R frames in the agent-sharded "frame ring" of coalign_amd/sharded.py (weak scaling): every rank encodes the
+agents the ring assigns to it out of the SAME frame pool, so the per-frame detection checksums printed here are equal
+for every --gpus value.  Rank 0 prints ONE JSON line; it carries the roofline of the dominant hand-written kernel, the
+north-star HBM figure of the pillar-scatter + warp path, and, at N=1, the CPU oracle timed on the host cores.
 """
 import argparse
 import json
@@ -26,14 +29,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from coalign_amd import ops  # noqa: E402
+from coalign_amd import backbone as backbone_mod  # noqa: E402
 from coalign_amd.config import builtin_config  # noqa: E402
 from coalign_amd.detector import build_model, to_device  # noqa: E402
+from coalign_amd.pipeline import FramePipeline  # noqa: E402
 from coalign_amd.postprocess import build_postprocessor  # noqa: E402
-from coalign_amd.sharded import FrameRing, encode_assignments  # noqa: E402
+from coalign_amd.sharded import FrameRing, ring_batch, split_agents  # noqa: E402
 from coalign_amd.synthetic import fill_parameters_, make_frame  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # dense fp32 matrix peak, /opt/skills/guides/MI355X_MICROARCH.md
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 matrix peak, same guide
+HBM_PEAK_GBPS = 8000.0            # 8 TB/s spec (about 6.3 TB/s achievable)
+POOL = 8                          # distinct frames the timed loop rotates over
 
 
 def calibrate_cls_bias(model, pp, batch, target=600):
@@ -52,27 +59,45 @@ def calibrate_cls_bias(model, pp, batch, target=600):
         model.cls_head.bias += (math.log(thr / (1 - thr)) - float(v))
 
 
+def checksum(boxes, scores):
+    """Order-sensitive digest of one frame's detections: (count, sum of scores, sum of |corner| in float64)."""
+    if boxes is None:
+        return [0, 0.0, 0.0]
+    return [int(boxes.shape[0]), round(float(scores.double().sum()), 9), round(float(boxes.double().abs().sum()), 6)]
+
+
+def hip_time(fn, iters=10, warm=3):
+    """Average duration (ms) of ``fn`` alone on the GPU: HIP events on the stream the kernels are launched on."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--agents", type=int, default=5)
     ap.add_argument("--pillars", type=int, default=8000)
     ap.add_argument("--config", default="opv2v_coalign")
     ap.add_argument("--lanes", type=int, default=4, help="frames in flight on separate HIP streams")
-    ap.add_argument("--result-lag", type=int, default=1, help="frames between enqueueing a frame and collecting its detections on the host "
-                    "(1 = collect the previous frame's; deeper lags were measured no faster)")
+    ap.add_argument("--result-lag", type=int, default=1, help="frames between enqueueing a frame and collecting its detections on the host")
     ap.add_argument("--no-miopen-find", action="store_true", help="leave torch.backends.cudnn.benchmark off (MIOpen immediate mode)")
-    ap.add_argument("--graph", action="store_true", help="capture encode + fuse + heads of a frame into one HIP graph per lane and replay it "
-                    "(single GPU; the synthetic frame has a fixed shape) -- removes the ~150 host-side launches per frame")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches (~150 host calls per frame) instead of one HIP graph replay per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--conv-emu", type=int, default=0, choices=(0, 2, 3),
-                    help="measure with the opt-in split-bf16 3x3 convolutions (COALIGN_CONV_EMU) instead of the native-fp32 default")
-    ap.add_argument("--no-opt-in", action="store_true", help="skip the extra timed passes of the opt-in convolution modes")
-    ap.add_argument("--cpu-frames", type=int, default=3)
-    ap.add_argument("--cpu-threads", type=int, default=16, help="torch CPU threads for the oracle (tiny batched matmuls "
-                    "get slower, not faster, with one thread per core on a many-core host)")
+    ap.add_argument("--conv-emu", type=int, default=None, choices=(0, 2, 3),
+                    help="override the 3x3 convolution arithmetic: 0 = native fp32 MFMA / MIOpen, 3 / 2 = split-bf16 products (default: the package default)")
+    ap.add_argument("--no-side-modes", action="store_true", help="skip the extra timed passes of the other convolution modes")
+    ap.add_argument("--cpu-frames", type=int, default=10)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the oracle (0 = best of the committed sweep, else 16)")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     args = ap.parse_args()
 
@@ -95,6 +120,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.conv_emu is not None:
+        backbone_mod.CONV_EMU_TERMS = args.conv_emu
+    default_terms = backbone_mod.CONV_EMU_TERMS
     hypes = builtin_config(args.config)
     N = args.agents
     nx, ny, _ = [int(v) for v in hypes["model"]["args"]["point_pillar_scatter"]["grid_size"]]
@@ -103,16 +131,17 @@ def main():
     model = model.to(dev).eval()
     pp = build_postprocessor(hypes["postprocess"], False)
     anchors = torch.from_numpy(pp.generate_anchor_box())
-    ego_meta = {"ego": {"transformation_matrix": torch.eye(4, device=dev), "anchor_box": anchors}}
 
-    # My frame (I am its ego): poses + the point clouds of the agents I encode this step.  In the ring each rank
-    # encodes agent a of frame (rank - a) mod R; synthetic frames are i.i.d., so a rank simply generates N agents'
-    # pillars plus its own frame's pose matrices -- same bytes, same work as the routed real thing.
-    frame_cpu = make_frame(hypes, N, pillars_per_agent=args.pillars, seed=303 + rank, noise=(0.2, 0.2))
-    frame = to_device(frame_cpu, dev)
-    frame["record_len"] = frame_cpu["record_len"]        # host-side agent counts: no device->host sync per frame
-    calibrate_cls_bias(model, pp, frame)
-    if world > 1:   # identical weights everywhere
+    # the frame pool: POOL distinct 5-agent frames (seed 303 + i, pose noise 0.2 m / 0.2 deg), identical on every rank
+    pool_n = POOL if world == 1 else world * max(1, POOL // world)
+    frames_cpu = [make_frame(hypes, N, pillars_per_agent=args.pillars, seed=303 + i, noise=(0.2, 0.2)) for i in range(pool_n)]
+    frames = []
+    for f in frames_cpu:
+        d = to_device(f, dev)
+        d["record_len"] = [N]                      # host-side agent counts: no device->host sync per frame
+        frames.append(d)
+    calibrate_cls_bias(model, pp, frames[0])       # same frame, same weights on every rank -> same calibration
+    if world > 1:   # identical weights everywhere, bit for bit
         for p in model.parameters():
             if backend == "nccl":
                 dist.broadcast(p.data, 0)
@@ -121,337 +150,286 @@ def main():
                 dist.broadcast(buf, 0)
                 p.data.copy_(buf)
 
-    record = [N]
-    import collections
-    pending = collections.deque()          # post-process handles whose results have not been collected yet
-    last = [(None, None)]
-
-    def flush():
-        while pending:
-            last[0] = pending.popleft().result()
-        return last[0]
-
-    # Frames are independent, so consecutive frames go to alternating HIP streams ("lanes"): the tail of one frame's kernels
-    # (partial last waves of every convolution launch, the small latency-bound fusion / head kernels) overlaps the other
-    # frame's work.  Throughput device; every frame still completes inside the timed bracket (device-wide synchronise).
     n_lanes = max(1, args.lanes)
-    result_lag = max(0, args.result_lag)
-    pp.buffer_sets = result_lag + 2        # decode / NMS buffer sets: one per uncollected frame + the one being filled
-    lanes = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)] if n_lanes > 1 else [None]
-    # one exchange buffer set per lane (a lane's all-to-all may still be in flight when the next lane packs); the collectives of
-    # all lanes go to the one communicator in frame order on every rank, ProcessGroupNCCL serialises them on its own stream
-    rings = [FrameRing(N) for _ in range(n_lanes)] if world > 1 else None
-    counter = [0]
+    use_graph = (not args.no_graph) and world == 1
+    rings = None
+    if world > 1:
+        # one communicator (own RCCL stream) and one ring per lane: the lanes' all-to-alls do not serialise behind each other
+        groups = [dist.new_group(backend=backend) for _ in range(n_lanes)]
+        rings = [FrameRing(N, group=g) for g in groups]
+        by_agent = [split_agents(f) for f in frames]
+        period = pool_n // world
+        step_batches = [ring_batch(by_agent, [f["pairwise_t_matrix"] for f in frames], rank, world, N, s) for s in range(period)]
+        del by_agent
+    else:
+        step_batches = frames
+    torch.backends.cudnn.benchmark = not args.no_miopen_find     # MIOpen find during warm-up for whatever still runs on it
 
-    def step():
-        k = counter[0] % len(lanes)
-        counter[0] += 1
-        if lanes[k] is None:
-            return _step(k)
-        with torch.cuda.stream(lanes[k]):
-            return _step(k)
-
-    graphs = {}                              # lane -> (HIP graph of encode + fuse + heads, its static output dict)
-
-    def capture(k):
-        # same launches, recorded once on the lane's stream; replay re-issues them with one host call.  The frame's tensors and
-        # the head outputs are static buffers of the graph; decode + NMS stay outside (their sizes are data-dependent).
-        g = torch.cuda.CUDAGraph()
-        with torch.no_grad():
-            with torch.cuda.graph(g, stream=lanes[k]):
-                feats, affine = model.encode(frame)
-                out = model.fuse_and_head(feats, record, affine)
-        graphs[k] = (g, out)
-
-    def _step(k):
-        ring = rings[k] if rings is not None else None
-        with torch.no_grad():
-            if k in graphs:
-                g, out = graphs[k]
-                g.replay()
-                handle = pp.post_process_async(ego_meta, {"ego": out})
-                pending.append(handle)
-                while len(pending) > result_lag:
-                    last[0] = pending.popleft().result()
-                return last[0]
-            with ops.timed("stage_encode(pillars+backbone)"):
-                feats, affine = model.encode(frame)
-            if ring is not None:
-                with ops.timed("stage_exchange(all_to_all)"):
-                    feats = ring.exchange(feats)
-            with ops.timed("stage_fuse_and_heads"):
-                out = model.fuse_and_head(feats, record, affine)
-            with ops.timed("stage_post_process(enqueue)"):
-                # decode + NMS run on a side stream and overlap the next frame's encoder; the previous frame's
-                # results are collected `result_lag` frames later (software pipeline, flushed before the timed region closes)
-                handle = pp.post_process_async(ego_meta, {"ego": out})
-            pending.append(handle)
-            while len(pending) > result_lag:       # collect the oldest frame's detections (host wait for that frame only)
-                last[0] = pending.popleft().result()
-            return last[0]
+    def make_pipe(graph):
+        return FramePipeline(model, pp, anchors, lanes=n_lanes, result_lag=args.result_lag, graph=graph, device=dev,
+                             exchange=None if rings is None else [r.exchange for r in rings])
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # MIOpen picks each convolution's solver by measurement during the warm-up (torch's cudnn.benchmark = miopenFind*): on a
-    # fresh machine the immediate-mode fallback, used when the user find-db is empty, is 10 % slower than what a second run gets
-    torch.backends.cudnn.benchmark = not args.no_miopen_find
-    from coalign_amd import backbone as backbone_mod
-    backbone_mod.CONV_EMU_TERMS = args.conv_emu          # 0 unless asked for: the headline number is the native-fp32 path
-    for _ in range(args.warmup):
-        step()
-    flush()
-    sync()
-    if args.graph and world == 1 and lanes[0] is not None:
-        for k in range(len(lanes)):
-            capture(k)
-        for _ in range(len(lanes)):
-            step()
-        flush()
+    def timed_run(pipe, steps, warmup):
+        for s in range(warmup):
+            pipe.submit(step_batches[s % len(step_batches)])
+        pipe.drain()
         sync()
-    # the roofline kernel alone on the GPU (outside the timed region): with several frames in flight the live launch durations
-    # below include time-sharing with the other lanes' kernels, so both figures are reported
-    iso_ms = iso_pillar_ms = iso_fuse_ms = None
+        pipe.host_enqueue_s = 0.0
+        results = []
+        t0 = time.perf_counter()
+        for s in range(steps):
+            results += pipe.submit(step_batches[s % len(step_batches)])
+        t_issue = pipe.host_enqueue_s
+        results += pipe.drain()              # the last frames' detections: all K frames are complete inside the bracket
+        sync()
+        return time.perf_counter() - t0, t_issue, results
+
+    pipe = make_pipe(use_graph)
+    warm = max(args.warmup, 2 * n_lanes if use_graph else args.warmup)     # every lane captures its graph during the warm-up
+    # ---- kernels alone on the GPU (outside the timed region): the roofline figures comparable to a rocprofv3 kernel trace
+    iso = {}
     if rank == 0:
         with torch.no_grad():
+            f0 = frames[0]
+            pl_in = dict(f0["processed_lidar"], record_len=f0["record_len"])
+            iso["pillar_ms"] = hip_time(lambda: model.pillar_vfe(dict(pl_in)))
             gx = torch.randn(N, 64, ny // 2, nx // 2, device=dev)
-            gw = ops.pack_conv3x3_weight(torch.randn(64, 64, 3, 3, device=dev) / 24.0)
+            gwt = torch.randn(64, 64, 3, 3, device=dev) / 24.0
             gb, gr = torch.randn(64, device=dev), torch.randn(N, 64, ny // 2, nx // 2, device=dev)
-            for _ in range(3):
-                ops.conv3x3_bias_act(gx, gw, gb, gr, True)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                ops.conv3x3_bias_act(gx, gw, gb, gr, True)
-            e1.record()
-            torch.cuda.synchronize()
-            iso_ms = e0.elapsed_time(e1) / 10
-            del gx, gw, gb, gr
-            # the HBM-bound pillar encoder (memset + cellmap + pillar_canvas) alone on the GPU, same bracket
-            pl_in = dict(frame["processed_lidar"], record_len=frame["record_len"])
-            for _ in range(3):
-                model.pillar_vfe(dict(pl_in))
-            e0.record()
-            for _ in range(10):
-                model.pillar_vfe(dict(pl_in))
-            e1.record()
-            torch.cuda.synchronize()
-            iso_pillar_ms = e0.elapsed_time(e1) / 10
+            gw = ops.pack_conv3x3_weight(gwt)
+            iso["conv_f32_ms"] = hip_time(lambda: ops.conv3x3_bias_act(gx, gw, gb, gr, True))
+            for terms in (3, 2):
+                gws = ops.pack_conv3x3_emu_weight(gwt, terms)
+                iso[f"conv_bf16x{terms}_ms"] = hip_time(lambda: ops.conv3x3_emu_bias_act(gx, gws, gb, 64, gr, True, terms))
+            del gx, gwt, gb, gr, gw
             try:
-                # ... and the warp + attention fusion of all three scales (launched as the model launches them), same bracket
-                # (the three launches + their stream fork / join cost more host time than GPU time, so the GPU-side duration is taken
-                #  from ten replays of a HIP graph of exactly these launches)
-                feats_iso, affine_iso = model.encode(frame)
+                # warp + attention fusion of all three scales, launched as the model launches them, replayed from a HIP graph so
+                # that host launch overhead does not enter the GPU-side duration
+                feats_iso, affine_iso = model.encode(f0)
                 for _ in range(3):
-                    model._fuse_scales(list(feats_iso), record, affine_iso)
+                    model._fuse_scales(list(feats_iso), [N], affine_iso)
                 torch.cuda.synchronize()
                 if world == 1:
                     gs = torch.cuda.Stream(device=dev)
                     gs.wait_stream(torch.cuda.current_stream(dev))
                     fg = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(fg, stream=gs):
-                        fused_iso = model._fuse_scales(list(feats_iso), record, affine_iso)
+                        model._fuse_scales(list(feats_iso), [N], affine_iso)
                     torch.cuda.synchronize()
-                    replay = fg.replay
+                    iso["fuse_ms"] = hip_time(fg.replay)
+                    del fg
                 else:       # no stream capture next to a live RCCL communicator (its watchdog thread polls events): plain launches
-                    replay = lambda: model._fuse_scales(list(feats_iso), record, affine_iso)
-                replay()
-                torch.cuda.synchronize()
-                e0.record()
-                for _ in range(10):
-                    replay()
-                e1.record()
-                torch.cuda.synchronize()
-                iso_fuse_ms = e0.elapsed_time(e1) / 10
-                del feats_iso, affine_iso, replay
-            except Exception:       # measurement aid only: the bench line must survive it
-                iso_fuse_ms = None
+                    iso["fuse_ms"] = hip_time(lambda: model._fuse_scales(list(feats_iso), [N], affine_iso))
+                del feats_iso, affine_iso
+            except Exception as e:       # measurement aid only: the bench line must survive it
+                iso["fuse_error"] = f"{type(e).__name__}: {str(e)[:120]}"
                 torch.cuda.synchronize()
     sync()
-    ops.PROFILE = {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_issue = time.perf_counter() - t0   # host time to enqueue the K frames (the GPU may still be working)
-    boxes, scores = flush()          # the last frame's detections: all K frames are complete inside the bracket
-    sync()
-    dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
-    if graphs:      # graph replays bypass the per-op event hooks: take the per-kernel profile from ordinary steps right after the region
-        saved = dict(graphs)
-        graphs.clear()
-        ops.PROFILE = {}
-        for _ in range(2 * n_lanes):
-            step()
-        flush(); sync()
-        prof, ops.PROFILE = ops.PROFILE, None
-        graphs.update(saved)
-    # the same bracket with the opt-in split-bf16 3x3 convolutions (reported beside `value`, never as `value`)
-    opt_in = None
-    if world == 1 and args.conv_emu == 0 and not args.no_opt_in:
-        try:
-            opt_in = {}
-            for terms in (3, 2):
-                backbone_mod.CONV_EMU_TERMS = terms
-                had_graphs = bool(graphs)
-                graphs.clear()
-                for _ in range(max(args.warmup, n_lanes + 1)):
-                    step()
-                flush(); sync()
-                if had_graphs:
-                    for k in range(len(lanes)):
-                        capture(k)
-                    for _ in range(len(lanes)):
-                        step()
-                    flush(); sync()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    step()
-                ti = time.perf_counter() - t1
-                flush(); sync()
-                d = time.perf_counter() - t1
-                opt_in[f"bf16x{terms}"] = {"value": round(args.steps / d, 3), "unit": "frames/s", "ms_per_step": round(d / args.steps * 1e3, 4),
-                                           "host_enqueue_ms_per_step": round(ti / args.steps * 1e3, 4)}
-            backbone_mod.CONV_EMU_TERMS = 0
-            opt_in["note"] = ("COALIGN_CONV_EMU=3|2: every 3x3 convolution through coalign_conv3x3_emu_bias_act -- fp32 operands split "
-                              "error-free into 3 (2) bf16 terms, 6 (3) cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; "
-                              "conv error vs fp64 1.1e-6..2.4e-6 (x3) / 2.7e-6..3.6e-6 (x2) of the output scale against 1.8e-6..3.6e-6 for "
-                              "the native fp32-MFMA kernel; end-to-end head outputs within 5.7e-6 (x3) / 3.8e-5 (x2) of eager PyTorch "
-                              "(north-star tolerance 1e-3).  Not the default: `value` keeps native fp32 products.")
-        except Exception as e:      # a side report must never cost the headline line
-            backbone_mod.CONV_EMU_TERMS = 0
-            graphs.clear()
-            opt_in = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
-            torch.cuda.synchronize()
+
+    dt, t_issue, results = timed_run(pipe, args.steps, warm)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- per-frame detection digests: pool frame -> digest; every recurrence of a pool frame must reproduce it exactly
+    digests, consistent = {}, True
+    for idx, boxes, scores in results[-min(len(results), 2 * pool_n):]:
+        g = (idx * world + rank) % pool_n if world > 1 else idx % pool_n
+        d = checksum(boxes, scores)
+        consistent = consistent and digests.setdefault(g, d) == d
+    if world > 1:
+        allg = [None] * world
+        dist.all_gather_object(allg, (digests, consistent))
+        digests = {}
+        for dg, ok in allg:
+            consistent = consistent and ok
+            for g, d in dg.items():
+                consistent = consistent and digests.setdefault(g, d) == d
+    last_boxes = results[-1][1] if results else None
+
+    # ---- per-kernel HIP-event profile inside ordinary (eager) steps right after the region (graph replays bypass the op hooks)
+    ops.PROFILE = {}
+    prof_pipe = pipe if not use_graph else make_pipe(False)
+    for s in range(2 * n_lanes):
+        prof_pipe.submit(step_batches[s % len(step_batches)])
+    prof_pipe.drain()
+    sync()
+    prof, ops.PROFILE = ops.PROFILE, None
+
+    # ---- the same bracket with the other convolution arithmetics (reported beside `value`, never as `value`)
+    side = None
+    if world == 1 and not args.no_side_modes:
+        side = {}
+        try:
+            for terms in (0, 3, 2):
+                if terms == default_terms:
+                    continue
+                backbone_mod.CONV_EMU_TERMS = terms
+                p2 = make_pipe(use_graph)
+                d2, ti2, _ = timed_run(p2, args.steps, warm)
+                side["native_fp32" if terms == 0 else f"bf16x{terms}"] = {
+                    "value": round(args.steps / d2, 3), "unit": "frames/s", "ms_per_step": round(d2 / args.steps * 1e3, 4),
+                    "host_enqueue_ms_per_step": round(ti2 / args.steps * 1e3, 4)}
+                del p2
+        except Exception as e:      # a side report must never cost the headline line
+            side["error"] = f"{type(e).__name__}: {str(e)[:200]}"
+            torch.cuda.synchronize()
+        backbone_mod.CONV_EMU_TERMS = default_terms
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         fps = world * args.steps / dt
-        M = int(frame["processed_lidar"]["voxel_features"].shape[0])
+        M = int(frames[0]["processed_lidar"]["voxel_features"].shape[0])
         scales = [(64, ny // 2, nx // 2), (128, ny // 4, nx // 4), (256, ny // 8, nx // 8)]
         alg_bytes = {"pillar_vfe_scatter": M * (32 * 4 * 4 + 4 * 4 + 4 + 64 * 4) + N * 64 * ny * nx * 4}
         for C, H, W in scales:
             alg_bytes[f"warp_fuse_C{C}"] = (N + 1) * C * H * W * 4
-        # the hand-written convolution serves the 64 -> 64 channel layers of the first ResNet stage: 2 * N * Cout * H * W * Cin * 9 flops
-        alg_flops = {"conv3x3_bias_act": 2 * N * 64 * (ny // 2) * (nx // 2) * 64 * 9}
+        fuse_bytes = sum(alg_bytes[f"warp_fuse_C{C}"] for C, _, _ in scales)
+        conv_flops = 2 * N * 64 * (ny // 2) * (nx // 2) * 64 * 9          # one 64 -> 64 channel 3x3 layer of the first ResNet stage
+        alg_flops = {"conv3x3_bias_act": conv_flops, "conv3x3_emu_bias_act": conv_flops}
         kernels = []
         for name, pairs in sorted(prof.items()):
             ms = sum(s.elapsed_time(e) for s, e in pairs) / len(pairs)
-            b, fl = alg_bytes.get(name), alg_flops.get(name)
+            b = alg_bytes.get(name)
             kernels.append({"name": name, "launches_timed": len(pairs), "avg_ms": round(ms, 5), "algorithmic_bytes": b,
                             "GBps": None if b is None else round(b / ms / 1e6, 1),
-                            "frac_of_8TBps": None if b is None else round(b / ms / 1e6 / HBM_PEAK_GBPS, 4),
-                            "algorithmic_flops": fl, "TFLOPs": None if fl is None else round(fl / ms / 1e9, 2),
-                            "frac_of_157TFLOPs": None if fl is None else round(fl / ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 4)})
-        dom = max((k for k in kernels if k["algorithmic_bytes"]), key=lambda k: k["avg_ms"])
-        dom_mfma = max((k for k in kernels if k["algorithmic_flops"]), key=lambda k: k["avg_ms"], default=None)
-        # HBM traffic per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, tools/gpu_round_artifacts.sh);
-        # it cannot be sampled from inside the process, so it is read from profiles/ and is null when that file is absent
-        traffic, traffic_src = None, None
-        pmc_kernels = {"pillar_vfe_scatter": ["pillar_canvas_kernel", "cellmap_kernel"], "warp_fuse_C64": ["warp_fuse_kernel<5, 8, true, 512, 8>"],
-                       "warp_fuse_C128": ["warp_fuse_kernel<5, 8, true, 1024, 8>"], "warp_fuse_C256": ["warp_fuse_kernel<5, 16, true, 1024, 4>"]}
-        pmc_path = os.path.join(ROOT, "profiles", "round1", "final_pmc_summary.json")
-        if os.path.exists(pmc_path) and N == 5 and args.pillars == 8000 and args.config == "opv2v_coalign":
-            pmc = json.load(open(pmc_path))
-            names = pmc_kernels.get(dom["name"], [])
-            if names and all(n in pmc and "hbm_bytes_raw" in pmc[n] for n in names):
-                traffic = int(sum(pmc[n]["hbm_bytes_raw"] for n in names))
-                traffic_src = "profiles/round1/final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, uncorrected sum)"
-        hbm_ms = iso_pillar_ms if (iso_pillar_ms and dom["name"] == "pillar_vfe_scatter") else dom["avg_ms"]
-        roofline_hbm = {"kernel": dom["name"] + (" = memset + cellmap_kernel + pillar_canvas_kernel" if dom["name"] == "pillar_vfe_scatter" else ""),
-                    "bound": "hbm", "achieved": round(dom["algorithmic_bytes"] / hbm_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(dom["algorithmic_bytes"] / hbm_ms / 1e6 / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_ms": round(hbm_ms, 5),
-                    "in_timed_region": {"avg_launch_ms": dom["avg_ms"], "achieved": dom["GBps"], "frac": dom["frac_of_8TBps"]},
-                    "note": "avg_launch_ms / achieved: HIP events around 10 calls of the op alone on the GPU right before the timed region (the "
-                            "figure comparable to the committed rocprofv3 kernel trace); in_timed_region: the same op inside the timed steps, "
-                            "where it shares the GPU with the other frames in flight and the previous frame's decode + NMS"}
-        if iso_fuse_ms and iso_pillar_ms and dom["name"] == "pillar_vfe_scatter":
-            fuse_bytes = sum(alg_bytes[f"warp_fuse_C{C}"] for C, _, _ in scales)
-            roofline_hbm["pillar_plus_warp_path"] = {
-                "warp_fuse_all_scales": {"algorithmic_bytes": fuse_bytes, "ms": round(iso_fuse_ms, 5), "achieved": round(fuse_bytes / iso_fuse_ms / 1e6, 1),
-                                         "frac": round(fuse_bytes / iso_fuse_ms / 1e6 / HBM_PEAK_GBPS, 4)},
-                "combined": {"algorithmic_bytes": dom["algorithmic_bytes"] + fuse_bytes, "ms": round(iso_pillar_ms + iso_fuse_ms, 5),
-                             "achieved": round((dom["algorithmic_bytes"] + fuse_bytes) / (iso_pillar_ms + iso_fuse_ms) / 1e6, 1),
-                             "frac": round((dom["algorithmic_bytes"] + fuse_bytes) / (iso_pillar_ms + iso_fuse_ms) / 1e6 / HBM_PEAK_GBPS, 4)},
-                "note": "north_star's pillar-scatter + warp path, each part alone on the GPU (HIP events around 10 calls before the timed region); "
-                        "the three fusion scales are launched the way the model launches them (finest scale on the main stream, the other two on side streams), "
-                        "replayed from a HIP graph so that host launch overhead does not enter the GPU-side duration"}
-        conv_traffic = None
-        if os.path.exists(pmc_path) and N == 5 and args.config == "opv2v_coalign":
-            for k, v in json.load(open(pmc_path)).items():
-                if k.startswith("conv3x3_kernel") and "hbm_bytes_raw" in v:
-                    conv_traffic = int(v["hbm_bytes_raw"])
-        # `roofline` = the hand-written kernel with the longest launches: the matrix-core convolution when the model routes layers
-        # through it (per launch 2x the pillar encoder's time), else the HBM-bound pillar encoder; the other one rides along
-        if dom_mfma is not None and dom_mfma["avg_ms"] >= dom["avg_ms"]:
-            live = {"avg_launch_ms": dom_mfma["avg_ms"], "achieved": dom_mfma["TFLOPs"], "frac": dom_mfma["frac_of_157TFLOPs"],
-                    "launches_timed": dom_mfma["launches_timed"]}
-            use_ms = iso_ms if iso_ms else dom_mfma["avg_ms"]
-            roofline = {"kernel": "conv3x3_bias_act (v_mfma_f32_32x32x2_f32 implicit GEMM, 64->64 channels at %dx%d, N=%d)" % (ny // 2, nx // 2, N),
-                        "bound": "mfma", "achieved": round(dom_mfma["algorithmic_flops"] / use_ms / 1e9, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(dom_mfma["algorithmic_flops"] / use_ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 4),
-                        "traffic": conv_traffic, "algorithmic_flops_per_launch": dom_mfma["algorithmic_flops"], "avg_launch_ms": round(use_ms, 5),
-                        "in_timed_region": live,
-                        "note": "fp32 matrix peak 157.3 TFLOP/s (MI355X_MICROARCH.md).  avg_launch_ms / achieved: HIP events around 10 launches of the "
-                                "kernel alone on the GPU, taken inside bench.py right before the timed region -- the figure that matches the "
-                                "kernel's duration in the committed rocprofv3 --kernel-trace summary.  in_timed_region: HIP events around the same "
-                                "launches inside the timed steps; with several frames in flight on separate streams an event pair also spans the "
-                                "time the launch waits for / shares compute units with the other lanes' kernels, so it is not the kernel's duration.  "
-                                "traffic = FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc pass (algorithmic: 45 MB in, 45 MB residual in, "
-                                "45 MB out per launch)",
-                        "hbm_bound_kernel": roofline_hbm}
+                            "frac_of_8TBps": None if b is None else round(b / ms / 1e6 / HBM_PEAK_GBPS, 4)})
+        live = {k["name"]: k for k in kernels}
+
+        # HBM traffic per launch from the committed rocprofv3 --pmc passes (separate passes, tools/gpu_round_artifacts.sh):
+        # reads = 2 x FETCH_SIZE (gfx950 tallies the 128-B requests of 16 B/lane streaming loads at 64 B, MI355X_MICROARCH.md
+        # "HBM"), writes = WRITE_SIZE; null when no summary is committed for this workload
+        pmc, pmc_src = {}, None
+        for rnd in ("round2", "round1"):
+            path = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json" if rnd != "round1" else "final_pmc_summary.json")
+            if os.path.exists(path) and N == 5 and args.pillars == 8000 and args.config == "opv2v_coalign":
+                pmc, pmc_src = json.load(open(path)), os.path.relpath(path, ROOT)
+                break
+
+        def traffic_of(prefixes):
+            hit = [v for k, v in pmc.items() if any(k.startswith(p) for p in prefixes) and "hbm_bytes_read_x2" in v]
+            return int(sum(v["hbm_bytes_read_x2"] for v in hit)) if hit else None
+
+        def hbm_entry(name, ms, nbytes, traffic, live_name=None):
+            e = {"kernel": name, "bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                 "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(ms, 5),
+                 "traffic": traffic, "traffic_over_algorithmic": None if not traffic else round(traffic / nbytes, 3)}
+            if live_name in live:
+                e["in_timed_steps"] = {"avg_launch_ms": live[live_name]["avg_ms"], "frac": live[live_name]["frac_of_8TBps"]}
+            return e
+
+        pillar = hbm_entry("pillar_vfe_scatter = memset + cellmap_kernel + pillar_canvas_kernel", iso["pillar_ms"], alg_bytes["pillar_vfe_scatter"],
+                           traffic_of(["pillar_canvas_kernel", "cellmap_kernel"]), "pillar_vfe_scatter")
+        north = {"target": 0.40, "pillar_vfe_scatter": pillar}
+        if "fuse_ms" in iso:
+            north["warp_fuse_all_scales"] = hbm_entry("coalign_warp_fuse x 3 scales", iso["fuse_ms"], fuse_bytes, traffic_of(["warp_fuse"]))
+            tot_ms, tot_b = iso["pillar_ms"] + iso["fuse_ms"], alg_bytes["pillar_vfe_scatter"] + fuse_bytes
+            north.update({"frac": round(tot_b / tot_ms / 1e6 / HBM_PEAK_GBPS, 4), "achieved": round(tot_b / tot_ms / 1e6, 1), "unit": "GB/s",
+                          "algorithmic_bytes": tot_b, "ms": round(tot_ms, 5)})
         else:
-            roofline = roofline_hbm
+            north.update({"frac": pillar["frac"], "note": "fusion timing failed: " + iso.get("fuse_error", "?")})
+        north["note"] = ("north_star: >= 40 % of the HBM roofline on the pillar-scatter + warp path.  Each part alone on the GPU (HIP events around "
+                         "10 calls right before the timed region); frac = algorithmic bytes (SURVEY 8d) / time / 8 TB/s; traffic = corrected PMC bytes "
+                         f"({pmc_src})")
+
+        # `roofline` = the hand-written kernel the frame spends most of its time in: the 3x3 convolution of the active arithmetic
+        if default_terms in (2, 3):
+            t = default_terms
+            ms = iso[f"conv_bf16x{t}_ms"]
+            executed = conv_flops * (6 if t == 3 else 3)
+            roofline = {"kernel": f"conv3x3_emu_bias_act (v_mfma_f32_32x32x16_bf16, fp32 operands split {t}-way, 64->64 channels at {ny // 2}x{nx // 2}, N={N})",
+                        "bound": "mfma", "achieved": round(executed / ms / 1e9, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(executed / ms / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 5),
+                        "algorithmic_flops_per_launch": executed, "fp32_equivalent_flops_per_launch": conv_flops,
+                        "fp32_equivalent_TFLOPs": round(conv_flops / ms / 1e9, 1), "traffic": traffic_of([f"conv3x3_emu_kernel_bf16x{t}"]),
+                        "note": f"executed bf16 products = {6 if t == 3 else 3} per fp32 product; peak = dense bf16 MFMA (MI355X_MICROARCH.md)"}
+        else:
+            ms = iso["conv_f32_ms"]
+            roofline = {"kernel": f"conv3x3_bias_act (v_mfma_f32_32x32x2_f32 implicit GEMM, 64->64 channels at {ny // 2}x{nx // 2}, N={N})", "bound": "mfma",
+                        "achieved": round(conv_flops / ms / 1e9, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(conv_flops / ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 5),
+                        "algorithmic_flops_per_launch": conv_flops, "traffic": traffic_of(["conv3x3_kernel"])}
+        roofline["isolated_ms"] = {k: round(v, 5) for k, v in iso.items() if k.endswith("_ms")}
+        roofline["hbm_bound_kernel"] = pillar
+
+        dtype = "f32" if default_terms == 0 else (f"f32 (3x3 convolution products evaluated as {default_terms}-way split bf16 products on the bf16 matrix cores, "
+                                                  "f32 accumulation" + ("; dropped terms <= 2^-24 |w x|, i.e. fp32-width arithmetic)" if default_terms == 3 else ")"))
         result = {
             "metric": "frames_per_s_5agent_opv2v_synthetic", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.conv_emu == 0 else f"f32 (3x3 convolutions: bf16x{args.conv_emu} split products, f32 accumulate)", "data": "synthetic",
+            "steps": args.steps, "warmup": warm, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"OPV2V PointPillar + CoAlign multiscale attention fusion ({args.config}.yaml, BASELINE configs[2] "
                                    f"geometry): {N} agents/frame, {args.pillars} pillars/agent, canvas {nx}x{ny}, 70400 anchors, "
-                                   "full path incl. decode + rotated NMS",
-                       "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": world, "frames_in_flight": n_lanes, "result_lag_frames": result_lag, "hip_graph": bool(graphs),
-                       "parallelism": "single GPU" if world == 1 else f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all",
-                       "detections_last_frame": 0 if boxes is None else int(boxes.shape[0]),
+                                   f"full path incl. decode + rotated NMS, {pool_n} distinct frames in rotation",
+                       "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": world, "frames_in_flight": n_lanes,
+                       "result_lag_frames": pipe.result_lag, "hip_graph": use_graph, "conv_arithmetic": "native fp32" if default_terms == 0 else f"bf16x{default_terms}",
+                       "parallelism": "single GPU" if world == 1 else f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all, one communicator per lane",
+                       "detections_last_frame": 0 if last_boxes is None else int(last_boxes.shape[0]),
                        "candidates_last_frame": pp.last_counts["candidates"]},
-            "roofline": roofline, "kernels": kernels,
+            "roofline": roofline, "north_star_hbm": north, "kernels": kernels,
             "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
+            "frame_digests": {str(k): digests[k] for k in sorted(digests)}, "frame_digests_reproducible": bool(consistent),
         }
-        if opt_in is not None:
-            result["opt_in_conv_emu"] = opt_in
+        if rings is not None:
+            result["exchange_bytes_sent_per_rank_per_step"] = rings[0].bytes_sent_last
+        if side is not None:
+            result["other_conv_arithmetics"] = side
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(hypes, model, frame_cpu, anchors, args.cpu_frames, args.cpu_threads, args.cpu_budget_s)
+            result["cpu_baseline"] = cpu_baseline(hypes, model, frames_cpu, anchors, args.cpu_frames, args.cpu_threads, args.cpu_budget_s)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(hypes, model, frame_cpu, anchors, n_frames, threads, budget_s):
-    """The CPU oracle (numpy/torch-CPU restatement of the reference path, oracle/) on the SAME frame.
-    Bounded sample: up to n_frames timed frames, stopping once `budget_s` seconds are spent (>= 1 frame)."""
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(hypes, model, frames_cpu, anchors, n_frames, threads, budget_s):
+    """The CPU oracle (numpy / torch-CPU restatement of the reference path, oracle/) on the SAME frames:
+    1 warm-up frame, then up to ``n_frames`` timed frames rotating over the pool, stopping once ``budget_s`` seconds of timed
+    work are spent (the default bench run has to finish within minutes).  Threads: the best setting of the committed sweep
+    (profiles/round2/cpu_baseline_sweep.json, tools/cpu_baseline_sweep.py) -- one torch thread per core is pathologically slow
+    for the tiny batched matmuls of the attention fusion on a many-core host."""
     from oracle import coalign_oracle as oracle
+    if threads <= 0:
+        threads = 16
+        sweep = os.path.join(ROOT, "profiles", "round2", "cpu_baseline_sweep.json")
+        if os.path.exists(sweep):
+            threads = int(json.load(open(sweep)).get("best_threads", 16))
     cores = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     margs = hypes["model"]["args"]
+
+    def one(frame):
+        with torch.no_grad():
+            out = oracle.coalign_forward(sd, margs, frame)
+            oracle.post_process([out], anchors, hypes["postprocess"])
+
+    one(frames_cpu[0])                          # warm-up (allocator, thread pool)
     done, t0 = 0, time.perf_counter()
     while done < n_frames and (done == 0 or time.perf_counter() - t0 < budget_s):
-        with torch.no_grad():
-            out = oracle.coalign_forward(sd, margs, frame_cpu)
-            oracle.post_process([out], anchors, hypes["postprocess"])
+        one(frames_cpu[done % len(frames_cpu)])
         done += 1
     dt = time.perf_counter() - t0
-    return {"value": round(done / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{done} frame(s) of the same 5-agent synthetic workload (no warm-up, {dt:.1f} s), torch CPU threads = {cores} "
-                      f"of {os.cpu_count()} host cores"}
+    return {"value": round(done / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_string(),
+            "host_cores": os.cpu_count(),
+            "sample": f"1 warm-up + {done} timed frame(s) of the same 5-agent synthetic pool ({dt:.1f} s, cap {budget_s:.0f} s), torch CPU threads = {cores} "
+                      f"of {os.cpu_count()} host cores; thread sweep in profiles/round2/cpu_baseline_sweep.json"}
 
 
 if __name__ == "__main__":

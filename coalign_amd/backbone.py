@@ -52,7 +52,8 @@ HIP_CONV_POLICY = os.environ.get("COALIGN_HIP_CONV", "stage1")      # measuremen
 
 # OPT-IN: 0 (default) keeps every product of the 3x3 convolutions in native fp32 (MIOpen / coalign_conv3x3_bias_act);
 # 2 or 3 routes every packable 3x3 convolution to coalign_conv3x3_emu_bias_act: fp32 products evaluated as 2- / 3-way split bf16
-# products on the bf16 matrix cores with fp32 accumulation (csrc/conv3x3_emu.hip).  Read at call time.
+# products on the bf16 matrix cores with fp32 accumulation (csrc/conv3x3_emu.hip).  The environment variable is
+# read once at import; the module attribute is read at every call (tests / bench.py set it directly).
 CONV_EMU_TERMS = int(os.environ.get("COALIGN_CONV_EMU", "0"))
 
 
@@ -266,6 +267,8 @@ class _MultiscaleDecodeMixin:
             if not isinstance(op, nn.ConvTranspose2d) or op.kernel_size != op.stride or op.stride[0] != op.stride[1] or op.stride[0] not in (1, 2, 4):
                 return False
             if op.in_channels > 256 or op.in_channels % 2 or f.shape[0] != feats[0].shape[0]:
+                return False
+            if (op.out_channels * op.stride[0] ** 2) % 32:        # GEMM rows of coalign_pointwise_conv come in tiles of 32
                 return False
             sizes.add((f.shape[2] * op.stride[0], f.shape[3] * op.stride[0]))
         return len(sizes) == 1

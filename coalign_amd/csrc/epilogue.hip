@@ -11,8 +11,8 @@ namespace {
 
 template <bool VEC4>
 __global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ y, const float *__restrict__ bias,
-                                                       const float *__restrict__ res, int C, int HW, int relu) {
-    const int plane = blockIdx.y;  // n * C + c
+                                                       const float *__restrict__ res, int planes, int C, int HW, int relu) {
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {   // plane = n * C + c (grid.y is capped at 65535)
     const float b = bias ? bias[plane % C] : 0.f;
     const size_t base = (size_t)plane * HW;
     if constexpr (VEC4) {
@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ y, co
             y[base + i] = v;
         }
     }
+  }
 }
 
 }  // namespace
@@ -45,13 +46,14 @@ extern "C" int coalign_bias_act(float *y, const float *bias, const float *residu
     if (N < 0 || C <= 0 || HW <= 0) return COALIGN_ERR_BAD_SHAPE;
     if (N == 0) return COALIGN_OK;
     if (!y) return COALIGN_ERR_NULL_POINTER;
-    if ((size_t)N * C > 65535u * 1024u) return COALIGN_ERR_UNSUPPORTED;
+    if ((size_t)N * C > (size_t)INT32_MAX) return COALIGN_ERR_UNSUPPORTED;
     const bool vec = (HW % 4 == 0) && (((uintptr_t)y & 15) == 0) && (!residual || ((uintptr_t)residual & 15) == 0);
     const int per = vec ? HW / 4 : HW;
     int bx = (per + 255) / 256;
     if (bx > 64) bx = 64;
-    dim3 grid(bx, N * C);
-    if (vec) hipLaunchKernelGGL(bias_act_kernel<true>, grid, dim3(256), 0, stream, y, bias, residual, C, HW, relu);
-    else hipLaunchKernelGGL(bias_act_kernel<false>, grid, dim3(256), 0, stream, y, bias, residual, C, HW, relu);
+    const int planes = N * C;
+    dim3 grid(bx, planes < 65535 ? planes : 65535);      // HIP's grid.y limit; the kernel strides over the planes beyond it
+    if (vec) hipLaunchKernelGGL(bias_act_kernel<true>, grid, dim3(256), 0, stream, y, bias, residual, planes, C, HW, relu);
+    else hipLaunchKernelGGL(bias_act_kernel<false>, grid, dim3(256), 0, stream, y, bias, residual, planes, C, HW, relu);
     return check_launch();
 }

@@ -337,6 +337,112 @@ __device__ float pcdet_iou(const float *A7, const float *B7) {
     return so / fmaxf(sa + sb - so, 1e-8f);
 }
 
+__device__ __forceinline__ float pcdet_iou_normal(const float *a, const float *b) {      // iou3d_nms_kernel.cu:313-325: heading ignored
+    const float lo_x = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), hi_x = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+    const float lo_y = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), hi_y = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+    const float w = fmaxf(hi_x - lo_x, 0.f), h = fmaxf(hi_y - lo_y, 0.f);
+    const float inter = w * h;
+    return inter / fmaxf(a[3] * a[4] + b[3] * b[4] - inter, 1e-8f);
+}
+
+// OpenPCDet-semantics suppression bitmask (iou3d_nms_kernel.cu:267-311 nms_kernel, :328-372 nms_normal_kernel): boxes are already
+// sorted by score; word (i, cb) bit l = "box cb*64+l is suppressed by box i", only for l > i.  Same tiling as mask_kernel above:
+// one 16-wave workgroup per 64x64 tile of the upper triangle, lanes = columns, 4 rows per wave, one __ballot = the row's word.
+// Row box = first argument of the IoU, column box = second (the reference's order; fp32 box_overlap is not symmetric in rounding).
+template <bool NORMAL>
+__global__ __launch_bounds__(kMaskWaves * 64) void pcdet_mask_kernel(const float *__restrict__ boxes, int n, float thr, int nb,
+                                                                     unsigned long long *__restrict__ mask) {
+    const int cb = blockIdx.x, rb = blockIdx.y;
+    if (cb < rb) return;
+    __shared__ float colb[64 * 7], rowb[64 * 7];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < 64 * 7; e += kMaskWaves * 64) {
+        const int jc = cb * 64 * 7 + e, jr = rb * 64 * 7 + e;
+        colb[e] = jc < n * 7 ? boxes[jc] : 0.f;
+        rowb[e] = jr < n * 7 ? boxes[jr] : 0.f;
+    }
+    __syncthreads();
+    const int j = cb * 64 + lane;
+    float c[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) c[k] = colb[lane * 7 + k];
+    constexpr int kRowsPerWave = 64 / kMaskWaves;
+#pragma unroll 1
+    for (int r = 0; r < kRowsPerWave; ++r) {
+        const int il = wv * kRowsPerWave + r;
+        const int i = rb * 64 + il;
+        if (i >= n) break;                                   // wave-uniform
+        float a[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) a[k] = rowb[il * 7 + k];   // LDS broadcast
+        bool bit = false;
+        if (j < n && j > i) {
+            if (NORMAL) bit = pcdet_iou_normal(a, c) > thr;
+            else {
+                // centres further apart than the two half diagonals: no edge crossing, no corner inside (margin 1e-2 included)
+                // => overlap exactly 0 => IoU 0, never '>' a non-negative threshold; skips the trigonometry for most pairs
+                const float dx = a[0] - c[0], dy = a[1] - c[1];
+                const float ra = 0.5f * sqrtf(a[3] * a[3] + a[4] * a[4]) + 0.02f, rc = 0.5f * sqrtf(c[3] * c[3] + c[4] * c[4]) + 0.02f;
+                const bool apart = thr >= 0.f && dx * dx + dy * dy > (ra + rc) * (ra + rc) * 1.0001f;
+                if (!apart) bit = pcdet_iou<false>(a, c) > thr;
+            }
+        }
+        const unsigned long long word = __ballot(bit);
+        if (lane == 0) mask[(size_t)i * nb + cb] = word;
+    }
+}
+
+// Greedy walk over the bitmask for more than 4096 boxes (nb > 64 words per row): lane w owns words w, w + 64, ... of the removed
+// set; rows are read straight from global memory (the LDS-staged single-word-per-lane reduce_kernel above serves nb <= 64).
+constexpr int kBigWords = 4;                                  // <= 16384 boxes
+__global__ __launch_bounds__(64) void reduce_big_kernel(const unsigned long long *__restrict__ mask, int n, int nb, int *__restrict__ keep,
+                                                        int *__restrict__ keep_count) {
+    const int lane = threadIdx.x;
+    unsigned long long removed[kBigWords] = {0ull, 0ull, 0ull, 0ull};
+    int cnt = 0;
+    const int nblk = (n + 63) / 64;
+    for (int b = 0; b < nblk; ++b) {
+        const int rows = min(64, n - b * 64);
+        const unsigned long long valid = rows == 64 ? ~0ull : ((1ull << rows) - 1ull);
+        const unsigned long long diag = (lane < rows) ? mask[(size_t)(b * 64 + lane) * nb + b] : 0ull;
+        unsigned long long own = 0ull;                        // word b of the removed set lives in lane b % 64, slot b / 64
+#pragma unroll
+        for (int q = 0; q < kBigWords; ++q)
+            if (q == b / 64) own = removed[q];
+        unsigned long long rem = readlane64(own, b % 64);
+        unsigned long long keepbits = 0, alive = ~rem & valid;
+        while (alive) {
+            const int t = __ffsll((long long)alive) - 1;
+            keepbits |= 1ull << t;
+            rem |= readlane64(diag, t);
+            const unsigned long long above = (t == 63) ? 0ull : (~0ull << (t + 1));
+            alive = ~rem & valid & above;
+        }
+        if ((keepbits >> lane) & 1ull) keep[cnt + __popcll(keepbits & ((1ull << lane) - 1ull))] = b * 64 + lane;
+        cnt += __popcll(keepbits);
+#pragma unroll
+        for (int q = 0; q < kBigWords; ++q) {
+            const int w = lane + 64 * q;
+            if (w > b && w < nb) {
+                unsigned long long kb = keepbits, acc = 0;
+                while (kb) {
+                    const int t = __ffsll((long long)kb) - 1;
+                    kb &= kb - 1;
+                    acc |= mask[(size_t)(b * 64 + t) * nb + w];
+                }
+                removed[q] |= acc;
+            }
+        }
+    }
+    if (lane == 0) *keep_count = cnt;
+}
+
+__global__ void iota_kernel(int *__restrict__ order, int *__restrict__ n_sorted, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) order[i] = i;
+    if (i == 0) *n_sorted = n;
+}
+
 template <bool AREA>
 __global__ __launch_bounds__(256) void iou_bev_kernel(const float *__restrict__ a, int Na, const float *__restrict__ b, int Nb,
                                                       float *__restrict__ iou) {
@@ -459,6 +565,42 @@ int coalign_boxes_iou_bev(const float *boxes_a, int Na, const float *boxes_b, in
 
 int coalign_boxes_overlap_bev(const float *boxes_a, int Na, const float *boxes_b, int Nb, float *overlap, void *stream) {
     return launch_iou_bev(true, boxes_a, Na, boxes_b, Nb, overlap, stream);
+}
+
+size_t coalign_pcdet_nms_workspace_bytes(int n) {
+    if (n <= 0) return 0;
+    const size_t nb = ((size_t)n + 63) / 64;
+    return coalign::align_up((size_t)n * nb * 8, 256) + coalign::align_up((size_t)n * 4, 256) + 256;
+}
+
+int coalign_pcdet_nms(const float *boxes_sorted, int n, float thresh, int normal, int32_t *keep, int32_t *keep_count, void *workspace,
+                      size_t workspace_bytes, void *stream_) {
+    using namespace coalign;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0) return COALIGN_ERR_BAD_SHAPE;
+    if (n > 64 * 64 * kBigWords) return COALIGN_ERR_UNSUPPORTED;
+    if (!keep_count) return COALIGN_ERR_NULL_POINTER;
+    if (n == 0) return hip_call(hipMemsetAsync(keep_count, 0, sizeof(int), stream));
+    if (!boxes_sorted || !keep || !workspace) return COALIGN_ERR_NULL_POINTER;
+    if (workspace_bytes < coalign_pcdet_nms_workspace_bytes(n)) return COALIGN_ERR_WORKSPACE;
+    const int nb = (n + 63) / 64;
+    char *p = (char *)workspace;
+    unsigned long long *mask = (unsigned long long *)p; p += align_up((size_t)n * nb * 8, 256);
+    int *order = (int *)p;                              p += align_up((size_t)n * 4, 256);
+    int *n_sorted = (int *)p;
+    if (normal) hipLaunchKernelGGL(pcdet_mask_kernel<true>, dim3(nb, nb), dim3(kMaskWaves * 64), 0, stream, boxes_sorted, n, thresh, nb, mask);
+    else hipLaunchKernelGGL(pcdet_mask_kernel<false>, dim3(nb, nb), dim3(kMaskWaves * 64), 0, stream, boxes_sorted, n, thresh, nb, mask);
+    int rc = check_launch();
+    if (rc) return rc;
+    if (nb <= 64) {                                        // the shared LDS-staged greedy reduction; order = identity (already sorted)
+        hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, order, n_sorted, n);
+        if ((rc = check_launch())) return rc;
+        hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(64), (size_t)64 * nb * sizeof(unsigned long long), stream, mask, order, n_sorted, nb,
+                           keep, keep_count);
+    } else {
+        hipLaunchKernelGGL(reduce_big_kernel, dim3(1), dim3(64), 0, stream, mask, n, nb, keep, keep_count);
+    }
+    return check_launch();
 }
 
 }  // extern "C"

@@ -41,6 +41,7 @@ struct WarpArgs {
     float *out;           // ATT/MAX: [C, Ho, Wo]; NONE: [n, C, Ho, Wo]
     int n, C, H, W, Ho, Wo, tiles_x, ntiles, mode, vec_ok;
     float sqrt_dim;
+    int rows[8];          // physical row of x holding logical agent i (identity unless the caller routes agents, coalign_warp_fuse_rows)
 };
 
 struct Tap {       // per (agent, pixel), parked in LDS
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int c = c_base + k;
             if (n < a.n && c < a.C) {                      // wave-uniform: scalar branch, scalar plane address
-                const char *plane = xb + ((size_t)n * a.C + c) * HW * sizeof(float);
+                const char *plane = xb + ((size_t)a.rows[n] * a.C + c) * HW * sizeof(float);
                 v = *reinterpret_cast<const float4 *>(plane + voff[n]);
             }
             return v;
@@ -228,12 +229,12 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
                 const size_t stride = (size_t)HW * sizeof(float);
                 const char *agent0 = xb + (size_t)c_base * stride;
                 const size_t agent_stride = (size_t)a.C * stride;
-                const char *pf = agent0;                   // plane of the next item to prefetch (uniform)
+                const char *pf = agent0 + (size_t)a.rows[0] * agent_stride;   // plane of the next item to prefetch (uniform)
                 float4 ring[D];
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
                     ring[j] = *reinterpret_cast<const float4 *>(pf + voff[j / CPT]);
-                    pf = ((j + 1) % CPT == 0) ? agent0 + (size_t)((j + 1) / CPT) * agent_stride : pf + stride;
+                    pf = ((j + 1) % CPT == 0) ? agent0 + (size_t)a.rows[((j + 1) / CPT) % NA] * agent_stride : pf + stride;
                 }
                 Tap t = taps[px];
 #pragma unroll
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
                     const float4 v = ring[j % D];
                     if (j + D < ITEMS) {
                         ring[j % D] = *reinterpret_cast<const float4 *>(pf + voff[(j + D) / CPT]);
-                        pf = ((j + D + 1) % CPT == 0) ? agent0 + (size_t)((j + D + 1) / CPT) * agent_stride : pf + stride;
+                        pf = ((j + D + 1) % CPT == 0) ? agent0 + (size_t)a.rows[((j + D + 1) / CPT) % NA] * agent_stride : pf + stride;
                     }
                     X[n][k] = resample(v, t, loff[n]);
 #pragma unroll
@@ -376,11 +377,11 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
         for (int k = 0; k < CPT; ++k) {
             const int c = c_base + k;
             if (c >= a.C) break;
-            const float v0 = sample_direct(a, a.x + (size_t)c * HW, ixs[0], iys[0]);
+            const float v0 = sample_direct(a, a.x + ((size_t)a.rows[0] * a.C + c) * HW, ixs[0], iys[0]);
 #pragma unroll
             for (int n = 0; n < NA; ++n) {
                 if (n < a.n) {
-                    const float v = n == 0 ? v0 : sample_direct(a, a.x + ((size_t)n * a.C + c) * HW, ixs[n], iys[n]);
+                    const float v = n == 0 ? v0 : sample_direct(a, a.x + ((size_t)a.rows[n] * a.C + c) * HW, ixs[n], iys[n]);
                     part[n] = fmaf(v0, v, part[n]);
                 }
             }
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(MAXT, (NA > 5 && MAXT <= 512) ? 2 : ((CPT == 8 && N
 #pragma unroll
         for (int n = 0; n < NA; ++n) {
             if (n < a.n) {
-                const float v = sample_direct(a, a.x + ((size_t)n * a.C + c) * HW, ixs[n], iys[n]);
+                const float v = sample_direct(a, a.x + ((size_t)a.rows[n] * a.C + c) * HW, ixs[n], iys[n]);
                 if (a.mode == COALIGN_FUSE_ATT) o = fmaf(s[n], v, o);
                 else if (a.mode == COALIGN_FUSE_MAX) m = fmaxf(m, v);
                 else if (pix_ok) a.out[((size_t)n * a.C + c) * HWo + opix] = v;
@@ -442,6 +443,12 @@ int dispatch(const WarpArgs &a, hipStream_t stream) {
 extern "C" int coalign_warp_fuse(const float *x, int n_total, int C, int H, int W, const double *theta,
                                  const int32_t *group_len, int n_groups, int mode, float *out, int Ho, int Wo,
                                  void *stream_) {
+    return coalign_warp_fuse_rows(x, n_total, C, H, W, theta, group_len, n_groups, nullptr, mode, out, Ho, Wo, stream_);
+}
+
+extern "C" int coalign_warp_fuse_rows(const float *x, int n_total, int C, int H, int W, const double *theta,
+                                      const int32_t *group_len, int n_groups, const int32_t *rows, int mode, float *out, int Ho, int Wo,
+                                      void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_total < 0 || C <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || n_groups < 0) return COALIGN_ERR_BAD_SHAPE;
     if (mode != COALIGN_FUSE_ATT && mode != COALIGN_FUSE_MAX && mode != COALIGN_FUSE_NONE) return COALIGN_ERR_UNSUPPORTED;
@@ -456,6 +463,18 @@ extern "C" int coalign_warp_fuse(const float *x, int n_total, int C, int H, int 
         sum += group_len[b];
     }
     if (sum != n_total) return COALIGN_ERR_BAD_SHAPE;
+    if (rows) {                              // a permutation inside every group
+        int o = 0;
+        for (int b = 0; b < n_groups; ++b) {
+            unsigned seen = 0;
+            for (int i = 0; i < group_len[b]; ++i) {
+                const int r = rows[o + i];
+                if (r < 0 || r >= group_len[b] || ((seen >> r) & 1u)) return COALIGN_ERR_BAD_SHAPE;
+                seen |= 1u << r;
+            }
+            o += group_len[b];
+        }
+    }
 
     WarpArgs a;
     a.C = C; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.mode = mode;
@@ -470,6 +489,7 @@ extern "C" int coalign_warp_fuse(const float *x, int n_total, int C, int H, int 
         a.x = x + (size_t)off * C * H * W;
         a.theta = theta + (size_t)off * 6;
         a.out = out + (size_t)(mode == COALIGN_FUSE_NONE ? off : b) * C * Ho * Wo;
+        for (int i = 0; i < 8; ++i) a.rows[i] = (rows && i < n) ? rows[off + i] : (i < n ? i : 0);
         int rc;
         if (n == 1) rc = dispatch<1>(a, stream);
         else if (n == 2) rc = dispatch<2>(a, stream);

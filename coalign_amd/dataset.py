@@ -110,7 +110,16 @@ class IntermediateFusionBatcher:
 
     # ------------------------------------------------------------------------------------------ one frame
     def get_item(self, base_data_dict: "OrderedDict", idx=0, rng: Optional[np.random.RandomState] = None) -> dict:
-        data = add_noise_data_dict(base_data_dict, self.params["noise_setting"], rng)
+        # The reference's retrieve_base_data hands every __getitem__ a FRESH dict (basedataset.py), so noise, box-aligned poses
+        # and the communication-range cut never leak into the scenario.  Same here: per-cav records and their ``params`` are
+        # copied (poses by value; point clouds and annotations are shared read-only), the caller's scenario is left untouched.
+        fresh = OrderedDict()
+        for cav_id, cav in base_data_dict.items():
+            rec = dict(cav)
+            rec["params"] = dict(cav["params"])
+            rec["params"]["lidar_pose"] = list(cav["params"]["lidar_pose"])
+            fresh[cav_id] = rec
+        data = add_noise_data_dict(fresh, self.params["noise_setting"], rng)
         first = next(iter(data))
         if not data[first]["ego"]:
             raise ValueError("the first element of the scenario must be the ego")

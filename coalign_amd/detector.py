@@ -101,13 +101,13 @@ class PointPillarBaselineMultiscale(nn.Module):
             spatial_features = self.naive_compressor(spatial_features)
         return self.backbone.get_multiscale_feature(spatial_features), affine
 
-    def _fuse_scales(self, feature_list, record_len, affine):
+    def _fuse_scales(self, feature_list, record_len, affine, rows=None):
         """The per-scale fusion launches are independent: on the GPU the coarser scales (few workgroups, latency bound)
         run on side streams next to the finest one instead of queueing behind it."""
         n = len(feature_list)
         x0 = feature_list[0]
         if n == 1 or not x0.is_cuda or self.training:
-            return [f(x, record_len, affine) for f, x in zip(self.fusion_net, feature_list)]
+            return [f(x, record_len, affine, rows=rows) for f, x in zip(self.fusion_net, feature_list)]
         main = torch.cuda.current_stream(x0.device)
         side = self.__dict__.get("_fusion_streams")
         if side is None or len(side) != n - 1 or side[0].device != x0.device:
@@ -117,18 +117,18 @@ class PointPillarBaselineMultiscale(nn.Module):
             s = side[i - 1]
             s.wait_stream(main)
             with torch.cuda.stream(s):
-                fused[i] = self.fusion_net[i](feature_list[i], record_len, affine)
+                fused[i] = self.fusion_net[i](feature_list[i], record_len, affine, rows=rows)
             feature_list[i].record_stream(s)
             affine.record_stream(s)
-        fused[0] = self.fusion_net[0](feature_list[0], record_len, affine)
+        fused[0] = self.fusion_net[0](feature_list[0], record_len, affine, rows=rows)
         for i in range(1, n):
             main.wait_stream(side[i - 1])
             fused[i].record_stream(main)
         return fused
 
-    def fuse_and_head(self, feature_list, record_len, affine) -> dict:
-        """Ego part: per-scale warp + fusion, deblocks, shrink header, heads."""
-        fused = self._fuse_scales(feature_list, record_len, affine)
+    def fuse_and_head(self, feature_list, record_len, affine, rows=None) -> dict:
+        """Ego part: per-scale warp + fusion, deblocks, shrink header, heads.  ``rows``: see ``AttFusion.forward``."""
+        fused = self._fuse_scales(feature_list, record_len, affine, rows)
         x = self.backbone.decode_multiscale_feature(fused)
         if self.shrink_flag:
             x = self.shrink_conv(x)

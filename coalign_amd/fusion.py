@@ -52,9 +52,10 @@ def warp_feature(x: torch.Tensor, record_len, pairwise_t_matrix: torch.Tensor) -
 
 
 class MaxFusion(nn.Module):
-    def forward(self, x: torch.Tensor, record_len, pairwise_t_matrix: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, record_len, pairwise_t_matrix: torch.Tensor, rows=None) -> torch.Tensor:
+        """``rows`` (not in the reference): row of ``x`` holding logical agent i, for agent-sharded callers."""
         groups = host_ints(record_len)
-        return ops.warp_fuse(x, _ego_rows(pairwise_t_matrix, groups), groups, ops.FUSE_MAX)
+        return ops.warp_fuse(x, _ego_rows(pairwise_t_matrix, groups), groups, ops.FUSE_MAX, rows=rows)
 
 
 class AttFusion(nn.Module):
@@ -62,6 +63,10 @@ class AttFusion(nn.Module):
         super().__init__()
         self.feature_dims = feature_dims
 
-    def forward(self, xx: torch.Tensor, record_len, normalized_affine_matrix: torch.Tensor) -> torch.Tensor:
+    def forward(self, xx: torch.Tensor, record_len, normalized_affine_matrix: torch.Tensor, rows=None) -> torch.Tensor:
         groups = host_ints(record_len)
-        return ops.warp_fuse(xx, _ego_rows(normalized_affine_matrix, groups), groups, ops.FUSE_ATT)
+        # ScaledDotProductAttention divides by sqrt(feat_dim) of the CONFIG (att_fuse.py:36-44), the kernel by sqrt(C) of the tensor:
+        # the two agree for every shipped yaml; a config where they differ would silently diverge from the reference's checkpoints
+        if self.feature_dims != xx.shape[1]:
+            raise ValueError(f"AttFusion(feat_dim={self.feature_dims}) fed {xx.shape[1]}-channel features: the fused kernel scales by sqrt(C)")
+        return ops.warp_fuse(xx, _ego_rows(normalized_affine_matrix, groups), groups, ops.FUSE_ATT, rows=rows)

@@ -25,6 +25,7 @@ SIGNATURES = {
                                            POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, P, c_size_t, P]),
     "coalign_scatter_to_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     "coalign_warp_fuse": (c_int, [P, c_int, c_int, c_int, c_int, P, POINTER(c_int32), c_int, c_int, P, c_int, c_int, P]),
+    "coalign_warp_fuse_rows": (c_int, [P, c_int, c_int, c_int, c_int, P, POINTER(c_int32), c_int, POINTER(c_int32), c_int, P, c_int, c_int, P]),
     "coalign_anchor_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "coalign_anchor_decode": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P, c_int, P, P, P,
                                       P, P, P, P, P, P, c_size_t, P]),
@@ -34,6 +35,8 @@ SIGNATURES = {
     "coalign_iou_rotated_matrix": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P]),
     "coalign_boxes_iou_bev": (c_int, [P, c_int, P, c_int, P, P]),
     "coalign_boxes_overlap_bev": (c_int, [P, c_int, P, c_int, P, P]),
+    "coalign_pcdet_nms_workspace_bytes": (c_size_t, [c_int]),
+    "coalign_pcdet_nms": (c_int, [P, c_int, c_float, c_int, P, P, P, c_size_t, P]),
     "coalign_bias_act": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "coalign_voxelize_capacity": (c_int64, [c_int64, c_int, POINTER(c_double), POINTER(c_double), c_int]),
     "coalign_voxelize_workspace_bytes": (c_size_t, [POINTER(c_int64), c_int, POINTER(c_double), POINTER(c_double), c_int]),

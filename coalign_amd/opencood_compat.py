@@ -44,7 +44,7 @@ _EXPORTS: Dict[str, Dict[str, object]] = {
     "opencood.tools.train_utils": {"create_model": detector.build_model, "to_device": detector.to_device},
     # rows N and the "next" rows of SURVEY section 8
     "opencood.pcdet_utils.iou3d_nms.iou3d_nms_utils": {"nms_gpu": pcdet.nms_gpu, "boxes_iou_bev": pcdet.boxes_iou_bev,
-                                                       "boxes_iou3d_gpu": pcdet.boxes_iou3d_gpu},
+                                                       "boxes_iou3d_gpu": pcdet.boxes_iou3d_gpu, "nms_normal_gpu": pcdet.nms_normal_gpu},
     "opencood.models.point_pillar_uncertainty": {"PointPillarUncertainty": detector.PointPillarUncertainty},
     "opencood.data_utils.post_processor.uncertainty_voxel_postprocessor": {"UncertaintyVoxelPostprocessor": postprocess.UncertaintyVoxelPostprocessor},
     "opencood.data_utils.pre_processor.sp_voxel_preprocessor": {"SpVoxelPreprocessor": preprocess.SpVoxelPreprocessor},

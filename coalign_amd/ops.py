@@ -45,7 +45,27 @@ class _Timed:
 
 
 def _stream() -> ctypes.c_void_p:
+    """The current HIP stream of the current device -- which, inside an op, is the device of its tensors (``_device_op``)."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _device_op(fn):
+    """Run ``fn`` with the device of its first GPU tensor argument current: outputs / workspaces are allocated there, and the
+    kernels go to THAT device's current stream (not to the stream of whatever device happens to be current in the caller)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for a in args:
+            if isinstance(a, DecodeBuffers):
+                a = a.counts
+            if torch.is_tensor(a) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapper
 
 
 def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
@@ -66,6 +86,7 @@ def _dbl3(v: Sequence[float]):
     return (ctypes.c_double * 3)(float(v[0]), float(v[1]), float(v[2]))
 
 
+@_device_op
 def pillar_vfe_scatter(voxel_features: torch.Tensor, voxel_num_points: torch.Tensor, voxel_coords: torch.Tensor,
                        weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[Tuple[torch.Tensor, ...]], bn_eps: float,
                        use_absolute_xyz: bool, with_distance: bool, voxel_size: Sequence[float], range_min: Sequence[float],
@@ -96,6 +117,7 @@ def pillar_vfe_scatter(voxel_features: torch.Tensor, voxel_num_points: torch.Ten
     return feats, canvas
 
 
+@_device_op
 def scatter_to_bev(pillar_features: torch.Tensor, voxel_coords: torch.Tensor, n_agents: int, ny: int, nx: int) -> torch.Tensor:
     """pillar_features [M, C] + coords (agent, z, y, x) -> canvas [n_agents, C, ny, nx]."""
     _need_gpu(pillar_features, voxel_coords)
@@ -111,10 +133,11 @@ def scatter_to_bev(pillar_features: torch.Tensor, voxel_coords: torch.Tensor, n_
     return canvas
 
 
+@_device_op
 def warp_fuse(x: torch.Tensor, theta: torch.Tensor, group_len: Sequence[int], mode: int,
-              out_hw: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+              out_hw: Optional[Tuple[int, int]] = None, rows: Optional[Sequence[int]] = None) -> torch.Tensor:
     """x [n_total, C, H, W] f32, theta [n_total, 2, 3] f64 (device) -> fused [len(group_len), C, Ho, Wo]
-    (or [n_total, C, Ho, Wo] for FUSE_NONE)."""
+    (or [n_total, C, Ho, Wo] for FUSE_NONE).  ``rows``: per frame, the row of x holding logical agent i (default identity)."""
     _need_gpu(x, theta)
     L = hip.lib()
     xc = _f32c(x)
@@ -125,9 +148,14 @@ def warp_fuse(x: torch.Tensor, theta: torch.Tensor, group_len: Sequence[int], mo
     n_out = n_total if mode == FUSE_NONE else len(groups)
     out = torch.empty((n_out, C, Ho, Wo), dtype=torch.float32, device=xc.device)
     gl = (ctypes.c_int32 * max(1, len(groups)))(*groups)
+    rw = None
+    if rows is not None:
+        if len(rows) != n_total:
+            raise ValueError("rows must have one entry per agent")
+        rw = (ctypes.c_int32 * max(1, n_total))(*[int(r) for r in rows])
     with _Timed(f"warp_fuse_C{C}"):
-        hip.check(L.coalign_warp_fuse(_ptr(xc), n_total, C, H, W, _ptr(th), gl, len(groups), mode, _ptr(out), Ho, Wo, _stream()),
-                  "coalign_warp_fuse")
+        hip.check(L.coalign_warp_fuse_rows(_ptr(xc), n_total, C, H, W, _ptr(th), gl, len(groups), rw, mode, _ptr(out), Ho, Wo, _stream()),
+                  "coalign_warp_fuse_rows")
     return out
 
 
@@ -156,6 +184,7 @@ class DecodeBuffers:
         self.host = torch.zeros(4, dtype=torch.int32).pin_memory()   # (final, candidates, kept, status) of the last frame
 
 
+@_device_op
 def anchor_decode(buf: DecodeBuffers, slot: int, cls: torch.Tensor, reg: torch.Tensor, dir_: Optional[torch.Tensor],
                   anchors_f32: torch.Tensor, score_thr: float, dir_offset: float, num_bins: int, order: str,
                   transform: Optional[torch.Tensor]) -> None:
@@ -180,6 +209,7 @@ def anchor_decode(buf: DecodeBuffers, slot: int, cls: torch.Tensor, reg: torch.T
               "coalign_anchor_decode")
 
 
+@_device_op
 def nms_rotated_device(boxes: torch.Tensor, scores: torch.Tensor, iou_thr: float, top: int = 1000,
                        valid: Optional[torch.Tensor] = None, k_dev: Optional[torch.Tensor] = None,
                        keep: Optional[torch.Tensor] = None, keep_count: Optional[torch.Tensor] = None,
@@ -203,6 +233,7 @@ def nms_rotated_device(boxes: torch.Tensor, scores: torch.Tensor, iou_thr: float
     return keep, keep_count
 
 
+@_device_op
 def gather_in_range(corners: torch.Tensor, scores: torch.Tensor, keep: torch.Tensor, keep_count: torch.Tensor,
                     limit_range: Sequence[float], out_corners: torch.Tensor, out_scores: torch.Tensor,
                     out_count: torch.Tensor) -> None:
@@ -213,6 +244,7 @@ def gather_in_range(corners: torch.Tensor, scores: torch.Tensor, keep: torch.Ten
                                         _ptr(out_corners), _ptr(out_scores), _ptr(out_count), _stream()), "coalign_gather_in_range")
 
 
+@_device_op
 def iou_rotated_matrix(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Tensor:
     """[Na, 8, 3] / [Na, 4, 2] corners x [Nb, ...] corners -> float32 IoU matrix [Na, Nb] (float64 clipping inside)."""
     _need_gpu(boxes_a, boxes_b)
@@ -225,6 +257,7 @@ def iou_rotated_matrix(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Te
     return out
 
 
+@_device_op
 def boxes_iou_bev(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Tensor:
     """OpenPCDet-semantics fp32 BEV IoU matrix [Na, Nb] of (x, y, z, dx, dy, dz, heading) boxes."""
     _need_gpu(boxes_a, boxes_b)
@@ -235,6 +268,7 @@ def boxes_iou_bev(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_device_op
 def bias_act_(y: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None, relu: bool = True) -> torch.Tensor:
     """In place ``y = act(y + bias[c] (+ residual))`` on a contiguous NCHW float32 tensor (fused conv epilogue)."""
     _need_gpu(y, bias, residual)
@@ -251,6 +285,7 @@ def bias_act_(y: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[
 VOX_FILTER_EGO, VOX_FILTER_RANGE = 1, 2   # COALIGN_VOX_FILTER_* of include/coalign_amd.h
 
 
+@_device_op
 def voxelize(points: torch.Tensor, cloud_offsets: Sequence[int], voxel_size: Sequence[float], lidar_range: Sequence[float],
              max_points: int, max_voxels: int, ego_filter: bool = False, filter_range: Optional[Sequence[float]] = None):
     """points [N, 4] (the clouds of a batch concatenated; ``cloud_offsets`` = host ints [n_clouds + 1]) ->
@@ -284,6 +319,7 @@ def voxelize(points: torch.Tensor, cloud_offsets: Sequence[int], voxel_size: Seq
     return voxels, coords, num, counts
 
 
+@_device_op
 def pose_graph_optimize(vertex_offsets: torch.Tensor, edge_offsets: torch.Tensor, n_agents: torch.Tensor, vertices: torch.Tensor,
                         kinds: torch.Tensor, edge_agent: torch.Tensor, edge_landmark: torch.Tensor, edge_meas: torch.Tensor,
                         edge_info: torch.Tensor, max_iterations: int = 1000) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -321,6 +357,7 @@ def pack_conv3x3_weight(weight: torch.Tensor) -> torch.Tensor:
     return out.contiguous()
 
 
+@_device_op
 def conv3x3_bias_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None,
                      relu: bool = True) -> torch.Tensor:
     """y = act(conv3x3(x, w) + bias (+ residual)), stride 1, padding 1, NCHW float32, on the fp32 matrix cores."""
@@ -371,6 +408,7 @@ def pack_conv3x3_emu_weight(weight: torch.Tensor, terms: int = 3) -> torch.Tenso
     return out
 
 
+@_device_op
 def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Tensor, cout: int, residual: Optional[torch.Tensor] = None,
                          relu: bool = True, terms: int = 3) -> torch.Tensor:
     """y = act(conv3x3(x, w) + bias (+ residual)) with every fp32 product evaluated as `terms`-way split bf16 products on the
@@ -411,6 +449,7 @@ def pack_pointwise_weight(weight: torch.Tensor, transposed: bool) -> torch.Tenso
     return out
 
 
+@_device_op
 def pointwise_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, up: int = 1, in_stride: int = 1, relu: bool = True,
                    out: Optional[torch.Tensor] = None, c_off: int = 0) -> torch.Tensor:
     """One-launch pointwise layer (include/coalign_amd.h (10)): ``up`` > 1 = non-overlapping transposed convolution, ``in_stride`` 2 =
@@ -430,6 +469,7 @@ def pointwise_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
     return out
 
 
+@_device_op
 def boxes_overlap_bev(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Tensor:
     """OpenPCDet-semantics fp32 BEV overlap AREA matrix [Na, Nb] of (x, y, z, dx, dy, dz, heading) boxes."""
     _need_gpu(boxes_a, boxes_b)
@@ -438,3 +478,18 @@ def boxes_overlap_bev(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Ten
     out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
     hip.check(L.coalign_boxes_overlap_bev(_ptr(a), a.shape[0], _ptr(b), b.shape[0], _ptr(out), _stream()), "coalign_boxes_overlap_bev")
     return out
+
+
+@_device_op
+def pcdet_nms(boxes_sorted: torch.Tensor, thresh: float, normal: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """boxes_sorted [n, 7] (descending score order) -> (keep int32 [n] positions, keep_count int32 [1]), both on the device."""
+    _need_gpu(boxes_sorted)
+    L = hip.lib()
+    b = _f32c(boxes_sorted)
+    n = b.shape[0]
+    keep = torch.empty(max(n, 1), dtype=torch.int32, device=b.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=b.device)
+    ws_bytes = L.coalign_pcdet_nms_workspace_bytes(n)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=b.device)
+    hip.check(L.coalign_pcdet_nms(_ptr(b), n, float(thresh), int(normal), _ptr(keep), _ptr(cnt), _ptr(ws), ws_bytes, _stream()), "coalign_pcdet_nms")
+    return keep, cnt

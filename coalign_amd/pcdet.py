@@ -1,12 +1,12 @@
 """OpenPCDet-semantics BEV / 3-D IoU and NMS: the functions callers import from
-``opencood/pcdet_utils/iou3d_nms/iou3d_nms_utils.py`` (``boxes_iou_bev`` :47-63, ``boxes_iou3d_gpu`` :66-98, ``nms_gpu`` :255-271), whose CUDA
-extension does not exist here.  Pair geometry (fp32 corner / edge intersection with the 1e-2 margin of the extension) runs in
-``coalign_boxes_iou_bev`` / ``coalign_boxes_overlap_bev``; the greedy suppression of ``nms_gpu`` walks the thresholded matrix on the host
-(the extension does the same walk over its bit mask on the CPU).
+``opencood/pcdet_utils/iou3d_nms/iou3d_nms_utils.py`` (``boxes_iou_bev`` :32-46, ``boxes_iou3d_gpu`` :147-181, ``nms_gpu`` :255-271,
+``nms_normal_gpu`` :274-289), whose CUDA extension does not exist here.  Pair geometry (fp32 corner / edge intersection with the
+1e-2 margin of the extension) runs in ``coalign_boxes_iou_bev`` / ``coalign_boxes_overlap_bev``; both NMS flavours run entirely on
+the device in ``coalign_pcdet_nms``: a 64-wide suppression bitmask per 64 x 64 tile of the pair matrix and a single-wavefront greedy
+walk over it (the extension builds the same mask on the GPU, copies it to the host and walks it there, iou3d_nms.cpp:90-137).
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 
 from . import ops
@@ -30,22 +30,24 @@ def boxes_iou3d_gpu(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Tenso
     return overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-6)
 
 
-def nms_gpu(boxes: torch.Tensor, scores: torch.Tensor, thresh: float, pre_maxsize=None, **kwargs):
-    """Sort by score (descending), keep a box unless an earlier kept box overlaps it with BEV IoU > thresh; returns
-    (indices into the input, None) like the reference."""
+def _nms(boxes: torch.Tensor, scores: torch.Tensor, thresh: float, pre_maxsize, normal: bool):
     assert boxes.shape[1] == 7
-    order = scores.sort(0, descending=True)[1]
+    # stable: equal scores keep their input order (torch's default sort leaves ties implementation-defined, like the reference's)
+    order = scores.sort(0, descending=True, stable=True)[1]
     if pre_maxsize is not None:
         order = order[:pre_maxsize]
-    b = boxes[order].contiguous()
-    k = b.shape[0]
-    if k == 0:
+    if order.numel() == 0:
         return order, None
-    suppress = (ops.boxes_iou_bev(b, b) > thresh).cpu().numpy()
-    removed = np.zeros(k, dtype=bool)
-    keep = []
-    for i in range(k):
-        if not removed[i]:
-            keep.append(i)
-            removed[i + 1:] |= suppress[i, i + 1:]
-    return order[torch.as_tensor(keep, dtype=torch.long, device=order.device)].contiguous(), None
+    keep, cnt = ops.pcdet_nms(boxes[order].contiguous(), thresh, normal)
+    return order[keep[: int(cnt.item())].long()].contiguous(), None
+
+
+def nms_gpu(boxes: torch.Tensor, scores: torch.Tensor, thresh: float, pre_maxsize=None, **kwargs):
+    """Rotated BEV boxes: sort by score (descending), keep a box unless an earlier kept box overlaps it with fp32 BEV IoU > thresh;
+    returns (indices into the input, None) like the reference."""
+    return _nms(boxes, scores, thresh, pre_maxsize, False)
+
+
+def nms_normal_gpu(boxes: torch.Tensor, scores: torch.Tensor, thresh: float, **kwargs):
+    """Heading ignored: axis-aligned (x, y, dx, dy) IoU; otherwise as ``nms_gpu`` (no ``pre_maxsize`` in the reference either)."""
+    return _nms(boxes, scores, thresh, None, True)

@@ -1,0 +1,210 @@
+"""Frame pipeline: the reference's inference loop with several frames in flight on one GPU.
+
+The reference runs ``for batch in loader: out = model(batch); boxes, scores = dataset.post_process(batch, out)``
+strictly one frame after the other on the default stream, with a device->host synchronisation inside NMS
+(opencood/tools/inference.py:125-179, inference_utils.py:122-173).  Frames are independent, so this runner keeps
+``lanes`` of them in flight, each on its own HIP stream ("lane"): the partial last wave of every convolution launch
+and the small latency-bound fusion / head / decode / NMS kernels of one frame overlap the other frames' work.
+Results come back in submission order, ``result_lag`` frames late (the host waits for the OLDEST frame only).
+
+Two launch modes:
+
+* eager (default)    ~150 host-side launches per frame through the C ABI; decode + NMS on a side stream.
+* HIP graph (``graph=True``)  encode -> fuse -> heads -> decode -> NMS -> range filter -> the four result scalars'
+  copy to pinned host memory are captured ONCE per (lane, input shape) and replayed with one host call per frame
+  (every kernel has static launch geometry; data-dependent sizes live in device memory).  Inputs are copied into the
+  graph's static buffers on the lane's stream.  A new input shape triggers a new capture; callers with ragged pillar
+  counts should pad ``processed_lidar`` to a bucket size with ``pad_pillars`` (padding rows are ignored by the kernels).
+
+Both modes produce bit-identical detections to ``model(batch)`` + ``post_processor.post_process`` (tests/test_pipeline_gpu.py).
+"""
+from __future__ import annotations
+
+import collections
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .encoder import host_ints
+from .postprocess import PostProcessHandle, VoxelPostprocessor
+
+FrameResult = Tuple[int, Optional[torch.Tensor], Optional[torch.Tensor]]      # (frame index, pred_box3d [K', 8, 3], scores [K'])
+
+
+def pad_pillars(processed_lidar: Dict[str, torch.Tensor], multiple: int = 4096) -> Dict[str, torch.Tensor]:
+    """Pad the pillar arrays to the next multiple of ``multiple`` rows so that consecutive frames share one graph.
+    Padding rows carry agent index -1: ``coalign_pillar_vfe_scatter`` ignores pillars outside the canvas / agent range."""
+    vf, vc, vn = processed_lidar["voxel_features"], processed_lidar["voxel_coords"], processed_lidar["voxel_num_points"]
+    m = vf.shape[0]
+    target = max(multiple, (m + multiple - 1) // multiple * multiple)
+    if target == m:
+        return processed_lidar
+    pad = target - m
+    return {"voxel_features": torch.cat([vf, vf.new_zeros((pad,) + tuple(vf.shape[1:]))]),
+            "voxel_coords": torch.cat([vc, vc.new_full((pad, vc.shape[1]), -1)]),
+            "voxel_num_points": torch.cat([vn, vn.new_ones(pad)])}
+
+
+class _GraphSlot:
+    """One captured frame: static inputs, the graph, the decode buffers it writes."""
+
+    def __init__(self):
+        self.graph = None
+        self.inputs: Dict[str, torch.Tensor] = {}
+        self.buf: Optional[ops.DecodeBuffers] = None
+        self.weights_sig = None
+
+
+class FramePipeline:
+    """``submit(batch)`` enqueues one frame (``batch`` = what the reference passes to ``model(...)``: ``batch_data['ego']``),
+    returns the frames that completed; ``drain()`` returns the rest.  ``run(frames)`` = the whole loop, results in order.
+
+    ``exchange``: optional per-lane callables ``feats -> (feats, rows)`` (``FrameRing.exchange``) placed between the per-agent encoder and the ego tail (the
+    agent-sharded multi-GPU schedules of ``coalign_amd.sharded`` plug in here; eager mode only)."""
+
+    def __init__(self, model, post_processor: VoxelPostprocessor, anchor_box, *, lanes: int = 4, result_lag: int = 1,
+                 graph: bool = False, device=None, transformation_matrix: Optional[torch.Tensor] = None,
+                 exchange: Optional[Sequence[Callable]] = None):
+        self.model = model
+        self.pp = post_processor
+        self.device = torch.device(device) if device is not None else next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise ops.hip.CoalignHipError("FramePipeline runs on the MI355X only (the hot path has no CPU implementation)")
+        self.n_lanes = max(1, int(lanes))
+        self.graph = bool(graph)
+        if exchange is not None and self.graph:
+            raise ValueError("collectives between encoder and tail are not captured: use eager mode with `exchange`")
+        if exchange is not None and len(exchange) != self.n_lanes:
+            raise ValueError("one exchange callable per lane")
+        self.exchange = exchange
+        # a lane's decode buffers / pinned result words are rewritten by its next replay: collect before that
+        self.result_lag = max(0, min(int(result_lag), self.n_lanes - 1)) if self.graph else max(0, int(result_lag))
+        a = anchor_box if torch.is_tensor(anchor_box) else torch.from_numpy(np.asarray(anchor_box))
+        T = torch.eye(4) if transformation_matrix is None else torch.as_tensor(transformation_matrix)
+        self.meta = {"ego": {"transformation_matrix": T.to(device=self.device, dtype=torch.float32), "anchor_box": a}}
+        with torch.cuda.device(self.device):
+            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_lanes)]
+        self.pp.buffer_sets = max(int(getattr(self.pp, "buffer_sets", 2)), self.result_lag + 2)
+        self._slots: List[Dict[tuple, _GraphSlot]] = [dict() for _ in range(self.n_lanes)]
+        self._lane_busy: List[Optional[int]] = [None] * self.n_lanes          # frame index whose result still sits in the lane's buffers
+        self._pending: "collections.deque" = collections.deque()              # (index, handle, keep-alive)
+        self._count = 0
+        self.host_enqueue_s = 0.0
+
+    # ------------------------------------------------------------------------------------------------ one frame
+    def _eager(self, k: int, batch: dict, record: List[int]) -> PostProcessHandle:
+        model = self.model
+        with ops.timed("stage_encode(pillars+backbone)"):
+            feats, affine = model.encode(batch)
+        rows = None
+        if self.exchange is not None:
+            with ops.timed("stage_exchange"):
+                feats, rows = self.exchange[k](feats)
+        with ops.timed("stage_fuse_and_heads"):
+            out = model.fuse_and_head(feats, record, affine, rows)
+        with ops.timed("stage_post_process(enqueue)"):
+            return self.pp.post_process_async(self.meta, {"ego": out})
+
+    def _frame_body(self, slot: _GraphSlot, record: List[int]) -> None:
+        batch = {"processed_lidar": {k: slot.inputs[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")},
+                 "record_len": record, "pairwise_t_matrix": slot.inputs["pairwise_t_matrix"]}
+        out = self.model(batch)
+        if slot.buf is None:
+            slot.buf = self.pp.decode_buffers({"ego": out})
+        self.pp.enqueue(self.meta, {"ego": out}, slot.buf)
+
+    def _graphed(self, k: int, batch: dict, record: List[int]) -> PostProcessHandle:
+        stream = self.streams[k]
+        pl = batch["processed_lidar"]
+        src = {"voxel_features": pl["voxel_features"], "voxel_coords": pl["voxel_coords"], "voxel_num_points": pl["voxel_num_points"],
+               "pairwise_t_matrix": batch["pairwise_t_matrix"]}
+        key = (tuple(record),) + tuple((tuple(t.shape), str(t.dtype)) for t in src.values())
+        slot = self._slots[k].get(key)
+        # a graph holds raw pointers to the folded / packed weight images of the moment it was captured: re-capture when any
+        # parameter or buffer of the model has been replaced or written since (load_state_dict, fine-tuning between runs)
+        sig = self._weights_signature()
+        if slot is not None and slot.weights_sig != sig:
+            slot = None
+        if slot is None:
+            slot = self._slots[k][key] = _GraphSlot()
+            slot.weights_sig = sig
+            for name, t in src.items():
+                slot.inputs[name] = torch.empty_like(t, device=self.device)
+                slot.inputs[name].copy_(t, non_blocking=True)
+            self._frame_body(slot, record)                      # eager warm-up on the lane: MIOpen find, weight folds, anchors, buffers
+            stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                self._frame_body(slot, record)
+            slot.graph = g
+        for name, t in src.items():
+            slot.inputs[name].copy_(t, non_blocking=True)
+        slot.graph.replay()
+        done = torch.cuda.Event()
+        done.record(stream)
+        return PostProcessHandle(self.pp, slot.buf, done)
+
+    def _weights_signature(self) -> tuple:
+        ts = self.__dict__.get("_weight_tensors")
+        if ts is None:
+            ts = self.__dict__["_weight_tensors"] = list(self.model.parameters()) + list(self.model.buffers())
+        return tuple((t.data_ptr(), t._version) for t in ts)
+
+    # ------------------------------------------------------------------------------------------------ the loop
+    def submit(self, batch: dict) -> List[FrameResult]:
+        import time
+        t0 = time.perf_counter()
+        idx = self._count
+        k = idx % self.n_lanes
+        self._count += 1
+        done: List[FrameResult] = []
+        if self.graph and self._lane_busy[k] is not None:
+            done += self._collect_through(self._lane_busy[k])
+        record = host_ints(batch["record_len"])
+        batch = dict(batch, record_len=record)
+        stream = self.streams[k]
+        with torch.cuda.device(self.device), torch.no_grad():
+            stream.wait_stream(torch.cuda.current_stream(self.device))      # inputs were produced on the caller's stream
+            with torch.cuda.stream(stream):
+                handle = self._graphed(k, batch, record) if self.graph else self._eager(k, batch, record)
+        self._lane_busy[k] = idx
+        self._pending.append((idx, handle, batch))              # the batch stays referenced until its frame has completed
+        while len(self._pending) > self.result_lag:
+            done.append(self._pop())
+        self.host_enqueue_s += time.perf_counter() - t0
+        return done
+
+    def _pop(self) -> FrameResult:
+        idx, handle, _keep = self._pending.popleft()
+        boxes, scores = handle.result()
+        k = idx % self.n_lanes
+        if self._lane_busy[k] == idx:
+            self._lane_busy[k] = None
+        return idx, boxes, scores
+
+    def _collect_through(self, idx: int) -> List[FrameResult]:
+        out = []
+        while self._pending and self._pending[0][0] <= idx:
+            out.append(self._pop())
+        return out
+
+    def drain(self) -> List[FrameResult]:
+        out = []
+        while self._pending:
+            out.append(self._pop())
+        return out
+
+    def run(self, frames: Iterable[dict]) -> List[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
+        """The reference's loop body for every frame of ``frames``; -> [(pred_box3d, scores)] in input order."""
+        results: List[FrameResult] = []
+        for batch in frames:
+            results += self.submit(batch)
+        results += self.drain()
+        assert [r[0] for r in results] == sorted(r[0] for r in results)
+        return [(b, s) for _, b, s in results]
+
+    def synchronize(self) -> None:
+        for s in self.streams:
+            s.synchronize()

@@ -79,6 +79,55 @@ class VoxelPostprocessor:
         threshold.  ``data_dict`` holds one entry per cav (only 'ego' for early / intermediate fusion)."""
         return self.post_process_async(data_dict, output_dict, side_stream=False).result()
 
+    def decode_buffers(self, output_dict: dict, n_cavs: int = 1) -> "ops.DecodeBuffers":
+        """A caller-owned buffer set sized for these head outputs (``FramePipeline`` keeps one per lane for its HIP graphs)."""
+        first = next(iter(output_dict.values()))
+        cls0 = first["cls_preds"] if "cls_preds" in first else first["psm"]
+        A, H, W = cls0.shape[-3:]
+        return ops.DecodeBuffers(A * H * W * n_cavs, A, H, W, NMS_TOP, cls0.device)
+
+    def enqueue(self, data_dict: dict, output_dict: dict, buf: "ops.DecodeBuffers", record_on: Optional[torch.cuda.Stream] = None) -> None:
+        """Enqueue decode + NMS + range filter + the four result scalars' copy to pinned host memory on the CURRENT stream, into
+        ``buf``.  Static launch geometry, no host synchronisation, no allocation once the anchors / transforms are on the device:
+        the sequence can be captured into a HIP graph.  ``record_on``: the head outputs are marked as used by that stream."""
+        cavs = list(data_dict.keys())
+        if len(cavs) + 1 > buf.counts.numel():
+            raise ValueError("too many cavs for one post_process call")
+        thr = self.params["target_args"]["score_threshold"]
+        da = self.params.get("dir_args", {})
+        buf.counts.zero_()
+        buf.status.zero_()
+        for slot, cav_id in enumerate(cavs):
+            assert cav_id in output_dict
+            out = output_dict[cav_id]
+            cls = out["cls_preds"] if "cls_preds" in out else out["psm"]
+            reg = out["reg_preds"] if "reg_preds" in out else out["rm"]
+            dirp = out.get("dir_preds", out.get("dm"))
+            if reg.dim() != 4:
+                raise NotImplementedError("anchor-free heads are outside the CoAlign hot path")
+            if "iou_preds" in out:
+                raise NotImplementedError("iou_preds rescoring is outside the CoAlign hot path")
+            content = data_dict[cav_id]
+            device = cls.device
+            T = torch.as_tensor(content["transformation_matrix"]).to(device=device, dtype=torch.float32)
+            anchors = self._anchors_f32(content["anchor_box"], device)
+            if record_on is not None:                     # keep the head outputs alive until the side stream is done
+                for t in (cls, reg, dirp):
+                    if t is not None:
+                        t.record_stream(record_on)
+            ops.anchor_decode(buf, slot, cls, reg, dirp, anchors, thr, da.get("dir_offset", 0.0), da.get("num_bins", 2),
+                              self.params["order"], T)
+        total_dev = buf.counts[len(cavs): len(cavs) + 1]
+        ops.nms_rotated_device(buf.cand_corners, buf.cand_score, self.params["nms_thresh"], NMS_TOP, valid=buf.cand_keep,
+                               k_dev=total_dev, keep=buf.keep, keep_count=buf.keep_count, ws=buf.nms_ws)
+        ops.gather_in_range(buf.cand_corners, buf.cand_score, buf.keep, buf.keep_count, self.params["gt_range"],
+                            buf.out_corners, buf.out_scores, buf.out_count)
+        # the frame's four scalars travel to pinned host memory behind the kernels: one small async copy each
+        buf.host[0:1].copy_(buf.out_count, non_blocking=True)
+        buf.host[1:2].copy_(total_dev, non_blocking=True)
+        buf.host[2:3].copy_(buf.keep_count, non_blocking=True)
+        buf.host[3:4].copy_(buf.status, non_blocking=True)
+
     def post_process_async(self, data_dict: dict, output_dict: dict, side_stream: bool = True) -> "PostProcessHandle":
         """Enqueue decode + NMS + range filter and return immediately.  With ``side_stream`` the kernels run on a
         second HIP stream (ordered after the head outputs), so the next frame's encoder overlaps these small,
@@ -92,12 +141,11 @@ class VoxelPostprocessor:
         capacity = A * H * W * len(cavs)
         key = (str(device), A, H, W, capacity)
         ring = self._buffers.get(key)
-        if ring is None:
-            ring = self._buffers[key] = [ops.DecodeBuffers(capacity, A, H, W, NMS_TOP, device) for _ in range(max(2, int(getattr(self, "buffer_sets", 2))))]
+        want = max(2, int(getattr(self, "buffer_sets", 2)))
+        if ring is None or len(ring) < want:
+            ring = self._buffers[key] = (ring or []) + [ops.DecodeBuffers(capacity, A, H, W, NMS_TOP, device) for _ in range(want - len(ring or []))]
         self._turn = getattr(self, "_turn", 0) + 1
         buf = ring[self._turn % len(ring)]
-        if len(cavs) + 1 > buf.counts.numel():
-            raise ValueError("too many cavs for one post_process call")
         main = torch.cuda.current_stream(device)
         stream = main
         if side_stream:
@@ -105,40 +153,8 @@ class VoxelPostprocessor:
                 self._side = torch.cuda.Stream(device=device)
             stream = self._side
             stream.wait_stream(main)
-        thr = self.params["target_args"]["score_threshold"]
-        da = self.params.get("dir_args", {})
-        with torch.cuda.stream(stream):
-            buf.counts.zero_()
-            buf.status.zero_()
-            for slot, cav_id in enumerate(cavs):
-                assert cav_id in output_dict
-                out = output_dict[cav_id]
-                cls = out["cls_preds"] if "cls_preds" in out else out["psm"]
-                reg = out["reg_preds"] if "reg_preds" in out else out["rm"]
-                dirp = out.get("dir_preds", out.get("dm"))
-                if reg.dim() != 4:
-                    raise NotImplementedError("anchor-free heads are outside the CoAlign hot path")
-                if "iou_preds" in out:
-                    raise NotImplementedError("iou_preds rescoring is outside the CoAlign hot path")
-                content = data_dict[cav_id]
-                T = torch.as_tensor(content["transformation_matrix"]).to(device=device, dtype=torch.float32)
-                anchors = self._anchors_f32(content["anchor_box"], device)
-                if side_stream:                     # keep the head outputs alive until the side stream is done
-                    for t in (cls, reg, dirp):
-                        if t is not None:
-                            t.record_stream(stream)
-                ops.anchor_decode(buf, slot, cls, reg, dirp, anchors, thr, da.get("dir_offset", 0.0), da.get("num_bins", 2),
-                                  self.params["order"], T)
-            total_dev = buf.counts[len(cavs): len(cavs) + 1]
-            ops.nms_rotated_device(buf.cand_corners, buf.cand_score, self.params["nms_thresh"], NMS_TOP, valid=buf.cand_keep,
-                                   k_dev=total_dev, keep=buf.keep, keep_count=buf.keep_count, ws=buf.nms_ws)
-            ops.gather_in_range(buf.cand_corners, buf.cand_score, buf.keep, buf.keep_count, self.params["gt_range"],
-                                buf.out_corners, buf.out_scores, buf.out_count)
-            # the frame's three scalars travel to pinned host memory behind the kernels: one small async copy each
-            buf.host[0:1].copy_(buf.out_count, non_blocking=True)
-            buf.host[1:2].copy_(total_dev, non_blocking=True)
-            buf.host[2:3].copy_(buf.keep_count, non_blocking=True)
-            buf.host[3:4].copy_(buf.status, non_blocking=True)
+        with torch.cuda.device(device), torch.cuda.stream(stream):
+            self.enqueue(data_dict, output_dict, buf, record_on=stream if side_stream else None)
             done = torch.cuda.Event()
             done.record(stream)
         return PostProcessHandle(self, buf, done)

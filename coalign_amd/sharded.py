@@ -1,31 +1,38 @@
 """Agent-sharded execution of the hot path across the GPUs of one node.
 
-The reference has no multi-GPU inference at all (every agent of a frame is a row of one batch on one device);
-this is the MI355X design: the per-agent stages (pillar encode -> canvas -> backbone) run where the agent's data
-lives, the three multiscale feature maps (15.77 MB fp32 per agent at OPV2V size) cross xGMI once, and the ego runs
-warp + fusion + heads + post-processing.
+The reference has no multi-GPU inference at all (every agent of a frame is a row of one batch on one device; its only
+distributed code is the DDP training wrapper, opencood/tools/train_ddp.py:104-109, multi_gpu_utils.py:32).  This is the
+MI355X design: the per-agent stages (pillar encode -> canvas -> backbone) run where the agent's data lives, the three
+multiscale feature maps (15.77 MB fp32 per agent at OPV2V size) cross xGMI once, and the ego runs warp + fusion + heads +
+post-processing.  Softmax and weighted sum run at the ego in fixed agent order, so results are independent of the sharding.
 
-Schedule ("frame ring", weak scaling): with R ranks a step processes R frames of N agents.  Rank r is the EGO of
-frame r and ENCODES agent a of frame (r - a) mod R, a = 0..N-1, so every rank does N encodes + 1 ego tail per step
-whatever R is.  The exchange is one all-to-all per step (RCCL over xGMI; point-to-point links, each rank talks to
-at most N-1 distinct peers, one 15.77 MB message per link): agent a encoded on rank r goes to rank (r - a) mod R;
-frame r's agent a arrives from rank (r + a) mod R.  For R == 1 nothing is exchanged.
+Two schedules:
+
+``FrameRing`` (throughput, weak scaling): with R ranks a step processes R frames of N agents.  Rank r is the EGO of frame r
+and ENCODES agent a of frame (r - a) mod R, a = 0..N-1, so every rank does N encodes + 1 ego tail per step whatever R is.
+One all-to-all per scale and step (RCCL over xGMI; point-to-point links, each rank talks to at most N-1 distinct peers,
+15.77 MB per agent and link).  No pack / unpack copies: the local agents are stacked in DESTINATION order, so the backbone's
+output tensors are the send buffers as they are, and the receive buffers (source-rank major) go to the fusion kernel together
+with a row table ``rows[i]`` = "physical row holding logical agent i" (``coalign_warp_fuse_rows``).
+
+``AgentGather`` (latency, BASELINE configs[2] as north_star words it): ONE frame, rank r owns a contiguous block of its
+agents, one all-gather per scale, rank 0 (the ego) fuses.  With 5 ranks and 5 agents: one agent per GPU.
+
+``wire_dtype`` (float16 / bfloat16): the feature maps are cast for the exchange and back (SURVEY §8f next-4 "compression on
+the wire"); fp32 (default) is exact.  Relative error per element <= 2^-11 (fp16, inside its normal range) / 2^-8 (bf16).
 """
 from __future__ import annotations
 
-from typing import Callable, List, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 
-def encode_assignments(rank: int, world: int, n_agents: int) -> List[Tuple[int, int]]:
-    """(frame, agent) pairs rank ``rank`` encodes in one step, in local slot order a = 0..n_agents-1."""
-    return [((rank - a) % world, a) for a in range(n_agents)]
-
-
+# ------------------------------------------------------------------------------------------------ frame ring: plans
 def send_plan(rank: int, world: int, n_agents: int):
-    """-> (send_order, send_counts): local slots grouped by destination rank (ascending), and per-destination counts."""
+    """-> (send_order, send_counts): the agents this rank encodes, grouped by destination rank (ascending), and the
+    per-destination counts.  ``send_order`` IS the local slot order."""
     order, counts = [], [0] * world
     for d in range(world):
         for a in range(n_agents):
@@ -36,7 +43,7 @@ def send_plan(rank: int, world: int, n_agents: int):
 
 
 def recv_plan(rank: int, world: int, n_agents: int):
-    """-> (agent_of_recv_slot, recv_counts): which agent of MY frame each received slot holds (source-rank major)."""
+    """-> (agent_of_recv_slot, recv_counts): which agent of MY frame each received row holds (source-rank major)."""
     agents, counts = [], [0] * world
     for s in range(world):
         for a in range(n_agents):
@@ -46,53 +53,148 @@ def recv_plan(rank: int, world: int, n_agents: int):
     return agents, counts
 
 
-class FrameRing:
-    """Runs ``encode_fn`` on the local agents, exchanges the packed multiscale features, returns this rank's
-    frame as per-scale tensors ``[n_agents, C_s, H_s, W_s]`` in agent order (agent 0 = ego)."""
+def encode_assignments(rank: int, world: int, n_agents: int) -> List[Tuple[int, int]]:
+    """(frame, agent) pairs rank ``rank`` encodes in one step, in LOCAL SLOT order (= destination-rank major)."""
+    order, _ = send_plan(rank, world, n_agents)
+    return [((rank - a) % world, a) for a in order]
 
-    def __init__(self, n_agents: int, group=None):
+
+def _is_gloo_cuda(t: torch.Tensor, group) -> bool:
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+class FrameRing:
+    """``exchange(feats)``: per scale ``[n_agents, C, H, W]`` in local slot order -> ``(recv, rows)``: per scale
+    ``[n_agents, C, H, W]`` holding MY frame's agents source-rank major, and ``rows[i]`` = the row of logical agent i
+    (agent 0 = ego)."""
+
+    def __init__(self, n_agents: int, group=None, wire_dtype: Optional[torch.dtype] = None):
         self.n = n_agents
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.send_order, self.send_counts = send_plan(self.rank, self.world, self.n)
         self.recv_agents, self.recv_counts = recv_plan(self.rank, self.world, self.n)
-        self._send = self._recv = None
-
-    def exchange(self, feats: Sequence[torch.Tensor]) -> List[torch.Tensor]:
-        """feats: per scale [n_agents, C, H, W] in local slot order -> same shapes holding MY frame's agents."""
-        if self.world == 1:
-            return list(feats)
-        shapes = [tuple(f.shape[1:]) for f in feats]
-        sizes = [f[0].numel() for f in feats]
-        per_agent = sum(sizes)
-        dev, dt = feats[0].device, feats[0].dtype
-        if self._send is None or self._send.shape != (self.n, per_agent) or self._send.device != dev:
-            self._send = torch.empty((self.n, per_agent), dtype=dt, device=dev)
-            self._recv = torch.empty((self.n, per_agent), dtype=dt, device=dev)
-        idx = torch.as_tensor(self.send_order, device=dev)
-        off = 0
-        for f, sz in zip(feats, sizes):          # pack: destination-major rows, scales side by side
-            self._send[:, off:off + sz] = f.reshape(self.n, sz).index_select(0, idx)
-            off += sz
-        if self._send.is_cuda and dist.get_backend(self.group) == "gloo":
-            # functional-test route only (two ranks sharing one GPU cannot use RCCL): stage through host memory
-            recv = torch.empty(self._recv.shape, dtype=dt)
-            dist.all_to_all_single(recv, self._send.cpu(), output_split_sizes=self.recv_counts,
-                                   input_split_sizes=self.send_counts, group=self.group)
-            self._recv.copy_(recv)
-        else:
-            dist.all_to_all_single(self._recv, self._send, output_split_sizes=self.recv_counts,
-                                   input_split_sizes=self.send_counts, group=self.group)
-        inv = torch.empty(self.n, dtype=torch.long)
+        self.rows = [0] * self.n
         for slot, a in enumerate(self.recv_agents):
-            inv[a] = slot
-        inv = inv.to(dev)
-        out, off = [], 0
-        for shp, sz in zip(shapes, sizes):
-            out.append(self._recv[:, off:off + sz].index_select(0, inv).reshape((self.n,) + shp))
-            off += sz
+            self.rows[a] = slot
+        self.wire_dtype = wire_dtype
+        self._recv: Dict[tuple, torch.Tensor] = {}
+        self.bytes_sent_last = 0
+
+    def assignments(self) -> List[Tuple[int, int]]:
+        return encode_assignments(self.rank, self.world, self.n)
+
+    def exchange(self, feats: Sequence[torch.Tensor]) -> Tuple[List[torch.Tensor], List[int]]:
+        if self.world == 1:
+            return list(feats), list(range(self.n))
+        out, sent = [], 0
+        for i, f in enumerate(feats):
+            assert f.shape[0] == self.n and f.is_contiguous()
+            send = f if self.wire_dtype is None else f.to(self.wire_dtype)
+            key = (i, tuple(send.shape), send.dtype, str(send.device))
+            recv = self._recv.get(key)
+            if recv is None:
+                recv = self._recv[key] = torch.empty_like(send)
+            send2, recv2 = send.view(self.n, -1), recv.view(self.n, -1)
+            if _is_gloo_cuda(send2, self.group):
+                # functional-test route only (ranks sharing one GPU cannot use RCCL): staged through host memory
+                host = torch.empty(recv2.shape, dtype=recv2.dtype)
+                dist.all_to_all_single(host, send2.cpu(), output_split_sizes=self.recv_counts, input_split_sizes=self.send_counts,
+                                       group=self.group)
+                recv2.copy_(host)
+            else:
+                dist.all_to_all_single(recv2, send2, output_split_sizes=self.recv_counts, input_split_sizes=self.send_counts,
+                                       group=self.group)
+            sent += sum(c for d, c in enumerate(self.send_counts) if d != self.rank) * send2.shape[1] * send2.element_size()
+            out.append(recv if self.wire_dtype is None else recv.to(f.dtype))
+        self.bytes_sent_last = sent
+        return out, list(self.rows)
+
+    def step(self, encode_fn: Callable[[], Sequence[torch.Tensor]], tail_fn: Callable[[List[torch.Tensor], List[int]], object]):
+        return tail_fn(*self.exchange(encode_fn()))
+
+
+# ------------------------------------------------------------------------------------------------ one frame over R ranks
+def agent_blocks(world: int, n_agents: int) -> Tuple[int, List[range]]:
+    """Contiguous agent blocks of ``per = ceil(N / R)`` agents: rank r owns agents [r * per, min(N, (r + 1) * per))."""
+    per = (n_agents + world - 1) // world
+    return per, [range(min(n_agents, r * per), min(n_agents, (r + 1) * per)) for r in range(world)]
+
+
+class AgentGather:
+    """Latency mode: the agents of ONE frame are split over the ranks, ``gather(feats)`` all-gathers the per-scale maps
+    (``[per, C, H, W]`` on every rank, unused rows arbitrary) into ``[n_agents, C, H, W]`` in agent order on every rank."""
+
+    def __init__(self, n_agents: int, group=None, wire_dtype: Optional[torch.dtype] = None):
+        self.n = n_agents
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.per, self.blocks = agent_blocks(self.world, self.n)
+        self.wire_dtype = wire_dtype
+        self._recv: Dict[tuple, torch.Tensor] = {}
+        self.bytes_sent_last = 0
+
+    def local_agents(self) -> range:
+        return self.blocks[self.rank]
+
+    def gather(self, feats: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        if self.world == 1:
+            return [f[: self.n] for f in feats]
+        out, sent = [], 0
+        for i, f in enumerate(feats):
+            assert f.shape[0] == self.per and f.is_contiguous()
+            send = f if self.wire_dtype is None else f.to(self.wire_dtype)
+            key = (i, tuple(send.shape), send.dtype, str(send.device))
+            recv = self._recv.get(key)
+            if recv is None:
+                recv = self._recv[key] = torch.empty((self.world * self.per,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+            if _is_gloo_cuda(send, self.group):
+                parts = [torch.empty(send.shape, dtype=send.dtype) for _ in range(self.world)]
+                dist.all_gather(parts, send.cpu(), group=self.group)
+                recv.copy_(torch.cat(parts))
+            else:
+                dist.all_gather_into_tensor(recv, send, group=self.group)
+            sent += (self.world - 1) * send.numel() * send.element_size()
+            full = recv[: self.n]                                # blocks are contiguous and in rank order: already agent order
+            out.append(full if self.wire_dtype is None else full.to(f.dtype))
+        self.bytes_sent_last = sent
         return out
 
-    def step(self, encode_fn: Callable[[], Sequence[torch.Tensor]], tail_fn: Callable[[List[torch.Tensor]], object]):
-        return tail_fn(self.exchange(encode_fn()))
+
+# ------------------------------------------------------------------------------------------------ routing real frames
+def split_agents(frame: dict) -> List[Dict[str, torch.Tensor]]:
+    """Collated frame (one frame, N agents) -> per-agent pillar sets (rows with ``voxel_coords[:, 0] == a``)."""
+    pl = frame["processed_lidar"]
+    n = int(frame["record_len"][0]) if torch.is_tensor(frame["record_len"]) else int(frame["record_len"][0])
+    agent = pl["voxel_coords"][:, 0]
+    out = []
+    for a in range(n):
+        sel = (agent == a).nonzero(as_tuple=True)[0]
+        out.append({k: pl[k].index_select(0, sel) for k in ("voxel_features", "voxel_coords", "voxel_num_points")})
+    return out
+
+
+def stack_agents(agent_sets: Sequence[Optional[Dict[str, torch.Tensor]]]) -> Dict[str, torch.Tensor]:
+    """Per-agent pillar sets -> one ``processed_lidar`` whose agent index is the position in ``agent_sets``
+    (``None`` = an empty slot: no pillars, all-zero canvas)."""
+    live = [(i, s) for i, s in enumerate(agent_sets) if s is not None]
+    feats = torch.cat([s["voxel_features"] for _, s in live])
+    npts = torch.cat([s["voxel_num_points"] for _, s in live])
+    coords = []
+    for i, s in live:
+        c = s["voxel_coords"].clone()
+        c[:, 0] = i
+        coords.append(c)
+    return {"voxel_features": feats, "voxel_coords": torch.cat(coords), "voxel_num_points": npts}
+
+
+def ring_batch(frames_by_agent: Sequence[Sequence[Dict[str, torch.Tensor]]], pairwise: Sequence[torch.Tensor], rank: int, world: int,
+               n_agents: int, step: int) -> dict:
+    """The batch rank ``rank`` works on in ring step ``step``: global frame ``step * world + f`` is frame f of the step; this
+    rank encodes agent a of frame (rank - a) mod world (slots in destination order) and is the ego of frame ``rank``, whose
+    pose matrices it carries.  ``frames_by_agent[g]`` = ``split_agents`` of pool frame g (indexed modulo the pool size)."""
+    pool = len(frames_by_agent)
+    sets = [frames_by_agent[(step * world + f) % pool][a] for f, a in encode_assignments(rank, world, n_agents)]
+    return {"processed_lidar": stack_agents(sets), "record_len": [n_agents], "pairwise_t_matrix": pairwise[(step * world + rank) % pool]}

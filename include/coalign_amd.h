@@ -93,6 +93,13 @@ int coalign_scatter_to_bev(const float *pillar_features, const int32_t *voxel_co
 enum { COALIGN_FUSE_ATT = 0, COALIGN_FUSE_MAX = 1, COALIGN_FUSE_NONE = 2 };
 int coalign_warp_fuse(const float *x, int n_total, int C, int H, int W, const double *theta, const int32_t *group_len,
                       int n_groups, int mode, float *out, int Ho, int Wo, void *stream);
+/* The same op when the agents of a frame do not sit in x in agent order (agent-sharded execution, coalign_amd/sharded.py: the
+ * receive buffer of the feature exchange is source-rank major).  rows [n_total] HOST int32 or NULL (= identity): for logical
+ * agent i of frame b (i = 0 is the ego), rows[off_b + i] is the row of that frame's block of x that holds it -- a permutation of
+ * 0..group_len[b]-1.  theta and the NONE-mode output stay in logical agent order; softmax / weighted sum run in logical order,
+ * so the result is bit-identical to the un-routed call (fusion_in_one.py:125-132 fixes that order through regroup). */
+int coalign_warp_fuse_rows(const float *x, int n_total, int C, int H, int W, const double *theta, const int32_t *group_len,
+                           int n_groups, const int32_t *rows, int mode, float *out, int Ho, int Wo, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * (3) Anchor decode: sigmoid + score threshold + box decode + direction-bin fix + 8 corners + projection +
@@ -155,12 +162,23 @@ int coalign_iou_rotated_matrix(const float *boxes_a, int rows_a, int cols_a, int
 
 /* ---------------------------------------------------------------------------------------------------------
  * (5) OpenPCDet-semantics BEV IoU (fp32 overlap with its 1e-2 corner margin) for callers of
- *     opencood/pcdet_utils/iou3d_nms/iou3d_nms_utils.py (boxes_iou_bev :47-63, nms_gpu :255-271).
+ *     opencood/pcdet_utils/iou3d_nms/iou3d_nms_utils.py (boxes_iou_bev :32-46, boxes_iou3d_gpu :147-181, nms_gpu :255-271, nms_normal_gpu :274-289).
  * boxes_a [Na, 7], boxes_b [Nb, 7] = (x, y, z, dx, dy, dz, heading) -> iou [Na, Nb]
  */
 int coalign_boxes_iou_bev(const float *boxes_a, int Na, const float *boxes_b, int Nb, float *iou, void *stream);
-/* same pairing, the overlap AREA instead of the IoU (iou3d_nms_cuda.boxes_overlap_bev_gpu, used by boxes_iou3d_gpu :66-98) */
+/* same pairing, the overlap AREA instead of the IoU (iou3d_nms_cuda.boxes_overlap_bev_gpu, used by boxes_iou3d_gpu :147-181) */
 int coalign_boxes_overlap_bev(const float *boxes_a, int Na, const float *boxes_b, int Nb, float *overlap, void *stream);
+
+/* Device bitmask NMS with OpenPCDet semantics -- replaces iou3d_nms_cuda.nms_gpu / nms_normal_gpu
+ * (opencood/pcdet_utils/iou3d_nms/src/iou3d_nms.cpp:90-137 + the host scan of the mask :121-133; kernels
+ * src/iou3d_nms_kernel.cu:267-311 nms_kernel, :328-372 nms_normal_kernel).  boxes_sorted [n, 7] must already be in descending
+ * score order (the Python caller sorts, like iou3d_nms_utils.py:264-269); a box is kept unless an earlier KEPT box has
+ * fp32 IoU > thresh with it (normal != 0: heading ignored, axis-aligned IoU of iou_normal :313-325).
+ * -> keep [n] int32 positions into boxes_sorted, ascending; *keep_count.  Nothing leaves the device (the reference copies the
+ * n x n/64 mask to the host and walks it there).  n <= 16384. */
+size_t coalign_pcdet_nms_workspace_bytes(int n);
+int coalign_pcdet_nms(const float *boxes_sorted, int n, float thresh, int normal, int32_t *keep, int32_t *keep_count, void *workspace,
+                      size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * (6) Fused convolution epilogue for the dense stages (rows E / I): in place  y = act(y + bias[c] (+ residual)).

@@ -317,6 +317,15 @@ def shrink_and_heads(x: torch.Tensor, sd, use_dir=True) -> Dict[str, torch.Tenso
     return out
 
 
+def naive_compressor(x: torch.Tensor, sd, prefix: str = "naive_compressor.") -> torch.Tensor:
+    """NaiveCompressor.forward, opencood/models/sub_modules/naive_compress.py:5-31: encoder = conv3x3 (64 -> 64 / r, bias) + BN(eps 1e-3)
+    + ReLU; decoder = two more such triples back to 64 channels (Sequential indices 0-1, 0-1, 3-4)."""
+    for conv, bn in (("encoder.0", "encoder.1"), ("decoder.0", "decoder.1"), ("decoder.3", "decoder.4")):
+        x = F.conv2d(x, sd[prefix + conv + ".weight"], sd[prefix + conv + ".bias"], stride=1, padding=1)
+        x = torch.relu(_bn2d(x, sd, prefix + bn + ".", 1e-3))
+    return x
+
+
 def coalign_forward(sd, margs: dict, batch: dict, return_intermediate: bool = False):
     """PointPillarBaselineMultiscale.forward, opencood/models/point_pillar_baseline_multiscale.py:93-135."""
     pl = batch["processed_lidar"]
@@ -329,6 +338,8 @@ def coalign_forward(sd, margs: dict, batch: dict, return_intermediate: bool = Fa
     H0, W0 = canvas.shape[2:]
     aff = normalize_pairwise_tfm(batch["pairwise_t_matrix"], H0, W0, margs["voxel_size"][0])
     bb = margs["base_bev_backbone"]
+    if "compression" in margs:                                    # point_pillar_baseline_multiscale.py:113-114
+        canvas = naive_compressor(canvas, sd)
     if bb.get("resnet", True):
         feats = resnet_stages(canvas, sd, bb["layer_nums"], bb["layer_strides"])
     else:
@@ -674,6 +685,27 @@ def pcdet_nms(boxes7: np.ndarray, scores: np.ndarray, thr: float, pre_max: Optio
     keep = np.empty(len(order), dtype=np.int32)
     n = _nms_lib().oracle_pcdet_nms(b.ctypes.data, len(order), ctypes.c_float(thr), keep.ctypes.data)
     return order[keep[:n]]
+
+
+def pcdet_nms_normal(boxes7: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarray:
+    """iou3d_nms_utils.nms_normal_gpu (:274-289): heading ignored, axis-aligned IoU (iou3d_nms_kernel.cu:313-325)."""
+    order = np.argsort(-scores, kind="stable")
+    b = np.ascontiguousarray(boxes7[order], dtype=np.float32)
+    keep = np.empty(len(order), dtype=np.int32)
+    lib = _nms_lib()
+    lib.oracle_pcdet_nms_normal.restype = ctypes.c_int
+    lib.oracle_pcdet_nms_normal.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+    n = lib.oracle_pcdet_nms_normal(b.ctypes.data, len(order), ctypes.c_float(thr), keep.ctypes.data)
+    return order[keep[:n]]
+
+
+def pcdet_min_margin(boxes7: np.ndarray, thr: float, normal: bool = False) -> float:
+    """min |IoU - thr| over the overlapping pairs (test helper, see rotated_nms.c)."""
+    b = np.ascontiguousarray(boxes7, dtype=np.float32)
+    lib = _nms_lib()
+    lib.oracle_pcdet_min_margin.restype = ctypes.c_float
+    lib.oracle_pcdet_min_margin.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int]
+    return float(lib.oracle_pcdet_min_margin(b.ctypes.data, len(b), ctypes.c_float(thr), int(normal)))
 
 
 # --------------------------------------------------------------------------------------

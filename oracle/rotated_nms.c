@@ -232,3 +232,42 @@ int oracle_pcdet_nms(const float *boxes7, int n, float thr, int *keep) {
     free(dead);
     return nk;
 }
+
+/* iou3d_nms_kernel.cu:313-325 (iou_normal): heading ignored, axis-aligned (x, y, dx, dy) rectangles in fp32. */
+float oracle_pcdet_iou_normal(const float *a, const float *b) {
+    const float lo_x = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), hi_x = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+    const float lo_y = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), hi_y = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+    const float w = fmaxf(hi_x - lo_x, 0.f), h = fmaxf(hi_y - lo_y, 0.f);
+    const float inter = w * h;
+    return inter / fmaxf(a[3] * a[4] + b[3] * b[4] - inter, 1e-8f);
+}
+
+/* nms_normal_gpu (iou3d_nms_utils.py:274-289): the same greedy walk on the axis-aligned IoU. */
+int oracle_pcdet_nms_normal(const float *boxes7, int n, float thr, int *keep) {
+    unsigned char *dead = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    int nk = 0;
+    for (int i = 0; i < n; ++i) {
+        if (dead[i]) continue;
+        keep[nk++] = i;
+        for (int j = i + 1; j < n; ++j)
+            if (!dead[j] && oracle_pcdet_iou_normal(boxes7 + 7 * i, boxes7 + 7 * j) > thr) dead[j] = 1;
+    }
+    free(dead);
+    return nk;
+}
+
+/* Smallest |IoU - thr| over all ordered pairs i < j whose IoU is not exactly 0 (test helper: tells a parity test whether a
+ * one-ulp difference between the device's and glibc's sinf / cosf / atan2f could flip a suppression decision). */
+float oracle_pcdet_min_margin(const float *boxes7, int n, float thr, int normal) {
+    float best = INFINITY;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            const float dx = boxes7[7 * i] - boxes7[7 * j], dy = boxes7[7 * i + 1] - boxes7[7 * j + 1];
+            if (dx * dx + dy * dy > 100.f) continue;               /* boxes <= 6 m long cannot touch beyond 10 m */
+            const float v = normal ? oracle_pcdet_iou_normal(boxes7 + 7 * i, boxes7 + 7 * j) : oracle_pcdet_iou(boxes7 + 7 * i, boxes7 + 7 * j);
+            if (v == 0.f) continue;
+            const float m = fabsf(v - thr);
+            if (m < best) best = m;
+        }
+    return best;
+}

@@ -592,6 +592,28 @@ def main():
     full["fusion_gen_seed"] = 13
     save("fullsize.npz", **full)
 
+    # ------------------------------------------------------------------ row D: NaiveCompressor (naive_compress.py:5-31)
+    # (a) the module alone, randomised BN statistics, ratios 2 and 8; (b) wired into the mini CoAlign model through the
+    # yaml's ``compression`` key (point_pillar_baseline_multiscale.py:50-53,113-114), end to end
+    from opencood.models.sub_modules.naive_compress import NaiveCompressor
+    comp = {}
+    gc = torch.Generator().manual_seed(21)
+    xin = torch.randn(1, 64, 16, 24, generator=gc)
+    comp["x"] = xin
+    for ratio in (2, 8):
+        nc = NaiveCompressor(64, ratio).eval()
+        fill_parameters_(nc, seed=40 + ratio)
+        comp[f"y_r{ratio}"] = nc(xin)
+        comp[f"keys_r{ratio}"] = np.array(list(nc.state_dict().keys()))
+    hc = load_hypes(YAML_COALIGN, MINI_RANGE)
+    hc["model"]["args"]["compression"] = 4
+    mc = train_utils.create_model(hc).eval()
+    fill_parameters_(mc, seed=0, cls_bias=-1.0)
+    oc = mc(frame)
+    comp.update(cls_preds=oc["cls_preds"], reg_preds=oc["reg_preds"], dir_preds=oc["dir_preds"], model_ratio=4,
+                state_keys=np.array(list(mc.state_dict().keys())))
+    save("naive_compress.npz", **comp)
+
 
 if __name__ == "__main__":
     main()

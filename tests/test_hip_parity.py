@@ -3,8 +3,8 @@
 size-independent properties at the full OPV2V sizes.  Run on the MI355X box with ``pytest -m gpu``.
 
 Tolerances (north_star: "within 1e-3 rel for fp32 BEV features, bit-exact for anchor indexing / NMS selection"):
-feature tensors are compared with rtol 1e-3 and an absolute floor of 1e-3 x the tensor's RMS-scale; measured
-differences are ~1e-6 and the tests additionally assert a much tighter bound on the mean error.
+feature tensors are compared with ``feat_close``: rtol 1e-4 plus an absolute floor of 1e-5 x the tensor's scale (measured
+differences are ~1e-6), and a mean-error bound of 1e-6 x scale.
 """
 import numpy as np
 import pytest
@@ -22,18 +22,22 @@ T = torch.from_numpy
 DEV = "cuda:0"
 
 
-def feat_close(got, ref, rtol=1e-3, what=""):
+def feat_close(got, ref, rtol=1e-4, what="", floor=1e-5):
+    """|got - ref| <= rtol * |ref| + floor * max|ref| element-wise, and mean error <= 1e-6 * max|ref|.  north_star asks for 1e-3
+    relative on fp32 BEV features; what is measured is ~1e-6, so the default is held an order of magnitude inside the requirement
+    (rtol 1e-4, absolute floor 1e-5 of the tensor's scale for elements near zero, where fp32 cancellation makes a relative bound
+    meaningless).  A test that needs the full 1e-3 passes it explicitly and says why."""
     got = got.detach().float().cpu()
     ref = ref if torch.is_tensor(ref) else T(np.asarray(ref))
     ref = ref.float()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     scale = float(ref.abs().max()) if ref.numel() else 1.0
     err = (got - ref).abs()
-    tol = rtol * ref.abs() + rtol * 1e-1 * scale
+    tol = rtol * ref.abs() + floor * scale
     bad = err > tol
     assert not bool(bad.any()), f"{what}: {int(bad.sum())} / {err.numel()} outside tolerance, max err {float(err.max()):.3e} (scale {scale:.3e})"
     if err.numel():
-        assert float(err.mean()) <= 1e-5 * max(scale, 1e-30), f"{what}: mean err {float(err.mean()):.3e} vs scale {scale:.3e}"
+        assert float(err.mean()) <= max(1e-6, rtol * 1e-2) * max(scale, 1e-30), f"{what}: mean err {float(err.mean()):.3e} vs scale {scale:.3e}"
 
 
 def pfn_state(g):
@@ -60,7 +64,7 @@ def test_pillar_golden_mini(golden):
     ref_canvas = oracle.scatter(T(g["pillar_features"]), T(g["voxel_coords"]), 5, 64, 32)
     empty = ref_canvas.abs().sum(dim=1) == 0                       # cells without a pillar: exactly zero
     assert bool((canvas.cpu().abs().sum(dim=1)[empty] == 0).all())
-    feat_close(canvas, oracle.scatter(feats.cpu(), T(g["voxel_coords"]), 5, 64, 32), rtol=0, what="scatter is a pure copy")
+    feat_close(canvas, oracle.scatter(feats.cpu(), T(g["voxel_coords"]), 5, 64, 32), rtol=0, floor=0, what="scatter is a pure copy")
 
 
 def test_pillar_fullsize_vs_oracle_and_reference(golden):
@@ -189,7 +193,7 @@ def test_fusion_properties():
     x = ego.repeat(4, 1, 1, 1)
     y = ops.warp_fuse(x, ident.repeat(4, 1, 1), [4], ops.FUSE_ATT)
     # (the identity warp itself is only exact to an ulp of the pixel coordinate: ix = j +- 3e-5 mixes in ~1e-4 of a neighbour)
-    feat_close(y, ego.cpu(), rtol=1e-3, what="identity pose, identical agents")
+    feat_close(y, ego.cpu(), what="identity pose, identical agents")
     # permuting the non-ego agents changes nothing but the fp summation order
     others = torch.randn(3, 64, 100, 352, generator=gen).to(DEV)
     th = torch.tensor([[[0.9, -0.1, 0.05], [0.3, 0.95, -0.02]], [[1.0, 0.0, 0.3], [0.0, 1.0, 0.1]], [[-1.0, 0.02, 0.0], [-0.1, -1.0, 0.0]]],

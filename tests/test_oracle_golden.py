@@ -348,3 +348,36 @@ def test_stage1_uncertainty_model_and_post_process_match_reference(golden):
         assert np.array_equal(unc[i].numpy(), g[f"unc{i}"])                      # same anchors kept, same order
         np.testing.assert_allclose(corners[i].numpy(), g[f"corners{i}"], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(boxes[i].numpy(), g[f"boxes{i}"], rtol=1e-5, atol=1e-5)
+
+
+def test_naive_compressor_matches_reference(golden):
+    """Row D: the oracle's restatement of NaiveCompressor (naive_compress.py:5-31) against the reference module (randomised BN
+    statistics, ratios 2 and 8) and against the reference model built from a yaml with ``compression: 4``."""
+    import copy
+    from coalign_amd.backbone import NaiveCompressor
+    from coalign_amd.detector import build_model
+    from coalign_amd.synthetic import fill_parameters_
+    g = golden("naive_compress.npz")
+    x = T(g["x"])
+    for ratio in (2, 8):
+        m = NaiveCompressor(64, ratio).eval()
+        fill_parameters_(m, seed=40 + ratio)
+        assert list(m.state_dict().keys()) == list(g[f"keys_r{ratio}"])          # checkpoint names of the reference module
+        sd = {"naive_compressor." + k: v for k, v in m.state_dict().items()}
+        y = oracle.naive_compressor(x, sd)
+        close(y, g[f"y_r{ratio}"], rtol=1e-5, atol=1e-6 * float(np.abs(g[f"y_r{ratio}"]).max()))
+        with torch.no_grad():
+            close(m(x), g[f"y_r{ratio}"], rtol=1e-5, atol=1e-6 * float(np.abs(g[f"y_r{ratio}"]).max()))   # the host mirror's plain-torch route
+    h = copy.deepcopy(builtin_config("mini_coalign"))
+    h["model"]["args"]["compression"] = int(g["model_ratio"])
+    model = build_model(h).eval()
+    fill_parameters_(model, seed=0, cls_bias=-1.0)
+    assert list(model.state_dict().keys()) == list(g["state_keys"])
+    gm = golden("model_mini.npz")
+    batch = {"processed_lidar": {"voxel_features": T(gm["voxel_features"]), "voxel_coords": T(gm["voxel_coords"]),
+                                 "voxel_num_points": T(gm["voxel_num_points"])},
+             "record_len": T(gm["record_len"]), "pairwise_t_matrix": T(gm["pairwise_t_matrix"])}
+    out = oracle.coalign_forward({k: v.clone() for k, v in model.state_dict().items()}, h["model"]["args"], batch)
+    for k in ("cls_preds", "reg_preds", "dir_preds"):
+        close(out[k], g[k], rtol=1e-4, atol=1e-4 * float(np.abs(g[k]).max()))
+        assert float(np.abs(g[k] - gm[k]).max()) > 1e-3                            # the compressor really changes the outputs

@@ -1,14 +1,18 @@
-"""World-size-2/3 gloo tests of the frame-ring exchange (CPU, no kernels): every rank must end up with exactly
-the agents of its own frame, in agent order, bit for bit."""
+"""World-size-2/3 gloo tests of the agent-sharded schedules (CPU tensors, no kernels): after the exchange every rank must
+hold exactly the agents of its own frame, addressable in agent order through the row table, bit for bit; the routing of real
+frames out of a shared pool reaches every (frame, agent) pair exactly once.  (The same schedules with the real kernels on a GPU:
+tests/test_sharded_gpu.py.)"""
 import os
-import sys
 
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from coalign_amd.sharded import FrameRing, encode_assignments, recv_plan, send_plan
+from coalign_amd.sharded import (AgentGather, FrameRing, agent_blocks, encode_assignments, recv_plan, ring_batch, send_plan, split_agents,
+                                 stack_agents)
+
+SHAPES = [(4, 6, 8), (8, 3, 4), (16, 2, 2)]
 
 
 def _tagged(frame, agent, shape):
@@ -16,27 +20,53 @@ def _tagged(frame, agent, shape):
     return torch.arange(int(torch.tensor(shape).prod()), dtype=torch.float32).reshape(shape) * 1e-3 + base
 
 
-def _worker(rank, world, n_agents, port, q):
+def _ring_worker(rank, world, n_agents, port, q, wire):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ring = FrameRing(n_agents)
-        shapes = [(4, 6, 8), (8, 3, 4), (16, 2, 2)]
-        local = encode_assignments(rank, world, n_agents)
-        feats = [torch.stack([_tagged(f, a, s) for f, a in local]) for s in shapes]
-        got = ring.exchange(feats)
-        ok = all(torch.equal(got[k][a], _tagged(rank, a, s)) for k, s in enumerate(shapes) for a in range(n_agents))
+        ring = FrameRing(n_agents, wire_dtype=wire)
+        local = ring.assignments()
+        assert local == encode_assignments(rank, world, n_agents)
+        feats = [torch.stack([_tagged(f, a, s) for f, a in local]) for s in SHAPES]
+        got, rows = ring.exchange(feats)
+        ok = sorted(rows) == list(range(n_agents))
+        for k, s in enumerate(SHAPES):
+            for a in range(n_agents):
+                want = _tagged(rank, a, s)
+                if wire is not None:
+                    want = want.to(wire).float()
+                ok = ok and torch.equal(got[k][rows[a]], want)
+        per_agent = sum(int(torch.tensor(s).prod()) for s in SHAPES) * (4 if wire is None else 2)
+        remote = sum(1 for f, a in local if f != rank)
+        ok = ok and ring.bytes_sent_last == remote * per_agent
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_agents", [(2, 5), (3, 2), (2, 1)])
-def test_frame_ring_exchange(world, n_agents):
+def _gather_worker(rank, world, n_agents, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ag = AgentGather(n_agents)
+        mine = list(ag.local_agents())
+        feats = []
+        for s in SHAPES:
+            rows = [_tagged(7, a, s) for a in mine] + [torch.full(s, -1.0)] * (ag.per - len(mine))      # unused slots: junk
+            feats.append(torch.stack(rows))
+        got = ag.gather(feats)
+        ok = all(g.shape[0] == n_agents for g in got)
+        ok = ok and all(torch.equal(got[k][a], _tagged(7, a, s)) for k, s in enumerate(SHAPES) for a in range(n_agents))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(target, world, args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + world * 7 + n_agents) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, world, n_agents, port, q)) for r in range(world)]
+    port = 29500 + (os.getpid() * 13 + world * 7 + hash(str(args)) % 997) % 2000
+    procs = [ctx.Process(target=target, args=(r, world) + tuple(args[:1]) + (port, q) + tuple(args[1:])) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -46,6 +76,16 @@ def test_frame_ring_exchange(world, n_agents):
     assert all(res[r] for r in range(world)), res
 
 
+@pytest.mark.parametrize("world,n_agents,wire", [(2, 5, None), (3, 2, None), (2, 1, None), (3, 5, torch.float16), (2, 5, torch.bfloat16)])
+def test_frame_ring_exchange(world, n_agents, wire):
+    _spawn(_ring_worker, world, (n_agents, wire))
+
+
+@pytest.mark.parametrize("world,n_agents", [(2, 5), (3, 5), (2, 2), (3, 2)])
+def test_agent_gather(world, n_agents):
+    _spawn(_gather_worker, world, (n_agents,))
+
+
 def test_plans_are_consistent():
     for world in (1, 2, 4, 5, 8):
         for n in (1, 2, 5, 8):
@@ -53,9 +93,10 @@ def test_plans_are_consistent():
             for r in range(world):
                 order, counts = send_plan(r, world, n)
                 assert sorted(order) == list(range(n)) and sum(counts) == n
+                dests = [(r - a) % world for a in order]
+                assert dests == sorted(dests)                      # local slot order IS destination order: no pack copy
                 for d in range(world):
                     total_sent[r][d] = counts[d]
-                # every frame gets each agent exactly once
             for r in range(world):
                 agents, counts = recv_plan(r, world, n)
                 assert sorted(agents) == list(range(n))
@@ -65,3 +106,42 @@ def test_plans_are_consistent():
                 for f, a in encode_assignments(r, world, n):
                     frames.setdefault(f, []).append(a)
             assert all(sorted(v) == list(range(n)) for v in frames.values()) and len(frames) == world
+            per, blocks = agent_blocks(world, n)
+            assert [a for b in blocks for a in b] == list(range(n)) and all(len(b) <= per for b in blocks)
+
+
+def _toy_frame(g, n_agents, pillars):
+    gen = torch.Generator().manual_seed(g)
+    coords = torch.cat([torch.stack([torch.full((pillars,), a), torch.zeros(pillars, dtype=torch.long), torch.arange(pillars), torch.arange(pillars) + g], 1)
+                        for a in range(n_agents)]).int()
+    m = coords.shape[0]
+    return {"processed_lidar": {"voxel_features": torch.randn(m, 4, 4, generator=gen), "voxel_coords": coords,
+                                "voxel_num_points": torch.randint(1, 5, (m,), generator=gen).int()},
+            "record_len": torch.tensor([n_agents]), "pairwise_t_matrix": torch.full((1, 5, 5, 4, 4), float(g), dtype=torch.float64)}
+
+
+def test_ring_batches_route_every_agent_of_every_pool_frame_once():
+    """Real-frame routing: over one period of steps the ranks together encode agent a of pool frame g exactly once, each rank
+    carries the pose matrices of the frame it is the ego of, and the local agent index is the slot."""
+    n, pool = 5, 8
+    frames = [_toy_frame(g, n, 3 + g) for g in range(pool)]
+    by_agent = [split_agents(f) for f in frames]
+    pair = [f["pairwise_t_matrix"] for f in frames]
+    for a in range(n):                                             # split + stack round trip
+        assert torch.equal(by_agent[2][a]["voxel_coords"][:, 0], torch.full((5,), a, dtype=torch.int32))
+    back = stack_agents(by_agent[2])
+    assert all(torch.equal(back[k], frames[2]["processed_lidar"][k]) for k in back)
+    for world in (1, 2, 4, 8):
+        seen = {}
+        for step in range(pool // world):
+            for r in range(world):
+                b = ring_batch(by_agent, pair, r, world, n, step)
+                assert float(b["pairwise_t_matrix"][0, 0, 0, 0, 0]) == (step * world + r) % pool       # my frame's poses
+                pl = b["processed_lidar"]
+                for slot, (f, a) in enumerate(encode_assignments(r, world, n)):
+                    g = (step * world + f) % pool
+                    sel = pl["voxel_coords"][:, 0] == slot
+                    assert torch.equal(pl["voxel_features"][sel], by_agent[g][a]["voxel_features"])
+                    assert torch.equal(pl["voxel_coords"][sel][:, 1:], by_agent[g][a]["voxel_coords"][:, 1:])
+                    seen[(g, a)] = seen.get((g, a), 0) + 1
+        assert seen == {(g, a): 1 for g in range(pool) for a in range(n)}
