@@ -1,6 +1,7 @@
-// 3x3 / stride 1 / pad 1 convolution with fused bias (+ residual) (+ ReLU), fp32 in / fp32 out, computed on the BF16 matrix
-// cores by error-free operand splitting ("fp32 emulation"), NCHW, gfx950.  OPT-IN (COALIGN_CONV_EMU, see backbone.py): the
-// default product path keeps every product in native fp32.
+// 3x3 / pad 1 convolution (stride 1 or 2) with fused bias (+ residual) (+ ReLU), fp32 in / fp32 out, computed on the BF16 matrix
+// cores by error-free operand splitting ("fp32 emulation"), gfx950.  The 3-way split is the product default (COALIGN_CONV_EMU,
+// backbone.py); NCHW in and out by default, optionally channels-last (NHWC) on the input or the output side (LAYOUT): the last
+// convolution of a ResNet stage writes its map channels-last for the fusion kernel and the next stage's strided convolution reads it.
 //
 // Same layers and semantics as conv3x3.hip (opencood/models/sub_modules/resblock.py:53-69, base_bev_backbone_resnet.py:59-138,
 // downsample_conv.py:7-50).  The fp32 MFMA runs at the VALU rate (157 TFLOP/s); v_mfma_f32_32x32x16_bf16 is 16x faster and
@@ -39,7 +40,8 @@ struct EmuArgs {
     const uint4 *__restrict__ wt;     // [Cout / 64][Cin / 8][5 steps][TERMS][2 k-groups][64 cout][8 bf16]
     const float *__restrict__ bias, *__restrict__ residual;
     float *__restrict__ y;
-    int N, Cin, Cout, H, W, relu, tiles_x, tiles_per_img, total_tiles;
+    int N, Cin, Cout, H, W, relu, tiles_x, tiles_per_img, total_tiles;      // H, W: OUTPUT size
+    int Hin, Win;                     // input size (== H, W for stride 1; H = ceil(Hin / 2) for stride 2)
     float *__restrict__ partial;      // [grid][16 * NCO][threads]: accumulators of a tile whose chunks are split over two workgroups
     int *flags;                       // [grid], zeroed per launch: flags[g] = 1 once workgroup g has published its partial tile
 #ifdef EMU_TRACE
@@ -55,12 +57,15 @@ struct EmuArgs {
 #define EMU_STAMP(k)
 #endif
 
-template <int BH, int BW, int NPB, int TERMS, int KCH>
+enum { LAYOUT_NCHW = 0, LAYOUT_OUT_NHWC = 1, LAYOUT_IN_NHWC = 2 };
+
+template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE = 1>
 struct Geo {
     static constexpr int NCO = NPB >= 4 ? 2 : 1;                              // accumulator tiles (32 output channels each) per wave
     static constexpr int WAVES = NPB >= 4 ? NPB : 2 * NPB;
     static constexpr int THREADS = 64 * WAVES;
-    static constexpr int TH = BH * NPB, TW = BW, PH = TH + 2, PW = TW + 2;    // halo patch: rows y0 - 1 .., columns x0 - 1 ..
+    static constexpr int TH = BH * NPB, TW = BW;                              // output tile
+    static constexpr int PH = STRIDE * TH + 3 - STRIDE, PW = STRIDE * TW + 3 - STRIDE;   // input halo patch: rows STRIDE * y0 - 1 .., columns STRIDE * x0 - 1 ..
     static constexpr int PIX = PH * PW;                                       // pixel slots of the patch
     static constexpr int SLOTS = (PIX + THREADS - 1) / THREADS;               // pixel slots one thread splits per chunk
     static constexpr int WQ = kSteps * TERMS * 2 * kCoutTile;                 // 16-byte groups of one weight chunk
@@ -92,14 +97,15 @@ __device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[T
 // The split variant's occupancy is pinned (registers capped): its hand-over code, executed once per split tile, would otherwise
 // cost a resident workgroup -- the spills it causes sit outside the chunk loop.  8 wavefronts x 2 workgroups = 4 per SIMD, 12
 // wavefronts = 3 per SIMD.  (Pinning the plain variant as well changes hipcc's scheduling and was measured 5-20 % slower.)
-template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT>
+template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT, int STRIDE = 1, int LAYOUT = LAYOUT_NCHW>
 __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB))
 __attribute__((amdgpu_waves_per_eu(SPLIT ? (NPB == 12 ? 3 : 4) : 1, SPLIT ? (NPB == 12 ? 3 : 4) : 8)))
 void conv3x3_emu_kernel(const EmuArgs a) {
-    using G = Geo<BH, BW, NPB, TERMS, KCH>;
+    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE>;
+    static_assert(!(SPLIT && (STRIDE != 1 || LAYOUT != LAYOUT_NCHW)), "stream-K hand-over only for the plain stride-1 NCHW variant");
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;      // wave: scalar
-    const size_t plane = (size_t)a.H * a.W;
+    const size_t plane = (size_t)a.H * a.W, plane_in = (size_t)a.Hin * a.Win;
     const int groups = a.Cout / kCoutTile, chunks = a.Cin / (kKC * KCH);       // `chunks`: barrier intervals per tile, KCH x 8 channels each
     auto decode = [&](int t) {
         Tile c;
@@ -117,7 +123,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) {
         const int t = 2 * s + half < 9 ? 2 * s + half : 8;
-        boff[s] = (py + t / 3) * G::PW + px + t % 3;
+        boff[s] = (STRIDE * py + t / 3) * G::PW + STRIDE * px + t % 3;
     }
     const int wlane = half * kCoutTile + cb + p;          // 16-byte group of this lane inside one (step, term) weight block
 
@@ -130,26 +136,40 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     };
     auto make_plan = [&](const Tile &t) {
         Plan pl;
-        pl.base = a.x + (size_t)t.n * a.Cin * plane;
+        pl.base = a.x + (size_t)t.n * a.Cin * plane_in;
         pl.wsrc = a.wt + (size_t)t.cg * chunks * (KCH * G::WQ) + lane;
 #pragma unroll
         for (int j = 0; j < G::SLOTS; ++j) {
             const int i = tid + j * G::THREADS;
             const int y = i / G::PW, xq = i - y * G::PW;
-            const int gy = t.y0 - 1 + y, gx = t.x0 - 1 + xq;
-            pl.off[j] = (i < G::PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? gy * a.W + gx : -1;
+            const int gy = STRIDE * t.y0 - 1 + y, gx = STRIDE * t.x0 - 1 + xq;
+            pl.off[j] = (i < G::PIX && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? gy * a.Win + gx : -1;
         }
         return pl;
     };
     // chunk c of the tile: the 8 input channels of this thread's pixel slots -> registers (plain coalesced loads: consecutive
     // lanes = consecutive pixels of a patch row; clamped address + zero select, no divergent branch around the loads)
     auto load_patch = [&](const Plan &pl, int c, float (&v)[G::SLOTS][8 * KCH]) {
-        const float *src = pl.base + (size_t)c * (kKC * KCH) * plane;
+        if constexpr (LAYOUT == LAYOUT_IN_NHWC) {          // channels-last input: the 8 channels of a pixel are 32 contiguous bytes
+            const float *src = pl.base + (size_t)c * (kKC * KCH);
 #pragma unroll
-        for (int j = 0; j < G::SLOTS; ++j) {
-            const int o = pl.off[j] < 0 ? 0 : pl.off[j];
+            for (int j = 0; j < G::SLOTS; ++j) {
+                const int o = pl.off[j] < 0 ? 0 : pl.off[j];
+                const float4 *q = reinterpret_cast<const float4 *>(src + (size_t)o * a.Cin);
 #pragma unroll
-            for (int k = 0; k < 8 * KCH; ++k) v[j][k] = src[(size_t)k * plane + o];
+                for (int k4 = 0; k4 < 2 * KCH; ++k4) {
+                    const float4 t = q[k4];
+                    v[j][4 * k4] = t.x; v[j][4 * k4 + 1] = t.y; v[j][4 * k4 + 2] = t.z; v[j][4 * k4 + 3] = t.w;
+                }
+            }
+        } else {
+            const float *src = pl.base + (size_t)c * (kKC * KCH) * plane_in;
+#pragma unroll
+            for (int j = 0; j < G::SLOTS; ++j) {
+                const int o = pl.off[j] < 0 ? 0 : pl.off[j];
+#pragma unroll
+                for (int k = 0; k < 8 * KCH; ++k) v[j][k] = src[(size_t)k * plane_in + o];
+            }
         }
     };
     // ... split into bf16 terms and written as [term][pixel slot][8 cin] into split-patch buffer `slot`
@@ -333,11 +353,22 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                     acc[q / 16][q % 16] += __hip_atomic_load(slot + (q / 16) * 1024 + (q % 16) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (live) {
+                if constexpr (LAYOUT == LAYOUT_OUT_NHWC) {      // channels-last output: accumulators 4 r .. 4 r + 3 are 4 consecutive channels
+                    float *yp = a.y + (((size_t)cur.n * a.H + gy) * a.W + gx) * a.Cout + cur.cg * kCoutTile + cb + 4 * half;
 #pragma unroll
-                for (int q = 0; q < 16 * G::NCO; ++q) {
-                    const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
-                    const float v = acc[q / 16][q % 16];
-                    a.y[obase + (size_t)c * plane] = a.relu ? fmaxf(v, 0.f) : v;
+                    for (int r = 0; r < 4 * G::NCO; ++r) {
+                        float4 o;
+                        o.x = acc[r / 4][4 * (r % 4)]; o.y = acc[r / 4][4 * (r % 4) + 1]; o.z = acc[r / 4][4 * (r % 4) + 2]; o.w = acc[r / 4][4 * (r % 4) + 3];
+                        if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                        *reinterpret_cast<float4 *>(yp + (r / 4) * 32 + 8 * (r % 4)) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16 * G::NCO; ++q) {
+                        const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
+                        const float v = acc[q / 16][q % 16];
+                        a.y[obase + (size_t)c * plane] = a.relu ? fmaxf(v, 0.f) : v;
+                    }
                 }
             }
         }
@@ -367,6 +398,54 @@ inline bool want_split(int total_tiles, int slots, int chunks) {
     if (chunks < 32 || total_tiles <= slots) return false;
     const int rounds = (total_tiles + slots - 1) / slots;
     return total_tiles * 10 < rounds * slots * 9;
+}
+
+// the strided / channels-last variants: whole tiles only (no stream-K), same persistent-workgroup schedule
+template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE, int LAYOUT>
+int launch_variant(const EmuArgs &a0, hipStream_t s) {
+    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE>;
+    static_assert(G::LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
+    static int resident = 0, cus = 0;
+    auto kern = conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, STRIDE, LAYOUT>;
+    if (!resident) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+        cus = prop.multiProcessorCount;
+        const int rc = coalign::hip_call(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+        if (rc != COALIGN_OK) {
+            (void)hipGetLastError();
+            return rc;
+        }
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, G::THREADS, G::LDS_BYTES) != hipSuccess || n < 1) n = 1;
+        resident = n;
+    }
+    EmuArgs a = a0;
+    a.tiles_x = (a.W + G::TW - 1) / G::TW;
+    a.tiles_per_img = a.tiles_x * ((a.H + G::TH - 1) / G::TH);
+    a.total_tiles = a.tiles_per_img * (a.Cout / kCoutTile) * a.N;
+    const int slots = cus * resident;
+    const int grid = a.total_tiles < slots ? a.total_tiles : slots;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+    return COALIGN_OK;
+}
+
+template <int TERMS>
+int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
+    if (stride == 2) {
+        // the input halo patch of a strided tile is (2 TH + 1) x 65 pixels: 6 rows per workgroup with the 3-way split (142 KB of LDS),
+        // 8 with the 2-way split
+        constexpr int NPB2 = TERMS == 3 ? 6 : 8;
+        if (layout == LAYOUT_NCHW) return launch_variant<1, 32, NPB2, TERMS, 1, 2, LAYOUT_NCHW>(a, s);
+        if (layout == LAYOUT_IN_NHWC) return launch_variant<1, 32, NPB2, TERMS, 1, 2, LAYOUT_IN_NHWC>(a, s);
+        return COALIGN_ERR_UNSUPPORTED;
+    }
+    if (layout == LAYOUT_OUT_NHWC) {
+        if (TERMS == 3 && a.H >= 64) return launch_variant<1, 32, 12, TERMS, 1, 1, LAYOUT_OUT_NHWC>(a, s);
+        return launch_variant<1, 32, 8, TERMS, 1, 1, LAYOUT_OUT_NHWC>(a, s);
+    }
+    return COALIGN_ERR_UNSUPPORTED;
 }
 
 template <int BH, int BW, int NPB, int TERMS, int KCH>
@@ -466,7 +545,7 @@ static int check_emu_args(int N, int Cin, int Cout, int H, int W, int terms) {
 
 extern "C" size_t coalign_conv3x3_emu_workspace_bytes(int N, int Cin, int Cout, int H, int W, int terms) {
     if (check_emu_args(N, Cin, Cout, H, W, terms) != COALIGN_OK || N == 0) return 0;
-    EmuArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, N, Cin, Cout, H, W, 0, 0, 0, 0, nullptr, nullptr};
+    EmuArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, N, Cin, Cout, H, W, 0, 0, 0, 0, H, W, nullptr, nullptr};
     Launch l{};
     const int rc = terms == 3 ? dispatch<3>(a, nullptr, 0, nullptr, &l) : dispatch<2>(a, nullptr, 0, nullptr, &l);
     return rc == COALIGN_OK && l.split ? l.ws_bytes : 0;
@@ -481,11 +560,32 @@ extern "C" int coalign_conv3x3_emu_bias_act(const float *x, const void *w_split,
     if (rc != COALIGN_OK) return rc;
     if (reinterpret_cast<uintptr_t>(w_split) & 15) return COALIGN_ERR_UNSUPPORTED;
     if (N == 0) return COALIGN_OK;
-    EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, nullptr, nullptr};
+    EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, H, W, nullptr, nullptr};
 #ifdef EMU_TRACE
     a.trace = g_emu_trace;
 #endif
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = terms == 3 ? dispatch<3>(a, workspace, workspace_bytes, s, nullptr) : dispatch<2>(a, workspace, workspace_bytes, s, nullptr);
+    return rc != COALIGN_OK ? rc : check_launch();
+}
+
+extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const float *bias, const float *residual, float *y, int N, int Cin,
+                                      int Cout, int Hin, int Win, int stride, int relu, int terms, int layout, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    using namespace coalign;
+    if (stride == 1 && layout == LAYOUT_NCHW)
+        return coalign_conv3x3_emu_bias_act(x, w_split, bias, residual, y, N, Cin, Cout, Hin, Win, relu, terms, workspace, workspace_bytes, stream);
+    if (!x || !w_split || !y || !bias) return COALIGN_ERR_NULL_POINTER;
+    if (stride != 1 && stride != 2) return COALIGN_ERR_UNSUPPORTED;
+    if (layout != LAYOUT_NCHW && layout != LAYOUT_OUT_NHWC && layout != LAYOUT_IN_NHWC) return COALIGN_ERR_UNSUPPORTED;
+    const int H = (Hin + stride - 1) / stride, W = (Win + stride - 1) / stride;          // 3x3, pad 1: floor((n + 2 - 3) / s) + 1
+    int rc = check_emu_args(N, Cin, Cout, Hin, Win, terms);
+    if (rc != COALIGN_OK) return rc;
+    if ((reinterpret_cast<uintptr_t>(w_split) & 15) || (layout != LAYOUT_NCHW && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15)))
+        return COALIGN_ERR_UNSUPPORTED;
+    if (N == 0) return COALIGN_OK;
+    EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, Hin, Win, nullptr, nullptr};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = terms == 3 ? dispatch_variant<3>(a, stride, layout, s) : dispatch_variant<2>(a, stride, layout, s);
     return rc != COALIGN_OK ? rc : check_launch();
 }

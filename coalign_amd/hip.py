@@ -45,6 +45,7 @@ SIGNATURES = {
     "coalign_conv3x3_emu_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
     "coalign_conv3x3_emu_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "coalign_conv3x3_emu_bias_act": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "coalign_conv3x3_emu_ex": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "coalign_pointwise_conv": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_pose_graph_workspace_bytes": (c_size_t, [c_int]),
     "coalign_pose_graph_optimize": (c_int, [c_int, P, P, P, c_int, P, P, P, P, P, P, c_int, P, P, c_size_t, P]),

@@ -408,32 +408,53 @@ def pack_conv3x3_emu_weight(weight: torch.Tensor, terms: int = 3) -> torch.Tenso
     return out
 
 
+LAYOUT_NCHW, LAYOUT_OUT_NHWC, LAYOUT_IN_NHWC = 0, 1, 2      # COALIGN_LAYOUT_* of include/coalign_amd.h
+
+
+def is_channels_last(t: torch.Tensor) -> bool:
+    """A 4-d tensor whose memory order is (N, H, W, C) and not at the same time plain NCHW (C > 1, H * W > 1)."""
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
+
 @_device_op
 def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Tensor, cout: int, residual: Optional[torch.Tensor] = None,
-                         relu: bool = True, terms: int = 3) -> torch.Tensor:
-    """y = act(conv3x3(x, w) + bias (+ residual)) with every fp32 product evaluated as `terms`-way split bf16 products on the
-    bf16 matrix cores, fp32 accumulation (csrc/conv3x3_emu.hip)."""
+                         relu: bool = True, terms: int = 3, stride: int = 1, out_channels_last: bool = False) -> torch.Tensor:
+    """y = act(conv3x3(x, w, stride, padding 1) + bias (+ residual)) with every fp32 product evaluated as `terms`-way split bf16
+    products on the bf16 matrix cores, fp32 accumulation (csrc/conv3x3_emu.hip).  A channels-last ``x`` is read in place by the
+    stride-2 variant; ``out_channels_last`` (stride 1) returns a tensor of logical shape [N, C, H, W] in channels-last memory."""
     _need_gpu(x, w_split, bias, residual)
     L = hip.lib()
-    xc = _f32c(x)
+    layout = LAYOUT_NCHW
+    if x.dtype == torch.float32 and stride == 2 and is_channels_last(x):
+        xc, layout = x, LAYOUT_IN_NHWC
+    else:
+        xc = _f32c(x)
     N, Cin, H, W = xc.shape
     if w_split.numel() != L.coalign_conv3x3_emu_weight_bytes(Cin, cout, terms):
         raise ValueError("split weight image does not match (Cin, Cout, terms)")
-    y = torch.empty((N, cout, H, W), dtype=torch.float32, device=xc.device)
+    if stride not in (1, 2) or (stride == 2 and (residual is not None or out_channels_last)):
+        raise ValueError("stride 2 takes no residual and writes NCHW")
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    if out_channels_last:
+        layout = LAYOUT_OUT_NHWC
+        y = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=xc.device, memory_format=torch.channels_last)
+    else:
+        y = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=xc.device)
     res = None if residual is None else _f32c(residual)
     if res is not None and res.shape != y.shape:
         raise ValueError("residual shape mismatch")
-    ws_bytes = L.coalign_conv3x3_emu_workspace_bytes(N, Cin, cout, H, W, terms)
-    ws = None
+    ws, ws_bytes = None, 0
+    if stride == 1 and layout == LAYOUT_NCHW:
+        ws_bytes = L.coalign_conv3x3_emu_workspace_bytes(N, Cin, cout, H, W, terms)
     if ws_bytes:
         key = (xc.device, torch.cuda.current_stream(xc.device).cuda_stream, "emu")
         ws = _CONV_WS.get(key)
         if ws is None or ws.numel() < ws_bytes:        # one workspace per (device, stream): launches on a stream are ordered
             ws = _CONV_WS[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=xc.device)
     with _Timed("conv3x3_emu_bias_act"):
-        hip.check(L.coalign_conv3x3_emu_bias_act(_ptr(xc), _ptr(w_split), _ptr(_f32c(bias)), _ptr(res), _ptr(y),
-                                                 N, Cin, cout, H, W, int(relu), terms, _ptr(ws), 0 if ws is None else ws.numel(), _stream()),
-                  "coalign_conv3x3_emu_bias_act")
+        hip.check(L.coalign_conv3x3_emu_ex(_ptr(xc), _ptr(w_split), _ptr(_f32c(bias)), _ptr(res), _ptr(y), N, Cin, cout, H, W, int(stride),
+                                           int(relu), terms, layout, _ptr(ws), 0 if ws is None else ws.numel(), _stream()),
+                  "coalign_conv3x3_emu_ex")
     return y
 
 

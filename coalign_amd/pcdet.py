@@ -33,7 +33,7 @@ def boxes_iou3d_gpu(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Tenso
 def _nms(boxes: torch.Tensor, scores: torch.Tensor, thresh: float, pre_maxsize, normal: bool):
     assert boxes.shape[1] == 7
     # stable: equal scores keep their input order (torch's default sort leaves ties implementation-defined, like the reference's)
-    order = scores.sort(0, descending=True, stable=True)[1]
+    order = scores.sort(dim=0, descending=True, stable=True)[1]
     if pre_maxsize is not None:
         order = order[:pre_maxsize]
     if order.numel() == 0:

@@ -162,6 +162,7 @@ class FramePipeline:
         done: List[FrameResult] = []
         if self.graph and self._lane_busy[k] is not None:
             done += self._collect_through(self._lane_busy[k])
+            t0 = time.perf_counter()
         record = host_ints(batch["record_len"])
         batch = dict(batch, record_len=record)
         stream = self.streams[k]
@@ -171,9 +172,9 @@ class FramePipeline:
                 handle = self._graphed(k, batch, record) if self.graph else self._eager(k, batch, record)
         self._lane_busy[k] = idx
         self._pending.append((idx, handle, batch))              # the batch stays referenced until its frame has completed
+        self.host_enqueue_s += time.perf_counter() - t0         # launch work only: waiting for older frames' results is GPU time
         while len(self._pending) > self.result_lag:
             done.append(self._pop())
-        self.host_enqueue_s += time.perf_counter() - t0
         return done
 
     def _pop(self) -> FrameResult:

@@ -122,6 +122,25 @@ def fill_parameters_(module: torch.nn.Module, seed: int = 0, cls_bias: float = -
             t.copy_(v.to(t.dtype))
 
 
+def calibrate_heads_(model: torch.nn.Module, batch: Dict, score_threshold: float, target: int = 600) -> None:
+    """Make a random-init detector's heads behave like a trained one's on ``batch`` ("head biases shifted so K ~ 300-1000
+    candidates"): box deltas of std 0.1 (decoded boxes stay car sized and pass the size / z sanity filters, neighbouring anchors
+    overlap -> NMS has work), classification logits of unit variance (scores spread over (0, 1): no pile-up of candidates at a
+    saturated score of exactly 1.0, whose order would be decided by tie-breaking alone) and a bias that puts ~``target`` anchors
+    above the score threshold.  Deterministic given (weights, batch)."""
+    import math
+    with torch.no_grad():
+        out = model(batch)
+        model.reg_head.weight *= 0.1 / float(out["reg_preds"].std())
+        model.reg_head.bias.zero_()
+        model.cls_head.weight *= 1.0 / float(out["cls_preds"].std())
+        model.cls_head.bias.zero_()
+        logits = model(batch)["cls_preds"].flatten()
+        k = min(target, logits.numel() - 1)
+        v = torch.topk(logits, k + 1).values[-1]
+        model.cls_head.bias += (math.log(score_threshold / (1 - score_threshold)) - float(v))
+
+
 def make_point_cloud(seed: int, beams: int = 64, azimuth_steps: int = 1800, sensor_height: float = 1.9, max_range: float = 120.0,
                      n_boxes: int = 30, dropout: float = 0.3) -> np.ndarray:
     """A spinning-lidar sweep [N, 4] float32 (x, y, z, intensity) in the sensor frame, N ~ 60-70 k like one OPV2V cav

@@ -287,6 +287,15 @@ size_t coalign_conv3x3_emu_workspace_bytes(int N, int Cin, int Cout, int H, int 
 int coalign_conv3x3_emu_bias_act(const float *x, const void *w_split, const float *bias, const float *residual, float *y,
                                  int N, int Cin, int Cout, int H, int W, int relu, int terms, void *workspace, size_t workspace_bytes,
                                  void *stream);
+/* The same convolution with a stride and a memory layout: stride 1 or 2 (3x3, pad 1: output ceil(Hin / stride) x ceil(Win / stride);
+ * the strided first convolution of a ResNet stage, resblock.py:150-174), layout 0 = NCHW in and out, 1 = NCHW in / channels-last
+ * (NHWC) out (stride 1 only: the last convolution of a stage, whose map the fusion kernel and the next stage read), 2 = NHWC in /
+ * NCHW out (stride 2 only).  residual (stride 1) is always NCHW.  workspace as coalign_conv3x3_emu_workspace_bytes for
+ * (stride 1, layout 0); the other variants need none. */
+enum { COALIGN_LAYOUT_NCHW = 0, COALIGN_LAYOUT_OUT_NHWC = 1, COALIGN_LAYOUT_IN_NHWC = 2 };
+int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const float *bias, const float *residual, float *y, int N, int Cin,
+                           int Cout, int Hin, int Win, int stride, int relu, int terms, int layout, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * (10) Pointwise layers of the BEV backbone as one GEMM launch each, bias (+ ReLU) fused, NCHW float32:

@@ -37,3 +37,14 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     return load
+
+
+@pytest.fixture(params=[3, 0], ids=["bf16x3_default", "native_fp32"])
+def conv_mode(request):
+    """Model-level parity tests run once per 3x3-convolution arithmetic: the product default (3-way split bf16 products, fp32
+    accumulation) and the native-fp32 route (COALIGN_CONV_EMU=0); both are held to the same tolerances."""
+    from coalign_amd import backbone
+    saved = backbone.CONV_EMU_TERMS
+    backbone.CONV_EMU_TERMS = request.param
+    yield request.param
+    backbone.CONV_EMU_TERMS = saved

@@ -37,7 +37,7 @@ def feat_close(got, ref, rtol=1e-4, what="", floor=1e-5):
     bad = err > tol
     assert not bool(bad.any()), f"{what}: {int(bad.sum())} / {err.numel()} outside tolerance, max err {float(err.max()):.3e} (scale {scale:.3e})"
     if err.numel():
-        assert float(err.mean()) <= max(1e-6, rtol * 1e-2) * max(scale, 1e-30), f"{what}: mean err {float(err.mean()):.3e} vs scale {scale:.3e}"
+        assert float(err.mean()) <= max(1e-6, 0.1 * floor) * max(scale, 1e-30), f"{what}: mean err {float(err.mean()):.3e} vs scale {scale:.3e}"
 
 
 def pfn_state(g):
@@ -193,7 +193,9 @@ def test_fusion_properties():
     x = ego.repeat(4, 1, 1, 1)
     y = ops.warp_fuse(x, ident.repeat(4, 1, 1), [4], ops.FUSE_ATT)
     # (the identity warp itself is only exact to an ulp of the pixel coordinate: ix = j +- 3e-5 mixes in ~1e-4 of a neighbour)
-    feat_close(y, ego.cpu(), what="identity pose, identical agents")
+    # an "identity" theta still leaves sub-pixel residue in float32 (ix = j +- 1e-5), so the bilinear tap mixes ~1e-5 of the neighbour
+    # in -- exactly like F.grid_sample does: hold the property to 1e-4 of the map's scale, not to rounding
+    feat_close(y, ego.cpu(), what="identity pose, identical agents", floor=1e-4)
     # permuting the non-ego agents changes nothing but the fp summation order
     others = torch.randn(3, 64, 100, 352, generator=gen).to(DEV)
     th = torch.tensor([[[0.9, -0.1, 0.05], [0.3, 0.95, -0.02]], [[1.0, 0.0, 0.3], [0.0, 1.0, 0.1]], [[-1.0, 0.02, 0.0], [-0.1, -1.0, 0.0]]],
@@ -310,7 +312,7 @@ def _batch_from(g):
             "record_len": T(g["record_len"]), "pairwise_t_matrix": T(g["pairwise_t_matrix"])}
 
 
-def test_model_mini_vs_reference(golden):
+def test_model_mini_vs_reference(golden, conv_mode):
     from coalign_amd.detector import to_device
     g = golden("model_mini.npz")
     h = builtin_config("mini_coalign")
@@ -329,7 +331,7 @@ def test_model_mini_vs_reference(golden):
         feat_close(out[k], g[k], what=k + " vs reference")
 
 
-def test_model_fullsize_vs_oracle_and_postprocess():
+def test_model_fullsize_vs_oracle_and_postprocess(conv_mode):
     """cfg 2 (OPV2V CoAlign, 2 agents, full 704x200 canvas): HIP path vs the CPU oracle end to end,
     then identical detections after post-processing."""
     h = builtin_config("opv2v_coalign")
@@ -358,7 +360,7 @@ def test_model_fullsize_vs_oracle_and_postprocess():
 
 
 # ------------------------------------------------------------------------------------------------ other configs / API level
-def test_late_fusion_pointpillar_vs_reference_and_oracle(golden):
+def test_late_fusion_pointpillar_vs_reference_and_oracle(golden, conv_mode):
     """cfg 1: single-agent PointPillar (plain BaseBEVBackbone) per cav + one merged post-process."""
     from coalign_amd.detector import to_device
     from coalign_amd.inference import inference_late_fusion
@@ -589,7 +591,7 @@ def test_voxelize_edge_cases(golden):
         ops.voxelize(T(cloud), [0, len(cloud)], OPV2V_VOXEL, OPV2V_RANGE, 32, 70000)
 
 
-def test_voxelize_feeds_the_detector():
+def test_voxelize_feeds_the_detector(conv_mode):
     """points -> pillars -> PillarVFE -> canvas on the device equals the oracle chain on the CPU."""
     from coalign_amd.preprocess import build_preprocessor
     from coalign_amd.synthetic import make_point_cloud
@@ -680,7 +682,7 @@ def test_box_alignment_end_to_end_vs_reference(golden):
     np.testing.assert_allclose(got[:, :2], g[f"{t}_solution"][:n, :2], rtol=0, atol=1e-6)
 
 
-def test_stage1_model_and_post_process_vs_reference(golden):
+def test_stage1_model_and_post_process_vs_reference(golden, conv_mode):
     """Stage 1 of box alignment on the device: PointPillarUncertainty (pillar kernel + MIOpen + merged 1x1 heads incl. unc_head)
     and UncertaintyVoxelPostprocessor.post_process_stage1 (decode with identity transform, per-agent NMS without the sanity
     mask, uncertainty gather) -- same kept anchors in the same order as the reference, boxes within float32 rounding."""
@@ -821,7 +823,7 @@ def test_conv3x3_emu_bias_act_vs_fp64(shape, terms, tol):
     assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max())
 
 
-def test_batch_dict_producer_on_device_vs_reference_dataset(golden):
+def test_batch_dict_producer_on_device_vs_reference_dataset(golden, conv_mode):
     """next-4 end to end: raw per-cav records -> IntermediateFusionBatcher with the device voxeliser -> the batch the reference's
     dataset + collate produce (bit-identical pillars, poses, transforms, ground truth), and the detector + post-process +
     evaluation run straight off that batch."""

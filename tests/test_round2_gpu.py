@@ -115,7 +115,7 @@ def test_pcdet_nms_edge_cases():
     far = one.repeat(130, 1)
     far[:, 0] = torch.arange(130, device=DEV) * 10.0         # disjoint boxes: everything survives, in score order
     sc = torch.rand(130, device=DEV)
-    assert pcdet.nms_gpu(far, sc, 0.01)[0].tolist() == sc.sort(descending=True, stable=True)[1].tolist()
+    assert pcdet.nms_gpu(far, sc, 0.01)[0].tolist() == sc.sort(dim=0, descending=True, stable=True)[1].tolist()
 
 
 # ------------------------------------------------------------------------------------------------ agent row table
@@ -153,3 +153,35 @@ def test_bias_act_many_planes():
     want = torch.relu(y + b.view(1, C, 1, 1) + r)
     got = ops.bias_act_(y.clone(), b, r, True)
     assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------ strided / channels-last convolution
+@pytest.mark.parametrize("terms,tol", [(3, 5e-6), (2, 2e-5)])
+@pytest.mark.parametrize("shape", [(5, 64, 64, 200, 704), (3, 64, 128, 100, 352), (2, 128, 256, 50, 176), (2, 64, 64, 37, 53), (1, 8, 64, 5, 4), (1, 16, 64, 1, 1), (2, 64, 64, 200, 504)])
+def test_conv3x3_emu_stride2_and_layouts_vs_fp64(shape, terms, tol):
+    """coalign_conv3x3_emu_ex: the stride-2 first convolution of every ResNet stage (resblock.py:150-174; odd and even map sizes,
+    the 704 x 200 canvas) against the fp64 convolution, from NCHW and from channels-last input (bit-identical to each other), and the
+    channels-last OUTPUT variant of the stride-1 kernel (bit-identical values to the NCHW one)."""
+    import torch.nn.functional as F
+    N, Ci, Co, H, W = shape
+    gen = torch.Generator(device="cpu").manual_seed(sum(shape) + terms)
+    x = torch.randn(N, Ci, H, W, generator=gen).to(DEV)
+    w = (torch.randn(Co, Ci, 3, 3, generator=gen) / (Ci * 9) ** 0.5).to(DEV)
+    b = torch.randn(Co, generator=gen).to(DEV)
+    ws = ops.pack_conv3x3_emu_weight(w, terms)
+    want = torch.relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1))
+    got = ops.conv3x3_emu_bias_act(x, ws, b, Co, None, True, terms, stride=2)
+    assert got.shape == want.shape and got.is_contiguous()
+    assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max())
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    if ops.is_channels_last(xcl):
+        got_cl = ops.conv3x3_emu_bias_act(xcl, ws, b, Co, None, True, terms, stride=2)
+        assert got_cl.is_contiguous() and torch.equal(got_cl, got)
+    nor = ops.conv3x3_emu_bias_act(x, ws, b, Co, None, False, terms, stride=2)
+    assert float((nor.double() - F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)).abs().max()) <= tol * float(want.abs().max())
+    if Ci == Co:                                             # stride 1, channels-last output, with residual
+        r = torch.randn(N, Co, H, W, generator=gen).to(DEV)
+        y_nchw = ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, terms)
+        y_cl = ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, terms, out_channels_last=True)
+        assert y_cl.shape == y_nchw.shape and (ops.is_channels_last(y_cl) or H * W == 1)
+        assert torch.equal(y_cl.contiguous(), y_nchw)

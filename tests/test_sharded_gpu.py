@@ -15,11 +15,10 @@ N_AGENTS, POOL, PILLARS = 3, 4, 3000
 
 
 def _setup():
-    import math
     from coalign_amd.config import builtin_config
     from coalign_amd.detector import build_model, to_device
     from coalign_amd.postprocess import build_postprocessor
-    from coalign_amd.synthetic import fill_parameters_, make_frame
+    from coalign_amd.synthetic import calibrate_heads_, fill_parameters_, make_frame
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     h = builtin_config("opv2v_coalign")
@@ -32,12 +31,7 @@ def _setup():
     fill_parameters_(model, seed=0)
     model = model.to(dev).eval()
     pp = build_postprocessor(h["postprocess"], False)
-    with torch.no_grad():                                   # deterministic calibration: same frame, same weights on every rank
-        out = model(frames[0])
-        model.reg_head.weight *= 0.1 / float(out["reg_preds"].std())
-        model.reg_head.bias.zero_()
-        v = torch.topk(out["cls_preds"].flatten(), 401).values[-1]
-        model.cls_head.bias += (math.log(0.2 / 0.8) - float(v))
+    calibrate_heads_(model, frames[0], 0.2, 400)            # deterministic: same frame, same weights on every rank
     anchors = torch.from_numpy(pp.generate_anchor_box())
     meta = {"ego": {"transformation_matrix": torch.eye(4, device=dev), "anchor_box": anchors}}
     return h, frames, model, pp, anchors, meta
