@@ -58,6 +58,11 @@ HIP_CONV_POLICY = os.environ.get("COALIGN_HIP_CONV", "stage1")      # measuremen
 # at import; the module attribute is read at every call (tests / bench.py set it directly).
 CONV_EMU_TERMS = int(os.environ.get("COALIGN_CONV_EMU", "3"))
 
+# With the split-bf16 convolutions active, the LAST convolution of every ResNet stage writes its map channels-last (logical shape
+# [N, C, H, W], NHWC memory): the fusion kernel then gathers C contiguous floats per bilinear tap (csrc/warp_fuse_nhwc.hip) and the
+# next stage's strided convolutions read the map in place.  Everything else stays NCHW.  0 switches the route off (measurement aid).
+NHWC_STAGE_OUTPUTS = os.environ.get("COALIGN_NHWC_STAGES", "1") != "0"
+
 
 class Conv3x3Pack:
     """Device images of one folded 3x3 weight, built on first use: the fp32 LDS image and the split-bf16 images."""
@@ -186,10 +191,13 @@ class BasicBlock(nn.Module):
             return w1, b1, w2, b2, wd, p1, p2, pd
         return _cache_of(self).get(self, build)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, out_channels_last: bool = False) -> torch.Tensor:
         if _fast_ok(self, x):
             w1, b1, w2, b2, wd, p1, p2, pd = self._folded()
-            x = x.contiguous()
+            emu = CONV_EMU_TERMS in (2, 3)
+            # a channels-last input (the previous stage's output) is read in place by the strided convolution and the pointwise skip
+            if not (ops.is_channels_last(x) and emu and self.stride == 2 and p1 is not None and pd is not None):
+                x = x.contiguous()
             y = conv3x3_fused(x, p1, w1, b1, None, self.stride)
             if wd is None:
                 skip = x
@@ -197,7 +205,7 @@ class BasicBlock(nn.Module):
                 skip = ops.pointwise_conv(x, pd[0], pd[1], wd.shape[0], in_stride=2, relu=False)      # its BN shift already sits in b2
             else:
                 skip = F.conv2d(x, wd, None, self.stride)
-            return conv3x3_fused(y, p2, w2, b2, skip)
+            return conv3x3_fused(y, p2, w2, b2, skip, out_channels_last=out_channels_last and emu and p2 is not None and p2.cout in (64, 128, 256))
         skip = x if self.downsample is None else self.downsample(x)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
@@ -229,7 +237,12 @@ class ResNetStages(nn.Module):
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
         feats = []
         for i in range(self.layernum):
-            x = getattr(self, f"layer{i}")(x)
+            layer = getattr(self, f"layer{i}")
+            if NHWC_STAGE_OUTPUTS and CONV_EMU_TERMS in (2, 3) and _fast_ok(self, x):
+                for j, blk in enumerate(layer):
+                    x = blk(x, out_channels_last=(j == len(layer) - 1))
+            else:
+                x = layer(x)
             feats.append(x)
         return feats
 
@@ -458,6 +471,8 @@ class NaiveCompressor(nn.Module):
 
     def forward(self, x):
         if _fast_ok(self, x):
+            x = x.contiguous()                       # a channels-last canvas is converted once; the convolutions below are NCHW
+
             def build():
                 seqs = [self.encoder, self.decoder[0:3], self.decoder[3:6]]
                 return [fold_bn(q[0].weight, q[0].bias, q[1]) for q in seqs]

@@ -21,7 +21,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip.so")
 INCLUDE = os.path.join(REPO, "include")
-SOURCES = ["status.cpp", "pillar_scatter.hip", "warp_fuse.hip", "decode.hip", "nms.hip", "epilogue.hip", "voxelize.hip", "pose_graph.hip", "conv3x3.hip", "conv3x3_emu.hip", "pointwise.hip"]
+SOURCES = ["status.cpp", "pillar_scatter.hip", "warp_fuse.hip", "warp_fuse_nhwc.hip", "decode.hip", "nms.hip", "epilogue.hip", "voxelize.hip", "pose_graph.hip", "conv3x3.hip", "conv3x3_emu.hip", "pointwise.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-cuda-compat", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}"]
 

@@ -502,6 +502,105 @@ __global__ __launch_bounds__(256) void pillar_canvas_kernel(FusedArgs f) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Channels-last canvas [n_agents, ny, nx, C]: a pillar's feature row IS its canvas cell (C contiguous floats), so the scatter is one
+// 256-byte store per pillar and the dense canvas is a plain memset (6.8 TB/s on this chip) -- no strips, no LDS feature buffer, no
+// read-back.  One wavefront encodes two pillars (pfn_pair), writes their pillar_features rows and, for the pillar that owns its
+// cell in the cell map ("larger row wins"), the canvas row.  Launch order on the stream: memset(canvas), memset(cell map),
+// cellmap_kernel, this.
+struct PairIn {     // lanes 0-31: pillar A's point / count / coords, lanes 32-63: pillar B's
+    float4 q;
+    int np;
+    int4 cd;
+};
+
+__device__ __forceinline__ PairIn pair_load(const PfnArgs &a, int lane, int mA) {
+    const int half = lane >> 5, pl = lane & 31;
+    const int m = mA + half;
+    PairIn in;
+    in.q = make_float4(0.f, 0.f, 0.f, 0.f);
+    in.np = 0;
+    in.cd = make_int4(-1, 0, 0, 0);
+    if (m < a.M) {
+        if (pl < a.P) in.q = a.pts[(size_t)m * a.P + pl];
+        in.np = a.npts[m];
+        in.cd = a.coords[m];
+    }
+    return in;
+}
+
+// pfn_pair's arithmetic on already loaded operands (same instruction sequence, so the rows are bit-identical to the NCHW route)
+__device__ __forceinline__ void pair_compute(const PfnArgs &a, const ChanParams &cp, float *slab, int lane, const PairIn &in, bool hasB,
+                                             float &va, float &vb) {
+    const int pl = lane & 31;
+    const float4 q = in.q;
+    const int np_eff = min(max(in.np, 0), a.P);
+    const float npf = (float)in.np;
+    const float mx = half_sum(q.x) / npf, my = half_sum(q.y) / npf, mz = half_sum(q.z) / npf;
+    const float ctr_x = (float)in.cd.w * a.vx + a.xo;
+    const float ctr_y = (float)in.cd.z * a.vy + a.yo;
+    const float ctr_z = (float)in.cd.y * a.vz + a.zo;
+    if (pl < np_eff) stage_point(a, slab, lane, q, mx, my, mz, ctr_x, ctr_y, ctr_z);   // row = lane: A -> 0.., B -> 32..
+    coalign::wave_lds_sync();
+    const int npA = __builtin_amdgcn_readlane(np_eff, 0), npB = __builtin_amdgcn_readlane(np_eff, 32);
+    va = rows_max(cp, slab, 0, npA, a.P);
+    vb = hasB ? rows_max(cp, slab, 32, npB, a.P) : 0.f;
+    coalign::wave_lds_sync();
+}
+
+// Persistent wavefronts: the channel parameters are loaded once, the operands of the NEXT pair and the cell-map entry of the
+// current one are in flight while the current pair is encoded -- one exposed memory round trip per wave instead of four per pair.
+__global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_nhwc_kernel(PfnArgs a, float *__restrict__ canvas) {
+    __shared__ __attribute__((aligned(16))) float slabs[kWavesPerBlock * 64 * kFeatStride];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *slab = slabs + wv * 64 * kFeatStride;
+    const int gwave = blockIdx.x * kWavesPerBlock + wv, nwave = gridDim.x * kWavesPerBlock;
+    const int npairs = (a.M + 1) / 2;
+    if (gwave >= npairs) return;
+    const int ncell = a.ny * a.nx;
+    // cell-map slot of a lane's pillar (lanes 0 / 32 speak for A / B), -1 when the pillar lies outside the canvas
+    auto slot_of = [&](const PairIn &p) -> long {
+        const int cell = p.cd.y + p.cd.z * a.nx + p.cd.w;                // z + y * nx + x (point_pillar_scatter.py:54)
+        const bool ok = p.cd.x >= 0 && p.cd.x < a.n_agents && cell >= 0 && cell < ncell;
+        return ok ? (long)p.cd.x * ncell + cell : -1;
+    };
+    PairIn nxt = pair_load(a, lane, 2 * gwave);
+    const ChanParams cp = load_chan(a, lane);
+    long slot_nxt = slot_of(nxt);
+    int owner_nxt = a.cellmap[slot_nxt < 0 ? 0 : slot_nxt];
+    for (int pair = gwave; pair < npairs; pair += nwave) {
+        const PairIn in = nxt;
+        const long slot = slot_nxt;
+        const int owner = owner_nxt;
+        const int mA = 2 * pair;
+        const bool hasB = mA + 1 < a.M;
+        const bool more = pair + nwave < npairs;
+        if (more) nxt = pair_load(a, lane, 2 * (pair + nwave));
+        float va, vb;
+        pair_compute(a, cp, slab, lane, in, hasB, va, vb);
+        // The next pair's owner lookup goes out BEFORE this pair's stores: vmcnt retires in order and counts stores, so a load
+        // issued behind the stores would make the next iteration wait for them to reach memory (measured: 5 us per pair).
+        if (more) {
+            slot_nxt = slot_of(nxt);
+            owner_nxt = a.cellmap[slot_nxt < 0 ? 0 : slot_nxt];
+        }
+        const int m_lane = mA + (lane >> 5);
+        const bool win = slot >= 0 && owner == m_lane && m_lane < a.M;
+        const int winA = __builtin_amdgcn_readlane((int)win, 0), winB = __builtin_amdgcn_readlane((int)win, 32);
+        const unsigned slo = (unsigned)(unsigned long)slot, shi = (unsigned)((unsigned long)slot >> 32);
+        const size_t slotA = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)shi, 0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)slo, 0);
+        const size_t slotB = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)shi, 32) << 32) | (unsigned)__builtin_amdgcn_readlane((int)slo, 32);
+        if (lane < a.C) {
+            a.feats[(size_t)mA * a.C + lane] = va;
+            if (winA) canvas[slotA * a.C + lane] = va;
+            if (hasB) {
+                a.feats[(size_t)(mA + 1) * a.C + lane] = vb;
+                if (winB) canvas[slotB * a.C + lane] = vb;
+            }
+        }
+    }
+}
+
 int launch_canvas(const int *cellmap, const float *feats, int C, int ncell, int n_agents, float *canvas, hipStream_t stream) {
     const int ch_per_block = 16;
     const int ych = (C + ch_per_block - 1) / ch_per_block;
@@ -524,12 +623,12 @@ size_t coalign_pillar_scatter_workspace_bytes(int n_agents, int ny, int nx) {
     return coalign::align_up((size_t)n_agents * ny * nx * sizeof(int), 256);
 }
 
-int coalign_pillar_vfe_scatter(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords,
+static int pillar_vfe_scatter_impl(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords,
                                int M, int P, const float *pfn_weight, const float *pfn_bias, const float *bn_weight,
                                const float *bn_bias, const float *bn_mean, const float *bn_var, float bn_eps, int C,
                                int use_absolute_xyz, int with_distance, const double *voxel_size, const double *range_min,
                                int n_agents, int ny, int nx, float *pillar_features, float *canvas, void *workspace,
-                               size_t workspace_bytes, void *stream_) {
+                               size_t workspace_bytes, void *stream_, bool nhwc) {
     using namespace coalign;
     hipStream_t stream = (hipStream_t)stream_;
     if (M < 0 || P <= 0 || C <= 0 || n_agents <= 0 || ny <= 0 || nx <= 0) return COALIGN_ERR_BAD_SHAPE;
@@ -541,11 +640,13 @@ int coalign_pillar_vfe_scatter(const float *voxel_features, const int32_t *voxel
     if (workspace_bytes < coalign_pillar_scatter_workspace_bytes(n_agents, ny, nx)) return COALIGN_ERR_WORKSPACE;
     const int Cin = (use_absolute_xyz ? 4 : 1) + 6 + (with_distance ? 1 : 0);
     if (Cin > kFeatStride) return COALIGN_ERR_UNSUPPORTED;
+    if (nhwc && (P > 32 || C > 64)) return COALIGN_ERR_UNSUPPORTED;       // two pillars per wavefront, lane = channel
 
     const int ncell = ny * nx;
     int *cellmap = (int *)workspace;
     int rc = hip_call(hipMemsetAsync(cellmap, 0xFF, (size_t)n_agents * ncell * sizeof(int), stream));
     if (rc) return rc;
+    if (nhwc && (rc = hip_call(hipMemsetAsync(canvas, 0, (size_t)n_agents * ncell * C * sizeof(float), stream)))) return rc;
 
     if (M > 0) {
         PfnArgs a;
@@ -559,6 +660,16 @@ int coalign_pillar_vfe_scatter(const float *voxel_features, const int32_t *voxel
         a.zo = (float)(voxel_size[2] / 2 + range_min[2]);
         a.n_agents = n_agents; a.ny = ny; a.nx = nx; a.feats = pillar_features; a.cellmap = cellmap;
         const size_t lds = (size_t)kWavesPerBlock * 64 * kFeatStride * sizeof(float);
+        if (nhwc) {
+            hipLaunchKernelGGL(cellmap_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, (const int4 *)voxel_coords, M, n_agents,
+                               ny, nx, cellmap);
+            if ((rc = check_launch())) return rc;
+            const int pairs = (M + 1) / 2;
+            const int want = (pairs + kWavesPerBlock - 1) / kWavesPerBlock;
+            const int cap = 256 * 4;                       // 4 workgroups (16 wavefronts) per CU are resident at this kernel's 112 registers
+            hipLaunchKernelGGL(pillar_rows_nhwc_kernel, dim3(want < cap ? want : cap), dim3(kWavesPerBlock * 64), 0, stream, a, canvas);
+            return check_launch();
+        }
         if (P <= 64 && C <= 64 && !getenv("COALIGN_UNFUSED_PILLARS")) {
             // cell map first, then ONE fused encoder + canvas pass
             hipLaunchKernelGGL(cellmap_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, (const int4 *)voxel_coords, M, n_agents,
@@ -581,7 +692,30 @@ int coalign_pillar_vfe_scatter(const float *voxel_features, const int32_t *voxel
         if ((rc = check_launch())) return rc;
     }
 
+    if (nhwc) return COALIGN_OK;          // M == 0: the memset was the whole canvas
     return launch_canvas(cellmap, pillar_features, C, ncell, n_agents, canvas, stream);
+}
+
+int coalign_pillar_vfe_scatter(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords,
+                               int M, int P, const float *pfn_weight, const float *pfn_bias, const float *bn_weight,
+                               const float *bn_bias, const float *bn_mean, const float *bn_var, float bn_eps, int C,
+                               int use_absolute_xyz, int with_distance, const double *voxel_size, const double *range_min,
+                               int n_agents, int ny, int nx, float *pillar_features, float *canvas, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+    return pillar_vfe_scatter_impl(voxel_features, voxel_num_points, voxel_coords, M, P, pfn_weight, pfn_bias, bn_weight, bn_bias, bn_mean, bn_var,
+                                   bn_eps, C, use_absolute_xyz, with_distance, voxel_size, range_min, n_agents, ny, nx, pillar_features, canvas,
+                                   workspace, workspace_bytes, stream, false);
+}
+
+int coalign_pillar_vfe_scatter_nhwc(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords,
+                                    int M, int P, const float *pfn_weight, const float *pfn_bias, const float *bn_weight,
+                                    const float *bn_bias, const float *bn_mean, const float *bn_var, float bn_eps, int C,
+                                    int use_absolute_xyz, int with_distance, const double *voxel_size, const double *range_min,
+                                    int n_agents, int ny, int nx, float *pillar_features, float *canvas, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    return pillar_vfe_scatter_impl(voxel_features, voxel_num_points, voxel_coords, M, P, pfn_weight, pfn_bias, bn_weight, bn_bias, bn_mean, bn_var,
+                                   bn_eps, C, use_absolute_xyz, with_distance, voxel_size, range_min, n_agents, ny, nx, pillar_features, canvas,
+                                   workspace, workspace_bytes, stream, true);
 }
 
 int coalign_scatter_to_bev(const float *pillar_features, const int32_t *voxel_coords, int M, int C, int n_agents, int ny,

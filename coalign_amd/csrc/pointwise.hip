@@ -25,6 +25,7 @@ struct PwArgs {
     const float *__restrict__ x, *__restrict__ w, *__restrict__ bias;
     float *__restrict__ y;
     int N, Cin, Hin, Win, in_stride, Hp, Wp, M, up, Cout, Ctot, c_off, relu;
+    int in_nhwc;          // x is [N, Hin, Win, Cin] (channels-last: the fused maps / stage outputs of the NHWC route)
 };
 
 template <int UP>
@@ -42,9 +43,19 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
         const bool ok = px < pixels;
         const int hp = ok ? px / a.Wp : 0, wp = ok ? px - hp * a.Wp : 0;
         const size_t off = (size_t)(hp * a.in_stride) * a.Win + (size_t)wp * a.in_stride;
-        for (int ci = tid >> 5; ci < a.Cin; ci += 8) {
-            const float v = xin[(size_t)ci * in_plane + off];
-            xt[ci * 32 + (tid & 31)] = ok ? v : 0.f;
+        if (a.in_nhwc) {       // a pixel's channels are contiguous: 16 B per lane, thread t takes channel quads t / 32, t / 32 + 8, ...
+            const float4 *xp = reinterpret_cast<const float4 *>(xin + off * a.Cin);
+            for (int c4 = tid >> 5; c4 < (a.Cin >> 2); c4 += 8) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) v = xp[c4];
+                xt[(4 * c4) * 32 + (tid & 31)] = v.x; xt[(4 * c4 + 1) * 32 + (tid & 31)] = v.y;
+                xt[(4 * c4 + 2) * 32 + (tid & 31)] = v.z; xt[(4 * c4 + 3) * 32 + (tid & 31)] = v.w;
+            }
+        } else {
+            for (int ci = tid >> 5; ci < a.Cin; ci += 8) {
+                const float v = xin[(size_t)ci * in_plane + off];
+                xt[ci * 32 + (tid & 31)] = ok ? v : 0.f;
+            }
         }
     }
     __syncthreads();
@@ -112,15 +123,22 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
 
 extern "C" int coalign_pointwise_conv(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
                                       int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, void *stream) {
+    return coalign_pointwise_conv_ex(x, w, bias, y, N, Cin, Hin, Win, in_stride, Cout, up, M_padded, Ctot, c_off, relu, 0, stream);
+}
+
+extern "C" int coalign_pointwise_conv_ex(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
+                                         int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc,
+                                         void *stream) {
     using namespace coalign;
     if (!x || !w || !bias || !y) return COALIGN_ERR_NULL_POINTER;
     if (N < 0 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1 || Ctot < Cout || c_off < 0 || c_off + Cout > Ctot) return COALIGN_ERR_BAD_SHAPE;
+    if (in_nhwc && ((Cin & 3) || (reinterpret_cast<uintptr_t>(x) & 15))) return COALIGN_ERR_UNSUPPORTED;
     if (Cin > kMaxCin || (Cin & 1) || (up != 1 && up != 2 && up != 4) || (in_stride != 1 && in_stride != 2) || (up != 1 && in_stride != 1))
         return COALIGN_ERR_UNSUPPORTED;
     const int M = Cout * up * up;
     if (M_padded < M || M_padded % 32 || (up != 1 && M_padded != M)) return COALIGN_ERR_BAD_SHAPE;
     if (N == 0) return COALIGN_OK;
-    PwArgs a{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu};
+    PwArgs a{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu, in_nhwc != 0};
     if (N > 65535) return COALIGN_ERR_UNSUPPORTED;
     const int pixels = a.Hp * a.Wp;
     if (up == 4 && ((a.Wp * 4) % 4 || (reinterpret_cast<uintptr_t>(y) & 15))) return COALIGN_ERR_UNSUPPORTED;

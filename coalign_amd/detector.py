@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from . import ops
 from .backbone import BaseBEVBackbone, DownsampleConv, NaiveCompressor, ResNetBEVBackbone, _cache_of, _fast_ok
 from .encoder import PillarVFE, PointPillarScatter, host_ints
-from .fusion import AttFusion, MaxFusion
+from .fusion import AttFusion, MaxFusion, fuse_multiscale
 from .pose import normalize_pairwise_tfm
 
 
@@ -106,6 +106,14 @@ class PointPillarBaselineMultiscale(nn.Module):
         run on side streams next to the finest one instead of queueing behind it."""
         n = len(feature_list)
         x0 = feature_list[0]
+        if x0.is_cuda and not self.training:
+            kinds = {type(f) for f in self.fusion_net}
+            if kinds == {AttFusion} or kinds == {MaxFusion}:
+                if kinds == {AttFusion} and any(f.feature_dims != x.shape[1] for f, x in zip(self.fusion_net, feature_list)):
+                    raise ValueError("AttFusion feat_dim differs from the feature channels: the fused kernel scales by sqrt(C)")
+                fused = fuse_multiscale(feature_list, record_len, affine, ops.FUSE_ATT if kinds == {AttFusion} else ops.FUSE_MAX, rows)
+                if fused is not None:
+                    return fused
         if n == 1 or not x0.is_cuda or self.training:
             return [f(x, record_len, affine, rows=rows) for f, x in zip(self.fusion_net, feature_list)]
         main = torch.cuda.current_stream(x0.device)

@@ -76,9 +76,12 @@ class PillarVFE(nn.Module):
             n_agents = int(coords[:, 0].max().item()) + 1 if coords.shape[0] else 1
         pfn = self.pfn_layers[0]
         bn = (pfn.norm.weight, pfn.norm.bias, pfn.norm.running_mean, pfn.norm.running_var) if self.use_norm else None
+        from . import backbone                       # the canvas layout follows the convolution route that will read it
+        channels_last = backbone.NHWC_STAGE_OUTPUTS and backbone.CONV_EMU_TERMS in (2, 3) and backbone.FAST_INFERENCE
         feats, canvas = ops.pillar_vfe_scatter(
             vf, npts, coords, pfn.linear.weight, pfn.linear.bias, bn, pfn.norm.eps if self.use_norm else 0.0,
-            self.use_absolute_xyz, self.with_distance, self.voxel_size, self.point_cloud_range[:3], n_agents, self.ny, self.nx)
+            self.use_absolute_xyz, self.with_distance, self.voxel_size, self.point_cloud_range[:3], n_agents, self.ny, self.nx,
+            channels_last=channels_last)
         batch_dict["pillar_features"] = feats
         batch_dict["_fused_canvas"] = (feats, canvas)
         return batch_dict

@@ -51,6 +51,26 @@ def warp_feature(x: torch.Tensor, record_len, pairwise_t_matrix: torch.Tensor) -
     return ops.warp_fuse(x, _ego_rows(pairwise_t_matrix, groups), groups, ops.FUSE_NONE)
 
 
+def fuse_multiscale(xs: Sequence[torch.Tensor], record_len, affine: torch.Tensor, mode: int, rows=None):
+    """All feature scales of a batch in ONE launch per frame when every map is channels-last (the route the split-bf16 backbone
+    produces): -> list of fused maps [B, C_s, H_s, W_s] (channels-last), or None when the maps do not qualify (caller falls back
+    to one ``coalign_warp_fuse`` launch per scale)."""
+    if len(xs) > 3 or not all(ops.warp_fuse_nhwc_ok(x) for x in xs):
+        return None
+    groups = host_ints(record_len)
+    if sum(groups) != xs[0].shape[0] or max(groups) > 8:
+        return None
+    outs, off = [], 0
+    for b, n in enumerate(groups):
+        theta = affine[b, 0, :n]
+        r = None if rows is None else [int(v) for v in rows[off:off + n]]
+        outs.append(ops.warp_fuse_nhwc([x[off:off + n] for x in xs], theta, mode, rows=r))
+        off += n
+    if len(outs) == 1:
+        return outs[0]
+    return [torch.cat([o[k] for o in outs], dim=0) for k in range(len(xs))]
+
+
 class MaxFusion(nn.Module):
     def forward(self, x: torch.Tensor, record_len, pairwise_t_matrix: torch.Tensor, rows=None) -> torch.Tensor:
         """``rows`` (not in the reference): row of ``x`` holding logical agent i, for agent-sharded callers."""

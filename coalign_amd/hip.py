@@ -23,9 +23,13 @@ SIGNATURES = {
     "coalign_pillar_scatter_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "coalign_pillar_vfe_scatter": (c_int, [P, P, P, c_int, c_int, P, P, P, P, P, P, c_float, c_int, c_int, c_int,
                                            POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, P, c_size_t, P]),
+    "coalign_pillar_vfe_scatter_nhwc": (c_int, [P, P, P, c_int, c_int, P, P, P, P, P, P, c_float, c_int, c_int, c_int,
+                                                POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, P, c_size_t, P]),
     "coalign_scatter_to_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     "coalign_warp_fuse": (c_int, [P, c_int, c_int, c_int, c_int, P, POINTER(c_int32), c_int, c_int, P, c_int, c_int, P]),
     "coalign_warp_fuse_rows": (c_int, [P, c_int, c_int, c_int, c_int, P, POINTER(c_int32), c_int, POINTER(c_int32), c_int, P, c_int, c_int, P]),
+    "coalign_warp_fuse_nhwc": (c_int, [c_int, POINTER(P), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(P), POINTER(c_int32),
+                                       POINTER(c_int32), c_int, P, POINTER(c_int32), c_int, P]),
     "coalign_anchor_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "coalign_anchor_decode": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P, c_int, P, P, P,
                                       P, P, P, P, P, P, c_size_t, P]),
@@ -47,6 +51,7 @@ SIGNATURES = {
     "coalign_conv3x3_emu_bias_act": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "coalign_conv3x3_emu_ex": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "coalign_pointwise_conv": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "coalign_pointwise_conv_ex": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_pose_graph_workspace_bytes": (c_size_t, [c_int]),
     "coalign_pose_graph_optimize": (c_int, [c_int, P, P, P, c_int, P, P, P, P, P, P, c_int, P, P, c_size_t, P]),
     "coalign_voxelize": (c_int, [P, POINTER(c_int64), c_int, POINTER(c_double), POINTER(c_double), c_int, c_int, c_int,

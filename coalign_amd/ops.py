@@ -90,8 +90,9 @@ def _dbl3(v: Sequence[float]):
 def pillar_vfe_scatter(voxel_features: torch.Tensor, voxel_num_points: torch.Tensor, voxel_coords: torch.Tensor,
                        weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[Tuple[torch.Tensor, ...]], bn_eps: float,
                        use_absolute_xyz: bool, with_distance: bool, voxel_size: Sequence[float], range_min: Sequence[float],
-                       n_agents: int, ny: int, nx: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """-> (pillar_features [M, C], canvas [n_agents, C, ny, nx]).  ``bn`` = (weight, bias, running_mean, running_var)."""
+                       n_agents: int, ny: int, nx: int, channels_last: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (pillar_features [M, C], canvas [n_agents, C, ny, nx]).  ``bn`` = (weight, bias, running_mean, running_var).
+    ``channels_last``: the canvas comes back in NHWC memory (same logical shape), see coalign_pillar_vfe_scatter_nhwc."""
     _need_gpu(voxel_features, voxel_num_points, voxel_coords, weight)
     L = hip.lib()
     vf = _f32c(voxel_features)
@@ -104,13 +105,16 @@ def pillar_vfe_scatter(voxel_features: torch.Tensor, voxel_num_points: torch.Ten
     C = w.shape[0]
     dev = vf.device
     feats = torch.empty((M, C), dtype=torch.float32, device=dev)
-    canvas = torch.empty((n_agents, C, ny, nx), dtype=torch.float32, device=dev)
+    channels_last = bool(channels_last) and P <= 32 and C <= 64 and C > 1 and ny * nx > 1
+    canvas = torch.empty((n_agents, C, ny, nx), dtype=torch.float32, device=dev,
+                         memory_format=torch.channels_last if channels_last else torch.contiguous_format)
     ws_bytes = L.coalign_pillar_scatter_workspace_bytes(n_agents, ny, nx)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     bnp = [None] * 4 if bn is None else [_f32c(t) for t in bn]
     b = None if bias is None else _f32c(bias)
     with _Timed("pillar_vfe_scatter"):
-      hip.check(L.coalign_pillar_vfe_scatter(_ptr(vf), _ptr(npts), _ptr(coords), M, P, _ptr(w), _ptr(b), _ptr(bnp[0]), _ptr(bnp[1]),
+      fn = L.coalign_pillar_vfe_scatter_nhwc if channels_last else L.coalign_pillar_vfe_scatter
+      hip.check(fn(_ptr(vf), _ptr(npts), _ptr(coords), M, P, _ptr(w), _ptr(b), _ptr(bnp[0]), _ptr(bnp[1]),
                                            _ptr(bnp[2]), _ptr(bnp[3]), float(bn_eps), C, int(use_absolute_xyz), int(with_distance),
                                            _dbl3(voxel_size), _dbl3(range_min), n_agents, ny, nx, _ptr(feats), _ptr(canvas),
                                            _ptr(ws), ws_bytes, _stream()), "coalign_pillar_vfe_scatter")
@@ -157,6 +161,42 @@ def warp_fuse(x: torch.Tensor, theta: torch.Tensor, group_len: Sequence[int], mo
         hip.check(L.coalign_warp_fuse_rows(_ptr(xc), n_total, C, H, W, _ptr(th), gl, len(groups), rw, mode, _ptr(out), Ho, Wo, _stream()),
                   "coalign_warp_fuse_rows")
     return out
+
+
+def warp_fuse_nhwc_ok(x: torch.Tensor) -> bool:
+    """Channels-last map the one-launch fusion kernel serves: [n <= 8, C in {64, 128, 256}, H, W] float32 in NHWC memory."""
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] in (64, 128, 256) and x.shape[0] <= 8 and is_channels_last(x)
+
+
+@_device_op
+def warp_fuse_nhwc(xs: Sequence[torch.Tensor], theta: torch.Tensor, mode: int, rows: Optional[Sequence[int]] = None,
+                   out_hw: Optional[Sequence[Tuple[int, int]]] = None) -> list:
+    """Up to three channels-last feature scales of ONE frame, ``xs[i]`` [n, C_i, H_i, W_i] (NHWC memory), theta [n, 2, 3] f64 ->
+    per scale the fused map [1, C_i, Ho_i, Wo_i] (ATT / MAX) or the warped maps [n, C_i, Ho_i, Wo_i] (NONE), channels-last."""
+    _need_gpu(*xs, theta)
+    L = hip.lib()
+    k = len(xs)
+    n = xs[0].shape[0]
+    if not 1 <= k <= 3 or any(not warp_fuse_nhwc_ok(x) or x.shape[0] != n for x in xs):
+        raise ValueError("warp_fuse_nhwc needs 1-3 channels-last float32 maps [n <= 8, C in {64, 128, 256}, H, W] of one frame")
+    th = theta.to(device=xs[0].device, dtype=torch.float64).contiguous()
+    if th.shape[0] != n:
+        raise ValueError("one theta row per agent")
+    hw = [tuple(x.shape[2:]) for x in xs] if out_hw is None else [(int(a), int(b)) for a, b in out_hw]
+    outs = [torch.empty((n if mode == FUSE_NONE else 1, x.shape[1], h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+            for x, (h, w) in zip(xs, hw)]
+    vp = ctypes.c_void_p * k
+    i32 = ctypes.c_int32 * k
+    rw = None
+    if rows is not None:
+        if len(rows) != n:
+            raise ValueError("rows must have one entry per agent")
+        rw = (ctypes.c_int32 * n)(*[int(r) for r in rows])
+    with _Timed("warp_fuse_nhwc"):
+        hip.check(L.coalign_warp_fuse_nhwc(k, vp(*[x.data_ptr() for x in xs]), i32(*[x.shape[1] for x in xs]), i32(*[x.shape[2] for x in xs]),
+                                           i32(*[x.shape[3] for x in xs]), vp(*[o.data_ptr() for o in outs]), i32(*[h for h, _ in hw]),
+                                           i32(*[w for _, w in hw]), n, _ptr(th), rw, mode, _stream()), "coalign_warp_fuse_nhwc")
+    return outs
 
 
 class DecodeBuffers:
@@ -477,7 +517,8 @@ def pointwise_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
     1x1 stride-2 convolution.  ``out`` [N, Ctot, H', W'] + ``c_off`` select a channel slice of a larger (concatenated) tensor."""
     _need_gpu(x, w_packed, bias)
     L = hip.lib()
-    xc = _f32c(x)
+    nhwc = x.dtype == torch.float32 and is_channels_last(x) and x.shape[1] % 4 == 0        # read in place, no NCHW copy
+    xc = x if nhwc else _f32c(x)
     N, Cin, Hin, Win = xc.shape
     Ho, Wo = (Hin + in_stride - 1) // in_stride * up, (Win + in_stride - 1) // in_stride * up
     if out is None:
@@ -485,8 +526,8 @@ def pointwise_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
     if tuple(out.shape[2:]) != (Ho, Wo) or out.shape[0] != N or not out.is_contiguous() or out.dtype != torch.float32:
         raise ValueError("output buffer shape / layout mismatch")
     with _Timed("pointwise_conv"):
-        hip.check(L.coalign_pointwise_conv(_ptr(xc), _ptr(w_packed), _ptr(_f32c(bias)), _ptr(out), N, Cin, Hin, Win, in_stride, cout, up,
-                                           w_packed.shape[1], out.shape[1], c_off, int(relu), _stream()), "coalign_pointwise_conv")
+        hip.check(L.coalign_pointwise_conv_ex(_ptr(xc), _ptr(w_packed), _ptr(_f32c(bias)), _ptr(out), N, Cin, Hin, Win, in_stride, cout, up,
+                                              w_packed.shape[1], out.shape[1], c_off, int(relu), int(nhwc), _stream()), "coalign_pointwise_conv")
     return out
 
 

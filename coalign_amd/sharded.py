@@ -63,6 +63,15 @@ def _is_gloo_cuda(t: torch.Tensor, group) -> bool:
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
+def _rows_view(t: torch.Tensor) -> torch.Tensor:
+    """[n, ...] -> [n, numel / n] view of the tensor's MEMORY (channels-last maps are flattened in their own (H, W, C) order)."""
+    n = t.shape[0]
+    if t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last):
+        return t.permute(0, 2, 3, 1).reshape(n, -1)
+    assert t.is_contiguous(), "feature maps must be dense (NCHW or channels-last)"
+    return t.reshape(n, -1)
+
+
 class FrameRing:
     """``exchange(feats)``: per scale ``[n_agents, C, H, W]`` in local slot order -> ``(recv, rows)``: per scale
     ``[n_agents, C, H, W]`` holding MY frame's agents source-rank major, and ``rows[i]`` = the row of logical agent i
@@ -90,13 +99,13 @@ class FrameRing:
             return list(feats), list(range(self.n))
         out, sent = [], 0
         for i, f in enumerate(feats):
-            assert f.shape[0] == self.n and f.is_contiguous()
+            assert f.shape[0] == self.n
             send = f if self.wire_dtype is None else f.to(self.wire_dtype)
-            key = (i, tuple(send.shape), send.dtype, str(send.device))
+            key = (i, tuple(send.shape), tuple(send.stride()), send.dtype, str(send.device))
             recv = self._recv.get(key)
             if recv is None:
-                recv = self._recv[key] = torch.empty_like(send)
-            send2, recv2 = send.view(self.n, -1), recv.view(self.n, -1)
+                recv = self._recv[key] = torch.empty_like(send)          # same memory format as the map (NCHW or channels-last)
+            send2, recv2 = _rows_view(send), _rows_view(recv)
             if _is_gloo_cuda(send2, self.group):
                 # functional-test route only (ranks sharing one GPU cannot use RCCL): staged through host memory
                 host = torch.empty(recv2.shape, dtype=recv2.dtype)
@@ -144,18 +153,21 @@ class AgentGather:
             return [f[: self.n] for f in feats]
         out, sent = [], 0
         for i, f in enumerate(feats):
-            assert f.shape[0] == self.per and f.is_contiguous()
+            assert f.shape[0] == self.per
             send = f if self.wire_dtype is None else f.to(self.wire_dtype)
-            key = (i, tuple(send.shape), send.dtype, str(send.device))
+            cl = send.dim() == 4 and not send.is_contiguous() and send.is_contiguous(memory_format=torch.channels_last)
+            key = (i, tuple(send.shape), cl, send.dtype, str(send.device))
             recv = self._recv.get(key)
             if recv is None:
-                recv = self._recv[key] = torch.empty((self.world * self.per,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+                recv = self._recv[key] = torch.empty((self.world * self.per,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device,
+                                                     memory_format=torch.channels_last if cl else torch.contiguous_format)
+            send2, recv2 = _rows_view(send), _rows_view(recv)
             if _is_gloo_cuda(send, self.group):
-                parts = [torch.empty(send.shape, dtype=send.dtype) for _ in range(self.world)]
-                dist.all_gather(parts, send.cpu(), group=self.group)
-                recv.copy_(torch.cat(parts))
+                parts = [torch.empty(send2.shape, dtype=send.dtype) for _ in range(self.world)]
+                dist.all_gather(parts, send2.cpu(), group=self.group)
+                recv2.copy_(torch.cat(parts))
             else:
-                dist.all_gather_into_tensor(recv, send, group=self.group)
+                dist.all_gather_into_tensor(recv2, send2, group=self.group)
             sent += (self.world - 1) * send.numel() * send.element_size()
             full = recv[: self.n]                                # blocks are contiguous and in rank order: already agent order
             out.append(full if self.wire_dtype is None else full.to(f.dtype))

@@ -66,6 +66,15 @@ int coalign_pillar_vfe_scatter(const float *voxel_features, const int32_t *voxel
                                int use_absolute_xyz, int with_distance, const double *voxel_size, const double *range_min,
                                int n_agents, int ny, int nx, float *pillar_features, float *canvas, void *workspace,
                                size_t workspace_bytes, void *stream);
+/* The same op writing the canvas CHANNELS-LAST, [n_agents, ny, nx, C] (the memory of a torch channels_last tensor of logical shape
+ * [n_agents, C, ny, nx]; P <= 32, C <= 64): a pillar's feature row is its canvas cell, the scatter is one C-float store per pillar on
+ * top of a memset.  Read in place by the strided convolutions of the first ResNet stage (coalign_conv3x3_emu_ex layout 2,
+ * coalign_pointwise_conv_ex in_nhwc). */
+int coalign_pillar_vfe_scatter_nhwc(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M, int P,
+                                    const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias,
+                                    const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz, int with_distance,
+                                    const double *voxel_size, const double *range_min, int n_agents, int ny, int nx, float *pillar_features,
+                                    float *canvas, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Scatter only (PointPillarScatter.forward on already-encoded pillars): pillar_features [M, C] -> canvas.
  * Same cell rule, duplicate rule and workspace as above. */
@@ -100,6 +109,13 @@ int coalign_warp_fuse(const float *x, int n_total, int C, int H, int W, const do
  * so the result is bit-identical to the un-routed call (fusion_in_one.py:125-132 fixes that order through regroup). */
 int coalign_warp_fuse_rows(const float *x, int n_total, int C, int H, int W, const double *theta, const int32_t *group_len,
                            int n_groups, const int32_t *rows, int mode, float *out, int Ho, int Wo, void *stream);
+/* The same op on CHANNELS-LAST maps, up to three feature scales of ONE frame in one launch (csrc/warp_fuse_nhwc.hip): x[i] is
+ * [n, H[i], W[i], C[i]] (the memory of a torch channels_last tensor of logical shape [n, C, H, W]), out[i] is [Ho[i], Wo[i], C[i]]
+ * (ATT / MAX) or [n, Ho[i], Wo[i], C[i]] (NONE), C[i] in {64, 128, 256}, 16-byte aligned.  x, C, H, W, out, Ho, Wo: HOST arrays of
+ * n_scales entries; theta [n, 2, 3] float64 DEVICE (shared by the scales: the normalised affine is resolution independent,
+ * point_pillar_baseline_multiscale.py:108-109); rows [n] HOST or NULL as in coalign_warp_fuse_rows. */
+int coalign_warp_fuse_nhwc(int n_scales, const float *const *x, const int32_t *C, const int32_t *H, const int32_t *W, float *const *out,
+                           const int32_t *Ho, const int32_t *Wo, int n, const double *theta, const int32_t *rows, int mode, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * (3) Anchor decode: sigmoid + score threshold + box decode + direction-bin fix + 8 corners + projection +
@@ -311,6 +327,9 @@ int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const float *bia
  */
 int coalign_pointwise_conv(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
                            int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, void *stream);
+/* in_nhwc != 0: x is channels-last, [N, Hin, Win, Cin] (Cin % 4 == 0, 16-byte aligned); the output stays NCHW. */
+int coalign_pointwise_conv_ex(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win, int in_stride,
+                              int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, void *stream);
 
 #ifdef __cplusplus
 }

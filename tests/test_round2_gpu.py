@@ -19,7 +19,7 @@ DEV = "cuda:0"
 
 def rel_err(got, ref):
     got = got.detach().float().cpu()
-    ref = (ref if torch.is_tensor(ref) else T(np.asarray(ref))).float()
+    ref = (ref.detach().cpu() if torch.is_tensor(ref) else T(np.asarray(ref))).float()
     return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
 
 
@@ -185,3 +185,134 @@ def test_conv3x3_emu_stride2_and_layouts_vs_fp64(shape, terms, tol):
         y_cl = ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, terms, out_channels_last=True)
         assert y_cl.shape == y_nchw.shape and (ops.is_channels_last(y_cl) or H * W == 1)
         assert torch.equal(y_cl.contiguous(), y_nchw)
+
+
+# ------------------------------------------------------------------------------------------------ channels-last fusion, one launch
+def _poses_theta(n, H0, W0, seed, spread=(20.0, 10.0), yaw=30.0):
+    from coalign_amd.synthetic import make_poses
+    from coalign_amd.pose import get_pairwise_transformation
+    rs = np.random.RandomState(seed)
+    poses = make_poses(rs, n, noise=(0.2, 0.2), spread_xy=spread, spread_yaw=yaw)
+    pair = T(get_pairwise_transformation(poses, max(n, 5)))[None]
+    return oracle.normalize_pairwise_tfm(pair, H0, W0, 0.4)
+
+
+@pytest.mark.parametrize("n,geom", [(5, "opv2v"), (2, "opv2v"), (1, "opv2v"), (3, "opv2v"), (8, "opv2v"), (2, "dair"), (8, "lss")])
+def test_warp_fuse_nhwc_vs_oracle(n, geom):
+    """csrc/warp_fuse_nhwc.hip (all scales in one launch, channels-last) against the oracle's AttFusion / MaxFusion / warp at the
+    OPV2V, DAIR-V2X (W = 252 / 126 / 63: nothing in this kernel needs W % 4) and LSS sizes, every agent-count variant; and the row
+    table: agents stored in another order give bit-identical results."""
+    H0, W0 = {"opv2v": (200, 704), "dair": (200, 504), "lss": (240, 240)}[geom]
+    aff = _poses_theta(n, H0, W0, seed=n * 7 + len(geom), spread=(15.0, 15.0) if geom == "lss" else (20.0, 10.0), yaw=180.0 if geom == "lss" else 30.0)
+    gen = torch.Generator().manual_seed(n + 11)
+    rl = torch.tensor([n])
+    xs = [torch.randn(n, C, H0 // d, W0 // d, generator=gen) for C, d in ((64, 2), (128, 4), (256, 8))]
+    xd = [x.to(DEV).contiguous(memory_format=torch.channels_last) for x in xs]
+    theta = aff[0, 0, :n].to(DEV)
+    att = ops.warp_fuse_nhwc(xd, theta, ops.FUSE_ATT)
+    mx = ops.warp_fuse_nhwc(xd, theta, ops.FUSE_MAX)
+    wp = ops.warp_fuse_nhwc(xd, theta, ops.FUSE_NONE)
+    for k, x in enumerate(xs):
+        assert att[k].shape == (1,) + tuple(x.shape[1:]) and ops.is_channels_last(att[k])
+        e = rel_err(att[k], oracle.att_fuse(x, rl, aff))
+        assert e < 1e-5, (k, "att", e)
+        assert rel_err(mx[k], oracle.max_fuse(x, rl, aff)) < 1e-5
+        ref_w = oracle.warp_affine_simple(x, aff[0, 0, :n], tuple(x.shape[2:]))
+        assert rel_err(wp[k], ref_w) < 1e-5
+        # the NCHW kernel computes the same taps: warped values are bit-identical, fused ones differ by summation order only
+        assert torch.equal(wp[k].contiguous(), ops.warp_fuse(x.to(DEV), theta, [n], ops.FUSE_NONE))
+        assert rel_err(att[k], ops.warp_fuse(x.to(DEV), theta, [n], ops.FUSE_ATT)) < 1e-5
+    perm = torch.randperm(n, generator=gen).tolist()
+    rows = [0] * n
+    for r, a in enumerate(perm):
+        rows[a] = r
+    shuffled = [x[perm].contiguous(memory_format=torch.channels_last) for x in xd]
+    for mode, want in ((ops.FUSE_ATT, att), (ops.FUSE_MAX, mx), (ops.FUSE_NONE, wp)):
+        got = ops.warp_fuse_nhwc(shuffled, theta, mode, rows=rows)
+        assert all(torch.equal(g, w) for g, w in zip(got, want))
+    # a single scale, and an output size different from the input size (warp_affine_simple's dsize)
+    one = ops.warp_fuse_nhwc(xd[1:2], theta, ops.FUSE_ATT)
+    assert torch.equal(one[0], att[1])
+    small = ops.warp_fuse_nhwc(xd[:1], theta, ops.FUSE_NONE, out_hw=[(37, 51)])
+    assert rel_err(small[0], oracle.warp_affine_simple(xs[0], aff[0, 0, :n], (37, 51))) < 1e-5
+
+
+def test_pointwise_reads_channels_last_in_place():
+    """coalign_pointwise_conv_ex with a channels-last input == the NCHW call, bit for bit (deblocks on fused maps, the 1 x 1 / stride-2 skip)."""
+    gen = torch.Generator().manual_seed(3)
+    for Cin, Cout, H, W, up, stride in ((64, 128, 100, 352, 1, 1), (128, 128, 50, 176, 2, 1), (256, 128, 25, 88, 4, 1), (64, 128, 100, 352, 1, 2), (128, 256, 51, 177, 1, 2)):
+        x = torch.randn(2, Cin, H, W, generator=gen).to(DEV)
+        if up == 1:
+            w = ops.pack_pointwise_weight((torch.randn(Cout, Cin, 1, 1, generator=gen) / Cin ** 0.5).to(DEV), False)
+        else:
+            w = ops.pack_pointwise_weight((torch.randn(Cin, Cout, up, up, generator=gen) / Cin ** 0.5).to(DEV), True)
+        b = torch.randn(Cout, generator=gen).to(DEV)
+        a = ops.pointwise_conv(x, w, b, Cout, up=up, in_stride=stride)
+        c = ops.pointwise_conv(x.contiguous(memory_format=torch.channels_last), w, b, Cout, up=up, in_stride=stride)
+        assert torch.equal(a, c)
+
+
+def test_nhwc_route_equals_nchw_route_end_to_end():
+    """The channels-last stage outputs + one-launch fusion against the all-NCHW route (COALIGN_NHWC_STAGES=0) on a full-size
+    frame: backbone maps bit-identical (same kernels, other store layout), head outputs equal to summation-order rounding."""
+    from coalign_amd import backbone as bb
+    from coalign_amd.synthetic import make_frame
+    h = builtin_config("opv2v_coalign")
+    model = build_model(h)
+    fill_parameters_(model, seed=0, cls_bias=-1.5)
+    model = model.to(DEV).eval()
+    frame = to_device(make_frame(h, 3, pillars_per_agent=5000, seed=21, noise=(0.2, 0.2)), DEV)
+    saved = bb.NHWC_STAGE_OUTPUTS
+    try:
+        with torch.no_grad():
+            bb.NHWC_STAGE_OUTPUTS = True
+            f1, aff = model.encode(frame)
+            o1 = model(frame)
+            bb.NHWC_STAGE_OUTPUTS = False
+            f0, _ = model.encode(frame)
+            o0 = model(frame)
+    finally:
+        bb.NHWC_STAGE_OUTPUTS = saved
+    assert all(ops.is_channels_last(f) for f in f1) and all(f.is_contiguous() for f in f0)
+    for a, b in zip(f1, f0):
+        assert torch.equal(a.contiguous(), b)
+    for k in o0:
+        assert rel_err(o1[k], o0[k]) < 1e-4, k            # the fusion's score sums run in another order; ~2e-5 after the 384-channel header
+
+
+def test_pillar_channels_last_canvas_equals_nchw():
+    """coalign_pillar_vfe_scatter_nhwc: pillar features and canvas bit-identical to the NCHW route (full OPV2V size, 5 agents; dense
+    mini canvas with duplicate cells, out-of-canvas pillars, 1- and 32-point pillars, an odd pillar count; empty input)."""
+    from coalign_amd.synthetic import make_frame
+    p = "pillar_vfe.pfn_layers.0."
+
+    def run(h, pl, n_agents, cl, seed=0):
+        margs = h["model"]["args"]
+        model = build_model(h)
+        fill_parameters_(model, seed=seed)
+        sd = model.state_dict()
+        nx, ny, _ = [int(v) for v in margs["point_pillar_scatter"]["grid_size"]]
+        bn = tuple(sd[p + k].to(DEV) for k in ("norm.weight", "norm.bias", "norm.running_mean", "norm.running_var"))
+        return ops.pillar_vfe_scatter(pl["voxel_features"].to(DEV), pl["voxel_num_points"].to(DEV), pl["voxel_coords"].to(DEV), sd[p + "linear.weight"].to(DEV),
+                                      None, bn, 1e-3, True, False, margs["voxel_size"], margs["lidar_range"][:3], n_agents, ny, nx, channels_last=cl)
+
+    h = builtin_config("opv2v_coalign")
+    pl = make_frame(h, 5, pillars_per_agent=8000, seed=303, noise=(0.2, 0.2))["processed_lidar"]
+    f0, c0 = run(h, pl, 5, False)
+    f1, c1 = run(h, pl, 5, True)
+    assert ops.is_channels_last(c1) and c0.is_contiguous() and c1.shape == c0.shape
+    assert torch.equal(f0, f1) and torch.equal(c1.contiguous(), c0)
+    hm = builtin_config("mini_coalign")
+    pl = make_frame(hm, 2, pillars_per_agent=601, seed=5, num_points_mode="uniform")["processed_lidar"]      # odd total count
+    pl = {k: v[:-1].clone() for k, v in pl.items()}
+    pl["voxel_num_points"][0] = 1; pl["voxel_features"][0, 1:] = 0
+    pl["voxel_num_points"][1] = 32
+    pl["voxel_coords"][10:40] = pl["voxel_coords"][100:130]          # duplicate cells: the larger row wins
+    pl["voxel_coords"][50, 3] = 9999                                 # outside the canvas
+    pl["voxel_coords"][51, 0] = -1                                   # padding row (pipeline.pad_pillars)
+    f0, c0 = run(hm, pl, 2, False, seed=3)
+    f1, c1 = run(hm, pl, 2, True, seed=3)
+    assert torch.equal(f0, f1) and torch.equal(c1.contiguous(), c0)
+    empty = {"voxel_features": torch.zeros(0, 32, 4), "voxel_num_points": torch.zeros(0, dtype=torch.int32), "voxel_coords": torch.zeros(0, 4, dtype=torch.int32)}
+    f1, c1 = run(hm, empty, 2, True)
+    assert f1.shape == (0, 64) and float(c1.abs().sum()) == 0.0

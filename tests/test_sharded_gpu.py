@@ -94,8 +94,8 @@ def _worker(rank, world, port, q):
                 batch = {"processed_lidar": stack_agents(sets), "record_len": [ag.per], "pairwise_t_matrix": pair[1]}
                 feats, affine = model.encode(batch)
             else:       # a rank without agents still takes part in the collective
-                feats = [torch.zeros((ag.per,) + tuple(t.shape[1:]), device=t.device) for t in single[1][0]]
-            full = ag.gather([f.contiguous() for f in feats])
+                feats = [torch.zeros_like(t[: ag.per]) for t in single[1][0]]
+            full = ag.gather(list(feats))
             for k in range(3):
                 if not torch.equal(full[k], single[1][0][k]):
                     err = float((full[k] - single[1][0][k]).abs().max())

@@ -34,8 +34,13 @@ def timed(fn, n):
 
 res = {}
 res["pillar_vfe_scatter_us"] = timed(lambda: ops.pillar_vfe_scatter(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], pfn.linear.weight, None, bn, 1e-3, True, False, h["model"]["args"]["voxel_size"], h["model"]["args"]["lidar_range"][:3], N, 200, 704), iters)
+res["pillar_vfe_scatter_nhwc_us"] = timed(lambda: ops.pillar_vfe_scatter(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], pfn.linear.weight, None, bn, 1e-3, True, False, h["model"]["args"]["voxel_size"], h["model"]["args"]["lidar_range"][:3], N, 200, 704, channels_last=True), iters)
 for x in xs:
     res[f"warp_fuse_att_C{x.shape[1]}_us"] = timed(lambda: ops.warp_fuse(x, theta, [N], ops.FUSE_ATT), iters)
+xcl = [x.contiguous(memory_format=torch.channels_last) for x in xs]
+res["warp_fuse_nhwc_3scales_us"] = timed(lambda: ops.warp_fuse_nhwc(xcl, theta, ops.FUSE_ATT), iters)
+for x in xcl:
+    res[f"warp_fuse_nhwc_C{x.shape[1]}_us"] = timed(lambda: ops.warp_fuse_nhwc([x], theta, ops.FUSE_ATT), iters)
 # the matrix-core convolution at the stage-1 shape (64 -> 64 channels, 100 x 352, N agents), with residual + ReLU
 wconv = torch.randn(64, 64, 3, 3, generator=g).to(dev) / 24.0
 wp, bconv, rconv = ops.pack_conv3x3_weight(wconv), torch.randn(64, generator=g).to(dev), torch.randn(N, 64, 100, 352, generator=g).to(dev)
