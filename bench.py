@@ -179,13 +179,14 @@ def main():
         sync()
         pipe.host_enqueue_s = 0.0
         results = []
+        base = pipe._count                   # frame indices of the results below are made relative to the timed loop
         t0 = time.perf_counter()
         for s in range(steps):
             results += pipe.submit(step_batches[s % len(step_batches)])
         t_issue = pipe.host_enqueue_s
         results += pipe.drain()              # the last frames' detections: all K frames are complete inside the bracket
         sync()
-        return time.perf_counter() - t0, t_issue, results
+        return time.perf_counter() - t0, t_issue, [(i - base, b, sc) for i, b, sc in results]
 
     pipe = make_pipe(use_graph)
     warm = max(args.warmup, 2 * n_lanes if use_graph else args.warmup)     # every lane captures its graph during the warm-up
@@ -312,15 +313,14 @@ def main():
         # reads = 2 x FETCH_SIZE (gfx950 tallies the 128-B requests of 16 B/lane streaming loads at 64 B, MI355X_MICROARCH.md
         # "HBM"), writes = WRITE_SIZE; null when no summary is committed for this workload
         pmc, pmc_src = {}, None
-        for rnd in ("round2", "round1"):
-            path = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json" if rnd != "round1" else "final_pmc_summary.json")
-            if os.path.exists(path) and N == 5 and args.pillars == 8000 and args.config == "opv2v_coalign":
-                pmc, pmc_src = json.load(open(path)), os.path.relpath(path, ROOT)
-                break
+        path = os.path.join(ROOT, "profiles", "round2", "pmc_summary.json")
+        if os.path.exists(path) and N == 5 and args.pillars == 8000 and args.config == "opv2v_coalign":
+            pmc, pmc_src = json.load(open(path)), os.path.relpath(path, ROOT)
 
-        def traffic_of(prefixes):
-            hit = [v for k, v in pmc.items() if any(k.startswith(p) for p in prefixes) and "hbm_bytes_read_x2" in v]
-            return int(sum(v["hbm_bytes_read_x2"] for v in hit)) if hit else None
+        def traffic_of(op):
+            """corrected HBM bytes of one call of the op (all its kernels and memsets), profiles/roundN/pmc_summary.json"""
+            e = pmc.get(op)
+            return int(e["hbm_bytes_read_x2"]) if e and "hbm_bytes_read_x2" in e else None
 
         def hbm_entry(name, ms, nbytes, traffic, live_name=None):
             e = {"kernel": name, "bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -330,11 +330,13 @@ def main():
                 e["in_timed_steps"] = {"avg_launch_ms": live[live_name]["avg_ms"], "frac": live[live_name]["frac_of_8TBps"]}
             return e
 
-        pillar = hbm_entry("pillar_vfe_scatter = memset + cellmap_kernel + pillar_canvas_kernel", iso["pillar_ms"], alg_bytes["pillar_vfe_scatter"],
-                           traffic_of(["pillar_canvas_kernel", "cellmap_kernel"]), "pillar_vfe_scatter")
+        pillar = hbm_entry("pillar_vfe_scatter = canvas memset + cell-map memset + cellmap_kernel + pillar_rows_nhwc_kernel (channels-last canvas)" if default_terms in (2, 3)
+                           else "pillar_vfe_scatter = memset + cellmap_kernel + pillar_canvas_kernel", iso["pillar_ms"], alg_bytes["pillar_vfe_scatter"],
+                           traffic_of("pillar_nhwc" if default_terms in (2, 3) else "pillar_nchw"), "pillar_vfe_scatter")
         north = {"target": 0.40, "pillar_vfe_scatter": pillar}
         if "fuse_ms" in iso:
-            north["warp_fuse_all_scales"] = hbm_entry("coalign_warp_fuse x 3 scales", iso["fuse_ms"], fuse_bytes, traffic_of(["warp_fuse"]))
+            north["warp_fuse_all_scales"] = hbm_entry("warp + attention fusion, 3 scales (coalign_warp_fuse_nhwc: one launch)" if default_terms in (2, 3) else "coalign_warp_fuse x 3 scales",
+                                                         iso["fuse_ms"], fuse_bytes, traffic_of("fuse_nhwc_3scales") if default_terms in (2, 3) else None)
             tot_ms, tot_b = iso["pillar_ms"] + iso["fuse_ms"], alg_bytes["pillar_vfe_scatter"] + fuse_bytes
             north.update({"frac": round(tot_b / tot_ms / 1e6 / HBM_PEAK_GBPS, 4), "achieved": round(tot_b / tot_ms / 1e6, 1), "unit": "GB/s",
                           "algorithmic_bytes": tot_b, "ms": round(tot_ms, 5)})
@@ -353,14 +355,14 @@ def main():
                         "bound": "mfma", "achieved": round(executed / ms / 1e9, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(executed / ms / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 5),
                         "algorithmic_flops_per_launch": executed, "fp32_equivalent_flops_per_launch": conv_flops,
-                        "fp32_equivalent_TFLOPs": round(conv_flops / ms / 1e9, 1), "traffic": traffic_of([f"conv3x3_emu_kernel_bf16x{t}"]),
+                        "fp32_equivalent_TFLOPs": round(conv_flops / ms / 1e9, 1), "traffic": traffic_of(f"conv_bf16x{t}_64ch"),
                         "note": f"executed bf16 products = {6 if t == 3 else 3} per fp32 product; peak = dense bf16 MFMA (MI355X_MICROARCH.md)"}
         else:
             ms = iso["conv_f32_ms"]
             roofline = {"kernel": f"conv3x3_bias_act (v_mfma_f32_32x32x2_f32 implicit GEMM, 64->64 channels at {ny // 2}x{nx // 2}, N={N})", "bound": "mfma",
                         "achieved": round(conv_flops / ms / 1e9, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(conv_flops / ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 5),
-                        "algorithmic_flops_per_launch": conv_flops, "traffic": traffic_of(["conv3x3_kernel"])}
+                        "algorithmic_flops_per_launch": conv_flops, "traffic": traffic_of("conv_f32_64ch")}
         roofline["isolated_ms"] = {k: round(v, 5) for k, v in iso.items() if k.endswith("_ms")}
         roofline["hbm_bound_kernel"] = pillar
 

@@ -59,7 +59,7 @@ struct EmuArgs {
 
 enum { LAYOUT_NCHW = 0, LAYOUT_OUT_NHWC = 1, LAYOUT_IN_NHWC = 2 };
 
-template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE = 1>
+template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE = 1, int PBUF = 2>
 struct Geo {
     static constexpr int NCO = NPB >= 4 ? 2 : 1;                              // accumulator tiles (32 output channels each) per wave
     static constexpr int WAVES = NPB >= 4 ? NPB : 2 * NPB;
@@ -73,7 +73,10 @@ struct Geo {
     // KCH 8-channel chunks are processed per barrier.  LDS map (floats): two weight images of KCH chunks | two split patches
     // [chunk][term][y][x][8 cin] bf16
     static constexpr int W_OFF = 0, WSZ = KCH * WQ * 4, B_OFF = 2 * WSZ, BSZ1 = TERMS * PIX * 4, BSZ = KCH * BSZ1;
-    static constexpr size_t LDS_BYTES = ((size_t)B_OFF + 2 * (size_t)BSZ) * 4;
+    // PBUF = 1: ONE split-patch buffer (one more barrier per chunk: the next chunk's pixels are written after every wave has read the
+    // current ones).  With the 3-way split that takes a workgroup from 94 to 78 KB, i.e. TWO workgroups per CU: the barrier / operand
+    // phases of one overlap the MFMA phase of the other.
+    static constexpr size_t LDS_BYTES = ((size_t)B_OFF + PBUF * (size_t)BSZ) * 4;
 };
 
 struct Tile {
@@ -97,11 +100,11 @@ __device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[T
 // The split variant's occupancy is pinned (registers capped): its hand-over code, executed once per split tile, would otherwise
 // cost a resident workgroup -- the spills it causes sit outside the chunk loop.  8 wavefronts x 2 workgroups = 4 per SIMD, 12
 // wavefronts = 3 per SIMD.  (Pinning the plain variant as well changes hipcc's scheduling and was measured 5-20 % slower.)
-template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT, int STRIDE = 1, int LAYOUT = LAYOUT_NCHW>
+template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT, int STRIDE = 1, int LAYOUT = LAYOUT_NCHW, int PBUF = 2>
 __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB))
 __attribute__((amdgpu_waves_per_eu(SPLIT ? (NPB == 12 ? 3 : 4) : 1, SPLIT ? (NPB == 12 ? 3 : 4) : 8)))
 void conv3x3_emu_kernel(const EmuArgs a) {
-    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE>;
+    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF>;
     static_assert(!(SPLIT && (STRIDE != 1 || LAYOUT != LAYOUT_NCHW)), "stream-K hand-over only for the plain stride-1 NCHW variant");
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;      // wave: scalar
@@ -174,7 +177,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     };
     // ... split into bf16 terms and written as [term][pixel slot][8 cin] into split-patch buffer `slot`
     auto store_patch = [&](const Plan &pl, int slot, float (&v)[G::SLOTS][8 * KCH]) {
-        uint4 *bt = reinterpret_cast<uint4 *>(lds + G::B_OFF + slot * G::BSZ);
+        uint4 *bt = reinterpret_cast<uint4 *>(lds + G::B_OFF + (PBUF == 2 ? slot : 0) * G::BSZ);
 #pragma unroll
         for (int j = 0; j < G::SLOTS; ++j) {
             const int i = tid + j * G::THREADS;
@@ -282,7 +285,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                 load_patch(nplan, ns - nt * chunks, pv);
             }
             EMU_STAMP(3);
-            const uint4 *bq = reinterpret_cast<const uint4 *>(lds + G::B_OFF + (L & 1) * G::BSZ);
+            const uint4 *bq = reinterpret_cast<const uint4 *>(lds + G::B_OFF + (PBUF == 2 ? (L & 1) : 0) * G::BSZ);
             const uint4 *wq = reinterpret_cast<const uint4 *>(lds + G::W_OFF + (L & 1) * G::WSZ) + wlane;
             constexpr int NS = kSteps * KCH;           // MFMA steps of this interval: step = (8-channel chunk h, tap pair s)
             auto load_b = [&](int st, bf16x8 (&b)[TERMS]) {
@@ -327,6 +330,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                     }
                 }
             }
+            if (PBUF == 1) __syncthreads();            // every wave is done reading the single patch buffer
             if (more) store_patch(nplan, (L + 1) & 1, pv);
             EMU_STAMP(4);
         }
@@ -400,6 +404,12 @@ inline bool want_split(int total_tiles, int slots, int chunks) {
     return total_tiles * 10 < rounds * slots * 9;
 }
 
+// Output rows per workgroup tile (= wavefronts per workgroup).  Measured (tools/ab_bench.sh, round 2): tiles fitted to the map height
+// (13 rows for the 25-row maps, 10 for 50 / 100) cut the padded work by up to 19 % per layer and changed nothing in the pipeline
+// (259 vs 260 frames/s): a workgroup owns its CU (94 KB of LDS with the 3-way split), so what a layer costs is CUs x time, and
+// 13 wavefronts on 4 SIMDs quantise as badly as 26 rows on 8-row tiles.  The rule below is the round-1 one.
+inline int rows_per_tile(int H, int terms) { return (terms == 3 && H >= 64) ? 12 : 8; }
+
 // the strided / channels-last variants: whole tiles only (no stream-K), same persistent-workgroup schedule
 template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE, int LAYOUT>
 int launch_variant(const EmuArgs &a0, hipStream_t s) {
@@ -442,15 +452,15 @@ int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
         return COALIGN_ERR_UNSUPPORTED;
     }
     if (layout == LAYOUT_OUT_NHWC) {
-        if (TERMS == 3 && a.H >= 64) return launch_variant<1, 32, 12, TERMS, 1, 1, LAYOUT_OUT_NHWC>(a, s);
+        if (rows_per_tile(a.H, TERMS) == 12) return launch_variant<1, 32, 12, TERMS, 1, 1, LAYOUT_OUT_NHWC>(a, s);
         return launch_variant<1, 32, 8, TERMS, 1, 1, LAYOUT_OUT_NHWC>(a, s);
     }
     return COALIGN_ERR_UNSUPPORTED;
 }
 
-template <int BH, int BW, int NPB, int TERMS, int KCH>
+template <int BH, int BW, int NPB, int TERMS, int KCH, int PBUF = 2>
 int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream_t s, Launch *query) {
-    using G = Geo<BH, BW, NPB, TERMS, KCH>;
+    using G = Geo<BH, BW, NPB, TERMS, KCH, 1, PBUF>;
     static int resident = 0, cus = 0;
     if (!resident) {
         int dev = 0;
@@ -458,8 +468,8 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
         cus = prop.multiProcessorCount;
         for (int sp = 0; sp < 2; ++sp) {
-            const void *fn = sp ? reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true>)
-                                : reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false>);
+            const void *fn = sp ? reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT_NCHW, PBUF>)
+                                : reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, 1, LAYOUT_NCHW, PBUF>);
             const int rc = coalign::hip_call(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
             if (rc != COALIGN_OK) {                // geometry does not fit this device's LDS: report, leave no sticky error behind
                 (void)hipGetLastError();
@@ -467,7 +477,7 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
             }
         }
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true>, G::THREADS, G::LDS_BYTES) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT_NCHW, PBUF>, G::THREADS, G::LDS_BYTES) != hipSuccess || n < 1) n = 1;
         resident = n;
     }
     EmuArgs a = a0;
@@ -497,9 +507,9 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
         a.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + l.flag_bytes);
         const int rc = coalign::hip_call(hipMemsetAsync(workspace, 0, l.flag_bytes, s));
         if (rc != COALIGN_OK) return rc;
-        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT_NCHW, PBUF>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
     } else {
-        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, 1, LAYOUT_NCHW, PBUF>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
     }
     return COALIGN_OK;
 }
@@ -507,16 +517,19 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
 template <int TERMS>
 int dispatch(const EmuArgs &a, void *ws, size_t ws_bytes, hipStream_t s, Launch *query) {
     static const int force = getenv("COALIGN_EMU_GEO") ? atoi(getenv("COALIGN_EMU_GEO")) : -1;      // experiments only
-    // geometry code = 10 * (wavefronts per workgroup) + (8-channel chunks per barrier)
+    // geometry code = 10 * (wavefronts per workgroup = output rows per tile) + (8-channel chunks per barrier)
     const bool even = (a.Cin / kKC) % 2 == 0;
-    // measured: 8 wavefronts (two workgroups per CU with the 2-way split) everywhere, except the 3-way split on the large maps,
-    // whose single resident workgroup does better with 12
-    int geo = (TERMS == 3 && a.H >= 64) ? 121 : 81;
+    int geo = 10 * rows_per_tile(a.H, TERMS) + 1;
     if (force >= 0) geo = force;
+    // 3-way split: 8-wavefront workgroups with ONE split-patch buffer (78 KB of LDS: two workgroups per CU) on every map size.
+    // Measured in the pipeline (round 2, same box): 258-262 frames/s against 249-250 with the double-buffered 8 / 12-wavefront geometries.
+    static const int pbuf1 = getenv("COALIGN_EMU_PBUF1") ? atoi(getenv("COALIGN_EMU_PBUF1")) : 2;     // experiments: 0 = off, 1 = small maps only
+    if (force < 0 && TERMS == 3 && ((pbuf1 == 1 && geo == 81) || pbuf1 == 2)) geo = 83;
     if (!even && geo % 10 == 2) geo -= 1;
     switch (geo) {
         case 81: return launch<1, 32, 8, TERMS, 1>(a, ws, ws_bytes, s, query);
         case 82: return launch<1, 32, 8, TERMS, 2>(a, ws, ws_bytes, s, query);
+        case 83: return launch<1, 32, 8, TERMS, 1, 1>(a, ws, ws_bytes, s, query);          // one patch buffer: two workgroups per CU with the 3-way split
         case 121: return launch<1, 32, 12, TERMS, 1>(a, ws, ws_bytes, s, query);
         case 122: return launch<1, 32, 12, TERMS, 2>(a, ws, ws_bytes, s, query);
         case 41: return launch<1, 32, 4, TERMS, 1>(a, ws, ws_bytes, s, query);

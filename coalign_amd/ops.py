@@ -90,9 +90,10 @@ def _dbl3(v: Sequence[float]):
 def pillar_vfe_scatter(voxel_features: torch.Tensor, voxel_num_points: torch.Tensor, voxel_coords: torch.Tensor,
                        weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[Tuple[torch.Tensor, ...]], bn_eps: float,
                        use_absolute_xyz: bool, with_distance: bool, voxel_size: Sequence[float], range_min: Sequence[float],
-                       n_agents: int, ny: int, nx: int, channels_last: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+                       n_agents: int, ny: int, nx: int, channels_last: bool = False, overlap_clear: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """-> (pillar_features [M, C], canvas [n_agents, C, ny, nx]).  ``bn`` = (weight, bias, running_mean, running_var).
-    ``channels_last``: the canvas comes back in NHWC memory (same logical shape), see coalign_pillar_vfe_scatter_nhwc."""
+    ``channels_last``: the canvas comes back in NHWC memory (same logical shape), see coalign_pillar_vfe_scatter_nhwc;
+    ``overlap_clear`` (channels-last only): memset on a side stream next to the encoder (split entry points) instead of the one-call form."""
     _need_gpu(voxel_features, voxel_num_points, voxel_coords, weight)
     L = hip.lib()
     vf = _f32c(voxel_features)
@@ -112,12 +113,25 @@ def pillar_vfe_scatter(voxel_features: torch.Tensor, voxel_num_points: torch.Ten
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     bnp = [None] * 4 if bn is None else [_f32c(t) for t in bn]
     b = None if bias is None else _f32c(bias)
+    args = (_ptr(vf), _ptr(npts), _ptr(coords), M, P, _ptr(w), _ptr(b), _ptr(bnp[0]), _ptr(bnp[1]), _ptr(bnp[2]), _ptr(bnp[3]), float(bn_eps), C,
+            int(use_absolute_xyz), int(with_distance), _dbl3(voxel_size), _dbl3(range_min), n_agents, ny, nx, _ptr(feats))
     with _Timed("pillar_vfe_scatter"):
-      fn = L.coalign_pillar_vfe_scatter_nhwc if channels_last else L.coalign_pillar_vfe_scatter
-      hip.check(fn(_ptr(vf), _ptr(npts), _ptr(coords), M, P, _ptr(w), _ptr(b), _ptr(bnp[0]), _ptr(bnp[1]),
-                                           _ptr(bnp[2]), _ptr(bnp[3]), float(bn_eps), C, int(use_absolute_xyz), int(with_distance),
-                                           _dbl3(voxel_size), _dbl3(range_min), n_agents, ny, nx, _ptr(feats), _ptr(canvas),
-                                           _ptr(ws), ws_bytes, _stream()), "coalign_pillar_vfe_scatter")
+        if channels_last and C % 4 == 0 and M > 0 and overlap_clear and PILLAR_OVERLAP_CLEAR:
+            # the dense canvas memset (HBM bound, 27 us at OPV2V size) runs on a side stream next to the encoder (VALU bound, 25 us)
+            main = torch.cuda.current_stream(dev)
+            side = _SIDE_STREAMS.get((dev, main.cuda_stream))          # one per caller stream: frames in flight on different lanes stay independent
+            if side is None:
+                side = _SIDE_STREAMS[(dev, main.cuda_stream)] = torch.cuda.Stream(device=dev)
+            dest = torch.empty(M, dtype=torch.int32, device=dev)
+            side.wait_stream(main)
+            hip.check(L.coalign_canvas_clear(_ptr(canvas), canvas.numel() * 4, ctypes.c_void_p(side.cuda_stream)), "coalign_canvas_clear")
+            canvas.record_stream(side)
+            hip.check(L.coalign_pillar_encode(*args, _ptr(dest), _ptr(ws), ws_bytes, _stream()), "coalign_pillar_encode")
+            main.wait_stream(side)
+            hip.check(L.coalign_pillar_rows_to_canvas(_ptr(feats), _ptr(dest), M, C, _ptr(canvas), _stream()), "coalign_pillar_rows_to_canvas")
+        else:
+            fn = L.coalign_pillar_vfe_scatter_nhwc if channels_last else L.coalign_pillar_vfe_scatter
+            hip.check(fn(*args, _ptr(canvas), _ptr(ws), ws_bytes, _stream()), "coalign_pillar_vfe_scatter")
     return feats, canvas
 
 
@@ -380,6 +394,12 @@ def pose_graph_optimize(vertex_offsets: torch.Tensor, edge_offsets: torch.Tensor
                                                 int(max_iterations), _ptr(stats), _ptr(ws), ws_bytes, _stream()), "coalign_pose_graph_optimize")
     return out, stats
 
+
+# Measured on MI355X / ROCm 7.2 (tools/ab_bench.sh, same box): running the canvas memset on a side stream next to the encoder is SLOWER
+# than the one-call form -- 71 vs 64 us for the op alone, 212 vs 250 frames/s for the whole pipeline (every cross-stream event pair
+# costs more than the overlap wins, and four lanes already fill the GPU).  The split entry points stay for callers that want them; off.
+PILLAR_OVERLAP_CLEAR = __import__("os").environ.get("COALIGN_PILLAR_OVERLAP", "0") != "0"
+_SIDE_STREAMS: dict = {}                   # per device: the stream the canvas memset of the channels-last pillar route runs on
 
 CONV_KC, CONV_WSTRIDE = 8, 9 * 64 + 32      # kKC / kWStride of csrc/conv3x3.hip
 _CONV_WS: dict = {}

@@ -30,6 +30,9 @@ from . import ops
 from .encoder import host_ints
 from .postprocess import PostProcessHandle, VoxelPostprocessor
 
+import os as _os
+POST_PROCESS_SIDE_STREAM = _os.environ.get("COALIGN_PP_SIDE", "1") != "0"       # measurement switch (tools/ab_bench.sh)
+
 FrameResult = Tuple[int, Optional[torch.Tensor], Optional[torch.Tensor]]      # (frame index, pred_box3d [K', 8, 3], scores [K'])
 
 
@@ -105,7 +108,7 @@ class FramePipeline:
         with ops.timed("stage_fuse_and_heads"):
             out = model.fuse_and_head(feats, record, affine, rows)
         with ops.timed("stage_post_process(enqueue)"):
-            return self.pp.post_process_async(self.meta, {"ego": out})
+            return self.pp.post_process_async(self.meta, {"ego": out}, side_stream=POST_PROCESS_SIDE_STREAM)
 
     def _frame_body(self, slot: _GraphSlot, record: List[int]) -> None:
         batch = {"processed_lidar": {k: slot.inputs[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")},

@@ -1,0 +1,35 @@
+"""Thread sweep of the CPU oracle on the bench workload: frames/s of the numpy / torch-CPU restatement of the path
+for several torch thread counts on this host; prints one JSON object (kept as profiles/roundN/cpu_baseline_sweep.json)."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from coalign_amd.config import builtin_config
+from coalign_amd.detector import build_model
+from coalign_amd.postprocess import build_postprocessor
+from coalign_amd.synthetic import fill_parameters_, make_frame
+from oracle import coalign_oracle as oracle
+
+h = builtin_config("opv2v_coalign")
+model = build_model(h); fill_parameters_(model, seed=0)
+sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+pp = build_postprocessor(h["postprocess"], False)
+anchors = torch.from_numpy(pp.generate_anchor_box())
+frames = [make_frame(h, 5, pillars_per_agent=8000, seed=303 + i, noise=(0.2, 0.2)) for i in range(2)]
+cpu = "unknown"
+for line in open("/proc/cpuinfo"):
+    if line.startswith("model name"):
+        cpu = line.split(":", 1)[1].strip(); break
+res = {"cpu_model": cpu, "host_cores": os.cpu_count(), "workload": "5 agents x 8000 pillars, OPV2V CoAlign, model + post-process", "threads": {}}
+budget = float(os.environ.get("SWEEP_BUDGET_S", "20"))
+for t in (4, 8, 16, 32, 64, 128):
+    torch.set_num_threads(t)
+    with torch.no_grad():
+        out = oracle.coalign_forward(sd, h["model"]["args"], frames[0]); oracle.post_process([out], anchors, h["postprocess"])      # warm-up
+        n, t0 = 0, time.perf_counter()
+        while n < 3 and time.perf_counter() - t0 < budget:
+            out = oracle.coalign_forward(sd, h["model"]["args"], frames[n % 2]); oracle.post_process([out], anchors, h["postprocess"]); n += 1
+    res["threads"][str(t)] = {"frames": n, "frames_per_s": round(n / (time.perf_counter() - t0), 4)}
+    print(t, res["threads"][str(t)], file=sys.stderr, flush=True)
+best = max(res["threads"], key=lambda k: res["threads"][k]["frames_per_s"])
+res["best_threads"] = int(best)
+print(json.dumps(res))

@@ -1,0 +1,28 @@
+#!/bin/bash
+# SURVEY 8(e) on a 1-GPU box: bench.py with 2 gloo ranks sharing the GPU (exchange staged through host memory) must print the SAME
+# per-frame detection digests as the 1-rank run: real frames are routed through the frame ring, not i.i.d. per rank.
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/multirank; mkdir -p $OUT; cd $ROOT
+timeout 300 python bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-side-modes > $OUT/n1.json 2> $OUT/n1.err
+for R in 2 4; do
+COALIGN_BENCH_BACKEND=gloo COALIGN_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $R --master-addr 127.0.0.1 --master-port $((29650 + R)) \
+    bench.py --gpus $R --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes > $OUT/n$R.json 2> $OUT/n$R.err
+done
+python - $OUT <<'PY'
+import json,sys
+out=sys.argv[1]
+ref=json.loads([l for l in open(out+"/n1.json") if l.startswith("{")][-1])
+print("N=1 ", ref["value"], "frames/s, digests reproducible:", ref["frame_digests_reproducible"])
+ok=True
+for R in (2,4):
+    try:
+        d=json.loads([l for l in open(f"{out}/n{R}.json") if l.startswith("{")][-1])
+    except Exception as e:
+        print(f"N={R}: no result ({e})"); ok=False; continue
+    same=all(ref["frame_digests"].get(k)==v for k,v in d["frame_digests"].items())
+    print(f"N={R} (gloo, one GPU shared; functional only): {d['value']} frames/s, parallelism = {d['config']['parallelism']}, "
+          f"bytes sent per rank and step = {d.get('exchange_bytes_sent_per_rank_per_step')}, {len(d['frame_digests'])} pool frames, digests equal to N=1: {same}, reproducible: {d['frame_digests_reproducible']}")
+    ok = ok and same
+print("N=1 digests:", ref["frame_digests"])
+print("MULTIRANK_CHECK", "PASS" if ok else "FAIL")
+PY
