@@ -550,9 +550,12 @@ __device__ __forceinline__ void pair_compute(const PfnArgs &a, const ChanParams 
 
 // Persistent wavefronts: the channel parameters are loaded once, the operands of the NEXT pair and the cell-map entry of the
 // current one are in flight while the current pair is encoded -- one exposed memory round trip per wave instead of four per pair.
-// `canvas` == nullptr: only pillar_features and dest[m] (the pillar's canvas slot agent * ncell + cell, or -1 when it lost its cell or
-// lies outside) are written -- the split form, whose canvas memset runs concurrently on another stream (see coalign_pillar_encode).
-__global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_nhwc_kernel(PfnArgs a, float *__restrict__ canvas, int *__restrict__ dest) {
+// `dest` (optional): dest[m] = the pillar's canvas slot agent * ncell + cell, or -1 when it lost its cell or lies outside the canvas --
+// what the persistent-canvas form clears before the next frame.
+// `reset_cellmap`: the winner puts its cell-map entry back to -1 once it has read it (a loser that looks later sees -1 instead of the
+// winner's row -- not its own either way), so a persistent cell map is all -1 again when the kernel ends and needs no memset per frame.
+__global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_nhwc_kernel(PfnArgs a, float *__restrict__ canvas, int *__restrict__ dest,
+                                                                               int reset_cellmap) {
     __shared__ __attribute__((aligned(16))) float slabs[kWavesPerBlock * 64 * kFeatStride];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float *slab = slabs + wv * 64 * kFeatStride;
@@ -594,27 +597,37 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_nhwc_kernel(P
         const size_t slotB = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)shi, 32) << 32) | (unsigned)__builtin_amdgcn_readlane((int)slo, 32);
         if (lane < a.C) {
             a.feats[(size_t)mA * a.C + lane] = va;
-            if (canvas && winA) canvas[slotA * a.C + lane] = va;
+            if (winA) canvas[slotA * a.C + lane] = va;
             if (hasB) {
                 a.feats[(size_t)(mA + 1) * a.C + lane] = vb;
-                if (canvas && winB) canvas[slotB * a.C + lane] = vb;
+                if (winB) canvas[slotB * a.C + lane] = vb;
             }
         }
-        if (dest && (lane == 0 || (lane == 32 && hasB))) dest[m_lane] = win ? (int)slot : -1;
+        if (lane == 0 || (lane == 32 && hasB)) {
+            if (dest) dest[m_lane] = win ? (int)slot : -1;
+            if (reset_cellmap && win) a.cellmap[slot] = -1;
+        }
     }
 }
 
-// dest-driven row copy of the split form: one wavefront moves 4 pillar rows (16 lanes x 16 B each for C = 64)
-__global__ __launch_bounds__(256) void rows_to_canvas_kernel(const float *__restrict__ feats, const int *__restrict__ dest, int M, int C,
-                                                             float *__restrict__ canvas) {
-    const int c4 = C / 4;                                  // float4 per row
+// Persistent canvas, one launch: zero the rows the PREVIOUS frame wrote (its dest list) and enter the NEW frame's pillars into the
+// cell map (which the previous rows kernel left all -1).
+__global__ __launch_bounds__(256) void pillar_prep_kernel(const int *__restrict__ dest_prev, int M_prev, int C, float *__restrict__ canvas,
+                                                          const int4 *__restrict__ coords, int M, int n_agents, int ny, int nx,
+                                                          int *__restrict__ cellmap) {
+    const int c4 = C / 4;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long m = idx / c4;
-    if (m >= M) return;
-    const int q = (int)(idx - m * c4);
-    const int d = dest[m];
-    if (d < 0) return;
-    reinterpret_cast<float4 *>(canvas + (size_t)d * C)[q] = reinterpret_cast<const float4 *>(feats + (size_t)m * C)[q];
+    if (idx < (long)M_prev * c4) {
+        const long m = idx / c4;
+        const int d = dest_prev[m];
+        if (d >= 0) reinterpret_cast<float4 *>(canvas + (size_t)d * C)[(int)(idx - m * c4)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (idx < M) {
+        const int4 cd = coords[idx];
+        const int ncell = ny * nx;
+        const int cell = cd.y + cd.z * nx + cd.w;
+        if (cd.x >= 0 && cd.x < n_agents && cell >= 0 && cell < ncell) atomicMax(cellmap + (size_t)cd.x * ncell + cell, (int)idx);
+    }
 }
 
 int launch_canvas(const int *cellmap, const float *feats, int C, int ncell, int n_agents, float *canvas, hipStream_t stream) {
@@ -644,11 +657,11 @@ static int pillar_vfe_scatter_impl(const float *voxel_features, const int32_t *v
                                const float *bn_bias, const float *bn_mean, const float *bn_var, float bn_eps, int C,
                                int use_absolute_xyz, int with_distance, const double *voxel_size, const double *range_min,
                                int n_agents, int ny, int nx, float *pillar_features, float *canvas, void *workspace,
-                               size_t workspace_bytes, void *stream_, bool nhwc, int32_t *dest = nullptr) {
+                               size_t workspace_bytes, void *stream_, bool nhwc) {
     using namespace coalign;
     hipStream_t stream = (hipStream_t)stream_;
     if (M < 0 || P <= 0 || C <= 0 || n_agents <= 0 || ny <= 0 || nx <= 0) return COALIGN_ERR_BAD_SHAPE;
-    if (!pfn_weight || !voxel_size || !range_min || (!canvas && !dest) || !workspace) return COALIGN_ERR_NULL_POINTER;
+    if (!pfn_weight || !voxel_size || !range_min || !canvas || !workspace) return COALIGN_ERR_NULL_POINTER;
     if (M > 0 && (!voxel_features || !voxel_num_points || !voxel_coords || !pillar_features)) return COALIGN_ERR_NULL_POINTER;
     const bool has_bn = bn_weight || bn_bias || bn_mean || bn_var;
     if (has_bn && !(bn_weight && bn_bias && bn_mean && bn_var)) return COALIGN_ERR_NULL_POINTER;
@@ -662,8 +675,7 @@ static int pillar_vfe_scatter_impl(const float *voxel_features, const int32_t *v
     int *cellmap = (int *)workspace;
     int rc = hip_call(hipMemsetAsync(cellmap, 0xFF, (size_t)n_agents * ncell * sizeof(int), stream));
     if (rc) return rc;
-    if (nhwc && canvas && (rc = hip_call(hipMemsetAsync(canvas, 0, (size_t)n_agents * ncell * C * sizeof(float), stream)))) return rc;
-    if (nhwc && dest && (size_t)n_agents * ncell > (size_t)INT32_MAX) return COALIGN_ERR_BAD_SHAPE;
+    if (nhwc && (rc = hip_call(hipMemsetAsync(canvas, 0, (size_t)n_agents * ncell * C * sizeof(float), stream)))) return rc;
 
     if (M > 0) {
         PfnArgs a;
@@ -684,7 +696,7 @@ static int pillar_vfe_scatter_impl(const float *voxel_features, const int32_t *v
             const int pairs = (M + 1) / 2;
             const int want = (pairs + kWavesPerBlock - 1) / kWavesPerBlock;
             const int cap = 256 * 4;                       // 4 workgroups (16 wavefronts) per CU are resident at this kernel's 112 registers
-            hipLaunchKernelGGL(pillar_rows_nhwc_kernel, dim3(want < cap ? want : cap), dim3(kWavesPerBlock * 64), 0, stream, a, canvas, dest);
+            hipLaunchKernelGGL(pillar_rows_nhwc_kernel, dim3(want < cap ? want : cap), dim3(kWavesPerBlock * 64), 0, stream, a, canvas, (int *)nullptr, 0);
             return check_launch();
         }
         if (P <= 64 && C <= 64 && !getenv("COALIGN_UNFUSED_PILLARS")) {
@@ -735,30 +747,43 @@ int coalign_pillar_vfe_scatter_nhwc(const float *voxel_features, const int32_t *
                                    workspace, workspace_bytes, stream, true);
 }
 
-int coalign_pillar_encode(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M, int P,
-                          const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias, const float *bn_mean,
-                          const float *bn_var, float bn_eps, int C, int use_absolute_xyz, int with_distance, const double *voxel_size,
-                          const double *range_min, int n_agents, int ny, int nx, float *pillar_features, int32_t *dest, void *workspace,
-                          size_t workspace_bytes, void *stream) {
-    if (!dest && M > 0) return COALIGN_ERR_NULL_POINTER;
-    return pillar_vfe_scatter_impl(voxel_features, voxel_num_points, voxel_coords, M, P, pfn_weight, pfn_bias, bn_weight, bn_bias, bn_mean, bn_var,
-                                   bn_eps, C, use_absolute_xyz, with_distance, voxel_size, range_min, n_agents, ny, nx, pillar_features, nullptr,
-                                   workspace, workspace_bytes, stream, true, dest ? dest : reinterpret_cast<int32_t *>(workspace));
-}
-
-int coalign_canvas_clear(float *canvas, size_t bytes, void *stream) {
-    if (!canvas && bytes) return COALIGN_ERR_NULL_POINTER;
-    return coalign::hip_call(hipMemsetAsync(canvas, 0, bytes, (hipStream_t)stream));
-}
-
-int coalign_pillar_rows_to_canvas(const float *pillar_features, const int32_t *dest, int M, int C, float *canvas, void *stream) {
+int coalign_pillar_encode_persistent(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M, int P,
+                                     const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias,
+                                     const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz, int with_distance,
+                                     const double *voxel_size, const double *range_min, int n_agents, int ny, int nx, float *pillar_features,
+                                     int32_t *dest, int M_prev, float *canvas, int32_t *cellmap, void *stream_) {
     using namespace coalign;
-    if (M < 0 || C < 4 || C % 4) return COALIGN_ERR_BAD_SHAPE;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M < 0 || M_prev < 0 || P <= 0 || P > 32 || C < 4 || C > 64 || C % 4 || n_agents <= 0 || ny <= 0 || nx <= 0) return COALIGN_ERR_BAD_SHAPE;
+    if (!pfn_weight || !voxel_size || !range_min || !canvas || !cellmap || ((M > 0 || M_prev > 0) && !dest)) return COALIGN_ERR_NULL_POINTER;
+    if (M > 0 && (!voxel_features || !voxel_num_points || !voxel_coords || !pillar_features)) return COALIGN_ERR_NULL_POINTER;
+    const bool has_bn = bn_weight || bn_bias || bn_mean || bn_var;
+    if (has_bn && !(bn_weight && bn_bias && bn_mean && bn_var)) return COALIGN_ERR_NULL_POINTER;
+    if ((size_t)n_agents * ny * nx > (size_t)INT32_MAX) return COALIGN_ERR_BAD_SHAPE;
+    const int Cin = (use_absolute_xyz ? 4 : 1) + 6 + (with_distance ? 1 : 0);
+    if (Cin > kFeatStride) return COALIGN_ERR_UNSUPPORTED;
+    const long threads = (long)M_prev * (C / 4) > M ? (long)M_prev * (C / 4) : M;
+    if (threads > 0) {
+        hipLaunchKernelGGL(pillar_prep_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, dest, M_prev, C, canvas,
+                           (const int4 *)voxel_coords, M, n_agents, ny, nx, cellmap);
+        int rc = check_launch();
+        if (rc) return rc;
+    }
     if (M == 0) return COALIGN_OK;
-    if (!pillar_features || !dest || !canvas) return COALIGN_ERR_NULL_POINTER;
-    if ((reinterpret_cast<uintptr_t>(pillar_features) | reinterpret_cast<uintptr_t>(canvas)) & 15) return COALIGN_ERR_UNSUPPORTED;
-    const long threads = (long)M * (C / 4);
-    hipLaunchKernelGGL(rows_to_canvas_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pillar_features, dest, M, C, canvas);
+    PfnArgs a;
+    a.pts = (const float4 *)voxel_features; a.npts = voxel_num_points; a.coords = (const int4 *)voxel_coords;
+    a.M = M; a.P = P;
+    a.weight = pfn_weight; a.bias = pfn_bias; a.bn_w = bn_weight; a.bn_b = bn_bias; a.bn_m = bn_mean; a.bn_v = bn_var;
+    a.eps = bn_eps; a.C = C; a.Cin = Cin; a.use_abs = use_absolute_xyz; a.with_dist = with_distance;
+    a.vx = (float)voxel_size[0]; a.vy = (float)voxel_size[1]; a.vz = (float)voxel_size[2];
+    a.xo = (float)(voxel_size[0] / 2 + range_min[0]);
+    a.yo = (float)(voxel_size[1] / 2 + range_min[1]);
+    a.zo = (float)(voxel_size[2] / 2 + range_min[2]);
+    a.n_agents = n_agents; a.ny = ny; a.nx = nx; a.feats = pillar_features; a.cellmap = cellmap;
+    const int pairs = (M + 1) / 2;
+    const int want = (pairs + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int cap = 256 * 4;
+    hipLaunchKernelGGL(pillar_rows_nhwc_kernel, dim3(want < cap ? want : cap), dim3(kWavesPerBlock * 64), 0, stream, a, canvas, dest, 1);
     return check_launch();
 }
 

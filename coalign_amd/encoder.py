@@ -58,6 +58,10 @@ class PillarVFE(nn.Module):
         self.x_offset = self.voxel_x / 2 + self.point_cloud_range[0]
         self.y_offset = self.voxel_y / 2 + self.point_cloud_range[1]
         self.z_offset = self.voxel_z / 2 + self.point_cloud_range[2]
+        # Opt-in (FramePipeline turns it on): keep one canvas per HIP stream alive and clear only the rows the previous frame wrote instead
+        # of zero-filling 36 MB per agent every frame.  The returned ``spatial_features`` is then overwritten by the next forward on the
+        # same stream -- fine for a detector that runs its backbone right away, wrong for a caller that holds canvases across frames.
+        self.persistent_canvas = False
         self.nx = int(round((self.point_cloud_range[3] - self.point_cloud_range[0]) / self.voxel_x))
         self.ny = int(round((self.point_cloud_range[4] - self.point_cloud_range[1]) / self.voxel_y))
 
@@ -81,7 +85,7 @@ class PillarVFE(nn.Module):
         feats, canvas = ops.pillar_vfe_scatter(
             vf, npts, coords, pfn.linear.weight, pfn.linear.bias, bn, pfn.norm.eps if self.use_norm else 0.0,
             self.use_absolute_xyz, self.with_distance, self.voxel_size, self.point_cloud_range[:3], n_agents, self.ny, self.nx,
-            channels_last=channels_last)
+            channels_last=channels_last, canvas_cache=self.__dict__.setdefault("_canvas_cache", {}) if self.persistent_canvas else None)
         batch_dict["pillar_features"] = feats
         batch_dict["_fused_canvas"] = (feats, canvas)
         return batch_dict

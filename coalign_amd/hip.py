@@ -25,10 +25,8 @@ SIGNATURES = {
                                            POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, P, c_size_t, P]),
     "coalign_pillar_vfe_scatter_nhwc": (c_int, [P, P, P, c_int, c_int, P, P, P, P, P, P, c_float, c_int, c_int, c_int,
                                                 POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, P, c_size_t, P]),
-    "coalign_pillar_encode": (c_int, [P, P, P, c_int, c_int, P, P, P, P, P, P, c_float, c_int, c_int, c_int,
-                                      POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, P, c_size_t, P]),
-    "coalign_canvas_clear": (c_int, [P, c_size_t, P]),
-    "coalign_pillar_rows_to_canvas": (c_int, [P, P, c_int, c_int, P, P]),
+    "coalign_pillar_encode_persistent": (c_int, [P, P, P, c_int, c_int, P, P, P, P, P, P, c_float, c_int, c_int, c_int,
+                                                 POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, c_int, P, P, P]),
     "coalign_scatter_to_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     "coalign_warp_fuse": (c_int, [P, c_int, c_int, c_int, c_int, P, POINTER(c_int32), c_int, c_int, P, c_int, c_int, P]),
     "coalign_warp_fuse_rows": (c_int, [P, c_int, c_int, c_int, c_int, P, POINTER(c_int32), c_int, POINTER(c_int32), c_int, P, c_int, c_int, P]),

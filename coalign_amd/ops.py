@@ -90,10 +90,15 @@ def _dbl3(v: Sequence[float]):
 def pillar_vfe_scatter(voxel_features: torch.Tensor, voxel_num_points: torch.Tensor, voxel_coords: torch.Tensor,
                        weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[Tuple[torch.Tensor, ...]], bn_eps: float,
                        use_absolute_xyz: bool, with_distance: bool, voxel_size: Sequence[float], range_min: Sequence[float],
-                       n_agents: int, ny: int, nx: int, channels_last: bool = False, overlap_clear: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+                       n_agents: int, ny: int, nx: int, channels_last: bool = False,
+                       canvas_cache: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """-> (pillar_features [M, C], canvas [n_agents, C, ny, nx]).  ``bn`` = (weight, bias, running_mean, running_var).
     ``channels_last``: the canvas comes back in NHWC memory (same logical shape), see coalign_pillar_vfe_scatter_nhwc;
-    ``overlap_clear`` (channels-last only): memset on a side stream next to the encoder (split entry points) instead of the one-call form."""
+    ``canvas_cache`` (channels-last only): a dict the caller keeps; the canvas is then a PERSISTENT tensor (one per device, stream and
+    shape) of which only the rows the previous call wrote are cleared -- 10 MB instead of a 180 MB memset, two launches per frame
+    (coalign_pillar_encode_persistent) -- and which the next call with the same cache on the same stream overwrites: for callers that
+    consume the canvas before they encode the next frame.  (Also measured and rejected: the memset on a side stream next to the VALU-bound
+    encoder -- 71 vs 64 us for the op and 212 vs 250 frames/s for the pipeline; cross-stream events cost more than the overlap wins.)"""
     _need_gpu(voxel_features, voxel_num_points, voxel_coords, weight)
     L = hip.lib()
     vf = _f32c(voxel_features)
@@ -107,29 +112,36 @@ def pillar_vfe_scatter(voxel_features: torch.Tensor, voxel_num_points: torch.Ten
     dev = vf.device
     feats = torch.empty((M, C), dtype=torch.float32, device=dev)
     channels_last = bool(channels_last) and P <= 32 and C <= 64 and C > 1 and ny * nx > 1
-    canvas = torch.empty((n_agents, C, ny, nx), dtype=torch.float32, device=dev,
-                         memory_format=torch.channels_last if channels_last else torch.contiguous_format)
-    ws_bytes = L.coalign_pillar_scatter_workspace_bytes(n_agents, ny, nx)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    entry = None
+    if channels_last and canvas_cache is not None and C % 4 == 0:
+        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream, n_agents, C, ny, nx)
+        entry = canvas_cache.get(key)
+        if entry is None or entry["M"] < 0:              # first use (or a failed call before): a zeroed canvas, an all -1 cell map
+            entry = canvas_cache[key] = {"canvas": torch.empty((n_agents, C, ny, nx), dtype=torch.float32, device=dev, memory_format=torch.channels_last).zero_(),
+                                         "cellmap": torch.full((n_agents * ny * nx,), -1, dtype=torch.int32, device=dev),
+                                         "dest": torch.empty(max(M, 1), dtype=torch.int32, device=dev), "M": 0}
+        canvas = entry["canvas"]
+    else:
+        canvas = torch.empty((n_agents, C, ny, nx), dtype=torch.float32, device=dev,
+                             memory_format=torch.channels_last if channels_last else torch.contiguous_format)
     bnp = [None] * 4 if bn is None else [_f32c(t) for t in bn]
     b = None if bias is None else _f32c(bias)
     args = (_ptr(vf), _ptr(npts), _ptr(coords), M, P, _ptr(w), _ptr(b), _ptr(bnp[0]), _ptr(bnp[1]), _ptr(bnp[2]), _ptr(bnp[3]), float(bn_eps), C,
             int(use_absolute_xyz), int(with_distance), _dbl3(voxel_size), _dbl3(range_min), n_agents, ny, nx, _ptr(feats))
     with _Timed("pillar_vfe_scatter"):
-        if channels_last and C % 4 == 0 and M > 0 and overlap_clear and PILLAR_OVERLAP_CLEAR:
-            # the dense canvas memset (HBM bound, 27 us at OPV2V size) runs on a side stream next to the encoder (VALU bound, 25 us)
-            main = torch.cuda.current_stream(dev)
-            side = _SIDE_STREAMS.get((dev, main.cuda_stream))          # one per caller stream: frames in flight on different lanes stay independent
-            if side is None:
-                side = _SIDE_STREAMS[(dev, main.cuda_stream)] = torch.cuda.Stream(device=dev)
-            dest = torch.empty(M, dtype=torch.int32, device=dev)
-            side.wait_stream(main)
-            hip.check(L.coalign_canvas_clear(_ptr(canvas), canvas.numel() * 4, ctypes.c_void_p(side.cuda_stream)), "coalign_canvas_clear")
-            canvas.record_stream(side)
-            hip.check(L.coalign_pillar_encode(*args, _ptr(dest), _ptr(ws), ws_bytes, _stream()), "coalign_pillar_encode")
-            main.wait_stream(side)
-            hip.check(L.coalign_pillar_rows_to_canvas(_ptr(feats), _ptr(dest), M, C, _ptr(canvas), _stream()), "coalign_pillar_rows_to_canvas")
+        if entry is not None:
+            need = max(M, entry["M"], 1)
+            if entry["dest"].numel() < need:
+                grown = torch.empty(need, dtype=torch.int32, device=dev)
+                grown[: entry["dest"].numel()] = entry["dest"]
+                entry["dest"] = grown
+            m_prev, entry["M"] = entry["M"], -1            # an exception below leaves the entry marked unusable
+            hip.check(L.coalign_pillar_encode_persistent(*args, _ptr(entry["dest"]), m_prev, _ptr(canvas), _ptr(entry["cellmap"]), _stream()),
+                      "coalign_pillar_encode_persistent")
+            entry["M"] = M
         else:
+            ws_bytes = L.coalign_pillar_scatter_workspace_bytes(n_agents, ny, nx)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             fn = L.coalign_pillar_vfe_scatter_nhwc if channels_last else L.coalign_pillar_vfe_scatter
             hip.check(fn(*args, _ptr(canvas), _ptr(ws), ws_bytes, _stream()), "coalign_pillar_vfe_scatter")
     return feats, canvas
@@ -394,12 +406,6 @@ def pose_graph_optimize(vertex_offsets: torch.Tensor, edge_offsets: torch.Tensor
                                                 int(max_iterations), _ptr(stats), _ptr(ws), ws_bytes, _stream()), "coalign_pose_graph_optimize")
     return out, stats
 
-
-# Measured on MI355X / ROCm 7.2 (tools/ab_bench.sh, same box): running the canvas memset on a side stream next to the encoder is SLOWER
-# than the one-call form -- 71 vs 64 us for the op alone, 212 vs 250 frames/s for the whole pipeline (every cross-stream event pair
-# costs more than the overlap wins, and four lanes already fill the GPU).  The split entry points stay for callers that want them; off.
-PILLAR_OVERLAP_CLEAR = __import__("os").environ.get("COALIGN_PILLAR_OVERLAP", "0") != "0"
-_SIDE_STREAMS: dict = {}                   # per device: the stream the canvas memset of the channels-last pillar route runs on
 
 CONV_KC, CONV_WSTRIDE = 8, 9 * 64 + 32      # kKC / kWStride of csrc/conv3x3.hip
 _CONV_WS: dict = {}

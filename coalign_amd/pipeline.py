@@ -71,6 +71,8 @@ class FramePipeline:
                  graph: bool = False, device=None, transformation_matrix: Optional[torch.Tensor] = None,
                  exchange: Optional[Sequence[Callable]] = None):
         self.model = model
+        if hasattr(model, "pillar_vfe"):
+            model.pillar_vfe.persistent_canvas = True        # every lane runs its backbone before it encodes its next frame
         self.pp = post_processor
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
         if self.device.type != "cuda":
@@ -113,7 +115,15 @@ class FramePipeline:
     def _frame_body(self, slot: _GraphSlot, record: List[int]) -> None:
         batch = {"processed_lidar": {k: slot.inputs[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")},
                  "record_len": record, "pairwise_t_matrix": slot.inputs["pairwise_t_matrix"]}
-        out = self.model(batch)
+        vfe = getattr(self.model, "pillar_vfe", None)
+        keep = getattr(vfe, "persistent_canvas", False)
+        try:
+            if vfe is not None:
+                vfe.persistent_canvas = False        # a graph bakes its launches: the "rows of the previous frame" bookkeeping is eager-only
+            out = self.model(batch)
+        finally:
+            if vfe is not None:
+                vfe.persistent_canvas = keep
         if slot.buf is None:
             slot.buf = self.pp.decode_buffers({"ego": out})
         self.pp.enqueue(self.meta, {"ego": out}, slot.buf)

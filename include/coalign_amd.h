@@ -75,21 +75,15 @@ int coalign_pillar_vfe_scatter_nhwc(const float *voxel_features, const int32_t *
                                     const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz, int with_distance,
                                     const double *voxel_size, const double *range_min, int n_agents, int ny, int nx, float *pillar_features,
                                     float *canvas, void *workspace, size_t workspace_bytes, void *stream);
-/* The split form of the channels-last route, for callers that can run the dense canvas memset on a second stream while the encoder
- * (VALU bound) runs on the first -- coalign_amd/ops.py does: coalign_canvas_clear on a side stream || coalign_pillar_encode, join,
- * coalign_pillar_rows_to_canvas.
- *   coalign_pillar_encode          pillar_features [M, C] and dest [M] int32: the pillar's canvas slot (agent * ny * nx + cell) or -1
- *                                  when it lost its cell to a larger row or lies outside the canvas (same workspace as above)
- *   coalign_canvas_clear           hipMemsetAsync(canvas, 0, bytes)
- *   coalign_pillar_rows_to_canvas  canvas[dest[m]] = pillar_features[m] for dest[m] >= 0 (C % 4 == 0) */
-int coalign_pillar_encode(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M, int P,
-                          const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias, const float *bn_mean,
-                          const float *bn_var, float bn_eps, int C, int use_absolute_xyz, int with_distance, const double *voxel_size,
-                          const double *range_min, int n_agents, int ny, int nx, float *pillar_features, int32_t *dest, void *workspace,
-                          size_t workspace_bytes, void *stream);
-int coalign_canvas_clear(float *canvas, size_t bytes, void *stream);
-int coalign_pillar_rows_to_canvas(const float *pillar_features, const int32_t *dest, int M, int C, float *canvas, void *stream);
-
+/* The persistent-canvas form, two launches per frame and no memset: canvas [n_agents, ny, nx, C] and cellmap [n_agents * ny * nx] int32
+ * are kept by the caller across frames -- canvas zeroed and cellmap filled with -1 ONCE -- and dest [>= max(M, M_prev)] holds the slots the
+ * previous call wrote (M_prev of them; 0 on the first call).  Launch 1 zeroes those rows and enters the new pillars into the cell map,
+ * launch 2 encodes, writes pillar_features, the winners' canvas rows and the new dest, and leaves the cell map all -1 again. */
+int coalign_pillar_encode_persistent(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M, int P,
+                                     const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias,
+                                     const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz, int with_distance,
+                                     const double *voxel_size, const double *range_min, int n_agents, int ny, int nx, float *pillar_features,
+                                     int32_t *dest, int M_prev, float *canvas, int32_t *cellmap, void *stream);
 /* Scatter only (PointPillarScatter.forward on already-encoded pillars): pillar_features [M, C] -> canvas.
  * Same cell rule, duplicate rule and workspace as above. */
 int coalign_scatter_to_bev(const float *pillar_features, const int32_t *voxel_coords, int M, int C, int n_agents, int ny,

@@ -286,7 +286,7 @@ def test_pillar_channels_last_canvas_equals_nchw():
     from coalign_amd.synthetic import make_frame
     p = "pillar_vfe.pfn_layers.0."
 
-    def run(h, pl, n_agents, cl, seed=0, overlap=True):
+    def run(h, pl, n_agents, cl, seed=0):
         margs = h["model"]["args"]
         model = build_model(h)
         fill_parameters_(model, seed=seed)
@@ -294,7 +294,7 @@ def test_pillar_channels_last_canvas_equals_nchw():
         nx, ny, _ = [int(v) for v in margs["point_pillar_scatter"]["grid_size"]]
         bn = tuple(sd[p + k].to(DEV) for k in ("norm.weight", "norm.bias", "norm.running_mean", "norm.running_var"))
         return ops.pillar_vfe_scatter(pl["voxel_features"].to(DEV), pl["voxel_num_points"].to(DEV), pl["voxel_coords"].to(DEV), sd[p + "linear.weight"].to(DEV),
-                                      None, bn, 1e-3, True, False, margs["voxel_size"], margs["lidar_range"][:3], n_agents, ny, nx, channels_last=cl, overlap_clear=overlap)
+                                      None, bn, 1e-3, True, False, margs["voxel_size"], margs["lidar_range"][:3], n_agents, ny, nx, channels_last=cl)
 
     h = builtin_config("opv2v_coalign")
     pl = make_frame(h, 5, pillars_per_agent=8000, seed=303, noise=(0.2, 0.2))["processed_lidar"]
@@ -302,8 +302,6 @@ def test_pillar_channels_last_canvas_equals_nchw():
     f1, c1 = run(h, pl, 5, True)
     assert ops.is_channels_last(c1) and c0.is_contiguous() and c1.shape == c0.shape
     assert torch.equal(f0, f1) and torch.equal(c1.contiguous(), c0)
-    f2, c2 = run(h, pl, 5, True, overlap=False)               # the one-call form (memset, cell map, rows kernel on one stream)
-    assert torch.equal(f0, f2) and torch.equal(c2.contiguous(), c0)
     hm = builtin_config("mini_coalign")
     pl = make_frame(hm, 2, pillars_per_agent=601, seed=5, num_points_mode="uniform")["processed_lidar"]      # odd total count
     pl = {k: v[:-1].clone() for k, v in pl.items()}
@@ -315,8 +313,32 @@ def test_pillar_channels_last_canvas_equals_nchw():
     f0, c0 = run(hm, pl, 2, False, seed=3)
     f1, c1 = run(hm, pl, 2, True, seed=3)
     assert torch.equal(f0, f1) and torch.equal(c1.contiguous(), c0)
-    f2, c2 = run(hm, pl, 2, True, seed=3, overlap=False)
-    assert torch.equal(f0, f2) and torch.equal(c2.contiguous(), c0)
     empty = {"voxel_features": torch.zeros(0, 32, 4), "voxel_num_points": torch.zeros(0, dtype=torch.int32), "voxel_coords": torch.zeros(0, 4, dtype=torch.int32)}
     f1, c1 = run(hm, empty, 2, True)
     assert f1.shape == (0, 64) and float(c1.abs().sum()) == 0.0
+
+
+def test_pillar_persistent_canvas_equals_fresh_canvas():
+    """canvas_cache: only the rows the previous call wrote are cleared (coalign_pillar_rows_clear); a sequence of different frames,
+    different pillar counts included, gives exactly the canvases a fresh memset gives."""
+    from coalign_amd.synthetic import make_frame
+    h = builtin_config("opv2v_coalign")
+    margs = h["model"]["args"]
+    model = build_model(h)
+    fill_parameters_(model, seed=0)
+    sd = model.state_dict()
+    p = "pillar_vfe.pfn_layers.0."
+    bn = tuple(sd[p + k].to(DEV) for k in ("norm.weight", "norm.bias", "norm.running_mean", "norm.running_var"))
+    w = sd[p + "linear.weight"].to(DEV)
+    frames = [to_device(make_frame(h, 3, pillars_per_agent=m, seed=70 + i)["processed_lidar"], DEV) for i, m in enumerate((5000, 7000, 100, 6000))]
+    cache = {}
+
+    def run(pl, c):
+        return ops.pillar_vfe_scatter(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], w, None, bn, 1e-3, True, False,
+                                      margs["voxel_size"], margs["lidar_range"][:3], 3, 200, 704, channels_last=True, canvas_cache=c)
+
+    for i in (0, 1, 2, 3, 0, 2):
+        f_ref, c_ref = run(frames[i], None)
+        f, c = run(frames[i], cache)
+        assert torch.equal(f, f_ref) and torch.equal(c, c_ref), i
+    assert len(cache) == 1

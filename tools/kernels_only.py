@@ -40,9 +40,12 @@ def pillar(cl):
                                           margs["voxel_size"], margs["lidar_range"][:3], N, 200, 704, channels_last=cl)
 
 
+_cache = {}
 OPS = {
     "pillar_nchw": pillar(False),
     "pillar_nhwc": pillar(True),
+    "pillar_nhwc_persistent": lambda: ops.pillar_vfe_scatter(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], pfn.linear.weight, None, bn, 1e-3, True, False,
+                                                             margs["voxel_size"], margs["lidar_range"][:3], N, 200, 704, channels_last=True, canvas_cache=_cache),
     "fuse_nchw_C64": lambda: ops.warp_fuse(xs[0], theta, [N], ops.FUSE_ATT),
     "fuse_nchw_C128": lambda: ops.warp_fuse(xs[1], theta, [N], ops.FUSE_ATT),
     "fuse_nchw_C256": lambda: ops.warp_fuse(xs[2], theta, [N], ops.FUSE_ATT),
