@@ -46,4 +46,32 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Workspace / flag clearing as a KERNEL instead of hipMemsetAsync.  Under HIP-graph replay (ROCm 7.2) a memset node followed by a kernel
+// that polls or accumulates into the cleared words was observed to race from an idle GPU (wrong stream-K hand-overs in the first replays
+// after a device synchronise, tools/diag_graph.py); a kernel node is ordered like every other kernel of the capture.
+static __global__ void fill_words_kernel(unsigned *__restrict__ p, size_t n_words, unsigned value) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) p[i] = value;
+}
+
+static __global__ void fill_vec4_kernel(uint4 *__restrict__ p, size_t n_vec, unsigned value) {      // 16 B per lane, coalesced
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_vec) p[i] = make_uint4(value, value, value, value);
+}
+
+inline int fill_words(void *p, size_t n_words, unsigned value, hipStream_t stream) {
+    if (n_words == 0) return COALIGN_OK;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && n_words >= 1024) {
+        const size_t n_vec = n_words / 4;
+        hipLaunchKernelGGL(fill_vec4_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, stream, static_cast<uint4 *>(p), n_vec, value);
+        int rc = check_launch();
+        if (rc) return rc;
+        p = static_cast<unsigned *>(p) + n_vec * 4;
+        n_words -= n_vec * 4;
+        if (n_words == 0) return COALIGN_OK;
+    }
+    hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, static_cast<unsigned *>(p), n_words, value);
+    return check_launch();
+}
+
 }  // namespace coalign

@@ -297,7 +297,7 @@ int launch(const ConvArgs &a0, void *workspace, size_t workspace_bytes, hipStrea
     const size_t flag_bytes = coalign::align_up((size_t)(grid + 1) * sizeof(int), 256);
     a.flags = static_cast<int *>(workspace);
     a.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + flag_bytes);
-    const int rc = coalign::hip_call(hipMemsetAsync(workspace, 0, flag_bytes, s));
+    const int rc = coalign::fill_words(workspace, flag_bytes / 4, 0u, s);
     if (rc != COALIGN_OK) return rc;
     if (a.Cin / kKC >= kSplitChunks) hipLaunchKernelGGL((conv3x3_kernel<BH, BW, NPB, true>), dim3(grid), dim3(G::THREADS), 0, s, a);
     else hipLaunchKernelGGL((conv3x3_kernel<BH, BW, NPB, false>), dim3(grid), dim3(G::THREADS), 0, s, a);

@@ -505,7 +505,7 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
         if (workspace_bytes < l.ws_bytes) return COALIGN_ERR_WORKSPACE;
         a.flags = static_cast<int *>(workspace);
         a.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + l.flag_bytes);
-        const int rc = coalign::hip_call(hipMemsetAsync(workspace, 0, l.flag_bytes, s));
+        const int rc = coalign::fill_words(workspace, l.flag_bytes / 4, 0u, s);
         if (rc != COALIGN_OK) return rc;
         hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT_NCHW, PBUF>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
     } else {

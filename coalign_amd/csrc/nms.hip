@@ -504,7 +504,7 @@ int coalign_nms_rotated(const float *boxes, int rows, int cols, const float *sco
     if (top > 4096) return COALIGN_ERR_UNSUPPORTED;
     if (!keep_count || !workspace || !keep) return COALIGN_ERR_NULL_POINTER;
     if (workspace_bytes < coalign_nms_rotated_workspace_bytes(K, top)) return COALIGN_ERR_WORKSPACE;
-    if (K == 0) return hip_call(hipMemsetAsync(keep_count, 0, sizeof(int), stream));
+    if (K == 0) return fill_words(keep_count, 1, 0u, stream);
     if (!boxes || !scores) return COALIGN_ERR_NULL_POINTER;
     NmsWs w = carve(workspace, top);
     const int nb = (top + 63) / 64;
@@ -580,7 +580,7 @@ int coalign_pcdet_nms(const float *boxes_sorted, int n, float thresh, int normal
     if (n < 0) return COALIGN_ERR_BAD_SHAPE;
     if (n > 64 * 64 * kBigWords) return COALIGN_ERR_UNSUPPORTED;
     if (!keep_count) return COALIGN_ERR_NULL_POINTER;
-    if (n == 0) return hip_call(hipMemsetAsync(keep_count, 0, sizeof(int), stream));
+    if (n == 0) return fill_words(keep_count, 1, 0u, stream);
     if (!boxes_sorted || !keep || !workspace) return COALIGN_ERR_NULL_POINTER;
     if (workspace_bytes < coalign_pcdet_nms_workspace_bytes(n)) return COALIGN_ERR_WORKSPACE;
     const int nb = (n + 63) / 64;

@@ -111,6 +111,77 @@ __device__ __forceinline__ float point_response(const ChanParams &cp, const floa
     return fmaf(x, cp.alpha, cp.shift);
 }
 
+// ---- packed variant used by the two-pillars-per-wavefront encoders: the staged points of a wavefront are laid out in PAIRS,
+// slab[pair][k][2] (pair = row / 2), so that one ds_read_b128 yields features k, k + 1 of two neighbouring points as two register
+// pairs and the linear layer runs on v_pk_fma_f32 (two points per instruction; the encoder is VALU bound: a wave instruction issues
+// in 4 cycles).  Same operations per point in the same order as point_response(): bit-identical results.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <bool ABS, bool DIST>
+__device__ __forceinline__ void stage_point_pk_t(float *slab, int row, float4 q, float mx, float my, float mz, float ctr_x, float ctr_y,
+                                                 float ctr_z) {
+    float f[kFeatStride];
+#pragma unroll
+    for (int k = 0; k < kFeatStride; ++k) f[k] = 0.f;
+    constexpr int B = ABS ? 4 : 1;
+    if constexpr (ABS) { f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w; }
+    else { f[0] = q.w; }
+    f[B] = q.x - mx; f[B + 1] = q.y - my; f[B + 2] = q.z - mz;
+    f[B + 3] = q.x - ctr_x; f[B + 4] = q.y - ctr_y; f[B + 5] = q.z - ctr_z;
+    if constexpr (DIST) f[B + 6] = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);
+    float *dst = slab + (row >> 1) * (2 * kFeatStride) + (row & 1);
+#pragma unroll
+    for (int k = 0; k < kFeatStride; ++k) dst[2 * k] = f[k];
+}
+
+__device__ __forceinline__ void stage_point_pk(const PfnArgs &a, float *slab, int row, float4 q, float mx, float my, float mz, float ctr_x,
+                                               float ctr_y, float ctr_z) {
+    if (a.use_abs) {
+        if (a.with_dist) stage_point_pk_t<true, true>(slab, row, q, mx, my, mz, ctr_x, ctr_y, ctr_z);
+        else stage_point_pk_t<true, false>(slab, row, q, mx, my, mz, ctr_x, ctr_y, ctr_z);
+    } else {
+        if (a.with_dist) stage_point_pk_t<false, true>(slab, row, q, mx, my, mz, ctr_x, ctr_y, ctr_z);
+        else stage_point_pk_t<false, false>(slab, row, q, mx, my, mz, ctr_x, ctr_y, ctr_z);
+    }
+}
+
+// responses of the two points of pair `pr` (rows 2 pr, 2 pr + 1): .x / .y
+__device__ __forceinline__ f2 pair_response(const ChanParams &cp, const float *slab, int pr) {
+    const float4 *src = reinterpret_cast<const float4 *>(slab + pr * (2 * kFeatStride));
+    const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5];
+    f2 x = f2{cp.w[0], cp.w[0]} * f2{v0.x, v0.y};
+    x = __builtin_elementwise_fma(f2{cp.w[1], cp.w[1]}, f2{v0.z, v0.w}, x);
+    x = __builtin_elementwise_fma(f2{cp.w[2], cp.w[2]}, f2{v1.x, v1.y}, x);
+    x = __builtin_elementwise_fma(f2{cp.w[3], cp.w[3]}, f2{v1.z, v1.w}, x);
+    x = __builtin_elementwise_fma(f2{cp.w[4], cp.w[4]}, f2{v2.x, v2.y}, x);
+    x = __builtin_elementwise_fma(f2{cp.w[5], cp.w[5]}, f2{v2.z, v2.w}, x);
+    x = __builtin_elementwise_fma(f2{cp.w[6], cp.w[6]}, f2{v3.x, v3.y}, x);
+    x = __builtin_elementwise_fma(f2{cp.w[7], cp.w[7]}, f2{v3.z, v3.w}, x);
+    x = __builtin_elementwise_fma(f2{cp.w[8], cp.w[8]}, f2{v4.x, v4.y}, x);
+    x = __builtin_elementwise_fma(f2{cp.w[9], cp.w[9]}, f2{v4.z, v4.w}, x);
+    x = __builtin_elementwise_fma(f2{cp.w[10], cp.w[10]}, f2{v5.x, v5.y}, x);
+    x = __builtin_elementwise_fma(f2{cp.w[11], cp.w[11]}, f2{v5.z, v5.w}, x);
+    return __builtin_elementwise_fma(x, f2{cp.alpha, cp.alpha}, f2{cp.shift, cp.shift});
+}
+
+// relu(max over the np_eff staged points starting at (even) row0) -- rows_max() on the paired layout
+__device__ __forceinline__ float rows_max_pk(const ChanParams &cp, const float *slab, int row0, int np_eff, int P) {
+    float best = (np_eff < P) ? cp.shift : -INFINITY;
+    const int pr0 = row0 >> 1;
+    int j = 0;
+    for (; j + 4 <= np_eff; j += 4) {
+        const f2 y01 = pair_response(cp, slab, pr0 + (j >> 1)), y23 = pair_response(cp, slab, pr0 + (j >> 1) + 1);
+        best = fmaxf(fmaxf(best, fmaxf(y01.x, y01.y)), fmaxf(y23.x, y23.y));
+    }
+    if (j + 2 <= np_eff) {
+        const f2 y = pair_response(cp, slab, pr0 + (j >> 1));
+        best = fmaxf(best, fmaxf(y.x, y.y));
+        j += 2;
+    }
+    if (j < np_eff) best = fmaxf(best, pair_response(cp, slab, pr0 + (j >> 1)).x);     // odd tail: the pair's second slot is stale
+    return fmaxf(best, 0.f);
+}
+
 // Fast path, P <= 64 and C <= 64: the pillar is read exactly once (lane = point), the NEXT pillar's loads are issued
 // before the current one is processed (one HBM round trip per pillar, hidden behind compute), phase B walks the
 // staged points four at a time with independent FMA chains.
@@ -370,11 +441,11 @@ __device__ __forceinline__ void pfn_pair(const PfnArgs &a, const ChanParams &cp,
     const float ctr_x = (float)cd.w * a.vx + a.xo;
     const float ctr_y = (float)cd.z * a.vy + a.yo;
     const float ctr_z = (float)cd.y * a.vz + a.zo;
-    if (pl < np_eff) stage_point(a, slab, lane, q, mx, my, mz, ctr_x, ctr_y, ctr_z);   // row = lane: A -> 0.., B -> 32..
+    if (pl < np_eff) stage_point_pk(a, slab, lane, q, mx, my, mz, ctr_x, ctr_y, ctr_z);   // row = lane: A -> 0.., B -> 32..
     coalign::wave_lds_sync();
     const int npA = __builtin_amdgcn_readlane(np_eff, 0), npB = __builtin_amdgcn_readlane(np_eff, 32);
-    va = rows_max(cp, slab, 0, npA, a.P);
-    vb = (mB >= 0) ? rows_max(cp, slab, 32, npB, a.P) : 0.f;
+    va = rows_max_pk(cp, slab, 0, npA, a.P);
+    vb = (mB >= 0) ? rows_max_pk(cp, slab, 32, npB, a.P) : 0.f;
     coalign::wave_lds_sync();
 }
 
@@ -540,11 +611,11 @@ __device__ __forceinline__ void pair_compute(const PfnArgs &a, const ChanParams 
     const float ctr_x = (float)in.cd.w * a.vx + a.xo;
     const float ctr_y = (float)in.cd.z * a.vy + a.yo;
     const float ctr_z = (float)in.cd.y * a.vz + a.zo;
-    if (pl < np_eff) stage_point(a, slab, lane, q, mx, my, mz, ctr_x, ctr_y, ctr_z);   // row = lane: A -> 0.., B -> 32..
+    if (pl < np_eff) stage_point_pk(a, slab, lane, q, mx, my, mz, ctr_x, ctr_y, ctr_z);   // row = lane: A -> 0.., B -> 32..
     coalign::wave_lds_sync();
     const int npA = __builtin_amdgcn_readlane(np_eff, 0), npB = __builtin_amdgcn_readlane(np_eff, 32);
-    va = rows_max(cp, slab, 0, npA, a.P);
-    vb = hasB ? rows_max(cp, slab, 32, npB, a.P) : 0.f;
+    va = rows_max_pk(cp, slab, 0, npA, a.P);
+    vb = hasB ? rows_max_pk(cp, slab, 32, npB, a.P) : 0.f;
     coalign::wave_lds_sync();
 }
 
@@ -563,6 +634,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_nhwc_kernel(P
     const int npairs = (a.M + 1) / 2;
     if (gwave >= npairs) return;
     const int ncell = a.ny * a.nx;
+    // (Handing the pairs out dynamically -- one atomicAdd per pair on a global counter, fetched an iteration ahead -- was measured at
+    //  281 us instead of 26: 20 000 same-address atomics serialise in one L2 channel.  Static round-robin it is.)
     // cell-map slot of a lane's pillar (lanes 0 / 32 speak for A / B), -1 when the pillar lies outside the canvas
     auto slot_of = [&](const PairIn &p) -> long {
         const int cell = p.cd.y + p.cd.z * a.nx + p.cd.w;                // z + y * nx + x (point_pillar_scatter.py:54)
@@ -673,9 +746,9 @@ static int pillar_vfe_scatter_impl(const float *voxel_features, const int32_t *v
 
     const int ncell = ny * nx;
     int *cellmap = (int *)workspace;
-    int rc = hip_call(hipMemsetAsync(cellmap, 0xFF, (size_t)n_agents * ncell * sizeof(int), stream));
+    int rc = fill_words(cellmap, (size_t)n_agents * ncell, 0xFFFFFFFFu, stream);       // kernels, not memset nodes: see common.h
     if (rc) return rc;
-    if (nhwc && (rc = hip_call(hipMemsetAsync(canvas, 0, (size_t)n_agents * ncell * C * sizeof(float), stream)))) return rc;
+    if (nhwc && (rc = fill_words(canvas, (size_t)n_agents * ncell * C, 0u, stream))) return rc;
 
     if (M > 0) {
         PfnArgs a;
@@ -797,7 +870,7 @@ int coalign_scatter_to_bev(const float *pillar_features, const int32_t *voxel_co
     if (workspace_bytes < coalign_pillar_scatter_workspace_bytes(n_agents, ny, nx)) return COALIGN_ERR_WORKSPACE;
     const int ncell = ny * nx;
     int *cellmap = (int *)workspace;
-    int rc = hip_call(hipMemsetAsync(cellmap, 0xFF, (size_t)n_agents * ncell * sizeof(int), stream));
+    int rc = fill_words(cellmap, (size_t)n_agents * ncell, 0xFFFFFFFFu, stream);
     if (rc) return rc;
     if (M > 0) {
         hipLaunchKernelGGL(cellmap_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, (const int4 *)voxel_coords, M, n_agents,

@@ -587,7 +587,7 @@ extern "C" int coalign_voxelize(const float *points, const int64_t *cloud_offset
     const int64_t need = std::min<int64_t>(n, (int64_t)n_clouds * std::min<int64_t>(ncell, max_voxels));
     if (capacity < need) return COALIGN_ERR_BAD_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (n == 0) return hip_call(hipMemsetAsync(voxel_counts, 0, sizeof(int32_t) * (n_clouds + 1), s));
+    if (n == 0) return fill_words(voxel_counts, (size_t)(n_clouds + 1), 0u, s);
     if (!points || !voxels || !coords || !num_points || !workspace) return COALIGN_ERR_NULL_POINTER;
     a.max_blocks = max_blocks_of(cloud_offsets, n_clouds);
     if (a.max_blocks > kMaxBlocks) return COALIGN_ERR_UNSUPPORTED;     // > 2 M points in one cloud

@@ -9,7 +9,7 @@ Results come back in submission order, ``result_lag`` frames late (the host wait
 
 Two launch modes:
 
-* eager (default)    ~150 host-side launches per frame through the C ABI; decode + NMS on a side stream.
+* eager               ~150 host-side launches per frame through the C ABI (1.5 ms of host time); decode + NMS on a side stream.
 * HIP graph (``graph=True``)  encode -> fuse -> heads -> decode -> NMS -> range filter -> the four result scalars'
   copy to pinned host memory are captured ONCE per (lane, input shape) and replayed with one host call per frame
   (every kernel has static launch geometry; data-dependent sizes live in device memory).  Inputs are copied into the
@@ -32,6 +32,7 @@ from .postprocess import PostProcessHandle, VoxelPostprocessor
 
 import os as _os
 POST_PROCESS_SIDE_STREAM = _os.environ.get("COALIGN_PP_SIDE", "1") != "0"       # measurement switch (tools/ab_bench.sh)
+GRAPH_PERSISTENT_CANVAS = _os.environ.get("COALIGN_GRAPH_PERSIST", "1") != "0"  # measurement switch
 
 FrameResult = Tuple[int, Optional[torch.Tensor], Optional[torch.Tensor]]      # (frame index, pred_box3d [K', 8, 3], scores [K'])
 
@@ -58,6 +59,7 @@ class _GraphSlot:
         self.inputs: Dict[str, torch.Tensor] = {}
         self.buf: Optional[ops.DecodeBuffers] = None
         self.weights_sig = None
+        self.canvas_cache: dict = {}
 
 
 class FramePipeline:
@@ -116,14 +118,21 @@ class FramePipeline:
         batch = {"processed_lidar": {k: slot.inputs[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")},
                  "record_len": record, "pairwise_t_matrix": slot.inputs["pairwise_t_matrix"]}
         vfe = getattr(self.model, "pillar_vfe", None)
-        keep = getattr(vfe, "persistent_canvas", False)
+        keep = None if vfe is None else (vfe.persistent_canvas, vfe.__dict__.get("_canvas_cache"))
         try:
             if vfe is not None:
-                vfe.persistent_canvas = False        # a graph bakes its launches: the "rows of the previous frame" bookkeeping is eager-only
+                # a graph bakes its launches, the persistent canvas's "rows of the previous frame" bookkeeping included: every captured
+                # frame gets a canvas / cell map / slot list of its own, touched by nothing but its own replays (warm-up call first:
+                # the capture then bakes "clear M rows, encode M pillars", which is what every replay needs)
+                vfe.persistent_canvas, vfe.__dict__["_canvas_cache"] = GRAPH_PERSISTENT_CANVAS, slot.canvas_cache
             out = self.model(batch)
         finally:
             if vfe is not None:
-                vfe.persistent_canvas = keep
+                vfe.persistent_canvas = keep[0]
+                if keep[1] is None:
+                    vfe.__dict__.pop("_canvas_cache", None)
+                else:
+                    vfe.__dict__["_canvas_cache"] = keep[1]
         if slot.buf is None:
             slot.buf = self.pp.decode_buffers({"ego": out})
         self.pp.enqueue(self.meta, {"ego": out}, slot.buf)

@@ -75,8 +75,17 @@ def test_pipeline_equals_synchronous_path_bit_for_bit(opv2v5, graph):
     in both launch modes, on every recurrence (buffer rotation, stream ordering, graph replays)."""
     w = opv2v5
     pipe = FramePipeline(w["model"], w["pp"], w["anchors"], lanes=4, result_lag=1, graph=graph)
-    order = [i % 8 for i in range(24)]
-    results = pipe.run(w["frames"][i] for i in order)
+    # bench.py's phases: one submit per lane (graph capture), drain + device synchronise, a warm-up, drain + synchronise, the timed loop.
+    # (Replays that start from an idle GPU are the hard case: with hipMemsetAsync nodes in the captured frame the first replays after a
+    #  synchronise came out wrong on ROCm 7.2 -- the library clears its workspaces with kernels since, csrc/common.h.)
+    phases = [[0, 1, 2, 3], [i % 8 for i in range(8)], [i % 8 for i in range(20)]]
+    order, results = [], []
+    for phase in phases:
+        for i in phase:
+            results += [(b, s) for _, b, s in pipe.submit(w["frames"][i])]
+        results += [(b, s) for _, b, s in pipe.drain()]
+        torch.cuda.synchronize()
+        order += phase
     assert len(results) == len(order)
     n_boxes = 0
     for i, (boxes, scores) in zip(order, results):
@@ -85,7 +94,7 @@ def test_pipeline_equals_synchronous_path_bit_for_bit(opv2v5, graph):
         if sb is not None:
             assert torch.equal(boxes, sb) and torch.equal(scores, ss), f"frame {i}: pipelined result differs from the synchronous one"
             n_boxes += sb.shape[0]
-    assert n_boxes > 24 * 100                         # the frames really carry detections (NMS had work)
+    assert n_boxes > len(order) * 100                 # the frames really carry detections (NMS had work)
 
 
 def test_pipeline_single_lane_and_deep_lag(opv2v5):
