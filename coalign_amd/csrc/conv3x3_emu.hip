@@ -411,12 +411,12 @@ inline bool want_split(int total_tiles, int slots, int chunks) {
 inline int rows_per_tile(int H, int terms) { return (terms == 3 && H >= 64) ? 12 : 8; }
 
 // the strided / channels-last variants: whole tiles only (no stream-K), same persistent-workgroup schedule
-template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE, int LAYOUT>
+template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE, int LAYOUT, int PBUF = 2>
 int launch_variant(const EmuArgs &a0, hipStream_t s) {
-    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE>;
+    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
     static int resident = 0, cus = 0;
-    auto kern = conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, STRIDE, LAYOUT>;
+    auto kern = conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, STRIDE, LAYOUT, PBUF>;
     if (!resident) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -447,6 +447,13 @@ int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
         // the input halo patch of a strided tile is (2 TH + 1) x 65 pixels: 6 rows per workgroup with the 3-way split (142 KB of LDS),
         // 8 with the 2-way split
         constexpr int NPB2 = TERMS == 3 ? 6 : 8;
+        // 3-way split: 8 output rows per workgroup with ONE patch buffer (114 KB) instead of 6 rows double buffered (142 KB): 8 wavefronts per
+        // CU instead of 6; measured 287.4 -> 291.1 frames/s (tools/ab_bench.sh, same box)
+        static const int s2pb = getenv("COALIGN_EMU_S2_PBUF1") ? atoi(getenv("COALIGN_EMU_S2_PBUF1")) : 1;
+        if (TERMS == 3 && s2pb) {
+            if (layout == LAYOUT_NCHW) return launch_variant<1, 32, 8, TERMS, 1, 2, LAYOUT_NCHW, 1>(a, s);
+            if (layout == LAYOUT_IN_NHWC) return launch_variant<1, 32, 8, TERMS, 1, 2, LAYOUT_IN_NHWC, 1>(a, s);
+        }
         if (layout == LAYOUT_NCHW) return launch_variant<1, 32, NPB2, TERMS, 1, 2, LAYOUT_NCHW>(a, s);
         if (layout == LAYOUT_IN_NHWC) return launch_variant<1, 32, NPB2, TERMS, 1, 2, LAYOUT_IN_NHWC>(a, s);
         return COALIGN_ERR_UNSUPPORTED;
@@ -525,6 +532,8 @@ int dispatch(const EmuArgs &a, void *ws, size_t ws_bytes, hipStream_t s, Launch 
     // Measured in the pipeline (round 2, same box): 258-262 frames/s against 249-250 with the double-buffered 8 / 12-wavefront geometries.
     static const int pbuf1 = getenv("COALIGN_EMU_PBUF1") ? atoi(getenv("COALIGN_EMU_PBUF1")) : 2;     // experiments: 0 = off, 1 = small maps only
     if (force < 0 && TERMS == 3 && ((pbuf1 == 1 && geo == 81) || pbuf1 == 2)) geo = 83;
+    // (9-row tiles -- 79.4 KB, nominally still two per CU, 27 / 54 / 108 padded rows -- measured 256 vs 283 frames/s: 18 wavefronts do not
+    //  spread over four SIMDs at this kernel's 95 registers, the second workgroup does not become resident.)
     if (!even && geo % 10 == 2) geo -= 1;
     switch (geo) {
         case 81: return launch<1, 32, 8, TERMS, 1>(a, ws, ws_bytes, s, query);
