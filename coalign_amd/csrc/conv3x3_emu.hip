@@ -532,6 +532,8 @@ int dispatch(const EmuArgs &a, void *ws, size_t ws_bytes, hipStream_t s, Launch 
     // Measured in the pipeline (round 2, same box): 258-262 frames/s against 249-250 with the double-buffered 8 / 12-wavefront geometries.
     static const int pbuf1 = getenv("COALIGN_EMU_PBUF1") ? atoi(getenv("COALIGN_EMU_PBUF1")) : 2;     // experiments: 0 = off, 1 = small maps only
     if (force < 0 && TERMS == 3 && ((pbuf1 == 1 && geo == 81) || pbuf1 == 2)) geo = 83;
+    // (One weight image + one patch buffer -- 47 KB, three workgroups per CU at 80 registers -- measured 157 vs 286 frames/s: 160 B of
+    //  scratch per lane in the chunk loop and the weight DMA exposed between the two barriers.)
     // (9-row tiles -- 79.4 KB, nominally still two per CU, 27 / 54 / 108 padded rows -- measured 256 vs 283 frames/s: 18 wavefronts do not
     //  spread over four SIMDs at this kernel's 95 registers, the second workgroup does not become resident.)
     if (!even && geo % 10 == 2) geo -= 1;
