@@ -440,6 +440,34 @@ int dispatch(const WarpArgs &a, hipStream_t stream) {
 
 }  // namespace
 
+// normalize_pairwise_tfm (opencood/utils/transformation_utils.py:69-91) in one launch: rows {0, 1} x columns {0, 1, 3} of every 4 x 4
+// matrix, [0,1] *= H / W, [1,0] *= W / H, [0,2] /= den_x, *= 2, [1,2] /= den_y, *= 2 -- float64, the reference's operation order
+// (the library is built with -ffp-contract=off), so the result is bit-identical to the torch expression it replaces (~14 tiny
+// element-wise launches per frame, 18-35 us each inside the pipeline).
+__global__ __launch_bounds__(256) void normalize_affine_kernel(const double *__restrict__ T, double *__restrict__ out, int n, double H, double W,
+                                                               double den_x, double den_y) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double *t = T + (size_t)i * 16;
+    double *o = out + (size_t)i * 6;
+    o[0] = t[0];
+    o[1] = t[1] * H / W;
+    o[2] = t[3] / den_x * 2.0;
+    o[3] = t[4] * W / H;
+    o[4] = t[5];
+    o[5] = t[7] / den_y * 2.0;
+}
+
+extern "C" int coalign_normalize_pairwise(const double *pairwise, int n_matrices, int H, int W, double den_x, double den_y, double *out,
+                                          void *stream_) {
+    if (n_matrices < 0 || H < 1 || W < 1) return COALIGN_ERR_BAD_SHAPE;
+    if (n_matrices == 0) return COALIGN_OK;
+    if (!pairwise || !out) return COALIGN_ERR_NULL_POINTER;
+    hipLaunchKernelGGL(normalize_affine_kernel, dim3((n_matrices + 255) / 256), dim3(256), 0, (hipStream_t)stream_, pairwise, out, n_matrices,
+                       (double)H, (double)W, den_x, den_y);
+    return coalign::check_launch();
+}
+
 extern "C" int coalign_warp_fuse(const float *x, int n_total, int C, int H, int W, const double *theta,
                                  const int32_t *group_len, int n_groups, int mode, float *out, int Ho, int Wo,
                                  void *stream_) {

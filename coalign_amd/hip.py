@@ -29,6 +29,7 @@ SIGNATURES = {
                                                  POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, c_int, P, P, P]),
     "coalign_scatter_to_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     "coalign_warp_fuse": (c_int, [P, c_int, c_int, c_int, c_int, P, POINTER(c_int32), c_int, c_int, P, c_int, c_int, P]),
+    "coalign_normalize_pairwise": (c_int, [P, c_int, c_int, c_int, c_double, c_double, P, P]),
     "coalign_warp_fuse_rows": (c_int, [P, c_int, c_int, c_int, c_int, P, POINTER(c_int32), c_int, POINTER(c_int32), c_int, P, c_int, c_int, P]),
     "coalign_warp_fuse_nhwc": (c_int, [c_int, POINTER(P), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(P), POINTER(c_int32),
                                        POINTER(c_int32), c_int, P, POINTER(c_int32), c_int, P]),

@@ -189,6 +189,20 @@ def warp_fuse(x: torch.Tensor, theta: torch.Tensor, group_len: Sequence[int], mo
     return out
 
 
+@_device_op
+def normalize_pairwise(pairwise_t_matrix: torch.Tensor, H: int, W: int, den_x: float, den_y: float) -> torch.Tensor:
+    """[..., 4, 4] float64 (device) -> [..., 2, 3] float64: normalize_pairwise_tfm in one launch (include/coalign_amd.h)."""
+    _need_gpu(pairwise_t_matrix)
+    t = pairwise_t_matrix.contiguous()
+    if t.dtype != torch.float64 or t.shape[-2:] != (4, 4):
+        raise ValueError("pairwise_t_matrix must be float64 [..., 4, 4]")
+    out = torch.empty(tuple(t.shape[:-2]) + (2, 3), dtype=torch.float64, device=t.device)
+    n = t.numel() // 16
+    hip.check(hip.lib().coalign_normalize_pairwise(_ptr(t), n, int(H), int(W), float(den_x), float(den_y), _ptr(out), _stream()),
+              "coalign_normalize_pairwise")
+    return out
+
+
 def warp_fuse_nhwc_ok(x: torch.Tensor) -> bool:
     """Channels-last map the one-launch fusion kernel serves: [n <= 8, C in {64, 128, 256}, H, W] float32 in NHWC memory."""
     return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] in (64, 128, 256) and x.shape[0] <= 8 and is_channels_last(x)

@@ -107,6 +107,12 @@ int coalign_scatter_to_bev(const float *pillar_features, const int32_t *voxel_co
  *            COALIGN_FUSE_NONE: out [n_total,  C, Ho, Wo]  the warped maps themselves
  * Sampling: bilinear, zeros padding, align_corners = False.  C <= 256 for ATT/MAX.
  */
+/* normalize_pairwise_tfm (opencood/utils/transformation_utils.py:69-91) on the device in one launch: pairwise [n_matrices, 4, 4]
+ * float64 (T_{j<-i}, any leading shape flattened) -> out [n_matrices, 2, 3] float64 in affine_grid's normalised coordinates;
+ * den_x = downsample_rate * discrete_ratio * W, den_y = ... * H, evaluated by the caller in double like the reference's Python scalars.
+ * Bit-identical to the reference's tensor expression. */
+int coalign_normalize_pairwise(const double *pairwise, int n_matrices, int H, int W, double den_x, double den_y, double *out, void *stream);
+
 enum { COALIGN_FUSE_ATT = 0, COALIGN_FUSE_MAX = 1, COALIGN_FUSE_NONE = 2 };
 int coalign_warp_fuse(const float *x, int n_total, int C, int H, int W, const double *theta, const int32_t *group_len,
                       int n_groups, int mode, float *out, int Ho, int Wo, void *stream);

@@ -342,3 +342,18 @@ def test_pillar_persistent_canvas_equals_fresh_canvas():
         f, c = run(frames[i], cache)
         assert torch.equal(f, f_ref) and torch.equal(c, c_ref), i
     assert len(cache) == 1
+
+
+def test_normalize_pairwise_kernel_is_bit_identical_to_the_tensor_expression(golden):
+    """coalign_normalize_pairwise (one launch) == normalize_pairwise_tfm's torch expression on the CPU, bit for bit, and the reference golden."""
+    from coalign_amd.pose import normalize_pairwise_tfm
+    g = golden("pose.npz")
+    pt = T(g["pairwise"])[None]
+    for H, W, key in ((200, 704, "normalized_200x704"), (32, 64, "normalized_32x64")):
+        cpu = normalize_pairwise_tfm(pt, H, W, 0.4)
+        dev = normalize_pairwise_tfm(pt.to(DEV), H, W, 0.4)
+        assert dev.is_cuda and torch.equal(dev.cpu(), cpu)
+        np.testing.assert_allclose(dev.cpu().numpy(), g[key], rtol=0, atol=1e-15)
+    gen = torch.Generator().manual_seed(1)
+    big = torch.randn(3, 8, 8, 4, 4, generator=gen, dtype=torch.float64) * 50
+    assert torch.equal(normalize_pairwise_tfm(big.to(DEV), 240, 240, 0.4, 2).cpu(), normalize_pairwise_tfm(big, 240, 240, 0.4, 2))
