@@ -73,8 +73,10 @@ class FramePipeline:
                  graph: bool = False, device=None, transformation_matrix: Optional[torch.Tensor] = None,
                  exchange: Optional[Sequence[Callable]] = None):
         self.model = model
+        self._vfe_flag = None
         if hasattr(model, "pillar_vfe"):
-            model.pillar_vfe.persistent_canvas = True        # every lane runs its backbone before it encodes its next frame
+            self._vfe_flag = model.pillar_vfe.persistent_canvas
+            model.pillar_vfe.persistent_canvas = True        # every lane runs its backbone before it encodes its next frame (close() restores)
         self.pp = post_processor
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
         if self.device.type != "cuda":
@@ -95,6 +97,7 @@ class FramePipeline:
             self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_lanes)]
         self.pp.buffer_sets = max(int(getattr(self.pp, "buffer_sets", 2)), self.result_lag + 2)
         self._slots: List[Dict[tuple, _GraphSlot]] = [dict() for _ in range(self.n_lanes)]
+        self.max_graphs_per_lane = 4                              # distinct input shapes kept captured per lane (oldest evicted)
         self._lane_busy: List[Optional[int]] = [None] * self.n_lanes          # frame index whose result still sits in the lane's buffers
         self._pending: "collections.deque" = collections.deque()              # (index, handle, keep-alive)
         self._count = 0
@@ -150,6 +153,8 @@ class FramePipeline:
         if slot is not None and slot.weights_sig != sig:
             slot = None
         if slot is None:
+            if len(self._slots[k]) >= self.max_graphs_per_lane:      # bound the memory captured frames hold (one private pool + canvas each)
+                self._slots[k].pop(next(iter(self._slots[k])))
             slot = self._slots[k][key] = _GraphSlot()
             slot.weights_sig = sig
             for name, t in src.items():
@@ -231,3 +236,13 @@ class FramePipeline:
     def synchronize(self) -> None:
         for s in self.streams:
             s.synchronize()
+
+    def close(self) -> None:
+        """Collect what is pending, drop the captured graphs (and the canvases they own) and give the model's ``persistent_canvas`` flag back."""
+        self.drain()
+        self.synchronize()
+        for d in self._slots:
+            d.clear()
+        if self._vfe_flag is not None and hasattr(self.model, "pillar_vfe"):
+            self.model.pillar_vfe.persistent_canvas = self._vfe_flag
+            self.model.pillar_vfe.__dict__.pop("_canvas_cache", None)
