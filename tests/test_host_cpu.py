@@ -263,3 +263,32 @@ def test_split_bf16_weight_image_layout_and_exactness():
     with pytest.raises(ValueError):
         ops.pack_conv3x3_emu_weight(torch.zeros(60, 16, 3, 3), 3)
     assert hip.lib().coalign_conv3x3_emu_weight_bytes(16, 128, 4) == 0
+
+
+def test_pipeline_helpers_on_cpu():
+    """pad_pillars (pure tensor code) and the pipeline's refusal to run without the GPU (no CPU fallback anywhere in the product)."""
+    from coalign_amd.pipeline import FramePipeline, pad_pillars
+    from coalign_amd.hip import CoalignHipError
+    pl = {"voxel_features": torch.randn(10, 32, 4), "voxel_coords": torch.randint(0, 5, (10, 4)).int(), "voxel_num_points": torch.randint(1, 33, (10,)).int()}
+    out = pad_pillars(pl, 16)
+    assert out["voxel_features"].shape == (16, 32, 4) and out["voxel_coords"].shape == (16, 4) and out["voxel_num_points"].shape == (16,)
+    assert torch.equal(out["voxel_features"][:10], pl["voxel_features"]) and bool((out["voxel_coords"][10:] == -1).all())
+    assert float(out["voxel_features"][10:].abs().sum()) == 0.0 and bool((out["voxel_num_points"][10:] == 1).all())
+    assert pad_pillars(out, 16) is out                                    # already a multiple: untouched
+    h = builtin_config("mini_coalign")
+    model = build_model(h).eval()
+    pp = build_postprocessor(h["postprocess"], False)
+    with pytest.raises(CoalignHipError):
+        FramePipeline(model, pp, pp.generate_anchor_box(), lanes=2)
+
+
+def test_pcdet_api_surface_and_citations():
+    """Row N's host mirror exposes the four functions callers import from iou3d_nms_utils, and refuses CPU tensors."""
+    from coalign_amd import pcdet
+    from coalign_amd.hip import CoalignHipError
+    for name in ("boxes_iou_bev", "boxes_iou3d_gpu", "nms_gpu", "nms_normal_gpu"):
+        assert callable(getattr(pcdet, name))
+    with pytest.raises(CoalignHipError):
+        pcdet.nms_gpu(torch.zeros(3, 7), torch.zeros(3), 0.1)
+    keep, none = pcdet.nms_gpu(torch.zeros(0, 7), torch.zeros(0), 0.1)       # empty input never reaches the device
+    assert keep.numel() == 0 and none is None
