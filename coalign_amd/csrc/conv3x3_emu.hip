@@ -534,6 +534,8 @@ int dispatch(const EmuArgs &a, void *ws, size_t ws_bytes, hipStream_t s, Launch 
     if (force < 0 && TERMS == 3 && ((pbuf1 == 1 && geo == 81) || pbuf1 == 2)) geo = 83;
     // (One weight image + one patch buffer -- 47 KB, three workgroups per CU at 80 registers -- measured 157 vs 286 frames/s: 160 B of
     //  scratch per lane in the chunk loop and the weight DMA exposed between the two barriers.)
+    // (4-row tiles with one patch buffer on the 25- and 50-row maps -- one wavefront per SIMD, 28 / 52 padded rows -- measured 281-286
+    //  against 285-287 frames/s: no gain.)
     // (9-row tiles -- 79.4 KB, nominally still two per CU, 27 / 54 / 108 padded rows -- measured 256 vs 283 frames/s: 18 wavefronts do not
     //  spread over four SIMDs at this kernel's 95 registers, the second workgroup does not become resident.)
     if (!even && geo % 10 == 2) geo -= 1;
