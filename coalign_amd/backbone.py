@@ -62,6 +62,9 @@ CONV_EMU_TERMS = int(os.environ.get("COALIGN_CONV_EMU", "3"))
 # [N, C, H, W], NHWC memory): the fusion kernel then gathers C contiguous floats per bilinear tap (csrc/warp_fuse_nhwc.hip) and the
 # next stage's strided convolutions read the map in place.  Everything else stays NCHW.  0 switches the route off (measurement aid).
 NHWC_STAGE_OUTPUTS = os.environ.get("COALIGN_NHWC_STAGES", "1") != "0"
+# Weight image of the stride-1 split-bf16 convolutions: "1" = tap-major (16-channel intervals of nine matrix steps, no zero tenth tap,
+# one workgroup per CU), "0" = tap pairs of 8-channel chunks (ten steps per 16 channels, two workgroups per CU).  Measured: DESIGN.md §8.
+CONV_EMU_TAP_MAJOR = os.environ.get("COALIGN_EMU_TAPK", "0") != "0"
 
 
 class Conv3x3Pack:
@@ -79,10 +82,11 @@ class Conv3x3Pack:
             self._f32 = ops.pack_conv3x3_weight(self.weight)
         return self._f32
 
-    def emu(self, terms: int) -> torch.Tensor:
-        if terms not in self._emu:
-            self._emu[terms] = ops.pack_conv3x3_emu_weight(self.weight, terms)
-        return self._emu[terms]
+    def emu(self, terms: int, tap_major: bool = False) -> torch.Tensor:
+        tap_major = bool(tap_major and self.cin % 16 == 0)
+        if (terms, tap_major) not in self._emu:
+            self._emu[terms, tap_major] = ops.pack_conv3x3_emu_weight(self.weight, terms, tap_major)
+        return self._emu[terms, tap_major]
 
 
 def packable(w: torch.Tensor) -> bool:
@@ -95,7 +99,7 @@ def conv3x3_fused(x: torch.Tensor, pack: Optional["Conv3x3Pack"], weight: torch.
     stride = stride[0] if isinstance(stride, (tuple, list)) else stride
     if pack is not None:
         if CONV_EMU_TERMS in (2, 3) and stride in (1, 2):              # any map size
-            return ops.conv3x3_emu_bias_act(x, pack.emu(CONV_EMU_TERMS), bias, pack.cout, residual, True, CONV_EMU_TERMS, stride=stride,
+            return ops.conv3x3_emu_bias_act(x, pack.emu(CONV_EMU_TERMS, CONV_EMU_TAP_MAJOR and stride == 1), bias, pack.cout, residual, True, CONV_EMU_TERMS, stride=stride,
                                             out_channels_last=out_channels_last and stride == 1)
         if stride == 1 and x.shape[3] % 4 == 0 and hip_conv3x3_wins(x, pack.cin, pack.cout):
             return ops.conv3x3_bias_act(x, pack.f32, bias, residual, True)

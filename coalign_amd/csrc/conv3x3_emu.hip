@@ -59,8 +59,12 @@ struct EmuArgs {
 
 enum { LAYOUT_NCHW = 0, LAYOUT_OUT_NHWC = 1, LAYOUT_IN_NHWC = 2 };
 
-template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE = 1, int PBUF = 2>
+// TAPK ("K = 144"): a barrier interval is 16 input channels x 9 taps = nine MFMA steps whose K = 16 is the 16 channels of ONE tap (lanes
+// 0-31 channels 0-7, lanes 32-63 channels 8-15) -- no zero tenth tap, 10 % fewer MFMAs.  Weight image [9 taps][term][2 channel halves]
+// [64 cout][8 cin] (55 KB per interval, double buffered), split patch as for KCH = 2.
+template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE = 1, int PBUF = 2, bool TAPK = false>
 struct Geo {
+    static_assert(!TAPK || KCH == 2, "tap-major steps pair the two 8-channel halves of a 16-channel interval");
     static constexpr int NCO = NPB >= 4 ? 2 : 1;                              // accumulator tiles (32 output channels each) per wave
     static constexpr int WAVES = NPB >= 4 ? NPB : 2 * NPB;
     static constexpr int THREADS = 64 * WAVES;
@@ -68,11 +72,13 @@ struct Geo {
     static constexpr int PH = STRIDE * TH + 3 - STRIDE, PW = STRIDE * TW + 3 - STRIDE;   // input halo patch: rows STRIDE * y0 - 1 .., columns STRIDE * x0 - 1 ..
     static constexpr int PIX = PH * PW;                                       // pixel slots of the patch
     static constexpr int SLOTS = (PIX + THREADS - 1) / THREADS;               // pixel slots one thread splits per chunk
-    static constexpr int WQ = kSteps * TERMS * 2 * kCoutTile;                 // 16-byte groups of one weight chunk
+    static constexpr int WQ = (TAPK ? 9 : kSteps) * TERMS * 2 * kCoutTile;    // 16-byte groups of one weight unit (8-channel chunk; TAPK: the whole interval)
+    static constexpr int WUNITS = TAPK ? 1 : KCH;                             // weight units per barrier interval
+    static constexpr int STEPS = TAPK ? 9 : kSteps * KCH;                     // MFMA steps per barrier interval
     static constexpr int WINSTR = WQ / 64;
     // KCH 8-channel chunks are processed per barrier.  LDS map (floats): two weight images of KCH chunks | two split patches
     // [chunk][term][y][x][8 cin] bf16
-    static constexpr int W_OFF = 0, WSZ = KCH * WQ * 4, B_OFF = 2 * WSZ, BSZ1 = TERMS * PIX * 4, BSZ = KCH * BSZ1;
+    static constexpr int W_OFF = 0, WSZ = WUNITS * WQ * 4, B_OFF = 2 * WSZ, BSZ1 = TERMS * PIX * 4, BSZ = KCH * BSZ1;
     // PBUF = 1: ONE split-patch buffer (one more barrier per chunk: the next chunk's pixels are written after every wave has read the
     // current ones).  With the 3-way split that takes a workgroup from 94 to 78 KB, i.e. TWO workgroups per CU: the barrier / operand
     // phases of one overlap the MFMA phase of the other.
@@ -100,11 +106,18 @@ __device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[T
 // The split variant's occupancy is pinned (registers capped): its hand-over code, executed once per split tile, would otherwise
 // cost a resident workgroup -- the spills it causes sit outside the chunk loop.  8 wavefronts x 2 workgroups = 4 per SIMD, 12
 // wavefronts = 3 per SIMD.  (Pinning the plain variant as well changes hipcc's scheduling and was measured 5-20 % slower.)
-template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT, int STRIDE = 1, int LAYOUT = LAYOUT_NCHW, int PBUF = 2>
+// VAR: bit 0 = tap-major weight image (TAPK), bit 1 = the weight LDS-DMA is issued from inline assembly: hipcc cannot prove the DMA
+// destination disjoint from the operand reads and otherwise waits for vmcnt(0) -- the full latency of everything just issued -- before
+// the first matrix instruction of every interval (the top-of-loop s_waitcnt(0) is the real synchronisation point of the transfer);
+// bit 2 = the order "next step's operand reads, then this step's matrix instructions" is pinned with sched_barrier (147 registers: for
+// the one-workgroup-per-CU tap-major geometries only; with the 128 registers of two 8-wavefront workgroups per CU it spills).
+enum { VAR_TAPK = 1, VAR_ASM_DMA = 2, VAR_SCHED = 4 };
+template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT, int STRIDE = 1, int LAYOUT = LAYOUT_NCHW, int PBUF = 2, int VAR = 0>
 __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB))
-__attribute__((amdgpu_waves_per_eu(SPLIT ? (NPB == 12 ? 3 : 4) : 1, SPLIT ? (NPB == 12 ? 3 : 4) : 8)))
+__attribute__((amdgpu_waves_per_eu(SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 1, SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 8)))
 void conv3x3_emu_kernel(const EmuArgs a) {
-    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF>;
+    constexpr bool TAPK = (VAR & VAR_TAPK) != 0;
+    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, TAPK>;
     static_assert(!(SPLIT && (STRIDE != 1 || LAYOUT != LAYOUT_NCHW)), "stream-K hand-over only for the plain stride-1 NCHW variant");
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;      // wave: scalar
@@ -122,11 +135,13 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     };
     const int pb = wave % NPB, cb = (G::NCO == 2 ? 0 : wave / NPB) * 32;
     const int py = pb * BH + p / BW, px = p % BW;
-    int boff[kSteps];                                     // pixel slot of this lane's tap in step s (tap 9 -> tap 8, zeroed below)
+    constexpr int NB = TAPK ? 9 : kSteps;
+    int boff[NB];                                         // pixel slot of this lane's tap in step s (tap 9 -> tap 8, zeroed below)
 #pragma unroll
-    for (int s = 0; s < kSteps; ++s) {
-        const int t = 2 * s + half < 9 ? 2 * s + half : 8;
-        boff[s] = (STRIDE * py + t / 3) * G::PW + STRIDE * px + t % 3;
+    for (int s = 0; s < NB; ++s) {
+        // TAPK: step s = tap s, this lane's channel half selects the 8-channel sub-patch
+        const int t = TAPK ? s : (2 * s + half < 9 ? 2 * s + half : 8);
+        boff[s] = (TAPK ? half * TERMS * G::PIX : 0) + (STRIDE * py + t / 3) * G::PW + STRIDE * px + t % 3;
     }
     const int wlane = half * kCoutTile + cb + p;          // 16-byte group of this lane inside one (step, term) weight block
 
@@ -140,7 +155,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     auto make_plan = [&](const Tile &t) {
         Plan pl;
         pl.base = a.x + (size_t)t.n * a.Cin * plane_in;
-        pl.wsrc = a.wt + (size_t)t.cg * chunks * (KCH * G::WQ) + lane;
+        pl.wsrc = a.wt + (size_t)t.cg * chunks * (G::WUNITS * G::WQ) + lane;
 #pragma unroll
         for (int j = 0; j < G::SLOTS; ++j) {
             const int i = tid + j * G::THREADS;
@@ -196,14 +211,21 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         }
     };
     // LDS-DMA of weight chunk c of the tile into weight buffer `slot` (scalar LDS addresses, every lane active)
-    constexpr int WJ = (KCH * G::WINSTR + G::WAVES - 1) / G::WAVES;
+    constexpr int WJ = (G::WUNITS * G::WINSTR + G::WAVES - 1) / G::WAVES;
     auto issue_weights = [&](const Plan &pl, int c, int slot) {
         float *wdst = lds + G::W_OFF + slot * G::WSZ;
-        const uint4 *wsrc = pl.wsrc + (size_t)c * (KCH * G::WQ);
+        const uint4 *wsrc = pl.wsrc + (size_t)c * (G::WUNITS * G::WQ);
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             const int ins = wave + G::WAVES * j;
-            if (ins < KCH * G::WINSTR) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ins * 64), (lptr_t)(wdst + ins * 256), 16, 0, 0);
+            if (ins < G::WUNITS * G::WINSTR) {
+                if constexpr (VAR & VAR_ASM_DMA) {
+                    const unsigned dst = (unsigned)(size_t)(lptr_t)(wdst + ins * 256);      // wave-uniform LDS byte address -> M0
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(dst)), "v"(wsrc + ins * 64) : "memory");
+                } else {
+                    __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ins * 64), (lptr_t)(wdst + ins * 256), 16, 0, 0);
+                }
+            }
         }
     };
 
@@ -287,18 +309,18 @@ void conv3x3_emu_kernel(const EmuArgs a) {
             EMU_STAMP(3);
             const uint4 *bq = reinterpret_cast<const uint4 *>(lds + G::B_OFF + (PBUF == 2 ? (L & 1) : 0) * G::BSZ);
             const uint4 *wq = reinterpret_cast<const uint4 *>(lds + G::W_OFF + (L & 1) * G::WSZ) + wlane;
-            constexpr int NS = kSteps * KCH;           // MFMA steps of this interval: step = (8-channel chunk h, tap pair s)
+            constexpr int NS = G::STEPS;               // MFMA steps of this interval: step = (8-channel chunk h, tap pair s); TAPK: step = tap
             auto load_b = [&](int st, bf16x8 (&b)[TERMS]) {
-                const int h = st / kSteps, s = st % kSteps;
+                const int h = TAPK ? 0 : st / kSteps, s = TAPK ? st : st % kSteps;
 #pragma unroll
                 for (int t = 0; t < TERMS; ++t) {
                     uint4 v = bq[(h * TERMS + t) * G::PIX + boff[s]];
-                    if (s == kSteps - 1 && half) v = uint4{0, 0, 0, 0};       // the tenth tap does not exist
+                    if (!TAPK && s == kSteps - 1 && half) v = uint4{0, 0, 0, 0};       // the tenth tap does not exist
                     b[t] = __builtin_bit_cast(bf16x8, v);
                 }
             };
             auto load_w = [&](int st, bf16x8 (&w)[G::NCO][TERMS]) {
-                const int h = st / kSteps, s = st % kSteps;
+                const int h = TAPK ? 0 : st / kSteps, s = TAPK ? st : st % kSteps;
 #pragma unroll
                 for (int q = 0; q < G::NCO; ++q)
 #pragma unroll
@@ -317,10 +339,14 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                     load_b(st + 1, bn);
                     load_w(st + 1, wn);
                 }
+                // the schedule the source spells out, pinned: all operand reads of the next step are issued before this step's matrix
+                // instructions (hipcc otherwise sinks them towards their uses and waits lgkmcnt(0) three times per step)
+                if constexpr (VAR & VAR_SCHED) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
                     for (int q = 0; q < G::NCO; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[q][wi[i]], bc[bi[i]], acc[q], 0, 0, 0);
+                if constexpr (VAR & VAR_SCHED) __builtin_amdgcn_sched_barrier(0);
                 if (st + 1 < NS) {
 #pragma unroll
                     for (int t = 0; t < TERMS; ++t) {
@@ -392,14 +418,14 @@ struct Launch {                    // what the host needs to know about one (sha
 };
 
 // stream-K pays when the whole-tile schedule leaves the last round badly filled; a tile must have at least two chunks to split
-inline bool want_split(int total_tiles, int slots, int chunks) {
+inline bool want_split(int total_tiles, int slots, int chunks, int long_tile = 32) {
     static const int force = getenv("COALIGN_EMU_SPLIT") ? atoi(getenv("COALIGN_EMU_SPLIT")) : -1;     // experiments only
     if (chunks < 2) return false;
     if (force >= 0) return force != 0;
     // measured (tools/bench_conv_emu_geo.py with COALIGN_EMU_SPLIT=0|1): as for the fp32 kernel, splitting pays on long tiles
     // (>= 32 chunks: the shrink header, 4-11 %) whose last round is under-filled; short tiles would nearly all be split and the
     // extra tile starts (residual fetch, epilogue) cost more than the imbalance
-    if (chunks < 32 || total_tiles <= slots) return false;
+    if (chunks < long_tile || total_tiles <= slots) return false;       // long_tile: 32 chunks of 8 channels = 16 tap-major intervals
     const int rounds = (total_tiles + slots - 1) / slots;
     return total_tiles * 10 < rounds * slots * 9;
 }
@@ -411,12 +437,12 @@ inline bool want_split(int total_tiles, int slots, int chunks) {
 inline int rows_per_tile(int H, int terms) { return (terms == 3 && H >= 64) ? 12 : 8; }
 
 // the strided / channels-last variants: whole tiles only (no stream-K), same persistent-workgroup schedule
-template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE, int LAYOUT, int PBUF = 2>
+template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE, int LAYOUT, int PBUF = 2, int VAR = 0>
 int launch_variant(const EmuArgs &a0, hipStream_t s) {
-    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF>;
+    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, (VAR & VAR_TAPK) != 0>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
     static int resident = 0, cus = 0;
-    auto kern = conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, STRIDE, LAYOUT, PBUF>;
+    auto kern = conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, STRIDE, LAYOUT, PBUF, VAR>;
     if (!resident) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -465,9 +491,11 @@ int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
     return COALIGN_ERR_UNSUPPORTED;
 }
 
-template <int BH, int BW, int NPB, int TERMS, int KCH, int PBUF = 2>
+template <int BH, int BW, int NPB, int TERMS, int KCH, int PBUF = 2, int VAR = 0>
 int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream_t s, Launch *query) {
-    using G = Geo<BH, BW, NPB, TERMS, KCH, 1, PBUF>;
+    constexpr bool TAPK = (VAR & VAR_TAPK) != 0;
+    using G = Geo<BH, BW, NPB, TERMS, KCH, 1, PBUF, TAPK>;
+    static_assert(!TAPK || G::LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
     static int resident = 0, cus = 0;
     if (!resident) {
         int dev = 0;
@@ -475,8 +503,8 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
         cus = prop.multiProcessorCount;
         for (int sp = 0; sp < 2; ++sp) {
-            const void *fn = sp ? reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT_NCHW, PBUF>)
-                                : reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, 1, LAYOUT_NCHW, PBUF>);
+            const void *fn = sp ? reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT_NCHW, PBUF, VAR>)
+                                : reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, 1, LAYOUT_NCHW, PBUF, VAR>);
             const int rc = coalign::hip_call(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
             if (rc != COALIGN_OK) {                // geometry does not fit this device's LDS: report, leave no sticky error behind
                 (void)hipGetLastError();
@@ -484,7 +512,7 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
             }
         }
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT_NCHW, PBUF>, G::THREADS, G::LDS_BYTES) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT_NCHW, PBUF, VAR>, G::THREADS, G::LDS_BYTES) != hipSuccess || n < 1) n = 1;
         resident = n;
     }
     EmuArgs a = a0;
@@ -493,7 +521,7 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
     a.total_tiles = a.tiles_per_img * (a.Cout / kCoutTile) * a.N;
     const int slots = cus * resident, chunks = a.Cin / (kKC * KCH);
     Launch l;
-    l.split = want_split(a.total_tiles, slots, chunks);
+    l.split = want_split(a.total_tiles, slots, chunks, TAPK ? 16 : 32);
     l.grid = a.total_tiles < slots ? a.total_tiles : slots;
     if (l.split && a.total_tiles < slots) {
         // fewer tiles than slots: an exact two-way split of every tile (ranges of chunks / 2 steps: range 2t opens tile t,
@@ -514,9 +542,9 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
         a.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + l.flag_bytes);
         const int rc = coalign::fill_words(workspace, l.flag_bytes / 4, 0u, s);
         if (rc != COALIGN_OK) return rc;
-        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT_NCHW, PBUF>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT_NCHW, PBUF, VAR>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
     } else {
-        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, 1, LAYOUT_NCHW, PBUF>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, 1, LAYOUT_NCHW, PBUF, VAR>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
     }
     return COALIGN_OK;
 }
@@ -543,12 +571,73 @@ int dispatch(const EmuArgs &a, void *ws, size_t ws_bytes, hipStream_t s, Launch 
         case 81: return launch<1, 32, 8, TERMS, 1>(a, ws, ws_bytes, s, query);
         case 82: return launch<1, 32, 8, TERMS, 2>(a, ws, ws_bytes, s, query);
         case 83: return launch<1, 32, 8, TERMS, 1, 1>(a, ws, ws_bytes, s, query);          // one patch buffer: two workgroups per CU with the 3-way split
+        case 84: return launch<1, 32, 8, TERMS, 1, 1, VAR_ASM_DMA>(a, ws, ws_bytes, s, query);      // ... with the weight DMA hidden from hipcc's waitcnt pass
         case 121: return launch<1, 32, 12, TERMS, 1>(a, ws, ws_bytes, s, query);
         case 122: return launch<1, 32, 12, TERMS, 2>(a, ws, ws_bytes, s, query);
         case 41: return launch<1, 32, 4, TERMS, 1>(a, ws, ws_bytes, s, query);
         default: return COALIGN_ERR_UNSUPPORTED;
     }
 }
+
+// Tap-major weight image (TAPK, "K = 144"): 16-channel intervals of nine steps, one workgroup per CU (111 KB of weights + one split
+// patch).  Output rows per workgroup = wavefronts: 8 (143 KB), 10 (150 KB) or 12 (156 KB) with the 3-way split.
+template <int TERMS>
+int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipStream_t s, Launch *query) {
+    static const int force = getenv("COALIGN_EMU_TAPK_ROWS") ? atoi(getenv("COALIGN_EMU_TAPK_ROWS")) : 0;      // experiments only
+    if (a.Cin % (2 * kKC)) return COALIGN_ERR_UNSUPPORTED;
+    static const int asm_dma = getenv("COALIGN_EMU_ASM_DMA") ? atoi(getenv("COALIGN_EMU_ASM_DMA")) : 1;
+    static const int sched = getenv("COALIGN_EMU_SCHED") ? atoi(getenv("COALIGN_EMU_SCHED")) : 0;
+    const int rows = force ? force : (a.H >= 64 ? 12 : 8);
+    constexpr int T = VAR_TAPK, TA = VAR_TAPK | VAR_ASM_DMA, TAS = VAR_TAPK | VAR_ASM_DMA | VAR_SCHED;
+    if (sched) {
+        if (layout == LAYOUT_OUT_NHWC) {
+            if (query) {
+                *query = Launch{0, 0, 0, false};
+                return COALIGN_OK;
+            }
+            switch (rows) {
+                case 8: return launch_variant<1, 32, 8, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, TAS>(a, s);
+                case 10: return launch_variant<1, 32, 10, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, TAS>(a, s);
+                case 12: return launch_variant<1, 32, 12, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, TAS>(a, s);
+                default: return COALIGN_ERR_UNSUPPORTED;
+            }
+        }
+        if (layout != LAYOUT_NCHW) return COALIGN_ERR_UNSUPPORTED;
+        switch (rows) {
+            case 8: return launch<1, 32, 8, TERMS, 2, 1, TAS>(a, ws, ws_bytes, s, query);
+            case 10: return launch<1, 32, 10, TERMS, 2, 1, TAS>(a, ws, ws_bytes, s, query);
+            case 12: return launch<1, 32, 12, TERMS, 2, 1, TAS>(a, ws, ws_bytes, s, query);
+            default: return COALIGN_ERR_UNSUPPORTED;
+        }
+    }
+    if (layout == LAYOUT_OUT_NHWC) {
+        if (query) {
+            *query = Launch{0, 0, 0, false};
+            return COALIGN_OK;
+        }
+        switch (rows + (asm_dma ? 100 : 0)) {
+            case 8: return launch_variant<1, 32, 8, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, T>(a, s);
+            case 10: return launch_variant<1, 32, 10, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, T>(a, s);
+            case 12: return launch_variant<1, 32, 12, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, T>(a, s);
+            case 108: return launch_variant<1, 32, 8, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, TA>(a, s);
+            case 110: return launch_variant<1, 32, 10, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, TA>(a, s);
+            case 112: return launch_variant<1, 32, 12, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, TA>(a, s);
+            default: return COALIGN_ERR_UNSUPPORTED;
+        }
+    }
+    if (layout != LAYOUT_NCHW) return COALIGN_ERR_UNSUPPORTED;
+    switch (rows + (asm_dma ? 100 : 0)) {
+        case 8: return launch<1, 32, 8, TERMS, 2, 1, T>(a, ws, ws_bytes, s, query);
+        case 10: return launch<1, 32, 10, TERMS, 2, 1, T>(a, ws, ws_bytes, s, query);
+        case 12: return launch<1, 32, 12, TERMS, 2, 1, T>(a, ws, ws_bytes, s, query);
+        case 108: return launch<1, 32, 8, TERMS, 2, 1, TA>(a, ws, ws_bytes, s, query);
+        case 110: return launch<1, 32, 10, TERMS, 2, 1, TA>(a, ws, ws_bytes, s, query);
+        case 112: return launch<1, 32, 12, TERMS, 2, 1, TA>(a, ws, ws_bytes, s, query);
+        default: return COALIGN_ERR_UNSUPPORTED;
+    }
+}
+
+constexpr int kLayoutTapMajor = 4;      // COALIGN_LAYOUT_W_TAPMAJOR: flag bit of `layout`
 
 }  // namespace
 
@@ -560,6 +649,12 @@ extern "C" void coalign_conv3x3_emu_set_trace(long long *p) { g_emu_trace = p; }
 extern "C" size_t coalign_conv3x3_emu_weight_bytes(int Cin, int Cout, int terms) {
     if (Cin < 1 || Cout < 1 || Cin % kKC || Cout % kCoutTile || (terms != 2 && terms != 3)) return 0;
     return (size_t)(Cout / kCoutTile) * (Cin / kKC) * kSteps * terms * 2 * kCoutTile * 16 + 16;      // + one zero group
+}
+
+extern "C" size_t coalign_conv3x3_emu_weight_bytes_ex(int Cin, int Cout, int terms, int tap_major) {
+    if (!tap_major) return coalign_conv3x3_emu_weight_bytes(Cin, Cout, terms);
+    if (Cin < 1 || Cout < 1 || Cin % (2 * kKC) || Cout % kCoutTile || (terms != 2 && terms != 3)) return 0;
+    return (size_t)(Cout / kCoutTile) * (Cin / (2 * kKC)) * 9 * terms * 2 * kCoutTile * 16 + 16;
 }
 
 static int check_emu_args(int N, int Cin, int Cout, int H, int W, int terms) {
@@ -574,6 +669,15 @@ extern "C" size_t coalign_conv3x3_emu_workspace_bytes(int N, int Cin, int Cout, 
     EmuArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, N, Cin, Cout, H, W, 0, 0, 0, 0, H, W, nullptr, nullptr};
     Launch l{};
     const int rc = terms == 3 ? dispatch<3>(a, nullptr, 0, nullptr, &l) : dispatch<2>(a, nullptr, 0, nullptr, &l);
+    return rc == COALIGN_OK && l.split ? l.ws_bytes : 0;
+}
+
+extern "C" size_t coalign_conv3x3_emu_workspace_bytes_ex(int N, int Cin, int Cout, int H, int W, int terms, int layout) {
+    if (!(layout & kLayoutTapMajor)) return (layout & 3) == LAYOUT_NCHW ? coalign_conv3x3_emu_workspace_bytes(N, Cin, Cout, H, W, terms) : 0;
+    if (check_emu_args(N, Cin, Cout, H, W, terms) != COALIGN_OK || N == 0) return 0;
+    EmuArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, N, Cin, Cout, H, W, 0, 0, 0, 0, H, W, nullptr, nullptr};
+    Launch l{};
+    const int rc = terms == 3 ? dispatch_tapk<3>(a, layout & 3, nullptr, 0, nullptr, &l) : dispatch_tapk<2>(a, layout & 3, nullptr, 0, nullptr, &l);
     return rc == COALIGN_OK && l.split ? l.ws_bytes : 0;
 }
 
@@ -602,6 +706,18 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
     if (stride == 1 && layout == LAYOUT_NCHW)
         return coalign_conv3x3_emu_bias_act(x, w_split, bias, residual, y, N, Cin, Cout, Hin, Win, relu, terms, workspace, workspace_bytes, stream);
     if (!x || !w_split || !y || !bias) return COALIGN_ERR_NULL_POINTER;
+    if (layout >= 0 && (layout & kLayoutTapMajor)) {          // tap-major weight image: stride 1, NCHW in, NCHW or channels-last out
+        const int lay = layout & 3;
+        if (stride != 1 || (lay != LAYOUT_NCHW && lay != LAYOUT_OUT_NHWC) || layout > (kLayoutTapMajor | 3)) return COALIGN_ERR_UNSUPPORTED;
+        int rc = check_emu_args(N, Cin, Cout, Hin, Win, terms);
+        if (rc != COALIGN_OK) return rc;
+        if ((reinterpret_cast<uintptr_t>(w_split) & 15) || (lay != LAYOUT_NCHW && (reinterpret_cast<uintptr_t>(y) & 15))) return COALIGN_ERR_UNSUPPORTED;
+        if (N == 0) return COALIGN_OK;
+        EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, Hin, Win, relu, 0, 0, 0, Hin, Win, nullptr, nullptr};
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        rc = terms == 3 ? dispatch_tapk<3>(a, lay, workspace, workspace_bytes, s, nullptr) : dispatch_tapk<2>(a, lay, workspace, workspace_bytes, s, nullptr);
+        return rc != COALIGN_OK ? rc : check_launch();
+    }
     if (stride != 1 && stride != 2) return COALIGN_ERR_UNSUPPORTED;
     if (layout != LAYOUT_NCHW && layout != LAYOUT_OUT_NHWC && layout != LAYOUT_IN_NHWC) return COALIGN_ERR_UNSUPPORTED;
     const int H = (Hin + stride - 1) / stride, W = (Win + stride - 1) / stride;          // 3x3, pad 1: floor((n + 2 - 3) / s) + 1

@@ -466,16 +466,22 @@ def conv3x3_bias_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[tor
     return y
 
 
-def pack_conv3x3_emu_weight(weight: torch.Tensor, terms: int = 3) -> torch.Tensor:
+def pack_conv3x3_emu_weight(weight: torch.Tensor, terms: int = 3, tap_major: bool = False) -> torch.Tensor:
     """[Cout, Cin, 3, 3] fp32 -> the split-bf16 LDS image of csrc/conv3x3_emu.hip, as uint8:
     [Cout / 64][Cin / 8][5 steps][terms][2 k-groups][64 cout][8 cin] bf16 (tap = 2 * step + k-group, the tenth tap is zero;
-    term 0 = bf16(w), term 1 = bf16(w - term 0), term 2 = bf16(w - term 0 - term 1)) followed by 16 zero bytes."""
+    term 0 = bf16(w), term 1 = bf16(w - term 0), term 2 = bf16(w - term 0 - term 1)) followed by 16 zero bytes.
+    ``tap_major`` (Cin % 16 == 0): [Cout / 64][Cin / 16][9 taps][terms][2 channel halves][64 cout][8 cin] -- one matrix
+    instruction = the 16 channels of one tap, no zero tap (COALIGN_LAYOUT_W_TAPMAJOR)."""
     co, ci, kh, kw = weight.shape
-    if (kh, kw) != (3, 3) or co % 64 or ci % CONV_KC or terms not in (2, 3):
-        raise ValueError(f"conv3x3_emu needs 3x3 weights with Cout % 64 == 0, Cin % 8 == 0 and terms in (2, 3), got {tuple(weight.shape)}, {terms}")
-    w = weight.detach().float().reshape(co // 64, 64, ci // CONV_KC, CONV_KC, 9)
-    w = torch.cat([w, torch.zeros_like(w[..., :1])], dim=-1).reshape(co // 64, 64, ci // CONV_KC, CONV_KC, 5, 2)
-    w = w.permute(0, 2, 4, 5, 1, 3)                                        # [g, chunk, step, k-group, cout, cin]
+    if (kh, kw) != (3, 3) or co % 64 or ci % (2 * CONV_KC if tap_major else CONV_KC) or terms not in (2, 3):
+        raise ValueError(f"conv3x3_emu needs 3x3 weights with Cout % 64 == 0, Cin % 8 == 0 (16 tap-major) and terms in (2, 3), got {tuple(weight.shape)}, {terms}")
+    if tap_major:
+        w = weight.detach().float().reshape(co // 64, 64, ci // (2 * CONV_KC), 2, CONV_KC, 9)
+        w = w.permute(0, 2, 5, 3, 1, 4)                                    # [g, interval, tap, channel half, cout, cin]
+    else:
+        w = weight.detach().float().reshape(co // 64, 64, ci // CONV_KC, CONV_KC, 9)
+        w = torch.cat([w, torch.zeros_like(w[..., :1])], dim=-1).reshape(co // 64, 64, ci // CONV_KC, CONV_KC, 5, 2)
+        w = w.permute(0, 2, 4, 5, 1, 3)                                    # [g, chunk, step, k-group, cout, cin]
     parts, rest = [], w
     for _ in range(terms):
         t = rest.bfloat16()
@@ -484,11 +490,11 @@ def pack_conv3x3_emu_weight(weight: torch.Tensor, terms: int = 3) -> torch.Tenso
     img = torch.stack(parts, dim=3).contiguous()                           # [g, chunk, step, term, k-group, cout, cin]
     flat = img.view(torch.uint8).reshape(-1)
     out = torch.cat([flat, torch.zeros(16, dtype=torch.uint8, device=flat.device)])
-    assert out.numel() == hip.lib().coalign_conv3x3_emu_weight_bytes(ci, co, terms)
+    assert out.numel() == hip.lib().coalign_conv3x3_emu_weight_bytes_ex(ci, co, terms, int(tap_major))
     return out
 
 
-LAYOUT_NCHW, LAYOUT_OUT_NHWC, LAYOUT_IN_NHWC = 0, 1, 2      # COALIGN_LAYOUT_* of include/coalign_amd.h
+LAYOUT_NCHW, LAYOUT_OUT_NHWC, LAYOUT_IN_NHWC, LAYOUT_W_TAPMAJOR = 0, 1, 2, 4      # COALIGN_LAYOUT_* of include/coalign_amd.h
 
 
 def is_channels_last(t: torch.Tensor) -> bool:
@@ -510,8 +516,11 @@ def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Ten
     else:
         xc = _f32c(x)
     N, Cin, H, W = xc.shape
+    tapk = 0                                               # the two weight images differ in size (9 : 10): recognised by it
     if w_split.numel() != L.coalign_conv3x3_emu_weight_bytes(Cin, cout, terms):
-        raise ValueError("split weight image does not match (Cin, Cout, terms)")
+        if stride != 1 or w_split.numel() != L.coalign_conv3x3_emu_weight_bytes_ex(Cin, cout, terms, 1):
+            raise ValueError("split weight image does not match (Cin, Cout, terms)")
+        tapk = LAYOUT_W_TAPMAJOR
     if stride not in (1, 2) or (stride == 2 and (residual is not None or out_channels_last)):
         raise ValueError("stride 2 takes no residual and writes NCHW")
     Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
@@ -524,8 +533,9 @@ def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Ten
     if res is not None and res.shape != y.shape:
         raise ValueError("residual shape mismatch")
     ws, ws_bytes = None, 0
-    if stride == 1 and layout == LAYOUT_NCHW:
-        ws_bytes = L.coalign_conv3x3_emu_workspace_bytes(N, Cin, cout, H, W, terms)
+    layout |= tapk
+    if stride == 1 and (layout & 3) == LAYOUT_NCHW:
+        ws_bytes = L.coalign_conv3x3_emu_workspace_bytes_ex(N, Cin, cout, H, W, terms, layout)
     if ws_bytes:
         key = (xc.device, torch.cuda.current_stream(xc.device).cuda_stream, "emu")
         ws = _CONV_WS.get(key)

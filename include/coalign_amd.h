@@ -299,7 +299,7 @@ size_t coalign_conv3x3_workspace_bytes(int N, int Cin, int Cout, int H, int W);
 int coalign_conv3x3_bias_act(const float *x, const float *w_packed, const float *bias, const float *residual, float *y,
                              int N, int Cin, int Cout, int H, int W, int relu, void *workspace, size_t workspace_bytes, void *stream);
 
-/* (9b) OPT-IN variant of (9): the same layers, fp32 in / fp32 out, with every fp32 product evaluated on the bf16 matrix cores by
+/* (9b) The DEFAULT route of the detector's 3x3 convolutions since round 2 (terms = 3; COALIGN_CONV_EMU=0 selects (9)): the same layers, fp32 in / fp32 out, with every fp32 product evaluated on the bf16 matrix cores by
  * error-free operand splitting (x = x_h + x_m + x_l, bf16 each; cross terms accumulated in fp32, smallest first).
  *   terms = 3: six bf16 products per fp32 product, dropped terms <= 2^-24 |w x| -- fp32-level accuracy;
  *   terms = 2: three products, dropped terms <= 2^-16 |w x|.
@@ -310,7 +310,7 @@ int coalign_conv3x3_bias_act(const float *x, const float *w_packed, const float 
  * workspace: coalign_conv3x3_emu_workspace_bytes(...) bytes of device scratch (0 = none needed for that shape) for the stream-K
  * hand-over of tiles split between two workgroups; one workspace per stream, not shared between concurrent launches.  The split is a
  * pure function of the shape (deterministic).
- * Not used by the default detector path (which keeps native fp32 products); selected with COALIGN_CONV_EMU (coalign_amd/backbone.py).
+ * terms = 3 is the detector's default arithmetic, terms = 2 is opt-in (COALIGN_CONV_EMU, coalign_amd/backbone.py).
  */
 size_t coalign_conv3x3_emu_weight_bytes(int Cin, int Cout, int terms);
 size_t coalign_conv3x3_emu_workspace_bytes(int N, int Cin, int Cout, int H, int W, int terms);
@@ -322,7 +322,13 @@ int coalign_conv3x3_emu_bias_act(const float *x, const void *w_split, const floa
  * (NHWC) out (stride 1 only: the last convolution of a stage, whose map the fusion kernel and the next stage read), 2 = NHWC in /
  * NCHW out (stride 2 only).  residual (stride 1) is always NCHW.  workspace as coalign_conv3x3_emu_workspace_bytes for
  * (stride 1, layout 0); the other variants need none. */
-enum { COALIGN_LAYOUT_NCHW = 0, COALIGN_LAYOUT_OUT_NHWC = 1, COALIGN_LAYOUT_IN_NHWC = 2 };
+enum { COALIGN_LAYOUT_NCHW = 0, COALIGN_LAYOUT_OUT_NHWC = 1, COALIGN_LAYOUT_IN_NHWC = 2, COALIGN_LAYOUT_W_TAPMAJOR = 4 };
+/* COALIGN_LAYOUT_W_TAPMAJOR (flag, or-ed into layout 0 or 1, stride 1, Cin % 16 == 0): w_split is the TAP-MAJOR image
+ *   [Cout / 64][Cin / 16][9 taps][terms][2 channel halves][64 cout][8 cin] bf16 (+ 16 zero bytes),
+ * coalign_conv3x3_emu_weight_bytes_ex(Cin, Cout, terms, 1) bytes: one matrix instruction = the 16 channels of one tap, nine per 16
+ * channels instead of ten (no zero tenth tap).  Workspace: coalign_conv3x3_emu_workspace_bytes_ex(..., layout). */
+size_t coalign_conv3x3_emu_weight_bytes_ex(int Cin, int Cout, int terms, int tap_major);
+size_t coalign_conv3x3_emu_workspace_bytes_ex(int N, int Cin, int Cout, int H, int W, int terms, int layout);
 int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const float *bias, const float *residual, float *y, int N, int Cin,
                            int Cout, int Hin, int Win, int stride, int relu, int terms, int layout, void *workspace,
                            size_t workspace_bytes, void *stream);

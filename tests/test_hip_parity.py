@@ -823,6 +823,37 @@ def test_conv3x3_emu_bias_act_vs_fp64(shape, terms, tol):
     assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max())
 
 
+@pytest.mark.parametrize("terms,tol", [(3, 5e-6), (2, 2e-5)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 100, 352), (3, 128, 128, 50, 176), (2, 256, 256, 25, 88), (1, 384, 256, 36, 96), (2, 64, 128, 37, 52),
+                                   (1, 16, 64, 9, 63), (1, 384, 256, 100, 352)])
+def test_conv3x3_emu_tap_major_vs_fp64(shape, terms, tol):
+    """The tap-major weight image of the split-bf16 convolution (COALIGN_LAYOUT_W_TAPMAJOR: 16-channel intervals of nine matrix steps,
+    no zero tenth tap): same bounds against the fp64 convolution as the default image, NCHW and channels-last output, residual / ReLU,
+    ragged maps, the shrink-header shape (stream-K hand-over), determinism, and agreement with the default image to rounding."""
+    import torch.nn.functional as F
+    N, Ci, Co, H, W = shape
+    gen = torch.Generator(device="cpu").manual_seed(sum(shape) + terms + 7)
+    x = torch.randn(N, Ci, H, W, generator=gen).to(DEV)
+    w = (torch.randn(Co, Ci, 3, 3, generator=gen) / (Ci * 9) ** 0.5).to(DEV)
+    b = torch.randn(Co, generator=gen).to(DEV)
+    r = torch.randn(N, Co, H, W, generator=gen).to(DEV)
+    wt = ops.pack_conv3x3_emu_weight(w, terms, tap_major=True)
+    assert wt.numel() != ops.pack_conv3x3_emu_weight(w, terms).numel()
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    for res, relu in ((None, False), (r, True)):
+        want = ref if res is None else ref + res.double()
+        want = torch.relu(want) if relu else want
+        for cl in (False, True):
+            got = ops.conv3x3_emu_bias_act(x, wt, b, Co, res, relu, terms, out_channels_last=cl)
+            assert got.shape == want.shape and ops.is_channels_last(got) == (cl and Co > 1)
+            assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max()), (shape, res is not None, relu, cl)
+    assert torch.equal(ops.conv3x3_emu_bias_act(x, wt, b, Co, r, True, terms), ops.conv3x3_emu_bias_act(x, wt, b, Co, r, True, terms))
+    pairs = ops.conv3x3_emu_bias_act(x, ops.pack_conv3x3_emu_weight(w, terms), b, Co, r, True, terms)
+    assert float((pairs - ops.conv3x3_emu_bias_act(x, wt, b, Co, r, True, terms)).abs().max()) <= 2 * tol * float(pairs.abs().max())
+    with pytest.raises(ValueError):
+        ops.conv3x3_emu_bias_act(x, wt, b, Co, None, True, terms, stride=2)
+
+
 def test_batch_dict_producer_on_device_vs_reference_dataset(golden, conv_mode):
     """next-4 end to end: raw per-cav records -> IntermediateFusionBatcher with the device voxeliser -> the batch the reference's
     dataset + collate produce (bit-identical pillars, poses, transforms, ground truth), and the detector + post-process +

@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Split-bf16 convolution, tap-pair image (default, two workgroups per CU) against the tap-major image ("K = 144": nine matrix steps per
+16 channels, one workgroup per CU) with 8 / 10 / 12 output rows per workgroup: one process per setting, all backbone shapes, 3-way split.
+Every child also checks its result against the fp64 convolution (rows = 10 is not reachable from the pytest suite)."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHAPES = ((5, 64, 64, 100, 352), (5, 128, 128, 50, 176), (5, 256, 256, 25, 88), (1, 384, 256, 100, 352), (1, 256, 256, 100, 352))
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    import torch
+    import torch.nn.functional as F
+    sys.path.insert(0, ROOT)
+    from coalign_amd import ops
+    tap_major = os.environ.get("TAPK", "0") == "1"
+    def timed(fn, n=20, warm=5):
+        for _ in range(warm): fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n): fn()
+        e.record(); torch.cuda.synchronize()
+        return s.elapsed_time(e) / n * 1e3
+    out = {}
+    for (N, Ci, Co, H, W) in SHAPES:
+        g = torch.Generator().manual_seed(N + Ci + H)
+        x = torch.randn(N, Ci, H, W, generator=g).cuda(); w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).cuda()
+        b = torch.randn(Co, generator=g).cuda(); r = torch.randn(N, Co, H, W, generator=g).cuda()
+        ws = ops.pack_conv3x3_emu_weight(w, 3, tap_major)
+        key = f"{N}x{Ci}x{Co}x{H}x{W}"
+        try:
+            got = ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, 3)
+            want = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1) + r.double())
+            err = float((got.double() - want).abs().max() / want.abs().max())
+            gotcl = ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, 3, out_channels_last=True)
+            errcl = float((gotcl.double() - want).abs().max() / want.abs().max())
+            out[key] = {"us": round(timed(lambda: ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, 3)), 1),
+                        "us_nhwc_out": round(timed(lambda: ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, 3, out_channels_last=True)), 1),
+                        "err": float(f"{err:.2e}"), "err_nhwc_out": float(f"{errcl:.2e}")}
+        except Exception as e:
+            out[key] = f"fail: {e}"
+    print(json.dumps(out))
+else:
+    settings = [("pairs", {"TAPK": "0"}), ("pairs_asm", {"TAPK": "0", "COALIGN_EMU_GEO": "84"})]
+    settings += [(f"tapk{r}_asm", {"TAPK": "1", "COALIGN_EMU_TAPK_ROWS": str(r), "COALIGN_EMU_ASM_DMA": "1"}) for r in (8, 10, 12)]
+    settings += [(f"tapk{r}_asm_sched", {"TAPK": "1", "COALIGN_EMU_TAPK_ROWS": str(r), "COALIGN_EMU_ASM_DMA": "1", "COALIGN_EMU_SCHED": "1"}) for r in (8, 10, 12)]
+    settings += [(f"tapk{r}", {"TAPK": "1", "COALIGN_EMU_TAPK_ROWS": str(r), "COALIGN_EMU_ASM_DMA": "0"}) for r in (12,)]
+    if os.environ.get("SETTINGS"):
+        settings = [x for x in settings if x[0] in os.environ["SETTINGS"].split(",")]
+    rows = {}
+    for name, env in settings:
+        r = subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        rows[name] = json.loads(line[0]) if line else r.stderr[-400:]
+    for shape in ["x".join(map(str, s)) for s in SHAPES]:
+        print(shape, {n: (rows[n].get(shape) if isinstance(rows[n], dict) else rows[n]) for n in rows})
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "tapk"), exist_ok=True)
+    json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "tapk", "conv_tapk.json"), "w"), indent=1)
+    # per-frame weights of the five shapes (stride-1 3x3 layers of the OPV2V model) -> the setting worth a whole-frame A/B
+    weight = dict(zip(["x".join(map(str, s)) for s in SHAPES], (5, 7, 9, 1, 1)))
+    score = {n: sum(weight[k] * v["us"] for k, v in r.items()) for n, r in rows.items() if isinstance(r, dict) and all(isinstance(v, dict) and v["err"] < 5e-6 for v in r.values())}
+    print("weighted us per frame:", {n: round(v) for n, v in score.items()})
+    envs = dict(settings)
+    best = min((n for n in score if n.startswith("tapk")), key=score.get, default=None)
+    runs = [("pairs", {}), ("pairs_asm", {"COALIGN_EMU_GEO": "84"})]
+    if best:
+        runs.append((best, {"COALIGN_EMU_TAPK": "1", **{k: v for k, v in envs[best].items() if k != "TAPK"}}))
+        mixed = {k: min((n for n in score if n.startswith("tapk")), key=lambda n: rows[n][k]["us"]) for k in weight}
+        print("best tap-major setting per shape:", mixed)
+    for name, env in runs + [("pairs", {})]:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-side-modes"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=400)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if line:
+            d = json.loads(line[0])
+            print("BENCH", name, env, "fps", d["value"], "iso", d["roofline"].get("isolated_ms"), "reproducible", d.get("frame_digests_reproducible"), "det", d.get("detections_last_frame"))
+        else:
+            print("BENCH", name, "failed", r.stderr[-300:])
