@@ -111,7 +111,7 @@ __device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[T
 // the first matrix instruction of every interval (the top-of-loop s_waitcnt(0) is the real synchronisation point of the transfer);
 // bit 2 = the order "next step's operand reads, then this step's matrix instructions" is pinned with sched_barrier (147 registers: for
 // the one-workgroup-per-CU tap-major geometries only; with the 128 registers of two 8-wavefront workgroups per CU it spills).
-enum { VAR_TAPK = 1, VAR_ASM_DMA = 2, VAR_SCHED = 4 };
+enum { VAR_TAPK = 1, VAR_ASM_DMA = 2, VAR_SCHED = 4, VAR_EARLY_SPLIT = 8 };
 template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT, int STRIDE = 1, int LAYOUT = LAYOUT_NCHW, int PBUF = 2, int VAR = 0>
 __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB))
 __attribute__((amdgpu_waves_per_eu(SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 1, SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 8)))
@@ -191,24 +191,38 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         }
     };
     // ... split into bf16 terms and written as [term][pixel slot][8 cin] into split-patch buffer `slot`
-    auto store_patch = [&](const Plan &pl, int slot, float (&v)[G::SLOTS][8 * KCH]) {
+    auto split_patch = [&](const Plan &pl, float (&v)[G::SLOTS][8 * KCH], uint4 (&sp)[G::SLOTS][KCH][TERMS]) {
+#pragma unroll
+        for (int j = 0; j < G::SLOTS; ++j) {
+#pragma unroll
+            for (int h = 0; h < KCH; ++h) {
+                float u[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) u[k] = pl.off[j] < 0 ? 0.f : v[j][8 * h + k];
+                bf16x8 o[TERMS];
+                split_pixel<TERMS>(u, o);
+#pragma unroll
+                for (int t = 0; t < TERMS; ++t) sp[j][h][t] = __builtin_bit_cast(uint4, o[t]);
+            }
+        }
+    };
+    auto write_patch = [&](int slot, const uint4 (&sp)[G::SLOTS][KCH][TERMS]) {
         uint4 *bt = reinterpret_cast<uint4 *>(lds + G::B_OFF + (PBUF == 2 ? slot : 0) * G::BSZ);
 #pragma unroll
         for (int j = 0; j < G::SLOTS; ++j) {
             const int i = tid + j * G::THREADS;
             if (i < G::PIX) {
 #pragma unroll
-                for (int h = 0; h < KCH; ++h) {
-                    float u[8];
+                for (int h = 0; h < KCH; ++h)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) u[k] = pl.off[j] < 0 ? 0.f : v[j][8 * h + k];
-                    bf16x8 o[TERMS];
-                    split_pixel<TERMS>(u, o);
-#pragma unroll
-                    for (int t = 0; t < TERMS; ++t) bt[(h * TERMS + t) * G::PIX + i] = __builtin_bit_cast(uint4, o[t]);
-                }
+                    for (int t = 0; t < TERMS; ++t) bt[(h * TERMS + t) * G::PIX + i] = sp[j][h][t];
             }
         }
+    };
+    auto store_patch = [&](const Plan &pl, int slot, float (&v)[G::SLOTS][8 * KCH]) {
+        uint4 sp[G::SLOTS][KCH][TERMS];
+        split_patch(pl, v, sp);
+        write_patch(slot, sp);
     };
     // LDS-DMA of weight chunk c of the tile into weight buffer `slot` (scalar LDS addresses, every lane active)
     constexpr int WJ = (G::WUNITS * G::WINSTR + G::WAVES - 1) / G::WAVES;
@@ -356,8 +370,18 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                     }
                 }
             }
-            if (PBUF == 1) __syncthreads();            // every wave is done reading the single patch buffer
-            if (more) store_patch(nplan, (L + 1) & 1, pv);
+            if constexpr ((VAR & VAR_EARLY_SPLIT) && PBUF == 1) {
+                // the VALU half of the hand-over (fp32 -> bf16 terms) runs before the barrier, beside the matrix instructions of the
+                // wavefronts still in their step loop; only the LDS writes wait for the single patch buffer to be free
+                uint4 sp[G::SLOTS][KCH][TERMS];
+                if (more) split_patch(nplan, pv, sp);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                if (more) write_patch((L + 1) & 1, sp);
+            } else {
+                if (PBUF == 1) __syncthreads();            // every wave is done reading the single patch buffer
+                if (more) store_patch(nplan, (L + 1) & 1, pv);
+            }
             EMU_STAMP(4);
         }
         // The hand-over of a split tile uses agent-scope *write-through* stores / L2-bypassing loads (relaxed atomics) and no
@@ -572,6 +596,8 @@ int dispatch(const EmuArgs &a, void *ws, size_t ws_bytes, hipStream_t s, Launch 
         case 82: return launch<1, 32, 8, TERMS, 2>(a, ws, ws_bytes, s, query);
         case 83: return launch<1, 32, 8, TERMS, 1, 1>(a, ws, ws_bytes, s, query);          // one patch buffer: two workgroups per CU with the 3-way split
         case 84: return launch<1, 32, 8, TERMS, 1, 1, VAR_ASM_DMA>(a, ws, ws_bytes, s, query);      // ... with the weight DMA hidden from hipcc's waitcnt pass
+        case 87: return launch<1, 32, 8, TERMS, 1, 1, VAR_EARLY_SPLIT>(a, ws, ws_bytes, s, query);  // ... with the split ahead of the barrier
+        case 88: return launch<1, 32, 8, TERMS, 1, 1, VAR_ASM_DMA | VAR_EARLY_SPLIT>(a, ws, ws_bytes, s, query);
         case 121: return launch<1, 32, 12, TERMS, 1>(a, ws, ws_bytes, s, query);
         case 122: return launch<1, 32, 12, TERMS, 2>(a, ws, ws_bytes, s, query);
         case 41: return launch<1, 32, 4, TERMS, 1>(a, ws, ws_bytes, s, query);
@@ -581,58 +607,40 @@ int dispatch(const EmuArgs &a, void *ws, size_t ws_bytes, hipStream_t s, Launch 
 
 // Tap-major weight image (TAPK, "K = 144"): 16-channel intervals of nine steps, one workgroup per CU (111 KB of weights + one split
 // patch).  Output rows per workgroup = wavefronts: 8 (143 KB), 10 (150 KB) or 12 (156 KB) with the 3-way split.
-template <int TERMS>
-int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipStream_t s, Launch *query) {
-    static const int force = getenv("COALIGN_EMU_TAPK_ROWS") ? atoi(getenv("COALIGN_EMU_TAPK_ROWS")) : 0;      // experiments only
-    if (a.Cin % (2 * kKC)) return COALIGN_ERR_UNSUPPORTED;
-    static const int asm_dma = getenv("COALIGN_EMU_ASM_DMA") ? atoi(getenv("COALIGN_EMU_ASM_DMA")) : 1;
-    static const int sched = getenv("COALIGN_EMU_SCHED") ? atoi(getenv("COALIGN_EMU_SCHED")) : 0;
-    const int rows = force ? force : (a.H >= 64 ? 12 : 8);
-    constexpr int T = VAR_TAPK, TA = VAR_TAPK | VAR_ASM_DMA, TAS = VAR_TAPK | VAR_ASM_DMA | VAR_SCHED;
-    if (sched) {
-        if (layout == LAYOUT_OUT_NHWC) {
-            if (query) {
-                *query = Launch{0, 0, 0, false};
-                return COALIGN_OK;
-            }
-            switch (rows) {
-                case 8: return launch_variant<1, 32, 8, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, TAS>(a, s);
-                case 10: return launch_variant<1, 32, 10, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, TAS>(a, s);
-                case 12: return launch_variant<1, 32, 12, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, TAS>(a, s);
-                default: return COALIGN_ERR_UNSUPPORTED;
-            }
-        }
-        if (layout != LAYOUT_NCHW) return COALIGN_ERR_UNSUPPORTED;
-        switch (rows) {
-            case 8: return launch<1, 32, 8, TERMS, 2, 1, TAS>(a, ws, ws_bytes, s, query);
-            case 10: return launch<1, 32, 10, TERMS, 2, 1, TAS>(a, ws, ws_bytes, s, query);
-            case 12: return launch<1, 32, 12, TERMS, 2, 1, TAS>(a, ws, ws_bytes, s, query);
-            default: return COALIGN_ERR_UNSUPPORTED;
-        }
-    }
+template <int TERMS, int ROWS, int VAR>
+int tapk_launch(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipStream_t s, Launch *query) {
     if (layout == LAYOUT_OUT_NHWC) {
         if (query) {
             *query = Launch{0, 0, 0, false};
             return COALIGN_OK;
         }
-        switch (rows + (asm_dma ? 100 : 0)) {
-            case 8: return launch_variant<1, 32, 8, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, T>(a, s);
-            case 10: return launch_variant<1, 32, 10, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, T>(a, s);
-            case 12: return launch_variant<1, 32, 12, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, T>(a, s);
-            case 108: return launch_variant<1, 32, 8, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, TA>(a, s);
-            case 110: return launch_variant<1, 32, 10, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, TA>(a, s);
-            case 112: return launch_variant<1, 32, 12, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, TA>(a, s);
-            default: return COALIGN_ERR_UNSUPPORTED;
-        }
+        return launch_variant<1, 32, ROWS, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, VAR>(a, s);
     }
     if (layout != LAYOUT_NCHW) return COALIGN_ERR_UNSUPPORTED;
-    switch (rows + (asm_dma ? 100 : 0)) {
-        case 8: return launch<1, 32, 8, TERMS, 2, 1, T>(a, ws, ws_bytes, s, query);
-        case 10: return launch<1, 32, 10, TERMS, 2, 1, T>(a, ws, ws_bytes, s, query);
-        case 12: return launch<1, 32, 12, TERMS, 2, 1, T>(a, ws, ws_bytes, s, query);
-        case 108: return launch<1, 32, 8, TERMS, 2, 1, TA>(a, ws, ws_bytes, s, query);
-        case 110: return launch<1, 32, 10, TERMS, 2, 1, TA>(a, ws, ws_bytes, s, query);
-        case 112: return launch<1, 32, 12, TERMS, 2, 1, TA>(a, ws, ws_bytes, s, query);
+    return launch<1, 32, ROWS, TERMS, 2, 1, VAR>(a, ws, ws_bytes, s, query);
+}
+
+template <int TERMS, int VAR>
+int tapk_rows(int rows, const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipStream_t s, Launch *query) {
+    switch (rows) {
+        case 8: return tapk_launch<TERMS, 8, VAR>(a, layout, ws, ws_bytes, s, query);
+        case 12: return tapk_launch<TERMS, 12, VAR>(a, layout, ws, ws_bytes, s, query);
+        default: return COALIGN_ERR_UNSUPPORTED;
+    }
+}
+
+template <int TERMS>
+int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipStream_t s, Launch *query) {
+    static const int force = getenv("COALIGN_EMU_TAPK_ROWS") ? atoi(getenv("COALIGN_EMU_TAPK_ROWS")) : 0;      // experiments only
+    static const int var = getenv("COALIGN_EMU_TAPK_VAR") ? atoi(getenv("COALIGN_EMU_TAPK_VAR")) : (VAR_TAPK | VAR_ASM_DMA);
+    if (a.Cin % (2 * kKC)) return COALIGN_ERR_UNSUPPORTED;
+    // measured per layer (tools/bench_conv_tapk.py): 12 rows on the 100-row maps (495 tiles = two full rounds of 256 workgroups), 8 rows
+    // on the 50- and 25-row maps; 10 rows lose everywhere but on the shrink header (-1 %)
+    const int rows = force ? force : (a.H >= 64 ? 12 : 8);
+    switch (var) {
+        case VAR_TAPK: return tapk_rows<TERMS, VAR_TAPK>(rows, a, layout, ws, ws_bytes, s, query);
+        case VAR_TAPK | VAR_ASM_DMA: return tapk_rows<TERMS, VAR_TAPK | VAR_ASM_DMA>(rows, a, layout, ws, ws_bytes, s, query);
+        case VAR_TAPK | VAR_ASM_DMA | VAR_EARLY_SPLIT: return tapk_rows<TERMS, VAR_TAPK | VAR_ASM_DMA | VAR_EARLY_SPLIT>(rows, a, layout, ws, ws_bytes, s, query);
         default: return COALIGN_ERR_UNSUPPORTED;
     }
 }

@@ -39,10 +39,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             out[key] = f"fail: {e}"
     print(json.dumps(out))
 else:
-    settings = [("pairs", {"TAPK": "0"}), ("pairs_asm", {"TAPK": "0", "COALIGN_EMU_GEO": "84"})]
-    settings += [(f"tapk{r}_asm", {"TAPK": "1", "COALIGN_EMU_TAPK_ROWS": str(r), "COALIGN_EMU_ASM_DMA": "1"}) for r in (8, 10, 12)]
-    settings += [(f"tapk{r}_asm_sched", {"TAPK": "1", "COALIGN_EMU_TAPK_ROWS": str(r), "COALIGN_EMU_ASM_DMA": "1", "COALIGN_EMU_SCHED": "1"}) for r in (8, 10, 12)]
-    settings += [(f"tapk{r}", {"TAPK": "1", "COALIGN_EMU_TAPK_ROWS": str(r), "COALIGN_EMU_ASM_DMA": "0"}) for r in (12,)]
+    # COALIGN_EMU_GEO: 83 = default tap-pair kernel, 84 = + asm-issued weight DMA, 87 = + split ahead of the barrier, 88 = both
+    # COALIGN_EMU_TAPK_VAR: 1 = tap-major, 3 = + asm DMA, 11 = + split ahead of the barrier; rows: 0 = the dispatch rule (12 / 8)
+    settings = [("pairs", {"TAPK": "0"})] + [(f"pairs_g{g}", {"TAPK": "0", "COALIGN_EMU_GEO": str(g)}) for g in (84, 87, 88)]
+    settings += [(f"tapk_v{v}_r{r}", {"TAPK": "1", "COALIGN_EMU_TAPK_ROWS": str(r), "COALIGN_EMU_TAPK_VAR": str(v)}) for v in (3, 11) for r in (0, 8)]
     if os.environ.get("SETTINGS"):
         settings = [x for x in settings if x[0] in os.environ["SETTINGS"].split(",")]
     rows = {}
@@ -60,7 +60,8 @@ else:
     print("weighted us per frame:", {n: round(v) for n, v in score.items()})
     envs = dict(settings)
     best = min((n for n in score if n.startswith("tapk")), key=score.get, default=None)
-    runs = [("pairs", {}), ("pairs_asm", {"COALIGN_EMU_GEO": "84"})]
+    bestp = min((n for n in score if n.startswith("pairs_")), key=score.get, default=None)
+    runs = [("pairs", {})] + ([(bestp, {k: v for k, v in envs[bestp].items() if k != "TAPK"})] if bestp else [])
     if best:
         runs.append((best, {"COALIGN_EMU_TAPK": "1", **{k: v for k, v in envs[best].items() if k != "TAPK"}}))
         mixed = {k: min((n for n in score if n.startswith("tapk")), key=lambda n: rows[n][k]["us"]) for k in weight}
