@@ -64,7 +64,7 @@ CONV_EMU_TERMS = int(os.environ.get("COALIGN_CONV_EMU", "3"))
 NHWC_STAGE_OUTPUTS = os.environ.get("COALIGN_NHWC_STAGES", "1") != "0"
 # Weight image of the stride-1 split-bf16 convolutions: "1" = tap-major (16-channel intervals of nine matrix steps, no zero tenth tap,
 # one workgroup per CU), "0" = tap pairs of 8-channel chunks (ten steps per 16 channels, two workgroups per CU).  Measured: DESIGN.md §8.
-CONV_EMU_TAP_MAJOR = os.environ.get("COALIGN_EMU_TAPK", "0") != "0"
+CONV_EMU_TAP_MAJOR = os.environ.get("COALIGN_EMU_TAPK", "1") != "0"
 
 
 class Conv3x3Pack:

@@ -45,14 +45,14 @@ struct EmuArgs {
     float *__restrict__ partial;      // [grid][16 * NCO][threads]: accumulators of a tile whose chunks are split over two workgroups
     int *flags;                       // [grid], zeroed per launch: flags[g] = 1 once workgroup g has published its partial tile
 #ifdef EMU_TRACE
-    long long *trace;                 // profiling aid (tools/trace_conv_emu.py): [2 workgroups][waves][64 chunks][5 stamps]
+    long long *trace;                 // profiling aid (tools/trace_conv_emu.py): [2 workgroups][waves][64 chunks][8 stamps]
 #endif
 };
 
 #ifdef EMU_TRACE
 #define EMU_STAMP(k)                                                                                              \
     if ((g == 0 || g == 100) && lane == 0 && L < 64)                                                              \
-        a.trace[((((g ? 1 : 0) * G::WAVES + wave) * 64) + L) * 5 + (k)] = (long long)__builtin_amdgcn_s_memtime()
+        a.trace[((((g ? 1 : 0) * G::WAVES + wave) * 64) + L) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime()
 #else
 #define EMU_STAMP(k)
 #endif
@@ -108,15 +108,19 @@ __device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[T
 // wavefronts = 3 per SIMD.  (Pinning the plain variant as well changes hipcc's scheduling and was measured 5-20 % slower.)
 // VAR: bit 0 = tap-major weight image (TAPK), bit 1 = the weight LDS-DMA is issued from inline assembly: hipcc cannot prove the DMA
 // destination disjoint from the operand reads and otherwise waits for vmcnt(0) -- the full latency of everything just issued -- before
-// the first matrix instruction of every interval (the top-of-loop s_waitcnt(0) is the real synchronisation point of the transfer);
-// bit 2 = the order "next step's operand reads, then this step's matrix instructions" is pinned with sched_barrier (147 registers: for
-// the one-workgroup-per-CU tap-major geometries only; with the 128 registers of two 8-wavefront workgroups per CU it spills).
-enum { VAR_TAPK = 1, VAR_ASM_DMA = 2, VAR_SCHED = 4, VAR_EARLY_SPLIT = 8 };
+// the first matrix instruction of every interval (the top-of-loop s_waitcnt(0) is the real synchronisation point of the transfer).
+// bit 2 (needs bit 1) = the next interval's weight DMA and halo-pixel loads are issued in shares between the matrix steps instead of
+// all at once after the barrier (interval timelines, tools/trace_conv_emu.py: with one 12-wavefront workgroup per CU the burst takes a
+// quarter of the interval -- 85 KB per CU from L2 with every CU asking at once -- and no matrix instruction runs meanwhile).
+// (Pinning the step loop's order "next step's operand reads, then this step's matrix instructions" with sched_barrier: 147 registers,
+// 3-7 % slower per layer on the tap-major geometries; computing the bf16 split ahead of the second barrier: no change.  Both removed.)
+enum { VAR_TAPK = 1, VAR_ASM_DMA = 2, VAR_SPREAD = 4 };
 template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT, int STRIDE = 1, int LAYOUT = LAYOUT_NCHW, int PBUF = 2, int VAR = 0>
 __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB))
 __attribute__((amdgpu_waves_per_eu(SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 1, SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 8)))
 void conv3x3_emu_kernel(const EmuArgs a) {
-    constexpr bool TAPK = (VAR & VAR_TAPK) != 0;
+    constexpr bool TAPK = (VAR & VAR_TAPK) != 0, SPREAD = (VAR & VAR_SPREAD) != 0;
+    static_assert(!SPREAD || (VAR & VAR_ASM_DMA), "a builtin DMA between the matrix steps makes hipcc wait for vmcnt(0) after each one");
     using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, TAPK>;
     static_assert(!(SPLIT && (STRIDE != 1 || LAYOUT != LAYOUT_NCHW)), "stream-K hand-over only for the plain stride-1 NCHW variant");
     extern __shared__ __attribute__((aligned(1024))) float lds[];
@@ -167,7 +171,9 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     };
     // chunk c of the tile: the 8 input channels of this thread's pixel slots -> registers (plain coalesced loads: consecutive
     // lanes = consecutive pixels of a patch row; clamped address + zero select, no divergent branch around the loads)
-    auto load_patch = [&](const Plan &pl, int c, float (&v)[G::SLOTS][8 * KCH]) {
+    // (lo, hi: the range of load instructions per pixel slot to issue -- all of them, or one step's share when the issue is spread)
+    constexpr int NLOAD = LAYOUT == LAYOUT_IN_NHWC ? 2 * KCH : 8 * KCH;
+    auto load_patch = [&](const Plan &pl, int c, float (&v)[G::SLOTS][8 * KCH], int lo = 0, int hi = 1 << 20) {
         if constexpr (LAYOUT == LAYOUT_IN_NHWC) {          // channels-last input: the 8 channels of a pixel are 32 contiguous bytes
             const float *src = pl.base + (size_t)c * (kKC * KCH);
 #pragma unroll
@@ -176,6 +182,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                 const float4 *q = reinterpret_cast<const float4 *>(src + (size_t)o * a.Cin);
 #pragma unroll
                 for (int k4 = 0; k4 < 2 * KCH; ++k4) {
+                    if (k4 < lo || k4 >= hi) continue;
                     const float4 t = q[k4];
                     v[j][4 * k4] = t.x; v[j][4 * k4 + 1] = t.y; v[j][4 * k4 + 2] = t.z; v[j][4 * k4 + 3] = t.w;
                 }
@@ -186,7 +193,8 @@ void conv3x3_emu_kernel(const EmuArgs a) {
             for (int j = 0; j < G::SLOTS; ++j) {
                 const int o = pl.off[j] < 0 ? 0 : pl.off[j];
 #pragma unroll
-                for (int k = 0; k < 8 * KCH; ++k) v[j][k] = src[(size_t)k * plane_in + o];
+                for (int k = 0; k < 8 * KCH; ++k)
+                    if (k >= lo && k < hi) v[j][k] = src[(size_t)k * plane_in + o];
             }
         }
     };
@@ -226,11 +234,12 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     };
     // LDS-DMA of weight chunk c of the tile into weight buffer `slot` (scalar LDS addresses, every lane active)
     constexpr int WJ = (G::WUNITS * G::WINSTR + G::WAVES - 1) / G::WAVES;
-    auto issue_weights = [&](const Plan &pl, int c, int slot) {
+    auto issue_weights = [&](const Plan &pl, int c, int slot, int lo = 0, int hi = 1 << 20) {
         float *wdst = lds + G::W_OFF + slot * G::WSZ;
         const uint4 *wsrc = pl.wsrc + (size_t)c * (G::WUNITS * G::WQ);
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
+            if (j < lo || j >= hi) continue;
             const int ins = wave + G::WAVES * j;
             if (ins < G::WUNITS * G::WINSTR) {
                 if constexpr (VAR & VAR_ASM_DMA) {
@@ -257,7 +266,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     auto global_step = [&](int l) { return SPLIT ? s0 + l : (g + (l / chunks) * n_wg) * chunks + l % chunks; };
     if (n_local <= 0) return;
 #ifdef EMU_TRACE
-    if (tid == 0) a.trace[2 * 16 * 64 * 5 + 2 * g] = wall_clock64();   // 100 MHz wall clock: start / end of every workgroup
+    if (tid == 0) a.trace[2 * 16 * 64 * 8 + 2 * g] = wall_clock64();   // 100 MHz wall clock: start / end of every workgroup
 #endif
 
     // Chunk-level software pipeline, one barrier per chunk, everything one chunk ahead.  In iteration L a wavefront
@@ -309,6 +318,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
             __syncthreads();
             EMU_STAMP(2);
             const bool more = L + 1 < n_local;
+            int nc = 0;                                                // the next interval's chunk index inside its tile
             if (more) {
                 const int ns = global_step(L + 1);
                 const int nt = ns / chunks;
@@ -317,8 +327,11 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                     next = decode(nt);
                     nplan = make_plan(next);
                 }
-                issue_weights(nplan, ns - nt * chunks, (L + 1) & 1);
-                load_patch(nplan, ns - nt * chunks, pv);
+                nc = ns - nt * chunks;
+                if constexpr (!SPREAD) {
+                    issue_weights(nplan, nc, (L + 1) & 1);
+                    load_patch(nplan, nc, pv);
+                }
             }
             EMU_STAMP(3);
             const uint4 *bq = reinterpret_cast<const uint4 *>(lds + G::B_OFF + (PBUF == 2 ? (L & 1) : 0) * G::BSZ);
@@ -353,14 +366,17 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                     load_b(st + 1, bn);
                     load_w(st + 1, wn);
                 }
-                // the schedule the source spells out, pinned: all operand reads of the next step are issued before this step's matrix
-                // instructions (hipcc otherwise sinks them towards their uses and waits lgkmcnt(0) three times per step)
-                if constexpr (VAR & VAR_SCHED) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
                     for (int q = 0; q < G::NCO; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[q][wi[i]], bc[bi[i]], acc[q], 0, 0, 0);
-                if constexpr (VAR & VAR_SCHED) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (SPREAD) {                // this step's share of the next interval's weight DMA and halo-pixel loads
+                    constexpr int LPS = (NLOAD + NS - 1) / NS, DPS = (WJ + NS - 1) / NS;
+                    if (more) {
+                        issue_weights(nplan, nc, (L + 1) & 1, st * DPS, (st + 1) * DPS);
+                        load_patch(nplan, nc, pv, st * LPS, (st + 1) * LPS);
+                    }
+                }
                 if (st + 1 < NS) {
 #pragma unroll
                     for (int t = 0; t < TERMS; ++t) {
@@ -370,19 +386,11 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                     }
                 }
             }
-            if constexpr ((VAR & VAR_EARLY_SPLIT) && PBUF == 1) {
-                // the VALU half of the hand-over (fp32 -> bf16 terms) runs before the barrier, beside the matrix instructions of the
-                // wavefronts still in their step loop; only the LDS writes wait for the single patch buffer to be free
-                uint4 sp[G::SLOTS][KCH][TERMS];
-                if (more) split_patch(nplan, pv, sp);
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();
-                if (more) write_patch((L + 1) & 1, sp);
-            } else {
-                if (PBUF == 1) __syncthreads();            // every wave is done reading the single patch buffer
-                if (more) store_patch(nplan, (L + 1) & 1, pv);
-            }
             EMU_STAMP(4);
+            if (PBUF == 1) __syncthreads();            // every wave is done reading the single patch buffer
+            EMU_STAMP(5);
+            if (more) store_patch(nplan, (L + 1) & 1, pv);
+            EMU_STAMP(6);
         }
         // The hand-over of a split tile uses agent-scope *write-through* stores / L2-bypassing loads (relaxed atomics) and no
         // fences (an agent-scope fence writes back and invalidates the XCD's whole L2; see conv3x3.hip).
@@ -431,7 +439,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         tile = ntile;
     }
 #ifdef EMU_TRACE
-    if (tid == 0) a.trace[2 * 16 * 64 * 5 + 2 * g + 1] = wall_clock64();
+    if (tid == 0) a.trace[2 * 16 * 64 * 8 + 2 * g + 1] = wall_clock64();
 #endif
 }
 
@@ -500,6 +508,11 @@ int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
         // 3-way split: 8 output rows per workgroup with ONE patch buffer (114 KB) instead of 6 rows double buffered (142 KB): 8 wavefronts per
         // CU instead of 6; measured 287.4 -> 291.1 frames/s (tools/ab_bench.sh, same box)
         static const int s2pb = getenv("COALIGN_EMU_S2_PBUF1") ? atoi(getenv("COALIGN_EMU_S2_PBUF1")) : 1;
+        static const int s2asm = getenv("COALIGN_EMU_S2_ASM") ? atoi(getenv("COALIGN_EMU_S2_ASM")) : 0;      // weight DMA issued from inline assembly (VAR_ASM_DMA)
+        if (TERMS == 3 && s2pb && s2asm) {
+            if (layout == LAYOUT_NCHW) return launch_variant<1, 32, 8, TERMS, 1, 2, LAYOUT_NCHW, 1, VAR_ASM_DMA>(a, s);
+            if (layout == LAYOUT_IN_NHWC) return launch_variant<1, 32, 8, TERMS, 1, 2, LAYOUT_IN_NHWC, 1, VAR_ASM_DMA>(a, s);
+        }
         if (TERMS == 3 && s2pb) {
             if (layout == LAYOUT_NCHW) return launch_variant<1, 32, 8, TERMS, 1, 2, LAYOUT_NCHW, 1>(a, s);
             if (layout == LAYOUT_IN_NHWC) return launch_variant<1, 32, 8, TERMS, 1, 2, LAYOUT_IN_NHWC, 1>(a, s);
@@ -596,8 +609,7 @@ int dispatch(const EmuArgs &a, void *ws, size_t ws_bytes, hipStream_t s, Launch 
         case 82: return launch<1, 32, 8, TERMS, 2>(a, ws, ws_bytes, s, query);
         case 83: return launch<1, 32, 8, TERMS, 1, 1>(a, ws, ws_bytes, s, query);          // one patch buffer: two workgroups per CU with the 3-way split
         case 84: return launch<1, 32, 8, TERMS, 1, 1, VAR_ASM_DMA>(a, ws, ws_bytes, s, query);      // ... with the weight DMA hidden from hipcc's waitcnt pass
-        case 87: return launch<1, 32, 8, TERMS, 1, 1, VAR_EARLY_SPLIT>(a, ws, ws_bytes, s, query);  // ... with the split ahead of the barrier
-        case 88: return launch<1, 32, 8, TERMS, 1, 1, VAR_ASM_DMA | VAR_EARLY_SPLIT>(a, ws, ws_bytes, s, query);
+        case 85: return launch<1, 32, 8, TERMS, 1, 1, VAR_ASM_DMA | VAR_SPREAD>(a, ws, ws_bytes, s, query);      // ... and issued in shares between the steps
         case 121: return launch<1, 32, 12, TERMS, 1>(a, ws, ws_bytes, s, query);
         case 122: return launch<1, 32, 12, TERMS, 2>(a, ws, ws_bytes, s, query);
         case 41: return launch<1, 32, 4, TERMS, 1>(a, ws, ws_bytes, s, query);
@@ -640,7 +652,7 @@ int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipSt
     switch (var) {
         case VAR_TAPK: return tapk_rows<TERMS, VAR_TAPK>(rows, a, layout, ws, ws_bytes, s, query);
         case VAR_TAPK | VAR_ASM_DMA: return tapk_rows<TERMS, VAR_TAPK | VAR_ASM_DMA>(rows, a, layout, ws, ws_bytes, s, query);
-        case VAR_TAPK | VAR_ASM_DMA | VAR_EARLY_SPLIT: return tapk_rows<TERMS, VAR_TAPK | VAR_ASM_DMA | VAR_EARLY_SPLIT>(rows, a, layout, ws, ws_bytes, s, query);
+        case VAR_TAPK | VAR_ASM_DMA | VAR_SPREAD: return tapk_rows<TERMS, VAR_TAPK | VAR_ASM_DMA | VAR_SPREAD>(rows, a, layout, ws, ws_bytes, s, query);
         default: return COALIGN_ERR_UNSUPPORTED;
     }
 }
@@ -722,6 +734,9 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
         if ((reinterpret_cast<uintptr_t>(w_split) & 15) || (lay != LAYOUT_NCHW && (reinterpret_cast<uintptr_t>(y) & 15))) return COALIGN_ERR_UNSUPPORTED;
         if (N == 0) return COALIGN_OK;
         EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, Hin, Win, relu, 0, 0, 0, Hin, Win, nullptr, nullptr};
+#ifdef EMU_TRACE
+        a.trace = g_emu_trace;
+#endif
         hipStream_t s = static_cast<hipStream_t>(stream);
         rc = terms == 3 ? dispatch_tapk<3>(a, lay, workspace, workspace_bytes, s, nullptr) : dispatch_tapk<2>(a, lay, workspace, workspace_bytes, s, nullptr);
         return rc != COALIGN_OK ? rc : check_launch();
@@ -735,6 +750,9 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
         return COALIGN_ERR_UNSUPPORTED;
     if (N == 0) return COALIGN_OK;
     EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, Hin, Win, nullptr, nullptr};
+#ifdef EMU_TRACE
+    a.trace = g_emu_trace;
+#endif
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = terms == 3 ? dispatch_variant<3>(a, stride, layout, s) : dispatch_variant<2>(a, stride, layout, s);
     return rc != COALIGN_OK ? rc : check_launch();

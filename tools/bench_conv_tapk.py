@@ -39,10 +39,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             out[key] = f"fail: {e}"
     print(json.dumps(out))
 else:
-    # COALIGN_EMU_GEO: 83 = default tap-pair kernel, 84 = + asm-issued weight DMA, 87 = + split ahead of the barrier, 88 = both
-    # COALIGN_EMU_TAPK_VAR: 1 = tap-major, 3 = + asm DMA, 11 = + split ahead of the barrier; rows: 0 = the dispatch rule (12 / 8)
-    settings = [("pairs", {"TAPK": "0"})] + [(f"pairs_g{g}", {"TAPK": "0", "COALIGN_EMU_GEO": str(g)}) for g in (84, 87, 88)]
-    settings += [(f"tapk_v{v}_r{r}", {"TAPK": "1", "COALIGN_EMU_TAPK_ROWS": str(r), "COALIGN_EMU_TAPK_VAR": str(v)}) for v in (3, 11) for r in (0, 8)]
+    # COALIGN_EMU_GEO: 83 = default tap-pair kernel, 84 = + asm-issued weight DMA, 85 = + issue spread over the steps
+    # COALIGN_EMU_TAPK_VAR: 1 = tap-major, 3 = + asm DMA, 7 = + issue spread over the steps; rows: 0 = the dispatch rule (12 / 8)
+    settings = [("pairs", {"TAPK": "0"})] + [(f"pairs_g{g}", {"TAPK": "0", "COALIGN_EMU_GEO": str(g)}) for g in (84, 85)]
+    settings += [(f"tapk_v{v}_r{r}", {"TAPK": "1", "COALIGN_EMU_TAPK_ROWS": str(r), "COALIGN_EMU_TAPK_VAR": str(v)}) for v, r in ((3, 0), (7, 0), (7, 8), (7, 12))]
     if os.environ.get("SETTINGS"):
         settings = [x for x in settings if x[0] in os.environ["SETTINGS"].split(",")]
     rows = {}
