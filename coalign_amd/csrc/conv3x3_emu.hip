@@ -44,8 +44,10 @@ struct EmuArgs {
     int Hin, Win;                     // input size (== H, W for stride 1; H = ceil(Hin / 2) for stride 2)
     float *__restrict__ partial;      // [grid][16 * NCO][threads]: accumulators of a tile whose chunks are split over two workgroups
     int *flags;                       // [grid], zeroed per launch: flags[g] = 1 once workgroup g has published its partial tile
+    int prio_mode;                    // 1: the first-dispatched half of the grid outranks the second half (see the kernel)
 #ifdef EMU_TRACE
     long long *trace;                 // profiling aid (tools/trace_conv_emu.py): [2 workgroups][waves][64 chunks][8 stamps]
+    int ablate;                       // 1: no weight DMA, 2: no halo-pixel loads, 4: no matrix steps (wrong results; what each part costs)
 #endif
 };
 
@@ -109,18 +111,16 @@ __device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[T
 // VAR: bit 0 = tap-major weight image (TAPK), bit 1 = the weight LDS-DMA is issued from inline assembly: hipcc cannot prove the DMA
 // destination disjoint from the operand reads and otherwise waits for vmcnt(0) -- the full latency of everything just issued -- before
 // the first matrix instruction of every interval (the top-of-loop s_waitcnt(0) is the real synchronisation point of the transfer).
-// bit 2 (needs bit 1) = the next interval's weight DMA and halo-pixel loads are issued in shares between the matrix steps instead of
-// all at once after the barrier (interval timelines, tools/trace_conv_emu.py: with one 12-wavefront workgroup per CU the burst takes a
-// quarter of the interval -- 85 KB per CU from L2 with every CU asking at once -- and no matrix instruction runs meanwhile).
 // (Pinning the step loop's order "next step's operand reads, then this step's matrix instructions" with sched_barrier: 147 registers,
-// 3-7 % slower per layer on the tap-major geometries; computing the bf16 split ahead of the second barrier: no change.  Both removed.)
-enum { VAR_TAPK = 1, VAR_ASM_DMA = 2, VAR_SPREAD = 4 };
+// 3-7 % slower per layer on the tap-major geometries; computing the bf16 split ahead of the second barrier: no change; issuing the next
+// interval's weight DMA and halo loads in shares between the matrix steps instead of all at once after the barrier: no change -- the
+// interval timelines (tools/trace_conv_emu.py) show the burst already overlapped by the other wavefronts' matrix instructions.  All removed.)
+enum { VAR_TAPK = 1, VAR_ASM_DMA = 2 };
 template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT, int STRIDE = 1, int LAYOUT = LAYOUT_NCHW, int PBUF = 2, int VAR = 0>
 __global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB))
 __attribute__((amdgpu_waves_per_eu(SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 1, SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 8)))
 void conv3x3_emu_kernel(const EmuArgs a) {
-    constexpr bool TAPK = (VAR & VAR_TAPK) != 0, SPREAD = (VAR & VAR_SPREAD) != 0;
-    static_assert(!SPREAD || (VAR & VAR_ASM_DMA), "a builtin DMA between the matrix steps makes hipcc wait for vmcnt(0) after each one");
+    constexpr bool TAPK = (VAR & VAR_TAPK) != 0;
     using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, TAPK>;
     static_assert(!(SPLIT && (STRIDE != 1 || LAYOUT != LAYOUT_NCHW)), "stream-K hand-over only for the plain stride-1 NCHW variant");
     extern __shared__ __attribute__((aligned(1024))) float lds[];
@@ -171,9 +171,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     };
     // chunk c of the tile: the 8 input channels of this thread's pixel slots -> registers (plain coalesced loads: consecutive
     // lanes = consecutive pixels of a patch row; clamped address + zero select, no divergent branch around the loads)
-    // (lo, hi: the range of load instructions per pixel slot to issue -- all of them, or one step's share when the issue is spread)
-    constexpr int NLOAD = LAYOUT == LAYOUT_IN_NHWC ? 2 * KCH : 8 * KCH;
-    auto load_patch = [&](const Plan &pl, int c, float (&v)[G::SLOTS][8 * KCH], int lo = 0, int hi = 1 << 20) {
+    auto load_patch = [&](const Plan &pl, int c, float (&v)[G::SLOTS][8 * KCH]) {
         if constexpr (LAYOUT == LAYOUT_IN_NHWC) {          // channels-last input: the 8 channels of a pixel are 32 contiguous bytes
             const float *src = pl.base + (size_t)c * (kKC * KCH);
 #pragma unroll
@@ -182,7 +180,6 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                 const float4 *q = reinterpret_cast<const float4 *>(src + (size_t)o * a.Cin);
 #pragma unroll
                 for (int k4 = 0; k4 < 2 * KCH; ++k4) {
-                    if (k4 < lo || k4 >= hi) continue;
                     const float4 t = q[k4];
                     v[j][4 * k4] = t.x; v[j][4 * k4 + 1] = t.y; v[j][4 * k4 + 2] = t.z; v[j][4 * k4 + 3] = t.w;
                 }
@@ -193,8 +190,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
             for (int j = 0; j < G::SLOTS; ++j) {
                 const int o = pl.off[j] < 0 ? 0 : pl.off[j];
 #pragma unroll
-                for (int k = 0; k < 8 * KCH; ++k)
-                    if (k >= lo && k < hi) v[j][k] = src[(size_t)k * plane_in + o];
+                for (int k = 0; k < 8 * KCH; ++k) v[j][k] = src[(size_t)k * plane_in + o];
             }
         }
     };
@@ -234,12 +230,11 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     };
     // LDS-DMA of weight chunk c of the tile into weight buffer `slot` (scalar LDS addresses, every lane active)
     constexpr int WJ = (G::WUNITS * G::WINSTR + G::WAVES - 1) / G::WAVES;
-    auto issue_weights = [&](const Plan &pl, int c, int slot, int lo = 0, int hi = 1 << 20) {
+    auto issue_weights = [&](const Plan &pl, int c, int slot) {
         float *wdst = lds + G::W_OFF + slot * G::WSZ;
         const uint4 *wsrc = pl.wsrc + (size_t)c * (G::WUNITS * G::WQ);
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
-            if (j < lo || j >= hi) continue;
             const int ins = wave + G::WAVES * j;
             if (ins < G::WUNITS * G::WINSTR) {
                 if constexpr (VAR & VAR_ASM_DMA) {
@@ -283,7 +278,17 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     load_patch(plan, global_step(0) - tile * chunks, pv);
     issue_weights(plan, global_step(0) - tile * chunks, 0);
     store_patch(plan, 0, pv);
-    if (wave >= G::WAVES / 2) __builtin_amdgcn_s_setprio(1);           // the later-dispatched half loses every arbitration otherwise
+    // Issue priorities.  Inside a workgroup the later-dispatched half of the wavefronts loses every arbitration otherwise.  Between the two
+    // workgroups that share a CU (prio_mode 1): the interval timelines show them running IN PHASE -- both in their matrix steps, then both in
+    // the barrier / load / split part with the matrix pipe idle (kernel time = matrix time + the rest, no overlap).  A strict rank makes the
+    // higher-ranked workgroup take the matrix pipe alone and finish its steps in half the time, so the other one's steps fall into its
+    // barrier / load / split part: anti-phase by arbitration.  Workgroups g and g + gridDim / 2 are the usual co-residents (dispatch order).
+    {
+        const int rank = (wave >= G::WAVES / 2 ? 1 : 0) + (a.prio_mode == 1 && 2 * (int)blockIdx.x < (int)gridDim.x ? 2 : 0);
+        if (rank == 1) __builtin_amdgcn_s_setprio(1);
+        else if (rank == 2) __builtin_amdgcn_s_setprio(2);
+        else if (rank == 3) __builtin_amdgcn_s_setprio(3);
+    }
     int L = 0;
     while (L < n_local) {
         const int gs0 = global_step(L);
@@ -294,8 +299,11 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         const bool live = gy < a.H && gx < a.W;
         const size_t obase = ((size_t)cur.n * a.Cout + cur.cg * kCoutTile + cb + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
         const float *bias = a.bias + cur.cg * kCoutTile + cb + 4 * half;
+        // a wavefront whose output rows lie below the map (the last row tile: 108 rows for 100, 56 for 50, 32 for 25) still stages pixels,
+        // issues weight transfers and meets the barriers, but runs no matrix steps: its share of the padded work costs no energy
+        const bool wave_live = __builtin_amdgcn_readfirstlane((int)(cur.y0 + pb * BH < a.H)) != 0;
         floatx16 acc[G::NCO];
-        if (SPLIT && !head) {
+        if ((SPLIT && !head) || !wave_live) {
 #pragma unroll
             for (int q = 0; q < G::NCO; ++q) acc[q] = floatx16{0};
         } else if (a.residual) {
@@ -318,7 +326,6 @@ void conv3x3_emu_kernel(const EmuArgs a) {
             __syncthreads();
             EMU_STAMP(2);
             const bool more = L + 1 < n_local;
-            int nc = 0;                                                // the next interval's chunk index inside its tile
             if (more) {
                 const int ns = global_step(L + 1);
                 const int nt = ns / chunks;
@@ -327,11 +334,13 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                     next = decode(nt);
                     nplan = make_plan(next);
                 }
-                nc = ns - nt * chunks;
-                if constexpr (!SPREAD) {
-                    issue_weights(nplan, nc, (L + 1) & 1);
-                    load_patch(nplan, nc, pv);
-                }
+#ifdef EMU_TRACE
+                if (!(a.ablate & 1)) issue_weights(nplan, ns - nt * chunks, (L + 1) & 1);
+                if (!(a.ablate & 2)) load_patch(nplan, ns - nt * chunks, pv);
+#else
+                issue_weights(nplan, ns - nt * chunks, (L + 1) & 1);
+                load_patch(nplan, ns - nt * chunks, pv);
+#endif
             }
             EMU_STAMP(3);
             const uint4 *bq = reinterpret_cast<const uint4 *>(lds + G::B_OFF + (PBUF == 2 ? (L & 1) : 0) * G::BSZ);
@@ -354,6 +363,11 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                     for (int t = 0; t < TERMS; ++t) w[q][t] = __builtin_bit_cast(bf16x8, wq[h * G::WQ + ((s * TERMS + t) * 2) * kCoutTile + q * 32]);
             };
             bf16x8 bc[TERMS], wc[G::NCO][TERMS];
+#ifdef EMU_TRACE
+            if (wave_live && !(a.ablate & 4)) {
+#else
+            if (wave_live) {
+#endif
             load_b(0, bc);
             load_w(0, wc);
 #pragma unroll
@@ -370,13 +384,6 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
                     for (int q = 0; q < G::NCO; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[q][wi[i]], bc[bi[i]], acc[q], 0, 0, 0);
-                if constexpr (SPREAD) {                // this step's share of the next interval's weight DMA and halo-pixel loads
-                    constexpr int LPS = (NLOAD + NS - 1) / NS, DPS = (WJ + NS - 1) / NS;
-                    if (more) {
-                        issue_weights(nplan, nc, (L + 1) & 1, st * DPS, (st + 1) * DPS);
-                        load_patch(nplan, nc, pv, st * LPS, (st + 1) * LPS);
-                    }
-                }
                 if (st + 1 < NS) {
 #pragma unroll
                     for (int t = 0; t < TERMS; ++t) {
@@ -385,6 +392,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                         for (int q = 0; q < G::NCO; ++q) wc[q][t] = wn[q][t];
                     }
                 }
+            }
             }
             EMU_STAMP(4);
             if (PBUF == 1) __syncthreads();            // every wave is done reading the single patch buffer
@@ -609,7 +617,6 @@ int dispatch(const EmuArgs &a, void *ws, size_t ws_bytes, hipStream_t s, Launch 
         case 82: return launch<1, 32, 8, TERMS, 2>(a, ws, ws_bytes, s, query);
         case 83: return launch<1, 32, 8, TERMS, 1, 1>(a, ws, ws_bytes, s, query);          // one patch buffer: two workgroups per CU with the 3-way split
         case 84: return launch<1, 32, 8, TERMS, 1, 1, VAR_ASM_DMA>(a, ws, ws_bytes, s, query);      // ... with the weight DMA hidden from hipcc's waitcnt pass
-        case 85: return launch<1, 32, 8, TERMS, 1, 1, VAR_ASM_DMA | VAR_SPREAD>(a, ws, ws_bytes, s, query);      // ... and issued in shares between the steps
         case 121: return launch<1, 32, 12, TERMS, 1>(a, ws, ws_bytes, s, query);
         case 122: return launch<1, 32, 12, TERMS, 2>(a, ws, ws_bytes, s, query);
         case 41: return launch<1, 32, 4, TERMS, 1>(a, ws, ws_bytes, s, query);
@@ -652,7 +659,6 @@ int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipSt
     switch (var) {
         case VAR_TAPK: return tapk_rows<TERMS, VAR_TAPK>(rows, a, layout, ws, ws_bytes, s, query);
         case VAR_TAPK | VAR_ASM_DMA: return tapk_rows<TERMS, VAR_TAPK | VAR_ASM_DMA>(rows, a, layout, ws, ws_bytes, s, query);
-        case VAR_TAPK | VAR_ASM_DMA | VAR_SPREAD: return tapk_rows<TERMS, VAR_TAPK | VAR_ASM_DMA | VAR_SPREAD>(rows, a, layout, ws, ws_bytes, s, query);
         default: return COALIGN_ERR_UNSUPPORTED;
     }
 }
@@ -663,7 +669,9 @@ constexpr int kLayoutTapMajor = 4;      // COALIGN_LAYOUT_W_TAPMAJOR: flag bit o
 
 #ifdef EMU_TRACE
 static long long *g_emu_trace = nullptr;
+static int g_emu_ablate = 0;
 extern "C" void coalign_conv3x3_emu_set_trace(long long *p) { g_emu_trace = p; }
+extern "C" void coalign_conv3x3_emu_set_ablate(int v) { g_emu_ablate = v; }
 #endif
 
 extern "C" size_t coalign_conv3x3_emu_weight_bytes(int Cin, int Cout, int terms) {
@@ -701,6 +709,11 @@ extern "C" size_t coalign_conv3x3_emu_workspace_bytes_ex(int N, int Cin, int Cou
     return rc == COALIGN_OK && l.split ? l.ws_bytes : 0;
 }
 
+static int emu_prio_mode() {
+    static const int v = getenv("COALIGN_EMU_PRIO") ? atoi(getenv("COALIGN_EMU_PRIO")) : 0;
+    return v;
+}
+
 extern "C" int coalign_conv3x3_emu_bias_act(const float *x, const void *w_split, const float *bias, const float *residual, float *y,
                                             int N, int Cin, int Cout, int H, int W, int relu, int terms, void *workspace,
                                             size_t workspace_bytes, void *stream) {
@@ -711,8 +724,10 @@ extern "C" int coalign_conv3x3_emu_bias_act(const float *x, const void *w_split,
     if (reinterpret_cast<uintptr_t>(w_split) & 15) return COALIGN_ERR_UNSUPPORTED;
     if (N == 0) return COALIGN_OK;
     EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, H, W, nullptr, nullptr};
+    a.prio_mode = emu_prio_mode();
 #ifdef EMU_TRACE
     a.trace = g_emu_trace;
+    a.ablate = g_emu_ablate;
 #endif
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = terms == 3 ? dispatch<3>(a, workspace, workspace_bytes, s, nullptr) : dispatch<2>(a, workspace, workspace_bytes, s, nullptr);
@@ -734,8 +749,10 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
         if ((reinterpret_cast<uintptr_t>(w_split) & 15) || (lay != LAYOUT_NCHW && (reinterpret_cast<uintptr_t>(y) & 15))) return COALIGN_ERR_UNSUPPORTED;
         if (N == 0) return COALIGN_OK;
         EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, Hin, Win, relu, 0, 0, 0, Hin, Win, nullptr, nullptr};
+        a.prio_mode = emu_prio_mode();
 #ifdef EMU_TRACE
         a.trace = g_emu_trace;
+        a.ablate = g_emu_ablate;
 #endif
         hipStream_t s = static_cast<hipStream_t>(stream);
         rc = terms == 3 ? dispatch_tapk<3>(a, lay, workspace, workspace_bytes, s, nullptr) : dispatch_tapk<2>(a, lay, workspace, workspace_bytes, s, nullptr);
@@ -750,8 +767,10 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
         return COALIGN_ERR_UNSUPPORTED;
     if (N == 0) return COALIGN_OK;
     EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, Hin, Win, nullptr, nullptr};
+    a.prio_mode = emu_prio_mode();
 #ifdef EMU_TRACE
     a.trace = g_emu_trace;
+    a.ablate = g_emu_ablate;
 #endif
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = terms == 3 ? dispatch_variant<3>(a, stride, layout, s) : dispatch_variant<2>(a, stride, layout, s);

@@ -39,10 +39,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             out[key] = f"fail: {e}"
     print(json.dumps(out))
 else:
-    # COALIGN_EMU_GEO: 83 = default tap-pair kernel, 84 = + asm-issued weight DMA, 85 = + issue spread over the steps
-    # COALIGN_EMU_TAPK_VAR: 1 = tap-major, 3 = + asm DMA, 7 = + issue spread over the steps; rows: 0 = the dispatch rule (12 / 8)
-    settings = [("pairs", {"TAPK": "0"})] + [(f"pairs_g{g}", {"TAPK": "0", "COALIGN_EMU_GEO": str(g)}) for g in (84, 85)]
-    settings += [(f"tapk_v{v}_r{r}", {"TAPK": "1", "COALIGN_EMU_TAPK_ROWS": str(r), "COALIGN_EMU_TAPK_VAR": str(v)}) for v, r in ((3, 0), (7, 0), (7, 8), (7, 12))]
+    # COALIGN_EMU_GEO: 83 = default tap-pair kernel, 84 = + asm-issued weight DMA
+    # COALIGN_EMU_TAPK_VAR: 1 = tap-major, 3 = + asm DMA; rows: 0 = the dispatch rule (12 / 8)
+    settings = [("pairs", {"TAPK": "0"}), ("pairs_prio", {"TAPK": "0", "COALIGN_EMU_PRIO": "1"}), ("pairs_g84_prio", {"TAPK": "0", "COALIGN_EMU_GEO": "84", "COALIGN_EMU_PRIO": "1"})]
+    settings += [(f"tapk_v{v}_r{r}", {"TAPK": "1", "COALIGN_EMU_TAPK_ROWS": str(r), "COALIGN_EMU_TAPK_VAR": str(v)}) for v, r in ((3, 0),)]
     if os.environ.get("SETTINGS"):
         settings = [x for x in settings if x[0] in os.environ["SETTINGS"].split(",")]
     rows = {}
@@ -61,12 +61,12 @@ else:
     envs = dict(settings)
     best = min((n for n in score if n.startswith("tapk")), key=score.get, default=None)
     bestp = min((n for n in score if n.startswith("pairs_")), key=score.get, default=None)
-    runs = [("pairs", {})] + ([(bestp, {k: v for k, v in envs[bestp].items() if k != "TAPK"})] if bestp else [])
+    runs = [("pairs", {"COALIGN_EMU_TAPK": "0"})] + ([(bestp, {"COALIGN_EMU_TAPK": "0", **{k: v for k, v in envs[bestp].items() if k != "TAPK"}})] if bestp else [])
     if best:
         runs.append((best, {"COALIGN_EMU_TAPK": "1", **{k: v for k, v in envs[best].items() if k != "TAPK"}}))
         mixed = {k: min((n for n in score if n.startswith("tapk")), key=lambda n: rows[n][k]["us"]) for k in weight}
         print("best tap-major setting per shape:", mixed)
-    for name, env in runs + [("pairs", {})]:
+    for name, env in runs + [("pairs", {"COALIGN_EMU_TAPK": "0"})]:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-side-modes"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=400)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if line:

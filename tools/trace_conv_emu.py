@@ -61,3 +61,22 @@ for wv in (0, nw - 1):
         nxt = t[wv, c + 1][0] if c + 1 < 64 and t[wv, c + 1][0] else s[6]
         d = [int(s[k + 1] - s[k]) for k in range(6)] + [int(nxt - s[6])]
         print("   %3d %s | %7d" % (c, " ".join("%7d" % v for v in d), int(nxt - s[0])))
+# what each part of an interval costs: kernel time with the weight DMA / the halo-pixel loads / the matrix steps switched off
+L.coalign_conv3x3_emu_set_ablate.argtypes = [ctypes.c_int]
+L.coalign_conv3x3_emu_set_trace(None)
+def run():
+    return L.coalign_conv3x3_emu_ex(x.data_ptr(), ws.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(), N, Ci, Co, H, W, 1, 1, terms, layout,
+                                    scratch.data_ptr(), scratch.numel(), None)
+tr.zero_()
+L.coalign_conv3x3_emu_set_trace(ctypes.c_void_p(tr.data_ptr()))
+out = {}
+for ab, name in ((0, "all"), (1, "no weight DMA"), (2, "no pixel loads"), (3, "no DMA, no loads"), (4, "no matrix steps"), (7, "barriers + split only")):
+    L.coalign_conv3x3_emu_set_ablate(ab)
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(10): run()
+    e.record(); torch.cuda.synchronize()
+    out[name] = round(s.elapsed_time(e) * 100, 1)
+print("kernel us by ablation (trace stamps on):", out)
