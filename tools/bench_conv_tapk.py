@@ -41,7 +41,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 else:
     # COALIGN_EMU_GEO: 83 = default tap-pair kernel, 84 = + asm-issued weight DMA
     # COALIGN_EMU_TAPK_VAR: 1 = tap-major, 3 = + asm DMA; rows: 0 = the dispatch rule (12 / 8)
-    settings = [("pairs", {"TAPK": "0"}), ("pairs_prio", {"TAPK": "0", "COALIGN_EMU_PRIO": "1"}), ("pairs_g84_prio", {"TAPK": "0", "COALIGN_EMU_GEO": "84", "COALIGN_EMU_PRIO": "1"})]
+    settings = [("pairs", {"TAPK": "0"}), ("pairs_pc", {"TAPK": "0", "COALIGN_EMU_PC": "1"}), ("pairs_pc8", {"TAPK": "0", "COALIGN_EMU_PC": "1", "COALIGN_EMU_PC_ROWS": "8"}),
+                ("pairs_pc12", {"TAPK": "0", "COALIGN_EMU_PC": "1", "COALIGN_EMU_PC_ROWS": "12"})]
     settings += [(f"tapk_v{v}_r{r}", {"TAPK": "1", "COALIGN_EMU_TAPK_ROWS": str(r), "COALIGN_EMU_TAPK_VAR": str(v)}) for v, r in ((3, 0),)]
     if os.environ.get("SETTINGS"):
         settings = [x for x in settings if x[0] in os.environ["SETTINGS"].split(",")]

@@ -44,23 +44,26 @@ for _ in range(3):
                                   scratch.data_ptr(), scratch.numel(), None)
     torch.cuda.synchronize()
 assert rc == 0, rc
-nw = int(os.environ.get("WAVES", 8))
-span = tr.cpu()[2 * waves * 64 * S:].view(-1, 2)
-span = span[span[:, 1] > 0]
-t0 = int(span[:, 0].min())
-st, en = (span[:, 0] - t0).float() / 100.0, (span[:, 1] - t0).float() / 100.0          # us
-print(f"{'tap-major' if tapk else 'tap pairs'} {N}x{Ci}->{Co} {H}x{W} terms {terms} residual {res is not None}: {len(span)} workgroups: start  min {st.min():.1f} median {st.median():.1f} max {st.max():.1f} us;"
-      f"  end  min {en.min():.1f} median {en.median():.1f} max {en.max():.1f} us")
-print("  per-workgroup duration: min %.1f median %.1f max %.1f us" % ((en - st).min(), (en - st).median(), (en - st).max()))
-t = tr.cpu()[: 2 * waves * 64 * S].view(-1)[: nw * 64 * S].reshape(nw, 64, S)        # workgroup 0
-for wv in (0, nw - 1):
-    print(f"workgroup 0 wave {wv}: interval    wait    barA   issue   steps    barB   store     gap | total (clocks)")
-    for c in range(20):
-        s = t[wv, c]
-        if s[6] == 0: break
-        nxt = t[wv, c + 1][0] if c + 1 < 64 and t[wv, c + 1][0] else s[6]
-        d = [int(s[k + 1] - s[k]) for k in range(6)] + [int(nxt - s[6])]
-        print("   %3d %s | %7d" % (c, " ".join("%7d" % v for v in d), int(nxt - s[0])))
+if not os.environ.get("COALIGN_EMU_PC"):        # (the producer / consumer kernel records no stamps)
+    nw = int(os.environ.get("WAVES", 8))
+    span = tr.cpu()[2 * waves * 64 * S:].view(-1, 2)
+    span = span[span[:, 1] > 0]
+    t0 = int(span[:, 0].min())
+    st, en = (span[:, 0] - t0).float() / 100.0, (span[:, 1] - t0).float() / 100.0          # us
+    print(f"{'tap-major' if tapk else 'tap pairs'} {N}x{Ci}->{Co} {H}x{W} terms {terms} residual {res is not None}: {len(span)} workgroups: start  min {st.min():.1f} median {st.median():.1f} max {st.max():.1f} us;"
+          f"  end  min {en.min():.1f} median {en.median():.1f} max {en.max():.1f} us")
+    print("  per-workgroup duration: min %.1f median %.1f max %.1f us" % ((en - st).min(), (en - st).median(), (en - st).max()))
+    t = tr.cpu()[: 2 * waves * 64 * S].view(-1)[: nw * 64 * S].reshape(nw, 64, S)        # workgroup 0
+    for wv in (0, nw - 1):
+        print(f"workgroup 0 wave {wv}: interval    wait    barA   issue   steps    barB   store     gap | total (clocks)")
+        for c in range(20):
+            s = t[wv, c]
+            if s[6] == 0: break
+            nxt = t[wv, c + 1][0] if c + 1 < 64 and t[wv, c + 1][0] else s[6]
+            d = [int(s[k + 1] - s[k]) for k in range(6)] + [int(nxt - s[6])]
+            print("   %3d %s | %7d" % (c, " ".join("%7d" % v for v in d), int(nxt - s[0])))
+else:
+    print(f"producer / consumer kernel {N}x{Ci}->{Co} {H}x{W} terms {terms} residual {res is not None}")
 # what each part of an interval costs: kernel time with the weight DMA / the halo-pixel loads / the matrix steps switched off
 L.coalign_conv3x3_emu_set_ablate.argtypes = [ctypes.c_int]
 L.coalign_conv3x3_emu_set_trace(None)
@@ -70,7 +73,8 @@ def run():
 tr.zero_()
 L.coalign_conv3x3_emu_set_trace(ctypes.c_void_p(tr.data_ptr()))
 out = {}
-for ab, name in ((0, "all"), (1, "no weight DMA"), (2, "no pixel loads"), (3, "no DMA, no loads"), (4, "no matrix steps"), (7, "barriers + split only")):
+for ab, name in ((0, "all"), (1, "no weight DMA"), (2, "no pixel loads"), (3, "no DMA, no loads"), (4, "no matrix steps"), (7, "barriers + split only"),
+                 (8, "no tile start / epilogue (pc kernel)"), (11, "steps + barriers only (pc kernel)"), (15, "barriers only (pc kernel)")):
     L.coalign_conv3x3_emu_set_ablate(ab)
     for _ in range(3): run()
     torch.cuda.synchronize()
