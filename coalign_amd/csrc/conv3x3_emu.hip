@@ -611,28 +611,31 @@ __global__ __launch_bounds__(64 * (NC + 4)) void conv3x3_emu_pc_kernel(const Emu
         const bool live = gy < a.H && gx < a.W;
         const bool wave_live = __builtin_amdgcn_readfirstlane((int)(cur.y0 + py < a.H)) != 0;
         const size_t obase = ((size_t)cur.n * a.Cout + cur.cg * kCoutTile + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
-        const float *bias = a.bias + cur.cg * kCoutTile + 4 * half;
-        floatx16 acc[2];
-#ifdef EMU_TRACE
-        if (!wave_live || (a.ablate & 8)) {
-#else
-        if (!wave_live) {
-#endif
-            acc[0] = floatx16{0};
-            acc[1] = floatx16{0};
-        } else if (a.residual) {
-#pragma unroll
-            for (int q = 0; q < 32; ++q) {
-                const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
-                acc[q / 16][q % 16] = a.residual[obase + (size_t)c * plane] + bias[c];
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 32; ++q) acc[q / 16][q % 16] = bias[(q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4)];
-        }
+        // Tile start and end without exposed memory latency: the accumulators start at zero; the residual values are requested at the
+        // start of the tile's LAST interval (32 registers, in flight beside its matrix steps) and added in the epilogue together with
+        // the bias, which comes through scalar loads (constant address space + wave-uniform address; two candidates per accumulator,
+        // selected by the lane half).  The stores of a tile then drain behind the next tile's matrix steps: nothing in the next
+        // intervals waits on the vector-memory counter.
+        typedef const __attribute__((address_space(4))) float *cfloat_t;
+        const cfloat_t bias_s = (cfloat_t)(uintptr_t)(a.bias + cur.cg * kCoutTile);
+        floatx16 acc[2] = {floatx16{0}, floatx16{0}};
+        float rv[32];
         for (int chunk = 0; chunk < chunks; ++chunk, ++L) {
             __syncthreads();
             if (!wave_live) continue;
+            if (chunk == chunks - 1) {
+#ifdef EMU_TRACE
+                if (a.residual && !(a.ablate & 8)) {
+#else
+                if (a.residual) {
+#endif
+#pragma unroll
+                    for (int q = 0; q < 32; ++q) rv[q] = a.residual[obase + (size_t)((q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4)) * plane];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 32; ++q) rv[q] = 0.f;
+                }
+            }
 #ifdef EMU_TRACE
             if (a.ablate & 4) continue;
 #endif
@@ -677,6 +680,14 @@ __global__ __launch_bounds__(64 * (NC + 4)) void conv3x3_emu_pc_kernel(const Emu
                         for (int q = 0; q < 2; ++q) wc[q][t] = wn[q][t];
                     }
                 }
+            }
+        }
+        if (wave_live) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
+                const float b0 = bias_s[c], b1 = bias_s[c + 4];
+                acc[q / 16][q % 16] += rv[q] + (half ? b1 : b0);
             }
         }
 #ifdef EMU_TRACE
