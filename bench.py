@@ -221,8 +221,9 @@ def main():
             gb, gr = torch.randn(64, device=dev), torch.randn(N, 64, ny // 2, nx // 2, device=dev)
             gw = ops.pack_conv3x3_weight(gwt)
             iso["conv_f32_ms"] = hip_time(lambda: ops.conv3x3_bias_act(gx, gw, gb, gr, True))
-            for terms in (3, 2):
-                gws = ops.pack_conv3x3_emu_weight(gwt, terms)
+            from coalign_amd import backbone as _bb
+            for terms in (3, 2):       # the weight image the detector uses (tap-major by default: backbone.CONV_EMU_TAP_MAJOR)
+                gws = ops.pack_conv3x3_emu_weight(gwt, terms, _bb.CONV_EMU_TAP_MAJOR)
                 iso[f"conv_bf16x{terms}_ms"] = hip_time(lambda: ops.conv3x3_emu_bias_act(gx, gws, gb, 64, gr, True, terms))
             del gx, gwt, gb, gr, gw
             try:

@@ -716,6 +716,10 @@ __global__ __launch_bounds__(64 * (NC + 4)) void conv3x3_emu_pc_kernel(const Emu
     }
 }
 
+// (A producer / consumer kernel on the TAP-MAJOR image -- 16-channel intervals, weights staged in two halves through a ring of three 30 KB
+// buffers, one barrier per half, 8 + 4 wavefronts, 157 KB -- was written and measured: correct, 139 vs 85 us on the 64-channel layer (85
+// spilled registers at the 168-register budget of 12 wavefronts, twice the barriers).  Removed; profiles/round2/experiments.)
+
 struct Launch {                    // what the host needs to know about one (shape, geometry) pair
     int grid;
     size_t flag_bytes, ws_bytes;

@@ -357,3 +357,41 @@ def test_normalize_pairwise_kernel_is_bit_identical_to_the_tensor_expression(gol
     gen = torch.Generator().manual_seed(1)
     big = torch.randn(3, 8, 8, 4, 4, generator=gen, dtype=torch.float64) * 50
     assert torch.equal(normalize_pairwise_tfm(big.to(DEV), 240, 240, 0.4, 2).cpu(), normalize_pairwise_tfm(big, 240, 240, 0.4, 2))
+
+
+# ------------------------------------------------------------------------------------------------ convolution kernel variants (opt-in)
+_VARIANT_CHECK = r"""
+import sys, torch
+import torch.nn.functional as F
+from coalign_amd import ops
+worst = 0.0
+for (N, Ci, Co, H, W) in ((2, 64, 64, 100, 352), (3, 128, 128, 50, 176), (2, 256, 256, 25, 88), (1, 16, 64, 9, 63), (1, 384, 256, 36, 96)):
+    g = torch.Generator().manual_seed(N + Ci + H)
+    x = torch.randn(N, Ci, H, W, generator=g).cuda(); w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).cuda()
+    b = torch.randn(Co, generator=g).cuda(); r = torch.randn(N, Co, H, W, generator=g).cuda()
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    for tap_major in (False, True):
+        ws = ops.pack_conv3x3_emu_weight(w, 3, tap_major)
+        for res, relu in ((None, False), (r, True)):
+            want = ref if res is None else ref + res.double()
+            want = torch.relu(want) if relu else want
+            for cl in (False, True):
+                got = ops.conv3x3_emu_bias_act(x, ws, b, Co, res, relu, 3, out_channels_last=cl)
+                worst = max(worst, float((got.double() - want).abs().max() / want.abs().max()))
+        assert torch.equal(ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, 3), ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, 3))
+print("WORST", worst)
+sys.exit(0 if worst <= 5e-6 else 1)
+"""
+
+
+@pytest.mark.parametrize("env", [{"COALIGN_EMU_PC": "1"}, {"COALIGN_EMU_PC": "1", "COALIGN_EMU_PC_ROWS": "12"}, {"COALIGN_EMU_GEO": "84"}, {"COALIGN_EMU_TAPK_VAR": "1"},
+                                 {"COALIGN_EMU_TAPK_ROWS": "8"}, {"COALIGN_EMU_TAPK_ROWS": "12"}, {"COALIGN_EMU_PRIO": "1"}])
+def test_conv3x3_emu_kernel_variants_in_a_subprocess(env):
+    """The kernel variants of the split-bf16 convolution that an environment switch selects at library load (the producer / consumer
+    kernel, the asm-issued weight DMA on the tap-pair image, the tap-major image with the builtin DMA or a forced tile height, the strict
+    inter-workgroup priority): each against the fp64 convolution (5e-6 of the output scale) in its own process, both weight images,
+    NCHW and channels-last output, residual / ReLU, ragged maps, determinism."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _VARIANT_CHECK], env=dict(os.environ, PYTHONPATH=root, **env), capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])

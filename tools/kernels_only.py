@@ -29,7 +29,8 @@ bn = (pfn.norm.weight, pfn.norm.bias, pfn.norm.running_mean, pfn.norm.running_va
 margs = h["model"]["args"]
 wconv = torch.randn(64, 64, 3, 3, generator=g).to(dev) / 24.0
 wp, bconv, rconv = ops.pack_conv3x3_weight(wconv), torch.randn(64, generator=g).to(dev), torch.randn(N, 64, 100, 352, generator=g).to(dev)
-wsplit = {t: ops.pack_conv3x3_emu_weight(wconv, t) for t in (3, 2)}
+wsplit = {t: ops.pack_conv3x3_emu_weight(wconv, t) for t in (3, 2)}                   # tap pairs: the strided layers, the 2-way split
+wtapm = ops.pack_conv3x3_emu_weight(wconv, 3, True)                                   # tap-major: the detector's stride-1 layers (default)
 canvas_cl = torch.randn(N, 64, 200, 704, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
 wt = torch.randn(256, 128, 4, 4, generator=g).to(dev) / 16.0
 wtp = ops.pack_pointwise_weight(wt, True)
@@ -51,9 +52,10 @@ OPS = {
     "fuse_nchw_C256": lambda: ops.warp_fuse(xs[2], theta, [N], ops.FUSE_ATT),
     "fuse_nhwc_3scales": lambda: ops.warp_fuse_nhwc(xcl, theta, ops.FUSE_ATT),
     "conv_f32_64ch": lambda: ops.conv3x3_bias_act(xs[0], wp, bconv, rconv, True),
-    "conv_bf16x3_64ch": lambda: ops.conv3x3_emu_bias_act(xs[0], wsplit[3], bconv, 64, rconv, True, 3),
+    "conv_bf16x3_64ch": lambda: ops.conv3x3_emu_bias_act(xs[0], wtapm, bconv, 64, rconv, True, 3),
+    "conv_bf16x3_64ch_tap_pairs": lambda: ops.conv3x3_emu_bias_act(xs[0], wsplit[3], bconv, 64, rconv, True, 3),
     "conv_bf16x2_64ch": lambda: ops.conv3x3_emu_bias_act(xs[0], wsplit[2], bconv, 64, rconv, True, 2),
-    "conv_bf16x3_64ch_nhwc_out": lambda: ops.conv3x3_emu_bias_act(xs[0], wsplit[3], bconv, 64, rconv, True, 3, out_channels_last=True),
+    "conv_bf16x3_64ch_nhwc_out": lambda: ops.conv3x3_emu_bias_act(xs[0], wtapm, bconv, 64, rconv, True, 3, out_channels_last=True),
     "conv_bf16x3_s2_canvas_nhwc_in": lambda: ops.conv3x3_emu_bias_act(canvas_cl, wsplit[3], bconv, 64, None, True, 3, stride=2),
     "pointwise_up4": lambda: ops.pointwise_conv(xs[2][:1], wtp, bconv.repeat(2), 128, up=4),
 }
