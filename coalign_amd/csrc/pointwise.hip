@@ -9,23 +9,25 @@
 // MIOpen serves these through NHWC implicit-GEMM / rocBLAS kernels wrapped in NCHW<->NHWC transposes, a col2im pass and a
 // separate bias / ReLU pass (profiles/round1: ~0.4 ms per frame for 5.3 GFLOP); here each is a single launch.
 //
-// A workgroup (4 wavefronts) owns 32 GEMM pixels and up to 256 GEMM rows (m = co * k * k + ky * k + kx); it stages the X tile
+// A workgroup (4 wavefronts) owns 32 GEMM pixels and up to 256 GEMM rows (m = co * k * k + ky * k + kx) -- or, for layers with <= 128 / <= 64
+// rows, 64 / 128 pixels and 128 / 64 rows, so that no wavefront idles --; it stages the X tile
 // [Cin x 32 pixels] in LDS once, each wavefront keeps two 32 x 32 accumulator tiles and streams its weight rows from L2
 // (the weight layout [Cin][M] of ConvTranspose2d is already the A operand: 32 consecutive m for one input channel).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMaxCin = 256;
-constexpr int kRowsPerWg = 256;       // GEMM rows per workgroup: 8 tiles of 32, two per wavefront
 
 struct PwArgs {
     const float *__restrict__ x, *__restrict__ w, *__restrict__ bias;
     float *__restrict__ y;
     int N, Cin, Hin, Win, in_stride, Hp, Wp, M, up, Cout, Ctot, c_off, relu;
     int in_nhwc;          // x is [N, Hin, Win, Cin] (channels-last: the fused maps / stage outputs of the NHWC route)
+    int pb;               // pixel blocks of 32 per workgroup: 1, 2 or 4 (see the kernel)
 };
 
 template <int UP>
@@ -33,48 +35,56 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
     __shared__ float xt[kMaxCin * 32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, p = lane & 31;
     const int pixels = a.Hp * a.Wp;
-    const int p0 = blockIdx.x * 32, n = blockIdx.z;
-    const int m_base = blockIdx.y * kRowsPerWg;
+    // PB pixel blocks of 32 per workgroup: a layer with few GEMM rows (M <= 64: one wavefront's two tiles; <= 128: two wavefronts) would
+    // leave three (two) of the four wavefronts idle after the staging -- they take further pixel blocks instead (a.pb in {1, 2, 4},
+    // Cin * 32 * pb floats of LDS)
+    const int PB = a.pb, WPB = 4 / PB;                    // wavefronts per pixel block = row tiles of 64 per workgroup
+    const int TP = 32 * PB;                               // pixels per workgroup
+    const int p0 = blockIdx.x * TP, n = blockIdx.z;
+    const int m_base = blockIdx.y * (64 * WPB);
     const size_t in_plane = (size_t)a.Hin * a.Win;
     const float *xin = a.x + (size_t)n * a.Cin * in_plane;
-    // stage X[ci][32 pixels]: thread t loads pixel t % 32 of channels t / 32, t / 32 + 8, ...
+    // stage X[ci][TP pixels]: thread t loads pixel t % TP of channels t / TP, t / TP + 256 / TP, ...
     {
-        const int px = p0 + (tid & 31);
+        const int pl = tid & (TP - 1), c0 = tid / TP, cstep = 256 / TP;
+        const int px = p0 + pl;
         const bool ok = px < pixels;
         const int hp = ok ? px / a.Wp : 0, wp = ok ? px - hp * a.Wp : 0;
         const size_t off = (size_t)(hp * a.in_stride) * a.Win + (size_t)wp * a.in_stride;
-        if (a.in_nhwc) {       // a pixel's channels are contiguous: 16 B per lane, thread t takes channel quads t / 32, t / 32 + 8, ...
+        if (a.in_nhwc) {       // a pixel's channels are contiguous: 16 B per lane, thread t takes channel quads c0, c0 + cstep, ...
             const float4 *xp = reinterpret_cast<const float4 *>(xin + off * a.Cin);
-            for (int c4 = tid >> 5; c4 < (a.Cin >> 2); c4 += 8) {
+            for (int c4 = c0; c4 < (a.Cin >> 2); c4 += cstep) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ok) v = xp[c4];
-                xt[(4 * c4) * 32 + (tid & 31)] = v.x; xt[(4 * c4 + 1) * 32 + (tid & 31)] = v.y;
-                xt[(4 * c4 + 2) * 32 + (tid & 31)] = v.z; xt[(4 * c4 + 3) * 32 + (tid & 31)] = v.w;
+                xt[(4 * c4) * TP + pl] = v.x; xt[(4 * c4 + 1) * TP + pl] = v.y;
+                xt[(4 * c4 + 2) * TP + pl] = v.z; xt[(4 * c4 + 3) * TP + pl] = v.w;
             }
         } else {
-            for (int ci = tid >> 5; ci < a.Cin; ci += 8) {
+            for (int ci = c0; ci < a.Cin; ci += cstep) {
                 const float v = xin[(size_t)ci * in_plane + off];
-                xt[ci * 32 + (tid & 31)] = ok ? v : 0.f;
+                xt[ci * TP + pl] = ok ? v : 0.f;
             }
         }
     }
     __syncthreads();
-    // this wavefront's two m-tiles
-    const int m0 = m_base + wave * 64;
+    // this wavefront's pixel block and its two m-tiles
+    const int pbk = wave / WPB, rt = wave - pbk * WPB;
+    const int m0 = m_base + rt * 64;
     if (m0 >= a.M) return;
     const bool second = m0 + 32 < a.M;
     floatx16 acc0 = {0}, acc1 = {0};
     const float *w0 = a.w + m0 + p;
+    const float *xb = xt + pbk * 32 + p;
 #pragma unroll 8
     for (int k0 = 0; k0 < a.Cin; k0 += 2) {
-        const float b = xt[(k0 + half) * 32 + p];
+        const float b = xb[(k0 + half) * TP];
         const float a0 = w0[(size_t)(k0 + half) * a.M];
         const float a1 = second ? w0[(size_t)(k0 + half) * a.M + 32] : 0.f;
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
     }
     // epilogue: accumulator r of lane l is GEMM row 8 * (r / 4) + 4 * (l / 32) + r % 4 of its tile, pixel l % 32
-    const int px = p0 + p;
+    const int px = p0 + pbk * 32 + p;
     if (px >= pixels) return;
     const int hp = px / a.Wp, wp = px - hp * a.Wp;
     const int Ho = a.Hp * UP, Wo = a.Wp * UP;
@@ -138,12 +148,16 @@ extern "C" int coalign_pointwise_conv_ex(const float *x, const float *w, const f
     const int M = Cout * up * up;
     if (M_padded < M || M_padded % 32 || (up != 1 && M_padded != M)) return COALIGN_ERR_BAD_SHAPE;
     if (N == 0) return COALIGN_OK;
-    PwArgs a{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu, in_nhwc != 0};
+    PwArgs a{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu, in_nhwc != 0, 1};
     if (N > 65535) return COALIGN_ERR_UNSUPPORTED;
     const int pixels = a.Hp * a.Wp;
+    static const int pb_max = getenv("COALIGN_PW_PB") ? atoi(getenv("COALIGN_PW_PB")) : 4;      // experiments: 1 = the round-1 mapping
+    a.pb = M_padded <= 64 ? 4 : M_padded <= 128 ? 2 : 1;
+    while (a.pb > 1 && (a.pb > pb_max || Cin * 32 * a.pb > kMaxCin * 32)) a.pb >>= 1;
     if (up == 4 && ((a.Wp * 4) % 4 || (reinterpret_cast<uintptr_t>(y) & 15))) return COALIGN_ERR_UNSUPPORTED;
     if (up == 2 && (reinterpret_cast<uintptr_t>(y) & 7)) return COALIGN_ERR_UNSUPPORTED;
-    const dim3 grid((pixels + 31) / 32, (M_padded + kRowsPerWg - 1) / kRowsPerWg, N);
+    const int rows_per_wg = 64 * (4 / a.pb), px_per_wg = 32 * a.pb;
+    const dim3 grid((pixels + px_per_wg - 1) / px_per_wg, (M_padded + rows_per_wg - 1) / rows_per_wg, N);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (up == 4) hipLaunchKernelGGL(pointwise_kernel<4>, grid, dim3(256), 0, s, a);
     else if (up == 2) hipLaunchKernelGGL(pointwise_kernel<2>, grid, dim3(256), 0, s, a);
