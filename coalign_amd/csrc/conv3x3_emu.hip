@@ -943,24 +943,25 @@ int dispatch(const EmuArgs &a, void *ws, size_t ws_bytes, hipStream_t s, Launch 
 
 // Tap-major weight image (TAPK, "K = 144"): 16-channel intervals of nine steps, one workgroup per CU (111 KB of weights + one split
 // patch).  Output rows per workgroup = wavefronts: 8 (143 KB), 10 (150 KB) or 12 (156 KB) with the 3-way split.
-template <int TERMS, int ROWS, int VAR>
+template <int TERMS, int BH, int BW, int NPB, int VAR>
 int tapk_launch(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipStream_t s, Launch *query) {
     if (layout == LAYOUT_OUT_NHWC) {
         if (query) {
             *query = Launch{0, 0, 0, false};
             return COALIGN_OK;
         }
-        return launch_variant<1, 32, ROWS, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, VAR>(a, s);
+        return launch_variant<BH, BW, NPB, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, VAR>(a, s);
     }
     if (layout != LAYOUT_NCHW) return COALIGN_ERR_UNSUPPORTED;
-    return launch<1, 32, ROWS, TERMS, 2, 1, VAR>(a, ws, ws_bytes, s, query);
+    return launch<BH, BW, NPB, TERMS, 2, 1, VAR>(a, ws, ws_bytes, s, query);
 }
 
 template <int TERMS, int VAR>
 int tapk_rows(int rows, const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipStream_t s, Launch *query) {
     switch (rows) {
-        case 8: return tapk_launch<TERMS, 8, VAR>(a, layout, ws, ws_bytes, s, query);
-        case 12: return tapk_launch<TERMS, 12, VAR>(a, layout, ws, ws_bytes, s, query);
+        case 8: return tapk_launch<TERMS, 1, 32, 8, VAR>(a, layout, ws, ws_bytes, s, query);
+        case 12: return tapk_launch<TERMS, 1, 32, 12, VAR>(a, layout, ws, ws_bytes, s, query);
+        case 26: return tapk_launch<TERMS, 2, 16, 13, VAR>(a, layout, ws, ws_bytes, s, query);       // 13 wavefronts x (2 rows x 16 pixels): 26 x 16 tiles
         default: return COALIGN_ERR_UNSUPPORTED;
     }
 }
@@ -971,8 +972,11 @@ int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipSt
     static const int var = getenv("COALIGN_EMU_TAPK_VAR") ? atoi(getenv("COALIGN_EMU_TAPK_VAR")) : (VAR_TAPK | VAR_ASM_DMA);
     if (a.Cin % (2 * kKC)) return COALIGN_ERR_UNSUPPORTED;
     // measured per layer (tools/bench_conv_tapk.py): 12 rows on the 100-row maps (495 tiles = two full rounds of 256 workgroups), 8 rows
-    // on the 50- and 25-row maps; 10 rows lose everywhere but on the shrink header (-1 %)
-    const int rows = force ? force : (a.H >= 64 ? 12 : 8);
+    // on the 25-row maps; 10 rows lose everywhere but on the shrink header (-1 %)
+    // 50 x 176 maps (W a multiple of 16, not of 32): 13 wavefronts of 2 rows x 16 pixels = 26 x 16 tiles cover the map exactly (220 tiles =
+    // ONE round; 8 x 32 tiles: 420 = 1.6 rounds, 9 % dead columns): 95 vs 108 us per layer
+    static const int t26 = getenv("COALIGN_EMU_TAPK_26") ? atoi(getenv("COALIGN_EMU_TAPK_26")) : 1;
+    const int rows = force ? force : (t26 && a.W % 32 == 16 && a.H > 26 && a.H <= 52) ? 26 : (a.H >= 64 ? 12 : 8);
     switch (var) {
         case VAR_TAPK: return tapk_rows<TERMS, VAR_TAPK>(rows, a, layout, ws, ws_bytes, s, query);
         case VAR_TAPK | VAR_ASM_DMA: return tapk_rows<TERMS, VAR_TAPK | VAR_ASM_DMA>(rows, a, layout, ws, ws_bytes, s, query);

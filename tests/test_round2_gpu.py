@@ -385,7 +385,7 @@ sys.exit(0 if worst <= 5e-6 else 1)
 
 
 @pytest.mark.parametrize("env", [{"COALIGN_EMU_PC": "1"}, {"COALIGN_EMU_PC": "1", "COALIGN_EMU_PC_ROWS": "12"}, {"COALIGN_EMU_GEO": "84"}, {"COALIGN_EMU_TAPK_VAR": "1"},
-                                 {"COALIGN_EMU_TAPK_ROWS": "8"}, {"COALIGN_EMU_TAPK_ROWS": "12"}, {"COALIGN_EMU_PRIO": "1"}])
+                                 {"COALIGN_EMU_TAPK_ROWS": "8"}, {"COALIGN_EMU_TAPK_ROWS": "12"}, {"COALIGN_EMU_TAPK_ROWS": "26"}, {"COALIGN_EMU_TAPK_26": "0"}, {"COALIGN_EMU_PRIO": "1"}])
 def test_conv3x3_emu_kernel_variants_in_a_subprocess(env):
     """The kernel variants of the split-bf16 convolution that an environment switch selects at library load (the producer / consumer
     kernel, the asm-issued weight DMA on the tap-pair image, the tap-major image with the builtin DMA or a forced tile height, the strict
