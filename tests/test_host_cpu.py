@@ -265,6 +265,34 @@ def test_split_bf16_weight_image_layout_and_exactness():
     assert hip.lib().coalign_conv3x3_emu_weight_bytes(16, 128, 4) == 0
 
 
+def test_split_bf16_tap_major_weight_image_layout_and_exactness():
+    """The tap-major image (COALIGN_LAYOUT_W_TAPMAJOR, the detector's stride-1 layers): [Cout/64][Cin/16][9 taps][terms][2 channel halves]
+    [64][8] bf16 + 16 zero bytes -- no zero tap, so 9/10 of the tap-pair image; the 3-way terms add up to the fp32 weight exactly; Cin must be
+    a multiple of 16; the size functions of the C ABI agree with the packer."""
+    from coalign_amd import hip, ops
+    L = hip.lib()
+    gen = torch.Generator().manual_seed(6)
+    w = torch.randn(128, 32, 3, 3, generator=gen) * torch.logspace(-3, 3, 128).view(-1, 1, 1, 1)
+    for terms in (3, 2):
+        img = ops.pack_conv3x3_emu_weight(w, terms, tap_major=True)
+        assert img.dtype == torch.uint8 and img.numel() == L.coalign_conv3x3_emu_weight_bytes_ex(32, 128, terms, 1)
+        assert (img.numel() - 16) * 10 == (L.coalign_conv3x3_emu_weight_bytes(32, 128, terms) - 16) * 9
+        assert L.coalign_conv3x3_emu_weight_bytes_ex(32, 128, terms, 0) == L.coalign_conv3x3_emu_weight_bytes(32, 128, terms)
+        assert int(img[-16:].sum()) == 0
+        t = img[:-16].view(torch.bfloat16).reshape(2, 2, 9, terms, 2, 64, 8).double()          # [g, interval, tap, term, half, cout, cin]
+        total = t.sum(dim=3)                                                                    # [g, interval, tap, half, cout, cin]
+        got = total.permute(0, 4, 1, 3, 5, 2).reshape(128, 32, 9)                               # [cout, cin = 16 * interval + 8 * half + i, tap]
+        want = w.reshape(128, 32, 9).double()
+        if terms == 3:
+            assert torch.equal(got, want)
+        else:
+            assert float(((got - want).abs() / want.abs().clamp_min(1e-30)).max()) <= 2.0 ** -16
+    with pytest.raises(ValueError):
+        ops.pack_conv3x3_emu_weight(torch.zeros(64, 24, 3, 3), 3, tap_major=True)              # Cin % 16
+    assert L.coalign_conv3x3_emu_weight_bytes_ex(24, 64, 3, 1) == 0
+    assert L.coalign_conv3x3_emu_workspace_bytes_ex(0, 64, 64, 100, 352, 3, 4) == 0             # nothing to do, no device needed
+
+
 def test_pipeline_helpers_on_cpu():
     """pad_pillars (pure tensor code) and the pipeline's refusal to run without the GPU (no CPU fallback anywhere in the product)."""
     from coalign_amd.pipeline import FramePipeline, pad_pillars
