@@ -1,6 +1,6 @@
 // 3x3 / pad 1 convolution (stride 1 or 2) with fused bias (+ residual) (+ ReLU), fp32 in / fp32 out, computed on the BF16 matrix
 // cores by error-free operand splitting ("fp32 emulation"), gfx950.  The 3-way split is the product default (COALIGN_CONV_EMU,
-// backbone.py); NCHW in and out by default, optionally channels-last (NHWC) on the input or the output side (LAYOUT): the last
+// backbone.py) for every 3x3 convolution of the detector; NCHW in and out by default, optionally channels-last (NHWC) on the input or the output side (LAYOUT): the last
 // convolution of a ResNet stage writes its map channels-last for the fusion kernel and the next stage's strided convolution reads it.
 //
 // Same layers and semantics as conv3x3.hip (opencood/models/sub_modules/resblock.py:53-69, base_bev_backbone_resnet.py:59-138,
@@ -13,9 +13,13 @@
 // i.e. 6 (or 3) bf16 MFMAs replace 8 fp32 MFMAs of the same K: 2.7x (5.3x) less matrix-pipe time.  The weights are split on the
 // host once; the input pixels are split in registers, once per pixel and chunk (v_cvt_pk_bf16_f32 + exact subtractions).
 //
-// GEMM view per image:  D[cout, pixel] = sum_{cin, tap} W[cout, cin, tap] * X[cin, pixel + tap].  One MFMA has K = 16 = two taps
-// x the 8 input channels of a chunk: lanes 0-31 (k 0..7) carry tap 2s, lanes 32-63 (k 8..15) tap 2s + 1, s = 0..4 (the tenth tap
-// is zero weights).  A workgroup (8 or 12 wavefronts) owns 8 / 12 row segments of 32 pixels and 64 output channels; persistent
+// GEMM view per image:  D[cout, pixel] = sum_{cin, tap} W[cout, cin, tap] * X[cin, pixel + tap].  Two weight images:
+//   * tap-major (the detector's stride-1 layers, COALIGN_LAYOUT_W_TAPMAJOR, template bit VAR_TAPK): one MFMA has K = 16 = the 16 input
+//     channels of ONE tap (lanes 0-31 channels 0-7, lanes 32-63 channels 8-15), nine per 16-channel interval, no zero tap; one
+//     workgroup per CU (111 KB of double-buffered weights + one 16-channel split patch);
+//   * tap pairs (the strided layers, the original kernel described below): K = 16 = two taps x the 8 input channels of a chunk:
+//     lanes 0-31 (k 0..7) carry tap 2s, lanes 32-63 (k 8..15) tap 2s + 1, s = 0..4 (the tenth tap is zero weights).
+// Plus an opt-in producer / consumer variant on the tap-pair image (conv3x3_emu_pc_kernel).  Measured history: DESIGN.md section 8.  A workgroup (8 or 12 wavefronts) owns 8 / 12 row segments of 32 pixels and 64 output channels; persistent
 // workgroups, one barrier per 8-channel chunk, everything one chunk ahead: the split weights of chunk L + 1 arrive by LDS-DMA, the
 // fp32 halo pixels of chunk L + 1 are loaded into registers (one lane = one pixel, coalesced along the patch rows), split ONCE per
 // pixel after the MFMA steps of chunk L and written to LDS as [term][pixel][8 cin] bf16 -- a B operand is then one ds_read_b128
