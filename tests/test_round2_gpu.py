@@ -379,13 +379,22 @@ for (N, Ci, Co, H, W) in ((2, 64, 64, 100, 352), (3, 128, 128, 50, 176), (2, 256
                 got = ops.conv3x3_emu_bias_act(x, ws, b, Co, res, relu, 3, out_channels_last=cl)
                 worst = max(worst, float((got.double() - want).abs().max() / want.abs().max()))
         assert torch.equal(ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, 3), ops.conv3x3_emu_bias_act(x, ws, b, Co, r, True, 3))
+for (N, Ci, Co, H, W) in ((2, 64, 64, 200, 704), (1, 64, 128, 100, 352), (1, 128, 256, 37, 53)):      # the strided layers (tap-pair image), NCHW and channels-last input
+    g = torch.Generator().manual_seed(N + Ci + H + 1)
+    x = torch.randn(N, Ci, H, W, generator=g).cuda(); w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    want = torch.relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1))
+    ws = ops.pack_conv3x3_emu_weight(w, 3)
+    for xin in (x, x.contiguous(memory_format=torch.channels_last)):
+        got = ops.conv3x3_emu_bias_act(xin, ws, b, Co, None, True, 3, stride=2)
+        worst = max(worst, float((got.double() - want).abs().max() / want.abs().max()))
 print("WORST", worst)
 sys.exit(0 if worst <= 5e-6 else 1)
 """
 
 
 @pytest.mark.parametrize("env", [{"COALIGN_EMU_PC": "1"}, {"COALIGN_EMU_PC": "1", "COALIGN_EMU_PC_ROWS": "12"}, {"COALIGN_EMU_GEO": "84"}, {"COALIGN_EMU_TAPK_VAR": "1"},
-                                 {"COALIGN_EMU_TAPK_ROWS": "8"}, {"COALIGN_EMU_TAPK_ROWS": "12"}, {"COALIGN_EMU_TAPK_ROWS": "26"}, {"COALIGN_EMU_TAPK_26": "0"}, {"COALIGN_EMU_PRIO": "1"}])
+                                 {"COALIGN_EMU_TAPK_ROWS": "8"}, {"COALIGN_EMU_TAPK_ROWS": "12"}, {"COALIGN_EMU_TAPK_ROWS": "26"}, {"COALIGN_EMU_TAPK_26": "0"}, {"COALIGN_EMU_PRIO": "1"}, {"COALIGN_EMU_S2_ASM": "1"}, {"COALIGN_EMU_S2_ASM": "0"}])
 def test_conv3x3_emu_kernel_variants_in_a_subprocess(env):
     """The kernel variants of the split-bf16 convolution that an environment switch selects at library load (the producer / consumer
     kernel, the asm-issued weight DMA on the tap-pair image, the tap-major image with the builtin DMA or a forced tile height, the strict
