@@ -34,7 +34,7 @@ from coalign_amd.detector import build_model, to_device  # noqa: E402
 from coalign_amd.pipeline import FramePipeline  # noqa: E402
 from coalign_amd.postprocess import build_postprocessor  # noqa: E402
 from coalign_amd.sharded import FrameRing, ring_batch, split_agents  # noqa: E402
-from coalign_amd.synthetic import calibrate_heads_, fill_parameters_, make_frame  # noqa: E402
+from coalign_amd.synthetic import calibrate_heads_, fill_parameters_, make_frame, make_points_frame  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # dense fp32 matrix peak, /opt/skills/guides/MI355X_MICROARCH.md
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 matrix peak, same guide
@@ -61,6 +61,34 @@ def hip_time(fn, iters=10, warm=3):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
+
+
+def pctl(xs, q):
+    xs = sorted(xs)
+    return None if not xs else round(xs[min(len(xs) - 1, int(round(q * (len(xs) - 1))))], 4)
+
+
+def latency_stats(lat_ms):
+    return {"p50": pctl(lat_ms, 0.5), "p99": pctl(lat_ms, 0.99), "max": pctl(lat_ms, 1.0), "frames": len(lat_ms)}
+
+
+def kernel_trace_us():
+    """Average kernel durations (us) of the pillar op and the fusion from the committed rocprofv3 --kernel-trace --stats summary of
+    tools/kernels_only.py (same workload as the roofline figures): an independent clock beside the HIP events."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "round3", "kernels_isolated_stats.csv")
+    if not os.path.exists(path):
+        return None
+    out = {}
+    for r in csv.DictReader(open(path)):
+        n, us = r["Name"], float(r["AverageNs"]) / 1e3
+        for key, tag in (("pillar_prep_kernel", "pillar_prep_us"), ("pillar_rows_mx_kernel", "pillar_rows_us"), ("warp_fuse_nhwc_kernel", "fuse_us")):
+            if key in n:
+                out[tag] = round(us, 2)
+    if "pillar_prep_us" in out and "pillar_rows_us" in out:
+        out["pillar_op_us"] = round(out["pillar_prep_us"] + out["pillar_rows_us"], 2)
+    out["source"] = os.path.relpath(path, ROOT)
+    return out
 
 
 def graph_time(fn, dev, iters=10):
@@ -98,6 +126,10 @@ def main():
     ap.add_argument("--conv-emu", type=int, default=None, choices=(0, 2, 3),
                     help="override the 3x3 convolution arithmetic: 0 = native fp32 MFMA / MIOpen, 3 / 2 = split-bf16 products (default: the package default)")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the extra timed passes of the other convolution modes")
+    ap.add_argument("--from-points", action="store_true", help="ALSO time the loop fed from raw point clouds in pinned host memory (async H2D + device "
+                    "voxeliser + encoder in every frame: `from_points` in the JSON line; `value` stays the from-pillars metric of BASELINE.json); on by default at --gpus 1")
+    ap.add_argument("--no-from-points", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the one-frame-in-flight latency pass")
     ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the oracle (0 = best of the committed sweep, else 16)")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
@@ -176,17 +208,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run(pipe, steps, warmup):
+    def timed_run(pipe, steps, warmup, batches=None, points=False):
+        batches = step_batches if batches is None else batches
+        submit = pipe.submit_points if points else pipe.submit
         for s in range(warmup):
-            pipe.submit(step_batches[s % len(step_batches)])
+            submit(batches[s % len(batches)])
         pipe.drain()
         sync()
         pipe.host_enqueue_s = 0.0
+        pipe.latencies_ms = []               # submit -> detections on the host, per frame of the timed loop
         results = []
         base = pipe._count                   # frame indices of the results below are made relative to the timed loop
         t0 = time.perf_counter()
         for s in range(steps):
-            results += pipe.submit(step_batches[s % len(step_batches)])
+            results += submit(batches[s % len(batches)])
         t_issue = pipe.host_enqueue_s
         results += pipe.drain()              # the last frames' detections: all K frames are complete inside the bracket
         sync()
@@ -251,6 +286,7 @@ def main():
     sync()
 
     dt, t_issue, results = timed_run(pipe, args.steps, warm)
+    lat_default = list(pipe.latencies_ms)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -282,6 +318,62 @@ def main():
     prof_pipe.drain()
     sync()
     prof, ops.PROFILE = ops.PROFILE, None
+
+    # ---- per-frame latency: ONE frame in flight, detections collected before the next frame is submitted (the reference's strictly
+    #      serial loop, opencood/tools/inference.py:125-179) -- what a 10 Hz LiDAR consumer sees
+    latency = None
+    if world == 1 and not args.no_latency:
+        latency = {"default_pipeline": dict(latency_stats(lat_default), frames_in_flight=n_lanes, result_lag_frames=pipe.result_lag)}
+        try:
+            p1 = FramePipeline(model, pp, anchors, lanes=1, result_lag=0, graph=use_graph, device=dev)
+            d1, _, _ = timed_run(p1, args.steps, max(4, args.warmup))
+            latency["one_frame_in_flight"] = dict(latency_stats(p1.latencies_ms), frames_per_s=round(args.steps / d1, 3))
+            del p1
+        except Exception as e:      # noqa: BLE001
+            latency["error"] = f"{type(e).__name__}: {str(e)[:200]}"
+            torch.cuda.synchronize()
+
+    # ---- the loop fed from RAW POINTS in host memory: pinned staging -> async H2D -> coalign_voxelize -> encoder (count on the device)
+    #      -> the same frame.  A second reported mode; `value` stays the from-pillars metric BASELINE.json names.
+    from_points = None
+    if world == 1 and (args.from_points or not args.no_from_points):
+        try:
+            from coalign_amd.preprocess import build_preprocessor
+            pre = build_preprocessor(hypes["preprocess"], False, dev)
+            pframes = [make_points_frame(hypes, N, seed=303 + i, noise=(0.2, 0.2)) for i in range(POOL)]
+            n_pts = [int(sum(len(c) for c in f["clouds"])) for f in pframes]
+            pv = pre.preprocess_clouds(pframes[0]["clouds"], ego_filter=True)
+            m_pillars = int(pv["voxel_features"].shape[0])
+            # the heads were calibrated on the pillar pool: calibrate a copy of the model on the first point frame (same ~600 candidates)
+            import copy
+            model_p = copy.deepcopy(model)
+            calibrate_heads_(model_p, {"processed_lidar": {k: pv[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")}, "record_len": [N],
+                                       "pairwise_t_matrix": pframes[0]["pairwise_t_matrix"].to(dev)}, pp.params["target_args"]["score_threshold"], 600)
+            del pv
+            slot = 1 << (max(max(len(c) for c in f["clouds"]) for f in pframes) - 1).bit_length()
+            pp_p = build_postprocessor(hypes["postprocess"], False)
+            fp = FramePipeline(model_p, pp_p, anchors, lanes=n_lanes, result_lag=args.result_lag, graph=use_graph, device=dev, preprocessor=pre,
+                               points_per_cloud=slot)
+            dp, tip, rp = timed_run(fp, args.steps, warm, batches=pframes, points=True)
+            from_points = {"value": round(args.steps / dp, 3), "unit": "frames/s", "ms_per_step": round(dp / args.steps * 1e3, 4),
+                           "host_enqueue_ms_per_step": round(tip / args.steps * 1e3, 4), "latency_ms": latency_stats(fp.latencies_ms),
+                           "points_per_frame": n_pts[0], "pillars_frame0": m_pillars, "h2d_bytes_per_frame": N * slot * 16,
+                           "detections_last_frame": 0 if not rp or rp[-1][1] is None else int(rp[-1][1].shape[0]),
+                           "input": f"{N} raw 64-beam sweeps per frame (coalign_amd.synthetic.make_point_cloud) in pinned host memory, "
+                                    f"{POOL} distinct frames in rotation; per frame: async copy of {N} x {slot} point slots, coalign_voxelize (4 launches), "
+                                    "coalign_pillar_encode_stream with the pillar count on the device, then the same path as `value`"}
+            fp.close()
+            if not args.no_latency:
+                fp1 = FramePipeline(model_p, pp_p, anchors, lanes=1, result_lag=0, graph=use_graph, device=dev, preprocessor=pre, points_per_cloud=slot)
+                d1, _, _ = timed_run(fp1, args.steps, max(4, args.warmup), batches=pframes, points=True)
+                from_points["one_frame_in_flight"] = dict(latency_stats(fp1.latencies_ms), frames_per_s=round(args.steps / d1, 3))
+                fp1.close()
+            del model_p
+        except Exception as e:      # noqa: BLE001  a second mode must never cost the headline line
+            from_points = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            torch.cuda.synchronize()
+    if hasattr(model, "pillar_vfe"):
+        model.pillar_vfe.persistent_canvas = True             # (a closed side pipeline hands the flag back)
 
     # ---- the same bracket with the other convolution arithmetics (reported beside `value`, never as `value`)
     side = None
@@ -323,9 +415,12 @@ def main():
         conv_flops = 2 * N * 64 * (ny // 2) * (nx // 2) * 64 * 9          # one 64 -> 64 channel 3x3 layer of the first ResNet stage
         alg_flops = {"conv3x3_bias_act": conv_flops, "conv3x3_emu_bias_act": conv_flops}
         kernels = []
+        alg_live = dict(alg_bytes)
+        if default_terms in (2, 3):     # the pipeline's persistent canvas: bytes really moved per call (see pillar_moved_model below), not the dense-canvas formula
+            alg_live["pillar_vfe_scatter"] = M * (532 + 256 + 256 + 256 + 12)
         for name, pairs in sorted(prof.items()):
             ms = sum(s.elapsed_time(e) for s, e in pairs) / len(pairs)
-            b = alg_bytes.get(name)
+            b = alg_live.get(name)
             kernels.append({"name": name, "launches_timed": len(pairs), "avg_ms": round(ms, 5), "algorithmic_bytes": b,
                             "GBps": None if b is None else round(b / ms / 1e6, 1),
                             "frac_of_8TBps": None if b is None else round(b / ms / 1e6 / HBM_PEAK_GBPS, 4)})
@@ -335,7 +430,9 @@ def main():
         # reads = 2 x FETCH_SIZE (gfx950 tallies the 128-B requests of 16 B/lane streaming loads at 64 B, MI355X_MICROARCH.md
         # "HBM"), writes = WRITE_SIZE; null when no summary is committed for this workload
         pmc, pmc_src = {}, None
-        path = os.path.join(ROOT, "profiles", "round2", "pmc_summary.json")
+        path = os.path.join(ROOT, "profiles", "round3", "pmc_summary.json")
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "round2", "pmc_summary.json")
         if os.path.exists(path) and N == 5 and args.pillars == 8000 and args.config == "opv2v_coalign":
             pmc, pmc_src = json.load(open(path)), os.path.relpath(path, ROOT)
 
@@ -352,29 +449,44 @@ def main():
                 e["in_timed_steps"] = {"avg_launch_ms": live[live_name]["avg_ms"], "frac": live[live_name]["frac_of_8TBps"]}
             return e
 
-        pillar = hbm_entry("pillar_vfe_scatter = pillar_prep_kernel + pillar_rows_nhwc_kernel (persistent channels-last canvas: only the previous frame's rows are cleared)" if default_terms in (2, 3)
-                           else "pillar_vfe_scatter = memset + cellmap_kernel + pillar_canvas_kernel", iso["pillar_ms"], alg_bytes["pillar_vfe_scatter"],
-                           traffic_of("pillar_nhwc_persistent" if default_terms in (2, 3) else "pillar_nchw"), "pillar_vfe_scatter")
+        persistent = default_terms in (2, 3)
+        # bytes the persistent-canvas pillar op has to move per call (what the timed configuration does; no dense zero-fill): per pillar
+        # 532 B in, 256 B feature row + 256 B canvas row out, 256 B to clear the row the previous frame wrote, 12 B of slot list / cell map
+        pillar_moved_model = M * (532 + 256 + 256 + 256 + 12)
+        pillar = hbm_entry("pillar_vfe_scatter = pillar_prep_kernel + pillar_rows_mx_kernel (persistent channels-last canvas: only the previous frame's rows are cleared)" if persistent
+                           else "pillar_vfe_scatter = memset + cellmap_kernel + pillar_canvas_kernel", iso["pillar_ms"],
+                           pillar_moved_model if persistent else alg_bytes["pillar_vfe_scatter"],
+                           traffic_of("pillar_nhwc_persistent" if persistent else "pillar_nchw"), "pillar_vfe_scatter")
+        pillar["survey_8d_formula_bytes"] = alg_bytes["pillar_vfe_scatter"]
         north = {"target": 0.40, "pillar_vfe_scatter": pillar}
         if "pillar_fresh_canvas_ms" in iso:
-            north["pillar_vfe_scatter_fresh_canvas"] = hbm_entry("pillar_vfe_scatter on a fresh canvas = canvas memset + cell-map memset + cellmap_kernel + pillar_rows_nhwc_kernel",
+            north["pillar_vfe_scatter_fresh_canvas"] = hbm_entry("pillar_vfe_scatter on a fresh canvas = canvas memset + cell-map memset + cellmap_kernel + pillar_rows_mx_kernel",
                                                                  iso["pillar_fresh_canvas_ms"], alg_bytes["pillar_vfe_scatter"], traffic_of("pillar_nhwc"))
+        ktrace = kernel_trace_us()
+        if ktrace:
+            north["kernel_trace_us"] = ktrace
         if "fuse_ms" in iso:
-            north["warp_fuse_all_scales"] = hbm_entry("warp + attention fusion, 3 scales (coalign_warp_fuse_nhwc: one launch)" if default_terms in (2, 3) else "coalign_warp_fuse x 3 scales",
-                                                         iso["fuse_ms"], fuse_bytes, traffic_of("fuse_nhwc_3scales") if default_terms in (2, 3) else None)
-            tot_ms, tot_b = iso["pillar_ms"] + iso["fuse_ms"], alg_bytes["pillar_vfe_scatter"] + fuse_bytes
-            north.update({"frac": round(tot_b / tot_ms / 1e6 / HBM_PEAK_GBPS, 4), "achieved": round(tot_b / tot_ms / 1e6, 1), "unit": "GB/s",
-                          "algorithmic_bytes": tot_b, "ms": round(tot_ms, 5)})
-            if "pillar_fresh_canvas_ms" in iso:
+            fuse = hbm_entry("warp + attention fusion, 3 scales (coalign_warp_fuse_nhwc: one launch)" if persistent else "coalign_warp_fuse x 3 scales",
+                             iso["fuse_ms"], fuse_bytes, traffic_of("fuse_nhwc_3scales") if persistent else None)
+            north["warp_fuse_all_scales"] = fuse
+            tot_ms = iso["pillar_ms"] + iso["fuse_ms"]
+            # `frac`: bytes REALLY moved (PMC traffic where a summary of this round is committed, else the per-pillar model above) / time
+            moved = (pillar["traffic"] or pillar["algorithmic_bytes_per_launch"]) + (fuse["traffic"] or fuse_bytes)
+            north.update({"frac": round(moved / tot_ms / 1e6 / HBM_PEAK_GBPS, 4), "achieved": round(moved / tot_ms / 1e6, 1), "unit": "GB/s",
+                          "bytes_moved": moved, "bytes_source": "rocprofv3 --pmc (corrected)" if pillar["traffic"] and fuse["traffic"] else "model (no PMC summary of this round for this workload)",
+                          "ms": round(tot_ms, 5)})
+            if ktrace and "pillar_op_us" in ktrace and "fuse_us" in ktrace:      # the same bytes over the kernel durations of the committed rocprofv3 trace
+                north["frac_kernel_trace"] = round(moved / ((ktrace["pillar_op_us"] + ktrace["fuse_us"]) * 1e-3) / 1e6 / HBM_PEAK_GBPS, 4)
+            if "pillar_fresh_canvas_ms" in iso:      # SURVEY 8d's formula (dense canvas write counted) only where a dense canvas is really written
+                tot_b = alg_bytes["pillar_vfe_scatter"] + fuse_bytes
                 north["frac_fresh_canvas"] = round(tot_b / (iso["pillar_fresh_canvas_ms"] + iso["fuse_ms"]) / 1e6 / HBM_PEAK_GBPS, 4)
         else:
             north.update({"frac": pillar["frac"], "note": "fusion timing failed: " + iso.get("fuse_error", "?")})
         north["note"] = ("north_star: >= 40 % of the HBM roofline on the pillar-scatter + warp path.  Each part alone on the GPU (HIP events around "
-                         "10 replays of a HIP graph of the op's launches, right before the timed region); frac = algorithmic bytes (SURVEY 8d: pillars in, "
-                         "features + the DENSE canvas out; N + 1 maps for the fusion) / time / 8 TB/s; traffic = corrected PMC bytes "
-                         f"({pmc_src}).  The pipeline keeps one canvas per lane and clears only the rows the previous frame wrote, so its pillar op "
-                         "moves 59 MB instead of the 212 MB the formula counts (traffic_over_algorithmic 0.28): `frac` is that configuration, "
-                         "`frac_fresh_canvas` the same path with a freshly zero-filled canvas every call")
+                         "10 replays of a HIP graph of the op's launches, right before the timed region).  `frac` = bytes the timed configuration really "
+                         f"moves / time / 8 TB/s: corrected PMC traffic ({pmc_src}) -- the persistent canvas writes no dense zero-fill, so SURVEY 8d's formula "
+                         "(which counts one) is used only in `frac_fresh_canvas`, the same path with a freshly zero-filled canvas per call; "
+                         "`frac_kernel_trace` = the same bytes over the kernel durations of the committed rocprofv3 trace (profiles/round3/kernels_isolated_stats.csv)")
 
         # `roofline` = the hand-written kernel the frame spends most of its time in: the 3x3 convolution of the active arithmetic
         if default_terms in (2, 3):
@@ -417,6 +529,10 @@ def main():
         }
         if rings is not None:
             result["exchange_bytes_sent_per_rank_per_step"] = rings[0].bytes_sent_last
+        if latency is not None:
+            result["latency_ms"] = latency
+        if from_points is not None:
+            result["from_points"] = from_points
         if side is not None:
             result["other_modes"] = side
         if world == 1 and not args.no_cpu_baseline:

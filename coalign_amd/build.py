@@ -23,6 +23,10 @@ LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip.so")
 INCLUDE = os.path.join(REPO, "include")
 SOURCES = ["status.cpp", "pillar_scatter.hip", "warp_fuse.hip", "warp_fuse_nhwc.hip", "decode.hip", "nms.hip", "epilogue.hip", "voxelize.hip", "pose_graph.hip", "conv3x3.hip", "conv3x3_emu.hip", "pointwise.hip"]
 ARCH = "gfx950"
+# per-source extras.  pillar_scatter.hip: its matrix-core encoder reduces the accumulators with VALU right after each instruction
+# pair -- results in VGPRs (not AGPRs) save 64 v_accvgpr_read per pass; -fno-honor-nans drops the canonicalising v_max the compiler
+# puts in front of every two-operand fmaxf of a raw matrix result (20 per pass; the file tests for NaN nowhere, its selects are explicit).
+EXTRA_FLAGS = {"pillar_scatter.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-cuda-compat", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
@@ -47,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         if force or not os.path.exists(op) or os.path.getmtime(op) < _newest([sp] + headers):
-            cmd = [hipcc, "-x", "hip"] + FLAGS + ["-c", sp, "-o", op]
+            cmd = [hipcc, "-x", "hip"] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -36,6 +36,8 @@ struct PfnArgs {
     int n_agents, ny, nx;
     float *feats;
     int *cellmap;
+    const int *M_dev;     // optional: the pillar count lives on the device (the voxeliser's voxel_counts word); M is then the capacity
+    int unique;           // the caller guarantees one pillar per cell (voxeliser output): no cell-map lookup
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -449,9 +451,289 @@ __device__ __forceinline__ void pfn_pair(const PfnArgs &a, const ChanParams &cp,
     coalign::wave_lds_sync();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Channels-last canvas [n_agents, ny, nx, C]: a pillar's feature row IS its canvas cell (C contiguous floats), so the scatter is one
+// 256-byte store per pillar and the dense canvas is a plain memset (6.8 TB/s on this chip) -- no strips, no LDS feature buffer, no
+// read-back.  One wavefront encodes two pillars (pfn_pair), writes their pillar_features rows and, for the pillar that owns its
+// cell in the cell map ("larger row wins"), the canvas row.  Launch order on the stream: memset(canvas), memset(cell map),
+// cellmap_kernel, this.
+struct PairIn {     // lanes 0-31: pillar A's point / count / coords, lanes 32-63: pillar B's
+    float4 q;
+    int np;
+    int4 cd;
+};
+
+__device__ __forceinline__ PairIn pair_load(const PfnArgs &a, int lane, int mA) {
+    const int half = lane >> 5, pl = lane & 31;
+    const int m = mA + half;
+    PairIn in;
+    in.q = make_float4(0.f, 0.f, 0.f, 0.f);
+    in.np = 0;
+    in.cd = make_int4(-1, 0, 0, 0);
+    if (m < a.M) {
+        if (pl < a.P) in.q = a.pts[(size_t)m * a.P + pl];
+        in.np = a.npts[m];
+        in.cd = a.coords[m];
+    }
+    return in;
+}
+
+// the same for two arbitrary rows (mB < 0: no second pillar)
+__device__ __forceinline__ PairIn pair_load_idx(const PfnArgs &a, int lane, int mA, int mB) {
+    const int half = lane >> 5, pl = lane & 31;
+    const int m = half ? mB : mA;
+    PairIn in;
+    in.q = make_float4(0.f, 0.f, 0.f, 0.f);
+    in.np = 0;
+    in.cd = make_int4(-1, 0, 0, 0);
+    if (m >= 0) {
+        if (pl < a.P) in.q = a.pts[(size_t)m * a.P + pl];
+        in.np = a.npts[m];
+        in.cd = a.coords[m];
+    }
+    return in;
+}
+
+// pfn_pair's arithmetic on already loaded operands (same instruction sequence, so the rows are bit-identical to the NCHW route)
+__device__ __forceinline__ void pair_compute(const PfnArgs &a, const ChanParams &cp, float *slab, int lane, const PairIn &in, bool hasB,
+                                             float &va, float &vb) {
+    const int pl = lane & 31;
+    const float4 q = in.q;
+    const int np_eff = min(max(in.np, 0), a.P);
+    const float npf = (float)in.np;
+    const float mx = half_sum(q.x) / npf, my = half_sum(q.y) / npf, mz = half_sum(q.z) / npf;
+    const float ctr_x = (float)in.cd.w * a.vx + a.xo;
+    const float ctr_y = (float)in.cd.z * a.vy + a.yo;
+    const float ctr_z = (float)in.cd.y * a.vz + a.zo;
+    if (pl < np_eff) stage_point_pk(a, slab, lane, q, mx, my, mz, ctr_x, ctr_y, ctr_z);   // row = lane: A -> 0.., B -> 32..
+    coalign::wave_lds_sync();
+    const int npA = __builtin_amdgcn_readlane(np_eff, 0), npB = __builtin_amdgcn_readlane(np_eff, 32);
+    va = rows_max_pk(cp, slab, 0, npA, a.P);
+    vb = hasB ? rows_max_pk(cp, slab, 32, npB, a.P) : 0.f;
+    coalign::wave_lds_sync();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Matrix-core encoder (P <= 32, C <= 64, no distance feature) -- the default of the channels-last routes since round 3.
+// The VALU encoder above evaluates the 10-term dot product per point and channel (9.6 M vector instructions per 40 k-pillar frame,
+// 26 us: VALU bound).  Two observations remove almost all of it:
+//   (1) the augmented point is an affine function of the raw point (pillar_vfe.py:118-141).  With c = the pillar centre, d = p - c
+//       (the reference's own f_center, one fp32 subtraction) and e = mean - c:
+//           x = c + d,  f_cluster = d - e,  f_center = d
+//           W f = (w_abs + w_cluster + w_center) d + w_i intensity  +  [ w_abs c - w_cluster e ]
+//       i.e. a 4-term product per point plus ONE constant per (pillar, channel).  No cancellation is introduced: the large coordinates
+//       only enter through w_abs c, evaluated once per pillar in fp32 exactly as large as the reference's own w_abs x term.
+//   (2) that 4-term product is a [points x 4] x [4 x 64] GEMM.  Like the 3x3 convolutions (conv3x3_emu.hip) it runs on the bf16 matrix
+//       cores by error-free 3-way operand splitting (x = x_h + x_m + x_l, each bf16; the six products w_h x_h, w_h x_m, w_m x_h, w_h x_l,
+//       w_l x_h, w_m x_m are exact in the fp32 accumulator; dropped terms <= 2^-24 |w x|: fp32-width arithmetic).  The six products of the
+//       four inputs are 24 K-slots = two v_mfma_f32_32x32x16_bf16 per 32 rows x 32 channels.
+// A wavefront still takes two pillars per pass (lanes 0-31 / 32-63 = their point slots).  Matrix rows 0-15 = pillar A's slots 0-15, rows
+// 16-31 = pillar B's slots 0-15 (a second tile with slots 16-31 only when either pillar has more than 16 points: 24 % of the passes at
+// LiDAR statistics); a row past num_points re-reads slot 0 of its pillar, so the row maximum needs no masking.  BatchNorm's scale can be
+// negative: the weights of such channels are negated (exact) so that the row reduction is always a max; max commutes with the monotone
+// fp32 operations that follow (add constant, fma with alpha).  In the accumulator layout a lane holds 8 rows of pillar A and 8 of pillar B
+// for one channel: 2 x 4 v_max3/v_max + one v_permlane32_swap + one v_max per 32 channels give both pillars' maxima, one more swap puts
+// them in lane = channel order.  Per pass: ~160 vector instructions + 4-8 matrix instructions instead of ~480.
+// Numerics: |result - fp64 evaluation| is within the fp32 rounding noise of the reference's own evaluation (tests: oracle + reference
+// goldens to 1e-4 / 1e-5 of scale as before); the canvas stays an exact copy of pillar_features.
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRowBytes = 80;        // staged point row: [l h | m m | h h | 0 0] (4 x 16 B) + 16 B pad -> ds_read_b128 of 16 rows hits 16 distinct bank groups
+
+struct MxChan {
+    bf16x8 b1[2], b2[2];             // B operands (column = lane & 31 of channel group g): step 1 / step 2
+    // epilogue parameters of channel 32 g + (lane & 31) ("half layout": lanes 0-31 work for pillar A, lanes 32-63 for pillar B)
+    float wc[2][3], wen[2][3];       // weights of the centre term, negated weights of the mean-offset term
+    float alpha[2], shift[2], sgn[2];
+};
+
+__device__ __forceinline__ void split3(float v, __bf16 &h, __bf16 &m, __bf16 &l) {
+    h = (__bf16)v;
+    const float r = v - (float)h;    // exact
+    m = (__bf16)r;
+    l = (__bf16)(r - (float)m);      // exact subtraction, exact conversion
+}
+
+__device__ __forceinline__ void bn_affine(const PfnArgs &a, int c, float &alpha, float &shift) {
+    alpha = 1.f; shift = 0.f;
+    if (c < a.C) {
+        if (a.bn_w) {
+            const float inv_std = 1.0f / sqrtf(a.bn_v[c] + a.eps);
+            alpha = a.bn_w[c] * inv_std;
+            shift = a.bn_b[c] - a.bn_m[c] * alpha;
+        } else if (a.bias) {
+            shift = a.bias[c];
+        }
+    }
+}
+
+template <bool ABS>
+__device__ __forceinline__ MxChan load_mx(const PfnArgs &a, int lane) {
+    MxChan mc;
+    constexpr int B = ABS ? 4 : 1;
+    const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int c = g * 32 + col;
+        float w4[4] = {0.f, 0.f, 0.f, 0.f};
+        float alpha, shift;
+        bn_affine(a, c, alpha, shift);
+        if (c < a.C) {
+            const float *w = a.weight + (size_t)c * a.Cin;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w4[k] = ((ABS ? w[k] : 0.f) + w[B + k]) + w[B + 3 + k];
+            w4[3] = w[ABS ? 3 : 0];
+        }
+        const float sg = alpha < 0.f ? -1.f : 1.f;
+        mc.alpha[g] = alpha; mc.shift[g] = shift; mc.sgn[g] = sg;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mc.wc[g][k] = (ABS && c < a.C) ? a.weight[(size_t)c * a.Cin + k] : 0.f;
+            mc.wen[g][k] = (c < a.C) ? -a.weight[(size_t)c * a.Cin + B + k] : 0.f;
+        }
+        bf16x4 h, m, l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __bf16 th, tm, tl;
+            split3(sg * w4[k], th, tm, tl);
+            h[k] = th; m[k] = tm; l[k] = tl;
+        }
+        const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        // K order of a step: half 0 = [first 4 | next 4], half 1 likewise.  step 1: A = [p_l p_h | p_m p_m], step 2: A = [p_h p_h | 0 0]
+        const bf16x4 s1a = half ? m : h, s1b = half ? h : l;      // x p_l, p_h  |  x p_m, p_m
+        const bf16x4 s2a = half ? z : m, s2b = half ? z : h;      // x p_h, p_h  |  0
+        mc.b1[g] = __builtin_shufflevector(s1a, s1b, 0, 1, 2, 3, 4, 5, 6, 7);
+        mc.b2[g] = __builtin_shufflevector(s2a, s2b, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    return mc;
+}
+
+__device__ __forceinline__ void swap32(float &a, float &b) {       // lanes 32-63 of a <-> lanes 0-31 of b
+    const auto q = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned x = q[0], y = q[1];                              // (bit-casting q[1] directly is miscompiled by hipcc 7.2: go through locals)
+    a = __builtin_bit_cast(float, x);
+    b = __builtin_bit_cast(float, y);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// sum over each 32-lane half, result in every lane of the half: four DPP steps inside the 16-lane rows, one v_permlane16_swap across rows
+__device__ __forceinline__ float half_sum_dpp(float v) {
+    v += dppf<0xB1>(v);              // quad_perm [1, 0, 3, 2]
+    v += dppf<0x4E>(v);              // quad_perm [2, 3, 0, 1]
+    v += dppf<0x141>(v);             // row_half_mirror
+    v += dppf<0x140>(v);             // row_mirror
+    const auto q = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    const unsigned x = q[0], y = q[1];          // x = [r0 r0 r2 r2], y = [r1 r1 r3 r3]
+    return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+}
+
+// max of accumulator elements o .. o + 7: v_max3 on matrix-instruction results only (a two-operand fmaxf of raw results costs two extra
+// canonicalising v_max each)
+__device__ __forceinline__ float max8(const floatx16 &v, int o) {
+    const float t1 = fmaxf(fmaxf(v[o], v[o + 1]), v[o + 2]), t2 = fmaxf(fmaxf(v[o + 3], v[o + 4]), v[o + 5]);
+    const float t3 = fmaxf(fmaxf(v[o + 6], v[o + 7]), t1);
+    return fmaxf(t2, t3);
+}
+
+// plain v_max_f32 for values the compiler cannot prove canonical (results of a lane swap): no canonicalising pre-pass
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// rows: this wavefront's 64 x kRowBytes LDS rows (part 3 of every row zeroed once by the caller).
+// -> y[g], g = 0, 1: relu(max) of channel 32 g + (lane & 31) for pillar A (lanes 0-31) / pillar B (lanes 32-63) -- the "half layout".
+template <bool ABS>
+__device__ __forceinline__ void mx_pair_half(const PfnArgs &a, const MxChan &mc, char *rows, int lane, const PairIn &in, bool hasB, float (&y)[2]) {
+    const float4 q = in.q;
+    const int np_eff = min(max(in.np, 0), a.P);
+    // mean over ALL P slots divided by num_points (pillar_vfe.py:118-120); the division as v_rcp_f32 + multiply (<= 1.5 ulp of the mean)
+    const float rn = __builtin_amdgcn_rcpf((float)in.np);
+    const float ctr_x = (float)in.cd.w * a.vx + a.xo;
+    const float ctr_y = (float)in.cd.z * a.vy + a.yo;
+    const float ctr_z = (float)in.cd.y * a.vz + a.zo;
+    const float ex = half_sum_dpp(q.x) * rn - ctr_x, ey = half_sum_dpp(q.y) * rn - ctr_y, ez = half_sum_dpp(q.z) * rn - ctr_z;
+    const float d[4] = {q.x - ctr_x, q.y - ctr_y, q.z - ctr_z, q.w};
+    bf16x4 h, m, l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        __bf16 th, tm, tl;
+        split3(d[k], th, tm, tl);
+        h[k] = th; m[k] = tm; l[k] = tl;
+    }
+    const uint2 hu = __builtin_bit_cast(uint2, h), mu = __builtin_bit_cast(uint2, m), lu = __builtin_bit_cast(uint2, l);
+    uint4 *dst = reinterpret_cast<uint4 *>(rows + lane * kRowBytes);         // row = lane: A -> 0.., B -> 32..
+    dst[0] = make_uint4(lu.x, lu.y, hu.x, hu.y);
+    dst[1] = make_uint4(mu.x, mu.y, mu.x, mu.y);
+    dst[2] = make_uint4(hu.x, hu.y, hu.x, hu.y);
+    coalign::wave_lds_sync();
+    const int npA = __builtin_amdgcn_readlane(np_eff, 0), npB = hasB ? __builtin_amdgcn_readlane(np_eff, 32) : 0;
+    const int i = lane & 31, half = lane >> 5, pil = i >> 4;
+    const int npp = pil ? npB : npA;
+    float r[2];
+    auto tile = [&](int t, float (&o)[2]) {
+        const int slot = (i & 15) + 16 * t;
+        const int row = pil * 32 + (slot < npp ? slot : 0);
+        const char *src = rows + row * kRowBytes + half * 16;
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(src), a2 = *reinterpret_cast<const bf16x8 *>(src + 32);
+        floatx16 acc[2];
+        const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, mc.b1[g], zero, 0, 0, 0);       // the small products first
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, mc.b2[g], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float mA = max8(acc[g], 0), mB = max8(acc[g], 8);  // rows 0-15 = pillar A, 16-31 = pillar B; this lane holds 8 of each
+            swap32(mA, mB);                                     // mA = [A.lo B.lo], mB = [A.hi B.hi]
+            o[g] = vmax_raw(mA, mB);                            // lanes 0-31: A's channel 32 g + lane, lanes 32-63: B's channel 32 g + lane - 32
+        }
+    };
+    tile(0, r);
+    if (max(npA, npB) > 16) {                                   // wave-uniform
+        float s2[2];
+        tile(1, s2);
+        r[0] = vmax_raw(r[0], s2[0]); r[1] = vmax_raw(r[1], s2[1]);
+    }
+    coalign::wave_lds_sync();
+    // the per-pillar constant  w_abs c - w_cluster e: every lane already holds its own pillar's centre / mean offset / point count
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float b = mc.wen[g][0] * ex;
+        b = fmaf(mc.wen[g][1], ey, b); b = fmaf(mc.wen[g][2], ez, b);
+        if constexpr (ABS) { b = fmaf(mc.wc[g][0], ctr_x, b); b = fmaf(mc.wc[g][1], ctr_y, b); b = fmaf(mc.wc[g][2], ctr_z, b); }
+        float v = fmaf(mc.sgn[g] * r[g] + b, mc.alpha[g], mc.shift[g]);
+        if (np_eff < a.P) v = fmaxf(v, mc.shift[g]);           // padded rows: Linear(0) = 0 -> BN -> shift
+        if (np_eff == 0) v = mc.shift[g];                       // (documented deviation: the reference divides by zero here)
+        y[g] = fmaxf(v, 0.f);
+    }
+}
+
+// the same with the result in lane = channel order: va / vb = pillar A's / B's 64 channels
+template <bool ABS>
+__device__ __forceinline__ void pair_compute_mx(const PfnArgs &a, const MxChan &mc, char *rows, int lane, const PairIn &in, bool hasB,
+                                                float &va, float &vb) {
+    float y[2];
+    mx_pair_half<ABS>(a, mc, rows, lane, in, hasB, y);
+    swap32(y[0], y[1]);                                         // [A ch 0-31 | B ch 0-31], [A ch 32-63 | B ch 32-63] -> [A 0-63], [B 0-63]
+    va = y[0];
+    vb = hasB ? y[1] : 0.f;
+}
+
+// ENC as in pillar_rows_nhwc_kernel: the strips' pillar pairs go through the same pair_compute / pair_compute_mx, so the NCHW and the
+// channels-last route produce bit-identical rows.
+template <int ENC>
 __global__ __launch_bounds__(256) void pillar_canvas_kernel(FusedArgs f) {
     const PfnArgs &a = f.p;
-    __shared__ __attribute__((aligned(16))) float slabs[4 * 64 * kFeatStride];
+    constexpr int kWaveLds = ENC ? 64 * kRowBytes : 64 * kFeatStride * (int)sizeof(float);
+    __shared__ __attribute__((aligned(16))) char slab_bytes[4 * kWaveLds];
     __shared__ __attribute__((aligned(16))) float featbuf[kMaxLds * 64];
     __shared__ int work_m[kStrip];           // pillar rows living in this strip
     __shared__ int orphan_m[256];            // orphans found in this workgroup's slice of the pillar list (normally none)
@@ -483,12 +765,27 @@ __global__ __launch_bounds__(256) void pillar_canvas_kernel(FusedArgs f) {
     const int nocc = n_occ;
     // ---- PFN for the strip's pillars
     const ChanParams cp = load_chan(a, lane);
-    float *slab = slabs + wv * 64 * kFeatStride;
+    char *wave_lds = slab_bytes + wv * kWaveLds;
+    float *slab = reinterpret_cast<float *>(wave_lds);
+    MxChan mc;
+    if constexpr (ENC != 0) {
+        mc = load_mx<ENC == 1>(a, lane);
+        *reinterpret_cast<uint4 *>(wave_lds + lane * kRowBytes + 48) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    auto one_pillar = [&](int m) -> float {
+        if constexpr (ENC == 0) return pfn_one_pillar(a, cp, slab, lane, m);
+        else {
+            float va, vb;
+            pair_compute_mx<ENC == 1>(a, mc, wave_lds, lane, pair_load_idx(a, lane, m, -1), false, va, vb);
+            return va;
+        }
+    };
     if (a.P <= 32) {
         for (int w = 2 * wv; w < nocc; w += 8) {          // two pillars per wave and pass
             const int mA = work_m[w], mB = (w + 1 < nocc) ? work_m[w + 1] : -1;
             float va, vb;
-            pfn_pair(a, cp, slab, lane, mA, mB, va, vb);
+            if constexpr (ENC == 0) pfn_pair(a, cp, slab, lane, mA, mB, va, vb);
+            else pair_compute_mx<ENC == 1>(a, mc, wave_lds, lane, pair_load_idx(a, lane, mA, mB), mB >= 0, va, vb);
             if (lane < a.C) {
                 a.feats[(size_t)mA * a.C + lane] = va;
                 if (w < kMaxLds) featbuf[w * 64 + lane] = va;
@@ -501,7 +798,7 @@ __global__ __launch_bounds__(256) void pillar_canvas_kernel(FusedArgs f) {
     } else {
         for (int w = wv; w < nocc; w += 4) {
             const int m = work_m[w];
-            const float v = pfn_one_pillar(a, cp, slab, lane, m);
+            const float v = one_pillar(m);
             if (lane < a.C) {
                 a.feats[(size_t)m * a.C + lane] = v;
                 if (w < kMaxLds) featbuf[w * 64 + lane] = v;
@@ -515,7 +812,7 @@ __global__ __launch_bounds__(256) void pillar_canvas_kernel(FusedArgs f) {
         if (orphan) orphan_m[atomicAdd(&n_orph, 1)] = m_o;
         __syncthreads();
         for (int w = wv; w < n_orph; w += 4) {
-            const float v = pfn_one_pillar(a, cp, slab, lane, orphan_m[w]);
+            const float v = one_pillar(orphan_m[w]);
             if (lane < a.C) a.feats[(size_t)orphan_m[w] * a.C + lane] = v;
         }
         for (int r0 = 256; r0 < f.pillars_per_wg; r0 += 256) {        // slices longer than the block (huge M, tiny canvas)
@@ -531,7 +828,7 @@ __global__ __launch_bounds__(256) void pillar_canvas_kernel(FusedArgs f) {
             }
             __syncthreads();
             for (int w = wv; w < n_orph; w += 4) {
-                const float v = pfn_one_pillar(a, cp, slab, lane, orphan_m[w]);
+                const float v = one_pillar(orphan_m[w]);
                 if (lane < a.C) a.feats[(size_t)orphan_m[w] * a.C + lane] = v;
             }
         }
@@ -573,51 +870,6 @@ __global__ __launch_bounds__(256) void pillar_canvas_kernel(FusedArgs f) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Channels-last canvas [n_agents, ny, nx, C]: a pillar's feature row IS its canvas cell (C contiguous floats), so the scatter is one
-// 256-byte store per pillar and the dense canvas is a plain memset (6.8 TB/s on this chip) -- no strips, no LDS feature buffer, no
-// read-back.  One wavefront encodes two pillars (pfn_pair), writes their pillar_features rows and, for the pillar that owns its
-// cell in the cell map ("larger row wins"), the canvas row.  Launch order on the stream: memset(canvas), memset(cell map),
-// cellmap_kernel, this.
-struct PairIn {     // lanes 0-31: pillar A's point / count / coords, lanes 32-63: pillar B's
-    float4 q;
-    int np;
-    int4 cd;
-};
-
-__device__ __forceinline__ PairIn pair_load(const PfnArgs &a, int lane, int mA) {
-    const int half = lane >> 5, pl = lane & 31;
-    const int m = mA + half;
-    PairIn in;
-    in.q = make_float4(0.f, 0.f, 0.f, 0.f);
-    in.np = 0;
-    in.cd = make_int4(-1, 0, 0, 0);
-    if (m < a.M) {
-        if (pl < a.P) in.q = a.pts[(size_t)m * a.P + pl];
-        in.np = a.npts[m];
-        in.cd = a.coords[m];
-    }
-    return in;
-}
-
-// pfn_pair's arithmetic on already loaded operands (same instruction sequence, so the rows are bit-identical to the NCHW route)
-__device__ __forceinline__ void pair_compute(const PfnArgs &a, const ChanParams &cp, float *slab, int lane, const PairIn &in, bool hasB,
-                                             float &va, float &vb) {
-    const int pl = lane & 31;
-    const float4 q = in.q;
-    const int np_eff = min(max(in.np, 0), a.P);
-    const float npf = (float)in.np;
-    const float mx = half_sum(q.x) / npf, my = half_sum(q.y) / npf, mz = half_sum(q.z) / npf;
-    const float ctr_x = (float)in.cd.w * a.vx + a.xo;
-    const float ctr_y = (float)in.cd.z * a.vy + a.yo;
-    const float ctr_z = (float)in.cd.y * a.vz + a.zo;
-    if (pl < np_eff) stage_point_pk(a, slab, lane, q, mx, my, mz, ctr_x, ctr_y, ctr_z);   // row = lane: A -> 0.., B -> 32..
-    coalign::wave_lds_sync();
-    const int npA = __builtin_amdgcn_readlane(np_eff, 0), npB = __builtin_amdgcn_readlane(np_eff, 32);
-    va = rows_max_pk(cp, slab, 0, npA, a.P);
-    vb = hasB ? rows_max_pk(cp, slab, 32, npB, a.P) : 0.f;
-    coalign::wave_lds_sync();
-}
 
 // Persistent wavefronts: the channel parameters are loaded once, the operands of the NEXT pair and the cell-map entry of the
 // current one are in flight while the current pair is encoded -- one exposed memory round trip per wave instead of four per pair.
@@ -625,12 +877,16 @@ __device__ __forceinline__ void pair_compute(const PfnArgs &a, const ChanParams 
 // what the persistent-canvas form clears before the next frame.
 // `reset_cellmap`: the winner puts its cell-map entry back to -1 once it has read it (a loser that looks later sees -1 instead of the
 // winner's row -- not its own either way), so a persistent cell map is all -1 again when the kernel ends and needs no memset per frame.
+// (This kernel runs the fp32 VALU encoder: feature sets with the distance term, tensors past 4 GB, COALIGN_PILLAR_MFMA=0.  The default is
+// pillar_rows_mx_kernel below.)  `a.feats` may be NULL (callers that only consume the canvas skip 256 B of writes per pillar).
 __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_nhwc_kernel(PfnArgs a, float *__restrict__ canvas, int *__restrict__ dest,
                                                                                int reset_cellmap) {
     __shared__ __attribute__((aligned(16))) float slabs[kWavesPerBlock * 64 * kFeatStride];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float *slab = slabs + wv * 64 * kFeatStride;
     const int gwave = blockIdx.x * kWavesPerBlock + wv, nwave = gridDim.x * kWavesPerBlock;
+    if (a.M_dev) a.M = min(max(*a.M_dev, 0), a.M);
+    if (a.M_dev && dest && blockIdx.x == 0 && threadIdx.x == 0) dest[-1] = a.M;      // the device-count form keeps "rows written" in front of the list
     const int npairs = (a.M + 1) / 2;
     if (gwave >= npairs) return;
     const int ncell = a.ny * a.nx;
@@ -645,7 +901,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_nhwc_kernel(P
     PairIn nxt = pair_load(a, lane, 2 * gwave);
     const ChanParams cp = load_chan(a, lane);
     long slot_nxt = slot_of(nxt);
-    int owner_nxt = a.cellmap[slot_nxt < 0 ? 0 : slot_nxt];
+    int owner_nxt = a.unique ? 0 : a.cellmap[slot_nxt < 0 ? 0 : slot_nxt];
     for (int pair = gwave; pair < npairs; pair += nwave) {
         const PairIn in = nxt;
         const long slot = slot_nxt;
@@ -660,19 +916,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_nhwc_kernel(P
         // issued behind the stores would make the next iteration wait for them to reach memory (measured: 5 us per pair).
         if (more) {
             slot_nxt = slot_of(nxt);
-            owner_nxt = a.cellmap[slot_nxt < 0 ? 0 : slot_nxt];
+            if (!a.unique) owner_nxt = a.cellmap[slot_nxt < 0 ? 0 : slot_nxt];
         }
         const int m_lane = mA + (lane >> 5);
-        const bool win = slot >= 0 && owner == m_lane && m_lane < a.M;
+        const bool win = slot >= 0 && (a.unique || owner == m_lane) && m_lane < a.M;
         const int winA = __builtin_amdgcn_readlane((int)win, 0), winB = __builtin_amdgcn_readlane((int)win, 32);
         const unsigned slo = (unsigned)(unsigned long)slot, shi = (unsigned)((unsigned long)slot >> 32);
         const size_t slotA = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)shi, 0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)slo, 0);
         const size_t slotB = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)shi, 32) << 32) | (unsigned)__builtin_amdgcn_readlane((int)slo, 32);
         if (lane < a.C) {
-            a.feats[(size_t)mA * a.C + lane] = va;
+            if (a.feats) a.feats[(size_t)mA * a.C + lane] = va;
             if (winA) canvas[slotA * a.C + lane] = va;
             if (hasB) {
-                a.feats[(size_t)(mA + 1) * a.C + lane] = vb;
+                if (a.feats) a.feats[(size_t)(mA + 1) * a.C + lane] = vb;
                 if (winB) canvas[slotB * a.C + lane] = vb;
             }
         }
@@ -684,23 +940,116 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_nhwc_kernel(P
 }
 
 // Persistent canvas, one launch: zero the rows the PREVIOUS frame wrote (its dest list) and enter the NEW frame's pillars into the
-// cell map (which the previous rows kernel left all -1).
+// cell map (which the previous rows kernel left all -1).  Grid-stride, so the counts may live on the device (M_dev: the voxeliser's
+// count word, M = capacity; dest[-1] = the previous call's count): the launch geometry never depends on them.
 __global__ __launch_bounds__(256) void pillar_prep_kernel(const int *__restrict__ dest_prev, int M_prev, int C, float *__restrict__ canvas,
-                                                          const int4 *__restrict__ coords, int M, int n_agents, int ny, int nx,
-                                                          int *__restrict__ cellmap) {
+                                                          const int4 *__restrict__ coords, int M, const int *__restrict__ M_dev, int n_agents,
+                                                          int ny, int nx, int *__restrict__ cellmap) {
     const int c4 = C / 4;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx < (long)M_prev * c4) {
+    if (M_dev) {
+        M = min(max(*M_dev, 0), M);
+        M_prev = min(max(dest_prev[-1], 0), M_prev);
+    }
+    const long stride = (long)gridDim.x * 256;
+    const long n_clear = (long)M_prev * c4;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n_clear; idx += stride) {
         const long m = idx / c4;
         const int d = dest_prev[m];
         if (d >= 0) reinterpret_cast<float4 *>(canvas + (size_t)d * C)[(int)(idx - m * c4)] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (idx < M) {
+    if (!cellmap) return;                         // unique pillars: no cell map
+    const int ncell = ny * nx;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < M; idx += stride) {
         const int4 cd = coords[idx];
-        const int ncell = ny * nx;
         const int cell = cd.y + cd.z * nx + cd.w;
         if (cd.x >= 0 && cd.x < n_agents && cell >= 0 && cell < ncell) atomicMax(cellmap + (size_t)cd.x * ncell + cell, (int)idx);
     }
+}
+
+// The rows kernel of the matrix-core encoder: as pillar_rows_nhwc_kernel, but everything stays in the half layout -- lanes 0-31 work for
+// pillar A, lanes 32-63 for pillar B from the point loads to the stores (a store instruction writes 128 B of A's row and 128 B of B's),
+// nothing is broadcast through scalar registers, and all addresses are 32-bit byte offsets from scalar bases (the launcher checks the sizes).
+template <bool ABS>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(PfnArgs a, float *__restrict__ canvas, int *__restrict__ dest, int reset_cellmap) {
+    __shared__ __attribute__((aligned(16))) char lds[kWavesPerBlock * 64 * kRowBytes];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    char *wave_lds = lds + wv * 64 * kRowBytes;
+    const int gwave = blockIdx.x * kWavesPerBlock + wv, nwave = gridDim.x * kWavesPerBlock;
+    if (a.M_dev) a.M = min(max(*a.M_dev, 0), a.M);
+    if (a.M_dev && dest && blockIdx.x == 0 && threadIdx.x == 0) dest[-1] = a.M;      // the device-count form keeps "rows written" in front of the list
+    const int npairs = (a.M + 1) / 2;
+    if (gwave >= npairs) return;
+    const int ncell = a.ny * a.nx;
+    const char *pts_b = reinterpret_cast<const char *>(a.pts), *np_b = reinterpret_cast<const char *>(a.npts), *cd_b = reinterpret_cast<const char *>(a.coords);
+    char *cm_b = reinterpret_cast<char *>(a.cellmap), *feat_b = reinterpret_cast<char *>(a.feats), *cv_b = reinterpret_cast<char *>(canvas),
+         *dest_b = reinterpret_cast<char *>(dest);
+    auto load = [&](int pair) -> PairIn {
+        const int m = min(2 * pair + half, a.M - 1);                      // a pillar B past the end re-reads the last pillar; its lanes store nothing
+        PairIn in;
+        in.q = *reinterpret_cast<const float4 *>(pts_b + (unsigned)(m * a.P + min(col, a.P - 1)) * 16u);
+        if (a.P < 32 && col >= a.P) in.q = make_float4(0.f, 0.f, 0.f, 0.f);
+        in.np = *reinterpret_cast<const int *>(np_b + (unsigned)m * 4u);
+        in.cd = *reinterpret_cast<const int4 *>(cd_b + (unsigned)m * 16u);
+        return in;
+    };
+    auto slot_of = [&](const PairIn &p) -> int {                           // agent * ncell + cell (z + y * nx + x, point_pillar_scatter.py:54) or -1
+        const int cell = p.cd.y + p.cd.z * a.nx + p.cd.w;
+        const bool ok = p.cd.x >= 0 && p.cd.x < a.n_agents && cell >= 0 && cell < ncell;
+        return ok ? p.cd.x * ncell + cell : -1;
+    };
+    PairIn nxt = load(gwave);
+    const MxChan mc = load_mx<ABS>(a, lane);
+    *reinterpret_cast<uint4 *>(wave_lds + lane * kRowBytes + 48) = make_uint4(0u, 0u, 0u, 0u);          // part 3 of every row: the zero half of step 2
+    int slot_nxt = slot_of(nxt);
+    int owner_nxt = a.unique ? 0 : *reinterpret_cast<const int *>(cm_b + (unsigned)max(slot_nxt, 0) * 4u);
+    const bool ch0 = col < a.C, ch1 = 32 + col < a.C;
+    for (int pair = gwave; pair < npairs; pair += nwave) {
+        const PairIn in = nxt;
+        const int slot = slot_nxt, owner = owner_nxt;
+        const int m = 2 * pair + half;
+        const bool live = m < a.M, hasB = 2 * pair + 1 < a.M;
+        const bool more = pair + nwave < npairs;
+        if (more) nxt = load(pair + nwave);
+        float y[2];
+        mx_pair_half<ABS>(a, mc, wave_lds, lane, in, hasB, y);
+        if (more) {                                                        // before this pair's stores: vmcnt retires in order and counts stores
+            slot_nxt = slot_of(nxt);
+            if (!a.unique) owner_nxt = *reinterpret_cast<const int *>(cm_b + (unsigned)max(slot_nxt, 0) * 4u);
+        }
+        const bool win = live && slot >= 0 && (a.unique || owner == m);
+        if (live) {
+            if (feat_b) {
+                const unsigned fo = ((unsigned)m * (unsigned)a.C + (unsigned)col) * 4u;
+                if (ch0) *reinterpret_cast<float *>(feat_b + fo) = y[0];
+                if (ch1) *reinterpret_cast<float *>(feat_b + fo + 128u) = y[1];
+            }
+            if (win) {
+                const unsigned co = ((unsigned)slot * (unsigned)a.C + (unsigned)col) * 4u;
+                if (ch0) *reinterpret_cast<float *>(cv_b + co) = y[0];
+                if (ch1) *reinterpret_cast<float *>(cv_b + co + 128u) = y[1];
+            }
+            if (col == 0) {
+                if (dest_b) *reinterpret_cast<int *>(dest_b + (unsigned)m * 4u) = win ? slot : -1;
+                if (reset_cellmap && win) *reinterpret_cast<int *>(cm_b + (unsigned)slot * 4u) = -1;
+            }
+        }
+    }
+}
+
+// The channels-last rows kernel with the encoder the feature set allows (the distance feature is not affine in the point: VALU encoder).
+bool pillar_mfma_enabled() {
+    static const bool on = [] { const char *e = getenv("COALIGN_PILLAR_MFMA"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+void launch_rows(const PfnArgs &a, float *canvas, int *dest, int reset_cellmap, int blocks, hipStream_t stream) {
+    const dim3 grid(blocks), block(kWavesPerBlock * 64);
+    // 32-bit byte offsets in the matrix-core kernel: pillars, feature rows and canvas each below 4 GB
+    const bool small = (size_t)a.M * a.P * 16 < ((size_t)1 << 32) && (size_t)a.M * a.C * 4 < ((size_t)1 << 32) &&
+                       (size_t)a.n_agents * a.ny * a.nx * a.C * 4 < ((size_t)1 << 32);
+    if (a.with_dist || !small || !pillar_mfma_enabled()) hipLaunchKernelGGL(pillar_rows_nhwc_kernel, grid, block, 0, stream, a, canvas, dest, reset_cellmap);
+    else if (a.use_abs) hipLaunchKernelGGL(pillar_rows_mx_kernel<true>, grid, block, 0, stream, a, canvas, dest, reset_cellmap);
+    else hipLaunchKernelGGL(pillar_rows_mx_kernel<false>, grid, block, 0, stream, a, canvas, dest, reset_cellmap);
 }
 
 int launch_canvas(const int *cellmap, const float *feats, int C, int ncell, int n_agents, float *canvas, hipStream_t stream) {
@@ -751,7 +1100,7 @@ static int pillar_vfe_scatter_impl(const float *voxel_features, const int32_t *v
     if (nhwc && (rc = fill_words(canvas, (size_t)n_agents * ncell * C, 0u, stream))) return rc;
 
     if (M > 0) {
-        PfnArgs a;
+        PfnArgs a{};
         a.pts = (const float4 *)voxel_features; a.npts = voxel_num_points; a.coords = (const int4 *)voxel_coords;
         a.M = M; a.P = P;
         a.weight = pfn_weight; a.bias = pfn_bias; a.bn_w = bn_weight; a.bn_b = bn_bias; a.bn_m = bn_mean; a.bn_v = bn_var;
@@ -769,7 +1118,7 @@ static int pillar_vfe_scatter_impl(const float *voxel_features, const int32_t *v
             const int pairs = (M + 1) / 2;
             const int want = (pairs + kWavesPerBlock - 1) / kWavesPerBlock;
             const int cap = 256 * 4;                       // 4 workgroups (16 wavefronts) per CU are resident at this kernel's 112 registers
-            hipLaunchKernelGGL(pillar_rows_nhwc_kernel, dim3(want < cap ? want : cap), dim3(kWavesPerBlock * 64), 0, stream, a, canvas, (int *)nullptr, 0);
+            launch_rows(a, canvas, nullptr, 0, want < cap ? want : cap, stream);
             return check_launch();
         }
         if (P <= 64 && C <= 64 && !getenv("COALIGN_UNFUSED_PILLARS")) {
@@ -782,7 +1131,10 @@ static int pillar_vfe_scatter_impl(const float *voxel_features, const int32_t *v
             f.strips_per_agent = (ncell + kStrip - 1) / kStrip;
             const long nwg = (long)f.strips_per_agent * n_agents;
             f.pillars_per_wg = (int)((M + nwg - 1) / nwg);
-            hipLaunchKernelGGL(pillar_canvas_kernel, dim3(f.strips_per_agent, n_agents), dim3(256), 0, stream, f);
+            const dim3 grid(f.strips_per_agent, n_agents);
+            if (a.with_dist || P > 32 || !pillar_mfma_enabled()) hipLaunchKernelGGL(pillar_canvas_kernel<0>, grid, dim3(256), 0, stream, f);
+            else if (a.use_abs) hipLaunchKernelGGL(pillar_canvas_kernel<1>, grid, dim3(256), 0, stream, f);
+            else hipLaunchKernelGGL(pillar_canvas_kernel<2>, grid, dim3(256), 0, stream, f);
             return check_launch();
         } else if (P <= 64 && C <= 64) {   // ~4 pillars per wave: enough to amortise the parameter load, prefetch hides the rest
             const int blocks = (int)min((long)(M + 4 * kWavesPerBlock - 1) / (4 * kWavesPerBlock), (long)256 * 16);
@@ -820,16 +1172,16 @@ int coalign_pillar_vfe_scatter_nhwc(const float *voxel_features, const int32_t *
                                    workspace, workspace_bytes, stream, true);
 }
 
-int coalign_pillar_encode_persistent(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M, int P,
-                                     const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias,
-                                     const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz, int with_distance,
-                                     const double *voxel_size, const double *range_min, int n_agents, int ny, int nx, float *pillar_features,
-                                     int32_t *dest, int M_prev, float *canvas, int32_t *cellmap, void *stream_) {
+static int encode_persistent_impl(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M, const int32_t *M_dev,
+                                  int P, const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias,
+                                  const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz, int with_distance,
+                                  const double *voxel_size, const double *range_min, int n_agents, int ny, int nx, float *pillar_features,
+                                  int32_t *dest, int M_prev, float *canvas, int32_t *cellmap, int unique, void *stream_) {
     using namespace coalign;
     hipStream_t stream = (hipStream_t)stream_;
     if (M < 0 || M_prev < 0 || P <= 0 || P > 32 || C < 4 || C > 64 || C % 4 || n_agents <= 0 || ny <= 0 || nx <= 0) return COALIGN_ERR_BAD_SHAPE;
-    if (!pfn_weight || !voxel_size || !range_min || !canvas || !cellmap || ((M > 0 || M_prev > 0) && !dest)) return COALIGN_ERR_NULL_POINTER;
-    if (M > 0 && (!voxel_features || !voxel_num_points || !voxel_coords || !pillar_features)) return COALIGN_ERR_NULL_POINTER;
+    if (!pfn_weight || !voxel_size || !range_min || !canvas || (!cellmap && !unique) || ((M > 0 || M_prev > 0) && !dest)) return COALIGN_ERR_NULL_POINTER;
+    if (M > 0 && (!voxel_features || !voxel_num_points || !voxel_coords)) return COALIGN_ERR_NULL_POINTER;
     const bool has_bn = bn_weight || bn_bias || bn_mean || bn_var;
     if (has_bn && !(bn_weight && bn_bias && bn_mean && bn_var)) return COALIGN_ERR_NULL_POINTER;
     if ((size_t)n_agents * ny * nx > (size_t)INT32_MAX) return COALIGN_ERR_BAD_SHAPE;
@@ -837,13 +1189,14 @@ int coalign_pillar_encode_persistent(const float *voxel_features, const int32_t 
     if (Cin > kFeatStride) return COALIGN_ERR_UNSUPPORTED;
     const long threads = (long)M_prev * (C / 4) > M ? (long)M_prev * (C / 4) : M;
     if (threads > 0) {
-        hipLaunchKernelGGL(pillar_prep_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, dest, M_prev, C, canvas,
-                           (const int4 *)voxel_coords, M, n_agents, ny, nx, cellmap);
+        const long blocks = (threads + 255) / 256;
+        hipLaunchKernelGGL(pillar_prep_kernel, dim3((unsigned)(M_dev && blocks > 4096 ? 4096 : blocks)), dim3(256), 0, stream, dest, M_prev, C, canvas,
+                           (const int4 *)voxel_coords, M, M_dev, n_agents, ny, nx, unique ? (int *)nullptr : cellmap);
         int rc = check_launch();
         if (rc) return rc;
     }
     if (M == 0) return COALIGN_OK;
-    PfnArgs a;
+    PfnArgs a{};
     a.pts = (const float4 *)voxel_features; a.npts = voxel_num_points; a.coords = (const int4 *)voxel_coords;
     a.M = M; a.P = P;
     a.weight = pfn_weight; a.bias = pfn_bias; a.bn_w = bn_weight; a.bn_b = bn_bias; a.bn_m = bn_mean; a.bn_v = bn_var;
@@ -853,11 +1206,36 @@ int coalign_pillar_encode_persistent(const float *voxel_features, const int32_t 
     a.yo = (float)(voxel_size[1] / 2 + range_min[1]);
     a.zo = (float)(voxel_size[2] / 2 + range_min[2]);
     a.n_agents = n_agents; a.ny = ny; a.nx = nx; a.feats = pillar_features; a.cellmap = cellmap;
+    a.M_dev = M_dev; a.unique = unique ? 1 : 0;
     const int pairs = (M + 1) / 2;
     const int want = (pairs + kWavesPerBlock - 1) / kWavesPerBlock;
     const int cap = 256 * 4;
-    hipLaunchKernelGGL(pillar_rows_nhwc_kernel, dim3(want < cap ? want : cap), dim3(kWavesPerBlock * 64), 0, stream, a, canvas, dest, 1);
+    launch_rows(a, canvas, dest, unique ? 0 : 1, want < cap ? want : cap, stream);
     return check_launch();
+}
+
+int coalign_pillar_encode_persistent(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M, int P,
+                                     const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias,
+                                     const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz, int with_distance,
+                                     const double *voxel_size, const double *range_min, int n_agents, int ny, int nx, float *pillar_features,
+                                     int32_t *dest, int M_prev, float *canvas, int32_t *cellmap, void *stream) {
+    if (M > 0 && !pillar_features) return COALIGN_ERR_NULL_POINTER;
+    return encode_persistent_impl(voxel_features, voxel_num_points, voxel_coords, M, nullptr, P, pfn_weight, pfn_bias, bn_weight, bn_bias, bn_mean, bn_var,
+                                  bn_eps, C, use_absolute_xyz, with_distance, voxel_size, range_min, n_agents, ny, nx, pillar_features, dest, M_prev,
+                                  canvas, cellmap, 0, stream);
+}
+
+int coalign_pillar_encode_stream(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M_capacity,
+                                 const int32_t *M_dev, int P, const float *pfn_weight, const float *pfn_bias, const float *bn_weight,
+                                 const float *bn_bias, const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz,
+                                 int with_distance, const double *voxel_size, const double *range_min, int n_agents, int ny, int nx,
+                                 float *pillar_features, int32_t *dest_state, float *canvas, int32_t *cellmap, int unique_cells, void *stream) {
+    if (!M_dev || !dest_state) return COALIGN_ERR_NULL_POINTER;
+    if (M_capacity <= 0) return COALIGN_ERR_BAD_SHAPE;
+    // dest_state[0] = rows the previous call wrote (device side), dest_state[1 ..] = their canvas slots
+    return encode_persistent_impl(voxel_features, voxel_num_points, voxel_coords, M_capacity, M_dev, P, pfn_weight, pfn_bias, bn_weight, bn_bias, bn_mean,
+                                  bn_var, bn_eps, C, use_absolute_xyz, with_distance, voxel_size, range_min, n_agents, ny, nx, pillar_features,
+                                  dest_state + 1, M_capacity, canvas, cellmap, unique_cells, stream);
 }
 
 int coalign_scatter_to_bev(const float *pillar_features, const int32_t *voxel_coords, int M, int C, int n_agents, int ny,

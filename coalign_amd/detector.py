@@ -93,6 +93,9 @@ class PointPillarBaselineMultiscale(nn.Module):
         record_len = host_ints(data_dict["record_len"])
         batch_dict = {"voxel_features": pl["voxel_features"], "voxel_coords": pl["voxel_coords"],
                       "voxel_num_points": pl["voxel_num_points"], "record_len": record_len}
+        for k in ("voxel_count_dev", "voxel_cells_unique", "want_pillar_features"):      # the device voxeliser's streaming form (PillarVFE.forward)
+            if k in pl:
+                batch_dict[k] = pl[k]
         batch_dict = self.scatter(self.pillar_vfe(batch_dict))
         spatial_features = batch_dict["spatial_features"]
         H0, W0 = spatial_features.shape[2:]

@@ -82,6 +82,20 @@ class PillarVFE(nn.Module):
         bn = (pfn.norm.weight, pfn.norm.bias, pfn.norm.running_mean, pfn.norm.running_var) if self.use_norm else None
         from . import backbone                       # the canvas layout follows the convolution route that will read it
         channels_last = backbone.NHWC_STAGE_OUTPUTS and backbone.CONV_EMU_TERMS in (2, 3) and backbone.FAST_INFERENCE
+        count_dev = batch_dict.get("voxel_count_dev")
+        if count_dev is not None:
+            # the producer (the device voxeliser) left the pillar count on the device: capacity-sized arrays, no host read of the count,
+            # always the persistent channels-last canvas (FramePipeline.submit_points; include/coalign_amd.h coalign_pillar_encode_stream)
+            if not channels_last:
+                raise ops.hip.CoalignHipError("voxel_count_dev needs the channels-last canvas route (default convolution mode)")
+            feats, canvas = ops.pillar_encode_stream(
+                vf, npts, coords, count_dev, pfn.linear.weight, pfn.linear.bias, bn, pfn.norm.eps if self.use_norm else 0.0,
+                self.use_absolute_xyz, self.with_distance, self.voxel_size, self.point_cloud_range[:3], n_agents, self.ny, self.nx,
+                canvas_cache=self.__dict__.setdefault("_canvas_cache", {}), unique_cells=bool(batch_dict.get("voxel_cells_unique", True)),
+                want_features=bool(batch_dict.get("want_pillar_features", False)))
+            batch_dict["pillar_features"] = feats
+            batch_dict["_fused_canvas"] = (feats, canvas)
+            return batch_dict
         feats, canvas = ops.pillar_vfe_scatter(
             vf, npts, coords, pfn.linear.weight, pfn.linear.bias, bn, pfn.norm.eps if self.use_norm else 0.0,
             self.use_absolute_xyz, self.with_distance, self.voxel_size, self.point_cloud_range[:3], n_agents, self.ny, self.nx,

@@ -27,6 +27,8 @@ SIGNATURES = {
                                                 POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, P, c_size_t, P]),
     "coalign_pillar_encode_persistent": (c_int, [P, P, P, c_int, c_int, P, P, P, P, P, P, c_float, c_int, c_int, c_int,
                                                  POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, c_int, P, P, P]),
+    "coalign_pillar_encode_stream": (c_int, [P, P, P, c_int, P, c_int, P, P, P, P, P, P, c_float, c_int, c_int, c_int,
+                                             POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, P, P, c_int, P]),
     "coalign_scatter_to_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     "coalign_warp_fuse": (c_int, [P, c_int, c_int, c_int, c_int, P, POINTER(c_int32), c_int, c_int, P, c_int, c_int, P]),
     "coalign_normalize_pairwise": (c_int, [P, c_int, c_int, c_int, c_double, c_double, P, P]),

@@ -148,6 +148,50 @@ def pillar_vfe_scatter(voxel_features: torch.Tensor, voxel_num_points: torch.Ten
 
 
 @_device_op
+def pillar_encode_stream(voxel_features: torch.Tensor, voxel_num_points: torch.Tensor, voxel_coords: torch.Tensor, count_dev: torch.Tensor,
+                         weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[Tuple[torch.Tensor, ...]], bn_eps: float,
+                         use_absolute_xyz: bool, with_distance: bool, voxel_size: Sequence[float], range_min: Sequence[float],
+                         n_agents: int, ny: int, nx: int, canvas_cache: dict, unique_cells: bool = True,
+                         want_features: bool = False) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+    """The persistent-canvas encoder behind a producer that keeps its pillar count on the device (``ops.voxelize``): the arrays are
+    capacity sized, ``count_dev`` (int32 device tensor, first element) says how many rows are valid; nothing here reads it on the host, so
+    voxeliser -> encoder -> backbone is one stream of launches (one captured graph).  ``canvas_cache``: as in ``pillar_vfe_scatter`` (one
+    persistent channels-last canvas per device, stream and shape).  -> (pillar_features [capacity, C] or None, canvas [n_agents, C, ny, nx])."""
+    _need_gpu(voxel_features, voxel_num_points, voxel_coords, count_dev, weight)
+    L = hip.lib()
+    vf = _f32c(voxel_features)
+    cap, P = vf.shape[0], vf.shape[1]
+    if vf.dim() != 3 or vf.shape[2] != 4:
+        raise ValueError(f"voxel_features must be [M, P, 4], got {tuple(vf.shape)}")
+    if count_dev.dtype != torch.int32:
+        raise ValueError("count_dev must be an int32 device tensor")
+    npts = voxel_num_points.to(torch.int32).contiguous()
+    coords = voxel_coords.to(torch.int32).contiguous()
+    w = _f32c(weight)
+    C = w.shape[0]
+    dev = vf.device
+    if P > 32 or C > 64 or C % 4:
+        raise hip.CoalignHipError("pillar_encode_stream: the channels-last encoder needs P <= 32 and C <= 64 (a multiple of 4)")
+    key = ("stream", str(dev), torch.cuda.current_stream(dev).cuda_stream, n_agents, C, ny, nx, bool(unique_cells))
+    entry = canvas_cache.get(key)
+    if entry is None or entry["dest"].numel() < cap + 1:
+        entry = canvas_cache[key] = {
+            "canvas": torch.empty((n_agents, C, ny, nx), dtype=torch.float32, device=dev, memory_format=torch.channels_last).zero_(),
+            "cellmap": None if unique_cells else torch.full((n_agents * ny * nx,), -1, dtype=torch.int32, device=dev),
+            "dest": torch.zeros(cap + 1, dtype=torch.int32, device=dev)}
+    canvas = entry["canvas"]
+    feats = torch.empty((cap, C), dtype=torch.float32, device=dev) if want_features else None
+    bnp = [None] * 4 if bn is None else [_f32c(t) for t in bn]
+    b = None if bias is None else _f32c(bias)
+    with _Timed("pillar_encode_stream"):
+        hip.check(L.coalign_pillar_encode_stream(_ptr(vf), _ptr(npts), _ptr(coords), cap, _ptr(count_dev), P, _ptr(w), _ptr(b), _ptr(bnp[0]), _ptr(bnp[1]),
+                                                 _ptr(bnp[2]), _ptr(bnp[3]), float(bn_eps), C, int(use_absolute_xyz), int(with_distance), _dbl3(voxel_size),
+                                                 _dbl3(range_min), n_agents, ny, nx, _ptr(feats), _ptr(entry["dest"]), _ptr(canvas), _ptr(entry["cellmap"]),
+                                                 int(bool(unique_cells)), _stream()), "coalign_pillar_encode_stream")
+    return feats, canvas
+
+
+@_device_op
 def scatter_to_bev(pillar_features: torch.Tensor, voxel_coords: torch.Tensor, n_agents: int, ny: int, nx: int) -> torch.Tensor:
     """pillar_features [M, C] + coords (agent, z, y, x) -> canvas [n_agents, C, ny, nx]."""
     _need_gpu(pillar_features, voxel_coords)

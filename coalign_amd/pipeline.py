@@ -17,6 +17,12 @@ Two launch modes:
   counts should pad ``processed_lidar`` to a bucket size with ``pad_pillars`` (padding rows are ignored by the kernels).
 
 Both modes produce bit-identical detections to ``model(batch)`` + ``post_processor.post_process`` (tests/test_pipeline_gpu.py).
+
+``submit_points`` is the loop as the reference runs it -- from RAW point clouds in host memory (opencood/tools/inference.py:125-130 moves
+the collated batch to the device every frame, train_utils.py:249-258; the voxeliser ran in the DataLoader workers before that,
+sp_voxel_preprocessor.py:62-85): host -> device copy of the frame's clouds out of a pinned staging buffer, ``coalign_voxelize``,
+``coalign_pillar_encode_stream`` (the pillar count never leaves the device) and the rest of the frame, all on the lane's stream -- in graph
+mode one async copy + one replay per frame.  ``latencies_ms`` records, per frame, host time from ``submit*`` to the detections in hand.
 """
 from __future__ import annotations
 
@@ -60,6 +66,7 @@ class _GraphSlot:
         self.buf: Optional[ops.DecodeBuffers] = None
         self.weights_sig = None
         self.canvas_cache: dict = {}
+        self.offsets: Optional[List[int]] = None        # points mode: first point slot of every cloud in the static input buffer
 
 
 class FramePipeline:
@@ -71,7 +78,8 @@ class FramePipeline:
 
     def __init__(self, model, post_processor: VoxelPostprocessor, anchor_box, *, lanes: int = 4, result_lag: int = 1,
                  graph: bool = False, device=None, transformation_matrix: Optional[torch.Tensor] = None,
-                 exchange: Optional[Sequence[Callable]] = None):
+                 exchange: Optional[Sequence[Callable]] = None, preprocessor=None, points_per_cloud: int = 131072,
+                 ego_filter: bool = True, filter_range: Optional[Sequence[float]] = None):
         self.model = model
         self._vfe_flag = None
         if hasattr(model, "pillar_vfe"):
@@ -102,10 +110,23 @@ class FramePipeline:
         self._pending: "collections.deque" = collections.deque()              # (index, handle, keep-alive)
         self._count = 0
         self.host_enqueue_s = 0.0
+        self.latencies_ms: List[float] = []                      # per collected frame: submit -> detections on the host
+        # ---- submit_points: the voxeliser in front of the model
+        self.preprocessor = preprocessor                          # coalign_amd.preprocess.SpVoxelPreprocessor (grid + voxel limits)
+        self.points_per_cloud = int(points_per_cloud)             # slot size of one cloud in the staging buffer (NaN padded)
+        self.ego_filter, self.filter_range = bool(ego_filter), filter_range
+        self._staging: List[Dict[int, torch.Tensor]] = [dict() for _ in range(self.n_lanes)]      # per lane: n_clouds -> pinned [n_clouds * slot, 4]
+        self._staged: List[Optional[torch.cuda.Event]] = [None] * self.n_lanes
 
     # ------------------------------------------------------------------------------------------------ one frame
     def _eager(self, k: int, batch: dict, record: List[int]) -> PostProcessHandle:
         model = self.model
+        if batch.get("_point_offsets") is not None:
+            with ops.timed("stage_h2d+voxelize"):
+                pts = batch["_points_pinned"].to(self.device, non_blocking=True)
+                self._staged[k] = torch.cuda.Event()
+                self._staged[k].record()
+                batch = self._points_batch(pts, batch["_point_offsets"], record, batch["pairwise_t_matrix"].to(self.device, non_blocking=True))
         with ops.timed("stage_encode(pillars+backbone)"):
             feats, affine = model.encode(batch)
         rows = None
@@ -117,9 +138,22 @@ class FramePipeline:
         with ops.timed("stage_post_process(enqueue)"):
             return self.pp.post_process_async(self.meta, {"ego": out}, side_stream=POST_PROCESS_SIDE_STREAM)
 
+    def _points_batch(self, pts: torch.Tensor, offsets: List[int], record: List[int], pairwise) -> dict:
+        """Raw points (device) -> the batch the model takes, pillar count left on the device (PillarVFE's ``voxel_count_dev`` form)."""
+        pre = self.preprocessor
+        voxels, coords, num, counts = ops.voxelize(pts, offsets, pre.voxel_size, pre.lidar_range, pre.max_points_per_voxel, pre.max_voxels,
+                                                   ego_filter=self.ego_filter, filter_range=self.filter_range)
+        n_clouds = len(offsets) - 1
+        return {"processed_lidar": {"voxel_features": voxels, "voxel_coords": coords, "voxel_num_points": num,
+                                    "voxel_count_dev": counts[n_clouds:], "voxel_cells_unique": True},
+                "record_len": record, "pairwise_t_matrix": pairwise}
+
     def _frame_body(self, slot: _GraphSlot, record: List[int]) -> None:
-        batch = {"processed_lidar": {k: slot.inputs[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")},
-                 "record_len": record, "pairwise_t_matrix": slot.inputs["pairwise_t_matrix"]}
+        if slot.offsets is not None:
+            batch = self._points_batch(slot.inputs["points"], slot.offsets, record, slot.inputs["pairwise_t_matrix"])
+        else:
+            batch = {"processed_lidar": {k: slot.inputs[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")},
+                     "record_len": record, "pairwise_t_matrix": slot.inputs["pairwise_t_matrix"]}
         vfe = getattr(self.model, "pillar_vfe", None)
         keep = None if vfe is None else (vfe.persistent_canvas, vfe.__dict__.get("_canvas_cache"))
         try:
@@ -142,23 +176,29 @@ class FramePipeline:
 
     def _graphed(self, k: int, batch: dict, record: List[int]) -> PostProcessHandle:
         stream = self.streams[k]
-        pl = batch["processed_lidar"]
-        src = {"voxel_features": pl["voxel_features"], "voxel_coords": pl["voxel_coords"], "voxel_num_points": pl["voxel_num_points"],
-               "pairwise_t_matrix": batch["pairwise_t_matrix"]}
-        key = (tuple(record),) + tuple((tuple(t.shape), str(t.dtype)) for t in src.values())
+        offsets = batch.get("_point_offsets")
+        if offsets is not None:
+            src = {"points": batch["_points_pinned"], "pairwise_t_matrix": batch["pairwise_t_matrix"]}
+        else:
+            pl = batch["processed_lidar"]
+            src = {"voxel_features": pl["voxel_features"], "voxel_coords": pl["voxel_coords"], "voxel_num_points": pl["voxel_num_points"],
+                   "pairwise_t_matrix": batch["pairwise_t_matrix"]}
+        key = (tuple(record), None if offsets is None else tuple(offsets)) + tuple((tuple(t.shape), str(t.dtype)) for t in src.values())
         slot = self._slots[k].get(key)
         # a graph holds raw pointers to the folded / packed weight images of the moment it was captured: re-capture when any
         # parameter or buffer of the model has been replaced or written since (load_state_dict, fine-tuning between runs)
         sig = self._weights_signature()
         if slot is not None and slot.weights_sig != sig:
+            self._slots[k].pop(key)
             slot = None
         if slot is None:
             if len(self._slots[k]) >= self.max_graphs_per_lane:      # bound the memory captured frames hold (one private pool + canvas each)
                 self._slots[k].pop(next(iter(self._slots[k])))
-            slot = self._slots[k][key] = _GraphSlot()
+            slot = _GraphSlot()
             slot.weights_sig = sig
+            slot.offsets = None if offsets is None else list(offsets)
             for name, t in src.items():
-                slot.inputs[name] = torch.empty_like(t, device=self.device)
+                slot.inputs[name] = torch.empty(t.shape, dtype=t.dtype, device=self.device)
                 slot.inputs[name].copy_(t, non_blocking=True)
             self._frame_body(slot, record)                      # eager warm-up on the lane: MIOpen find, weight folds, anchors, buffers
             stream.synchronize()
@@ -166,23 +206,60 @@ class FramePipeline:
             with torch.cuda.graph(g, stream=stream):
                 self._frame_body(slot, record)
             slot.graph = g
+            self._slots[k][key] = slot                          # only a slot whose capture succeeded is ever looked up again
         for name, t in src.items():
             slot.inputs[name].copy_(t, non_blocking=True)
+        if offsets is not None:
+            self._staged[k] = torch.cuda.Event()
+            self._staged[k].record(stream)                      # the pinned staging buffer may be refilled once this has passed
         slot.graph.replay()
         done = torch.cuda.Event()
         done.record(stream)
         return PostProcessHandle(self.pp, slot.buf, done)
 
     def _weights_signature(self) -> tuple:
-        ts = self.__dict__.get("_weight_tensors")
-        if ts is None:
-            ts = self.__dict__["_weight_tensors"] = list(self.model.parameters()) + list(self.model.buffers())
-        return tuple((t.data_ptr(), t._version) for t in ts)
+        # rebuilt on every call: parameters replaced as objects (load_state_dict(assign=True), module surgery) change the list itself
+        return tuple((id(t), t.data_ptr(), t._version) for t in list(self.model.parameters()) + list(self.model.buffers()))
 
     # ------------------------------------------------------------------------------------------------ the loop
-    def submit(self, batch: dict) -> List[FrameResult]:
+    def submit_points(self, frame: dict) -> List[FrameResult]:
+        """One frame from raw clouds in HOST memory: ``frame`` = {"clouds": [ndarray / CPU tensor [n_i, 4] float32 per cav, ego first],
+        "record_len": [N] (or [n_1, n_2, ...] for a batch), "pairwise_t_matrix": float64 [B, L, L, 4, 4]}.  The clouds are packed into the
+        lane's pinned staging buffer (``points_per_cloud`` slots per cloud, the tail NaN: the voxeliser rejects NaN coordinates) and the
+        frame goes: async copy -> voxelise -> encode -> fuse -> heads -> decode -> NMS.  Returns the frames that completed, like ``submit``."""
+        if self.preprocessor is None:
+            raise ValueError("submit_points needs FramePipeline(preprocessor=SpVoxelPreprocessor(...)): grid, max points / voxels")
+        if self.exchange is not None:
+            raise ValueError("submit_points is the single-GPU feeder path")
+        import time
+        t_sub = time.perf_counter()
+        clouds = frame["clouds"]
+        n, S = len(clouds), self.points_per_cloud
+        k = self._count % self.n_lanes
+        done: List[FrameResult] = []
+        if self.graph and self._lane_busy[k] is not None:
+            done += self._collect_through(self._lane_busy[k])
+        stage = self._staging[k].get(n)
+        if stage is None:
+            stage = self._staging[k][n] = torch.empty((n * S, 4), dtype=torch.float32).pin_memory()
+        if self._staged[k] is not None:
+            self._staged[k].synchronize()                        # the previous copy out of this buffer has left the host
+        view = stage.view(n, S, 4).numpy()
+        for i, c in enumerate(clouds):
+            c = c.numpy() if torch.is_tensor(c) else np.asarray(c, dtype=np.float32)
+            if c.shape[0] > S:
+                raise ValueError(f"cloud {i} has {c.shape[0]} points; FramePipeline(points_per_cloud={S}) is the slot size")
+            view[i, : c.shape[0]] = c
+            view[i, c.shape[0]:] = np.nan
+        pw = frame["pairwise_t_matrix"]
+        pw = pw if torch.is_tensor(pw) else torch.from_numpy(np.asarray(pw))
+        batch = {"record_len": frame["record_len"], "pairwise_t_matrix": pw, "_points_pinned": stage, "_point_offsets": [i * S for i in range(n + 1)]}
+        return done + self.submit(batch, _t_submit=t_sub)
+
+    def submit(self, batch: dict, _t_submit: Optional[float] = None) -> List[FrameResult]:
         import time
         t0 = time.perf_counter()
+        t_sub = t0 if _t_submit is None else _t_submit
         idx = self._count
         k = idx % self.n_lanes
         self._count += 1
@@ -198,15 +275,17 @@ class FramePipeline:
             with torch.cuda.stream(stream):
                 handle = self._graphed(k, batch, record) if self.graph else self._eager(k, batch, record)
         self._lane_busy[k] = idx
-        self._pending.append((idx, handle, batch))              # the batch stays referenced until its frame has completed
+        self._pending.append((idx, handle, batch, t_sub))       # the batch stays referenced until its frame has completed
         self.host_enqueue_s += time.perf_counter() - t0         # launch work only: waiting for older frames' results is GPU time
         while len(self._pending) > self.result_lag:
             done.append(self._pop())
         return done
 
     def _pop(self) -> FrameResult:
-        idx, handle, _keep = self._pending.popleft()
+        import time
+        idx, handle, _keep, t_sub = self._pending.popleft()
         boxes, scores = handle.result()
+        self.latencies_ms.append((time.perf_counter() - t_sub) * 1e3)
         k = idx % self.n_lanes
         if self._lane_busy[k] == idx:
             self._lane_busy[k] = None

@@ -177,3 +177,14 @@ def make_point_cloud(seed: int, beams: int = 64, azimuth_steps: int = 1800, sens
     t = np.where(hit, t, 0.0) + rs.normal(0, 0.02, t.shape)
     pts = np.stack([t * dx, t * dy, t * dz, rs.uniform(0, 1, t.shape)], axis=-1)[hit]
     return np.ascontiguousarray(pts, dtype=np.float32)
+
+
+def make_points_frame(hypes: dict, n_agents: int, seed: int = 303, noise: Optional[Sequence[float]] = None, **cloud_kw) -> Dict:
+    """A frame as the reference's loader holds it BEFORE the voxeliser: one raw sweep per cav (``make_point_cloud``, each in its own sensor
+    frame, ~65 k points) + poses -> {"clouds": [ndarray [n_i, 4]], "record_len": [n_agents], "pairwise_t_matrix": float64 [1, L, L, 4, 4]} --
+    the input of ``FramePipeline.submit_points``."""
+    rng = np.random.RandomState(seed)
+    L = max(int(hypes.get("train_params", {}).get("max_cav", 5)), n_agents)
+    clouds = [make_point_cloud(seed * 16 + i, **cloud_kw) for i in range(n_agents)]
+    poses = make_poses(rng, n_agents, noise=noise)
+    return {"clouds": clouds, "record_len": [n_agents], "pairwise_t_matrix": torch.from_numpy(get_pairwise_transformation(poses, L)[None])}

@@ -84,6 +84,18 @@ int coalign_pillar_encode_persistent(const float *voxel_features, const int32_t 
                                      const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz, int with_distance,
                                      const double *voxel_size, const double *range_min, int n_agents, int ny, int nx, float *pillar_features,
                                      int32_t *dest, int M_prev, float *canvas, int32_t *cellmap, void *stream);
+/* The same for a producer that leaves its pillar count ON THE DEVICE (coalign_voxelize's voxel_counts word): nothing on the host depends on
+ * the count, so the call can sit behind the voxeliser in one stream / one captured HIP graph -- the reference's loop reads the count back
+ * through collate_batch (sp_voxel_preprocessor.py:145-174) and train_utils.to_device (train_utils.py:249-258) before the model starts.
+ * The arrays hold M_capacity rows, *M_dev (clamped to [0, M_capacity]) of them valid.  dest_state [M_capacity + 1] int32 is the caller's
+ * persistent list: element 0 = rows the previous call wrote (zero it once), elements 1.. = their canvas slots.  pillar_features may be NULL
+ * (the canvas is the only consumer in the inference loop).  unique_cells != 0: the caller guarantees at most one pillar per cell (true of
+ * every voxeliser's output) -- no cell map is consulted and cellmap may be NULL; otherwise the duplicate rule of (1) applies. */
+int coalign_pillar_encode_stream(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M_capacity,
+                                 const int32_t *M_dev, int P, const float *pfn_weight, const float *pfn_bias, const float *bn_weight,
+                                 const float *bn_bias, const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz,
+                                 int with_distance, const double *voxel_size, const double *range_min, int n_agents, int ny, int nx,
+                                 float *pillar_features, int32_t *dest_state, float *canvas, int32_t *cellmap, int unique_cells, void *stream);
 /* Scatter only (PointPillarScatter.forward on already-encoded pillars): pillar_features [M, C] -> canvas.
  * Same cell rule, duplicate rule and workspace as above. */
 int coalign_scatter_to_bev(const float *pillar_features, const int32_t *voxel_coords, int M, int C, int n_agents, int ny,
