@@ -231,6 +231,9 @@ void conv3x3_kernel(const ConvArgs a) {
         // The hand-over of a split tile uses agent-scope *write-through* stores / L2-bypassing loads (relaxed atomics) and no
         // fences: an agent-scope release / acquire fence writes back and invalidates the whole L2 of the XCD -- with hundreds of
         // workgroups doing that, the weights and patches of everybody else kept being evicted (measured: 141 -> 382 us).
+        // Ordering without fences: write-through stores -> s_waitcnt vmcnt(0) -> workgroup barrier -> flag store on the producer side;
+        // flag load (L2 bypass) -> workgroup barrier -> L2-bypassing loads on the consumer side.  The step-by-step argument stands next to
+        // the same code in conv3x3_emu.hip; tests/test_round3_gpu.py::test_stream_k_handover_stress[fp32] guards this kernel.
         // (slot layout [wave][q][lane]: one base pointer per 16 values + immediate offsets, so the addresses cost four registers)
         if (SPLIT && !head) {              // contributor: publish the partial sums of the tile's last chunks (slot g)
             float *slot = a.partial + (size_t)g * (16 * G::NCO * G::THREADS) + (size_t)wave * (16 * G::NCO * 64) + lane;

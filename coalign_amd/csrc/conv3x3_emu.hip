@@ -243,7 +243,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
             if (ins < G::WUNITS * G::WINSTR) {
                 if constexpr (VAR & VAR_ASM_DMA) {
                     const unsigned dst = (unsigned)(size_t)(lptr_t)(wdst + ins * 256);      // wave-uniform LDS byte address -> M0
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(dst)), "v"(wsrc + ins * 64) : "memory");
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(dst)), "v"(wsrc + ins * 64) : "memory", "m0");
                 } else {
                     __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ins * 64), (lptr_t)(wdst + ins * 256), 16, 0, 0);
                 }
@@ -406,6 +406,18 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         }
         // The hand-over of a split tile uses agent-scope *write-through* stores / L2-bypassing loads (relaxed atomics) and no
         // fences (an agent-scope fence writes back and invalidates the XCD's whole L2; see conv3x3.hip).
+        // Why this is ordered although every access is memory_order_relaxed (the C++ model alone does not give it; the ISA does):
+        //   producer  (1) the partial sums leave as agent-scope atomic stores = write-through (sc1), they never sit dirty in the
+        //                 XCD-private L2;  (2) s_waitcnt vmcnt(0): each wave's stores have been ACKNOWLEDGED, i.e. are visible at agent
+        //                 scope;  (3) the workgroup barrier: that holds for all waves;  (4) only then is the flag store issued -- stores
+        //                 are not speculated, so "flag visible" implies "partials visible".
+        //   consumer  (5) one thread spins on an agent-scope atomic load of the flag (bypasses L2, sees the coherent value);  (6) the
+        //                 barrier releases the workgroup, and __syncthreads is a compiler barrier for memory operations;  (7) the
+        //                 partials are read by agent-scope atomic loads ISSUED after the barrier: they bypass the cache, so no stale
+        //                 line can satisfy them, and the hardware neither hoists nor speculates vector loads across s_barrier.
+        //   flags are zeroed by a kernel earlier on the stream (fill_words) and each (launch, g) writes its flag once.
+        // Guarded by tests/test_round3_gpu.py::test_stream_k_handover_stress (thousands of launches next to a second busy stream,
+        // bit-equality every time); the same argument and test cover conv3x3.hip.
         // slot layout [wave][q][lane]: one base pointer per 16 values + immediate offsets (q x 256 B), so the 32 addresses cost
         // four registers, not sixty-four
         if (SPLIT && !head) {              // contributor: publish the partial sums of the tile's last chunks (slot g)
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(64 * (NC + 4)) void conv3x3_emu_pc_kernel(const Emu
                 const int ins = pw + G::NP * j;
                 if (ins < G::WINSTR) {
                     const unsigned dst = (unsigned)(size_t)(lptr_t)(wdst + ins * 256);
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(dst)), "v"(wsrc + ins * 64) : "memory");
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(dst)), "v"(wsrc + ins * 64) : "memory", "m0");
                 }
             }
         };

@@ -16,6 +16,8 @@
 //                  the row ORs into the later words are parallel over lanes
 //   gather_kernel  kept boxes with all 8 corners inside the range (float64 compare), order preserving
 // Compiled with -ffp-contract=off so the float64 arithmetic is bit-identical to the gcc-built CPU oracle.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -214,6 +216,269 @@ __global__ __launch_bounds__(64) void reduce_kernel(const unsigned long long *__
         coalign::wave_lds_sync();
     }
     if (lane == 0) *keep_count = cnt;
+}
+
+// ------------------------------------------------------------------------------------------------ round 3: the fast path (top <= 1024)
+// The three kernels above cost 24 + 50 + 105-120 us at K ~ 600 (profiles/round2): a handful of workgroups looping over K serially in
+// rank_kernel, 512 B of scratch per lane in mask_kernel (the clipper's dynamically indexed polygon buffers) with 9 of 10 lanes idle behind
+// the bounding-box test, and a single wavefront walking global memory in reduce_kernel.  Same arithmetic, same results, restructured:
+//   rank16_kernel   16 lanes per candidate (DPP row sum of the partial counts): 16 x the workgroups, 1/16 of the serial loop
+//   mask2_kernel    per 64 x 64 tile: bounding-box test for all pairs (one ballot per row), the surviving pairs COMPACTED into an LDS list,
+//                   then every lane clips one listed pair at a time with its polygon buffers in LDS ([slot][lane]: conflict free,
+//                   dynamic indexing costs nothing there); bits land in the tile's words by LDS atomics
+//   reduce2_kernel  one 16-wave workgroup: the whole bitmask (<= 1024 x 16 words = 128 KB) and the order list are brought into LDS by all
+//                   threads at once, wavefront 0 walks the blocks out of LDS -- the suppression word of a block is an OR over the earlier
+//                   kept rows taken lane-parallel (row q * 64 + lane, one LDS read per earlier block) and reduced across the wave -- and
+//                   all 1024 threads then run the in-range gather (optional), so decode -> detections is rank, mask, reduce: 3 launches.
+__device__ __forceinline__ int row16_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);      // quad_perm [2, 3, 0, 1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);     // row_mirror
+    return v;
+}
+
+__global__ __launch_bounds__(256) void rank16_kernel(const float *__restrict__ scores, const uint8_t *__restrict__ valid, int Kcap, const int *K_dev,
+                                                     int top, int *__restrict__ order, int *__restrict__ n_sorted) {
+    __shared__ float tile[256];
+    const int K = live_k(K_dev, Kcap);
+    const int i0 = blockIdx.x * 16;
+    if (i0 >= K && blockIdx.x != 0) return;
+    const int sub = threadIdx.x & 15, i = i0 + (threadIdx.x >> 4);
+    const float nanv = __builtin_nanf("");
+    float si = nanv;
+    if (i < K && (!valid || valid[i])) si = scores[i];
+    const bool vi = si == si;
+    int rank = 0, nvalid = 0;
+    for (int j0 = 0; j0 < K; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        float sj = nanv;
+        if (j < K && (!valid || valid[j])) sj = scores[j];
+        __syncthreads();
+        tile[threadIdx.x] = sj;
+        __syncthreads();
+        const int lim = min(256, K - j0);
+        for (int q = sub; q < lim; q += 16) {
+            const float s = tile[q];
+            nvalid += (s == s);
+            rank += (s > si) || (s == si && (j0 + q) > i);     // the key of rank_kernel: score descending, index descending
+        }
+    }
+    rank = row16_sum(rank);
+    nvalid = row16_sum(nvalid);
+    if (sub == 0 && vi && rank < top) order[rank] = i;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_sorted = nvalid < top ? nvalid : top;
+}
+
+constexpr int kM2 = 256;          // threads of a mask2 workgroup
+constexpr int kSlots = 12;        // polygon buffer entries per lane (quad_iou's buf0 / buf1)
+
+struct LaneBuf {                  // one lane's polygon buffer in LDS: entry i at base[i * kM2]
+    P2 *base;
+    __device__ __forceinline__ P2 &operator[](int i) const { return base[i * kM2]; }
+};
+
+// clip_halfplane / signed_area / quad_iou on LaneBuf storage: the same operations in the same order (bit-identical results)
+__device__ __forceinline__ int clip_halfplane_l(const LaneBuf subj, int n, P2 q0, P2 q1, double sgn, const LaneBuf out) {
+    int m = 0;
+    const double ex = q1.x - q0.x, ey = q1.y - q0.y;
+    for (int i = 0; i < n; ++i) {
+        const P2 s = subj[i], e = subj[(i + 1 == n) ? 0 : i + 1];
+        const double ds = sgn * (ex * (s.y - q0.y) - ey * (s.x - q0.x));
+        const double de = sgn * (ex * (e.y - q0.y) - ey * (e.x - q0.x));
+        const bool s_in = ds >= 0.0, e_in = de >= 0.0;
+        if (s_in) out[m++] = s;
+        if (s_in != e_in) {
+            const double t = ds / (ds - de);
+            P2 r;
+            r.x = s.x + t * (e.x - s.x);
+            r.y = s.y + t * (e.y - s.y);
+            out[m++] = r;
+        }
+    }
+    return m;
+}
+
+__device__ __forceinline__ double quad_iou_l(const P2 *a, double area_a, const P2 *b, double area_b, double sgn_b, LaneBuf buf0, LaneBuf buf1) {
+    int n = 4;
+    for (int i = 0; i < 4; ++i) buf0[i] = a[i];
+    LaneBuf src = buf0, dst = buf1;
+    for (int k = 0; k < 4 && n > 0; ++k) {
+        n = clip_halfplane_l(src, n, b[k], b[(k + 1) & 3], sgn_b, dst);
+        const LaneBuf t = src; src = dst; dst = t;
+    }
+    double inter = 0.0;
+    if (n >= 3) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const P2 p = src[i], q = src[(i + 1 == n) ? 0 : i + 1];
+            s += p.x * q.y - q.x * p.y;
+        }
+        inter = fabs(0.5 * s);
+    }
+    const double uni = area_a + area_b - inter;
+    return inter / uni;
+}
+
+__global__ __launch_bounds__(kM2) void mask2_kernel(const float *__restrict__ boxes, int rows, int cols, const int *__restrict__ order,
+                                                    const int *__restrict__ n_sorted, float thr, int nb, unsigned long long *__restrict__ mask) {
+    const int cb = blockIdx.x, rb = blockIdx.y;
+    if (cb < rb) return;
+    const int n = *n_sorted;
+    if (rb * 64 >= n || cb * 64 >= n) return;
+    __shared__ Poly colp[64], rowp[64];
+    __shared__ unsigned long long cand[64];
+    __shared__ unsigned res32[128];
+    __shared__ int rowbase[65];
+    __shared__ unsigned short list[4096];
+    __shared__ __attribute__((aligned(16))) P2 pbuf[2 * kSlots * kM2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (wv == 0) {
+        const int j = cb * 64 + lane;
+        if (j < n) load_poly(boxes, rows, cols, order[j], colp[lane]);
+    } else if (wv == 1) {
+        const int i = rb * 64 + lane;
+        if (i < n) load_poly(boxes, rows, cols, order[i], rowp[lane]);
+    }
+    if (tid < 128) res32[tid] = 0u;
+    __syncthreads();
+    // ---- every pair of the tile: only the bounding-box test (disjoint boxes => intersection exactly 0 => never '>' a non-negative thr)
+    const int j = cb * 64 + lane;
+    {
+        double cx0 = 0, cx1 = 0, cy0 = 0, cy1 = 0;
+        if (j < n) { cx0 = colp[lane].xmin; cx1 = colp[lane].xmax; cy0 = colp[lane].ymin; cy1 = colp[lane].ymax; }
+        for (int r = 0; r < 16; ++r) {
+            const int il = wv * 16 + r, i = rb * 64 + il;
+            bool c = false;
+            if (i < n && j < n && j > i) {
+                const Poly &row = rowp[il];
+                c = !(thr >= 0.f && (row.xmax < cx0 || cx1 < row.xmin || row.ymax < cy0 || cy1 < row.ymin));
+            }
+            const unsigned long long w = __ballot(c);
+            if (lane == 0) cand[il] = w;
+        }
+    }
+    __syncthreads();
+    if (wv == 0) {                                           // exclusive scan of the rows' candidate counts
+        const int cnt = __popcll(cand[lane]);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        rowbase[lane] = incl - cnt;
+        if (lane == 63) rowbase[64] = incl;
+    }
+    __syncthreads();
+    for (int r = 0; r < 16; ++r) {
+        const int il = wv * 16 + r;
+        const unsigned long long w = cand[il];
+        if ((w >> lane) & 1ull) list[rowbase[il] + __popcll(w & ((1ull << lane) - 1ull))] = (unsigned short)((il << 6) | lane);
+    }
+    __syncthreads();
+    // ---- the listed pairs, one per lane and round: float64 convex clipping, polygon buffers in LDS
+    const int total = rowbase[64];
+    const LaneBuf b0{pbuf + tid}, b1{pbuf + kSlots * kM2 + tid};
+    for (int c = tid; c < total; c += kM2) {
+        const int e = list[c], il = e >> 6, jl = e & 63;
+        const Poly &row = rowp[il];
+        const Poly &col = colp[jl];
+        if ((float)quad_iou_l(row.v, row.area, col.v, col.area, col.sgn, b0, b1) > thr) atomicOr(&res32[il * 2 + (jl >> 5)], 1u << (jl & 31));
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int i = rb * 64 + tid;
+        if (i < n) mask[(size_t)i * nb + cb] = (unsigned long long)res32[2 * tid] | ((unsigned long long)res32[2 * tid + 1] << 32);
+    }
+}
+
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        lo |= (unsigned)__shfl_xor((int)lo, d);
+        hi |= (unsigned)__shfl_xor((int)hi, d);
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+constexpr int kR2Rows = 1024, kR2Words = 16;      // reduce2: top <= 1024
+
+__global__ __launch_bounds__(1024) void reduce2_kernel(const unsigned long long *__restrict__ mask, const int *__restrict__ order,
+                                                       const int *__restrict__ n_sorted, int nb, int *__restrict__ keep, int *__restrict__ keep_count,
+                                                       int do_gather, const float *__restrict__ corners, int box_floats, const float *__restrict__ scores,
+                                                       double x0, double y0, double z0, double x1, double y1, double z1,
+                                                       float *__restrict__ out_corners, float *__restrict__ out_scores, int *__restrict__ out_count) {
+    __shared__ unsigned long long rows[kR2Rows * kR2Words];
+    __shared__ unsigned long long kbs[kR2Words];
+    __shared__ int ord[kR2Rows], keep_l[kR2Rows];
+    __shared__ int wcnt[16];
+    __shared__ int s_total;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = *n_sorted;
+    const int nblk = (n + 63) / 64;
+    for (int e = tid; e < n * nb; e += 1024) {
+        const int r = e / nb, w = e - r * nb;
+        rows[e] = (w >= (r >> 6)) ? mask[e] : 0ull;           // words left of the diagonal are never produced nor needed
+    }
+    for (int e = tid; e < n; e += 1024) ord[e] = order[e];
+    __syncthreads();
+    if (wv == 0) {
+        int cnt = 0;
+        for (int b = 0; b < nblk; ++b) {
+            const int nrow = min(64, n - b * 64);
+            unsigned long long acc = 0ull;
+            for (int q = 0; q < b; ++q)
+                if ((kbs[q] >> lane) & 1ull) acc |= rows[(q * 64 + lane) * nb + b];
+            unsigned long long rem = readlane64(wave_or64(acc), 0);       // scalar from here on: the walk below runs on the scalar unit
+            const unsigned long long diag = (lane < nrow) ? rows[(b * 64 + lane) * nb + b] : 0ull;
+            const unsigned long long valid = nrow == 64 ? ~0ull : ((1ull << nrow) - 1ull);
+            unsigned long long keepbits = 0, alive = ~rem & valid;
+            while (alive) {                                   // the inherently sequential part: only the boxes still alive
+                const int t = __ffsll((long long)alive) - 1;
+                keepbits |= 1ull << t;
+                rem |= readlane64(diag, t);
+                const unsigned long long above = (t == 63) ? 0ull : (~0ull << (t + 1));
+                alive = ~rem & valid & above;
+            }
+            if ((keepbits >> lane) & 1ull) keep_l[cnt + __popcll(keepbits & ((1ull << lane) - 1ull))] = ord[b * 64 + lane];
+            cnt += __popcll(keepbits);
+            if (lane == 0) kbs[b] = keepbits;
+            coalign::wave_lds_sync();
+        }
+        if (lane == 0) { s_total = cnt; *keep_count = cnt; }
+    }
+    __syncthreads();
+    const int total = s_total;
+    if (tid < total) keep[tid] = keep_l[tid];
+    if (!do_gather) return;
+    // ---- in-range gather (gather_kernel's rule: all 8 corners inside the range, float64 compare), order preserving
+    bool ok = false;
+    int src = 0;
+    if (tid < total) {
+        src = keep_l[tid];
+        const float *c = corners + (size_t)src * 24;
+        ok = true;
+        for (int k = 0; k < 8; ++k) {
+            const double X = c[3 * k], Y = c[3 * k + 1], Z = c[3 * k + 2];
+            ok = ok && X >= x0 && X <= x1 && Y >= y0 && Y <= y1 && Z >= z0 && Z <= z1;
+        }
+    }
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) wcnt[wv] = __popcll(m);
+    __syncthreads();
+    int pos = __popcll(m & ((1ull << lane) - 1ull)), tot = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wv) pos += wcnt[w];
+        tot += wcnt[w];
+    }
+    if (ok) {
+        for (int k = 0; k < 24; ++k) out_corners[(size_t)pos * 24 + k] = corners[(size_t)src * 24 + k];
+        out_scores[pos] = scores[src];
+    }
+    if (tid == 0) *out_count = tot;
+    (void)box_floats;
 }
 
 // ------------------------------------------------------------------------------------------------ gather
@@ -495,27 +760,67 @@ size_t coalign_nms_rotated_workspace_bytes(int K, int top) {
     return coalign::align_up((size_t)top * nb * 8, 256) + coalign::align_up((size_t)top * 4, 256) + 256;
 }
 
-int coalign_nms_rotated(const float *boxes, int rows, int cols, const float *scores, const uint8_t *valid, int K,
-                        const int32_t *K_dev, float iou_thr, int top, int32_t *keep, int32_t *keep_count, void *workspace,
-                        size_t workspace_bytes, void *stream_) {
+static int nms_rotated_impl(const float *boxes, int rows, int cols, const float *scores, const uint8_t *valid, int K, const int32_t *K_dev,
+                            float iou_thr, int top, int32_t *keep, int32_t *keep_count, void *workspace, size_t workspace_bytes,
+                            const double *range6_host, float *out_corners, float *out_scores, int32_t *out_count, void *stream_) {
     using namespace coalign;
     hipStream_t stream = (hipStream_t)stream_;
+    const bool gather = range6_host != nullptr;
     if (K < 0 || rows < 4 || cols < 2 || top <= 0) return COALIGN_ERR_BAD_SHAPE;
     if (top > 4096) return COALIGN_ERR_UNSUPPORTED;
     if (!keep_count || !workspace || !keep) return COALIGN_ERR_NULL_POINTER;
+    if (gather && (rows != 8 || cols != 3)) return COALIGN_ERR_BAD_SHAPE;                 // the gather copies [8, 3] corner blocks
+    if (gather && top > kR2Rows) return COALIGN_ERR_UNSUPPORTED;
+    if (gather && (!out_corners || !out_scores || !out_count)) return COALIGN_ERR_NULL_POINTER;
     if (workspace_bytes < coalign_nms_rotated_workspace_bytes(K, top)) return COALIGN_ERR_WORKSPACE;
-    if (K == 0) return fill_words(keep_count, 1, 0u, stream);
+    if (K == 0) {
+        int rc = fill_words(keep_count, 1, 0u, stream);
+        if (!rc && gather) rc = fill_words(out_count, 1, 0u, stream);
+        return rc;
+    }
     if (!boxes || !scores) return COALIGN_ERR_NULL_POINTER;
     NmsWs w = carve(workspace, top);
     const int nb = (top + 63) / 64;
-    hipLaunchKernelGGL(rank_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, scores, valid, K, K_dev, top, w.order, w.n_sorted);
-    int rc = check_launch();
-    if (rc) return rc;
-    hipLaunchKernelGGL(mask_kernel, dim3(nb, nb), dim3(kMaskWaves * 64), 0, stream, boxes, rows, cols, w.order, w.n_sorted, iou_thr, nb, w.mask);
+    static const bool legacy = [] { const char *e = getenv("COALIGN_NMS_LEGACY"); return e && e[0] == '1'; }();      // measurement switch: round-2 kernels
+    const bool fast = top <= kR2Rows && !legacy;
+    int rc;
+    if (fast) hipLaunchKernelGGL(rank16_kernel, dim3((K + 15) / 16), dim3(256), 0, stream, scores, valid, K, K_dev, top, w.order, w.n_sorted);
+    else hipLaunchKernelGGL(rank_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, scores, valid, K, K_dev, top, w.order, w.n_sorted);
     if ((rc = check_launch())) return rc;
+    if (fast) hipLaunchKernelGGL(mask2_kernel, dim3(nb, nb), dim3(kM2), 0, stream, boxes, rows, cols, w.order, w.n_sorted, iou_thr, nb, w.mask);
+    else hipLaunchKernelGGL(mask_kernel, dim3(nb, nb), dim3(kMaskWaves * 64), 0, stream, boxes, rows, cols, w.order, w.n_sorted, iou_thr, nb, w.mask);
+    if ((rc = check_launch())) return rc;
+    const double zero6[6] = {0, 0, 0, 0, 0, 0};
+    const double *r = gather ? range6_host : zero6;
+    if (fast) {
+        hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(1024), 0, stream, w.mask, w.order, w.n_sorted, nb, keep, keep_count, gather ? 1 : 0, boxes,
+                           rows * cols, scores, r[0], r[1], r[2], r[3], r[4], r[5], out_corners, out_scores, out_count);
+        return check_launch();
+    }
     hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(64), (size_t)64 * nb * sizeof(unsigned long long), stream, w.mask, w.order,
                        w.n_sorted, nb, keep, keep_count);
-    return check_launch();
+    if ((rc = check_launch())) return rc;
+    if (gather) {
+        hipLaunchKernelGGL(gather_kernel, dim3(1), dim3(1024), 0, stream, boxes, scores, keep, keep_count, top, r[0], r[1], r[2], r[3], r[4], r[5],
+                           out_corners, out_scores, out_count);
+        return check_launch();
+    }
+    return COALIGN_OK;
+}
+
+int coalign_nms_rotated(const float *boxes, int rows, int cols, const float *scores, const uint8_t *valid, int K,
+                        const int32_t *K_dev, float iou_thr, int top, int32_t *keep, int32_t *keep_count, void *workspace,
+                        size_t workspace_bytes, void *stream) {
+    return nms_rotated_impl(boxes, rows, cols, scores, valid, K, K_dev, iou_thr, top, keep, keep_count, workspace, workspace_bytes, nullptr, nullptr,
+                            nullptr, nullptr, stream);
+}
+
+int coalign_nms_rotated_gather(const float *corners, const float *scores, const uint8_t *valid, int K, const int32_t *K_dev, float iou_thr, int top,
+                               int32_t *keep, int32_t *keep_count, const double *range6_host, float *out_corners, float *out_scores,
+                               int32_t *out_count, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!range6_host) return COALIGN_ERR_NULL_POINTER;
+    return nms_rotated_impl(corners, 8, 3, scores, valid, K, K_dev, iou_thr, top, keep, keep_count, workspace, workspace_bytes, range6_host, out_corners,
+                            out_scores, out_count, stream);
 }
 
 int coalign_gather_in_range(const float *corners, const float *scores, const int32_t *keep, const int32_t *keep_count,

@@ -997,7 +997,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(Pfn
         const bool ok = p.cd.x >= 0 && p.cd.x < a.n_agents && cell >= 0 && cell < ncell;
         return ok ? p.cd.x * ncell + cell : -1;
     };
+    // Two pairs ahead: one wave keeps 2 KB of point loads in flight (4096 waves x 1 KB were latency bound at ~2 TB/s, measured)
     PairIn nxt = load(gwave);
+    PairIn nx2 = load(min(gwave + nwave, npairs - 1));
     const MxChan mc = load_mx<ABS>(a, lane);
     *reinterpret_cast<uint4 *>(wave_lds + lane * kRowBytes + 48) = make_uint4(0u, 0u, 0u, 0u);          // part 3 of every row: the zero half of step 2
     int slot_nxt = slot_of(nxt);
@@ -1009,7 +1011,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(Pfn
         const int m = 2 * pair + half;
         const bool live = m < a.M, hasB = 2 * pair + 1 < a.M;
         const bool more = pair + nwave < npairs;
-        if (more) nxt = load(pair + nwave);
+        nxt = nx2;
+        if (pair + 2 * nwave < npairs) nx2 = load(pair + 2 * nwave);
         float y[2];
         mx_pair_half<ABS>(a, mc, wave_lds, lane, in, hasB, y);
         if (more) {                                                        // before this pair's stores: vmcnt retires in order and counts stores

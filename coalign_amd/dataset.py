@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import box_align
-from .pose import generate_noise, get_pairwise_transformation, x_to_world
+from .pose import generate_noise, generate_noise_laplace, get_pairwise_transformation, x_to_world
 from .postprocess import build_postprocessor
 from .preprocess import build_preprocessor
 
@@ -81,9 +81,8 @@ def add_noise_data_dict(data_dict: dict, noise_setting: dict, rng: Optional[np.r
         cav["params"]["lidar_pose_clean"] = cav["params"]["lidar_pose"]
         if noise_setting["add_noise"]:
             a = noise_setting["args"]
-            if a.get("laplace", False):
-                raise NotImplementedError("laplace pose noise is outside the hot path")
-            cav["params"]["lidar_pose"] = cav["params"]["lidar_pose"] + generate_noise(a["pos_std"], a["rot_std"], a["pos_mean"], a["rot_mean"], rng=rng if rng is not None else np.random)
+            draw = generate_noise_laplace if a.get("laplace", False) is True else generate_noise      # the same key names serve both (pose_utils.py:19-34)
+            cav["params"]["lidar_pose"] = cav["params"]["lidar_pose"] + draw(a["pos_std"], a["rot_std"], a["pos_mean"], a["rot_mean"], rng=rng if rng is not None else np.random)
     return data_dict
 
 
@@ -97,9 +96,9 @@ class IntermediateFusionBatcher:
         self.train = train
         self.device = torch.device(device)
         self.max_cav = hypes["train_params"]["max_cav"]
-        self.proj_first = hypes.get("fusion", {}).get("args", {}).get("proj_first", False)
-        if self.proj_first:
-            raise NotImplementedError("proj_first = True (early projection of the clouds) is outside the CoAlign hot path")
+        # proj_first: every cav's cloud is projected into the ego frame BEFORE it is voxelised and the pairwise matrices are identity
+        # (intermediate_fusion_dataset.py:43-44, 104; transformation_utils.py:43-49)
+        self.proj_first = bool(hypes.get("fusion", {}).get("args", {}).get("proj_first", False))
         self.post_processor = build_postprocessor(hypes["postprocess"], train)
         self.pre_processor = preprocessor if preprocessor is not None else build_preprocessor(hypes["preprocess"], train, device)
         self.anchor_box = self.post_processor.generate_anchor_box()
@@ -151,7 +150,15 @@ class IntermediateFusionBatcher:
         clouds, object_stack, object_ids = [], [], []
         for cav_id in cav_ids:
             cav = data[cav_id]
-            clouds.append(self.shuffle(cav["lidar_np"]))                    # mask_ego_points rides in the voxeliser call
+            pts = self.shuffle(cav["lidar_np"])                             # mask_ego_points rides in the voxeliser call ...
+            if self.proj_first:
+                # ... unless the cloud moves first: the reference masks the cav's own body in the SENSOR frame, then projects with the
+                # float32 T_ego<-cav of the (noisy / corrected) poses (get_item_single_car :84-105, box_utils.py:893-921)
+                pts = pts[~((pts[:, 0] >= -1.95) & (pts[:, 0] <= 2.95) & (pts[:, 1] >= -1.1) & (pts[:, 1] <= 1.1))].copy()
+                T = torch.from_numpy(x1_to_x2(cav["params"]["lidar_pose"], data[first]["params"]["lidar_pose"])).float()
+                homo = torch.nn.functional.pad(torch.from_numpy(np.ascontiguousarray(pts[:, :3])).float(), (0, 1), mode="constant", value=1)
+                pts[:, :3] = torch.einsum("ik, jk->ij", homo, T)[:, :3].numpy()
+            clouds.append(pts)
             boxes, mask, ids = generate_object_center([cav], ego_clean, self.params["postprocess"], self.train)
             object_stack.append(boxes[mask == 1])
             object_ids += ids
@@ -161,7 +168,7 @@ class IntermediateFusionBatcher:
         centre, mask = np.zeros((max_num, 7)), np.zeros(max_num)
         centre[: stack.shape[0]] = stack
         mask[: stack.shape[0]] = 1
-        lidar = self.pre_processor.preprocess_clouds(clouds, ego_filter=True)
+        lidar = self.pre_processor.preprocess_clouds(clouds, ego_filter=not self.proj_first)
         return {"ego": {"object_bbx_center": centre, "object_bbx_mask": mask, "object_ids": [object_ids[i] for i in unique],
                         "anchor_box": self.anchor_box, "processed_lidar": lidar, "cav_num": len(cav_ids), "pairwise_t_matrix": pairwise,
                         "lidar_poses_clean": np.array(poses_clean).reshape(-1, 6), "lidar_poses": np.array(poses).reshape(-1, 6),

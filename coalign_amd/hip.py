@@ -40,6 +40,7 @@ SIGNATURES = {
                                       P, P, P, P, P, P, c_size_t, P]),
     "coalign_nms_rotated_workspace_bytes": (c_size_t, [c_int, c_int]),
     "coalign_nms_rotated": (c_int, [P, c_int, c_int, P, P, c_int, P, c_float, c_int, P, P, P, c_size_t, P]),
+    "coalign_nms_rotated_gather": (c_int, [P, P, P, c_int, P, c_float, c_int, P, P, POINTER(c_double), P, P, P, P, c_size_t, P]),
     "coalign_gather_in_range": (c_int, [P, P, P, P, c_int, POINTER(c_double), P, P, P, P]),
     "coalign_iou_rotated_matrix": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P, P]),
     "coalign_boxes_iou_bev": (c_int, [P, c_int, P, c_int, P, P]),

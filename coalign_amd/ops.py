@@ -358,6 +358,22 @@ def nms_rotated_device(boxes: torch.Tensor, scores: torch.Tensor, iou_thr: float
 
 
 @_device_op
+def nms_rotated_gather(corners: torch.Tensor, scores: torch.Tensor, iou_thr: float, top: int, valid: Optional[torch.Tensor], k_dev: Optional[torch.Tensor],
+                       keep: torch.Tensor, keep_count: torch.Tensor, limit_range: Sequence[float], out_corners: torch.Tensor, out_scores: torch.Tensor,
+                       out_count: torch.Tensor, ws: torch.Tensor) -> None:
+    """``nms_rotated_device`` + ``gather_in_range`` as one C-ABI call (rank, bitmask, walk + gather: three launches); corners [K, 8, 3]."""
+    _need_gpu(corners, scores, keep)
+    L = hip.lib()
+    b, s_ = _f32c(corners), _f32c(scores)
+    if b.dim() != 3 or tuple(b.shape[1:]) != (8, 3):
+        raise ValueError(f"corners must be [K, 8, 3], got {tuple(b.shape)}")
+    v = None if valid is None else valid.to(torch.uint8).contiguous()
+    r = (ctypes.c_double * 6)(*[float(x) for x in limit_range])
+    hip.check(L.coalign_nms_rotated_gather(_ptr(b), _ptr(s_), _ptr(v), b.shape[0], _ptr(k_dev), float(iou_thr), int(top), _ptr(keep), _ptr(keep_count), r,
+                                           _ptr(out_corners), _ptr(out_scores), _ptr(out_count), _ptr(ws), ws.numel(), _stream()), "coalign_nms_rotated_gather")
+
+
+@_device_op
 def gather_in_range(corners: torch.Tensor, scores: torch.Tensor, keep: torch.Tensor, keep_count: torch.Tensor,
                     limit_range: Sequence[float], out_corners: torch.Tensor, out_scores: torch.Tensor,
                     out_count: torch.Tensor) -> None:
@@ -467,6 +483,19 @@ def pose_graph_optimize(vertex_offsets: torch.Tensor, edge_offsets: torch.Tensor
 
 CONV_KC, CONV_WSTRIDE = 8, 9 * 64 + 32      # kKC / kWStride of csrc/conv3x3.hip
 _CONV_WS: dict = {}
+_CONV_WS_RETIRED: list = []      # outgrown workspaces stay allocated: HIP graphs captured earlier on the lane still hold their raw pointers
+
+
+def _conv_workspace(key, ws_bytes: int, device) -> torch.Tensor:
+    """One stream-K workspace per (device, stream[, kernel family]): launches on a stream are ordered.  A workspace that has to grow is
+    replaced, never freed (a captured graph replays with the pointer it was captured with; flags and partials of different launches on one
+    stream never overlap in time, so the retired buffer stays private to those graphs)."""
+    ws = _CONV_WS.get(key)
+    if ws is None or ws.numel() < ws_bytes:
+        if ws is not None:
+            _CONV_WS_RETIRED.append(ws)
+        ws = _CONV_WS[key] = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=device)
+    return ws
 
 
 def pack_conv3x3_weight(weight: torch.Tensor) -> torch.Tensor:
@@ -500,9 +529,7 @@ def conv3x3_bias_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[tor
         raise ValueError("residual shape mismatch")
     ws_bytes = L.coalign_conv3x3_workspace_bytes(N, Cin, Cout, H, W)
     key = (xc.device, torch.cuda.current_stream(xc.device).cuda_stream)
-    ws = _CONV_WS.get(key)
-    if ws is None or ws.numel() < ws_bytes:        # one workspace per (device, stream): launches on a stream are ordered
-        ws = _CONV_WS[key] = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=xc.device)
+    ws = _conv_workspace(key, ws_bytes, xc.device)
     b = torch.zeros(Cout, dtype=torch.float32, device=xc.device) if bias is None else _f32c(bias)
     with _Timed("conv3x3_bias_act"):
         hip.check(L.coalign_conv3x3_bias_act(_ptr(xc), _ptr(w_packed), _ptr(b), _ptr(res), _ptr(y),
@@ -582,9 +609,7 @@ def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Ten
         ws_bytes = L.coalign_conv3x3_emu_workspace_bytes_ex(N, Cin, cout, H, W, terms, layout)
     if ws_bytes:
         key = (xc.device, torch.cuda.current_stream(xc.device).cuda_stream, "emu")
-        ws = _CONV_WS.get(key)
-        if ws is None or ws.numel() < ws_bytes:        # one workspace per (device, stream): launches on a stream are ordered
-            ws = _CONV_WS[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=xc.device)
+        ws = _conv_workspace(key, ws_bytes, xc.device)
     with _Timed("conv3x3_emu_bias_act"):
         hip.check(L.coalign_conv3x3_emu_ex(_ptr(xc), _ptr(w_split), _ptr(_f32c(bias)), _ptr(res), _ptr(y), N, Cin, cout, H, W, int(stride),
                                            int(relu), terms, layout, _ptr(ws), 0 if ws is None else ws.numel(), _stream()),

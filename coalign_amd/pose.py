@@ -67,6 +67,14 @@ def normalize_pairwise_tfm(pairwise_t_matrix: torch.Tensor, H: int, W: int, disc
     return m
 
 
+def generate_noise_laplace(pos_b: float, rot_b: float, pos_mu: float = 0, rot_mu: float = 0, rng=np.random) -> np.ndarray:
+    """Laplace localisation noise on (x, y, yaw) (opencood/utils/pose_utils.py:77-105): ``laplace(size=2)`` then ``laplace(size=1)``,
+    the reference's draw order."""
+    xy = rng.laplace(pos_mu, pos_b, size=2)
+    yaw = rng.laplace(rot_mu, rot_b, size=1)
+    return np.array([xy[0], xy[1], 0.0, 0.0, yaw[0], 0.0])
+
+
 def generate_noise(pos_std: float, rot_std: float, pos_mean: float = 0, rot_mean: float = 0,
                    rng=np.random) -> np.ndarray:
     """Gaussian localisation noise on (x, y, yaw); draw order ``normal(size=2)`` then ``normal(size=1)``

@@ -105,8 +105,6 @@ class VoxelPostprocessor:
             dirp = out.get("dir_preds", out.get("dm"))
             if reg.dim() != 4:
                 raise NotImplementedError("anchor-free heads are outside the CoAlign hot path")
-            if "iou_preds" in out:
-                raise NotImplementedError("iou_preds rescoring is outside the CoAlign hot path")
             content = data_dict[cav_id]
             device = cls.device
             T = torch.as_tensor(content["transformation_matrix"]).to(device=device, dtype=torch.float32)
@@ -117,11 +115,24 @@ class VoxelPostprocessor:
                         t.record_stream(record_on)
             ops.anchor_decode(buf, slot, cls, reg, dirp, anchors, thr, da.get("dir_offset", 0.0), da.get("num_bins", 2),
                               self.params["order"], T)
+            if "iou_preds" in out:
+                # IoU-head rescoring (voxel_postprocessor.py:335-339): scores *= ((clamp(sigmoid(iou), 0, 1) + 1) / 2) ** 4 on the candidates
+                # this cav just appended (rows counts[slot] .. counts[slot + 1], flat anchor index in cand_index); element-wise torch ops on
+                # the same values the reference forms, no host synchronisation (row bounds stay on the device)
+                fac = torch.pow((torch.clamp(torch.sigmoid(out["iou_preds"].permute(0, 2, 3, 1).contiguous()).reshape(-1), min=0.0, max=1.0) + 1) * 0.5, 4)
+                rows = torch.arange(buf.capacity, device=device, dtype=torch.int32)
+                sel = (rows >= buf.counts[slot]) & (rows < buf.counts[slot + 1])
+                idx = buf.cand_index.long().clamp_(0, fac.numel() - 1)
+                buf.cand_score.copy_(torch.where(sel, buf.cand_score * fac[idx], buf.cand_score))
         total_dev = buf.counts[len(cavs): len(cavs) + 1]
-        ops.nms_rotated_device(buf.cand_corners, buf.cand_score, self.params["nms_thresh"], NMS_TOP, valid=buf.cand_keep,
-                               k_dev=total_dev, keep=buf.keep, keep_count=buf.keep_count, ws=buf.nms_ws)
-        ops.gather_in_range(buf.cand_corners, buf.cand_score, buf.keep, buf.keep_count, self.params["gt_range"],
-                            buf.out_corners, buf.out_scores, buf.out_count)
+        if NMS_TOP <= 1024:        # rank, bitmask, walk + in-range gather: three launches (coalign_nms_rotated_gather)
+            ops.nms_rotated_gather(buf.cand_corners, buf.cand_score, self.params["nms_thresh"], NMS_TOP, buf.cand_keep, total_dev, buf.keep, buf.keep_count,
+                                   self.params["gt_range"], buf.out_corners, buf.out_scores, buf.out_count, buf.nms_ws)
+        else:
+            ops.nms_rotated_device(buf.cand_corners, buf.cand_score, self.params["nms_thresh"], NMS_TOP, valid=buf.cand_keep,
+                                   k_dev=total_dev, keep=buf.keep, keep_count=buf.keep_count, ws=buf.nms_ws)
+            ops.gather_in_range(buf.cand_corners, buf.cand_score, buf.keep, buf.keep_count, self.params["gt_range"],
+                                buf.out_corners, buf.out_scores, buf.out_count)
         # the frame's four scalars travel to pinned host memory behind the kernels: one small async copy each
         buf.host[0:1].copy_(buf.out_count, non_blocking=True)
         buf.host[1:2].copy_(total_dev, non_blocking=True)

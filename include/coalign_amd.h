@@ -186,6 +186,13 @@ int coalign_nms_rotated(const float *boxes, int rows, int cols, const float *sco
                         const int32_t *K_dev, float iou_thr, int top, int32_t *keep, int32_t *keep_count, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* (4) + (5) in one call: rank, suppression bitmask, greedy walk AND the in-range gather of coalign_gather_in_range (three launches
+ * instead of four; the walk and the gather share one workgroup that holds the whole bitmask in LDS).  corners [K, 8, 3] are the boxes the
+ * NMS clips (their first four corners' x, y, box_utils.py:716-717) and the rows the gather copies.  top <= 1024 (the reference uses 1000).
+ * keep / keep_count as in coalign_nms_rotated; out_* as in coalign_gather_in_range. */
+int coalign_nms_rotated_gather(const float *corners, const float *scores, const uint8_t *valid, int K, const int32_t *K_dev, float iou_thr, int top,
+                               int32_t *keep, int32_t *keep_count, const double *range6_host, float *out_corners, float *out_scores,
+                               int32_t *out_count, void *workspace, size_t workspace_bytes, void *stream);
 /* Gather the kept boxes and drop those with a corner outside `range` (xmin, ymin, zmin, xmax, ymax, zmax;
  * compared in float64 like mask_boxes_outside_range_numpy, opencood/utils/box_utils.py:384-421 with
  * min_num_corners = 8), preserving pick order (voxel_postprocessor.py:385-397).

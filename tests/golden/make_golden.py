@@ -494,6 +494,41 @@ def main():
     np.savez_compressed(os.path.join(HERE, "dataset.npz"), **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in dsg.items()})
     print(f"wrote dataset.npz: {os.path.getsize(os.path.join(HERE, 'dataset.npz')) // 1024} KiB")
 
+    # ------------------------------------------------------------------ the dataset's side branches (round 3): Laplace pose noise
+    # (pose_utils.py:19-21, 77-105) and proj_first = True (intermediate_fusion_dataset.py:43-44, 104; transformation_utils.py:43-49),
+    # and iou_preds rescoring in the post-processor (voxel_postprocessor.py:335-339)
+    hb = copy.deepcopy(hd)
+    hb["fusion"]["args"]["proj_first"] = True
+    hb["noise_setting"] = {"add_noise": True, "args": {"pos_std": 0.3, "rot_std": 0.4, "pos_mean": 0.0, "rot_mean": 0.0, "laplace": True}}
+    dsb = IFD(hb, visualize=False, train=False)
+    brg = {}
+    dsb.scenario = memory_scenario(6, 3, far=False)
+    np.random.seed(2024)
+    batch = dsb.collate_batch_test([dsb[0]])["ego"]
+    for c, (cid, cav) in enumerate(dsb.scenario.items()):
+        brg.update({f"lidar{c}": cav["lidar_np"], f"pose{c}": np.array(cav["params"]["lidar_pose"]),
+                    f"veh_ids{c}": np.array(list(cav["params"]["vehicles"].keys())),
+                    f"veh{c}": np.array([v["location"] + v["angle"] + v["extent"] + v["center"] for v in cav["params"]["vehicles"].values()]).reshape(-1, 12)})
+    brg.update({"n_cav": 3, "cav_ids": np.array(list(dsb.scenario.keys())), "np_seed": 2024,
+                "voxel_features": batch["processed_lidar"]["voxel_features"], "voxel_coords": batch["processed_lidar"]["voxel_coords"],
+                "voxel_num_points": batch["processed_lidar"]["voxel_num_points"], "record_len": batch["record_len"],
+                "pairwise_t_matrix": batch["pairwise_t_matrix"], "object_bbx_center": batch["object_bbx_center"],
+                "object_bbx_mask": batch["object_bbx_mask"], "object_ids": np.array(batch["object_ids"]),
+                "lidar_pose": batch["lidar_pose"], "lidar_pose_clean": batch["lidar_pose_clean"]})
+    print(f"  dataset branches: voxels {tuple(batch['processed_lidar']['voxel_features'].shape)}, poses {batch['lidar_pose'][:, [0, 1, 4]].tolist()}")
+    # iou_preds: the mini model's head outputs of postprocess.npz + an IoU head, through the reference's post_process
+    gp = np.load(os.path.join(HERE, "postprocess.npz"))
+    ppr = ref_build_post(load_hypes(YAML_COALIGN, lidar_range=MINI_RANGE)["postprocess"], False)
+    gen = torch.Generator().manual_seed(77)
+    iou_map = torch.randn(1, 2, gp["i_cls"].shape[2], gp["i_cls"].shape[3], generator=gen)
+    anchors_t = torch.from_numpy(gp["anchors"])
+    outd = {"ego": {"cls_preds": torch.from_numpy(gp["i_cls"]), "reg_preds": torch.from_numpy(gp["i_reg"]), "dir_preds": torch.from_numpy(gp["i_dir"]), "iou_preds": iou_map}}
+    bx, sc = ppr.post_process({"ego": {"transformation_matrix": torch.eye(4), "anchor_box": anchors_t}}, outd)
+    brg.update({"iou_preds": iou_map.numpy(), "iou_boxes": bx.numpy(), "iou_scores": sc.numpy()})
+    print(f"  iou_preds rescoring: {bx.shape[0]} boxes")
+    np.savez_compressed(os.path.join(HERE, "dataset_branches.npz"), **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in brg.items()})
+    print(f"wrote dataset_branches.npz: {os.path.getsize(os.path.join(HERE, 'dataset_branches.npz')) // 1024} KiB")
+
     # ------------------------------------------------------------------ stage-1 detector with uncertainty head + its post-process (next-3)
     from opencood.data_utils.post_processor.uncertainty_voxel_postprocessor import UncertaintyVoxelPostprocessor as RefUncPost
     hu = load_hypes(YAML_UNC, MINI_RANGE)

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(REPO, "include", "coalign_amd.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(coalign_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) == 39
+    assert len(declared) == 40
     lib = hip.lib()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/coalign_amd.h but not exported"
@@ -238,6 +238,45 @@ def test_batch_dict_producer_matches_reference_dataset(golden):
         np.random.seed(int(g[f"{tag}_np_seed"]))
         check_batch_against_reference(batcher(dataset_scenario(g, tag)), g, tag)
     assert len(g["a_cav_id_list"]) == 3 and int(g["a_n_cav"]) == 4          # one cav was beyond comm_range
+
+
+def test_dataset_side_branches_match_reference(golden):
+    """Laplace pose noise (pose_utils.py:19-21, 77-105) and proj_first = True (intermediate_fusion_dataset.py:43-44, 104: clouds projected
+    into the ego frame before the voxeliser, identity pairwise matrices) against the reference's dataset class on the same scenario and numpy
+    seed: poses, pairwise matrices, ground truth and -- through the injected oracle voxeliser -- the very same pillars."""
+    import copy
+    import numpy as np
+    import torch
+    from oracle import coalign_oracle as oracle
+    from coalign_amd.config import builtin_config
+    from coalign_amd.dataset import IntermediateFusionBatcher
+
+    class OracleVoxels:
+        def __init__(self, p):
+            self.p = p
+
+        def preprocess_clouds(self, clouds, ego_filter=False, filter_range=None):
+            a = self.p["args"]
+            per = [oracle.points_to_voxel(oracle.mask_ego_points(c) if ego_filter else c, a["voxel_size"], self.p["cav_lidar_range"],
+                                          a["max_points_per_voxel"], a["max_voxel_test"]) for c in clouds]
+            f, c, n = oracle.collate_voxels(per)
+            return {"voxel_features": torch.from_numpy(f), "voxel_coords": torch.from_numpy(c), "voxel_num_points": torch.from_numpy(n)}
+
+    g = golden("dataset_branches.npz")
+    gg = {f"c_{k}": g[k] for k in g.files}
+    gg["c_cav_id_list"] = g["cav_ids"]                                   # nobody out of range in this scenario
+    gg["c_transformation_matrix"] = np.identity(4, dtype=np.float32)
+    h = copy.deepcopy(builtin_config("opv2v_coalign"))
+    h.pop("box_align", None)
+    h.setdefault("fusion", {}).setdefault("args", {})["proj_first"] = True
+    h["noise_setting"] = {"add_noise": True, "args": {"pos_std": 0.3, "rot_std": 0.4, "pos_mean": 0.0, "rot_mean": 0.0, "laplace": True}}
+    batcher = IntermediateFusionBatcher(h, train=False, device="cpu", preprocessor=OracleVoxels(h["preprocess"]))
+    np.random.seed(int(g["np_seed"]))
+    batch = batcher(dataset_scenario(gg, "c"))
+    check_batch_against_reference(batch, gg, "c")
+    pw = batch["ego"]["pairwise_t_matrix"].numpy()
+    assert np.array_equal(pw, np.tile(np.eye(4), pw.shape[:3] + (1, 1)))
+    assert float(np.abs(g["lidar_pose"] - g["lidar_pose_clean"]).max()) > 0.01      # the noise really was drawn
 
 
 def test_split_bf16_weight_image_layout_and_exactness():

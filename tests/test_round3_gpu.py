@@ -191,3 +191,115 @@ def test_pillar_encode_stream_equals_the_host_count_form(points_world):
             f, c = ops.pillar_encode_stream(voxels, num, coords, counts[3:], *args, canvas_cache=cache, unique_cells=unique, want_features=True)
             assert torch.equal(c, c_ref), (i, unique)
             assert torch.equal(f[:m], f_ref), (i, unique)
+
+
+# ------------------------------------------------------------------------------------------------ fast NMS (rank16 / mask2 / reduce2)
+def _nms_inputs(K, seed, dense=False):
+    rs = np.random.RandomState(seed)
+    b7 = np.zeros((K, 7), np.float32)
+    span = (30.0, 12.0) if dense else (100.0, 40.0)
+    b7[:, 0] = rs.uniform(-span[0], span[0], K); b7[:, 1] = rs.uniform(-span[1], span[1], K); b7[:, 2] = rs.uniform(-1.5, -0.5, K); b7[:, 3] = 1.5
+    b7[:, 4] = rs.uniform(1.4, 2.2, K); b7[:, 5] = rs.uniform(3, 5.5, K); b7[:, 6] = rs.uniform(-3.2, 3.2, K)
+    corners = oracle.boxes_to_corners_3d(torch.from_numpy(b7), "hwl")
+    scores = torch.from_numpy(rs.uniform(0.2, 1, K).astype(np.float32))
+    valid = torch.from_numpy((rs.uniform(0, 1, K) > 0.1).astype(np.uint8))
+    return corners, scores, valid
+
+
+@pytest.mark.parametrize("K,dense", [(1, False), (63, True), (64, True), (65, True), (600, True), (600, False), (1000, True), (1024, True), (2500, False)])
+def test_fused_nms_gather_equals_the_separate_calls_and_the_oracle(K, dense):
+    """coalign_nms_rotated_gather (rank16 -> mask2 -> reduce2 with the in-range gather) against (a) the oracle's nms_rotated on the valid
+    candidates + the range rule, (b) coalign_nms_rotated + coalign_gather_in_range: keep lists, counts and gathered rows identical.
+    Dense sets (most pairs overlap: long compacted lists, deep suppression chains), sets of more than `top` candidates, block edges."""
+    corners, scores, valid = _nms_inputs(K, 100 + K, dense)
+    top = 1000
+    rng = [-60.0, -38.0, -3.0, 60.0, 38.0, 1.0]
+    c, s, v = corners.to(DEV), scores.to(DEV), valid.to(DEV)
+    L = ops.hip.lib()
+    ws = torch.empty(L.coalign_nms_rotated_workspace_bytes(K, top), dtype=torch.uint8, device=DEV)
+    keep = torch.full((top,), -1, dtype=torch.int32, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    oc, osc, on = torch.zeros(top, 8, 3, device=DEV), torch.zeros(top, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.nms_rotated_gather(c, s, 0.15, top, v, None, keep, cnt, rng, oc, osc, on, ws)
+    n = int(cnt)
+    got = keep[:n].cpu().numpy()
+    idx = np.nonzero(valid.numpy())[0]
+    want = idx[oracle.nms_rotated(corners.numpy()[idx], scores.numpy()[idx], 0.15)]
+    assert np.array_equal(got, want.astype(np.int32)), (K, dense, n, len(want))
+    # (b) the two-call form
+    k2, c2 = ops.nms_rotated_device(c, s, 0.15, top, valid=v)
+    assert int(c2) == n and torch.equal(k2[:n], keep[:n])
+    oc2, os2, on2 = torch.zeros_like(oc), torch.zeros_like(osc), torch.zeros_like(on)
+    ops.gather_in_range(c, s, k2, c2, rng, oc2, os2, on2)
+    m = int(on)
+    assert m == int(on2) and torch.equal(oc[:m], oc2[:m]) and torch.equal(osc[:m], os2[:m])
+    inside = [i for i in want if bool(((corners[i].double() >= torch.tensor(rng[:3]).double()) & (corners[i].double() <= torch.tensor(rng[3:]).double())).all())]
+    assert m == len(inside) and torch.equal(oc[:m].cpu(), corners[inside]) and torch.equal(osc[:m].cpu(), scores[inside])
+
+
+def test_legacy_nms_kernels_in_a_subprocess():
+    """COALIGN_NMS_LEGACY=1 selects round 2's rank / mask / reduce kernels (kept for tops above 1024 and as the A/B reference): the NMS tests
+    again, in their own process."""
+    tests = ["tests/test_hip_parity.py::test_nms_golden", "tests/test_hip_parity.py::test_nms_edge_cases_and_properties",
+             "tests/test_round3_gpu.py::test_fused_nms_gather_equals_the_separate_calls_and_the_oracle"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + tests,
+                       env=dict(os.environ, PYTHONPATH=ROOT, COALIGN_NMS_LEGACY="1"), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-500:])
+
+
+# ------------------------------------------------------------------------------------------------ stream-K hand-over
+@pytest.mark.parametrize("kind", ["bf16x3", "fp32"])
+def test_stream_k_handover_stress(kind):
+    """The shrink-header shape (1 x 384 -> 256 at 100 x 352: long tiles, split between workgroups and handed over through write-through
+    stores + a flag, conv3x3_emu.hip / conv3x3.hip) launched 2000 times while a second stream keeps the GPU busy with other convolutions and
+    copies: every output bit-equal to the first.  (The hand-over is relaxed-atomic + ISA ordering, argued next to the code; this guards it.)"""
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 384, 100, 352, generator=g).to(DEV)
+    w = (torch.randn(256, 384, 3, 3, generator=g) / (384 * 9) ** 0.5).to(DEV)
+    b = torch.randn(256, generator=g).to(DEV)
+    x2 = torch.randn(5, 64, 100, 352, generator=g).to(DEV)
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).to(DEV)
+    b2 = torch.randn(64, generator=g).to(DEV)
+    if kind == "bf16x3":
+        wp, wp2 = ops.pack_conv3x3_emu_weight(w, 3, True), ops.pack_conv3x3_emu_weight(w2, 3, True)
+        run = lambda: ops.conv3x3_emu_bias_act(x, wp, b, 256, None, True, 3)
+        other = lambda: ops.conv3x3_emu_bias_act(x2, wp2, b2, 64, None, True, 3)
+    else:
+        wp, wp2 = ops.pack_conv3x3_weight(w), ops.pack_conv3x3_weight(w2)
+        run = lambda: ops.conv3x3_bias_act(x, wp, b, None, True)
+        other = lambda: ops.conv3x3_bias_act(x2, wp2, b2, None, True)
+    ref = run()
+    want = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1))
+    assert float((ref.double() - want).abs().max() / want.abs().max()) < 5e-6
+    side = torch.cuda.Stream()
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    n_iter = 2000 if kind == "bf16x3" else 1000
+    for it in range(n_iter):
+        if it % 4 == 0:                       # keep the second stream a few launches deep: varied co-runners, some of them bandwidth hogs
+            with torch.cuda.stream(side):
+                other()
+                if it % 8 == 0:
+                    scratch.zero_()
+        y = run()
+        bad += (y != ref).any()               # EVERY iteration is compared, on the device (no host synchronisation: launches stay back to back)
+        if it % 97 == 96:
+            torch.cuda.synchronize()          # ... with launches that start on an idle GPU mixed in
+    torch.cuda.synchronize()
+    assert int(bad) == 0, int(bad)
+
+
+# ------------------------------------------------------------------------------------------------ small reference branches
+def test_iou_preds_rescoring_golden(golden):
+    """voxel_postprocessor.py:335-339: an `iou_preds` head rescales the candidate scores ((clamp(sigmoid, 0, 1) + 1) / 2) ** 4 before NMS.
+    Golden: the reference's post_process on the mini model's heads + a random IoU map (tests/golden/dataset_branches.npz)."""
+    from coalign_amd.postprocess import build_postprocessor
+    g, gb = golden("postprocess.npz"), golden("dataset_branches.npz")
+    pp = build_postprocessor(builtin_config("mini_coalign")["postprocess"], False)
+    T = torch.from_numpy
+    out = {"ego": {"cls_preds": T(g["i_cls"]).to(DEV), "reg_preds": T(g["i_reg"]).to(DEV), "dir_preds": T(g["i_dir"]).to(DEV), "iou_preds": T(gb["iou_preds"]).to(DEV)}}
+    boxes, scores = pp.post_process({"ego": {"transformation_matrix": torch.eye(4), "anchor_box": T(g["anchors"])}}, out)
+    assert boxes.shape == gb["iou_boxes"].shape
+    np.testing.assert_allclose(scores.cpu().numpy(), gb["iou_scores"], rtol=3e-7, atol=0)
+    np.testing.assert_allclose(boxes.cpu().numpy(), gb["iou_boxes"], rtol=2e-6, atol=1e-5)
+    assert not np.allclose(gb["iou_scores"][: len(g["i_scores"])], g["i_scores"][: len(gb["iou_scores"])])      # the rescoring changed something
