@@ -38,6 +38,7 @@ struct PfnArgs {
     int *cellmap;
     const int *M_dev;     // optional: the pillar count lives on the device (the voxeliser's voxel_counts word); M is then the capacity
     int unique;           // the caller guarantees one pillar per cell (voxeliser output): no cell-map lookup
+    int debug;            // measurement switches (COALIGN_PILLAR_DEBUG): 1 no feature-row stores, 2 no canvas stores, 4 no matrix / epilogue work
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -966,75 +967,120 @@ __global__ __launch_bounds__(256) void pillar_prep_kernel(const int *__restrict_
     }
 }
 
-// The rows kernel of the matrix-core encoder: as pillar_rows_nhwc_kernel, but everything stays in the half layout -- lanes 0-31 work for
-// pillar A, lanes 32-63 for pillar B from the point loads to the stores (a store instruction writes 128 B of A's row and 128 B of B's),
-// nothing is broadcast through scalar registers, and all addresses are 32-bit byte offsets from scalar bases (the launcher checks the sizes).
+// The rows kernel of the matrix-core encoder.  Against pillar_rows_nhwc_kernel:
+//   * everything stays in the half layout -- lanes 0-31 work for pillar A, lanes 32-63 for pillar B from the point loads to the stores (a
+//     store instruction writes 128 B of A's row and 128 B of B's), nothing is broadcast through scalar registers on the way;
+//   * all addresses are 32-bit byte offsets from scalar bases (the launcher checks the sizes);
+//   * memory latency is paid once per ROUND of five pairs, not once per pair: a wavefront owns a CONTIGUOUS run of pairs; at the start of a
+//     round it sends the five pairs' points (5 x 1 KB) straight into LDS (global_load_lds: no staging registers), reads the ten pillars'
+//     counts and coordinates through the scalar cache and issues the five cell-map lookups; the five passes then run out of LDS.
+//     (Measured on the round-robin, register-prefetched version: 20 us, of which 12 us remained with the arithmetic AND the stores switched
+//      off -- 4096 waves x 5 dependent passes x one exposed memory round trip each; profiles/round3/pillar_rows_ablation.txt.)
+typedef __attribute__((address_space(3))) void *lptr_ps_t;
+typedef const __attribute__((address_space(4))) int *cint_ps_t;
+constexpr int kRound = 5;                                   // pairs per round (5 KB of points per wavefront in LDS)
+
 template <bool ABS>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(PfnArgs a, float *__restrict__ canvas, int *__restrict__ dest, int reset_cellmap) {
-    __shared__ __attribute__((aligned(16))) char lds[kWavesPerBlock * 64 * kRowBytes];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
-    char *wave_lds = lds + wv * 64 * kRowBytes;
+    constexpr int kWaveLds = 64 * kRowBytes + kRound * 1024;
+    __shared__ __attribute__((aligned(16))) char lds[kWavesPerBlock * kWaveLds];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
+    char *wave_lds = lds + wv * kWaveLds;
+    char *pbuf = wave_lds + 64 * kRowBytes;
     const int gwave = blockIdx.x * kWavesPerBlock + wv, nwave = gridDim.x * kWavesPerBlock;
     if (a.M_dev) a.M = min(max(*a.M_dev, 0), a.M);
     if (a.M_dev && dest && blockIdx.x == 0 && threadIdx.x == 0) dest[-1] = a.M;      // the device-count form keeps "rows written" in front of the list
     const int npairs = (a.M + 1) / 2;
-    if (gwave >= npairs) return;
+    const int per_wave = (npairs + nwave - 1) / nwave;
+    const int p0 = gwave * per_wave, p1 = min(p0 + per_wave, npairs);
+    if (p0 >= p1) return;
     const int ncell = a.ny * a.nx;
-    const char *pts_b = reinterpret_cast<const char *>(a.pts), *np_b = reinterpret_cast<const char *>(a.npts), *cd_b = reinterpret_cast<const char *>(a.coords);
+    const char *pts_b = reinterpret_cast<const char *>(a.pts);
+    const cint_ps_t np_s = (cint_ps_t)a.npts, cd_s = (cint_ps_t)a.coords, cm_s = (cint_ps_t)a.cellmap;      // wave-uniform indices below: scalar loads
     char *cm_b = reinterpret_cast<char *>(a.cellmap), *feat_b = reinterpret_cast<char *>(a.feats), *cv_b = reinterpret_cast<char *>(canvas),
          *dest_b = reinterpret_cast<char *>(dest);
-    auto load = [&](int pair) -> PairIn {
-        const int m = min(2 * pair + half, a.M - 1);                      // a pillar B past the end re-reads the last pillar; its lanes store nothing
-        PairIn in;
-        in.q = *reinterpret_cast<const float4 *>(pts_b + (unsigned)(m * a.P + min(col, a.P - 1)) * 16u);
-        if (a.P < 32 && col >= a.P) in.q = make_float4(0.f, 0.f, 0.f, 0.f);
-        in.np = *reinterpret_cast<const int *>(np_b + (unsigned)m * 4u);
-        in.cd = *reinterpret_cast<const int4 *>(cd_b + (unsigned)m * 16u);
-        return in;
+    // a round's points go straight into LDS (issued from inline assembly: after a BUILTIN LDS-DMA hipcc puts s_waitcnt vmcnt(0) in front of every
+    // later LDS read it cannot prove unrelated -- here in front of every pass, i.e. each pass would wait for the previous pass's stores)
+    auto issue_round = [&](int r0) {
+        const int nr = min(kRound, p1 - r0);
+#pragma unroll
+        for (int k = 0; k < kRound; ++k) {
+            if (k < nr) {
+                const int m = min(2 * (r0 + k) + half, a.M - 1);                       // a pillar B past the end re-reads the last pillar; its lanes store nothing
+                const char *src = pts_b + (unsigned)(m * a.P + min(col, a.P - 1)) * 16u;
+                const unsigned dst = (unsigned)(size_t)(lptr_ps_t)(pbuf + k * 1024);   // wave-uniform LDS byte address -> M0; lane i lands at dst + 16 i
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(dst)), "v"(src) : "memory", "m0");
+            }
+        }
     };
-    auto slot_of = [&](const PairIn &p) -> int {                           // agent * ncell + cell (z + y * nx + x, point_pillar_scatter.py:54) or -1
-        const int cell = p.cd.y + p.cd.z * a.nx + p.cd.w;
-        const bool ok = p.cd.x >= 0 && p.cd.x < a.n_agents && cell >= 0 && cell < ncell;
-        return ok ? p.cd.x * ncell + cell : -1;
-    };
-    // Two pairs ahead: one wave keeps 2 KB of point loads in flight (4096 waves x 1 KB were latency bound at ~2 TB/s, measured)
-    PairIn nxt = load(gwave);
-    PairIn nx2 = load(min(gwave + nwave, npairs - 1));
+    issue_round(p0);                                                                   // in flight while the channel parameters are fetched and split
     const MxChan mc = load_mx<ABS>(a, lane);
     *reinterpret_cast<uint4 *>(wave_lds + lane * kRowBytes + 48) = make_uint4(0u, 0u, 0u, 0u);          // part 3 of every row: the zero half of step 2
-    int slot_nxt = slot_of(nxt);
-    int owner_nxt = a.unique ? 0 : *reinterpret_cast<const int *>(cm_b + (unsigned)max(slot_nxt, 0) * 4u);
     const bool ch0 = col < a.C, ch1 = 32 + col < a.C;
-    for (int pair = gwave; pair < npairs; pair += nwave) {
-        const PairIn in = nxt;
-        const int slot = slot_nxt, owner = owner_nxt;
-        const int m = 2 * pair + half;
-        const bool live = m < a.M, hasB = 2 * pair + 1 < a.M;
-        const bool more = pair + nwave < npairs;
-        nxt = nx2;
-        if (pair + 2 * nwave < npairs) nx2 = load(pair + 2 * nwave);
-        float y[2];
-        mx_pair_half<ABS>(a, mc, wave_lds, lane, in, hasB, y);
-        if (more) {                                                        // before this pair's stores: vmcnt retires in order and counts stores
-            slot_nxt = slot_of(nxt);
-            if (!a.unique) owner_nxt = *reinterpret_cast<const int *>(cm_b + (unsigned)max(slot_nxt, 0) * 4u);
+    for (int r0 = p0; r0 < p1; r0 += kRound) {
+        const int nr = min(kRound, p1 - r0);
+        // counts, coordinates AND the cell-map entries of a pair through the scalar cache: every index is wave-uniform (pillar A / B of the
+        // pair), so the pass loop issues no vector loads at all -- its only vector-memory instructions are the stores, and nothing in a pass
+        // waits on vmcnt (which retires in order and counts stores).  The cell map is read-only here except for the winners' own resets;
+        // a loser that reads a stale or a reset entry sees "not me" either way.  One pass ahead.
+        struct Meta { int npA, npB; int4 cA, cB; int slotA, slotB, ownA, ownB; };
+        auto slot_s = [&](const int4 c) -> int {
+            const int cell = c.y + c.z * a.nx + c.w;                                   // z + y * nx + x (point_pillar_scatter.py:54)
+            const bool ok = c.x >= 0 && c.x < a.n_agents && cell >= 0 && cell < ncell;
+            return ok ? c.x * ncell + cell : -1;
+        };
+        auto meta_of = [&](int pair) -> Meta {
+            const int mA = 2 * pair, mB = min(mA + 1, a.M - 1);
+            Meta t;
+            t.npA = np_s[mA]; t.npB = np_s[mB];
+            t.cA = make_int4(cd_s[4 * mA], cd_s[4 * mA + 1], cd_s[4 * mA + 2], cd_s[4 * mA + 3]);
+            t.cB = make_int4(cd_s[4 * mB], cd_s[4 * mB + 1], cd_s[4 * mB + 2], cd_s[4 * mB + 3]);
+            t.slotA = slot_s(t.cA); t.slotB = slot_s(t.cB);
+            t.ownA = a.unique ? 0 : cm_s[max(t.slotA, 0)];
+            t.ownB = a.unique ? 0 : cm_s[max(t.slotB, 0)];
+            return t;
+        };
+        Meta cur = meta_of(r0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                            // vmcnt(0): the round's points are in LDS (once per round)
+        coalign::wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < kRound; ++k) {
+            if (k < nr) {
+                const int pair = r0 + k;
+                const int m = 2 * pair + half;
+                const bool live = m < a.M, hasB = 2 * pair + 1 < a.M;
+                PairIn in;
+                in.q = *reinterpret_cast<const float4 *>(pbuf + k * 1024 + lane * 16);
+                if (a.P < 32 && col >= a.P) in.q = make_float4(0.f, 0.f, 0.f, 0.f);
+                in.np = half ? cur.npB : cur.npA;
+                in.cd = half ? cur.cB : cur.cA;
+                const int slot = half ? cur.slotB : cur.slotA, owner = half ? cur.ownB : cur.ownA;
+                if (k + 1 < nr) cur = meta_of(pair + 1);                               // two dependent scalar round trips, hidden behind this pass
+                float y[2];
+                if (a.debug & 4) { y[0] = in.q.x + (float)in.np; y[1] = in.q.y + (float)in.cd.w; }
+                else mx_pair_half<ABS>(a, mc, wave_lds, lane, in, hasB, y);
+                const bool win = live && slot >= 0 && (a.unique || owner == m);
+                if (live) {
+                    if (feat_b && !(a.debug & 1)) {
+                        const unsigned fo = ((unsigned)m * (unsigned)a.C + (unsigned)col) * 4u;
+                        if (ch0) *reinterpret_cast<float *>(feat_b + fo) = y[0];
+                        if (ch1) *reinterpret_cast<float *>(feat_b + fo + 128u) = y[1];
+                    }
+                    if (win && !(a.debug & 2)) {
+                        const unsigned co = ((unsigned)slot * (unsigned)a.C + (unsigned)col) * 4u;
+                        if (ch0) *reinterpret_cast<float *>(cv_b + co) = y[0];
+                        if (ch1) *reinterpret_cast<float *>(cv_b + co + 128u) = y[1];
+                    }
+                    if (col == 0) {
+                        if (dest_b) *reinterpret_cast<int *>(dest_b + (unsigned)m * 4u) = win ? slot : -1;
+                        if (reset_cellmap && win) *reinterpret_cast<int *>(cm_b + (unsigned)slot * 4u) = -1;
+                    }
+                }
+            }
         }
-        const bool win = live && slot >= 0 && (a.unique || owner == m);
-        if (live) {
-            if (feat_b) {
-                const unsigned fo = ((unsigned)m * (unsigned)a.C + (unsigned)col) * 4u;
-                if (ch0) *reinterpret_cast<float *>(feat_b + fo) = y[0];
-                if (ch1) *reinterpret_cast<float *>(feat_b + fo + 128u) = y[1];
-            }
-            if (win) {
-                const unsigned co = ((unsigned)slot * (unsigned)a.C + (unsigned)col) * 4u;
-                if (ch0) *reinterpret_cast<float *>(cv_b + co) = y[0];
-                if (ch1) *reinterpret_cast<float *>(cv_b + co + 128u) = y[1];
-            }
-            if (col == 0) {
-                if (dest_b) *reinterpret_cast<int *>(dest_b + (unsigned)m * 4u) = win ? slot : -1;
-                if (reset_cellmap && win) *reinterpret_cast<int *>(cm_b + (unsigned)slot * 4u) = -1;
-            }
+        if (r0 + kRound < p1) {                                                        // more than five pairs per wavefront (M > 40 960): next round
+            coalign::wave_lds_sync();                                                  // this round's reads of pbuf are done (their data was consumed above)
+            issue_round(r0 + kRound);
         }
     }
 }
@@ -1045,7 +1091,12 @@ bool pillar_mfma_enabled() {
     return on;
 }
 
-void launch_rows(const PfnArgs &a, float *canvas, int *dest, int reset_cellmap, int blocks, hipStream_t stream) {
+void launch_rows(const PfnArgs &a_in, float *canvas, int *dest, int reset_cellmap, int blocks, hipStream_t stream) {
+    static const int debug = [] { const char *e = getenv("COALIGN_PILLAR_DEBUG"); return e ? atoi(e) : 0; }();
+    static const int blocks_override = [] { const char *e = getenv("COALIGN_PILLAR_BLOCKS"); return e ? atoi(e) : 0; }();
+    PfnArgs a = a_in;
+    a.debug = debug;
+    if (blocks_override > 0 && blocks > blocks_override) blocks = blocks_override;
     const dim3 grid(blocks), block(kWavesPerBlock * 64);
     // 32-bit byte offsets in the matrix-core kernel: pillars, feature rows and canvas each below 4 GB
     const bool small = (size_t)a.M * a.P * 16 < ((size_t)1 << 32) && (size_t)a.M * a.C * 4 < ((size_t)1 << 32) &&

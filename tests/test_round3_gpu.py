@@ -75,6 +75,31 @@ def test_matrix_core_encoder_against_float64():
         assert torch.equal(canvas.contiguous().cpu(), oracle.scatter(feats.cpu(), pl["voxel_coords"], 5, 704, 200))
 
 
+def test_matrix_core_encoder_many_pillars_several_rounds():
+    """90 000 pillars: a wavefront of pillar_rows_mx_kernel owns 11 pairs = three LDS-DMA rounds (the benchmarked 40 000 pillars are one round);
+    features against the oracle, the canvas an exact copy, persistent canvas == fresh canvas when the big frame follows a small one."""
+    h = builtin_config("opv2v_coalign")
+    margs = h["model"]["args"]
+    model = build_model(h)
+    fill_parameters_(model, seed=1)
+    sd = model.state_dict()
+    big = make_frame(h, 3, pillars_per_agent=30000, seed=77)["processed_lidar"]
+    small = make_frame(h, 3, pillars_per_agent=500, seed=78)["processed_lidar"]
+    ref = oracle.pillar_vfe(big["voxel_features"], big["voxel_num_points"], big["voxel_coords"], sd, margs["voxel_size"], margs["lidar_range"])
+    feats, canvas = _run_pillar(big, sd, margs, 3, True)
+    scale = float(ref.abs().max())
+    assert float((feats.cpu() - ref).abs().max()) <= 2e-6 * scale
+    assert torch.equal(canvas.contiguous().cpu(), oracle.scatter(feats.cpu(), big["voxel_coords"], 3, 704, 200))
+    bn = tuple(sd[P + k].to(DEV) for k in ("norm.weight", "norm.bias", "norm.running_mean", "norm.running_var"))
+    cache = {}
+    for pl in (small, big, small):
+        args = (pl["voxel_features"].to(DEV), pl["voxel_num_points"].to(DEV), pl["voxel_coords"].to(DEV), sd[P + "linear.weight"].to(DEV), None, bn, 1e-3, True, False,
+                margs["voxel_size"], margs["lidar_range"][:3], 3, 200, 704)
+        f1, c1 = ops.pillar_vfe_scatter(*args, channels_last=True, canvas_cache=cache)
+        f0, c0 = ops.pillar_vfe_scatter(*args, channels_last=True)
+        assert torch.equal(f1, f0) and torch.equal(c1, c0)
+
+
 def test_matrix_core_encoder_without_absolute_xyz():
     """use_absolute_xyz = False (7 input features; not in the five configs): the same kernel with the centre term dropped."""
     h = builtin_config("mini_coalign")

@@ -41,8 +41,39 @@ def pillar(cl):
                                           margs["voxel_size"], margs["lidar_range"][:3], N, 200, 704, channels_last=cl)
 
 
+# post-processing on ~600 candidates shaped like a calibrated frame's (clusters of overlapping boxes around 120 objects)
+import numpy as np
+from oracle import coalign_oracle as _oracle
+_rs = np.random.RandomState(11)
+_K = 600
+_ctr = _rs.uniform([-120, -36], [120, 36], size=(120, 2))
+_b7 = np.zeros((_K, 7), np.float32)
+_pick = _rs.randint(0, 120, _K)
+_b7[:, 0:2] = _ctr[_pick] + _rs.normal(0, 0.4, (_K, 2)); _b7[:, 2] = -1.0; _b7[:, 3] = 1.5; _b7[:, 4] = _rs.uniform(1.5, 2.0, _K)
+_b7[:, 5] = _rs.uniform(3.5, 5.0, _K); _b7[:, 6] = _rs.uniform(-0.3, 0.3, _K) + (_pick % 2) * 1.57
+_corners = _oracle.boxes_to_corners_3d(torch.from_numpy(_b7), "hwl").to(dev)
+_scores = torch.from_numpy(_rs.uniform(0.2, 1, _K).astype(np.float32)).to(dev)
+_valid = torch.ones(_K, dtype=torch.uint8, device=dev)
+_L = ops.hip.lib()
+_nws = torch.empty(_L.coalign_nms_rotated_workspace_bytes(_K, 1000), dtype=torch.uint8, device=dev)
+_keep, _kc = torch.empty(1000, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+_oc, _os, _on = torch.empty(1000, 8, 3, device=dev), torch.empty(1000, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+_rng = [-140.8, -40, -3, 140.8, 40, 1]
+
+
+def _nms_fused():
+    ops.nms_rotated_gather(_corners, _scores, 0.15, 1000, _valid, None, _keep, _kc, _rng, _oc, _os, _on, _nws)
+
+
+def _nms_two_calls():
+    ops.nms_rotated_device(_corners, _scores, 0.15, 1000, valid=_valid, keep=_keep, keep_count=_kc, ws=_nws)
+    ops.gather_in_range(_corners, _scores, _keep, _kc, _rng, _oc, _os, _on)
+
+
 _cache = {}
 OPS = {
+    "nms_gather_K600": _nms_fused,
+    "nms_then_gather_K600": _nms_two_calls,
     "pillar_nchw": pillar(False),
     "pillar_nhwc": pillar(True),
     "pillar_nhwc_persistent": lambda: ops.pillar_vfe_scatter(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], pfn.linear.weight, None, bn, 1e-3, True, False,
