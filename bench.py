@@ -33,7 +33,7 @@ from coalign_amd.config import builtin_config  # noqa: E402
 from coalign_amd.detector import build_model, to_device  # noqa: E402
 from coalign_amd.pipeline import FramePipeline  # noqa: E402
 from coalign_amd.postprocess import build_postprocessor  # noqa: E402
-from coalign_amd.sharded import FrameRing, ring_batch, split_agents  # noqa: E402
+from coalign_amd.sharded import AgentGather, FrameRing, ring_batch, split_agents, stack_agents  # noqa: E402
 from coalign_amd.synthetic import calibrate_heads_, fill_parameters_, make_frame, make_points_frame  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # dense fp32 matrix peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -130,10 +130,28 @@ def main():
                     "voxeliser + encoder in every frame: `from_points` in the JSON line; `value` stays the from-pillars metric of BASELINE.json); on by default at --gpus 1")
     ap.add_argument("--no-from-points", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-frame-in-flight latency pass")
+    ap.add_argument("--mode", choices=("ring", "gather"), default="ring", help="multi-GPU schedule: 'ring' = one frame per rank and step, agents routed by all-to-all "
+                    "(weak scaling, the default); 'gather' = ONE frame per step, rank r encodes its block of the agents, one all-gather per scale, every rank then "
+                    "holds all maps and runs the ego tail (north_star's one-agent-per-GPU wording; strong scaling of a single frame)")
+    ap.add_argument("--comm-per-lane", action="store_true", help="one RCCL communicator per lane instead of ONE shared by all lanes (collectives are issued in frame order "
+                    "on every rank, so one communicator is deadlock-free by construction; several communicators used concurrently are not)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: build the exchange plans and shape-only buffers of EVERY rank for --gpus N and validate them against what "
+                    "RCCL's all_to_all_single / all_gather_into_tensor require (coalign_amd.sharded.preflight); prints the report as one JSON line")
     ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the oracle (0 = best of the committed sweep, else 16)")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     args = ap.parse_args()
+    if args.dry_run:
+        from coalign_amd.sharded import preflight
+        hy = builtin_config(args.config)
+        nx_, ny_, _ = [int(v) for v in hy["model"]["args"]["point_pillar_scatter"]["grid_size"]]
+        shapes = [(64, ny_ // 2, nx_ // 2), (128, ny_ // 4, nx_ // 4), (256, ny_ // 8, nx_ // 8)]
+        lanes = args.lanes if args.lanes > 0 else 4
+        rep = {"dry_run": True, "gpus": args.gpus, "ring": preflight(args.gpus, args.agents, shapes, True, None, lanes, "ring"),
+               "gather": preflight(args.gpus, args.agents, shapes, True, None, lanes, "gather"),
+               "launch": f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} --mode {args.mode}"}
+        print(json.dumps(rep), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -187,13 +205,34 @@ def main():
     use_graph = (not args.no_graph) and world == 1
     n_lanes = args.lanes if args.lanes > 0 else (3 if use_graph else 4)
     rings = None
+    exchanges = None
     if world > 1:
-        # one communicator (own RCCL stream) and one ring per lane: the lanes' all-to-alls do not serialise behind each other
-        groups = [dist.new_group(backend=backend) for _ in range(n_lanes)]
-        rings = [FrameRing(N, group=g) for g in groups]
+        # ONE communicator for all lanes by default: every rank issues its collectives in frame order (frame i -> lane i mod lanes, the
+        # exchange enqueued inside submit()), so a single RCCL communicator sees the same sequence everywhere -- deadlock-free by
+        # construction; the lanes' exchanges then serialise on the communicator's stream (0.1 ms each against ~3.7 ms of compute).
+        # --comm-per-lane restores one communicator per lane (concurrent use of several communicators is documented as deadlock-prone).
+        groups = [dist.new_group(backend=backend) for _ in range(n_lanes)] if args.comm_per_lane else [None] * n_lanes
         by_agent = [split_agents(f) for f in frames]
-        period = pool_n // world
-        step_batches = [ring_batch(by_agent, [f["pairwise_t_matrix"] for f in frames], rank, world, N, s) for s in range(period)]
+        if args.mode == "ring":
+            rings = [FrameRing(N, group=g) for g in groups]
+            exchanges = [r.exchange for r in rings]
+            period = pool_n // world
+            step_batches = [ring_batch(by_agent, [f["pairwise_t_matrix"] for f in frames], rank, world, N, s) for s in range(period)]
+        else:
+            # gather mode: every step is ONE frame; this rank encodes its contiguous block of the agents (empty slots where the block runs past
+            # N), the per-scale maps are all-gathered, and the ego tail runs with all N agents (on every rank: same latency, rank 0 reports)
+            gathers = [AgentGather(N, group=g) for g in groups]
+            rings = gathers
+            exchanges = [(lambda feats, _g=g: (_g.gather(feats), None)) for g in gathers]
+            per = gathers[0].per
+            mine = list(gathers[0].local_agents())
+            step_batches = []
+            for g_, f in enumerate(frames):
+                sets = [by_agent[g_][a] if a < N else None for a in range(rank * per, rank * per + per)]
+                if all(s_ is None for s_ in sets):       # a rank without agents still takes part in the collective: one empty slot set
+                    sets = [{k: v[:0] for k, v in by_agent[g_][0].items()}] + [None] * (per - 1)
+                step_batches.append({"processed_lidar": stack_agents(sets), "record_len": [per], "tail_record_len": [N],
+                                     "pairwise_t_matrix": f["pairwise_t_matrix"]})
         del by_agent
     else:
         step_batches = frames
@@ -201,7 +240,7 @@ def main():
 
     def make_pipe(graph):
         return FramePipeline(model, pp, anchors, lanes=n_lanes, result_lag=args.result_lag, graph=graph, device=dev,
-                             exchange=None if rings is None else [r.exchange for r in rings])
+                             exchange=exchanges)
 
     def sync():
         if world > 1:
@@ -295,7 +334,7 @@ def main():
     # ---- per-frame detection digests: pool frame -> digest; every recurrence of a pool frame must reproduce it exactly
     digests, consistent, mismatches = {}, True, []
     for idx, boxes, scores in results[-min(len(results), 2 * pool_n):]:
-        g = (idx * world + rank) % pool_n if world > 1 else idx % pool_n
+        g = (idx * world + rank) % pool_n if (world > 1 and args.mode == "ring") else idx % pool_n
         d = checksum(boxes, scores)
         if digests.setdefault(g, d) != d:
             consistent = False
@@ -405,7 +444,8 @@ def main():
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        fps = world * args.steps / dt
+        frames_per_step = world if args.mode == "ring" else 1        # gather mode: the ranks share ONE frame per step
+        fps = frames_per_step * args.steps / dt
         M = int(frames[0]["processed_lidar"]["voxel_features"].shape[0])
         scales = [(64, ny // 2, nx // 2), (128, ny // 4, nx // 4), (256, ny // 8, nx // 8)]
         alg_bytes = {"pillar_vfe_scatter": M * (32 * 4 * 4 + 4 * 4 + 4 + 64 * 4) + N * 64 * ny * nx * 4}
@@ -513,13 +553,15 @@ def main():
         result = {
             "metric": "frames_per_s_5agent_opv2v_synthetic", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": warm, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "scaling": "weak" if args.mode == "ring" else "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"OPV2V PointPillar + CoAlign multiscale attention fusion ({args.config}.yaml, BASELINE configs[2] "
                                    f"geometry): {N} agents/frame, {args.pillars} pillars/agent, canvas {nx}x{ny}, 70400 anchors, "
                                    f"full path incl. decode + rotated NMS, {pool_n} distinct frames in rotation",
-                       "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": world, "frames_in_flight": n_lanes,
+                       "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": frames_per_step, "frames_in_flight": n_lanes,
                        "result_lag_frames": pipe.result_lag, "hip_graph": use_graph, "conv_arithmetic": "native fp32" if default_terms == 0 else f"bf16x{default_terms}",
-                       "parallelism": "single GPU" if world == 1 else f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all, one communicator per lane",
+                       "parallelism": "single GPU" if world == 1 else (f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all" if args.mode == "ring" else
+                                                                                      f"one frame over {world} ranks (agent blocks), {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-gather, ego tail on every rank") +
+                                       (", one communicator per lane" if args.comm_per_lane else ", one communicator"),
                        "detections_last_frame": 0 if last_boxes is None else int(last_boxes.shape[0]),
                        "candidates_last_frame": pp.last_counts["candidates"]},
             "roofline": roofline, "north_star_hbm": north, "kernels": kernels,

@@ -134,7 +134,8 @@ class FramePipeline:
             with ops.timed("stage_exchange"):
                 feats, rows = self.exchange[k](feats)
         with ops.timed("stage_fuse_and_heads"):
-            out = model.fuse_and_head(feats, record, affine, rows)
+            # (an exchange that gathers agents encoded elsewhere says how many the ego tail sees: AgentGather, bench.py --mode gather)
+            out = model.fuse_and_head(feats, host_ints(batch["tail_record_len"]) if "tail_record_len" in batch else record, affine, rows)
         with ops.timed("stage_post_process(enqueue)"):
             return self.pp.post_process_async(self.meta, {"ego": out}, side_stream=POST_PROCESS_SIDE_STREAM)
 

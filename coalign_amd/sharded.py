@@ -210,3 +210,83 @@ def ring_batch(frames_by_agent: Sequence[Sequence[Dict[str, torch.Tensor]]], pai
     pool = len(frames_by_agent)
     sets = [frames_by_agent[(step * world + f) % pool][a] for f, a in encode_assignments(rank, world, n_agents)]
     return {"processed_lidar": stack_agents(sets), "record_len": [n_agents], "pairwise_t_matrix": pairwise[(step * world + rank) % pool]}
+
+
+# ------------------------------------------------------------------------------------------------ pre-flight (no communicator needed)
+def preflight(world: int, n_agents: int, feature_shapes: Sequence[Tuple[int, int, int]], channels_last: bool = True,
+              wire_dtype: Optional[torch.dtype] = None, lanes: int = 1, mode: str = "ring") -> dict:
+    """Everything about the exchange that can be checked WITHOUT a multi-GPU node: builds every rank's plans and (shape-only, ``meta`` device)
+    buffers and validates them against what ``all_to_all_single`` / ``all_gather_into_tensor`` require on the NCCL (= RCCL) backend:
+
+    * ring: rank s sends rank d exactly what d expects from s (split sizes match pairwise), every rank sends and receives ``n_agents`` rows,
+      every (frame, agent) of a step is encoded exactly once, the row table is a permutation, each rank talks to at most ``n_agents - 1`` peers;
+    * gather: every rank contributes the same number of rows (``per``), ``world * per >= n_agents``, blocks are contiguous and in rank order;
+    * both: the send / receive views handed to the collective are CONTIGUOUS VIEWS of the feature maps (no hidden copy: channels-last maps are
+      flattened in their own (H, W, C) order), one row = one agent, row size and every split boundary a multiple of 16 bytes.
+
+    Raises ``ValueError`` on the first violation; returns a report (bytes per rank and step, peers per rank, buffers per lane).
+    ``bench.py --gpus N --dry-run`` prints it; tests/test_sharded_cpu.py runs it for every world size 1..8."""
+    if mode not in ("ring", "gather"):
+        raise ValueError("mode must be 'ring' or 'gather'")
+    dt = torch.float32 if wire_dtype is None else wire_dtype
+    esize = torch.empty((), dtype=dt).element_size()
+
+    def fail(msg):
+        raise ValueError(f"exchange pre-flight ({mode}, world {world}, {n_agents} agents): {msg}")
+
+    def views_ok(n_rows, C, H, W):
+        t = torch.empty((n_rows, C, H, W), dtype=dt, device="meta", memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+        v = _rows_view(t)
+        if not v.is_contiguous() or tuple(v.shape) != (n_rows, C * H * W) or v.stride(0) != C * H * W:
+            fail(f"the row view of a [{n_rows}, {C}, {H}, {W}] map is not a dense [rows, row_size] matrix")
+        if (C * H * W * esize) % 16:
+            fail(f"row size {C * H * W * esize} B is not a multiple of 16 B")
+        return C * H * W * esize
+
+    row_bytes = [views_ok(max(n_agents, 1), C, H, W) for C, H, W in feature_shapes]
+    report = {"mode": mode, "world": world, "n_agents": n_agents, "lanes": lanes, "wire_dtype": str(dt), "row_bytes_per_scale": row_bytes,
+              "communicators": 1, "collectives_per_step": len(feature_shapes)}
+    if mode == "ring":
+        sends = [send_plan(r, world, n_agents) for r in range(world)]
+        recvs = [recv_plan(r, world, n_agents) for r in range(world)]
+        seen = set()
+        for r in range(world):
+            order, sc = sends[r]
+            agents, rc = recvs[r]
+            if sum(sc) != n_agents or sum(rc) != n_agents or len(order) != n_agents:
+                fail(f"rank {r} sends {sum(sc)} / receives {sum(rc)} rows, expected {n_agents}")
+            for d in range(world):
+                if sc[d] != recvs[d][1][r]:
+                    fail(f"rank {r} sends {sc[d]} rows to rank {d}, which expects {recvs[d][1][r]}")
+            if sorted(agents) != list(range(n_agents)):
+                fail(f"rank {r}'s received rows do not cover agents 0..{n_agents - 1} once: {agents}")
+            rows = [0] * n_agents
+            for slot, a in enumerate(agents):
+                rows[a] = slot
+            if sorted(rows) != list(range(n_agents)):
+                fail(f"rank {r}'s row table is not a permutation: {rows}")
+            for fa in encode_assignments(r, world, n_agents):
+                if fa in seen:
+                    fail(f"(frame, agent) {fa} is encoded twice")
+                seen.add(fa)
+        if len(seen) != world * n_agents:
+            fail(f"{len(seen)} (frame, agent) pairs encoded per step, expected {world * n_agents}")
+        peers = [sum(1 for d, c in enumerate(sends[r][1]) if c and d != r) for r in range(world)]
+        if world > 1 and max(peers) > max(1, min(world - 1, n_agents)):
+            fail(f"a rank talks to {max(peers)} peers")
+        report.update({"peers_per_rank": peers, "send_counts": [sc for _, sc in sends], "recv_counts": [rc for _, rc in recvs],
+                       "bytes_sent_per_rank_per_step": [sum(c for d, c in enumerate(sends[r][1]) if d != r) * sum(row_bytes) for r in range(world)],
+                       "buffers_per_lane": {"send": "the backbone's output maps themselves", "recv_bytes": n_agents * sum(row_bytes)}})
+    else:
+        per, blocks = agent_blocks(world, n_agents)
+        if per * world < n_agents:
+            fail(f"{world} blocks of {per} agents do not cover {n_agents}")
+        flat = [a for b in blocks for a in b]
+        if flat != list(range(n_agents)):
+            fail(f"agent blocks are not contiguous / in rank order: {blocks}")
+        for C, H, W in feature_shapes:
+            views_ok(per, C, H, W)
+            views_ok(world * per, C, H, W)
+        report.update({"per": per, "blocks": [list(b) for b in blocks], "bytes_sent_per_rank_per_step": [(world - 1) * per * sum(row_bytes)] * world,
+                       "buffers_per_lane": {"recv_bytes": world * per * sum(row_bytes)}})
+    return report

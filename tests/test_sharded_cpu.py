@@ -145,3 +145,32 @@ def test_ring_batches_route_every_agent_of_every_pool_frame_once():
                     assert torch.equal(pl["voxel_coords"][sel][:, 1:], by_agent[g][a]["voxel_coords"][:, 1:])
                     seen[(g, a)] = seen.get((g, a), 0) + 1
         assert seen == {(g, a): 1 for g in range(pool) for a in range(n)}
+
+
+def test_exchange_preflight_every_world_size():
+    """coalign_amd.sharded.preflight (what `bench.py --gpus N --dry-run` prints): plans of every rank consistent pairwise, every (frame, agent)
+    encoded once, contiguous row views for NCHW and channels-last maps, 16-byte rows -- for world sizes 1..8 and 5 / 8 agents, both schedules;
+    and it does fail on a broken configuration."""
+    import pytest
+    import torch
+    from coalign_amd.sharded import preflight
+    opv2v = [(64, 100, 352), (128, 50, 176), (256, 25, 88)]
+    lss = [(64, 120, 120), (128, 60, 60), (256, 30, 30)]
+    for world in range(1, 9):
+        for n, shapes in ((5, opv2v), (8, lss), (2, opv2v)):
+            for cl in (True, False):
+                for mode in ("ring", "gather"):
+                    rep = preflight(world, n, shapes, cl, None, 3, mode)
+                    assert rep["communicators"] == 1 and rep["collectives_per_step"] == 3
+                    if mode == "ring":
+                        assert max(rep["peers_per_rank"]) <= min(world - 1, n) and all(sum(c) == n for c in rep["send_counts"])
+                        if world > 1:      # all but the rows a rank keeps for itself cross a link, once
+                            keep = [rep["send_counts"][r][r] for r in range(world)]
+                            assert rep["bytes_sent_per_rank_per_step"] == [(n - k) * sum(rep["row_bytes_per_scale"]) for k in keep]
+                    else:
+                        assert rep["per"] * world >= n and sum(len(b) for b in rep["blocks"]) == n
+    assert preflight(5, 5, opv2v, wire_dtype=torch.float16)["row_bytes_per_scale"][0] == 64 * 100 * 352 * 2
+    with pytest.raises(ValueError):
+        preflight(2, 5, [(3, 5, 7)])                    # 105 floats per row: not a multiple of 16 bytes
+    with pytest.raises(ValueError):
+        preflight(2, 5, opv2v, mode="scatter")

@@ -8,6 +8,11 @@ for R in 2 4; do
 COALIGN_BENCH_BACKEND=gloo COALIGN_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $R --master-addr 127.0.0.1 --master-port $((29650 + R)) \
     bench.py --gpus $R --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes > $OUT/n$R.json 2> $OUT/n$R.err
 done
+# north_star's wording: ONE frame, agents split over the ranks, all-gather, ego tail (bench.py --mode gather); 2 and 5 ranks (5 = one agent per rank)
+for R in 2 5; do
+COALIGN_BENCH_BACKEND=gloo COALIGN_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $R --master-addr 127.0.0.1 --master-port $((29670 + R)) \
+    bench.py --gpus $R --mode gather --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes > $OUT/g$R.json 2> $OUT/g$R.err
+done
 python - $OUT <<'PY'
 import json,sys
 out=sys.argv[1]
@@ -22,6 +27,15 @@ for R in (2,4):
     same=all(ref["frame_digests"].get(k)==v for k,v in d["frame_digests"].items())
     print(f"N={R} (gloo, one GPU shared; functional only): {d['value']} frames/s, parallelism = {d['config']['parallelism']}, "
           f"bytes sent per rank and step = {d.get('exchange_bytes_sent_per_rank_per_step')}, {len(d['frame_digests'])} pool frames, digests equal to N=1: {same}, reproducible: {d['frame_digests_reproducible']}")
+    ok = ok and same
+for R in (2,5):
+    try:
+        d=json.loads([l for l in open(f"{out}/g{R}.json") if l.startswith("{")][-1])
+    except Exception as e:
+        print(f"gather N={R}: no result ({e})"); ok=False; continue
+    same=all(ref["frame_digests"].get(k)==v for k,v in d["frame_digests"].items())
+    print(f"gather N={R} (gloo, one GPU shared; functional only): {d['value']} frames/s ({d['scaling']}), parallelism = {d['config']['parallelism']}, "
+          f"{len(d['frame_digests'])} pool frames, digests equal to N=1: {same}")
     ok = ok and same
 print("N=1 digests:", ref["frame_digests"])
 print("MULTIRANK_CHECK", "PASS" if ok else "FAIL")
