@@ -111,9 +111,10 @@ class PointPillarBaselineMultiscale(nn.Module):
         x0 = feature_list[0]
         if x0.is_cuda and not self.training:
             kinds = {type(f) for f in self.fusion_net}
-            if kinds == {AttFusion} or kinds == {MaxFusion}:
-                if kinds == {AttFusion} and any(f.feature_dims != x.shape[1] for f, x in zip(self.fusion_net, feature_list)):
-                    raise ValueError("AttFusion feat_dim differs from the feature channels: the fused kernel scales by sqrt(C)")
+            # (an AttFusion whose configured feat_dim differs from its map's channels -- no shipped yaml -- takes the per-scale route below,
+            #  where the module rescales its input so that the scores are divided by sqrt(feat_dim) like the reference's)
+            plain_att = kinds == {AttFusion} and all(f.feature_dims == x.shape[1] for f, x in zip(self.fusion_net, feature_list))
+            if plain_att or kinds == {MaxFusion}:
                 fused = fuse_multiscale(feature_list, record_len, affine, ops.FUSE_ATT if kinds == {AttFusion} else ops.FUSE_MAX, rows)
                 if fused is not None:
                     return fused

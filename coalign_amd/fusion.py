@@ -88,5 +88,9 @@ class AttFusion(nn.Module):
         # ScaledDotProductAttention divides by sqrt(feat_dim) of the CONFIG (att_fuse.py:36-44), the kernel by sqrt(C) of the tensor:
         # the two agree for every shipped yaml; a config where they differ would silently diverge from the reference's checkpoints
         if self.feature_dims != xx.shape[1]:
-            raise ValueError(f"AttFusion(feat_dim={self.feature_dims}) fed {xx.shape[1]}-channel features: the fused kernel scales by sqrt(C)")
+            # not the case in any shipped yaml.  The kernel's scores are <X0, Xj> / sqrt(C); feeding s X with s = (C / feat_dim)^(1/4) turns them
+            # into <X0, Xj> / sqrt(feat_dim) and scales the output by s, which is divided out again (the warp is linear): the reference's
+            # result to float32 rounding (one extra multiply and divide per element), instead of raising
+            s = (xx.shape[1] / float(self.feature_dims)) ** 0.25
+            return ops.warp_fuse(xx * s, _ego_rows(normalized_affine_matrix, groups), groups, ops.FUSE_ATT, rows=rows) / s
         return ops.warp_fuse(xx, _ego_rows(normalized_affine_matrix, groups), groups, ops.FUSE_ATT, rows=rows)

@@ -38,8 +38,44 @@ def _nms(boxes: torch.Tensor, scores: torch.Tensor, thresh: float, pre_maxsize, 
         order = order[:pre_maxsize]
     if order.numel() == 0:
         return order, None
-    keep, cnt = ops.pcdet_nms(boxes[order].contiguous(), thresh, normal)
+    srt = boxes[order].contiguous()
+    if srt.shape[0] > PCDET_NMS_DEVICE_MAX:
+        return order[_nms_large(srt, thresh, normal)].contiguous(), None
+    keep, cnt = ops.pcdet_nms(srt, thresh, normal)
     return order[keep[: int(cnt.item())].long()].contiguous(), None
+
+
+PCDET_NMS_DEVICE_MAX = 16384          # coalign_pcdet_nms walks the bitmask on the device for up to this many boxes
+
+
+def _nms_large(srt: torch.Tensor, thresh: float, normal: bool, rows_per_chunk: int = 2048) -> torch.Tensor:
+    """More boxes than the device walk takes (the reference's nms_gpu has no size limit when ``pre_maxsize`` is None, iou3d_nms_utils.py:255-271):
+    the extension's own scheme -- suppression matrix on the GPU, greedy walk on the host (iou3d_nms.cpp:90-137) -- in row chunks: IoU of
+    ``rows_per_chunk`` sorted boxes against all, thresholded on the device, one bool block per chunk to the host."""
+    import numpy as np
+    n = srt.shape[0]
+    removed = np.zeros(n, dtype=bool)
+    keep = []
+    for r0 in range(0, n, rows_per_chunk):
+        rows = srt[r0: r0 + rows_per_chunk]
+        if normal:
+            a, b = rows, srt
+            lo_x = torch.max((a[:, 0] - a[:, 3] / 2)[:, None], (b[:, 0] - b[:, 3] / 2)[None])
+            hi_x = torch.min((a[:, 0] + a[:, 3] / 2)[:, None], (b[:, 0] + b[:, 3] / 2)[None])
+            lo_y = torch.max((a[:, 1] - a[:, 4] / 2)[:, None], (b[:, 1] - b[:, 4] / 2)[None])
+            hi_y = torch.min((a[:, 1] + a[:, 4] / 2)[:, None], (b[:, 1] + b[:, 4] / 2)[None])
+            inter = torch.clamp(hi_x - lo_x, min=0) * torch.clamp(hi_y - lo_y, min=0)
+            iou = inter / torch.clamp((a[:, 3] * a[:, 4])[:, None] + (b[:, 3] * b[:, 4])[None] - inter, min=1e-8)      # iou3d_nms_kernel.cu:313-325
+        else:
+            iou = ops.boxes_iou_bev(rows, srt)
+        sup = (iou > thresh).cpu().numpy()
+        for k in range(sup.shape[0]):
+            i = r0 + k
+            if removed[i]:
+                continue
+            keep.append(i)
+            removed[i + 1:] |= sup[k, i + 1:]
+    return torch.tensor(keep, dtype=torch.long, device=srt.device)
 
 
 def nms_gpu(boxes: torch.Tensor, scores: torch.Tensor, thresh: float, pre_maxsize=None, **kwargs):

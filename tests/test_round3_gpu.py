@@ -328,3 +328,202 @@ def test_iou_preds_rescoring_golden(golden):
     np.testing.assert_allclose(scores.cpu().numpy(), gb["iou_scores"], rtol=3e-7, atol=0)
     np.testing.assert_allclose(boxes.cpu().numpy(), gb["iou_boxes"], rtol=2e-6, atol=1e-5)
     assert not np.allclose(gb["iou_scores"][: len(g["i_scores"])], g["i_scores"][: len(gb["iou_scores"])])      # the rescoring changed something
+
+
+# ------------------------------------------------------------------------------------------------ cfg 4: the correction path at full size
+def _dair_stage1_hypes():
+    """The stage-1 (PointPillarUncertainty) config at DAIR-V2X-C geometry: 504 x 200 canvas, anchors l = 4.5, w = 2 (dairv2x yaml :57-75)."""
+    import copy
+    from coalign_amd.config import load_point_pillar_params
+    h, hd = copy.deepcopy(builtin_config("opv2v_pointpillar_uncertainty")), builtin_config("dairv2x_coalign")
+    rng, vox = list(hd["preprocess"]["cav_lidar_range"]), list(hd["preprocess"]["args"]["voxel_size"])
+    h["preprocess"]["cav_lidar_range"], h["preprocess"]["args"]["voxel_size"] = rng, vox
+    h["model"]["args"]["lidar_range"], h["model"]["args"]["voxel_size"] = rng, vox
+    h["postprocess"]["anchor_args"].update({"cav_lidar_range": rng, "l": 4.5, "w": 2, "h": 1.56})
+    h["postprocess"]["gt_range"] = rng
+    return load_point_pillar_params(h)
+
+
+def _plant_stage1_heads(objects_agent, anchors, rs):
+    """Head maps (cls / reg / unc, [1, A * k, H, W]) whose decode gives exactly `objects_agent` ([K, 7] = x, y, z, h, w, l, yaw in the agent's
+    frame): logit +4 at the nearest anchor, -9 elsewhere; regression deltas = the inverse of delta_to_boxes3d (voxel_postprocessor.py:405-450)."""
+    H, W, A, _ = anchors.shape
+    cls = np.full((1, A, H, W), -9.0, np.float32)
+    reg = np.zeros((1, A * 7, H, W), np.float32)
+    unc = rs.normal(-2.0, 0.3, (1, A * 3, H, W)).astype(np.float32)
+    xs, ys = anchors[0, :, 0, 0], anchors[:, 0, 0, 1]
+    for b in objects_agent:
+        j, i = int(np.abs(xs - b[0]).argmin()), int(np.abs(ys - b[1]).argmin())
+        a = int(np.abs(np.cos(b[6] - anchors[i, j, :, 6])).argmax())          # the anchor yaw (0 / 90 deg) closest to the heading, modulo pi
+        an = anchors[i, j, a]
+        r = b[6] - an[6]                  # not wrapped: without a direction head the decode returns r + r_anchor, i.e. the heading itself
+        d = np.sqrt(an[4] ** 2 + an[5] ** 2)
+        delta = [(b[0] - an[0]) / d, (b[1] - an[1]) / d, (b[2] - an[2]) / an[3], np.log(b[3] / an[3]), np.log(b[4] / an[4]), np.log(b[5] / an[5]), r]
+        cls[0, a, i, j] = 4.0
+        reg[0, a * 7: a * 7 + 7, i, j] = delta
+    return cls, reg, unc
+
+
+def _relative_error(poses, clean):
+    """(translation error [m], yaw error [deg]) of T_ego<-infra built from `poses` against the clean one."""
+    from coalign_amd.pose import get_pairwise_transformation
+    T, Tc = get_pairwise_transformation(poses, 2)[1, 0], get_pairwise_transformation(clean, 2)[1, 0]
+    dyaw = np.degrees(np.arctan2(T[1, 0], T[0, 0]) - np.arctan2(Tc[1, 0], Tc[0, 0]))
+    return float(np.hypot(*(T[:2, 3] - Tc[:2, 3]))), float(abs((dyaw + 180) % 360 - 180))
+
+
+def test_cfg4_correction_path_full_geometry_noise_sweep():
+    """BASELINE configs[3] end to end at the DAIR-V2X-C geometry (504 x 200, vehicle + road-side unit facing back), pose noise sigma in
+    {0, 0.2, 0.4, 0.6} (m / deg) like opencood/tools/inference_w_noise.py:39-214:
+      stage 1 on the device (PointPillarUncertainty forward against the oracle; post_process_stage1 on head maps that decode to the two
+      agents' views of ONE scene -- a random-init network cannot produce matching detections in two frames, so the detections are planted at
+      the head, everything after the head is the product path) -> box alignment (host graph + coalign_pose_graph_optimize) -> corrected poses
+      (hook of intermediate_fusion_dataset.py:301-328) -> pairwise matrices -> CoAlign fusion model -> post-process -> TP / FP at IoU 0.3 / 0.5 / 0.7.
+    Asserted per sigma: device stage-1 detections == oracle's, device-aligned poses == oracle-aligned (1e-5 m / 1e-4 deg), alignment
+    LOWERS the relative pose error (sigma > 0), TP / FP sequences and AP identical to the oracle's run of the same pipeline."""
+    import math
+    from coalign_amd import box_align, evaluation as ev
+    from coalign_amd.pose import generate_noise, get_pairwise_transformation
+    from coalign_amd.postprocess import build_postprocessor
+    from coalign_amd.synthetic import calibrate_heads_
+    from tests.inference_synthetic import plant_ground_truth
+
+    # ---- stage 1: the network at full geometry against the oracle (2 agents)
+    h1 = _dair_stage1_hypes()
+    assert [int(v) for v in h1["model"]["args"]["point_pillar_scatter"]["grid_size"]][:2] == [504, 200]
+    m1 = build_model(h1)
+    fill_parameters_(m1, seed=2, cls_bias=-1.0)
+    sd1 = {k: v.clone() for k, v in m1.state_dict().items()}
+    hd = builtin_config("dairv2x_coalign")
+    frame = make_frame(hd, 2, pillars_per_agent=7000, seed=5, infra_agent=True)
+    with torch.no_grad():
+        out1 = m1.to(DEV).eval()({"processed_lidar": to_device(frame["processed_lidar"], DEV)})
+        ref1 = oracle.pointpillar_forward(sd1, h1["model"]["args"], frame)
+    for k in ("cls_preds", "reg_preds", "unc_preds"):
+        e = float((out1[k].cpu() - ref1[k]).abs().max()) / float(ref1[k].abs().max())
+        assert e < 1e-4, (k, e)
+
+    # ---- one scene, two views: objects in the ego (= world) frame, each agent sees the ones inside its range (+ 5 cm of detection noise)
+    rs = np.random.RandomState(42)
+    clean = [np.zeros(6), np.array([30.0, 5.0, 0.0, 0.0, 170.0, 0.0])]
+    gx, gy = np.meshgrid(np.arange(-24, 72, 12.0), np.arange(-30, 31, 10.0))
+    world = np.stack([gx.ravel() + rs.uniform(-2, 2, gx.size), gy.ravel() + rs.uniform(-2, 2, gx.size)], 1)
+    yaw_w = rs.uniform(-2.5, 2.5, len(world))                 # headings away from +-pi: the two agents' world yaws must not straddle the wrap
+    pp1 = build_postprocessor(h1["postprocess"], False)
+    anchors1 = pp1.generate_anchor_box()
+    rngd = hd["preprocess"]["cav_lidar_range"]
+    heads = {"cls_preds": [], "reg_preds": [], "unc_preds": []}
+    for pose in clean:
+        th = math.radians(pose[4])
+        R = np.array([[math.cos(th), math.sin(th)], [-math.sin(th), math.cos(th)]])           # world -> agent
+        xy = (world - pose[:2]) @ R.T + rs.normal(0, 0.05, world.shape)
+        inside = (xy[:, 0] > rngd[0] + 6) & (xy[:, 0] < rngd[3] - 6) & (xy[:, 1] > rngd[1] + 6) & (xy[:, 1] < rngd[4] - 6)
+        obj = np.zeros((int(inside.sum()), 7))
+        obj[:, :2], obj[:, 2], obj[:, 3:6], obj[:, 6] = xy[inside], -1.0, [1.56, 2.0, 4.5], yaw_w[inside] - th
+        c, r, u = _plant_stage1_heads(obj, anchors1, rs)
+        heads["cls_preds"].append(c); heads["reg_preds"].append(r); heads["unc_preds"].append(u)
+    heads = {k: torch.from_numpy(np.concatenate(v)) for k, v in heads.items()}
+    a1 = torch.from_numpy(anchors1)
+    cd, bd, ud = pp1.post_process_stage1({k: v.to(DEV) for k, v in heads.items()}, a1)
+    co, bo, uo = oracle.post_process_stage1(heads, a1, h1["postprocess"])
+    assert [len(c) for c in cd] == [len(c) for c in co] and min(len(c) for c in cd) >= 20
+    for i in range(2):
+        np.testing.assert_allclose(cd[i].cpu().numpy(), co[i].numpy(), rtol=1e-5, atol=1e-4)
+        assert np.array_equal(ud[i].cpu().numpy(), uo[i].numpy())
+    corners_d = [c.cpu().numpy().astype(np.float64) for c in cd]
+    corners_o = [c.numpy().astype(np.float64) for c in co]
+    unc_d, unc_o = [u.cpu().numpy().astype(np.float64) for u in ud], [u.numpy().astype(np.float64) for u in uo]
+
+    # ---- the fusion model (full geometry), heads calibrated on the clean-pose frame, logits kept clear of the score threshold
+    model = build_model(hd)
+    fill_parameters_(model, seed=1)
+    model = model.to(DEV).eval()
+    pp = build_postprocessor(hd["postprocess"], False)
+    fd = to_device(frame, DEV)
+    calibrate_heads_(model, fd, pp.params["target_args"]["score_threshold"], 400)
+    anchors = torch.from_numpy(pp.generate_anchor_box())
+    meta = {"ego": {"transformation_matrix": torch.eye(4), "anchor_box": anchors}}
+    flags = dict(use_uncertainty=True, landmark_SE2=True, adaptive_landmark=False, normalize_uncertainty=False, abandon_hard_cases=True, drop_hard_boxes=True)
+    sigmas = (0.0, 0.2, 0.4, 0.6)
+    runs = []
+    for s in sigmas:
+        g = np.random.RandomState(1000 + int(10 * s))
+        noisy = np.array([p + generate_noise(s, s, rng=g) for p in clean])
+        ref_d = box_align.box_alignment_relative_sample_np(corners_d, noisy.copy(), uncertainty_list=unc_d, **flags)
+        ref_o = oracle.box_alignment_relative_sample_np(corners_o, noisy.copy(), unc_o, **flags)
+        np.testing.assert_allclose(ref_d[:, :2], ref_o[:, :2], rtol=0, atol=1e-5, err_msg=f"sigma {s}")
+        assert np.abs((ref_d[:, 2] - ref_o[:, 2] + 180) % 360 - 180).max() < 1e-4, s
+        fixed_d, fixed_o = noisy.copy(), noisy.copy()
+        fixed_d[:, [0, 1, 4]], fixed_o[:, [0, 1, 4]] = ref_d, ref_o
+        e_noisy, e_fixed = _relative_error(noisy, clean), _relative_error(fixed_d, clean)
+        print(f"cfg4 sigma {s}: relative pose error noisy {e_noisy[0]:.3f} m / {e_noisy[1]:.3f} deg -> aligned {e_fixed[0]:.3f} m / {e_fixed[1]:.3f} deg")
+        if s > 0:
+            assert e_fixed[0] < 0.5 * e_noisy[0] + 0.02 and e_fixed[1] < 0.5 * e_noisy[1] + 0.02, (s, e_noisy, e_fixed)
+        assert e_fixed[0] < 0.08 and e_fixed[1] < 0.08, (s, e_fixed)                    # left: the 5 cm detection noise of the planted boxes
+        runs.append((s, torch.from_numpy(get_pairwise_transformation(fixed_d, 5)[None]), torch.from_numpy(get_pairwise_transformation(fixed_o, 5)[None])))
+    # a common bias shift that keeps every logit of every run away from the threshold's logit (a 1e-6 difference must not flip a candidate)
+    lt = math.log(0.2 / 0.8)
+    with torch.no_grad():
+        logits = [model(dict(fd, pairwise_t_matrix=pw.to(DEV)))["cls_preds"].double().flatten() for _, pw, _ in runs]
+        for shift in np.arange(0.0, 0.05, 0.0005):
+            if all(float((l + shift - lt).abs().min()) > 2e-4 for l in logits):
+                break
+        else:
+            raise AssertionError("no bias shift clears the threshold for all four runs")
+        model.cls_head.bias += float(shift)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    for s, pw_d, pw_o in runs:
+        with torch.no_grad():
+            out = model(dict(fd, pairwise_t_matrix=pw_d.to(DEV)))
+            ref = oracle.coalign_forward(sd, hd["model"]["args"], dict(frame, pairwise_t_matrix=pw_o))
+        boxes, scores = pp.post_process(meta, {"ego": out})
+        rb, rsc, info = oracle.post_process([ref], anchors, hd["postprocess"])
+        assert pp.last_counts["candidates"] == len(info["cand_index"]) > 100, s
+        assert boxes.shape == rb.shape and rb.shape[0] > 30, (s, boxes.shape, rb.shape)
+        gt = plant_ground_truth(boxes, 9000 + int(10 * s))
+        st_d, st_o = ev.new_result_stat(), ev.new_result_stat()
+        for thr in ev.IOU_THRESHOLDS:
+            ev.caluclate_tp_fp(boxes, scores, gt.to(DEV), st_d, thr)
+            oracle.caluclate_tp_fp(rb.numpy(), rsc.numpy(), gt.numpy(), st_o, thr)
+            assert st_d[thr]["tp"] == st_o[thr]["tp"] and st_d[thr]["fp"] == st_o[thr]["fp"] and st_d[thr]["gt"] == st_o[thr]["gt"], (s, thr)
+            assert ev.calculate_ap(st_d, thr)[0] == oracle.calculate_ap(st_o, thr)[0], (s, thr)
+        assert sum(st_d[0.7]["tp"]) > 5, s
+
+
+def test_attfusion_with_a_configured_feat_dim_that_differs_from_the_channels():
+    """ScaledDotProductAttention divides by sqrt(feat_dim) of the CONFIG (att_fuse.py:36-47, fusion_in_one.py:96-136); the kernel by sqrt(C).
+    A module built with another feat_dim now computes the reference's result (input rescaling, fusion.py) instead of raising."""
+    import torch.nn.functional as F
+    from coalign_amd.fusion import AttFusion
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 64, 24, 40, generator=g)
+    theta = torch.tensor([[[1, 0, 0], [0, 1, 0]], [[0.98, -0.1, 0.05], [0.1, 0.98, -0.02]], [[1.0, 0.05, -0.1], [-0.05, 1.0, 0.04]]], dtype=torch.float64)
+    aff = torch.zeros(1, 5, 5, 2, 3, dtype=torch.float64)
+    aff[0, 0, :3] = theta
+    w = oracle.warp_affine_simple(x, theta, (24, 40))
+    q = w.view(3, 64, -1).permute(2, 0, 1)
+    want = torch.bmm(F.softmax(torch.bmm(q, q.transpose(1, 2)) / np.sqrt(16.0), -1), q).permute(1, 2, 0).reshape(3, 64, 24, 40)[0]
+    got = AttFusion(16)(x.to(DEV), [3], aff.to(DEV))[0].cpu()
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    plain = AttFusion(64)(x.to(DEV), [3], aff.to(DEV))[0].cpu()
+    assert float((plain - want).abs().max()) > 1e-3 * float(want.abs().max())       # sqrt(64) and sqrt(16) really differ on this input
+
+
+def test_pcdet_nms_beyond_the_device_walk_limit(monkeypatch):
+    """nms_gpu / nms_normal_gpu with more boxes than coalign_pcdet_nms walks on the device (the reference has no size limit): the
+    chunked host walk gives the oracle's keep list; forced at a small limit so that the test stays small."""
+    from coalign_amd import pcdet
+    rs = np.random.RandomState(4)
+    n = 3000
+    b = np.zeros((n, 7), np.float32)
+    b[:, 0] = rs.uniform(-60, 60, n); b[:, 1] = rs.uniform(-30, 30, n); b[:, 3] = rs.uniform(3, 5, n); b[:, 4] = rs.uniform(1.5, 2.2, n); b[:, 5] = 1.6
+    b[:, 6] = rs.uniform(-3.1, 3.1, n)
+    sc = rs.uniform(0, 1, n).astype(np.float32)
+    boxes, scores = torch.from_numpy(b).to(DEV), torch.from_numpy(sc).to(DEV)
+    for normal, thr in ((False, 0.1), (True, 0.3)):
+        fn = pcdet.nms_normal_gpu if normal else pcdet.nms_gpu
+        ref = fn(boxes, scores, thr)[0]
+        monkeypatch.setattr(pcdet, "PCDET_NMS_DEVICE_MAX", 1000)
+        big = fn(boxes, scores, thr)[0]
+        monkeypatch.setattr(pcdet, "PCDET_NMS_DEVICE_MAX", 16384)
+        assert torch.equal(big, ref), normal
