@@ -104,6 +104,44 @@ def test_unchanged_reference_yamls_load_and_build():
         build_model(ref)                                                     # the unchanged yaml drives the plugin classes
 
 
+def test_kernel_routes_of_every_config():
+    """coalign_amd.routes.plan: (a) the configs behind the five BASELINE workloads leave NO 3x3 / skip / head layer on a library fallback, run
+    the one-launch channels-last fusion and the matrix-core pillar encoder; a config built to fall off the fast path (Cout % 64 != 0,
+    distance feature, 96-channel scale) is reported, not silent.  (b) the committed walk over the reference's hypes_yaml/**/pointpillar*.yaml
+    (tests/golden/yaml_routes.json: 16 yamls of the hot-path families, 21 of other families) is reproduced when the checkout is present."""
+    import copy
+    import glob
+    import json
+    from coalign_amd.routes import plan, summary
+    for cfg in ("opv2v_coalign", "dairv2x_coalign", "opv2v_pointpillar_late", "opv2v_pointpillar_uncertainty", "lss_coalign_fusion"):
+        h = builtin_config(cfg)
+        if "core_method" not in h.get("model", {}) or h["model"]["core_method"] not in ("point_pillar_baseline_multiscale", "point_pillar_coalign", "point_pillar", "point_pillar_uncertainty"):
+            continue                                   # cfg 5 ships only its fusion step (SURVEY 8a row P)
+        p = plan(h)
+        assert p["outside_hot_path"] is None and p["fallbacks"] == [], (cfg, p["fallbacks"])
+        assert p["pillar"].startswith("matrix-core"), cfg
+        assert all(not r.startswith("MIOpen") for r in p["layers"].values()), cfg
+        if p["fusion"] is not None:
+            assert p["fusion"].startswith("warp_fuse_nhwc"), cfg
+    odd = copy.deepcopy(builtin_config("opv2v_coalign"))
+    odd["model"]["args"]["base_bev_backbone"]["num_filters"] = [64, 96, 256]
+    odd["model"]["args"]["att"]["feat_dim"] = [64, 96, 256]
+    odd["model"]["args"]["pillar_vfe"]["with_distance"] = True
+    p = plan(odd)
+    assert "fusion" in p["fallbacks"] and any("layer1" in n for n in p["fallbacks"]) and p["pillar"].startswith("fp32 VALU")
+    table = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "yaml_routes.json")))
+    hot = {k: v for k, v in table.items() if not v.get("outside_hot_path")}
+    assert len(table) == 37 and len(hot) == 16 and all(v["fallbacks"] == [] for v in hot.values())
+    base = "/root/reference/opencood/hypes_yaml/"
+    if os.path.isdir(base):
+        for path in sorted(glob.glob(base + "**/pointpillar*.yaml", recursive=True)):
+            try:
+                got = summary(plan(load_yaml(path)))
+            except Exception as e:      # noqa: BLE001
+                got = {"outside_hot_path": f"{type(e).__name__}: {str(e)[:120]}"}
+            assert got == table[path[len(base):]], path
+
+
 def test_state_dict_names_match_reference(golden):
     for cfg, gname in (("mini_coalign", "model_mini.npz"), ("mini_pointpillar_late", "late_mini.npz")):
         g = golden(gname)
