@@ -977,16 +977,16 @@ __global__ __launch_bounds__(256) void pillar_prep_kernel(const int *__restrict_
 //     (Measured on the round-robin, register-prefetched version: 20 us, of which 12 us remained with the arithmetic AND the stores switched
 //      off -- 4096 waves x 5 dependent passes x one exposed memory round trip each; profiles/round3/pillar_rows_ablation.txt.)
 typedef __attribute__((address_space(3))) void *lptr_ps_t;
-typedef const __attribute__((address_space(4))) int *cint_ps_t;
 constexpr int kRound = 5;                                   // pairs per round (5 KB of points per wavefront in LDS)
 
 template <bool ABS>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(PfnArgs a, float *__restrict__ canvas, int *__restrict__ dest, int reset_cellmap) {
-    constexpr int kWaveLds = 64 * kRowBytes + kRound * 1024;
+    constexpr int kWaveLds = 64 * kRowBytes + kRound * 1024 + 2 * kRound * 32;          // staged rows | the round's points | the round's pillar records
     __shared__ __attribute__((aligned(16))) char lds[kWavesPerBlock * kWaveLds];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
     char *wave_lds = lds + wv * kWaveLds;
     char *pbuf = wave_lds + 64 * kRowBytes;
+    char *meta = pbuf + kRound * 1024;
     const int gwave = blockIdx.x * kWavesPerBlock + wv, nwave = gridDim.x * kWavesPerBlock;
     if (a.M_dev) a.M = min(max(*a.M_dev, 0), a.M);
     if (a.M_dev && dest && blockIdx.x == 0 && threadIdx.x == 0) dest[-1] = a.M;      // the device-count form keeps "rows written" in front of the list
@@ -996,7 +996,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(Pfn
     if (p0 >= p1) return;
     const int ncell = a.ny * a.nx;
     const char *pts_b = reinterpret_cast<const char *>(a.pts);
-    const cint_ps_t np_s = (cint_ps_t)a.npts, cd_s = (cint_ps_t)a.coords, cm_s = (cint_ps_t)a.cellmap;      // wave-uniform indices below: scalar loads
+    const char *np_b = reinterpret_cast<const char *>(a.npts), *cd_b = reinterpret_cast<const char *>(a.coords);
     char *cm_b = reinterpret_cast<char *>(a.cellmap), *feat_b = reinterpret_cast<char *>(a.feats), *cv_b = reinterpret_cast<char *>(canvas),
          *dest_b = reinterpret_cast<char *>(dest);
     // a round's points go straight into LDS (issued from inline assembly: after a BUILTIN LDS-DMA hipcc puts s_waitcnt vmcnt(0) in front of every
@@ -1013,34 +1013,30 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(Pfn
             }
         }
     };
+    // counts, coordinates and the cell-map entries of a round's ten pillars: lane j fetches pillar 2 r0 + j (two dependent memory round trips:
+    // coordinates -> cell-map entry), ONCE per round and for all ten in parallel, and leaves a 32-byte record in LDS; the passes read their
+    // records from there.  (One lookup chain per pass, even prefetched a pass ahead, bounded every pass by two memory latencies.)
+    auto fetch_meta = [&](int r0) {
+        if (lane < 2 * kRound) {
+            const int mj = min(2 * r0 + lane, a.M - 1);
+            const int np_j = *reinterpret_cast<const int *>(np_b + (unsigned)mj * 4u);
+            const int4 cd_j = *reinterpret_cast<const int4 *>(cd_b + (unsigned)mj * 16u);
+            const int cell = cd_j.y + cd_j.z * a.nx + cd_j.w;                          // z + y * nx + x (point_pillar_scatter.py:54)
+            const bool ok = cd_j.x >= 0 && cd_j.x < a.n_agents && cell >= 0 && cell < ncell;
+            const int slot_j = ok ? cd_j.x * ncell + cell : -1;
+            const int own_j = a.unique ? 0 : *reinterpret_cast<const int *>(cm_b + (unsigned)max(slot_j, 0) * 4u);
+            int4 *rec = reinterpret_cast<int4 *>(meta + lane * 32);
+            rec[0] = make_int4(np_j, cd_j.y, cd_j.z, cd_j.w);
+            rec[1] = make_int4(slot_j, own_j, 0, 0);
+        }
+    };
     issue_round(p0);                                                                   // in flight while the channel parameters are fetched and split
+    fetch_meta(p0);
     const MxChan mc = load_mx<ABS>(a, lane);
     *reinterpret_cast<uint4 *>(wave_lds + lane * kRowBytes + 48) = make_uint4(0u, 0u, 0u, 0u);          // part 3 of every row: the zero half of step 2
     const bool ch0 = col < a.C, ch1 = 32 + col < a.C;
     for (int r0 = p0; r0 < p1; r0 += kRound) {
         const int nr = min(kRound, p1 - r0);
-        // counts, coordinates AND the cell-map entries of a pair through the scalar cache: every index is wave-uniform (pillar A / B of the
-        // pair), so the pass loop issues no vector loads at all -- its only vector-memory instructions are the stores, and nothing in a pass
-        // waits on vmcnt (which retires in order and counts stores).  The cell map is read-only here except for the winners' own resets;
-        // a loser that reads a stale or a reset entry sees "not me" either way.  One pass ahead.
-        struct Meta { int npA, npB; int4 cA, cB; int slotA, slotB, ownA, ownB; };
-        auto slot_s = [&](const int4 c) -> int {
-            const int cell = c.y + c.z * a.nx + c.w;                                   // z + y * nx + x (point_pillar_scatter.py:54)
-            const bool ok = c.x >= 0 && c.x < a.n_agents && cell >= 0 && cell < ncell;
-            return ok ? c.x * ncell + cell : -1;
-        };
-        auto meta_of = [&](int pair) -> Meta {
-            const int mA = 2 * pair, mB = min(mA + 1, a.M - 1);
-            Meta t;
-            t.npA = np_s[mA]; t.npB = np_s[mB];
-            t.cA = make_int4(cd_s[4 * mA], cd_s[4 * mA + 1], cd_s[4 * mA + 2], cd_s[4 * mA + 3]);
-            t.cB = make_int4(cd_s[4 * mB], cd_s[4 * mB + 1], cd_s[4 * mB + 2], cd_s[4 * mB + 3]);
-            t.slotA = slot_s(t.cA); t.slotB = slot_s(t.cB);
-            t.ownA = a.unique ? 0 : cm_s[max(t.slotA, 0)];
-            t.ownB = a.unique ? 0 : cm_s[max(t.slotB, 0)];
-            return t;
-        };
-        Meta cur = meta_of(r0);
         __builtin_amdgcn_s_waitcnt(0x0F70);                                            // vmcnt(0): the round's points are in LDS (once per round)
         coalign::wave_lds_sync();
 #pragma unroll
@@ -1052,10 +1048,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(Pfn
                 PairIn in;
                 in.q = *reinterpret_cast<const float4 *>(pbuf + k * 1024 + lane * 16);
                 if (a.P < 32 && col >= a.P) in.q = make_float4(0.f, 0.f, 0.f, 0.f);
-                in.np = half ? cur.npB : cur.npA;
-                in.cd = half ? cur.cB : cur.cA;
-                const int slot = half ? cur.slotB : cur.slotA, owner = half ? cur.ownB : cur.ownA;
-                if (k + 1 < nr) cur = meta_of(pair + 1);                               // two dependent scalar round trips, hidden behind this pass
+                const int4 *rec = reinterpret_cast<const int4 *>(meta + (2 * k + half) * 32);
+                const int4 r0v = rec[0], r1v = rec[1];
+                in.np = r0v.x;
+                in.cd = make_int4(0, r0v.y, r0v.z, r0v.w);
+                const int slot = r1v.x, owner = r1v.y;
                 float y[2];
                 if (a.debug & 4) { y[0] = in.q.x + (float)in.np; y[1] = in.q.y + (float)in.cd.w; }
                 else mx_pair_half<ABS>(a, mc, wave_lds, lane, in, hasB, y);
@@ -1079,8 +1076,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(Pfn
             }
         }
         if (r0 + kRound < p1) {                                                        // more than five pairs per wavefront (M > 40 960): next round
-            coalign::wave_lds_sync();                                                  // this round's reads of pbuf are done (their data was consumed above)
+            coalign::wave_lds_sync();                                                  // this round's reads of pbuf / meta are done (their data was consumed above)
             issue_round(r0 + kRound);
+            fetch_meta(r0 + kRound);
         }
     }
 }
