@@ -27,24 +27,27 @@ MAX_AGENTS, MAX_LANDMARKS = 8, 256         # limits of coalign_pose_graph_optimi
 
 
 def pose_to_tfm(pose: np.ndarray) -> np.ndarray:
-    """[N, 3] (x, y, yaw) or [N, 6] (x, y, z, roll, yaw, pitch), degrees -> [N, 4, 4] float32 (transformation_utils.py:93-160)."""
-    p = np.asarray(pose).astype(np.float32)
+    """[N, 3] (x, y, yaw) or [N, 6] (x, y, z, roll, yaw, pitch), degrees -> [N, 4, 4] float32 (transformation_utils.py:93-160).
+    Evaluated with torch float32 operations like the reference (numpy input goes through ``check_numpy_to_torch(...).float()`` there):
+    numpy's and torch's float32 cos / sin / deg2rad differ in the last bit now and then, and the clustering below thresholds float32
+    distances that cancel to rounding noise for near-coincident detections."""
+    p = torch.from_numpy(np.ascontiguousarray(np.asarray(pose))).float()
     n = p.shape[0]
-    tfm = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
-    rad = lambda d: np.deg2rad(d, dtype=np.float32)
+    tfm = torch.eye(4).view(1, 4, 4).repeat(n, 1, 1)
+    ang = lambda col: torch.deg2rad(p[:, col])
     if p.shape[1] == 3:
-        c, s = np.cos(rad(p[:, 2])), np.sin(rad(p[:, 2]))
+        c, s = torch.cos(ang(2)), torch.sin(ang(2))
         tfm[:, 0, 0], tfm[:, 0, 1], tfm[:, 1, 0], tfm[:, 1, 1] = c, -s, s, c
         tfm[:, 0, 3], tfm[:, 1, 3] = p[:, 0], p[:, 1]
-        return tfm
-    cy, sy = np.cos(rad(p[:, 4])), np.sin(rad(p[:, 4]))
-    cr, sr = np.cos(rad(p[:, 3])), np.sin(rad(p[:, 3]))
-    cp, sp = np.cos(rad(p[:, 5])), np.sin(rad(p[:, 5]))
+        return tfm.numpy()
+    cy, sy = torch.cos(ang(4)), torch.sin(ang(4))
+    cr, sr = torch.cos(ang(3)), torch.sin(ang(3))
+    cp, sp = torch.cos(ang(5)), torch.sin(ang(5))
     tfm[:, 0, 3], tfm[:, 1, 3], tfm[:, 2, 3] = p[:, 0], p[:, 1], p[:, 2]
     tfm[:, 0, 0], tfm[:, 0, 1], tfm[:, 0, 2] = cp * cy, cy * sp * sr - sy * cr, -cy * sp * cr - sy * sr
     tfm[:, 1, 0], tfm[:, 1, 1], tfm[:, 1, 2] = sy * cp, sy * sp * sr + cy * cr, -sy * sp * cr + cy * sr
     tfm[:, 2, 0], tfm[:, 2, 1], tfm[:, 2, 2] = sp, -cp * sr, cp * cr
-    return tfm
+    return tfm.numpy()
 
 
 def corner_to_center(corner3d: np.ndarray, order: str = "lwh") -> np.ndarray:
@@ -63,8 +66,11 @@ def corner_to_center(corner3d: np.ndarray, order: str = "lwh") -> np.ndarray:
 
 
 def _project_f32(corners: np.ndarray, tfm: np.ndarray) -> np.ndarray:
-    c = np.asarray(corners).astype(np.float32)
-    return c @ tfm[:3, :3].T + tfm[:3, 3]
+    """box_utils.project_box3d on numpy input (:278-316): float32, the 4 x 4 applied to HOMOGENEOUS corners in one torch.matmul (the
+    translation is the fourth product of each dot product, not a separate addition: other rounding)."""
+    c = torch.from_numpy(np.ascontiguousarray(np.asarray(corners))).float().transpose(1, 2)
+    c = torch.cat((c, torch.ones(c.shape[0], 1, 8)), dim=1)
+    return torch.matmul(torch.from_numpy(np.asarray(tfm)).float(), c)[:, :3, :].transpose(1, 2).numpy()
 
 
 class PoseGraph:
@@ -99,7 +105,11 @@ def build_pose_graph(pred_corners_list: Sequence[np.ndarray], noisy_lidar_pose: 
     tfm = pose_to_tfm(noisy_lidar_pose)
     local = np.concatenate([corner_to_center(c) for c in pred_corners_list if len(c)], axis=0)                       # float64, agent frames
     world = np.concatenate([corner_to_center(_project_f32(c, tfm[i])) for i, c in enumerate(pred_corners_list) if len(c)], axis=0)
-    centre, yaw = world[:, :3], world[:, 6]                                                                           # float32, world frame
+    # float32, world frame.  CONTIGUOUS copies like the reference's np.concatenate of slices (:166-180): the all-pair distance below cancels
+    # ~1e3-sized squares in float32, two detections of one object a centimetre apart land within rounding of zero, and whether sqrt sees a
+    # tiny positive or a tiny negative number (NaN: "not near", the pair is never clustered) depends on the matmul's summation order --
+    # which BLAS chooses by memory layout (found by the cfg-4 sweep test: a strided view paired two boxes the reference's layout leaves apart)
+    centre, yaw = np.ascontiguousarray(world[:, :3]), np.ascontiguousarray(world[:, 6])
     owner = np.repeat(np.arange(n_agents), counts)
     certainty = None
     if use_uncertainty and uncertainty_list is not None:
