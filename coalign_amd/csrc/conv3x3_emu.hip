@@ -68,14 +68,19 @@ enum { LAYOUT_NCHW = 0, LAYOUT_OUT_NHWC = 1, LAYOUT_IN_NHWC = 2 };
 // TAPK ("K = 144"): a barrier interval is 16 input channels x 9 taps = nine MFMA steps whose K = 16 is the 16 channels of ONE tap (lanes
 // 0-31 channels 0-7, lanes 32-63 channels 8-15) -- no zero tenth tap, 10 % fewer MFMAs.  Weight image [9 taps][term][2 channel halves]
 // [64 cout][8 cin] (55 KB per interval, double buffered), split patch as for KCH = 2.
-template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE = 1, int PBUF = 2, bool TAPK = false>
+// XV bit 0 (STACK): the N images of the batch are tiled as ONE tall image of N * H rows (a tile may straddle two images: two zero rows
+// in the patch stand in for the padding below the upper image and above the lower one); bit 1 (NCO1): a wavefront owns 32 output
+// channels, the workgroup has 2 * NPB wavefronts.  Both exist for load balance, see dispatch_tapk().
+template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE = 1, int PBUF = 2, bool TAPK = false, int XV = 0>
 struct Geo {
     static_assert(!TAPK || KCH == 2, "tap-major steps pair the two 8-channel halves of a 16-channel interval");
-    static constexpr int NCO = NPB >= 4 ? 2 : 1;                              // accumulator tiles (32 output channels each) per wave
-    static constexpr int WAVES = NPB >= 4 ? NPB : 2 * NPB;
+    static constexpr bool STACK = (XV & 1) != 0, NCO1 = (XV & 2) != 0;
+    static_assert(!STACK || STRIDE == 1, "stacked tiles: stride-1 layers only");
+    static constexpr int NCO = (NPB >= 4 && !NCO1) ? 2 : 1;                   // accumulator tiles (32 output channels each) per wave
+    static constexpr int WAVES = NCO == 2 ? NPB : 2 * NPB;
     static constexpr int THREADS = 64 * WAVES;
     static constexpr int TH = BH * NPB, TW = BW;                              // output tile
-    static constexpr int PH = STRIDE * TH + 3 - STRIDE, PW = STRIDE * TW + 3 - STRIDE;   // input halo patch: rows STRIDE * y0 - 1 .., columns STRIDE * x0 - 1 ..
+    static constexpr int PH = STRIDE * TH + 3 - STRIDE + (STACK ? 2 : 0), PW = STRIDE * TW + 3 - STRIDE;   // input halo patch: rows STRIDE * y0 - 1 .., columns STRIDE * x0 - 1 ..
     static constexpr int PIX = PH * PW;                                       // pixel slots of the patch
     static constexpr int SLOTS = (PIX + THREADS - 1) / THREADS;               // pixel slots one thread splits per chunk
     static constexpr int WQ = (TAPK ? 9 : kSteps) * TERMS * 2 * kCoutTile;    // 16-byte groups of one weight unit (8-channel chunk; TAPK: the whole interval)
@@ -119,14 +124,14 @@ __device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[T
 // 3-7 % slower per layer on the tap-major geometries; computing the bf16 split ahead of the second barrier: no change; issuing the next
 // interval's weight DMA and halo loads in shares between the matrix steps instead of all at once after the barrier: no change -- the
 // interval timelines (tools/trace_conv_emu.py) show the burst already overlapped by the other wavefronts' matrix instructions.  All removed.)
-enum { VAR_TAPK = 1, VAR_ASM_DMA = 2 };
+enum { VAR_TAPK = 1, VAR_ASM_DMA = 2, VAR_STACK = 4, VAR_NCO1 = 8 };
 template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT, int STRIDE = 1, int LAYOUT = LAYOUT_NCHW, int PBUF = 2, int VAR = 0>
-__global__ __launch_bounds__(64 * (NPB >= 4 ? NPB : 2 * NPB))
+__global__ __launch_bounds__(64 * ((NPB >= 4 && !(VAR & VAR_NCO1)) ? NPB : 2 * NPB))
 __attribute__((amdgpu_waves_per_eu(SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 1, SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 8)))
 void conv3x3_emu_kernel(const EmuArgs a) {
-    constexpr bool TAPK = (VAR & VAR_TAPK) != 0;
-    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, TAPK>;
-    static_assert(!(SPLIT && (STRIDE != 1 || LAYOUT != LAYOUT_NCHW)), "stream-K hand-over only for the plain stride-1 NCHW variant");
+    constexpr bool TAPK = (VAR & VAR_TAPK) != 0, STACK = (VAR & VAR_STACK) != 0;
+    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, TAPK, (VAR >> 2) & 3>;
+    static_assert(!(SPLIT && (STRIDE != 1 || LAYOUT != LAYOUT_NCHW || STACK)), "stream-K hand-over only for the plain stride-1 NCHW variant");
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;      // wave: scalar
     const size_t plane = (size_t)a.H * a.W, plane_in = (size_t)a.Hin * a.Win;
@@ -160,16 +165,33 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         const uint4 *wsrc;     // this lane inside the tile's first weight chunk
         int off[G::SLOTS];
     };
+    // STACK: t.y0 is a row of the stacked image (N * H rows).  n0 = its image, yl0 = its row inside that image, yb = H - yl0 = how many
+    // of the tile's rows still belong to image n0 (yb >= TH: no image boundary inside the tile).  Patch rows with a boundary inside:
+    //   0 .. yb        rows yl0 - 1 .. H - 1 of image n0        | yb + 1, yb + 2   ZERO (below image n0 / above image n0 + 1)
+    //   yb + 3 ..      rows 0 .. of image n0 + 1                  so tile row j reads patch rows j + shift .. j + shift + 2, shift = 2 for j >= yb
     auto make_plan = [&](const Tile &t) {
         Plan pl;
-        pl.base = a.x + (size_t)t.n * a.Cin * plane_in;
+        const int n0 = STACK ? t.y0 / a.H : t.n;
+        pl.base = a.x + (size_t)n0 * a.Cin * plane_in;
         pl.wsrc = a.wt + (size_t)t.cg * chunks * (G::WUNITS * G::WQ) + lane;
+        const int yl0 = t.y0 - n0 * a.H, yb = a.H - yl0;
 #pragma unroll
         for (int j = 0; j < G::SLOTS; ++j) {
             const int i = tid + j * G::THREADS;
             const int y = i / G::PW, xq = i - y * G::PW;
-            const int gy = STRIDE * t.y0 - 1 + y, gx = STRIDE * t.x0 - 1 + xq;
-            pl.off[j] = (i < G::PIX && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? gy * a.Win + gx : -1;
+            const int gx = STRIDE * t.x0 - 1 + xq;
+            if constexpr (STACK) {
+                int gy, img = 0;
+                bool ok = i < G::PIX && gx >= 0 && gx < a.Win;
+                if (yb >= G::TH || y <= yb) gy = yl0 - 1 + y;
+                else if (y <= yb + 2) { gy = 0; ok = false; }
+                else { gy = y - (yb + 3); img = 1; ok = ok && n0 + 1 < a.N; }
+                ok = ok && gy >= 0 && gy < a.Hin;
+                pl.off[j] = ok ? img * a.Cin * (int)plane_in + gy * a.Win + gx : -1;
+            } else {
+                const int gy = STRIDE * t.y0 - 1 + y;
+                pl.off[j] = (i < G::PIX && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? gy * a.Win + gx : -1;
+            }
         }
         return pl;
     };
@@ -299,13 +321,25 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         const int c_begin = gs0 - tile * chunks;
         const int c_end = (n_local - L) < (chunks - c_begin) ? c_begin + (n_local - L) : chunks;
         const bool head = c_begin == 0, complete = c_end == chunks;
-        const int gy = cur.y0 + py, gx = cur.x0 + px;
-        const bool live = gy < a.H && gx < a.W;
-        const size_t obase = ((size_t)cur.n * a.Cout + cur.cg * kCoutTile + cb + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
+        // STACK: this lane's output pixel lives in image out_n at row gy; tile rows at / past the image boundary read the patch two rows lower
+        int out_n = cur.n, gy = cur.y0 + py, bshift = 0;
+        const int gx = cur.x0 + px;
+        bool live;
+        if constexpr (STACK) {
+            const int n0 = cur.y0 / a.H, yl0 = cur.y0 - n0 * a.H, yb = a.H - yl0;
+            const bool lower = py >= yb;                   // (yb >= TH: never)
+            out_n = n0 + (lower ? 1 : 0);
+            gy = lower ? py - yb : yl0 + py;
+            bshift = lower ? 2 * G::PW : 0;
+            live = out_n < a.N && gx < a.W;
+        } else {
+            live = gy < a.H && gx < a.W;
+        }
+        const size_t obase = ((size_t)out_n * a.Cout + cur.cg * kCoutTile + cb + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
         const float *bias = a.bias + cur.cg * kCoutTile + cb + 4 * half;
         // a wavefront whose output rows lie below the map (the last row tile: 108 rows for 100, 56 for 50, 32 for 25) still stages pixels,
         // issues weight transfers and meets the barriers, but runs no matrix steps: its share of the padded work costs no energy
-        const bool wave_live = __builtin_amdgcn_readfirstlane((int)(cur.y0 + pb * BH < a.H)) != 0;
+        const bool wave_live = __builtin_amdgcn_readfirstlane((int)(cur.y0 + pb * BH < (STACK ? a.N * a.H : a.H))) != 0;
         floatx16 acc[G::NCO];
         if ((SPLIT && !head) || !wave_live) {
 #pragma unroll
@@ -347,7 +381,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
 #endif
             }
             EMU_STAMP(3);
-            const uint4 *bq = reinterpret_cast<const uint4 *>(lds + G::B_OFF + (PBUF == 2 ? (L & 1) : 0) * G::BSZ);
+            const uint4 *bq = reinterpret_cast<const uint4 *>(lds + G::B_OFF + (PBUF == 2 ? (L & 1) : 0) * G::BSZ) + bshift;
             const uint4 *wq = reinterpret_cast<const uint4 *>(lds + G::W_OFF + (L & 1) * G::WSZ) + wlane;
             constexpr int NS = G::STEPS;               // MFMA steps of this interval: step = (8-channel chunk h, tap pair s); TAPK: step = tap
             auto load_b = [&](int st, bf16x8 (&b)[TERMS]) {
@@ -440,7 +474,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
             }
             if (live) {
                 if constexpr (LAYOUT == LAYOUT_OUT_NHWC) {      // channels-last output: accumulators 4 r .. 4 r + 3 are 4 consecutive channels
-                    float *yp = a.y + (((size_t)cur.n * a.H + gy) * a.W + gx) * a.Cout + cur.cg * kCoutTile + cb + 4 * half;
+                    float *yp = a.y + (((size_t)out_n * a.H + gy) * a.W + gx) * a.Cout + cur.cg * kCoutTile + cb + 4 * half;
 #pragma unroll
                     for (int r = 0; r < 4 * G::NCO; ++r) {
                         float4 o;
@@ -764,7 +798,7 @@ inline int rows_per_tile(int H, int terms) { return (terms == 3 && H >= 64) ? 12
 // the strided / channels-last variants: whole tiles only (no stream-K), same persistent-workgroup schedule
 template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE, int LAYOUT, int PBUF = 2, int VAR = 0>
 int launch_variant(const EmuArgs &a0, hipStream_t s) {
-    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, (VAR & VAR_TAPK) != 0>;
+    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, (VAR & VAR_TAPK) != 0, (VAR >> 2) & 3>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
     static int resident = 0, cus = 0;
     auto kern = conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, STRIDE, LAYOUT, PBUF, VAR>;
@@ -784,8 +818,14 @@ int launch_variant(const EmuArgs &a0, hipStream_t s) {
     }
     EmuArgs a = a0;
     a.tiles_x = (a.W + G::TW - 1) / G::TW;
-    a.tiles_per_img = a.tiles_x * ((a.H + G::TH - 1) / G::TH);
-    a.total_tiles = a.tiles_per_img * (a.Cout / kCoutTile) * a.N;
+    if constexpr (G::STACK) {                                  // the batch as one image of N * H rows: decode() then yields n = 0, y0 = stacked row
+        if (G::TH > a.H) return COALIGN_ERR_UNSUPPORTED;       // at most one image boundary per tile
+        a.tiles_per_img = a.tiles_x * ((a.N * a.H + G::TH - 1) / G::TH);
+        a.total_tiles = a.tiles_per_img * (a.Cout / kCoutTile);
+    } else {
+        a.tiles_per_img = a.tiles_x * ((a.H + G::TH - 1) / G::TH);
+        a.total_tiles = a.tiles_per_img * (a.Cout / kCoutTile) * a.N;
+    }
     const int slots = cus * resident;
     const int grid = a.total_tiles < slots ? a.total_tiles : slots;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
@@ -865,6 +905,7 @@ int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
 template <int BH, int BW, int NPB, int TERMS, int KCH, int PBUF = 2, int VAR = 0>
 int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream_t s, Launch *query) {
     constexpr bool TAPK = (VAR & VAR_TAPK) != 0;
+    static_assert(!(VAR & (VAR_STACK | VAR_NCO1)), "stacked / 32-channel variants go through launch_variant (whole tiles)");
     using G = Geo<BH, BW, NPB, TERMS, KCH, 1, PBUF, TAPK>;
     static_assert(!TAPK || G::LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
     static int resident = 0, cus = 0;
@@ -972,12 +1013,29 @@ int tapk_launch(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipStre
     return launch<BH, BW, NPB, TERMS, 2, 1, VAR>(a, ws, ws_bytes, s, query);
 }
 
+// Stacked tiles (round 3): the batch is tiled as one image of N * H rows, whole tiles only.  Same output layouts as tapk_launch.
+template <int TERMS, int BH, int BW, int NPB, int VAR>
+int tapk_stacked(const EmuArgs &a, int layout, hipStream_t s, Launch *query) {
+    if (query) {
+        *query = Launch{0, 0, 0, false};
+        return COALIGN_OK;
+    }
+    if (layout == LAYOUT_OUT_NHWC) return launch_variant<BH, BW, NPB, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, VAR>(a, s);
+    if (layout == LAYOUT_NCHW) return launch_variant<BH, BW, NPB, TERMS, 2, 1, LAYOUT_NCHW, 1, VAR>(a, s);
+    return COALIGN_ERR_UNSUPPORTED;
+}
+
 template <int TERMS, int VAR>
 int tapk_rows(int rows, const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipStream_t s, Launch *query) {
     switch (rows) {
         case 8: return tapk_launch<TERMS, 1, 32, 8, VAR>(a, layout, ws, ws_bytes, s, query);
         case 12: return tapk_launch<TERMS, 1, 32, 12, VAR>(a, layout, ws, ws_bytes, s, query);
         case 26: return tapk_launch<TERMS, 2, 16, 13, VAR>(a, layout, ws, ws_bytes, s, query);       // 13 wavefronts x (2 rows x 16 pixels): 26 x 16 tiles
+        // stacked: 12 wavefronts x (2 rows x 16 pixels) = 24 x 16 tiles over N * H rows (the 50 x 176 maps: 11 x 11 x 2 = 242 tiles of 12 units)
+        case 124: return tapk_stacked<TERMS, 2, 16, 12, VAR | VAR_STACK>(a, layout, s, query);
+        // stacked, 32 output channels per wavefront: 6 rows x 32 pixels x 64 channels per workgroup = 12 wavefronts of half a unit (the 25 x 88
+        // maps: 21 x 3 x 4 = 252 tiles, three half units per SIMD instead of two whole ones)
+        case 106: return tapk_stacked<TERMS, 1, 32, 6, VAR | VAR_STACK | VAR_NCO1>(a, layout, s, query);
         default: return COALIGN_ERR_UNSUPPORTED;
     }
 }
@@ -992,7 +1050,17 @@ int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipSt
     // 50 x 176 maps (W a multiple of 16, not of 32): 13 wavefronts of 2 rows x 16 pixels = 26 x 16 tiles cover the map exactly (220 tiles =
     // ONE round; 8 x 32 tiles: 420 = 1.6 rounds, 9 % dead columns): 95 vs 108 us per layer
     static const int t26 = getenv("COALIGN_EMU_TAPK_26") ? atoi(getenv("COALIGN_EMU_TAPK_26")) : 1;
-    const int rows = force ? force : (t26 && a.W % 32 == 16 && a.H > 26 && a.H <= 52) ? 26 : (a.H >= 64 ? 12 : 8);
+    // Round 3, load balance.  A workgroup owns its CU (143-159 KB of LDS), so a layer costs (busiest SIMD's work) x time: with per-image tiles
+    // the 25 x 88 maps of a 5-agent frame are 240 tiles of 8 wavefront units (two per SIMD) of which 60 hold a single live row (the 25th) and
+    // still keep their CU for the whole K loop; the 50 x 176 maps 220 tiles of 13 units (four on one SIMD).  Tiling the batch as ONE image
+    // of N * H rows removes the per-image remainder: 252 tiles of 6 rows x 32 pixels with 32-channel wavefronts = three HALF units per SIMD
+    // (1.5 instead of 2); 242 tiles of 24 x 16 pixels = three units per SIMD (instead of four).  COALIGN_EMU_STACK=0: the per-image tiles.
+    static const int stack = getenv("COALIGN_EMU_STACK") ? atoi(getenv("COALIGN_EMU_STACK")) : 1;
+    int rows = force ? force : (t26 && a.W % 32 == 16 && a.H > 26 && a.H <= 52) ? 26 : (a.H >= 64 ? 12 : 8);
+    if (!force && stack && TERMS == 3) {
+        if (rows == 26 && a.H >= 24) rows = 124;
+        else if (rows == 8 && a.H >= 6 && a.H <= 32) rows = 106;
+    }
     switch (var) {
         case VAR_TAPK: return tapk_rows<TERMS, VAR_TAPK>(rows, a, layout, ws, ws_bytes, s, query);
         case VAR_TAPK | VAR_ASM_DMA: return tapk_rows<TERMS, VAR_TAPK | VAR_ASM_DMA>(rows, a, layout, ws, ws_bytes, s, query);

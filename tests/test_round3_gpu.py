@@ -535,3 +535,43 @@ def test_pcdet_nms_beyond_the_device_walk_limit(monkeypatch):
         big = fn(boxes, scores, thr)[0]
         monkeypatch.setattr(pcdet, "PCDET_NMS_DEVICE_MAX", 16384)
         assert torch.equal(big, ref), normal
+
+
+# ------------------------------------------------------------------------------------------------ stacked convolution tiles
+_STACK_CHECK = r"""
+import hashlib, sys, torch
+import torch.nn.functional as F
+from coalign_amd import ops
+h = hashlib.sha256()
+worst = 0.0
+# (N, C, H, W): the detector's stage-2 / stage-3 maps at 5 and 2 agents, DAIR and LSS sizes, one image, ragged sizes, a tile height that divides H
+for (N, C, H, W) in ((5, 256, 25, 88), (5, 128, 50, 176), (2, 256, 25, 88), (2, 128, 50, 176), (2, 256, 25, 63), (2, 128, 50, 126), (8, 256, 30, 30),
+                     (1, 256, 25, 88), (1, 128, 50, 176), (3, 64, 24, 40), (7, 64, 6, 33), (4, 128, 48, 48), (3, 128, 27, 48)):
+    g = torch.Generator().manual_seed(N * 1000 + C + H)
+    x = torch.randn(N, C, H, W, generator=g).cuda(); w = (torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).cuda()
+    b = torch.randn(C, generator=g).cuda(); r = torch.randn(N, C, H, W, generator=g).cuda()
+    ws = ops.pack_conv3x3_emu_weight(w, 3, True)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    for res, relu in ((None, False), (r, True)):
+        want = ref if res is None else ref + res.double()
+        want = torch.relu(want) if relu else want
+        for cl in (False, True):
+            got = ops.conv3x3_emu_bias_act(x, ws, b, C, res, relu, 3, out_channels_last=cl)
+            worst = max(worst, float((got.double() - want).abs().max() / want.abs().max()))
+            h.update(got.contiguous().cpu().numpy().tobytes())
+print("WORST", worst, "SHA", h.hexdigest())
+sys.exit(0 if worst <= 5e-6 else 1)
+"""
+
+
+def test_stacked_convolution_tiles_equal_per_image_tiles_bit_for_bit():
+    """conv3x3_emu.hip, VAR_STACK / VAR_NCO1 (the batch tiled as one image of N * H rows; 32-channel wavefronts): every output against the
+    fp64 convolution (5e-6 of the output scale) AND bit-identical to the per-image tiles (COALIGN_EMU_STACK=0) -- the per-output sequence of
+    products does not depend on the tile geometry.  Shapes with an image boundary inside a tile, at a tile edge, one image, ragged columns."""
+    outs = {}
+    for stack in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _STACK_CHECK], env=dict(os.environ, PYTHONPATH=ROOT, COALIGN_EMU_STACK=stack), capture_output=True, text=True,
+                           timeout=900, cwd=ROOT)
+        assert r.returncode == 0, (stack, r.stdout[-300:], r.stderr[-800:])
+        outs[stack] = r.stdout.strip().split("SHA")[-1].strip()
+    assert outs["1"] == outs["0"], outs
