@@ -494,7 +494,7 @@ def test_cfg4_correction_path_full_geometry_noise_sweep():
             ev.caluclate_tp_fp(boxes, scores, gt.to(DEV), st_d, thr)
             oracle.caluclate_tp_fp(rb.numpy(), rsc.numpy(), gt.numpy(), st_o, thr)
             assert st_d[thr]["tp"] == st_o[thr]["tp"] and st_d[thr]["fp"] == st_o[thr]["fp"] and st_d[thr]["gt"] == st_o[thr]["gt"], (s, thr)
-            assert ev.calculate_ap(st_d, thr)[0] == oracle.calculate_ap(st_o, thr)[0], (s, thr)
+            assert abs(ev.calculate_ap(st_d, thr)[0] - oracle.calculate_ap(st_o, thr)[0]) <= 1e-12, (s, thr)      # same TP / FP lists; the two VOC sums add in another order
         assert sum(st_d[0.7]["tp"]) > 5, s
 
 
