@@ -26,8 +26,12 @@ ARCH = "gfx950"
 # per-source extras.  pillar_scatter.hip: its matrix-core encoder reduces the accumulators with VALU right after each instruction
 # pair -- results in VGPRs (not AGPRs) save 64 v_accvgpr_read per pass; -fno-honor-nans drops the canonicalising v_max the compiler
 # puts in front of every two-operand fmaxf of a raw matrix result (20 per pass; the file tests for NaN nowhere, its selects are explicit).
+# -fno-slp-vectorize (all sources): no packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 formed from scalar code).  Measured
+# on the MI355X (profiles/round3/README.md, "packed fp32 beside matrix wavefronts"): a wavefront executing them while it shares a SIMD with
+# three densely issuing matrix wavefronts of another kernel got wrong results in lanes 48-63.  Frame rate with / without the flag: equal
+# (309-314 vs 307-312 frames/s, same box, alternating).  The explicit float2 arithmetic of the fp32 VALU pillar encoder (fallback route) remains.
 EXTRA_FLAGS = {"pillar_scatter.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-cuda-compat", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-cuda-compat", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
 def _hipcc() -> str:

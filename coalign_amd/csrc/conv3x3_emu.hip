@@ -1036,8 +1036,6 @@ int tapk_rows(int rows, const EmuArgs &a, int layout, void *ws, size_t ws_bytes,
         // stacked, 32 output channels per wavefront: 6 rows x 32 pixels x 64 channels per workgroup = 12 wavefronts of half a unit (the 25 x 88
         // maps: 21 x 3 x 4 = 252 tiles, three half units per SIMD instead of two whole ones)
         case 106: return tapk_stacked<TERMS, 1, 32, 6, VAR | VAR_STACK | VAR_NCO1>(a, layout, s, query);
-        case 206: return tapk_stacked<TERMS, 1, 32, 6, VAR | VAR_STACK>(a, layout, s, query);               // diagnostics: stacked, 64-channel wavefronts (6 per workgroup)
-        case 308: return tapk_stacked<TERMS, 1, 32, 8, VAR | VAR_NCO1>(a, layout, s, query);                // diagnostics: per-image 8-row tiles, 32-channel wavefronts (16 per workgroup)
         default: return COALIGN_ERR_UNSUPPORTED;
     }
 }
@@ -1057,11 +1055,13 @@ int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipSt
     // still keep their CU for the whole K loop; the 50 x 176 maps 220 tiles of 13 units (four on one SIMD).  Tiling the batch as ONE image
     // of N * H rows removes the per-image remainder: 252 tiles of 6 rows x 32 pixels with 32-channel wavefronts = three HALF units per SIMD
     // (1.5 instead of 2); 242 tiles of 24 x 16 pixels = three units per SIMD (instead of four).  COALIGN_EMU_STACK=0: the per-image tiles.
-    // DEFAULT = 1: only the 24 x 16 tiles.  The 6 x 32 / 32-channel variant (bit 1) is 9 % faster on its layer (94 vs 103 us) and bit-equal to
-    // the per-image tiles, but WITHDRAWN: while it runs on one stream, warp_fuse_nhwc running on another stream returns wrong values at a
-    // few pixels (tools/diag_fuse_corun.py: ~1/3 of 1500 fused maps differ; none with any other variant -- 8, 12, 26, 124, stream-K, nor with
-    // the stacked-only (206) or 32-channel-only (308) halves of it; not a cache-coherence effect: invalidate / write-back change nothing,
-    // one hardware queue does).  Cause not found; the frame pipeline overlaps lanes, so the variant stays off (profiles/round3/README.md).
+    // DEFAULT = 1: only the 24 x 16 tiles.  The 6 x 32 / 32-channel variant (bit 1) is 9 % faster on its layer in isolation (94 vs 103 us) and
+    // bit-equal to the per-image tiles, but gives nothing in the 3-lane frame pipeline (308-310 vs 309-314 frames/s, same box, alternating:
+    // the other lanes' kernels already fill the CUs its better balance frees), so it stays opt-in.  It is also the kernel that exposed the
+    // packed-fp32 hazard written up in profiles/round3/README.md: a wavefront of ANOTHER kernel that shares a SIMD with this variant's three
+    // matrix wavefronts got wrong results in lanes 48-63 of its v_pk_mul_f32 / v_pk_add_f32 instructions (warp_fuse_nhwc: ~1/3 of fused maps
+    // differed).  Every kernel of the library is now built without packed fp32 instructions (-fno-slp-vectorize, build.py), after which
+    // tools/diag_fuse_corun.py and a 3000-frame soak (tools/soak_pipeline.py) show no difference with the variant on.
     static const int stack = getenv("COALIGN_EMU_STACK") ? atoi(getenv("COALIGN_EMU_STACK")) : 1;
     int rows = force ? force : (t26 && a.W % 32 == 16 && a.H > 26 && a.H <= 52) ? 26 : (a.H >= 64 ? 12 : 8);
     if (!force && stack && TERMS == 3) {          // (bit 0: the 24 x 16 tiles, bit 1: the 6 x 32 tiles -- separately switchable for measurements)

@@ -397,3 +397,10 @@ def test_pcdet_api_surface_and_citations():
         pcdet.nms_gpu(torch.zeros(3, 7), torch.zeros(3), 0.1)
     keep, none = pcdet.nms_gpu(torch.zeros(0, 7), torch.zeros(0), 0.1)       # empty input never reaches the device
     assert keep.numel() == 0 and none is None
+
+
+def test_library_is_built_without_packed_fp32_instructions():
+    """build.py: -fno-slp-vectorize on every source (the packed-fp32 hazard of profiles/round3/README.md); the flag must not get lost."""
+    from coalign_amd import build
+    assert "-fno-slp-vectorize" in build.FLAGS
+    assert "-ffp-contract=off" in build.FLAGS

@@ -569,9 +569,50 @@ def test_stacked_convolution_tiles_equal_per_image_tiles_bit_for_bit():
     fp64 convolution (5e-6 of the output scale) AND bit-identical to the per-image tiles (COALIGN_EMU_STACK=0) -- the per-output sequence of
     products does not depend on the tile geometry.  Shapes with an image boundary inside a tile, at a tile edge, one image, ragged columns."""
     outs = {}
-    for stack in ("1", "0"):
+    for stack in ("3", "1", "0"):          # bit 0: the 24 x 16 tiles (default), bit 1: the opt-in 6 x 32 / 32-channel tiles
         r = subprocess.run([sys.executable, "-c", _STACK_CHECK], env=dict(os.environ, PYTHONPATH=ROOT, COALIGN_EMU_STACK=stack), capture_output=True, text=True,
                            timeout=900, cwd=ROOT)
         assert r.returncode == 0, (stack, r.stdout[-300:], r.stderr[-800:])
         outs[stack] = r.stdout.strip().split("SHA")[-1].strip()
-    assert outs["1"] == outs["0"], outs
+    assert outs["3"] == outs["1"] == outs["0"], outs
+
+
+_CORUN_CHECK = r"""
+import sys, torch
+from coalign_amd import ops
+from coalign_amd.config import builtin_config
+from coalign_amd.pose import normalize_pairwise_tfm
+from coalign_amd.synthetic import make_frame
+g = torch.Generator().manual_seed(3)
+N = 5
+fr = make_frame(builtin_config("opv2v_coalign"), N, pillars_per_agent=100, seed=303, noise=(0.2, 0.2))
+theta = normalize_pairwise_tfm(fr["pairwise_t_matrix"].cuda(), 200, 704, 0.4)[0, 0, :N].contiguous()
+xcl = [torch.randn(N, C, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last) for C, H, W in ((64, 100, 352), (128, 50, 176), (256, 25, 88))]
+def conv(N_, C, H, W):
+    x = torch.randn(N_, C, H, W, generator=g).cuda(); w = ops.pack_conv3x3_emu_weight((torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).cuda(), 3, True)
+    b = torch.randn(C, generator=g).cuda(); r = torch.randn(N_, C, H, W, generator=g).cuda()
+    return lambda: ops.conv3x3_emu_bias_act(x, w, b, C, r, True, 3)
+side = torch.cuda.Stream()
+ref = [t.clone() for t in ops.warp_fuse_nhwc(xcl, theta, ops.FUSE_ATT)]
+bad = torch.zeros((), dtype=torch.int64, device="cuda")
+for fn in (conv(5, 256, 25, 88), conv(5, 128, 50, 176), conv(5, 64, 100, 352)):
+    for it in range(150):
+        with torch.cuda.stream(side):
+            fn()
+        for a, b in zip(ops.warp_fuse_nhwc(xcl, theta, ops.FUSE_ATT), ref):
+            bad += (a != b).any()
+torch.cuda.synchronize()
+print("DIFFERING", int(bad))
+sys.exit(0 if int(bad) == 0 else 1)
+"""
+
+
+def test_fusion_is_not_disturbed_by_a_convolution_on_another_stream():
+    """The hazard found in round 3 (profiles/round3/README.md): packed fp32 instructions of a wavefront that shares a SIMD with the matrix
+    wavefronts of the 6 x 32 stacked convolution returned wrong lanes 48-63 -- one third of the fused maps differed.  The library is built
+    without packed fp32 instructions; here the fusion kernel runs 450 times beside each convolution geometry (the opt-in variant included)
+    and every fused map must equal the one computed alone."""
+    for stack in ("3", "1"):
+        r = subprocess.run([sys.executable, "-c", _CORUN_CHECK], env=dict(os.environ, PYTHONPATH=ROOT, COALIGN_EMU_STACK=stack), capture_output=True, text=True,
+                           timeout=600, cwd=ROOT)
+        assert r.returncode == 0, (stack, r.stdout[-300:], r.stderr[-800:])
