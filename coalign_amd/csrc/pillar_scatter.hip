@@ -971,27 +971,32 @@ __global__ __launch_bounds__(256) void pillar_prep_kernel(const int *__restrict_
 //   * everything stays in the half layout -- lanes 0-31 work for pillar A, lanes 32-63 for pillar B from the point loads to the stores (a
 //     store instruction writes 128 B of A's row and 128 B of B's), nothing is broadcast through scalar registers on the way;
 //   * all addresses are 32-bit byte offsets from scalar bases (the launcher checks the sizes);
-//   * memory latency is paid once per ROUND of five pairs, not once per pair: a wavefront owns a CONTIGUOUS run of pairs; at the start of a
-//     round it sends the five pairs' points (5 x 1 KB) straight into LDS (global_load_lds: no staging registers), reads the ten pillars'
-//     counts and coordinates through the scalar cache and issues the five cell-map lookups; the five passes then run out of LDS.
-//     (Measured on the round-robin, register-prefetched version: 20 us, of which 12 us remained with the arithmetic AND the stores switched
-//      off -- 4096 waves x 5 dependent passes x one exposed memory round trip each; profiles/round3/pillar_rows_ablation.txt.)
+//   * a wavefront owns a CONTIGUOUS run of up to 32 pairs and works through it in ROUNDS of five pairs.  Memory latency is paid once per
+//     WAVEFRONT: in the prologue lane j reads pillar j's count and coordinates and looks its cell up in the cell map (two dependent round
+//     trips, all 64 pillars of the run in parallel) and leaves a 32-byte record in LDS, while the first round's points (5 x 1 KB) travel
+//     straight into LDS (global_load_lds: no staging registers) and the channel parameters are fetched and split.  From then on the points
+//     of round r + 1 are in flight into the OTHER point buffer while the five passes of round r run out of LDS.
+//     (History, profiles/round3/pillar_rows_ablation.txt: round-robin pairs with register prefetch 20 us, of which 12 us remained with the
+//      arithmetic AND the stores switched off -- 4096 waves x 5 dependent passes x one exposed round trip each; one round of five pairs per
+//      wavefront, 4096 wavefronts: 20 us / 12.5 us -- every wavefront still paid prologue + one exposed transfer for five pairs of work.)
 typedef __attribute__((address_space(3))) void *lptr_ps_t;
-constexpr int kRound = 5;                                   // pairs per round (5 KB of points per wavefront in LDS)
+constexpr int kRunPairs = 32;                               // pairs per wavefront at most: one lane per pillar in the prologue
 
-template <bool ABS>
+// ROUND: pairs per round (ROUND KB of points per wavefront and buffer)
+template <bool ABS, int ROUND>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(PfnArgs a, float *__restrict__ canvas, int *__restrict__ dest, int reset_cellmap) {
-    constexpr int kWaveLds = 64 * kRowBytes + kRound * 1024 + 2 * kRound * 32;          // staged rows | the round's points | the round's pillar records
-    __shared__ __attribute__((aligned(16))) char lds[kWavesPerBlock * kWaveLds];
+    constexpr int kRound = ROUND;
+    constexpr int kMxWaveLds = 64 * kRowBytes + 2 * kRound * 1024 + 64 * 32;      // staged rows | two point buffers | the run's pillar records
+    __shared__ __attribute__((aligned(16))) char lds[kWavesPerBlock * kMxWaveLds];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
-    char *wave_lds = lds + wv * kWaveLds;
+    char *wave_lds = lds + wv * kMxWaveLds;
     char *pbuf = wave_lds + 64 * kRowBytes;
-    char *meta = pbuf + kRound * 1024;
+    char *meta = pbuf + 2 * kRound * 1024;
     const int gwave = blockIdx.x * kWavesPerBlock + wv, nwave = gridDim.x * kWavesPerBlock;
     if (a.M_dev) a.M = min(max(*a.M_dev, 0), a.M);
     if (a.M_dev && dest && blockIdx.x == 0 && threadIdx.x == 0) dest[-1] = a.M;      // the device-count form keeps "rows written" in front of the list
     const int npairs = (a.M + 1) / 2;
-    const int per_wave = (npairs + nwave - 1) / nwave;
+    const int per_wave = (npairs + nwave - 1) / nwave;                                  // <= kRunPairs: the launcher sizes the grid on the capacity
     const int p0 = gwave * per_wave, p1 = min(p0 + per_wave, npairs);
     if (p0 >= p1) return;
     const int ncell = a.ny * a.nx;
@@ -1001,44 +1006,41 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(Pfn
          *dest_b = reinterpret_cast<char *>(dest);
     // a round's points go straight into LDS (issued from inline assembly: after a BUILTIN LDS-DMA hipcc puts s_waitcnt vmcnt(0) in front of every
     // later LDS read it cannot prove unrelated -- here in front of every pass, i.e. each pass would wait for the previous pass's stores)
-    auto issue_round = [&](int r0) {
+    auto issue_round = [&](int r0, int buf) {
         const int nr = min(kRound, p1 - r0);
 #pragma unroll
         for (int k = 0; k < kRound; ++k) {
             if (k < nr) {
                 const int m = min(2 * (r0 + k) + half, a.M - 1);                       // a pillar B past the end re-reads the last pillar; its lanes store nothing
                 const char *src = pts_b + (unsigned)(m * a.P + min(col, a.P - 1)) * 16u;
-                const unsigned dst = (unsigned)(size_t)(lptr_ps_t)(pbuf + k * 1024);   // wave-uniform LDS byte address -> M0; lane i lands at dst + 16 i
+                const unsigned dst = (unsigned)(size_t)(lptr_ps_t)(pbuf + (buf * kRound + k) * 1024);   // wave-uniform LDS byte address -> M0; lane i lands at dst + 16 i
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(dst)), "v"(src) : "memory", "m0");
             }
         }
     };
-    // counts, coordinates and the cell-map entries of a round's ten pillars: lane j fetches pillar 2 r0 + j (two dependent memory round trips:
-    // coordinates -> cell-map entry), ONCE per round and for all ten in parallel, and leaves a 32-byte record in LDS; the passes read their
-    // records from there.  (One lookup chain per pass, even prefetched a pass ahead, bounded every pass by two memory latencies.)
-    auto fetch_meta = [&](int r0) {
-        if (lane < 2 * kRound) {
-            const int mj = min(2 * r0 + lane, a.M - 1);
-            const int np_j = *reinterpret_cast<const int *>(np_b + (unsigned)mj * 4u);
-            const int4 cd_j = *reinterpret_cast<const int4 *>(cd_b + (unsigned)mj * 16u);
-            const int cell = cd_j.y + cd_j.z * a.nx + cd_j.w;                          // z + y * nx + x (point_pillar_scatter.py:54)
-            const bool ok = cd_j.x >= 0 && cd_j.x < a.n_agents && cell >= 0 && cell < ncell;
-            const int slot_j = ok ? cd_j.x * ncell + cell : -1;
-            const int own_j = a.unique ? 0 : *reinterpret_cast<const int *>(cm_b + (unsigned)max(slot_j, 0) * 4u);
-            int4 *rec = reinterpret_cast<int4 *>(meta + lane * 32);
-            rec[0] = make_int4(np_j, cd_j.y, cd_j.z, cd_j.w);
-            rec[1] = make_int4(slot_j, own_j, 0, 0);
-        }
-    };
-    issue_round(p0);                                                                   // in flight while the channel parameters are fetched and split
-    fetch_meta(p0);
+    issue_round(p0, 0);                                                                // in flight while the records are built and the channel parameters are split
+    if (lane < 2 * (p1 - p0)) {                                                        // counts, coordinates, cell-map entries of the whole run: once per wavefront
+        const int mj = min(2 * p0 + lane, a.M - 1);
+        const int np_j = *reinterpret_cast<const int *>(np_b + (unsigned)mj * 4u);
+        const int4 cd_j = *reinterpret_cast<const int4 *>(cd_b + (unsigned)mj * 16u);
+        const int cell = cd_j.y + cd_j.z * a.nx + cd_j.w;                              // z + y * nx + x (point_pillar_scatter.py:54)
+        const bool ok = cd_j.x >= 0 && cd_j.x < a.n_agents && cell >= 0 && cell < ncell;
+        const int slot_j = ok ? cd_j.x * ncell + cell : -1;
+        const int own_j = a.unique ? 0 : *reinterpret_cast<const int *>(cm_b + (unsigned)max(slot_j, 0) * 4u);
+        int4 *rec = reinterpret_cast<int4 *>(meta + lane * 32);
+        rec[0] = make_int4(np_j, cd_j.y, cd_j.z, cd_j.w);
+        rec[1] = make_int4(slot_j, own_j, 0, 0);
+    }
     const MxChan mc = load_mx<ABS>(a, lane);
     *reinterpret_cast<uint4 *>(wave_lds + lane * kRowBytes + 48) = make_uint4(0u, 0u, 0u, 0u);          // part 3 of every row: the zero half of step 2
     const bool ch0 = col < a.C, ch1 = 32 + col < a.C;
-    for (int r0 = p0; r0 < p1; r0 += kRound) {
+    int buf = 0;
+    for (int r0 = p0; r0 < p1; r0 += kRound, buf ^= 1) {
         const int nr = min(kRound, p1 - r0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);                                            // vmcnt(0): the round's points are in LDS (once per round)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                            // vmcnt(0): this round's points are in LDS (and the last round's stores are out)
         coalign::wave_lds_sync();
+        if (r0 + kRound < p1) issue_round(r0 + kRound, buf ^ 1);                       // the other buffer was consumed by the passes of the round before this one
+        const char *pb = pbuf + buf * (kRound * 1024);
 #pragma unroll
         for (int k = 0; k < kRound; ++k) {
             if (k < nr) {
@@ -1046,9 +1048,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(Pfn
                 const int m = 2 * pair + half;
                 const bool live = m < a.M, hasB = 2 * pair + 1 < a.M;
                 PairIn in;
-                in.q = *reinterpret_cast<const float4 *>(pbuf + k * 1024 + lane * 16);
+                in.q = *reinterpret_cast<const float4 *>(pb + k * 1024 + lane * 16);
                 if (a.P < 32 && col >= a.P) in.q = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int4 *rec = reinterpret_cast<const int4 *>(meta + (2 * k + half) * 32);
+                const int4 *rec = reinterpret_cast<const int4 *>(meta + (2 * (pair - p0) + half) * 32);
                 const int4 r0v = rec[0], r1v = rec[1];
                 in.np = r0v.x;
                 in.cd = make_int4(0, r0v.y, r0v.z, r0v.w);
@@ -1075,11 +1077,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(Pfn
                 }
             }
         }
-        if (r0 + kRound < p1) {                                                        // more than five pairs per wavefront (M > 40 960): next round
-            coalign::wave_lds_sync();                                                  // this round's reads of pbuf / meta are done (their data was consumed above)
-            issue_round(r0 + kRound);
-            fetch_meta(r0 + kRound);
-        }
     }
 }
 
@@ -1099,9 +1096,27 @@ void launch_rows(const PfnArgs &a_in, float *canvas, int *dest, int reset_cellma
     // 32-bit byte offsets in the matrix-core kernel: pillars, feature rows and canvas each below 4 GB
     const bool small = (size_t)a.M * a.P * 16 < ((size_t)1 << 32) && (size_t)a.M * a.C * 4 < ((size_t)1 << 32) &&
                        (size_t)a.n_agents * a.ny * a.nx * a.C * 4 < ((size_t)1 << 32);
-    if (a.with_dist || !small || !pillar_mfma_enabled()) hipLaunchKernelGGL(pillar_rows_nhwc_kernel, grid, block, 0, stream, a, canvas, dest, reset_cellmap);
-    else if (a.use_abs) hipLaunchKernelGGL(pillar_rows_mx_kernel<true>, grid, block, 0, stream, a, canvas, dest, reset_cellmap);
-    else hipLaunchKernelGGL(pillar_rows_mx_kernel<false>, grid, block, 0, stream, a, canvas, dest, reset_cellmap);
+    if (a.with_dist || !small || !pillar_mfma_enabled()) {
+        hipLaunchKernelGGL(pillar_rows_nhwc_kernel, grid, block, 0, stream, a, canvas, dest, reset_cellmap);
+        return;
+    }
+    // matrix-core kernel: two workgroups (8 wavefronts, 2 x 68 KB of LDS) per CU; a wavefront takes two rounds' pairs unless the pillar count asks
+    // for more than the 512 resident workgroups -- then up to kRunPairs each, then more workgroups.  (Measured at 40 000 pillars, rocprofv3:
+    // 18.9 us; rounds of three pairs -- 129 registers, three workgroups per CU -- 19.1 us; 16 / 20 / 32 pairs per wavefront 23.8 / 23.6 / 32.2 us;
+    // without arithmetic and stores 9-10 us, without arithmetic 12.2 us, without stores 16.6 us: the six-product matrix steps and their
+    // reductions, ~750 issue cycles per pair and SIMD, are what is left.  profiles/round3/pillar_rows_ablation.txt)
+    static const int pairs_target = [] { const char *e = getenv("COALIGN_PILLAR_PAIRS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= kRunPairs ? v : 0; }();
+    constexpr int kRound = 5;
+    const int target = pairs_target ? pairs_target : 2 * kRound, resident = 512;
+    const int pairs = (a.M + 1) / 2;
+    int mx_blocks = (pairs + kWavesPerBlock * target - 1) / (kWavesPerBlock * target);
+    if (mx_blocks > resident) mx_blocks = resident;
+    const int need = (pairs + kWavesPerBlock * kRunPairs - 1) / (kWavesPerBlock * kRunPairs);
+    if (mx_blocks < need) mx_blocks = need;
+    if (blocks_override > 0 && mx_blocks > blocks_override && blocks_override >= need) mx_blocks = blocks_override;
+    const dim3 mx_grid(mx_blocks < 1 ? 1 : mx_blocks);
+    if (a.use_abs) hipLaunchKernelGGL((pillar_rows_mx_kernel<true, kRound>), mx_grid, block, 0, stream, a, canvas, dest, reset_cellmap);
+    else hipLaunchKernelGGL((pillar_rows_mx_kernel<false, kRound>), mx_grid, block, 0, stream, a, canvas, dest, reset_cellmap);
 }
 
 int launch_canvas(const int *cellmap, const float *feats, int C, int ncell, int n_agents, float *canvas, hipStream_t stream) {

@@ -510,6 +510,21 @@ def test_synthetic_inference_loop_ap_vs_oracle():
     assert 0.0 < rep["hip"]["ap30"] <= 1.0
 
 
+def test_synthetic_inference_loop_ap_vs_oracle_full_size():
+    """The same loop at the benchmarked geometry (opv2v_coalign: 704 x 200 canvas, three-scale backbone, two cavs with 3000 pillars each):
+    TP/FP sequences and AP of the gfx950 path equal the CPU oracle's at every IoU threshold."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("inference_synthetic", os.path.join(os.path.dirname(__file__), "inference_synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rep = mod.run("opv2v_coalign", frames=2, agents=2, pillars=3000, check_oracle=True)
+    assert rep["detections"] > 8, rep
+    assert rep["tp_fp_identical"], rep
+    for k, v in rep["hip"].items():
+        assert abs(v - rep["oracle"][k]) < 1e-12, rep
+
+
 # ------------------------------------------------------------------------------------------------ points -> pillars (next-1)
 OPV2V_RANGE, OPV2V_VOXEL = [-140.8, -40, -3, 140.8, 40, 1], [0.4, 0.4, 4]
 

@@ -126,15 +126,16 @@ def test_pipeline_graph_with_padded_ragged_frames(opv2v5):
     assert sum(len(d) for d in pipe._slots) == 2      # one graph per lane, reused
 
 
-def test_benchmarked_frame_end_to_end_vs_oracle(opv2v5):
-    """(b) One frame of the benchmarked workload (N = 5 x 8000 pillars, pose noise) against the CPU oracle end to end:
+@pytest.mark.parametrize("pool_frame", [1, 6])
+def test_benchmarked_frame_end_to_end_vs_oracle(opv2v5, pool_frame):
+    """(b) Frames of the benchmarked workload (N = 5 x 8000 pillars, pose noise) against the CPU oracle end to end:
     head outputs within 1e-3 relative (measured ~1e-6), identical candidate set, identical NMS keep set, boxes equal."""
     w = opv2v5
     h, model, pp, anchors = w["hypes"], w["model"], w["pp"], w["anchors"]
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     thr = pp.params["target_args"]["score_threshold"]
     with torch.no_grad():
-        ref = oracle.coalign_forward(sd, h["model"]["args"], w["frames_cpu"][1])
+        ref = oracle.coalign_forward(sd, h["model"]["args"], w["frames_cpu"][pool_frame])
         # move the classification bias (on both sides) until no oracle logit is within 2e-4 of the threshold: the two
         # implementations agree to ~1e-6, so the candidate sets must then be identical
         shift = next(d for d in (0.0, 1e-3, 2e-3, 3e-3, 5e-3, 8e-3, 1.3e-2) if clear_of_threshold(ref["cls_preds"] + d, thr, 2e-4))
@@ -142,9 +143,9 @@ def test_benchmarked_frame_end_to_end_vs_oracle(opv2v5):
         try:
             model.cls_head.bias += shift
             sd["cls_head.bias"] = sd["cls_head.bias"] + shift
-            ref = oracle.coalign_forward(sd, h["model"]["args"], w["frames_cpu"][1])
+            ref = oracle.coalign_forward(sd, h["model"]["args"], w["frames_cpu"][pool_frame])
             assert clear_of_threshold(ref["cls_preds"], thr, 1e-4)
-            out = model(w["frames"][1])
+            out = model(w["frames"][pool_frame])
             boxes, scores = pp.post_process(w["meta"], {"ego": out})
             n_cand = pp.last_counts["candidates"]
         finally:
