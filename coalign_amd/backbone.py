@@ -89,6 +89,27 @@ class Conv3x3Pack:
         return self._emu[terms, tap_major]
 
 
+# The pointwise layers (up-sampling heads, stride-2 skip convolutions) on the split-bf16 matrix cores together with the 3x3 layers
+# (coalign_pointwise_conv_emu); "0" keeps them on the fp32 matrix cores (coalign_pointwise_conv) -- measurement aid.
+POINTWISE_EMU = os.environ.get("COALIGN_PW_EMU", "1") != "0"
+
+
+class PointwisePack:
+    """Device images of one folded pointwise weight: the fp32 [Cin, M] matrix and, built on first use, the split-bf16 operand image."""
+
+    def __init__(self, weight: torch.Tensor, transposed: bool):
+        self.f32 = ops.pack_pointwise_weight(weight, transposed)
+        self._emu = None
+
+    def get(self) -> torch.Tensor:
+        """The image for the arithmetic in force: 3-way split when the 3x3 layers use it and Cin is a multiple of 16, else fp32."""
+        if POINTWISE_EMU and CONV_EMU_TERMS == 3 and self.f32.shape[0] % 16 == 0:
+            if self._emu is None:
+                self._emu = ops.pack_pointwise_emu_weight(self.f32)
+            return self._emu
+        return self.f32
+
+
 def packable(w: torch.Tensor) -> bool:
     return w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0
 
@@ -191,7 +212,7 @@ class BasicBlock(nn.Module):
             p2 = Conv3x3Pack(w2) if packable(w2) else None
             pd = None                                    # 1x1 / stride-2 skip convolution through the pointwise kernel
             if wd is not None and self.stride == 2 and wd.shape[1] % 2 == 0 and wd.shape[1] <= 256:
-                pd = (ops.pack_pointwise_weight(wd, False), torch.zeros(wd.shape[0], dtype=torch.float32, device=wd.device))
+                pd = (PointwisePack(wd, False), torch.zeros(wd.shape[0], dtype=torch.float32, device=wd.device))
             return w1, b1, w2, b2, wd, p1, p2, pd
         return _cache_of(self).get(self, build)
 
@@ -206,7 +227,7 @@ class BasicBlock(nn.Module):
             if wd is None:
                 skip = x
             elif pd is not None:
-                skip = ops.pointwise_conv(x, pd[0], pd[1], wd.shape[0], in_stride=2, relu=False)      # its BN shift already sits in b2
+                skip = ops.pointwise_conv(x, pd[0].get(), pd[1], wd.shape[0], in_stride=2, relu=False)      # its BN shift already sits in b2
             else:
                 skip = F.conv2d(x, wd, None, self.stride)
             return conv3x3_fused(y, p2, w2, b2, skip, out_channels_last=out_channels_last and emu and p2 is not None and p2.cout in (64, 128, 256))
@@ -310,13 +331,13 @@ class _MultiscaleDecodeMixin:
             for i, f in enumerate(feats[: self.num_levels]):
                 blk = self.deblocks[i]
                 op, bn = blk[0], blk[1]
-                w, b = _pw_cache_of(blk).get(blk, lambda op=op, bn=bn: (lambda wf, bf: (ops.pack_pointwise_weight(wf, True), bf))(*fold_bn(op.weight, None, bn, out_dim=1)))
+                w, b = _pw_cache_of(blk).get(blk, lambda op=op, bn=bn: (lambda wf, bf: (PointwisePack(wf, True), bf))(*fold_bn(op.weight, None, bn, out_dim=1)))
                 ops_.append((f, w, b, op.out_channels, op.stride[0], c_tot))
                 c_tot += op.out_channels
             f0, s0 = feats[0], self.deblocks[0][0].stride[0]
             x = torch.empty((f0.shape[0], c_tot, f0.shape[2] * s0, f0.shape[3] * s0), dtype=torch.float32, device=f0.device)
             for f, w, b, cout, up, off in ops_:
-                ops.pointwise_conv(f, w, b, cout, up=up, relu=True, out=x, c_off=off)
+                ops.pointwise_conv(f, w.get(), b, cout, up=up, relu=True, out=x, c_off=off)
             if len(self.deblocks) > self.num_levels:
                 x = self._deblock(len(self.deblocks) - 1, x)
             return x

@@ -30,6 +30,54 @@ struct PwArgs {
     int pb;               // pixel blocks of 32 per workgroup: 1, 2 or 4 (see the kernel)
 };
 
+// Epilogue shared by both kernels: accumulator r of lane l is GEMM row 8 * (r / 4) + 4 * (l / 32) + r % 4 of its 32-row tile, pixel l % 32
+template <int UP>
+__device__ __forceinline__ void pw_store(const PwArgs &a, int n, int m0, bool second, int px, int half, const floatx16 &acc0, const floatx16 &acc1) {
+    const int pixels = a.Hp * a.Wp;
+    if (px >= pixels) return;
+    const int hp = px / a.Wp, wp = px - hp * a.Wp;
+    const int Ho = a.Hp * UP, Wo = a.Wp * UP;
+    const size_t out_plane = (size_t)Ho * Wo;
+    float *yout = a.y + ((size_t)n * a.Ctot + a.c_off) * out_plane;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t == 1 && !second) break;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int m = m0 + t * 32 + 8 * r4 + 4 * half;            // rows m .. m + 3 are accumulators 4 * r4 .. 4 * r4 + 3
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = t == 0 ? acc0[4 * r4 + j] : acc1[4 * r4 + j];
+            if (UP == 4) {                 // m % 16 = ky * 4 + kx: the four rows are kx = 0..3 of one (co, ky): one 16-byte store
+                const int co = m >> 4, ky = (m >> 2) & 3;
+                const float bb = a.bias[co];
+                float4 o;
+                o.x = v[0] + bb; o.y = v[1] + bb; o.z = v[2] + bb; o.w = v[3] + bb;
+                if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                *reinterpret_cast<float4 *>(yout + (size_t)co * out_plane + (size_t)(hp * 4 + ky) * Wo + wp * 4) = o;
+            } else if (UP == 2) {          // m % 4 = ky * 2 + kx: the four rows are the 2 x 2 patch of one co: two 8-byte stores
+                const int co = m >> 2;
+                const float bb = a.bias[co];
+#pragma unroll
+                for (int ky = 0; ky < 2; ++ky) {
+                    float2 o;
+                    o.x = v[ky * 2] + bb; o.y = v[ky * 2 + 1] + bb;
+                    if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); }
+                    *reinterpret_cast<float2 *>(yout + (size_t)co * out_plane + (size_t)(hp * 2 + ky) * Wo + wp * 2) = o;
+                }
+            } else {                       // four consecutive output channels
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (m + j < a.Cout) {
+                        const float o = v[j] + a.bias[m + j];
+                        yout[(size_t)(m + j) * out_plane + (size_t)hp * Wo + wp] = a.relu ? fmaxf(o, 0.f) : o;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int UP>
 __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
     __shared__ float xt[kMaxCin * 32];
@@ -83,50 +131,105 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
     }
-    // epilogue: accumulator r of lane l is GEMM row 8 * (r / 4) + 4 * (l / 32) + r % 4 of its tile, pixel l % 32
-    const int px = p0 + pbk * 32 + p;
-    if (px >= pixels) return;
-    const int hp = px / a.Wp, wp = px - hp * a.Wp;
-    const int Ho = a.Hp * UP, Wo = a.Wp * UP;
-    const size_t out_plane = (size_t)Ho * Wo;
-    float *yout = a.y + ((size_t)n * a.Ctot + a.c_off) * out_plane;
+    pw_store<UP>(a, n, m0, second, p0 + pbk * 32 + p, half, acc0, acc1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same layers on the bf16 matrix cores by error-free 3-way operand splitting (round 3), as conv3x3_emu.hip does for the 3 x 3 layers:
+// w = w_h + w_m + w_l, x = x_h + x_m + x_l (bf16 terms, round-to-nearest-even), the six products down to 2^-16 of the leading one
+// (hl, mm, lh, hm, mh, hh, smallest first) accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The fp32 instruction above moves K = 2 per
+// issue and needs one weight word per lane for it; here one issue covers K = 16, the pixel tile is split ONCE while it is staged
+// ([term][8-channel group][pixel] x 16 B in LDS: a B operand is one ds_read_b128), and the weights come pre-split in operand order
+// (image below), one 16-byte load per lane, tile, step and term, a step ahead of the matrix instructions that use them.
+// Weight image (ops.pack_pointwise_emu_weight): uint4 [M / 32 row tiles][Cin / 16 steps][3 terms][64 lanes]; lane l of (tile, step, term) holds
+// term `term` of W[k = 16 step + 8 (l / 32) + 0..7][m = 32 tile + l % 32] as 8 bf16.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&out)[3]) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (t == 1 && !second) break;
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)v[i];
+        const float r = v[i] - (float)h;
+        const __bf16 m = (__bf16)r;
+        out[0][i] = h; out[1][i] = m; out[2][i] = (__bf16)(r - (float)m);
+    }
+}
+
+template <int UP>
+__global__ __launch_bounds__(256) void pointwise_emu_kernel(const PwArgs a) {
+    extern __shared__ uint4 xs[];                         // [3][Cin / 8][TP]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, p = lane & 31;
+    const int pixels = a.Hp * a.Wp;
+    const int PB = a.pb, WPB = 4 / PB, TP = 32 * PB;
+    const int p0 = blockIdx.x * TP, n = blockIdx.z;
+    const int m_base = blockIdx.y * (64 * WPB);
+    const size_t in_plane = (size_t)a.Hin * a.Win;
+    const float *xin = a.x + (size_t)n * a.Cin * in_plane;
+    const int G = a.Cin >> 3;
+    {
+        const int pl = tid & (TP - 1), g0 = tid / TP, gstep = 256 / TP;
+        const int px = p0 + pl;
+        const bool ok = px < pixels;
+        const int hp = ok ? px / a.Wp : 0, wp = ok ? px - hp * a.Wp : 0;
+        const size_t off = (size_t)(hp * a.in_stride) * a.Win + (size_t)wp * a.in_stride;
+        for (int g = g0; g < G; g += gstep) {
+            float u[8];
+            if (a.in_nhwc) {
+                const float4 *xp = reinterpret_cast<const float4 *>(xin + off * a.Cin) + 2 * g;
+                const float4 q0 = xp[0], q1 = xp[1];
+                u[0] = q0.x; u[1] = q0.y; u[2] = q0.z; u[3] = q0.w; u[4] = q1.x; u[5] = q1.y; u[6] = q1.z; u[7] = q1.w;
+            } else {
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const int m = m0 + t * 32 + 8 * r4 + 4 * half;            // rows m .. m + 3 are accumulators 4 * r4 .. 4 * r4 + 3
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = t == 0 ? acc0[4 * r4 + j] : acc1[4 * r4 + j];
-            if (UP == 4) {                 // m % 16 = ky * 4 + kx: the four rows are kx = 0..3 of one (co, ky): one 16-byte store
-                const int co = m >> 4, ky = (m >> 2) & 3;
-                const float bb = a.bias[co];
-                float4 o;
-                o.x = v[0] + bb; o.y = v[1] + bb; o.z = v[2] + bb; o.w = v[3] + bb;
-                if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-                *reinterpret_cast<float4 *>(yout + (size_t)co * out_plane + (size_t)(hp * 4 + ky) * Wo + wp * 4) = o;
-            } else if (UP == 2) {          // m % 4 = ky * 2 + kx: the four rows are the 2 x 2 patch of one co: two 8-byte stores
-                const int co = m >> 2;
-                const float bb = a.bias[co];
-#pragma unroll
-                for (int ky = 0; ky < 2; ++ky) {
-                    float2 o;
-                    o.x = v[ky * 2] + bb; o.y = v[ky * 2 + 1] + bb;
-                    if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); }
-                    *reinterpret_cast<float2 *>(yout + (size_t)co * out_plane + (size_t)(hp * 2 + ky) * Wo + wp * 2) = o;
-                }
-            } else {                       // four consecutive output channels
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (m + j < a.Cout) {
-                        const float o = v[j] + a.bias[m + j];
-                        yout[(size_t)(m + j) * out_plane + (size_t)hp * Wo + wp] = a.relu ? fmaxf(o, 0.f) : o;
-                    }
-                }
+                for (int j = 0; j < 8; ++j) u[j] = xin[(size_t)(8 * g + j) * in_plane + off];
             }
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) u[j] = 0.f;
+            }
+            bf16x8 o[3];
+            split8(u, o);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) xs[(t * G + g) * TP + pl] = __builtin_bit_cast(uint4, o[t]);
         }
     }
+    __syncthreads();
+    const int pbk = wave / WPB, rt = wave - pbk * WPB;
+    const int m0 = m_base + rt * 64;
+    if (m0 >= a.M) return;
+    const bool second = m0 + 32 < a.M;
+    const int S = a.Cin >> 4;
+    const uint4 *w0 = reinterpret_cast<const uint4 *>(a.w) + (size_t)(m0 >> 5) * S * 192 + lane;      // 3 terms x 64 lanes per (tile, step)
+    const uint4 *w1 = w0 + (second ? (size_t)S * 192 : 0);
+    const uint4 *xb = xs + pbk * 32 + p;
+    floatx16 acc0 = {0}, acc1 = {0};
+    constexpr int wi[6] = {0, 1, 2, 0, 1, 0};             // weight term of product i   (0 = h, 1 = m, 2 = l): hl, mm, lh, hm, mh, hh
+    constexpr int bi[6] = {2, 1, 0, 1, 0, 0};             // pixel term of product i
+    bf16x8 wa[3], wb[3], bc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        wa[t] = __builtin_bit_cast(bf16x8, w0[t * 64]);
+        wb[t] = __builtin_bit_cast(bf16x8, w1[t * 64]);
+        bc[t] = __builtin_bit_cast(bf16x8, xb[(t * G + half) * TP]);
+    }
+#pragma unroll 2
+    for (int s = 0; s < S; ++s) {
+        bf16x8 na[3], nb[3], nc[3];
+        const int sn = s + 1 < S ? s + 1 : s;             // (the last step reloads itself: no branch in the stream)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            na[t] = __builtin_bit_cast(bf16x8, w0[(sn * 3 + t) * 64]);
+            nb[t] = __builtin_bit_cast(bf16x8, w1[(sn * 3 + t) * 64]);
+            nc[t] = __builtin_bit_cast(bf16x8, xb[(t * G + 2 * sn + half) * TP]);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[wi[i]], bc[bi[i]], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[wi[i]], bc[bi[i]], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { wa[t] = na[t]; wb[t] = nb[t]; bc[t] = nc[t]; }
+    }
+    pw_store<UP>(a, n, m0, second, p0 + pbk * 32 + p, half, acc0, acc1);
 }
 
 }  // namespace
@@ -136,11 +239,12 @@ extern "C" int coalign_pointwise_conv(const float *x, const float *w, const floa
     return coalign_pointwise_conv_ex(x, w, bias, y, N, Cin, Hin, Win, in_stride, Cout, up, M_padded, Ctot, c_off, relu, 0, stream);
 }
 
-extern "C" int coalign_pointwise_conv_ex(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
-                                         int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc,
-                                         void *stream) {
+static int pointwise_impl(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
+                          int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, bool emu,
+                          void *stream) {
     using namespace coalign;
     if (!x || !w || !bias || !y) return COALIGN_ERR_NULL_POINTER;
+    if (emu && ((Cin & 15) || (reinterpret_cast<uintptr_t>(w) & 15))) return COALIGN_ERR_UNSUPPORTED;
     if (N < 0 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1 || Ctot < Cout || c_off < 0 || c_off + Cout > Ctot) return COALIGN_ERR_BAD_SHAPE;
     if (in_nhwc && ((Cin & 3) || (reinterpret_cast<uintptr_t>(x) & 15))) return COALIGN_ERR_UNSUPPORTED;
     if (Cin > kMaxCin || (Cin & 1) || (up != 1 && up != 2 && up != 4) || (in_stride != 1 && in_stride != 2) || (up != 1 && in_stride != 1))
@@ -159,8 +263,33 @@ extern "C" int coalign_pointwise_conv_ex(const float *x, const float *w, const f
     const int rows_per_wg = 64 * (4 / a.pb), px_per_wg = 32 * a.pb;
     const dim3 grid((pixels + px_per_wg - 1) / px_per_wg, (M_padded + rows_per_wg - 1) / rows_per_wg, N);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (emu) {
+        const size_t lds = (size_t)Cin * px_per_wg * 6;           // three bf16 terms of the pixel tile (<= 48 KB)
+        if (up == 4) hipLaunchKernelGGL(pointwise_emu_kernel<4>, grid, dim3(256), lds, s, a);
+        else if (up == 2) hipLaunchKernelGGL(pointwise_emu_kernel<2>, grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL(pointwise_emu_kernel<1>, grid, dim3(256), lds, s, a);
+        return check_launch();
+    }
     if (up == 4) hipLaunchKernelGGL(pointwise_kernel<4>, grid, dim3(256), 0, s, a);
     else if (up == 2) hipLaunchKernelGGL(pointwise_kernel<2>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(pointwise_kernel<1>, grid, dim3(256), 0, s, a);
     return check_launch();
+}
+
+extern "C" int coalign_pointwise_conv_ex(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
+                                         int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc,
+                                         void *stream) {
+    return pointwise_impl(x, w, bias, y, N, Cin, Hin, Win, in_stride, Cout, up, M_padded, Ctot, c_off, relu, in_nhwc, false, stream);
+}
+
+extern "C" size_t coalign_pointwise_emu_weight_bytes(int Cin, int M_padded) {
+    if (Cin < 16 || (Cin & 15) || Cin > kMaxCin || M_padded < 32 || (M_padded & 31)) return 0;
+    return (size_t)M_padded * Cin * 6;
+}
+
+extern "C" int coalign_pointwise_conv_emu(const float *x, const void *w_split, const float *bias, float *y, int N, int Cin, int Hin, int Win,
+                                          int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc,
+                                          void *stream) {
+    return pointwise_impl(x, static_cast<const float *>(w_split), bias, y, N, Cin, Hin, Win, in_stride, Cout, up, M_padded, Ctot, c_off, relu, in_nhwc,
+                          true, stream);
 }

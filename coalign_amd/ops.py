@@ -629,12 +629,33 @@ def pack_pointwise_weight(weight: torch.Tensor, transposed: bool) -> torch.Tenso
     return out
 
 
+def pack_pointwise_emu_weight(w_packed: torch.Tensor) -> torch.Tensor:
+    """[Cin, M] fp32 (``pack_pointwise_weight``; Cin % 16 == 0, M % 32 == 0) -> the pre-split operand image of ``coalign_pointwise_conv_emu``
+    (include/coalign_amd.h): int16 [M / 32, Cin / 16, 3 terms, 64 lanes, 8] = the bf16 bit patterns of term t of
+    W[16 step + 8 (lane // 32) + j, 32 tile + lane % 32].  Terms: bf16(w), bf16(w - h), bf16(w - h - m), round-to-nearest-even (torch's
+    float32 -> bfloat16 conversion, the rounding of v_cvt_pk_bf16_f32)."""
+    w = w_packed.detach().float()
+    Cin, M = w.shape
+    if Cin % 16 or M % 32:
+        raise ValueError("pointwise emu weights: Cin % 16 == 0 and M % 32 == 0")
+    h = w.to(torch.bfloat16)
+    r1 = w - h.float()
+    m = r1.to(torch.bfloat16)
+    lo = (r1 - m.float()).to(torch.bfloat16)
+    terms = torch.stack([h, m, lo], 0).view(torch.int16)                       # [3, Cin, M]
+    img = terms.view(3, Cin // 16, 2, 8, M // 32, 32)                           # [t, step, half, j, tile, row]
+    img = img.permute(4, 1, 0, 2, 5, 3).contiguous()                           # [tile, step, t, half, row, j]
+    return img.view(M // 32, Cin // 16, 3, 64, 8)
+
+
 @_device_op
 def pointwise_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, up: int = 1, in_stride: int = 1, relu: bool = True,
                    out: Optional[torch.Tensor] = None, c_off: int = 0) -> torch.Tensor:
     """One-launch pointwise layer (include/coalign_amd.h (10)): ``up`` > 1 = non-overlapping transposed convolution, ``in_stride`` 2 =
-    1x1 stride-2 convolution.  ``out`` [N, Ctot, H', W'] + ``c_off`` select a channel slice of a larger (concatenated) tensor."""
+    1x1 stride-2 convolution.  ``out`` [N, Ctot, H', W'] + ``c_off`` select a channel slice of a larger (concatenated) tensor.
+    ``w_packed``: [Cin, M] float32 (fp32 matrix cores) or the int16 image of ``pack_pointwise_emu_weight`` (split-bf16 matrix cores)."""
     _need_gpu(x, w_packed, bias)
+    emu = w_packed.dtype == torch.int16
     L = hip.lib()
     nhwc = x.dtype == torch.float32 and is_channels_last(x) and x.shape[1] % 4 == 0        # read in place, no NCHW copy
     xc = x if nhwc else _f32c(x)
@@ -645,8 +666,14 @@ def pointwise_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
     if tuple(out.shape[2:]) != (Ho, Wo) or out.shape[0] != N or not out.is_contiguous() or out.dtype != torch.float32:
         raise ValueError("output buffer shape / layout mismatch")
     with _Timed("pointwise_conv"):
-        hip.check(L.coalign_pointwise_conv_ex(_ptr(xc), _ptr(w_packed), _ptr(_f32c(bias)), _ptr(out), N, Cin, Hin, Win, in_stride, cout, up,
-                                              w_packed.shape[1], out.shape[1], c_off, int(relu), int(nhwc), _stream()), "coalign_pointwise_conv")
+        if emu:
+            if w_packed.dim() != 5 or w_packed.shape[1] * 16 != Cin or not w_packed.is_contiguous():
+                raise ValueError("split weight image does not match Cin")
+            hip.check(L.coalign_pointwise_conv_emu(_ptr(xc), _ptr(w_packed), _ptr(_f32c(bias)), _ptr(out), N, Cin, Hin, Win, in_stride, cout, up,
+                                                   w_packed.shape[0] * 32, out.shape[1], c_off, int(relu), int(nhwc), _stream()), "coalign_pointwise_conv_emu")
+        else:
+            hip.check(L.coalign_pointwise_conv_ex(_ptr(xc), _ptr(w_packed), _ptr(_f32c(bias)), _ptr(out), N, Cin, Hin, Win, in_stride, cout, up,
+                                                  w_packed.shape[1], out.shape[1], c_off, int(relu), int(nhwc), _stream()), "coalign_pointwise_conv")
     return out
 
 

@@ -20,7 +20,7 @@ import torch.nn as nn
 from . import backbone as bb
 from .detector import MODEL_REGISTRY, build_model
 
-EMU, F32, MIOPEN, ROCBLAS, POINTWISE = "conv3x3_emu (split-bf16 matrix cores)", "conv3x3 (fp32 matrix cores) / MIOpen by shape", "MIOpen", "rocBLAS (1x1 heads)", "pointwise (fp32 matrix cores)"
+EMU, F32, MIOPEN, ROCBLAS, POINTWISE = "conv3x3_emu (split-bf16 matrix cores)", "conv3x3 (fp32 matrix cores) / MIOpen by shape", "MIOpen", "rocBLAS (1x1 heads)", "pointwise"
 
 
 def _conv3x3_route(conv: nn.Conv2d, terms: int) -> str:
@@ -34,6 +34,11 @@ def _conv3x3_route(conv: nn.Conv2d, terms: int) -> str:
     if terms in (2, 3):
         return EMU + (", tap-major image" if s == 1 and conv.in_channels % 16 == 0 else ", tap-pair image")
     return F32 if s == 1 else MIOPEN + " (native mode, strided)"
+
+
+def _pointwise_route(cin: int, terms: int) -> str:
+    """backbone.PointwisePack.get: split-bf16 image when the 3x3 layers use the 3-way split and Cin % 16 == 0, else the fp32 kernel."""
+    return POINTWISE + (" (split-bf16 matrix cores)" if terms == 3 and cin % 16 == 0 and bb.POINTWISE_EMU else " (fp32 matrix cores)")
 
 
 def plan(hypes: dict, terms: int = 3) -> Dict[str, object]:
@@ -64,7 +69,7 @@ def plan(hypes: dict, terms: int = 3) -> Dict[str, object]:
                 layers[n] = ROCBLAS
             elif tuple(m.kernel_size) == (1, 1) and ".downsample." in n:      # BasicBlock skip: pointwise kernel when stride 2, Cin even and <= 256
                 ok = m.stride[0] == 2 and m.in_channels % 2 == 0 and m.in_channels <= 256
-                note(n, POINTWISE if ok else MIOPEN + " (skip convolution outside the pointwise kernel's shapes)", not ok)
+                note(n, _pointwise_route(m.in_channels, terms) if ok else MIOPEN + " (skip convolution outside the pointwise kernel's shapes)", not ok)
             else:
                 note(n, MIOPEN, True)
     backbone = getattr(model, "backbone", None)
@@ -75,7 +80,7 @@ def plan(hypes: dict, terms: int = 3) -> Dict[str, object]:
             ok = ok and isinstance(op, nn.ConvTranspose2d) and op.kernel_size == op.stride and op.stride[0] == op.stride[1] and op.stride[0] in (1, 2, 4)
             ok = ok and op.in_channels <= 256 and op.in_channels % 2 == 0 and (op.out_channels * op.stride[0] ** 2) % 32 == 0
         for i in range(len(backbone.deblocks)):
-            note(f"backbone.deblocks.{i}", POINTWISE + ", writes its slice of the concatenation" if ok and i < backbone.num_levels else MIOPEN + " + bias_act",
+            note(f"backbone.deblocks.{i}", _pointwise_route(backbone.deblocks[i][0].in_channels, terms) + ", writes its slice of the concatenation" if ok and i < backbone.num_levels else MIOPEN + " + bias_act",
                  not (ok and i < backbone.num_levels))
     vfe = getattr(model, "pillar_vfe", None)
     pillar = None

@@ -369,6 +369,16 @@ int coalign_pointwise_conv(const float *x, const float *w, const float *bias, fl
 /* in_nhwc != 0: x is channels-last, [N, Hin, Win, Cin] (Cin % 4 == 0, 16-byte aligned); the output stays NCHW. */
 int coalign_pointwise_conv_ex(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win, int in_stride,
                               int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, void *stream);
+/* The same layers on the bf16 matrix cores by error-free 3-way operand splitting (fp32-width products, fp32 accumulation; the arithmetic of
+ * coalign_conv3x3_emu_ex, used together with it).  Replaces the same reference modules as coalign_pointwise_conv: the up-sampling heads
+ * (opencood/models/sub_modules/base_bev_backbone_resnet.py:47-87, 121-138) and the stride-2 skip convolutions (resblock.py:53-69, 165-174).
+ * Cin % 16 == 0, Cin <= 256.  w_split: the pre-split weight image, coalign_pointwise_emu_weight_bytes(Cin, M_padded) bytes, 16-byte
+ * aligned: uint4 [M_padded / 32][Cin / 16][3 terms][64 lanes]; lane l of (row tile, step, term) = term `term` (0: bf16(w), 1: bf16 of the
+ * remainder, 2: bf16 of what is left, round-to-nearest-even) of W[k = 16 step + 8 (l / 32) + j][m = 32 tile + l % 32], j = 0..7, as 8
+ * bf16 -- W being the [Cin][M_padded] matrix coalign_pointwise_conv takes.  Every other argument as coalign_pointwise_conv_ex. */
+size_t coalign_pointwise_emu_weight_bytes(int Cin, int M_padded);
+int coalign_pointwise_conv_emu(const float *x, const void *w_split, const float *bias, float *y, int N, int Cin, int Hin, int Win, int in_stride,
+                               int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, void *stream);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(REPO, "include", "coalign_amd.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(coalign_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) == 40
+    assert len(declared) == 42
     lib = hip.lib()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/coalign_amd.h but not exported"
@@ -404,3 +404,24 @@ def test_library_is_built_without_packed_fp32_instructions():
     from coalign_amd import build
     assert "-fno-slp-vectorize" in build.FLAGS
     assert "-ffp-contract=off" in build.FLAGS
+
+
+def test_pointwise_emu_weight_image_layout():
+    """ops.pack_pointwise_emu_weight against the indexing documented in include/coalign_amd.h: lane l of (row tile, step, term) holds term
+    `term` of W[16 step + 8 (l // 32) + j][32 tile + l % 32]; the three terms add up to the fp32 weight exactly."""
+    import torch
+    from coalign_amd import ops
+    g = torch.Generator().manual_seed(5)
+    Cin, M = 48, 96
+    w = torch.randn(Cin, M, generator=g)
+    img = ops.pack_pointwise_emu_weight(w)
+    assert tuple(img.shape) == (M // 32, Cin // 16, 3, 64, 8) and img.dtype == torch.int16
+    h = w.to(torch.bfloat16); r1 = w - h.float(); m = r1.to(torch.bfloat16); lo = (r1 - m.float()).to(torch.bfloat16)
+    assert float((h.float() + m.float() + lo.float() - w).abs().max()) == 0.0
+    terms = [t.view(torch.int16) for t in (h, m, lo)]
+    for tile in range(M // 32):
+        for step in range(Cin // 16):
+            for t in range(3):
+                for lane in (0, 7, 31, 32, 45, 63):
+                    k0, mm = 16 * step + 8 * (lane // 32), 32 * tile + lane % 32
+                    assert img[tile, step, t, lane].tolist() == terms[t][k0: k0 + 8, mm].tolist()

@@ -161,7 +161,17 @@ def test_benchmarked_frame_end_to_end_vs_oracle(opv2v5, pool_frame):
     # end to end the two implementations' logits differ by ~1e-5 of their scale (fp32 accumulation order over ~35 layers), so scores
     # and box coordinates agree to ~1e-4; the SELECTION (same anchors kept, same order) is what must be identical
     np.testing.assert_allclose(scores.cpu().numpy(), rs.numpy(), rtol=1e-3, atol=1e-4)
-    np.testing.assert_allclose(boxes.cpu().numpy(), rb.numpy(), rtol=1e-3, atol=5e-3)
+    # ... up to the order of detections whose scores differ by less than that logit noise (pool frame 6 holds such a pair): every device box
+    # is matched to the oracle box of (nearly) the same score that lies closest, the matching must be a permutation
+    gb, ob, gs, os_ = boxes.cpu().numpy(), rb.numpy(), scores.cpu().numpy(), rs.numpy()
+    taken = []
+    for i in range(len(gb)):
+        cand = np.nonzero(np.abs(os_ - gs[i]) <= 1e-4 + 1e-3 * abs(gs[i]))[0]
+        j = cand[int(np.argmin([np.abs(ob[c] - gb[i]).max() for c in cand]))]
+        np.testing.assert_allclose(gb[i], ob[j], rtol=1e-3, atol=5e-3)
+        taken.append(int(j))
+    assert sorted(taken) == list(range(len(ob)))
+    assert sum(int(j != i) for i, j in enumerate(taken)) <= 4, taken          # a swapped near-tie or two, not a different ranking
     # selection itself, isolated from logit rounding: the oracle post-processing the DEVICE logits picks exactly the same boxes
     db, ds, _ = oracle.post_process([{k: v.cpu() for k, v in out.items()}], anchors, h["postprocess"])
     assert db.shape == boxes.shape

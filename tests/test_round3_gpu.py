@@ -616,3 +616,45 @@ def test_fusion_is_not_disturbed_by_a_convolution_on_another_stream():
         r = subprocess.run([sys.executable, "-c", _CORUN_CHECK], env=dict(os.environ, PYTHONPATH=ROOT, COALIGN_EMU_STACK=stack), capture_output=True, text=True,
                            timeout=600, cwd=ROOT)
         assert r.returncode == 0, (stack, r.stdout[-300:], r.stderr[-800:])
+
+
+# ------------------------------------------------------------------------------------------------ pointwise layers on the split-bf16 matrix cores
+@pytest.mark.parametrize("case", [(1, 64, 128, 100, 352, 1, 1), (2, 128, 128, 50, 176, 2, 1), (1, 256, 128, 25, 88, 4, 1), (5, 64, 64, 200, 704, 1, 2),
+                                  (3, 64, 128, 101, 353, 1, 2), (2, 128, 256, 51, 177, 1, 2), (1, 16, 40, 7, 9, 1, 1), (1, 32, 8, 5, 3, 2, 1), (2, 48, 24, 9, 11, 4, 1)])
+def test_pointwise_emu_against_float64(case):
+    """coalign_pointwise_conv_emu (up-sampling heads and stride-2 skip convolutions as 3-way split bf16 products, fp32 accumulation) against
+    the float64 layer: 5e-6 of the output scale -- the bound the split-bf16 3 x 3 layers are held to --, NCHW and channels-last input bit
+    for bit the same, a channel slice of a larger tensor written without touching its neighbours."""
+    import torch.nn.functional as F
+    N, Ci, Co, H, W, up, st = case
+    gen = torch.Generator(device="cpu").manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=gen).to(DEV)
+    b = torch.randn(Co, generator=gen).to(DEV)
+    if st == 1:
+        w = (torch.randn(Ci, Co, up, up, generator=gen) / Ci ** 0.5).to(DEV)
+        ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=up)
+        if (Co * up * up) % 32:
+            assert up == 1
+            wp = ops.pack_pointwise_weight(w.reshape(Ci, Co).t().reshape(Co, Ci, 1, 1).contiguous(), False)
+        else:
+            wp = ops.pack_pointwise_weight(w, True)
+    else:
+        w = (torch.randn(Co, Ci, 1, 1, generator=gen) / Ci ** 0.5).to(DEV)
+        ref = F.conv2d(x.double(), w.double(), b.double(), stride=st)
+        wp = ops.pack_pointwise_weight(w, False)
+    we = ops.pack_pointwise_emu_weight(wp)
+    assert we.dtype == torch.int16 and we.numel() * 2 == ops.hip.lib().coalign_pointwise_emu_weight_bytes(Ci, wp.shape[1])
+    scale = max(1.0, float(ref.abs().max()))
+    for relu in (True, False):
+        want = torch.relu(ref) if relu else ref
+        got = ops.pointwise_conv(x, we, b, Co, up=up, in_stride=st, relu=relu)
+        assert got.shape == want.shape
+        assert float((got.double() - want).abs().max()) <= 5e-6 * scale, (case, relu)
+        if Ci % 4 == 0:
+            assert torch.equal(got, ops.pointwise_conv(x.contiguous(memory_format=torch.channels_last), we, b, Co, up=up, in_stride=st, relu=relu))
+    f32 = ops.pointwise_conv(x, wp, b, Co, up=up, in_stride=st, relu=False)
+    assert float((f32.double() - ref).abs().max()) <= 2e-5 * scale          # (the fp32 matrix-core kernel, same layer: its own bound)
+    big = torch.full((N, Co + 40, ref.shape[2], ref.shape[3]), 7.0, device=DEV)
+    ops.pointwise_conv(x, we, b, Co, up=up, in_stride=st, relu=True, out=big, c_off=24)
+    assert float((big[:, 24:24 + Co].double() - torch.relu(ref)).abs().max()) <= 5e-6 * scale
+    assert bool((big[:, :24] == 7.0).all()) and bool((big[:, 24 + Co:] == 7.0).all())

@@ -34,6 +34,12 @@ wtapm = ops.pack_conv3x3_emu_weight(wconv, 3, True)                             
 canvas_cl = torch.randn(N, 64, 200, 704, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
 wt = torch.randn(256, 128, 4, 4, generator=g).to(dev) / 16.0
 wtp = ops.pack_pointwise_weight(wt, True)
+wtp_emu = ops.pack_pointwise_emu_weight(wtp)
+_pw = {}
+for _tag, (_ci, _co, _up) in {"up1": (64, 128, 1), "up2": (128, 128, 2), "skip1": (64, 64, 1), "skip2": (64, 128, 1), "skip3": (128, 256, 1)}.items():
+    _w = torch.randn(_ci, _co, _up, _up, generator=g).to(dev) / _ci ** 0.5
+    _f = ops.pack_pointwise_weight(_w, True)
+    _pw[_tag] = (_f, ops.pack_pointwise_emu_weight(_f), torch.randn(_co, generator=g).to(dev), _co, _up)
 
 
 def pillar(cl):
@@ -89,6 +95,17 @@ OPS = {
     "conv_bf16x3_64ch_nhwc_out": lambda: ops.conv3x3_emu_bias_act(xs[0], wtapm, bconv, 64, rconv, True, 3, out_channels_last=True),
     "conv_bf16x3_s2_canvas_nhwc_in": lambda: ops.conv3x3_emu_bias_act(canvas_cl, wsplit[3], bconv, 64, None, True, 3, stride=2),
     "pointwise_up4": lambda: ops.pointwise_conv(xs[2][:1], wtp, bconv.repeat(2), 128, up=4),
+    "pointwise_up4_bf16x3": lambda: ops.pointwise_conv(xs[2][:1], wtp_emu, bconv.repeat(2), 128, up=4),
+    "pointwise_up2": lambda: ops.pointwise_conv(xs[1][:1], _pw["up2"][0], _pw["up2"][2], 128, up=2),
+    "pointwise_up2_bf16x3": lambda: ops.pointwise_conv(xs[1][:1], _pw["up2"][1], _pw["up2"][2], 128, up=2),
+    "pointwise_up1": lambda: ops.pointwise_conv(xs[0][:1], _pw["up1"][0], _pw["up1"][2], 128, up=1),
+    "pointwise_up1_bf16x3": lambda: ops.pointwise_conv(xs[0][:1], _pw["up1"][1], _pw["up1"][2], 128, up=1),
+    "pointwise_skip1_canvas": lambda: ops.pointwise_conv(canvas_cl, _pw["skip1"][0], _pw["skip1"][2], 64, in_stride=2, relu=False),
+    "pointwise_skip1_canvas_bf16x3": lambda: ops.pointwise_conv(canvas_cl, _pw["skip1"][1], _pw["skip1"][2], 64, in_stride=2, relu=False),
+    "pointwise_skip2": lambda: ops.pointwise_conv(xcl[0], _pw["skip2"][0], _pw["skip2"][2], 128, in_stride=2, relu=False),
+    "pointwise_skip2_bf16x3": lambda: ops.pointwise_conv(xcl[0], _pw["skip2"][1], _pw["skip2"][2], 128, in_stride=2, relu=False),
+    "pointwise_skip3": lambda: ops.pointwise_conv(xcl[1], _pw["skip3"][0], _pw["skip3"][2], 256, in_stride=2, relu=False),
+    "pointwise_skip3_bf16x3": lambda: ops.pointwise_conv(xcl[1], _pw["skip3"][1], _pw["skip3"][2], 256, in_stride=2, relu=False),
 }
 
 
