@@ -1,9 +1,14 @@
-"""Dense BEV CNN stages of the hot path.
+"""Dense BEV CNN stages of the hot path: the reference's modules with the reference's parameter names, every
+layer routed to a hand-written gfx950 kernel where one takes its shape.
 
-These are plain ``torch.nn`` convolutions: on MI355X they run on MIOpen through
-PyTorch-ROCm.  north_star names four hand-written HIP ops (pillar encode +
-scatter, warp, attention fusion, decode + NMS); dense 3x3 convolution is *not*
-one of them, so this file is host-side module wiring only.
+* 3x3 convolutions (stride 1 / 2, BatchNorm folded, ReLU and the residual add in the epilogue): ``coalign_conv3x3_emu_ex`` -- fp32 products
+  as 3-way split bf16 products on the bf16 matrix cores (``csrc/conv3x3_emu.hip``; ``COALIGN_CONV_EMU=0``: ``coalign_conv3x3_bias_act``
+  on the fp32 matrix cores, ``csrc/conv3x3.hip``).  ``conv3x3_fused`` picks; ``Conv3x3Pack`` holds the weight images.
+* the stride-2 1x1 skip convolutions and the up-sampling heads (ConvTranspose2d with kernel = stride, written straight into their
+  slice of the concatenated map): ``coalign_pointwise_conv_emu`` / ``coalign_pointwise_conv`` (``csrc/pointwise.hip``, ``PointwisePack``).
+* the last convolution of every ResNet stage writes channels-last for the one-launch fusion kernel (``NHWC_STAGE_OUTPUTS``).
+* what no kernel takes (``Cout % 64``, ``Cin % 8``, the NaiveCompressor, the 1x1 heads) runs on MIOpen / rocBLAS with ``bias_act_`` as the
+  epilogue; ``coalign_amd.routes.plan(hypes)`` lists the route of every layer of a config without a GPU.
 
 Parameter / buffer names are kept identical to the reference so that its
 ``.pth`` checkpoints load (SURVEY §5 "Checkpoint / resume"):

@@ -528,34 +528,42 @@ __global__ __launch_bounds__(1024) void gather_kernel(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ pcdet fp32 BEV IoU
+// RESTATEMENT of OpenPCDet's fp32 overlap arithmetic, not a design of ours: row N asks for the rounding sequence of
+// opencood/pcdet_utils/iou3d_nms/src/iou3d_nms_kernel.cu -- cross (:39-42), check_rect_cross + intersection (:44-84: the rectangle pre-test,
+// the four orientation products, the ratio form and its line-equation fallback below 1e-8), check_in_box2d (:86-93, margin 1e-2),
+// rotate_around_center (:95-101), box_overlap (:104-225: crossings first, then the corners inside the other box, bubble sort by atan2f
+// about the centroid, shoelace sum), iou_bev (:227-234), iou_normal (:313-325) -- so every operation below appears in that order; the
+// keep lists are compared bit for bit with the oracle's C restatement of the same lines (oracle/rotated_nms.c, tests/test_round2_gpu.py).
+// What is ours: the 64 x 64 ballot tiles, the centre-distance early-out and the device-side greedy walk around it (below).
 struct F2 { float x, y; };
-__device__ __forceinline__ float crs3(F2 p1, F2 p2, F2 p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
+__device__ __forceinline__ float orient(F2 u, F2 v, F2 origin) { return (u.x - origin.x) * (v.y - origin.y) - (v.x - origin.x) * (u.y - origin.y); }
 
-__device__ int seg_isect(F2 p1, F2 p0, F2 q1, F2 q0, F2 &ans) {
-    if (!(fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
-          fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y)))
+// edges (e0 -> e1) of one rectangle and (f0 -> f1) of the other: 1 and the crossing point if they properly cross
+__device__ int edge_crossing(F2 e1, F2 e0, F2 f1, F2 f0, F2 &hit) {
+    if (!(fminf(e0.x, e1.x) <= fmaxf(f0.x, f1.x) && fminf(f0.x, f1.x) <= fmaxf(e0.x, e1.x) &&
+          fminf(e0.y, e1.y) <= fmaxf(f0.y, f1.y) && fminf(f0.y, f1.y) <= fmaxf(e0.y, e1.y)))
         return 0;
-    const float s1 = crs3(q0, p1, p0), s2 = crs3(p1, q1, p0), s3 = crs3(p0, q1, q0), s4 = crs3(q1, p1, q0);
-    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
-    const float s5 = crs3(q1, p1, p0);
-    if (fabsf(s5 - s1) > 1e-8f) {
-        ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
-        ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
-    } else {
-        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
-        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
-        const float D = a0 * b1 - a1 * b0;
-        ans.x = (b0 * c1 - b1 * c0) / D;
-        ans.y = (a1 * c0 - a0 * c1) / D;
+    const float side_f0 = orient(f0, e1, e0), side_f1 = orient(e1, f1, e0), side_e0 = orient(e0, f1, f0), side_e1 = orient(f1, e1, f0);
+    if (!(side_f0 * side_f1 > 0 && side_e0 * side_e1 > 0)) return 0;
+    const float span = orient(f1, e1, e0);
+    if (fabsf(span - side_f0) > 1e-8f) {
+        hit.x = (span * f0.x - side_f0 * f1.x) / (span - side_f0);
+        hit.y = (span * f0.y - side_f0 * f1.y) / (span - side_f0);
+    } else {                              // nearly parallel: intersect the two line equations  l . (x, y, 1) = 0
+        const float la = e0.y - e1.y, lb = e1.x - e0.x, lc = e0.x * e1.y - e1.x * e0.y;
+        const float ma = f0.y - f1.y, mb = f1.x - f0.x, mc = f0.x * f1.y - f1.x * f0.y;
+        const float det = la * mb - ma * lb;
+        hit.x = (lb * mc - mb * lc) / det;
+        hit.y = (ma * lc - la * mc) / det;
     }
     return 1;
 }
 
-__device__ int in_box_margin(const float *box, F2 p) {
+__device__ int inside_with_margin(const float *box, F2 pt) {
     const float ca = cosf(-box[6]), sa = sinf(-box[6]);
-    const float rx = (p.x - box[0]) * ca + (p.y - box[1]) * (-sa);
-    const float ry = (p.x - box[0]) * sa + (p.y - box[1]) * ca;
-    return fabsf(rx) < box[3] / 2 + 1e-2f && fabsf(ry) < box[4] / 2 + 1e-2f;
+    const float lx = (pt.x - box[0]) * ca + (pt.y - box[1]) * (-sa);
+    const float ly = (pt.x - box[0]) * sa + (pt.y - box[1]) * ca;
+    return fabsf(lx) < box[3] / 2 + 1e-2f && fabsf(ly) < box[4] / 2 + 1e-2f;
 }
 
 __device__ void box_corners_f32(const float *box, F2 *c) {
@@ -579,10 +587,10 @@ __device__ float pcdet_iou(const float *A7, const float *B7) {
     box_corners_f32(B7, B);
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j)
-            if (seg_isect(A[i + 1], A[i], B[j + 1], B[j], pts[cnt])) { ctr.x += pts[cnt].x; ctr.y += pts[cnt].y; ++cnt; }
+            if (edge_crossing(A[i + 1], A[i], B[j + 1], B[j], pts[cnt])) { ctr.x += pts[cnt].x; ctr.y += pts[cnt].y; ++cnt; }
     for (int k = 0; k < 4; ++k) {
-        if (in_box_margin(A7, B[k])) { ctr.x += B[k].x; ctr.y += B[k].y; pts[cnt++] = B[k]; }
-        if (in_box_margin(B7, A[k])) { ctr.x += A[k].x; ctr.y += A[k].y; pts[cnt++] = A[k]; }
+        if (inside_with_margin(A7, B[k])) { ctr.x += B[k].x; ctr.y += B[k].y; pts[cnt++] = B[k]; }
+        if (inside_with_margin(B7, A[k])) { ctr.x += A[k].x; ctr.y += A[k].y; pts[cnt++] = A[k]; }
     }
     ctr.x /= cnt; ctr.y /= cnt;
     for (int j = 0; j < cnt - 1; ++j)
