@@ -43,11 +43,15 @@ def plant_ground_truth(pred: torch.Tensor, seed: int) -> torch.Tensor:
     return torch.from_numpy(np.concatenate([base + shift, extra]))
 
 
-def run(config: str, frames: int, agents: int, pillars: int, check_oracle: bool, head_scale=(0.01, 0.05)) -> dict:
+def run(config: str, frames: int, agents: int, pillars: int, check_oracle: bool, head_scale=(0.01, 0.05), oracle_heads: str = "oracle",
+        cls_bias: float = -1.0) -> dict:
+    """``oracle_heads`` = "device": the oracle's post-processing + evaluation run on the DEVICE model's head outputs (the model itself is compared
+    with the oracle elsewhere): at full size ~1e5 logits lie within 1e-5 -- the two implementations' logit noise -- of the score threshold, so two
+    independently computed candidate sets cannot be expected to coincide; decode, NMS, range filter, matching and AP can."""
     dev = torch.device("cuda:0")
     h = builtin_config(config)
     model = build_model(h)
-    fill_parameters_(model, seed=0, cls_bias=-1.0)
+    fill_parameters_(model, seed=0, cls_bias=cls_bias)
     with torch.no_grad():                  # small box deltas / moderate logits so that a usable number of boxes survives
         model.reg_head.weight.mul_(head_scale[0]); model.reg_head.bias.zero_(); model.cls_head.weight.mul_(head_scale[1])
     sd = {k: v.clone() for k, v in model.state_dict().items()}
@@ -55,9 +59,10 @@ def run(config: str, frames: int, agents: int, pillars: int, check_oracle: bool,
     post = build_postprocessor(h["postprocess"], False)
     anchors = torch.from_numpy(post.generate_anchor_box())
     stat_hip, stat_cpu = ev.new_result_stat(), ev.new_result_stat()
-    n_boxes = 0
+    n_boxes = n_cand = n_ties = 0
+    all_frames = [make_frame(h, agents, pillars_per_agent=pillars, seed=100 + i, spread_xy=(4.0, 2.0), spread_yaw=45.0) for i in range(frames)]
     for i in range(frames):
-        frame = make_frame(h, agents, pillars_per_agent=pillars, seed=100 + i, spread_xy=(4.0, 2.0), spread_yaw=45.0)
+        frame = all_frames[i]
         batch = {"ego": dict(to_device(frame, dev), transformation_matrix=torch.eye(4, device=dev), anchor_box=anchors.to(dev))}
         res = inference_intermediate_fusion(batch, model, post)
         gt = plant_ground_truth(res["pred_box_tensor"], 7000 + i)
@@ -67,8 +72,14 @@ def run(config: str, frames: int, agents: int, pillars: int, check_oracle: bool,
         if check_oracle:
             from oracle import coalign_oracle as oracle
             with torch.no_grad():
-                out = oracle.coalign_forward(sd, h["model"]["args"], frame)
-            ob, osc, _ = oracle.post_process([out], anchors, h["postprocess"])
+                if oracle_heads == "device":
+                    out = {k: v.cpu() for k, v in model(batch["ego"]).items()}
+                else:
+                    out = oracle.coalign_forward(sd, h["model"]["args"], frame)
+            ob, osc, info = oracle.post_process([out], anchors, h["postprocess"])
+            cs = np.asarray(info["cand_scores"])
+            n_cand += len(cs)
+            n_ties += len(cs) - len(np.unique(cs))
             for thr in ev.IOU_THRESHOLDS:
                 oracle.caluclate_tp_fp(None if ob is None else ob.numpy(), None if osc is None else osc.numpy(), gt.numpy(), stat_cpu, thr)
     report = {"config": config, "frames": frames, "agents": agents, "detections": n_boxes,
@@ -76,6 +87,9 @@ def run(config: str, frames: int, agents: int, pillars: int, check_oracle: bool,
     if check_oracle:
         from oracle import coalign_oracle as oracle
         report["oracle"] = {f"ap{int(t * 100)}": oracle.calculate_ap(stat_cpu, t)[0] for t in ev.IOU_THRESHOLDS}
+        report["candidates"], report["tied_candidate_scores"] = n_cand, n_ties      # equal fp32 scores: their order is the sort algorithm's, also in the reference
+        report["counts_identical"] = all(sum(stat_hip[t]["tp"]) == sum(stat_cpu[t]["tp"]) and sum(stat_hip[t]["fp"]) == sum(stat_cpu[t]["fp"])
+                                         and stat_hip[t]["gt"] == stat_cpu[t]["gt"] for t in ev.IOU_THRESHOLDS)
         report["tp_fp_identical"] = all(stat_hip[t]["tp"] == stat_cpu[t]["tp"] and stat_hip[t]["fp"] == stat_cpu[t]["fp"]
                                         and stat_hip[t]["gt"] == stat_cpu[t]["gt"] for t in ev.IOU_THRESHOLDS)
     return report

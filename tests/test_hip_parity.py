@@ -511,18 +511,27 @@ def test_synthetic_inference_loop_ap_vs_oracle():
 
 
 def test_synthetic_inference_loop_ap_vs_oracle_full_size():
-    """The same loop at the benchmarked geometry (opv2v_coalign: 704 x 200 canvas, three-scale backbone, two cavs with 3000 pillars each):
-    TP/FP sequences and AP of the gfx950 path equal the CPU oracle's at every IoU threshold."""
+    """The same loop at the benchmarked geometry (opv2v_coalign: 704 x 200 canvas, three-scale backbone, two cavs with 3000 pillars each, ~800
+    detections per frame): decode + NMS + range filter + matching + AP of the gfx950 path equal the CPU oracle's chain on the same head outputs,
+    sequence for sequence, at every IoU threshold.  (The head outputs themselves against the oracle's model at this size:
+    tests/test_pipeline_gpu.py::test_benchmarked_frame_end_to_end_vs_oracle, the cfg 1 / cfg 4 tests.)"""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("inference_synthetic", os.path.join(os.path.dirname(__file__), "inference_synthetic.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    rep = mod.run("opv2v_coalign", frames=2, agents=2, pillars=3000, check_oracle=True)
-    assert rep["detections"] > 8, rep
-    assert rep["tp_fp_identical"], rep
-    for k, v in rep["hip"].items():
-        assert abs(v - rep["oracle"][k]) < 1e-12, rep
+    # head scale / bias chosen for ~1 % of the anchors above the score threshold and no saturated sigmoid (at the mini harness's scale the
+    # full-size maps give logits up to 85: 10 000 scores of exactly 1.0, whose order is the sort algorithm's -- in the reference too)
+    rep = mod.run("opv2v_coalign", frames=2, agents=2, pillars=3000, check_oracle=True, oracle_heads="device", head_scale=(0.01, 0.005), cls_bias=-5.0)
+    assert rep["detections"] > 60 and rep["candidates"] > 500, rep
+    assert rep["counts_identical"], rep
+    if rep["tied_candidate_scores"] == 0:
+        assert rep["tp_fp_identical"], rep
+        for k, v in rep["hip"].items():
+            assert abs(v - rep["oracle"][k]) < 1e-12, rep
+    else:
+        for k, v in rep["hip"].items():
+            assert abs(v - rep["oracle"][k]) < 1e-3, rep
 
 
 # ------------------------------------------------------------------------------------------------ points -> pillars (next-1)
