@@ -1056,12 +1056,13 @@ int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipSt
     // of N * H rows removes the per-image remainder: 252 tiles of 6 rows x 32 pixels with 32-channel wavefronts = three HALF units per SIMD
     // (1.5 instead of 2); 242 tiles of 24 x 16 pixels = three units per SIMD (instead of four).  COALIGN_EMU_STACK=0: the per-image tiles.
     // DEFAULT = 1: only the 24 x 16 tiles.  The 6 x 32 / 32-channel variant (bit 1) is 9 % faster on its layer in isolation (94 vs 103 us) and
-    // bit-equal to the per-image tiles, but gives nothing in the 3-lane frame pipeline (308-310 vs 309-314 frames/s, same box, alternating:
-    // the other lanes' kernels already fill the CUs its better balance frees), so it stays opt-in.  It is also the kernel that exposed the
-    // packed-fp32 hazard written up in profiles/round3/README.md: a wavefront of ANOTHER kernel that shares a SIMD with this variant's three
+    // bit-equal to the per-image tiles; in the 3-lane frame pipeline -1 ... +2 % depending on the box (the other lanes' kernels mostly fill the
+    // CUs its better balance frees), with one frame in flight 3.55 vs 3.66 ms per frame.  It stays opt-in: it is the kernel that exposed the
+    // packed-fp32 hazard written up in profiles/round3/README.md -- a wavefront of ANOTHER kernel that shares a SIMD with this variant's three
     // matrix wavefronts got wrong results in lanes 48-63 of its v_pk_mul_f32 / v_pk_add_f32 instructions (warp_fuse_nhwc: ~1/3 of fused maps
-    // differed).  Every kernel of the library is now built without packed fp32 instructions (-fno-slp-vectorize, build.py), after which
-    // tools/diag_fuse_corun.py and a 3000-frame soak (tools/soak_pipeline.py) show no difference with the variant on.
+    // differed).  Every kernel of this library is now built without packed fp32 instructions (-fno-slp-vectorize, build.py), after which
+    // tools/diag_fuse_corun.py and a 3000-frame soak (tools/soak_pipeline.py) show no difference with the variant on; kernels that are not
+    // ours and share the GPU may still contain them.
     static const int stack = getenv("COALIGN_EMU_STACK") ? atoi(getenv("COALIGN_EMU_STACK")) : 1;
     int rows = force ? force : (t26 && a.W % 32 == 16 && a.H > 26 && a.H <= 52) ? 26 : (a.H >= 64 ? 12 : 8);
     if (!force && stack && TERMS == 3) {          // (bit 0: the 24 x 16 tiles, bit 1: the 6 x 32 tiles -- separately switchable for measurements)
