@@ -26,12 +26,13 @@ ARCH = "gfx950"
 # per-source extras.  pillar_scatter.hip: its matrix-core encoder reduces the accumulators with VALU right after each instruction
 # pair -- results in VGPRs (not AGPRs) save 64 v_accvgpr_read per pass; -fno-honor-nans drops the canonicalising v_max the compiler
 # puts in front of every two-operand fmaxf of a raw matrix result (20 per pass; the file tests for NaN nowhere, its selects are explicit).
-# -fno-slp-vectorize (all sources): no packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 formed from scalar code).  Measured
+# -fno-slp-vectorize -fno-vectorize (all sources): no packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 formed from scalar
+# code by the SLP vectoriser or by loop interleaving; `packed_fp32_count` below checks a source's ISA).  Measured
 # on the MI355X (profiles/round3/README.md, "packed fp32 beside matrix wavefronts"): a wavefront executing them while it shares a SIMD with
 # three densely issuing matrix wavefronts of another kernel got wrong results in lanes 48-63.  Frame rate with / without the flag: equal
-# (309-314 vs 307-312 frames/s, same box, alternating).  The explicit float2 arithmetic of the fp32 VALU pillar encoder (fallback route) remains.
+# (309-314 vs 307-312 frames/s, same box, alternating).  (The fp32 VALU pillar encoder's explicit float2 arithmetic was rewritten as scalar chains.)
 EXTRA_FLAGS = {"pillar_scatter.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-cuda-compat", "-Wno-inline-asm", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-vectorize", "-Wno-cuda-compat", "-Wno-inline-asm", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
 def _hipcc() -> str:
@@ -73,3 +74,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+
+
+def packed_fp32_count(src: str) -> int:
+    """Number of packed fp32 arithmetic instructions in the gfx950 ISA hipcc emits for ``csrc/<src>`` with the library's flags (0 expected:
+    profiles/round3/README.md).  Compiles to assembly only; takes seconds to a minute per source."""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        cmd = [_hipcc(), "-x", "hip"] + FLAGS + EXTRA_FLAGS.get(src, []) + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out]
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return len(re.findall(r"\bv_pk_(?:add|mul|fma)_f32\b", open(out).read()))

@@ -116,9 +116,8 @@ __device__ __forceinline__ float point_response(const ChanParams &cp, const floa
 
 // ---- packed variant used by the two-pillars-per-wavefront encoders: the staged points of a wavefront are laid out in PAIRS,
 // slab[pair][k][2] (pair = row / 2), so that one ds_read_b128 yields features k, k + 1 of two neighbouring points as two register
-// pairs and the linear layer runs on v_pk_fma_f32 (two points per instruction; the encoder is VALU bound: a wave instruction issues
-// in 4 cycles).  Same operations per point in the same order as point_response(): bit-identical results.
-typedef float f2 __attribute__((ext_vector_type(2)));
+// pairs (the linear layer ran on v_pk_fma_f32 in round 2; scalar FMA chains since round 3).  Same operations per point in the same order as
+// point_response(): bit-identical results.
 
 template <bool ABS, bool DIST>
 __device__ __forceinline__ void stage_point_pk_t(float *slab, int row, float4 q, float mx, float my, float mz, float ctr_x, float ctr_y,
@@ -148,23 +147,21 @@ __device__ __forceinline__ void stage_point_pk(const PfnArgs &a, float *slab, in
     }
 }
 
-// responses of the two points of pair `pr` (rows 2 pr, 2 pr + 1): .x / .y
+// responses of the two points of pair `pr` (rows 2 pr, 2 pr + 1): .x / .y.  Two scalar FMA chains: until round 3 this was v_pk_fma_f32 on
+// float2 operands (measured no faster: the kernel is not issue bound) -- packed fp32 instructions are gone from the library
+// (profiles/round3/README.md); same operations per point in the same order, bit-identical results.
+struct f2 { float x, y; };
 __device__ __forceinline__ f2 pair_response(const ChanParams &cp, const float *slab, int pr) {
     const float4 *src = reinterpret_cast<const float4 *>(slab + pr * (2 * kFeatStride));
-    const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5];
-    f2 x = f2{cp.w[0], cp.w[0]} * f2{v0.x, v0.y};
-    x = __builtin_elementwise_fma(f2{cp.w[1], cp.w[1]}, f2{v0.z, v0.w}, x);
-    x = __builtin_elementwise_fma(f2{cp.w[2], cp.w[2]}, f2{v1.x, v1.y}, x);
-    x = __builtin_elementwise_fma(f2{cp.w[3], cp.w[3]}, f2{v1.z, v1.w}, x);
-    x = __builtin_elementwise_fma(f2{cp.w[4], cp.w[4]}, f2{v2.x, v2.y}, x);
-    x = __builtin_elementwise_fma(f2{cp.w[5], cp.w[5]}, f2{v2.z, v2.w}, x);
-    x = __builtin_elementwise_fma(f2{cp.w[6], cp.w[6]}, f2{v3.x, v3.y}, x);
-    x = __builtin_elementwise_fma(f2{cp.w[7], cp.w[7]}, f2{v3.z, v3.w}, x);
-    x = __builtin_elementwise_fma(f2{cp.w[8], cp.w[8]}, f2{v4.x, v4.y}, x);
-    x = __builtin_elementwise_fma(f2{cp.w[9], cp.w[9]}, f2{v4.z, v4.w}, x);
-    x = __builtin_elementwise_fma(f2{cp.w[10], cp.w[10]}, f2{v5.x, v5.y}, x);
-    x = __builtin_elementwise_fma(f2{cp.w[11], cp.w[11]}, f2{v5.z, v5.w}, x);
-    return __builtin_elementwise_fma(x, f2{cp.alpha, cp.alpha}, f2{cp.shift, cp.shift});
+    const float4 v[6] = {src[0], src[1], src[2], src[3], src[4], src[5]};
+    float x = cp.w[0] * v[0].x, y = cp.w[0] * v[0].y;
+    x = fmaf(cp.w[1], v[0].z, x); y = fmaf(cp.w[1], v[0].w, y);
+#pragma unroll
+    for (int k = 1; k < 6; ++k) {
+        x = fmaf(cp.w[2 * k], v[k].x, x); y = fmaf(cp.w[2 * k], v[k].y, y);
+        x = fmaf(cp.w[2 * k + 1], v[k].z, x); y = fmaf(cp.w[2 * k + 1], v[k].w, y);
+    }
+    return f2{fmaf(x, cp.alpha, cp.shift), fmaf(y, cp.alpha, cp.shift)};
 }
 
 // relu(max over the np_eff staged points starting at (even) row0) -- rows_max() on the paired layout

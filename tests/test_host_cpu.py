@@ -402,8 +402,11 @@ def test_pcdet_api_surface_and_citations():
 def test_library_is_built_without_packed_fp32_instructions():
     """build.py: -fno-slp-vectorize on every source (the packed-fp32 hazard of profiles/round3/README.md); the flag must not get lost."""
     from coalign_amd import build
-    assert "-fno-slp-vectorize" in build.FLAGS
+    assert "-fno-slp-vectorize" in build.FLAGS and "-fno-vectorize" in build.FLAGS
     assert "-ffp-contract=off" in build.FLAGS
+    # the kernel the finding was made on, and the file whose encoder was written for v_pk_fma_f32 in round 2: ISA checked
+    assert build.packed_fp32_count("warp_fuse_nhwc.hip") == 0
+    assert build.packed_fp32_count("pillar_scatter.hip") == 0
 
 
 def test_pointwise_emu_weight_image_layout():
