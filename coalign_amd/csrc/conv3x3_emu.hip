@@ -75,12 +75,19 @@ template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE = 1, int PBUF 
 struct Geo {
     static_assert(!TAPK || KCH == 2, "tap-major steps pair the two 8-channel halves of a 16-channel interval");
     static constexpr bool STACK = (XV & 1) != 0, NCO1 = (XV & 2) != 0;
+    // XV bit 2 (NBX4): the workgroup's NPB pixel blocks form a grid of four block columns (a tile of BH * NPB / 4 rows x 4 * BW columns) instead of
+    // one column of blocks: with 4 x 8-pixel blocks, an 88-column map ends in a tile whose fourth block column lies past the map -- those
+    // wavefronts run no matrix steps (the 1 x 32 blocks compute 96 columns for 88).  PW is padded to 8 mod 16 so that the four rows a B-operand
+    // read touches fall into alternating halves of the LDS banks.
+    static constexpr int NBX = (XV & 4) ? 4 : 1;
+    static_assert(NPB % NBX == 0, "whole block rows");
     static_assert(!STACK || STRIDE == 1, "stacked tiles: stride-1 layers only");
     static constexpr int NCO = (NPB >= 4 && !NCO1) ? 2 : 1;                   // accumulator tiles (32 output channels each) per wave
     static constexpr int WAVES = NCO == 2 ? NPB : 2 * NPB;
     static constexpr int THREADS = 64 * WAVES;
-    static constexpr int TH = BH * NPB, TW = BW;                              // output tile
-    static constexpr int PH = STRIDE * TH + 3 - STRIDE + (STACK ? 2 : 0), PW = STRIDE * TW + 3 - STRIDE;   // input halo patch: rows STRIDE * y0 - 1 .., columns STRIDE * x0 - 1 ..
+    static constexpr int TH = BH * NPB / NBX, TW = BW * NBX;                  // output tile
+    static constexpr int PWU = STRIDE * TW + 3 - STRIDE;                      // patch columns in use
+    static constexpr int PH = STRIDE * TH + 3 - STRIDE + (STACK ? 2 : 0), PW = NBX == 1 ? PWU : (PWU + 7) / 16 * 16 + 8;   // input halo patch: rows STRIDE * y0 - 1 .., columns STRIDE * x0 - 1 ..
     static constexpr int PIX = PH * PW;                                       // pixel slots of the patch
     static constexpr int SLOTS = (PIX + THREADS - 1) / THREADS;               // pixel slots one thread splits per chunk
     static constexpr int WQ = (TAPK ? 9 : kSteps) * TERMS * 2 * kCoutTile;    // 16-byte groups of one weight unit (8-channel chunk; TAPK: the whole interval)
@@ -124,13 +131,13 @@ __device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[T
 // 3-7 % slower per layer on the tap-major geometries; computing the bf16 split ahead of the second barrier: no change; issuing the next
 // interval's weight DMA and halo loads in shares between the matrix steps instead of all at once after the barrier: no change -- the
 // interval timelines (tools/trace_conv_emu.py) show the burst already overlapped by the other wavefronts' matrix instructions.  All removed.)
-enum { VAR_TAPK = 1, VAR_ASM_DMA = 2, VAR_STACK = 4, VAR_NCO1 = 8 };
+enum { VAR_TAPK = 1, VAR_ASM_DMA = 2, VAR_STACK = 4, VAR_NCO1 = 8, VAR_NBX4 = 16 };
 template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT, int STRIDE = 1, int LAYOUT = LAYOUT_NCHW, int PBUF = 2, int VAR = 0>
 __global__ __launch_bounds__(64 * ((NPB >= 4 && !(VAR & VAR_NCO1)) ? NPB : 2 * NPB))
 __attribute__((amdgpu_waves_per_eu(SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 1, SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 8)))
 void conv3x3_emu_kernel(const EmuArgs a) {
     constexpr bool TAPK = (VAR & VAR_TAPK) != 0, STACK = (VAR & VAR_STACK) != 0;
-    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, TAPK, (VAR >> 2) & 3>;
+    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, TAPK, (VAR >> 2) & 7>;
     static_assert(!(SPLIT && (STRIDE != 1 || LAYOUT != LAYOUT_NCHW || STACK)), "stream-K hand-over only for the plain stride-1 NCHW variant");
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;      // wave: scalar
@@ -147,7 +154,8 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         return c;
     };
     const int pb = wave % NPB, cb = (G::NCO == 2 ? 0 : wave / NPB) * 32;
-    const int py = pb * BH + p / BW, px = p % BW;
+    const int blk_y = pb / G::NBX, blk_x = pb - blk_y * G::NBX;             // this wavefront's pixel block inside the tile
+    const int py = blk_y * BH + p / BW, px = blk_x * BW + p % BW;
     constexpr int NB = TAPK ? 9 : kSteps;
     int boff[NB];                                         // pixel slot of this lane's tap in step s (tap 9 -> tap 8, zeroed below)
 #pragma unroll
@@ -182,7 +190,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
             const int gx = STRIDE * t.x0 - 1 + xq;
             if constexpr (STACK) {
                 int gy, img = 0;
-                bool ok = i < G::PIX && gx >= 0 && gx < a.Win;
+                bool ok = i < G::PIX && xq < G::PWU && gx >= 0 && gx < a.Win;
                 if (yb >= G::TH || y <= yb) gy = yl0 - 1 + y;
                 else if (y <= yb + 2) { gy = 0; ok = false; }
                 else { gy = y - (yb + 3); img = 1; ok = ok && n0 + 1 < a.N; }
@@ -190,7 +198,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                 pl.off[j] = ok ? img * a.Cin * (int)plane_in + gy * a.Win + gx : -1;
             } else {
                 const int gy = STRIDE * t.y0 - 1 + y;
-                pl.off[j] = (i < G::PIX && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? gy * a.Win + gx : -1;
+                pl.off[j] = (i < G::PIX && xq < G::PWU && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? gy * a.Win + gx : -1;
             }
         }
         return pl;
@@ -335,11 +343,12 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         } else {
             live = gy < a.H && gx < a.W;
         }
-        const size_t obase = ((size_t)out_n * a.Cout + cur.cg * kCoutTile + cb + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
+        // (a lane without an output pixel reads the residual of pixel 0 of image 0: a block of several rows may end past the last image)
+        const size_t obase = ((size_t)(live ? out_n : 0) * a.Cout + cur.cg * kCoutTile + cb + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
         const float *bias = a.bias + cur.cg * kCoutTile + cb + 4 * half;
         // a wavefront whose output rows lie below the map (the last row tile: 108 rows for 100, 56 for 50, 32 for 25) still stages pixels,
         // issues weight transfers and meets the barriers, but runs no matrix steps: its share of the padded work costs no energy
-        const bool wave_live = __builtin_amdgcn_readfirstlane((int)(cur.y0 + pb * BH < (STACK ? a.N * a.H : a.H))) != 0;
+        const bool wave_live = __builtin_amdgcn_readfirstlane((int)(cur.y0 + blk_y * BH < (STACK ? a.N * a.H : a.H) && cur.x0 + blk_x * BW < a.W)) != 0;
         floatx16 acc[G::NCO];
         if ((SPLIT && !head) || !wave_live) {
 #pragma unroll
@@ -798,7 +807,7 @@ inline int rows_per_tile(int H, int terms) { return (terms == 3 && H >= 64) ? 12
 // the strided / channels-last variants: whole tiles only (no stream-K), same persistent-workgroup schedule
 template <int BH, int BW, int NPB, int TERMS, int KCH, int STRIDE, int LAYOUT, int PBUF = 2, int VAR = 0>
 int launch_variant(const EmuArgs &a0, hipStream_t s) {
-    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, (VAR & VAR_TAPK) != 0, (VAR >> 2) & 3>;
+    using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, (VAR & VAR_TAPK) != 0, (VAR >> 2) & 7>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
     static int resident = 0, cus = 0;
     auto kern = conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, STRIDE, LAYOUT, PBUF, VAR>;
@@ -1036,6 +1045,8 @@ int tapk_rows(int rows, const EmuArgs &a, int layout, void *ws, size_t ws_bytes,
         // stacked, 32 output channels per wavefront: 6 rows x 32 pixels x 64 channels per workgroup = 12 wavefronts of half a unit (the 25 x 88
         // maps: 21 x 3 x 4 = 252 tiles, three half units per SIMD instead of two whole ones)
         case 106: return tapk_stacked<TERMS, 1, 32, 6, VAR | VAR_STACK | VAR_NCO1>(a, layout, s, query);
+        // stacked, 4 x 8-pixel blocks in four block columns: 8 x 32 tiles whose fourth block column is idle where the map ends after 88 columns
+        case 148: return tapk_stacked<TERMS, 4, 8, 8, VAR | VAR_STACK | VAR_NBX4>(a, layout, s, query);
         default: return COALIGN_ERR_UNSUPPORTED;
     }
 }
@@ -1055,18 +1066,23 @@ int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipSt
     // still keep their CU for the whole K loop; the 50 x 176 maps 220 tiles of 13 units (four on one SIMD).  Tiling the batch as ONE image
     // of N * H rows removes the per-image remainder: 252 tiles of 6 rows x 32 pixels with 32-channel wavefronts = three HALF units per SIMD
     // (1.5 instead of 2); 242 tiles of 24 x 16 pixels = three units per SIMD (instead of four).  COALIGN_EMU_STACK=0: the per-image tiles.
-    // DEFAULT = 1: only the 24 x 16 tiles.  The 6 x 32 / 32-channel variant (bit 1) is 9 % faster on its layer in isolation (94 vs 103 us) and
-    // bit-equal to the per-image tiles; in the 3-lane frame pipeline -1 ... +2 % depending on the box (the other lanes' kernels mostly fill the
-    // CUs its better balance frees), with one frame in flight 3.55 vs 3.66 ms per frame.  It stays opt-in: it is the kernel that exposed the
-    // packed-fp32 hazard written up in profiles/round3/README.md -- a wavefront of ANOTHER kernel that shares a SIMD with this variant's three
-    // matrix wavefronts got wrong results in lanes 48-63 of its v_pk_mul_f32 / v_pk_add_f32 instructions (warp_fuse_nhwc: ~1/3 of fused maps
-    // differed).  Every kernel of this library is now built without packed fp32 instructions (-fno-slp-vectorize, build.py), after which
-    // tools/diag_fuse_corun.py and a 3000-frame soak (tools/soak_pipeline.py) show no difference with the variant on; kernels that are not
-    // ours and share the GPU may still contain them.
-    static const int stack = getenv("COALIGN_EMU_STACK") ? atoi(getenv("COALIGN_EMU_STACK")) : 1;
+    // Bit 2: the 25 x 88 maps in 4 x 8-pixel blocks, four block columns per tile (8 x 32-pixel tiles over the stacked batch): the map ends inside the
+    // third tile column after three of its four block columns, so 11 block columns are computed for 88 pixels instead of 12 (the 1 x 32 blocks
+    // compute 96): -6 % matrix instructions on these layers, same time per layer alone (87.0 vs 86.4 us) at 6.6 % less board power (1202 vs
+    // 1287 W) -- and, the board being at its power limit whenever three frames are in flight, 352-353 vs 336-338 frames/s (same box, alternating).
+    // DEFAULT = 5: bits 0 and 2.  The 6 x 32 / 32-channel variant (bit 1; takes the 25-row maps when bit 2 does not) is 9 % faster on its layer in
+    // isolation (94 vs 103 us) and bit-equal to the per-image tiles; in the 3-lane frame pipeline -1 ... +2 % depending on the box (it executes the same
+    // matrix instructions: balance inside a launch is not what a power-limited pipeline is short of), with one frame in flight 3.55 vs 3.66 ms per
+    // frame.  It stays opt-in: it is the kernel that exposed the packed-fp32 hazard written up in profiles/round3/README.md -- a wavefront of
+    // ANOTHER kernel that shares a SIMD with this variant's three matrix wavefronts got wrong results in lanes 48-63 of its v_pk_mul_f32 /
+    // v_pk_add_f32 instructions (warp_fuse_nhwc: ~1/3 of fused maps differed).  Every kernel of this library is now built without packed fp32
+    // instructions (build.py), after which tools/diag_fuse_corun.py and a 3000-frame soak (tools/soak_pipeline.py) show no difference with the
+    // variant on; kernels that are not ours and share the GPU may still contain them.
+    static const int stack = getenv("COALIGN_EMU_STACK") ? atoi(getenv("COALIGN_EMU_STACK")) : 5;
     int rows = force ? force : (t26 && a.W % 32 == 16 && a.H > 26 && a.H <= 52) ? 26 : (a.H >= 64 ? 12 : 8);
-    if (!force && stack && TERMS == 3) {          // (bit 0: the 24 x 16 tiles, bit 1: the 6 x 32 tiles -- separately switchable for measurements)
+    if (!force && stack && TERMS == 3) {          // (bit 0: the 24 x 16 tiles, bit 1: the 6 x 32 tiles, bit 2: the 4 x 8-pixel blocks -- separately switchable)
         if (rows == 26 && a.H >= 24 && (stack & 1)) rows = 124;
+        else if (rows == 8 && a.H >= 8 && a.H <= 32 && a.W % 32 > 0 && a.W % 32 <= 24 && (stack & 4)) rows = 148;
         else if (rows == 8 && a.H >= 6 && a.H <= 32 && (stack & 2)) rows = 106;
     }
     switch (var) {

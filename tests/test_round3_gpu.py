@@ -569,12 +569,12 @@ def test_stacked_convolution_tiles_equal_per_image_tiles_bit_for_bit():
     fp64 convolution (5e-6 of the output scale) AND bit-identical to the per-image tiles (COALIGN_EMU_STACK=0) -- the per-output sequence of
     products does not depend on the tile geometry.  Shapes with an image boundary inside a tile, at a tile edge, one image, ragged columns."""
     outs = {}
-    for stack in ("3", "1", "0"):          # bit 0: the 24 x 16 tiles (default), bit 1: the opt-in 6 x 32 / 32-channel tiles
+    for stack in ("5", "3", "1", "0"):     # bit 0: the 24 x 16 tiles, bit 1: the opt-in 6 x 32 / 32-channel tiles, bit 2: 4 x 8-pixel blocks on 88-wide maps (default: 5)
         r = subprocess.run([sys.executable, "-c", _STACK_CHECK], env=dict(os.environ, PYTHONPATH=ROOT, COALIGN_EMU_STACK=stack), capture_output=True, text=True,
                            timeout=900, cwd=ROOT)
         assert r.returncode == 0, (stack, r.stdout[-300:], r.stderr[-800:])
         outs[stack] = r.stdout.strip().split("SHA")[-1].strip()
-    assert outs["3"] == outs["1"] == outs["0"], outs
+    assert outs["5"] == outs["3"] == outs["1"] == outs["0"], outs
 
 
 _CORUN_CHECK = r"""
@@ -612,7 +612,7 @@ def test_fusion_is_not_disturbed_by_a_convolution_on_another_stream():
     wavefronts of the 6 x 32 stacked convolution returned wrong lanes 48-63 -- one third of the fused maps differed.  The library is built
     without packed fp32 instructions; here the fusion kernel runs 450 times beside each convolution geometry (the opt-in variant included)
     and every fused map must equal the one computed alone."""
-    for stack in ("3", "1"):
+    for stack in ("3", "5"):          # the opt-in variant the finding was made with; the default set
         r = subprocess.run([sys.executable, "-c", _CORUN_CHECK], env=dict(os.environ, PYTHONPATH=ROOT, COALIGN_EMU_STACK=stack), capture_output=True, text=True,
                            timeout=600, cwd=ROOT)
         assert r.returncode == 0, (stack, r.stdout[-300:], r.stderr[-800:])
