@@ -21,9 +21,10 @@ def sample(stop, out):
 
 N, C, H, W = [int(v) for v in os.environ.get("SHAPE", "5,256,25,88").split(",")]
 g = torch.Generator().manual_seed(0)
-x = torch.randn(N, C, H, W, generator=g).cuda(); w = ops.pack_conv3x3_emu_weight((torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).cuda(), 3, True)
+STRIDE = int(os.environ.get("STRIDE", "1"))          # 2: the strided layers (tap-pair weight image, no residual), H, W = INPUT size
+x = torch.randn(N, C, H, W, generator=g).cuda(); w = ops.pack_conv3x3_emu_weight((torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).cuda(), 3, STRIDE == 1)
 b = torch.randn(C, generator=g).cuda(); r = torch.randn(N, C, H, W, generator=g).cuda()
-fn = lambda: ops.conv3x3_emu_bias_act(x, w, b, C, r, True, 3)
+fn = (lambda: ops.conv3x3_emu_bias_act(x, w, b, C, r, True, 3)) if STRIDE == 1 else (lambda: ops.conv3x3_emu_bias_act(x, w, b, C, None, True, 3, stride=2))
 for _ in range(5): fn()
 torch.cuda.synchronize()
 stop, out = threading.Event(), []
@@ -36,4 +37,4 @@ dt = time.time() - t0
 stop.set(); th.join()
 clk = [c for c, _ in out if isinstance(c, int)]; pw = [p for _, p in out if isinstance(p, float)]
 print(json.dumps({"shape": [N, C, H, W], "rows": os.environ.get("COALIGN_EMU_TAPK_ROWS", "default"), "stack": os.environ.get("COALIGN_EMU_STACK", "default"),
-                  "us_per_call": round(dt / n * 1e6, 1), "sclk_MHz": clk[2:-1], "power_W": [round(p) for p in pw[2:-1]]}))
+                  "stride": STRIDE, "us_per_call": round(dt / n * 1e6, 1), "sclk_MHz": clk[2:-1], "power_W": [round(p) for p in pw[2:-1]]}))
