@@ -428,3 +428,18 @@ def test_pointwise_emu_weight_image_layout():
                 for lane in (0, 7, 31, 32, 45, 63):
                     k0, mm = 16 * step + 8 * (lane // 32), 32 * tile + lane % 32
                     assert img[tile, step, t, lane].tolist() == terms[t][k0: k0 + 8, mm].tolist()
+
+
+def test_xcd_order_of_the_convolution_workgroups_is_a_permutation():
+    """conv3x3_emu.hip: hardware workgroup b (on XCD b % 8) works as logical id k * q + min(k, r) + j (k = b % 8, j = b // 8, q = n // 8, r = n % 8): XCD k
+    gets the k-th contiguous share of the ids.  Restated here: a permutation of range(n) for every grid size, shares contiguous and ordered."""
+    for n in list(range(1, 70)) + [132, 192, 240, 242, 256, 462, 495, 512, 1000]:
+        q, r = n // 8, n % 8
+        ids = [(b % 8) * q + min(b % 8, r) + b // 8 for b in range(n)]
+        assert sorted(ids) == list(range(n)), n
+        for k in range(8):
+            mine = [ids[b] for b in range(k, n, 8)]
+            assert mine == list(range(mine[0], mine[0] + len(mine))) if mine else True
+            if k and mine:
+                prev = [ids[b] for b in range(k - 1, n, 8)]
+                assert prev[-1] + 1 == mine[0], (n, k)
