@@ -1,0 +1,362 @@
+// 3x3 / pad 1 / stride 1 convolution with fused bias (+ residual) (+ ReLU) as Winograd F(2x2, 3x3) on the BF16 matrix cores, fp32 operands
+// by the same error-free 3-way bf16 split as conv3x3_emu.hip, fp32 accumulation, channels-last in and out, gfx950.
+//
+// Layers: the stride-1 3x3 convolutions of the ResNet stages and of the shrink header
+// (opencood/models/sub_modules/resblock.py:53-69, base_bev_backbone_resnet.py:59-138, downsample_conv.py:7-50).
+//
+// Why: every convolution layer of the detector runs at the board's power limit and the frame rate follows the number of executed matrix
+// instructions.  F(2x2, 3x3) evaluates a 2x2 output tile from a 4x4 input patch with 16 products per (cin, cout)
+// instead of 36:
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A,      B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],   A^T = [1 1 1 0; 0 1 -1 -1],
+//     G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+// i.e. 16 independent GEMMs over cin, one per position p = (i, j) of the 4x4 transform domain:  M_p[cout, tile] = sum_cin U_p[cout, cin] V_p[cin, tile].
+//   * U = G g G^T is computed on the host in float64 from the BatchNorm-folded fp32 weights and split into three bf16 terms (ops.pack_conv3x3_wino_weight);
+//   * V = B^T d B is computed in fp32 (additions only) from the fp32 activations while the patch is staged, and split AFTER the transform
+//     (v = v_h + v_m + v_l exactly);
+//   * each product U V is the six cross terms down to 2^-16 |u v| on v_mfma_f32_32x32x16_bf16 (what is dropped is <= 2^-24 |u v|), fp32 accumulators;
+//   * the output transform, bias, residual and ReLU run in the epilogue.
+//
+// Workgroup = 8 wavefronts = one unit of 64 output channels x 64 Winograd tiles (a block of TBH x TBW tiles = 2 TBH x 2 TBW output pixels of
+// the batch stacked as one tall image: `pitch` rows per image, the rows H .. pitch - 1 are the zero padding between two images).
+// The K loop runs over 16-channel steps, each cut in two HALF STAGES h = 0, 1 that cover the transform columns j in {2h, 2h + 1}:
+//   consumer role of wavefront w: transform row i = w & 3, output-channel half c = w >> 2: positions (i, 0..3) x 32 couts x 64 tiles = 8 accumulator
+//     tiles of 32 x 32 (128 registers).  Its A operands (U) are private to it: six 1 KB loads per half stage straight from L2 into registers, one half
+//     stage ahead (the image is stored in exactly that order).  Its B operands (V) come from LDS, one ds_read_b128 each.
+//   producer role of wavefront w: transform row i = w & 3, channel group g = w >> 2 (8 of the 16 channels), lane = tile: reads the two raw rows and
+//     three raw columns its two positions need from the fp32 patch in LDS, transforms (5 additions per 2 values), splits, and writes 6 ready B operands.
+//   The two wavefronts that share a SIMD (w, w + 4) run the two roles in opposite order, so one feeds the matrix pipe while the other transforms.
+// LDS: two V buffers of 48 KB ([jj][i][term][channel group][tile] x 16 B), two raw fp32 patches ([4-channel chunk][column parity][row][column / 2] x 16 B:
+// tiles that are neighbours in x read neighbouring 16-byte slots), 150 KB in all; the epilogue reuses it for the cross-wavefront half of the output transform.
+#include "common.h"
+#include <type_traits>
+
+#ifndef WINO_SWAP_COND
+#define WINO_SWAP_COND (wc == 0)
+#endif
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kCoutUnit = 64;        // output channels per workgroup
+constexpr int kTiles = 64;           // Winograd tiles per workgroup
+constexpr int kVBuf = 2 * 4 * 3 * 2 * kTiles;      // uint4 per V buffer: [jj][i][term][g][tile]
+
+struct WinoArgs {
+    const float *__restrict__ x;          // [N][H][W][Cin]
+    const uint4 *__restrict__ u;          // [Cout / 64][Cin / 16][2 h][8 waves][2 jj][3 terms][64 lanes] x 16 B
+    const float *__restrict__ bias;       // [Cout]
+    const float *__restrict__ residual;   // [N][H][W][Cout] or null
+    float *__restrict__ y;                // [N][H][W][Cout]
+    int N, Cin, Cout, H, W, relu;
+    int pitch;                            // rows per image in the stacked image (H + 1 for odd H, H + 2 for even H)
+    int blocks_x, blocks, units, xcd;
+};
+
+template <int TBW>
+struct WGeo {
+    static_assert(TBW == 8 || TBW == 16, "tile blocks of 8 x 8 or 4 x 16 tiles");
+    static constexpr int TBH = kTiles / TBW;
+    static constexpr int PR = 2 * TBH + 2, PC = 2 * TBW + 2;        // raw patch rows / columns
+    static constexpr int PCH = TBW == 16 ? 20 : 12;                 // column pairs per row, padded to 4 mod 8 (two tile rows = half the banks apart)
+    static constexpr int RAWQ = 2 * PR * PCH;                       // uint4 per 4-channel chunk plane: [parity][row][column / 2]
+    static constexpr int RAWSZ = 4 * RAWQ;                          // uint4 per raw buffer
+    static constexpr int NU = PR * PC * 4;                          // 16-byte units of one patch, pixel-major, chunk fastest
+    static constexpr int NJ = (NU + 511) / 512;
+    static constexpr int V_OFF = 0, R_OFF = 2 * kVBuf;
+    static constexpr int ZSTRIDE = 68;                              // floats per (row, b, tile) in the epilogue exchange: 64 couts + 4 of bank shift
+    static constexpr size_t LDS_MAIN = (size_t)(2 * kVBuf + 2 * RAWSZ) * 16, LDS_EPI = (size_t)4 * 2 * kTiles * ZSTRIDE * 4;
+    static constexpr size_t LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+};
+
+// error-free 3-way split of 8 fp32 values: out[t] = term t of each, 8 bf16 = one matrix operand
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[3]) {
+    bf16x8 o[3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        const float r = v[e] - (float)h;
+        const __bf16 m = (__bf16)r;
+        o[0][e] = h;
+        o[1][e] = m;
+        o[2][e] = (__bf16)(r - (float)m);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) out[t] = __builtin_bit_cast(uint4, o[t]);
+}
+
+// workgroup barrier that waits for this wavefront's LDS traffic only (the register prefetches of the next half stage stay in flight)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int TBW>
+__global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoArgs a) {
+    using G = WGeo<TBW>;
+    extern __shared__ __attribute__((aligned(1024))) uint4 lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wi = wave & 3, wc = wave >> 2;              // consumer: transform row, cout half; producer: transform row, channel group
+    const int K = a.Cin >> 4, groups = a.Cout / kCoutUnit;
+    // producer constants: the raw rows of R[i] = d[ra] + sg d[rb]  (B^T rows: d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+    const int ra = wi == 0 ? 0 : wi == 2 ? 2 : 1, rb = wi == 0 ? 2 : wi == 1 ? 2 : wi == 2 ? 1 : 3;
+    const float sg = wi == 1 ? 1.f : -1.f;
+    const int pty = lane / TBW, ptx = lane % TBW;         // producer: this lane's tile inside the block
+    // raw slot of patch pixel (2 pty + r, 2 ptx + c) for chunk q: ((q * 2 + (c & 1)) * PR + 2 pty + r) * PCH + ptx + (c >> 1)
+    const int praw = (2 * pty) * G::PCH + ptx;
+    const int vwr = (wi * 3) * 2 * kTiles + wc * kTiles + lane;                        // + jj * 4 * 3 * 2 * 64 + term * 128: this lane's B-operand slot as a producer
+    const int vrd = (wi * 3) * 2 * kTiles + (lane >> 5) * kTiles + (lane & 31);        // + jj * ... + term * 128 + 32 tb: as a consumer
+
+    int g = blockIdx.x;
+    if (a.xcd) g = coalign::xcd_remap(g, gridDim.x);       // neighbouring units (same tiles, other couts; same couts, next tiles) share an L2
+    for (int unit = g; unit < a.units; unit += gridDim.x) {
+        const int cg = unit % groups, blk = unit / groups;
+        const int by = blk / a.blocks_x, bx = blk - by * a.blocks_x;
+        const int ty0 = by * G::TBH, tx0 = bx * TBW;      // first tile of the block (stacked tile rows)
+        // ---- raw patch plan: 16-byte unit e = tid + 512 j: pixel e >> 2 of the patch, chunk e & 3
+        int goff[G::NJ], ldst[G::NJ];
+#pragma unroll
+        for (int j = 0; j < G::NJ; ++j) {
+            const int e = tid + 512 * j, pi = e >> 2, q = e & 3;
+            const int pr = pi / G::PC, pc = pi - pr * G::PC;
+            const int s = 2 * ty0 - 1 + pr, xg = 2 * tx0 - 1 + pc;
+            const int n = s >= 0 ? s / a.pitch : 0, r = s - n * a.pitch;
+            const bool ok = e < G::NU && s >= 0 && n < a.N && r < a.H && xg >= 0 && xg < a.W;
+            goff[j] = ok ? ((n * a.H + r) * a.W + xg) * a.Cin + 4 * q : -1;
+            ldst[j] = e < G::NU ? ((q * 2 + (pc & 1)) * G::PR + pr) * G::PCH + (pc >> 1) : -1;
+        }
+        auto load_raw = [&](int k, uint4 (&rv)[G::NJ]) {
+#pragma unroll
+            for (int j = 0; j < G::NJ; ++j) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(a.x + (goff[j] < 0 ? 0 : goff[j]) + 16 * k);
+                rv[j] = goff[j] < 0 ? uint4{0, 0, 0, 0} : t;
+            }
+        };
+        auto write_raw = [&](int buf, const uint4 (&rv)[G::NJ]) {
+            uint4 *rbuf = lds + G::R_OFF + buf * G::RAWSZ;
+#pragma unroll
+            for (int j = 0; j < G::NJ; ++j)
+                if (ldst[j] >= 0) rbuf[ldst[j]] = rv[j];
+        };
+        const uint4 *ubase = a.u + ((size_t)cg * K * 2 * 8 + wave) * (2 * 3 * 64) + lane;        // + (k * 2 + h) * 8 * 384 + (jj * 3 + term) * 64
+        auto load_a = [&](int k, int h, uint4 (&av)[2][3]) {
+            const uint4 *p = ubase + (size_t)(k * 2 + h) * (8 * 2 * 3 * 64);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) av[jj][t] = p[(jj * 3 + t) * 64];
+        };
+        // producer: half stage (k, h) -> V buffer vb, from raw buffer rbi
+        auto produce = [&](auto hc, int rbi, int vb) {
+            constexpr int h = decltype(hc)::value;
+            const uint4 *rbuf = lds + G::R_OFF + rbi * G::RAWSZ + praw;
+            float v0[8], v1[8];
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int q = 2 * wc + q2;
+                float4 R[3];
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const int c = h + ci;                  // raw columns h .. h + 2
+                    const int base = (q * 2 + (c & 1)) * G::PR * G::PCH + (c >> 1);
+                    const float4 da = __builtin_bit_cast(float4, rbuf[base + ra * G::PCH]);
+                    const float4 db = __builtin_bit_cast(float4, rbuf[base + rb * G::PCH]);
+                    R[ci].x = fmaf(sg, db.x, da.x); R[ci].y = fmaf(sg, db.y, da.y); R[ci].z = fmaf(sg, db.z, da.z); R[ci].w = fmaf(sg, db.w, da.w);
+                }
+                // h = 0: V[i][0] = R0 - R2, V[i][1] = R1 + R2 (columns 0 1 2);  h = 1: V[i][2] = R2 - R1, V[i][3] = R1 - R3 (columns 1 2 3 -> R[0..2])
+                float4 p0, p1;
+                if (h == 0) {
+                    p0 = float4{R[0].x - R[2].x, R[0].y - R[2].y, R[0].z - R[2].z, R[0].w - R[2].w};
+                    p1 = float4{R[1].x + R[2].x, R[1].y + R[2].y, R[1].z + R[2].z, R[1].w + R[2].w};
+                } else {
+                    p0 = float4{R[1].x - R[0].x, R[1].y - R[0].y, R[1].z - R[0].z, R[1].w - R[0].w};
+                    p1 = float4{R[0].x - R[2].x, R[0].y - R[2].y, R[0].z - R[2].z, R[0].w - R[2].w};
+                }
+                v0[4 * q2] = p0.x; v0[4 * q2 + 1] = p0.y; v0[4 * q2 + 2] = p0.z; v0[4 * q2 + 3] = p0.w;
+                v1[4 * q2] = p1.x; v1[4 * q2 + 1] = p1.y; v1[4 * q2 + 2] = p1.z; v1[4 * q2 + 3] = p1.w;
+            }
+            uint4 s0[3], s1[3];
+            split8(v0, s0);
+            split8(v1, s1);
+            uint4 *vbuf = lds + G::V_OFF + vb * kVBuf + vwr;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                vbuf[t * 2 * kTiles] = s0[t];
+                vbuf[4 * 3 * 2 * kTiles + t * 2 * kTiles] = s1[t];
+            }
+        };
+
+        floatx16 acc[4][2];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) acc[p][tb] = floatx16{0};
+        // a 32-tile half of the block that lies wholly below the stacked image runs no matrix steps
+        const bool live0 = 2 * ty0 < a.N * a.pitch, live1 = 2 * (ty0 + G::TBH / 2) < a.N * a.pitch;
+        auto consume = [&](auto hc, int vb, const uint4 (&av)[2][3]) {
+            constexpr int h = decltype(hc)::value;
+            const uint4 *vbuf = lds + G::V_OFF + vb * kVBuf + vrd;
+            constexpr int wt[6] = {0, 1, 2, 0, 1, 0}, bt[6] = {2, 1, 0, 1, 0, 0};      // smallest products first
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) {
+                    if (tb == 0 ? !live0 : !live1) continue;
+                    uint4 b[3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) b[t] = vbuf[jj * 4 * 3 * 2 * kTiles + t * 2 * kTiles + 32 * tb];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        floatx16 &d = acc[2 * h + jj][tb];
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[jj][wt[i]]), __builtin_bit_cast(bf16x8, b[bt[i]]), d, 0, 0, 0);
+                    }
+                }
+        };
+
+        constexpr std::integral_constant<int, 0> H0{};
+        constexpr std::integral_constant<int, 1> H1{};
+        // ---- prologue
+        uint4 rawv[G::NJ], a0[2][3], a1[2][3];
+        load_raw(0, rawv);
+        load_a(0, 0, a0);
+        write_raw(0, rawv);
+        if (K > 1) load_raw(1, rawv);
+        lds_barrier();
+        produce(H0, 0, 0);
+        // ---- K loop: two half stages per 16 channels; everything one half stage ahead, one barrier per half stage
+        for (int k = 0; k < K; ++k) {
+            lds_barrier();                                 // V(k, 0) complete; V buffer 1 and raw buffer (k + 1) & 1 free
+            load_a(k, 1, a1);
+            if (k + 1 < K) write_raw((k + 1) & 1, rawv);
+#pragma nounroll
+            for (int sub = 0; sub < 2; ++sub) {            // wavefronts w and w + 4 share a SIMD: one transforms while the other runs its matrix steps
+                if (sub == wc) consume(H0, 0, a0);
+                else produce(H1, k & 1, 1);
+            }
+            lds_barrier();                                 // V(k, 1) and raw(k + 1) complete; V buffer 0 free
+            if (k + 1 < K) load_a(k + 1, 0, a0);
+            if (k + 2 < K) load_raw(k + 2, rawv);
+#pragma nounroll
+            for (int sub = 0; sub < 2; ++sub) {
+                if (sub == wc) consume(H1, 1, a1);
+                else if (k + 1 < K) produce(H0, (k + 1) & 1, 0);
+            }
+        }
+        // ---- epilogue.  Output transform, column half inside the wavefront: Z[i][0] = M[i][0] + M[i][1] + M[i][2], Z[i][1] = M[i][1] - M[i][2] - M[i][3]
+        __syncthreads();                                   // every wavefront is done with the V / raw buffers
+        float *zf = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const int tile = 32 * tb + (lane & 31);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float4 z0, z1;
+                float *o0 = &z0.x, *o1 = &z1.x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * rg + e;
+                    o0[e] = (acc[0][tb][r] + acc[1][tb][r]) + acc[2][tb][r];
+                    o1[e] = (acc[1][tb][r] - acc[2][tb][r]) - acc[3][tb][r];
+                }
+                const int cout = 32 * wc + 8 * rg + 4 * (lane >> 5);          // accumulator register r = 4 rg + e holds cout 8 rg + 4 (lane >> 5) + e
+                *reinterpret_cast<float4 *>(zf + ((wi * 2 + 0) * kTiles + tile) * G::ZSTRIDE + cout) = z0;
+                *reinterpret_cast<float4 *>(zf + ((wi * 2 + 1) * kTiles + tile) * G::ZSTRIDE + cout) = z1;
+            }
+        }
+        __syncthreads();
+        // row half across the wavefronts: Y[0][b] = Z[0][b] + Z[1][b] + Z[2][b], Y[1][b] = Z[1][b] - Z[2][b] - Z[3][b]; item = (a, b, tile, 4 couts),
+        // 16 consecutive lanes = the 64 couts of one pixel (256 contiguous bytes)
+        {
+            const int cq = tid & 15;
+            const float4 bias = *reinterpret_cast<const float4 *>(a.bias + cg * kCoutUnit + 4 * cq);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ab = j >> 1, oa = ab >> 1, ob = ab & 1;
+                const int tile = (tid >> 4) + 32 * (j & 1);
+                const int ty = tile / TBW, tx = tile - ty * TBW;
+                const int s = 2 * (ty0 + ty) + oa, ox = 2 * (tx0 + tx) + ob;
+                const int n = s / a.pitch, oy = s - n * a.pitch;
+                if (n < a.N && oy < a.H && ox < a.W) {
+                    const float *zp = zf + (ob * kTiles + tile) * G::ZSTRIDE + 4 * cq;
+                    const float4 z0 = *reinterpret_cast<const float4 *>(zp + (oa ? 1 : 0) * 2 * kTiles * G::ZSTRIDE);
+                    const float4 z1 = *reinterpret_cast<const float4 *>(zp + (oa ? 2 : 1) * 2 * kTiles * G::ZSTRIDE);
+                    const float4 z2 = *reinterpret_cast<const float4 *>(zp + (oa ? 3 : 2) * 2 * kTiles * G::ZSTRIDE);
+                    float4 o;
+                    if (oa == 0) o = float4{(z0.x + z1.x) + z2.x, (z0.y + z1.y) + z2.y, (z0.z + z1.z) + z2.z, (z0.w + z1.w) + z2.w};
+                    else o = float4{(z0.x - z1.x) - z2.x, (z0.y - z1.y) - z2.y, (z0.z - z1.z) - z2.z, (z0.w - z1.w) - z2.w};
+                    const size_t off = ((size_t)(n * a.H + oy) * a.W + ox) * a.Cout + cg * kCoutUnit + 4 * cq;
+                    o.x += bias.x; o.y += bias.y; o.z += bias.z; o.w += bias.w;
+                    if (a.residual) {
+                        const float4 rsd = *reinterpret_cast<const float4 *>(a.residual + off);
+                        o.x += rsd.x; o.y += rsd.y; o.z += rsd.z; o.w += rsd.w;
+                    }
+                    if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    *reinterpret_cast<float4 *>(a.y + off) = o;
+                }
+            }
+        }
+        __syncthreads();                                   // the next unit's prologue overwrites the exchange area
+    }
+}
+
+template <int TBW>
+int launch_wino(const WinoArgs &a0, hipStream_t s) {
+    using G = WGeo<TBW>;
+    static_assert(G::LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
+    static int cus = 0;
+    auto kern = conv3x3_wino_kernel<TBW>;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+        const int rc = coalign::hip_call(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+        if (rc != COALIGN_OK) {
+            (void)hipGetLastError();
+            return rc;
+        }
+        cus = prop.multiProcessorCount;
+    }
+    WinoArgs a = a0;
+    a.pitch = a.H + ((a.H & 1) ? 1 : 2);
+    const int tile_rows = a.N * a.pitch / 2, tile_cols = (a.W + 1) / 2;
+    a.blocks_x = (tile_cols + TBW - 1) / TBW;
+    a.blocks = a.blocks_x * ((tile_rows + G::TBH - 1) / G::TBH);
+    a.units = a.blocks * (a.Cout / kCoutUnit);
+    const int grid = a.units < cus ? a.units : cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS_BYTES, s, a);
+    return COALIGN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t coalign_conv3x3_wino_weight_bytes(int Cin, int Cout) {
+    if (Cin < 16 || Cout < 64 || Cin % 16 || Cout % kCoutUnit) return 0;
+    return (size_t)(Cout / kCoutUnit) * (Cin / 16) * 2 * 8 * 2 * 3 * 64 * 16;
+}
+
+extern "C" int coalign_conv3x3_wino(const float *x, const void *u_split, const float *bias, const float *residual, float *y, int N, int Cin, int Cout,
+                                    int H, int W, int relu, int tile_block_w, void *stream) {
+    using namespace coalign;
+    if (!x || !u_split || !bias || !y) return COALIGN_ERR_NULL_POINTER;
+    if (N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return COALIGN_ERR_BAD_SHAPE;
+    if (Cin % 16 || Cout % kCoutUnit) return COALIGN_ERR_UNSUPPORTED;
+    if ((int64_t)N * (H + 2) * W * (Cin > Cout ? Cin : Cout) >= (int64_t)1 << 31) return COALIGN_ERR_UNSUPPORTED;      // 32-bit pixel offsets
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(u_split) | reinterpret_cast<uintptr_t>(bias) |
+         reinterpret_cast<uintptr_t>(residual)) & 15)
+        return COALIGN_ERR_UNSUPPORTED;
+    if (N == 0) return COALIGN_OK;
+    WinoArgs a{x, static_cast<const uint4 *>(u_split), bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, 0, 1};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // block shape: 4 x 16 tiles (8 x 32 pixels) unless the map is narrow or 8 x 8 tiles waste fewer columns
+    int tbw = tile_block_w;
+    if (tbw == 0) {
+        const int tc = (W + 1) / 2;
+        const int waste16 = (tc + 15) / 16 * 16 - tc, waste8 = (tc + 7) / 8 * 8 - tc;
+        tbw = waste8 < waste16 ? 8 : 16;
+    }
+    int rc;
+    if (tbw == 16) rc = launch_wino<16>(a, s);
+    else if (tbw == 8) rc = launch_wino<8>(a, s);
+    else return COALIGN_ERR_UNSUPPORTED;
+    return rc != COALIGN_OK ? rc : check_launch();
+}

@@ -617,6 +617,61 @@ def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Ten
     return y
 
 
+def pack_conv3x3_wino_weight(weight: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] fp32 (BatchNorm folded) -> the operand image of ``coalign_conv3x3_wino`` (include/coalign_amd.h (9c)), uint8:
+    U = G g G^T in float64, split into three bf16 terms (term 0 = bf16(U), term 1 = bf16(U - term 0), term 2 = bf16(U - term 0 - term 1), the
+    residuals exact in float64), stored [Cout / 64][Cin / 16][h][wave = 4 c + i][jj][term][lane][8]: the 16 bytes lane ``l`` of wavefront (i, c) loads for
+    transform position (i, 2 h + jj) are U[i, 2 h + jj, 64 g + 32 c + l % 32, 16 k + 8 (l // 32) : + 8]."""
+    co, ci, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or co % 64 or ci % 16:
+        raise ValueError(f"conv3x3_wino needs 3x3 weights with Cout % 64 == 0 and Cin % 16 == 0, got {tuple(weight.shape)}")
+    Gm = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=weight.device)
+    U = torch.einsum("ia,ocab,jb->ijoc", Gm, weight.detach().double(), Gm)                 # [4 i, 4 j, Cout, Cin]
+    parts, rest = [], U
+    for _ in range(3):
+        t = rest.float().bfloat16()
+        parts.append(t)
+        rest = rest - t.double()
+    T = torch.stack(parts, 0)                                                              # [term, i, j, Cout, Cin] bf16
+    T = T.view(3, 4, 2, 2, co // 64, 2, 32, ci // 16, 2, 8)                                # [term, i, h, jj, g, c, m, k, half, e]
+    img = T.permute(4, 7, 2, 5, 1, 3, 0, 8, 6, 9).contiguous()                             # [g, k, h, c, i, jj, term, half, m, e]
+    out = img.view(torch.uint8).reshape(-1)
+    assert out.numel() == hip.lib().coalign_conv3x3_wino_weight_bytes(ci, co)
+    return out
+
+
+def nhwc_memory(t: torch.Tensor) -> bool:
+    """A 4-d float32 tensor of logical shape [N, C, H, W] whose memory is dense [N, H, W, C]."""
+    return t.dim() == 4 and t.dtype == torch.float32 and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def to_nhwc(t: torch.Tensor) -> torch.Tensor:
+    return t if nhwc_memory(t) else t.float().contiguous(memory_format=torch.channels_last)
+
+
+@_device_op
+def conv3x3_wino(x: torch.Tensor, u_split: torch.Tensor, bias: torch.Tensor, cout: int, residual: Optional[torch.Tensor] = None,
+                 relu: bool = True, tile_block_w: int = 0) -> torch.Tensor:
+    """y = act(conv3x3(x, w, stride 1, padding 1) + bias (+ residual)) as Winograd F(2x2, 3x3) on the split-bf16 matrix cores
+    (csrc/conv3x3_wino.hip).  x / residual / y: logical [N, C, H, W] in channels-last memory (x and residual are converted if they are not)."""
+    _need_gpu(x, u_split, bias, residual)
+    L = hip.lib()
+    xc = to_nhwc(x)
+    N, Cin, H, W = xc.shape
+    if u_split.numel() != L.coalign_conv3x3_wino_weight_bytes(Cin, cout):
+        raise ValueError("transformed weight image does not match (Cin, Cout)")
+    y = torch.empty((N, cout, H, W), dtype=torch.float32, device=xc.device, memory_format=torch.channels_last)
+    if not nhwc_memory(y):                                 # (C == 1 or H * W == 1 cannot occur here: Cout % 64 == 0)
+        y = torch.empty((N, H, W, cout), dtype=torch.float32, device=xc.device).permute(0, 3, 1, 2)
+    res = None if residual is None else to_nhwc(residual)
+    if res is not None and res.shape != y.shape:
+        raise ValueError("residual shape mismatch")
+    with _Timed("conv3x3_wino"):
+        hip.check(L.coalign_conv3x3_wino(_ptr(xc), _ptr(u_split), _ptr(_f32c(bias)), _ptr(res), _ptr(y), N, Cin, cout, H, W, int(relu),
+                                         int(tile_block_w), _stream()), "coalign_conv3x3_wino")
+    return y
+
+
 def pack_pointwise_weight(weight: torch.Tensor, transposed: bool) -> torch.Tensor:
     """ConvTranspose2d weight [Cin, Cout, k, k] -> [Cin, Cout * k * k] (a view of the same layout); Conv2d 1x1 weight
     [Cout, Cin, 1, 1] -> [Cin, Cout padded to a multiple of 32] (zero columns)."""
