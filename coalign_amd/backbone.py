@@ -70,6 +70,15 @@ NHWC_STAGE_OUTPUTS = os.environ.get("COALIGN_NHWC_STAGES", "1") != "0"
 # Weight image of the stride-1 split-bf16 convolutions: "1" = tap-major (16-channel intervals of nine matrix steps, no zero tenth tap,
 # one workgroup per CU), "0" = tap pairs of 8-channel chunks (ten steps per 16 channels, two workgroups per CU).  Measured: DESIGN.md §8.
 CONV_EMU_TAP_MAJOR = os.environ.get("COALIGN_EMU_TAPK", "1") != "0"
+# Round 4: with the 3-way split active, every stride-1 3x3 convolution whose input is channels-last runs as Winograd F(2x2, 3x3) on the split-bf16
+# matrix cores (coalign_conv3x3_wino: 16 instead of 36 products per 2 x 2 outputs, same fp32-width arithmetic, channels-last in and out).  The
+# layers around them hand channels-last maps on: the strided first convolution of a stage (channels-last in and out), the 1x1 skip convolution,
+# and the first shrink-header convolution (NCHW concatenation in, channels-last out).  "0": the direct kernels everywhere (round 3's route).
+CONV_WINOGRAD = os.environ.get("COALIGN_WINOGRAD", "1") != "0"
+
+
+def winograd_active() -> bool:
+    return CONV_WINOGRAD and CONV_EMU_TERMS == 3
 
 
 class Conv3x3Pack:
@@ -80,12 +89,22 @@ class Conv3x3Pack:
         self.cout, self.cin = weight.shape[0], weight.shape[1]
         self._f32 = None
         self._emu = {}
+        self._wino = None
 
     @property
     def f32(self) -> torch.Tensor:
         if self._f32 is None:
             self._f32 = ops.pack_conv3x3_weight(self.weight)
         return self._f32
+
+    @property
+    def wino_ok(self) -> bool:
+        return self.cin % 16 == 0 and self.cout % 64 == 0
+
+    def wino(self) -> torch.Tensor:
+        if self._wino is None:
+            self._wino = ops.pack_conv3x3_wino_weight(self.weight)
+        return self._wino
 
     def emu(self, terms: int, tap_major: bool = False) -> torch.Tensor:
         tap_major = bool(tap_major and self.cin % 16 == 0)
@@ -125,8 +144,11 @@ def conv3x3_fused(x: torch.Tensor, pack: Optional["Conv3x3Pack"], weight: torch.
     stride = stride[0] if isinstance(stride, (tuple, list)) else stride
     if pack is not None:
         if CONV_EMU_TERMS in (2, 3) and stride in (1, 2):              # any map size
+            cl_in = ops.is_channels_last(x)
+            if stride == 1 and winograd_active() and cl_in and pack.wino_ok:
+                return ops.conv3x3_wino(x, pack.wino(), bias, pack.cout, residual, True)
             return ops.conv3x3_emu_bias_act(x, pack.emu(CONV_EMU_TERMS, CONV_EMU_TAP_MAJOR and stride == 1), bias, pack.cout, residual, True, CONV_EMU_TERMS, stride=stride,
-                                            out_channels_last=out_channels_last and stride == 1)
+                                            out_channels_last=out_channels_last and (stride == 1 or cl_in))
         if stride == 1 and x.shape[3] % 4 == 0 and hip_conv3x3_wins(x, pack.cin, pack.cout):
             return ops.conv3x3_bias_act(x, pack.f32, bias, residual, True)
     return ops.bias_act_(F.conv2d(x.contiguous(), weight, None, stride, 1), bias, residual, True)
@@ -225,17 +247,22 @@ class BasicBlock(nn.Module):
         if _fast_ok(self, x):
             w1, b1, w2, b2, wd, p1, p2, pd = self._folded()
             emu = CONV_EMU_TERMS in (2, 3)
-            # a channels-last input (the previous stage's output) is read in place by the strided convolution and the pointwise skip
-            if not (ops.is_channels_last(x) and emu and self.stride == 2 and p1 is not None and pd is not None):
+            # Winograd route: the block's maps stay channels-last from its first convolution on (conv1 -> conv2 -> output, and the skip)
+            wino = winograd_active() and p1 is not None and p2 is not None and p2.wino_ok and (self.stride == 1 or pd is not None)
+            cl = ops.is_channels_last(x)
+            # a channels-last input (the previous stage's output / a Winograd block's output) is read in place: by the strided convolution and the
+            # pointwise skip, or by the Winograd layers
+            if not (cl and emu and p1 is not None and ((self.stride == 2 and pd is not None) or (wino and self.stride == 1 and p1.wino_ok))):
                 x = x.contiguous()
-            y = conv3x3_fused(x, p1, w1, b1, None, self.stride)
+            y = conv3x3_fused(x, p1, w1, b1, None, self.stride, out_channels_last=wino)
             if wd is None:
                 skip = x
             elif pd is not None:
-                skip = ops.pointwise_conv(x, pd[0].get(), pd[1], wd.shape[0], in_stride=2, relu=False)      # its BN shift already sits in b2
+                skip = ops.pointwise_conv(x, pd[0].get(), pd[1], wd.shape[0], in_stride=2, relu=False,      # its BN shift already sits in b2
+                                          out_channels_last=wino and wd.shape[0] % 4 == 0 and ops.is_channels_last(y))
             else:
                 skip = F.conv2d(x, wd, None, self.stride)
-            return conv3x3_fused(y, p2, w2, b2, skip, out_channels_last=out_channels_last and emu and p2 is not None and p2.cout in (64, 128, 256))
+            return conv3x3_fused(y, p2, w2, b2, skip, out_channels_last=(wino or out_channels_last) and emu and p2 is not None and p2.cout % 4 == 0)
         skip = x if self.downsample is None else self.downsample(x)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
@@ -422,14 +449,15 @@ class BaseBEVBackbone(_MultiscaleDecodeMixin, nn.Module):
                 out.append((w, b, stride, Conv3x3Pack(w) if packable(w) and stride in (1, 2) and blk[k].stride[0] == blk[k].stride[1] else None))
             return out
         for w, b, stride, pack in _cache_of(blk).get(blk, build):
-            x = conv3x3_fused(x, pack, w, b, None, stride)                      # ZeroPad2d(1) + pad 0 == pad 1
+            # (Winograd route: the strided first layer of a block writes channels-last when it read channels-last; the stride-1 layers behind it follow)
+            x = conv3x3_fused(x, pack, w, b, None, stride, out_channels_last=winograd_active() and pack is not None and pack.wino_ok)      # ZeroPad2d(1) + pad 0 == pad 1
         return x
 
     def get_multiscale_feature(self, spatial_features: torch.Tensor) -> List[torch.Tensor]:
         feats, x = [], spatial_features
         fast = _fast_ok(self, x)
         for blk in self.blocks:
-            x = self._block_fast(blk, x.contiguous()) if fast else blk(x)
+            x = self._block_fast(blk, x if (winograd_active() and ops.is_channels_last(x)) else x.contiguous()) if fast else blk(x)
             feats.append(x)
         return feats
 
@@ -461,7 +489,7 @@ class DoubleConv(nn.Module):
             p1, p2 = _cache_of(self).get([c1.weight, c2.weight], build)
             x = x.contiguous()
             if p1 is not None:
-                y = conv3x3_fused(x, p1, c1.weight, c1.bias, None)
+                y = conv3x3_fused(x, p1, c1.weight, c1.bias, None, out_channels_last=winograd_active() and p2 is not None and p2.wino_ok)
             else:
                 y = ops.bias_act_(F.conv2d(x, c1.weight, None, c1.stride, c1.padding), c1.bias, None, True)
             return conv3x3_fused(y, p2, c2.weight, c2.bias, None)

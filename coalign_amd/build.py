@@ -20,6 +20,10 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip.so")
+# The LABORATORY build (tools/ only): the same sources with -DCOALIGN_LAB, which compiles in the ablation / debug switches and the measured-and-rejected
+# kernel variants (read from COALIGN_* environment variables).  The product library above contains none of them; `python -m coalign_amd.build --lab`
+# builds it, COALIGN_LAB=1 makes coalign_amd.hip load it.
+LAB_LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip_lab.so")
 INCLUDE = os.path.join(REPO, "include")
 SOURCES = ["status.cpp", "pillar_scatter.hip", "warp_fuse.hip", "warp_fuse_nhwc.hip", "decode.hip", "nms.hip", "epilogue.hip", "voxelize.hip", "pose_graph.hip", "conv3x3.hip", "conv3x3_emu.hip", "conv3x3_wino.hip", "pointwise.hip"]
 ARCH = "gfx950"
@@ -46,7 +50,9 @@ def _newest(paths) -> float:
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
+    OBJ = os.path.join(CSRC, "_obj_lab" if lab else "_obj")
+    LIB_PATH = LAB_LIB_PATH if lab else globals()["LIB_PATH"]
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     headers = [os.path.join(INCLUDE, "coalign_amd.h"), os.path.join(CSRC, "common.h"), os.path.abspath(__file__)]
@@ -56,7 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         if force or not os.path.exists(op) or os.path.getmtime(op) < _newest([sp] + headers):
-            cmd = [hipcc, "-x", "hip"] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", op]
+            cmd = [hipcc, "-x", "hip"] + FLAGS + (["-DCOALIGN_LAB"] if lab else []) + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
@@ -73,7 +79,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, lab="--lab" in sys.argv))
 
 
 def packed_fp32_count(src: str) -> int:

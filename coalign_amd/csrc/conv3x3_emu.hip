@@ -63,7 +63,7 @@ struct EmuArgs {
 #define EMU_STAMP(k)
 #endif
 
-enum { LAYOUT_NCHW = 0, LAYOUT_OUT_NHWC = 1, LAYOUT_IN_NHWC = 2 };
+enum { LAYOUT_NCHW = 0, LAYOUT_OUT_NHWC = 1, LAYOUT_IN_NHWC = 2, LAYOUT_NHWC = 3 };      // bits: 1 = channels-last output, 2 = channels-last input
 
 // TAPK ("K = 144"): a barrier interval is 16 input channels x 9 taps = nine MFMA steps whose K = 16 is the 16 channels of ONE tap (lanes
 // 0-31 channels 0-7, lanes 32-63 channels 8-15) -- no zero tenth tap, 10 % fewer MFMAs.  Weight image [9 taps][term][2 channel halves]
@@ -206,7 +206,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     // chunk c of the tile: the 8 input channels of this thread's pixel slots -> registers (plain coalesced loads: consecutive
     // lanes = consecutive pixels of a patch row; clamped address + zero select, no divergent branch around the loads)
     auto load_patch = [&](const Plan &pl, int c, float (&v)[G::SLOTS][8 * KCH]) {
-        if constexpr (LAYOUT == LAYOUT_IN_NHWC) {          // channels-last input: the 8 channels of a pixel are 32 contiguous bytes
+        if constexpr ((LAYOUT & LAYOUT_IN_NHWC) != 0) {          // channels-last input: the 8 channels of a pixel are 32 contiguous bytes
             const float *src = pl.base + (size_t)c * (kKC * KCH);
 #pragma unroll
             for (int j = 0; j < G::SLOTS; ++j) {
@@ -492,7 +492,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                     acc[q / 16][q % 16] += __hip_atomic_load(slot + (q / 16) * 1024 + (q % 16) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (live) {
-                if constexpr (LAYOUT == LAYOUT_OUT_NHWC) {      // channels-last output: accumulators 4 r .. 4 r + 3 are 4 consecutive channels
+                if constexpr ((LAYOUT & LAYOUT_OUT_NHWC) != 0) {      // channels-last output: accumulators 4 r .. 4 r + 3 are 4 consecutive channels
                     float *yp = a.y + (((size_t)out_n * a.H + gy) * a.W + gx) * a.Cout + cur.cg * kCoutTile + cb + 4 * half;
 #pragma unroll
                     for (int r = 0; r < 4 * G::NCO; ++r) {
@@ -907,9 +907,11 @@ int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
         if (TERMS == 3 && s2pb) {
             if (layout == LAYOUT_NCHW) return launch_variant<1, 32, 8, TERMS, 1, 2, LAYOUT_NCHW, 1>(a, s);
             if (layout == LAYOUT_IN_NHWC) return launch_variant<1, 32, 8, TERMS, 1, 2, LAYOUT_IN_NHWC, 1>(a, s);
+            if (layout == LAYOUT_NHWC) return launch_variant<1, 32, 8, TERMS, 1, 2, LAYOUT_NHWC, 1>(a, s);      // round 4: channels-last in AND out (feeds the Winograd layers)
         }
         if (layout == LAYOUT_NCHW) return launch_variant<1, 32, NPB2, TERMS, 1, 2, LAYOUT_NCHW>(a, s);
         if (layout == LAYOUT_IN_NHWC) return launch_variant<1, 32, NPB2, TERMS, 1, 2, LAYOUT_IN_NHWC>(a, s);
+        if (layout == LAYOUT_NHWC) return launch_variant<1, 32, NPB2, TERMS, 1, 2, LAYOUT_NHWC>(a, s);
         return COALIGN_ERR_UNSUPPORTED;
     }
     if (layout == LAYOUT_OUT_NHWC) {
@@ -1199,7 +1201,7 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
         return rc != COALIGN_OK ? rc : check_launch();
     }
     if (stride != 1 && stride != 2) return COALIGN_ERR_UNSUPPORTED;
-    if (layout != LAYOUT_NCHW && layout != LAYOUT_OUT_NHWC && layout != LAYOUT_IN_NHWC) return COALIGN_ERR_UNSUPPORTED;
+    if (layout != LAYOUT_NCHW && layout != LAYOUT_OUT_NHWC && layout != LAYOUT_IN_NHWC && !(layout == LAYOUT_NHWC && stride == 2)) return COALIGN_ERR_UNSUPPORTED;
     const int H = (Hin + stride - 1) / stride, W = (Win + stride - 1) / stride;          // 3x3, pad 1: floor((n + 2 - 3) / s) + 1
     int rc = check_emu_args(N, Cin, Cout, Hin, Win, terms);
     if (rc != COALIGN_OK) return rc;

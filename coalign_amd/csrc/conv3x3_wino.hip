@@ -28,6 +28,7 @@
 // LDS: two V buffers of 48 KB ([jj][i][term][channel group][tile] x 16 B), two raw fp32 patches ([4-channel chunk][column parity][row][column / 2] x 16 B:
 // tiles that are neighbours in x read neighbouring 16-byte slots), 150 KB in all; the epilogue reuses it for the cross-wavefront half of the output transform.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 #ifndef WINO_SWAP_COND
@@ -59,7 +60,7 @@ struct WGeo {
     static_assert(TBW == 8 || TBW == 16, "tile blocks of 8 x 8 or 4 x 16 tiles");
     static constexpr int TBH = kTiles / TBW;
     static constexpr int PR = 2 * TBH + 2, PC = 2 * TBW + 2;        // raw patch rows / columns
-    static constexpr int PCH = TBW == 16 ? 20 : 12;                 // column pairs per row, padded to 4 mod 8 (two tile rows = half the banks apart)
+    static constexpr int PCH = TBW == 16 ? 24 : 12;                 // column pairs per row, padded so that the 16 lanes one ds_read_b128 cycle serves ({0-3, 12-15, 20-27}, ...) hit 64 distinct banks: tile rows 256 B (TBW 16) / 128 B (TBW 8) apart mod 256
     static constexpr int RAWQ = 2 * PR * PCH;                       // uint4 per 4-channel chunk plane: [parity][row][column / 2]
     static constexpr int RAWSZ = 4 * RAWQ;                          // uint4 per raw buffer
     static constexpr int NU = PR * PC * 4;                          // 16-byte units of one patch, pixel-major, chunk fastest
@@ -70,20 +71,28 @@ struct WGeo {
     static constexpr size_t LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
 };
 
-// error-free 3-way split of 8 fp32 values: out[t] = term t of each, 8 bf16 = one matrix operand
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// error-free 3-way split of 8 fp32 values: out[t] = term t of each, 8 bf16 = one matrix operand.  Pairs go through v_cvt_pk_bf16_f32; the
+// fp32 value of a term is the packed word shifted / masked (no second conversion).
 __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[3]) {
-    bf16x8 o[3];
+    unsigned o[3][4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const __bf16 h = (__bf16)v[e];
-        const float r = v[e] - (float)h;
-        const __bf16 m = (__bf16)r;
-        o[0][e] = h;
-        o[1][e] = m;
-        o[2][e] = (__bf16)(r - (float)m);
+    for (int e = 0; e < 4; ++e) {
+        float a = v[2 * e], b = v[2 * e + 1];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(floatx2{a, b}, bf16x2));
+            o[t][e] = w;
+            if (t < 2) {
+                a -= __builtin_bit_cast(float, w << 16);              // exact
+                b -= __builtin_bit_cast(float, w & 0xffff0000u);
+            }
+        }
     }
 #pragma unroll
-    for (int t = 0; t < 3; ++t) out[t] = __builtin_bit_cast(uint4, o[t]);
+    for (int t = 0; t < 3; ++t) out[t] = uint4{o[t][0], o[t][1], o[t][2], o[t][3]};
 }
 
 // workgroup barrier that waits for this wavefront's LDS traffic only (the register prefetches of the next half stage stay in flight)
@@ -91,7 +100,8 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int TBW>
+// ABL (lab builds only, -DCOALIGN_LAB): bit 0 = no matrix steps, bit 1 = no transform / split, bit 2 = operands of half stage 0 only (wrong results; what each part costs)
+template <int TBW, int ABL = 0, int MODE = 0>
 __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoArgs a) {
     using G = WGeo<TBW>;
     extern __shared__ __attribute__((aligned(1024))) uint4 lds[];
@@ -107,6 +117,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoArgs a) {
     const int vwr = (wi * 3) * 2 * kTiles + wc * kTiles + lane;                        // + jj * 4 * 3 * 2 * 64 + term * 128: this lane's B-operand slot as a producer
     const int vrd = (wi * 3) * 2 * kTiles + (lane >> 5) * kTiles + (lane & 31);        // + jj * ... + term * 128 + 32 tb: as a consumer
 
+    // Which of the two wavefronts of a SIMD transforms first and which runs its matrix steps first: decided per SIMD (hardware SIMD id + one LDS
+    // counter each), not from the wavefront index -- the dispatcher's wavefront -> SIMD assignment is not w % 4.
+    __shared__ int simd_count[4];
+    if (tid < 4) simd_count[tid] = 0;
+    __syncthreads();
+    int first = 0;
+    if (lane == 0) first = atomicAdd(&simd_count[(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4)) & 3], 1);      // HW_REG_HW_ID bits 5:4 = SIMD_ID
+    first = __builtin_amdgcn_readfirstlane(first) & 1;
     int g = blockIdx.x;
     if (a.xcd) g = coalign::xcd_remap(g, gridDim.x);       // neighbouring units (same tiles, other couts; same couts, next tiles) share an L2
     for (int unit = g; unit < a.units; unit += gridDim.x) {
@@ -114,7 +132,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoArgs a) {
         const int by = blk / a.blocks_x, bx = blk - by * a.blocks_x;
         const int ty0 = by * G::TBH, tx0 = bx * TBW;      // first tile of the block (stacked tile rows)
         // ---- raw patch plan: 16-byte unit e = tid + 512 j: pixel e >> 2 of the patch, chunk e & 3
-        int goff[G::NJ], ldst[G::NJ];
+        int goff[G::NJ];
 #pragma unroll
         for (int j = 0; j < G::NJ; ++j) {
             const int e = tid + 512 * j, pi = e >> 2, q = e & 3;
@@ -123,7 +141,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoArgs a) {
             const int n = s >= 0 ? s / a.pitch : 0, r = s - n * a.pitch;
             const bool ok = e < G::NU && s >= 0 && n < a.N && r < a.H && xg >= 0 && xg < a.W;
             goff[j] = ok ? ((n * a.H + r) * a.W + xg) * a.Cin + 4 * q : -1;
-            ldst[j] = e < G::NU ? ((q * 2 + (pc & 1)) * G::PR + pr) * G::PCH + (pc >> 1) : -1;
         }
         auto load_raw = [&](int k, uint4 (&rv)[G::NJ]) {
 #pragma unroll
@@ -134,12 +151,20 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoArgs a) {
         };
         auto write_raw = [&](int buf, const uint4 (&rv)[G::NJ]) {
             uint4 *rbuf = lds + G::R_OFF + buf * G::RAWSZ;
+            unsigned ones = ~0u;
+            asm volatile("" : "+s"(ones));                 // (opaque: keeps the three lines below inside the K loop)
+            const int t = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));      // = tid, from the scalar wave index and the lane count                    // recomputed here on purpose: hoisted out of the K loop the three slot indices are spilled and
+                                                           // every reload costs an s_waitcnt vmcnt(0), i.e. waits for the operand prefetch
 #pragma unroll
-            for (int j = 0; j < G::NJ; ++j)
-                if (ldst[j] >= 0) rbuf[ldst[j]] = rv[j];
+            for (int j = 0; j < G::NJ; ++j) {
+                const int e = t + 512 * j, pi = e >> 2, q = e & 3;
+                const int pr = pi / G::PC, pc = pi - pr * G::PC;
+                if (e < G::NU) rbuf[((q * 2 + (pc & 1)) * G::PR + pr) * G::PCH + (pc >> 1)] = rv[j];
+            }
         };
         const uint4 *ubase = a.u + ((size_t)cg * K * 2 * 8 + wave) * (2 * 3 * 64) + lane;        // + (k * 2 + h) * 8 * 384 + (jj * 3 + term) * 64
         auto load_a = [&](int k, int h, uint4 (&av)[2][3]) {
+            if (ABL & 4) k = 0;                            // (lab) every half stage re-reads the first one: L1-resident operands
             const uint4 *p = ubase + (size_t)(k * 2 + h) * (8 * 2 * 3 * 64);
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
@@ -149,6 +174,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoArgs a) {
         // producer: half stage (k, h) -> V buffer vb, from raw buffer rbi
         auto produce = [&](auto hc, int rbi, int vb) {
             constexpr int h = decltype(hc)::value;
+            if (ABL & 2) return;
             const uint4 *rbuf = lds + G::R_OFF + rbi * G::RAWSZ + praw;
             float v0[8], v1[8];
 #pragma unroll
@@ -191,28 +217,41 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoArgs a) {
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) acc[p][tb] = floatx16{0};
-        // a 32-tile half of the block that lies wholly below the stacked image runs no matrix steps
-        const bool live0 = 2 * ty0 < a.N * a.pitch, live1 = 2 * (ty0 + G::TBH / 2) < a.N * a.pitch;
         auto consume = [&](auto hc, int vb, const uint4 (&av)[2][3]) {
             constexpr int h = decltype(hc)::value;
+            if (ABL & 1) return;
             const uint4 *vbuf = lds + G::V_OFF + vb * kVBuf + vrd;
             constexpr int wt[6] = {0, 1, 2, 0, 1, 0}, bt[6] = {2, 1, 0, 1, 0, 0};      // smallest products first
+            // (tiles below the stacked image are computed like the others and never stored: a liveness branch around the matrix steps makes hipcc
+            //  copy the accumulators into temporaries and back -- 64 v_mov_b64 per half stage)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+            for (int jj = 0; jj < 2; ++jj) {
+                uint4 b[2][3];
 #pragma unroll
-                for (int tb = 0; tb < 2; ++tb) {
-                    if (tb == 0 ? !live0 : !live1) continue;
-                    uint4 b[3];
+                for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) b[t] = vbuf[jj * 4 * 3 * 2 * kTiles + t * 2 * kTiles + 32 * tb];
+                    for (int tb = 0; tb < 2; ++tb) b[tb][t] = vbuf[jj * 4 * 3 * 2 * kTiles + t * 2 * kTiles + 32 * tb];
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        floatx16 &d = acc[2 * h + jj][tb];
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[jj][wt[i]]), __builtin_bit_cast(bf16x8, b[bt[i]]), d, 0, 0, 0);
-                    }
-                }
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb)         // two independent accumulator chains
+                        acc[2 * h + jj][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[jj][wt[i]]), __builtin_bit_cast(bf16x8, b[tb][bt[i]]),
+                                                                                      acc[2 * h + jj][tb], 0, 0, 0);
+            }
         };
 
+        // MODE 2: the interleave spelled out for the scheduler -- per matrix instruction one LDS read and five VALU instructions, an LDS write every fourth
+        auto interleave = [&]() {
+            if constexpr (MODE == 2) {
+#pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);      // VALU
+                    if (i % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+                }
+            }
+        };
         constexpr std::integral_constant<int, 0> H0{};
         constexpr std::integral_constant<int, 1> H1{};
         // ---- prologue
@@ -228,18 +267,30 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoArgs a) {
             lds_barrier();                                 // V(k, 0) complete; V buffer 1 and raw buffer (k + 1) & 1 free
             load_a(k, 1, a1);
             if (k + 1 < K) write_raw((k + 1) & 1, rawv);
+            if constexpr (MODE == 0) {
 #pragma nounroll
-            for (int sub = 0; sub < 2; ++sub) {            // wavefronts w and w + 4 share a SIMD: one transforms while the other runs its matrix steps
-                if (sub == wc) consume(H0, 0, a0);
-                else produce(H1, k & 1, 1);
+                for (int sub = 0; sub < 2; ++sub) {        // the two wavefronts of a SIMD: one transforms while the other runs its matrix steps
+                    if (sub == first) consume(H0, 0, a0);
+                    else produce(H1, k & 1, 1);
+                }
+            } else {                                       // one basic block: the matrix steps and the transform interleaved inside every wavefront
+                consume(H0, 0, a0);
+                produce(H1, k & 1, 1);
+                interleave();
             }
             lds_barrier();                                 // V(k, 1) and raw(k + 1) complete; V buffer 0 free
             if (k + 1 < K) load_a(k + 1, 0, a0);
             if (k + 2 < K) load_raw(k + 2, rawv);
+            if constexpr (MODE == 0) {
 #pragma nounroll
-            for (int sub = 0; sub < 2; ++sub) {
-                if (sub == wc) consume(H1, 1, a1);
-                else if (k + 1 < K) produce(H0, (k + 1) & 1, 0);
+                for (int sub = 0; sub < 2; ++sub) {
+                    if (sub == first) consume(H1, 1, a1);
+                    else if (k + 1 < K) produce(H0, (k + 1) & 1, 0);
+                }
+            } else {
+                consume(H1, 1, a1);
+                produce(H0, (k + 1) & 1, 0);               // (after the last step: transforms a stale patch into a buffer nobody reads)
+                interleave();
             }
         }
         // ---- epilogue.  Output transform, column half inside the wavefront: Z[i][0] = M[i][0] + M[i][1] + M[i][2], Z[i][1] = M[i][1] - M[i][2] - M[i][3]
@@ -299,12 +350,12 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoArgs a) {
     }
 }
 
-template <int TBW>
+template <int TBW, int ABL = 0, int MODE = 0>
 int launch_wino(const WinoArgs &a0, hipStream_t s) {
     using G = WGeo<TBW>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
     static int cus = 0;
-    auto kern = conv3x3_wino_kernel<TBW>;
+    auto kern = conv3x3_wino_kernel<TBW, ABL, MODE>;
     if (!cus) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -355,6 +406,23 @@ extern "C" int coalign_conv3x3_wino(const float *x, const void *u_split, const f
         tbw = waste8 < waste16 ? 8 : 16;
     }
     int rc;
+#ifdef COALIGN_LAB
+    static const int mode = getenv("COALIGN_WINO_MODE") ? atoi(getenv("COALIGN_WINO_MODE")) : 0;
+    if (mode == 1 && tbw == 16) { rc = launch_wino<16, 0, 1>(a, s); return rc != COALIGN_OK ? rc : check_launch(); }
+    if (mode == 2 && tbw == 16) { rc = launch_wino<16, 0, 2>(a, s); return rc != COALIGN_OK ? rc : check_launch(); }
+    static const int abl = getenv("COALIGN_WINO_ABL") ? atoi(getenv("COALIGN_WINO_ABL")) : 0;
+    if (abl) {
+        switch (abl * 100 + tbw) {
+            case 116: rc = launch_wino<16, 1>(a, s); break;
+            case 216: rc = launch_wino<16, 2>(a, s); break;
+            case 316: rc = launch_wino<16, 3>(a, s); break;
+            case 416: rc = launch_wino<16, 4>(a, s); break;
+            case 716: rc = launch_wino<16, 7>(a, s); break;
+            default: return COALIGN_ERR_UNSUPPORTED;
+        }
+        return rc != COALIGN_OK ? rc : check_launch();
+    }
+#endif
     if (tbw == 16) rc = launch_wino<16>(a, s);
     else if (tbw == 8) rc = launch_wino<8>(a, s);
     else return COALIGN_ERR_UNSUPPORTED;

@@ -28,6 +28,7 @@ struct PwArgs {
     int N, Cin, Hin, Win, in_stride, Hp, Wp, M, up, Cout, Ctot, c_off, relu;
     int in_nhwc;          // x is [N, Hin, Win, Cin] (channels-last: the fused maps / stage outputs of the NHWC route)
     int pb;               // pixel blocks of 32 per workgroup: 1, 2 or 4 (see the kernel)
+    int out_nhwc;         // y is [N, Hp, Wp, Ctot] (up = 1 only): the skip convolution feeding a channels-last residual add
 };
 
 // Epilogue shared by both kernels: accumulator r of lane l is GEMM row 8 * (r / 4) + 4 * (l / 32) + r % 4 of its 32-row tile, pixel l % 32
@@ -64,6 +65,21 @@ __device__ __forceinline__ void pw_store(const PwArgs &a, int n, int m0, bool se
                     o.x = v[ky * 2] + bb; o.y = v[ky * 2 + 1] + bb;
                     if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); }
                     *reinterpret_cast<float2 *>(yout + (size_t)co * out_plane + (size_t)(hp * 2 + ky) * Wo + wp * 2) = o;
+                }
+            } else if (a.out_nhwc) {       // channels-last output: four consecutive channels of one pixel = one 16-byte store
+                if (m + 3 < a.Cout) {
+                    const float4 bb = *reinterpret_cast<const float4 *>(a.bias + m);
+                    float4 o;
+                    o.x = v[0] + bb.x; o.y = v[1] + bb.y; o.z = v[2] + bb.z; o.w = v[3] + bb.w;
+                    if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    *reinterpret_cast<float4 *>(a.y + ((size_t)n * pixels + px) * a.Ctot + a.c_off + m) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (m + j < a.Cout) {
+                            const float o = v[j] + a.bias[m + j];
+                            a.y[((size_t)n * pixels + px) * a.Ctot + a.c_off + m + j] = a.relu ? fmaxf(o, 0.f) : o;
+                        }
                 }
             } else {                       // four consecutive output channels
 #pragma unroll
@@ -246,13 +262,17 @@ static int pointwise_impl(const float *x, const float *w, const float *bias, flo
     if (!x || !w || !bias || !y) return COALIGN_ERR_NULL_POINTER;
     if (emu && ((Cin & 15) || (reinterpret_cast<uintptr_t>(w) & 15))) return COALIGN_ERR_UNSUPPORTED;
     if (N < 0 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1 || Ctot < Cout || c_off < 0 || c_off + Cout > Ctot) return COALIGN_ERR_BAD_SHAPE;
-    if (in_nhwc && ((Cin & 3) || (reinterpret_cast<uintptr_t>(x) & 15))) return COALIGN_ERR_UNSUPPORTED;
+    if ((in_nhwc & 1) && ((Cin & 3) || (reinterpret_cast<uintptr_t>(x) & 15))) return COALIGN_ERR_UNSUPPORTED;
     if (Cin > kMaxCin || (Cin & 1) || (up != 1 && up != 2 && up != 4) || (in_stride != 1 && in_stride != 2) || (up != 1 && in_stride != 1))
         return COALIGN_ERR_UNSUPPORTED;
     const int M = Cout * up * up;
     if (M_padded < M || M_padded % 32 || (up != 1 && M_padded != M)) return COALIGN_ERR_BAD_SHAPE;
     if (N == 0) return COALIGN_OK;
-    PwArgs a{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu, in_nhwc != 0, 1};
+    // in_nhwc: bit 0 = channels-last input, bit 1 = channels-last output (up = 1; Ctot, c_off multiples of 4, 16-byte aligned y and bias)
+    const int out_nhwc = (in_nhwc >> 1) & 1;
+    in_nhwc &= 1;
+    if (out_nhwc && (up != 1 || (Ctot & 3) || (c_off & 3) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias)) & 15))) return COALIGN_ERR_UNSUPPORTED;
+    PwArgs a{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu, in_nhwc != 0, 1, out_nhwc};
     if (N > 65535) return COALIGN_ERR_UNSUPPORTED;
     const int pixels = a.Hp * a.Wp;
     static const int pb_max = getenv("COALIGN_PW_PB") ? atoi(getenv("COALIGN_PW_PB")) : 4;      // experiments: 1 = the round-1 mapping

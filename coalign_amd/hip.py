@@ -85,10 +85,11 @@ def lib() -> ctypes.CDLL:
     if _LIB is not None:
         return _LIB
     import torch  # noqa: F401  -- load PyTorch-ROCm's HIP runtime first so both share one libamdhip64.so.7
-    path = _build.LIB_PATH
+    lab = os.environ.get("COALIGN_LAB", "0") == "1"      # tools/ only: the laboratory build with its ablation switches (build.py)
+    path = _build.LAB_LIB_PATH if lab else _build.LIB_PATH
     if not os.path.exists(path):
         try:
-            _build.build()
+            _build.build(lab=lab)
         except Exception as exc:  # noqa: BLE001
             raise CoalignHipError(
                 f"{path} is missing and could not be built ({exc}); the CoAlign hot path has no CPU fallback") from exc

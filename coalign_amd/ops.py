@@ -592,11 +592,11 @@ def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Ten
         if stride != 1 or w_split.numel() != L.coalign_conv3x3_emu_weight_bytes_ex(Cin, cout, terms, 1):
             raise ValueError("split weight image does not match (Cin, Cout, terms)")
         tapk = LAYOUT_W_TAPMAJOR
-    if stride not in (1, 2) or (stride == 2 and (residual is not None or out_channels_last)):
-        raise ValueError("stride 2 takes no residual and writes NCHW")
+    if stride not in (1, 2) or (stride == 2 and (residual is not None or (out_channels_last and layout != LAYOUT_IN_NHWC))):
+        raise ValueError("stride 2 takes no residual and writes NCHW (channels-last only from a channels-last input)")
     Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
     if out_channels_last:
-        layout = LAYOUT_OUT_NHWC
+        layout |= LAYOUT_OUT_NHWC
         y = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=xc.device, memory_format=torch.channels_last)
     else:
         y = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=xc.device)
@@ -705,7 +705,7 @@ def pack_pointwise_emu_weight(w_packed: torch.Tensor) -> torch.Tensor:
 
 @_device_op
 def pointwise_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, up: int = 1, in_stride: int = 1, relu: bool = True,
-                   out: Optional[torch.Tensor] = None, c_off: int = 0) -> torch.Tensor:
+                   out: Optional[torch.Tensor] = None, c_off: int = 0, out_channels_last: bool = False) -> torch.Tensor:
     """One-launch pointwise layer (include/coalign_amd.h (10)): ``up`` > 1 = non-overlapping transposed convolution, ``in_stride`` 2 =
     1x1 stride-2 convolution.  ``out`` [N, Ctot, H', W'] + ``c_off`` select a channel slice of a larger (concatenated) tensor.
     ``w_packed``: [Cin, M] float32 (fp32 matrix cores) or the int16 image of ``pack_pointwise_emu_weight`` (split-bf16 matrix cores)."""
@@ -716,19 +716,24 @@ def pointwise_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
     xc = x if nhwc else _f32c(x)
     N, Cin, Hin, Win = xc.shape
     Ho, Wo = (Hin + in_stride - 1) // in_stride * up, (Win + in_stride - 1) // in_stride * up
-    if out is None:
+    if out_channels_last:                                  # (up = 1) a fresh [N, cout, Ho, Wo] tensor in channels-last memory
+        if out is not None or up != 1 or cout % 4:
+            raise ValueError("channels-last output: up = 1, Cout % 4 == 0, no output slice")
+        out = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=xc.device, memory_format=torch.channels_last)
+    elif out is None:
         out = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=xc.device)
-    if tuple(out.shape[2:]) != (Ho, Wo) or out.shape[0] != N or not out.is_contiguous() or out.dtype != torch.float32:
+    if tuple(out.shape[2:]) != (Ho, Wo) or out.shape[0] != N or not (nhwc_memory(out) if out_channels_last else out.is_contiguous()) or out.dtype != torch.float32:
         raise ValueError("output buffer shape / layout mismatch")
+    nhwc_flags = int(nhwc) | (2 if out_channels_last else 0)
     with _Timed("pointwise_conv"):
         if emu:
             if w_packed.dim() != 5 or w_packed.shape[1] * 16 != Cin or not w_packed.is_contiguous():
                 raise ValueError("split weight image does not match Cin")
             hip.check(L.coalign_pointwise_conv_emu(_ptr(xc), _ptr(w_packed), _ptr(_f32c(bias)), _ptr(out), N, Cin, Hin, Win, in_stride, cout, up,
-                                                   w_packed.shape[0] * 32, out.shape[1], c_off, int(relu), int(nhwc), _stream()), "coalign_pointwise_conv_emu")
+                                                   w_packed.shape[0] * 32, out.shape[1], c_off, int(relu), nhwc_flags, _stream()), "coalign_pointwise_conv_emu")
         else:
             hip.check(L.coalign_pointwise_conv_ex(_ptr(xc), _ptr(w_packed), _ptr(_f32c(bias)), _ptr(out), N, Cin, Hin, Win, in_stride, cout, up,
-                                                  w_packed.shape[1], out.shape[1], c_off, int(relu), int(nhwc), _stream()), "coalign_pointwise_conv")
+                                                  w_packed.shape[1], out.shape[1], c_off, int(relu), nhwc_flags, _stream()), "coalign_pointwise_conv")
     return out
 
 

@@ -342,6 +342,8 @@ int coalign_conv3x3_emu_bias_act(const float *x, const void *w_split, const floa
  * NCHW out (stride 2 only).  residual (stride 1) is always NCHW.  workspace as coalign_conv3x3_emu_workspace_bytes for
  * (stride 1, layout 0); the other variants need none. */
 enum { COALIGN_LAYOUT_NCHW = 0, COALIGN_LAYOUT_OUT_NHWC = 1, COALIGN_LAYOUT_IN_NHWC = 2, COALIGN_LAYOUT_W_TAPMAJOR = 4 };
+/* Round 4: layout 3 (= IN_NHWC | OUT_NHWC) with stride 2: channels-last in AND out -- the strided first convolution of a ResNet stage in front of
+ * the Winograd layers (9c), which read and write channels-last. */
 /* COALIGN_LAYOUT_W_TAPMAJOR (flag, or-ed into layout 0 or 1, stride 1, Cin % 16 == 0): w_split is the TAP-MAJOR image
  *   [Cout / 64][Cin / 16][9 taps][terms][2 channel halves][64 cout][8 cin] bf16 (+ 16 zero bytes),
  * coalign_conv3x3_emu_weight_bytes_ex(Cin, Cout, terms, 1) bytes: one matrix instruction = the 16 channels of one tap, nine per 16
@@ -380,7 +382,8 @@ int coalign_conv3x3_wino(const float *x, const void *u_split, const float *bias,
  */
 int coalign_pointwise_conv(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
                            int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, void *stream);
-/* in_nhwc != 0: x is channels-last, [N, Hin, Win, Cin] (Cin % 4 == 0, 16-byte aligned); the output stays NCHW. */
+/* in_nhwc bit 0: x is channels-last, [N, Hin, Win, Cin] (Cin % 4 == 0, 16-byte aligned).  in_nhwc bit 1 (round 4, up = 1 only): y is channels-last,
+ * [N, Hp, Wp, Ctot] (Ctot % 4 == 0, c_off % 4 == 0, y and bias 16-byte aligned) -- the skip convolution whose result is the residual of a Winograd layer. */
 int coalign_pointwise_conv_ex(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win, int in_stride,
                               int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, void *stream);
 /* The same layers on the bf16 matrix cores by error-free 3-way operand splitting (fp32-width products, fp32 accumulation; the arithmetic of

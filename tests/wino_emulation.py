@@ -19,7 +19,7 @@ def emulate(x_nhwc: np.ndarray, u_img: torch.Tensor, bias: np.ndarray, residual,
     K, groups = Cin // 16, Cout // 64
     TBH = 64 // tbw
     PR, PC = 2 * TBH + 2, 2 * tbw + 2
-    PCH = 20 if tbw == 16 else 12
+    PCH = 24 if tbw == 16 else 12
     pitch = H + (1 if H % 2 else 2)
     tile_rows, tile_cols = N * pitch // 2, (W + 1) // 2
     blocks_x = (tile_cols + tbw - 1) // tbw
