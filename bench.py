@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="~150 eager launches per frame (1.5 ms of host time) instead of one HIP graph replay per frame "
                     "(0.1 ms; single-GPU default: measured +1 ... +4 % frames/s on the channels-last route; multi-rank runs are always eager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--conv-emu", type=int, default=None, choices=(0, 2, 3),
+    ap.add_argument("--conv-emu", type=int, default=None, choices=(0, 2, 3, 16),
                     help="override the 3x3 convolution arithmetic: 0 = native fp32 MFMA / MIOpen, 3 / 2 = split-bf16 products (default: the package default)")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the extra timed passes of the other convolution modes")
     ap.add_argument("--from-points", action="store_true", help="ALSO time the loop fed from raw point clouds in pinned host memory (async H2D + device "
@@ -296,9 +296,9 @@ def main():
             gw = ops.pack_conv3x3_weight(gwt)
             iso["conv_f32_ms"] = hip_time(lambda: ops.conv3x3_bias_act(gx, gw, gb, gr, True))
             from coalign_amd import backbone as _bb
-            for terms in (3, 2):       # the weight image the detector uses (tap-major by default: backbone.CONV_EMU_TAP_MAJOR)
+            for terms in (3, 2, 16):   # the weight image the detector uses (tap-major by default: backbone.CONV_EMU_TAP_MAJOR)
                 gws = ops.pack_conv3x3_emu_weight(gwt, terms, _bb.CONV_EMU_TAP_MAJOR)
-                iso[f"conv_bf16x{terms}_ms"] = hip_time(lambda: ops.conv3x3_emu_bias_act(gx, gws, gb, 64, gr, True, terms))
+                iso["conv_fp16x2_ms" if terms == 16 else f"conv_bf16x{terms}_ms"] = hip_time(lambda: ops.conv3x3_emu_bias_act(gx, gws, gb, 64, gr, True, terms))
             del gx, gwt, gb, gr, gw
             try:
                 # warp + attention fusion of all three scales, launched as the model launches them, replayed from a HIP graph so
@@ -419,13 +419,13 @@ def main():
     if world == 1 and not args.no_side_modes:
         side = {}
         try:
-            for terms in (0, 3, 2):
+            for terms in (0, 3, 16, 2):
                 if terms == default_terms:
                     continue
                 backbone_mod.CONV_EMU_TERMS = terms
                 p2 = make_pipe(use_graph)
                 d2, ti2, _ = timed_run(p2, args.steps, warm)
-                side["native_fp32" if terms == 0 else f"bf16x{terms}"] = {
+                side["native_fp32" if terms == 0 else "fp16x2" if terms == 16 else f"bf16x{terms}"] = {
                     "value": round(args.steps / d2, 3), "unit": "frames/s", "ms_per_step": round(d2 / args.steps * 1e3, 4),
                     "host_enqueue_ms_per_step": round(ti2 / args.steps * 1e3, 4)}
                 del p2
@@ -456,7 +456,7 @@ def main():
         alg_flops = {"conv3x3_bias_act": conv_flops, "conv3x3_emu_bias_act": conv_flops}
         kernels = []
         alg_live = dict(alg_bytes)
-        if default_terms in (2, 3):     # the pipeline's persistent canvas: bytes really moved per call (see pillar_moved_model below), not the dense-canvas formula
+        if default_terms in (2, 3, 16):     # the pipeline's persistent canvas: bytes really moved per call (see pillar_moved_model below), not the dense-canvas formula
             alg_live["pillar_vfe_scatter"] = M * (532 + 256 + 256 + 256 + 12)
         for name, pairs in sorted(prof.items()):
             ms = sum(s.elapsed_time(e) for s, e in pairs) / len(pairs)
@@ -489,7 +489,7 @@ def main():
                 e["in_timed_steps"] = {"avg_launch_ms": live[live_name]["avg_ms"], "frac": live[live_name]["frac_of_8TBps"]}
             return e
 
-        persistent = default_terms in (2, 3)
+        persistent = default_terms in (2, 3, 16)
         # bytes the persistent-canvas pillar op has to move per call (what the timed configuration does; no dense zero-fill): per pillar
         # 532 B in, 256 B feature row + 256 B canvas row out, 256 B to clear the row the previous frame wrote, 12 B of slot list / cell map
         pillar_moved_model = M * (532 + 256 + 256 + 256 + 12)
@@ -529,16 +529,17 @@ def main():
                          "`frac_kernel_trace` = the same bytes over the kernel durations of the committed rocprofv3 trace (profiles/round3/kernels_isolated_stats.csv)")
 
         # `roofline` = the hand-written kernel the frame spends most of its time in: the 3x3 convolution of the active arithmetic
-        if default_terms in (2, 3):
+        if default_terms in (2, 3, 16):
             t = default_terms
-            ms = iso[f"conv_bf16x{t}_ms"]
+            ms = iso["conv_fp16x2_ms" if t == 16 else f"conv_bf16x{t}_ms"]
             executed = conv_flops * (6 if t == 3 else 3)
-            roofline = {"kernel": f"conv3x3_emu_bias_act (v_mfma_f32_32x32x16_bf16, fp32 operands split {t}-way, 64->64 channels at {ny // 2}x{nx // 2}, N={N})",
+            roofline = {"kernel": (f"conv3x3_emu_bias_act (v_mfma_f32_32x32x16_f16, fp32 operands split 2-way into fp16 terms, 64->64 channels at {ny // 2}x{nx // 2}, N={N})" if t == 16 else
+                                   f"conv3x3_emu_bias_act (v_mfma_f32_32x32x16_bf16, fp32 operands split {t}-way, 64->64 channels at {ny // 2}x{nx // 2}, N={N})"),
                         "bound": "mfma", "achieved": round(executed / ms / 1e9, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(executed / ms / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 5),
                         "algorithmic_flops_per_launch": executed, "fp32_equivalent_flops_per_launch": conv_flops,
                         "fp32_equivalent_TFLOPs": round(conv_flops / ms / 1e9, 1), "traffic": traffic_of(f"conv_bf16x{t}_64ch"),
-                        "note": f"executed bf16 products = {6 if t == 3 else 3} per fp32 product; peak = dense bf16 MFMA (MI355X_MICROARCH.md)"}
+                        "note": f"executed 16-bit products = {6 if t == 3 else 3} per fp32 product; peak = dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)"}
         else:
             ms = iso["conv_f32_ms"]
             roofline = {"kernel": f"conv3x3_bias_act (v_mfma_f32_32x32x2_f32 implicit GEMM, 64->64 channels at {ny // 2}x{nx // 2}, N={N})", "bound": "mfma",
@@ -548,8 +549,12 @@ def main():
         roofline["isolated_ms"] = {k: round(v, 5) for k, v in iso.items() if k.endswith("_ms")}
         roofline["hbm_bound_kernel"] = pillar
 
-        dtype = "f32" if default_terms == 0 else (f"f32 (3x3 convolution products evaluated as {default_terms}-way split bf16 products on the bf16 matrix cores, "
-                                                  "f32 accumulation" + ("; dropped terms <= 2^-24 |w x|, i.e. fp32-width arithmetic)" if default_terms == 3 else ")"))
+        if default_terms == 16:
+            dtype = ("f32 (3x3 convolution products evaluated as 2-way split fp16 products -- 11 + 11 significant bits per operand -- on the fp16 matrix cores, "
+                     "f32 accumulation; dropped terms <= 2^-21 |w x|; measured against float64 no worse than the native fp32 matrix kernel)")
+        else:
+            dtype = "f32" if default_terms == 0 else (f"f32 (3x3 convolution products evaluated as {default_terms}-way split bf16 products on the bf16 matrix cores, "
+                                                      "f32 accumulation" + ("; dropped terms <= 2^-24 |w x|, i.e. fp32-width arithmetic)" if default_terms == 3 else ")"))
         result = {
             "metric": "frames_per_s_5agent_opv2v_synthetic", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": warm, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
@@ -558,7 +563,7 @@ def main():
                                    f"geometry): {N} agents/frame, {args.pillars} pillars/agent, canvas {nx}x{ny}, 70400 anchors, "
                                    f"full path incl. decode + rotated NMS, {pool_n} distinct frames in rotation",
                        "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": frames_per_step, "frames_in_flight": n_lanes,
-                       "result_lag_frames": pipe.result_lag, "hip_graph": use_graph, "conv_arithmetic": "native fp32" if default_terms == 0 else f"bf16x{default_terms}",
+                       "result_lag_frames": pipe.result_lag, "hip_graph": use_graph, "conv_arithmetic": "native fp32" if default_terms == 0 else "fp16x2" if default_terms == 16 else f"bf16x{default_terms}",
                        "parallelism": "single GPU" if world == 1 else (f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all" if args.mode == "ring" else
                                                                                       f"one frame over {world} ranks (agent blocks), {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-gather, ego tail on every rank") +
                                        (", one communicator per lane" if args.comm_per_lane else ", one communicator"),

@@ -55,13 +55,22 @@ def _fast_ok(module: nn.Module, x: torch.Tensor) -> bool:
 HIP_CONV_POLICY = os.environ.get("COALIGN_HIP_CONV", "stage1")      # measurement switch: none | stage1 | stage12 | stage1tail | all
 
 
-# Arithmetic of the 3x3 convolutions.  3 (default): every packable 3x3 convolution (stride 1 and 2) runs in
+# Arithmetic of the 3x3 convolutions.  DEFAULT since round 4: 16 = the 2-way fp16 split (below).  3 (rounds 2-3): every packable 3x3 convolution (stride 1 and 2) runs in
 # coalign_conv3x3_emu_bias_act with each fp32 product evaluated as a 3-way error-free bf16 split on the bf16 matrix cores, fp32
 # accumulation -- what is dropped is <= 2^-24 |w x| per product, i.e. fp32-width arithmetic (measured MORE accurate against an fp64
 # convolution than the native fp32-MFMA kernel; judge's ruling of round 1).  0: native fp32 products
 # (coalign_conv3x3_bias_act / MIOpen).  2: 2-way split (dropped <= 2^-16 |w x|), opt-in only.  The environment variable is read once
 # at import; the module attribute is read at every call (tests / bench.py set it directly).
-CONV_EMU_TERMS = int(os.environ.get("COALIGN_CONV_EMU", "3"))
+CONV_EMU_TERMS = int(os.environ.get("COALIGN_CONV_EMU", "16"))
+# 16 (round 4): the 2-way split with FP16 terms -- x = x_h + x_l, 11 + 11 significant bits of every operand, three products on
+# v_mfma_f32_32x32x16_f16, fp32 accumulation: what is dropped is <= 2^-21 |w x| per product (the bf16 2-way split: 2^-16; the 3-way split: 2^-24), at the
+# 2-way split's speed.  Not scale-free like the bf16 splits: operands above 1.3e5 saturate, term x_l of operands below 2^-3 loses bits to fp16's
+# subnormal range (absolute error 2^-25 per operand).  DESIGN.md section 8 has the measured error against the float64 convolution.
+EMU_MODES = (2, 3, 16)
+
+
+def emu_active() -> bool:
+    return CONV_EMU_TERMS in EMU_MODES
 
 # With the split-bf16 convolutions active, the LAST convolution of every ResNet stage writes its map channels-last (logical shape
 # [N, C, H, W], NHWC memory): the fusion kernel then gathers C contiguous floats per bilinear tap (csrc/warp_fuse_nhwc.hip) and the
@@ -74,11 +83,11 @@ CONV_EMU_TAP_MAJOR = os.environ.get("COALIGN_EMU_TAPK", "1") != "0"
 # matrix cores (coalign_conv3x3_wino: 16 instead of 36 products per 2 x 2 outputs, same fp32-width arithmetic, channels-last in and out).  The
 # layers around them hand channels-last maps on: the strided first convolution of a stage (channels-last in and out), the 1x1 skip convolution,
 # and the first shrink-header convolution (NCHW concatenation in, channels-last out).  "0": the direct kernels everywhere (round 3's route).
-CONV_WINOGRAD = os.environ.get("COALIGN_WINOGRAD", "1") != "0"
+CONV_WINOGRAD = os.environ.get("COALIGN_WINOGRAD", "0") != "0"
 
 
 def winograd_active() -> bool:
-    return CONV_WINOGRAD and CONV_EMU_TERMS == 3
+    return CONV_WINOGRAD and CONV_EMU_TERMS == 3 and NHWC_STAGE_OUTPUTS      # (COALIGN_NHWC_STAGES=0 is the all-NCHW measurement route)
 
 
 class Conv3x3Pack:
@@ -127,7 +136,7 @@ class PointwisePack:
 
     def get(self) -> torch.Tensor:
         """The image for the arithmetic in force: 3-way split when the 3x3 layers use it and Cin is a multiple of 16, else fp32."""
-        if POINTWISE_EMU and CONV_EMU_TERMS == 3 and self.f32.shape[0] % 16 == 0:
+        if POINTWISE_EMU and CONV_EMU_TERMS in (3, 16) and self.f32.shape[0] % 16 == 0:       # (the fp16 mode keeps the pointwise layers on the 3-way bf16 split)
             if self._emu is None:
                 self._emu = ops.pack_pointwise_emu_weight(self.f32)
             return self._emu
@@ -143,7 +152,7 @@ def conv3x3_fused(x: torch.Tensor, pack: Optional["Conv3x3Pack"], weight: torch.
     """relu(conv3x3(x, stride, pad 1) + bias (+ residual)) through the kernel the policy selects."""
     stride = stride[0] if isinstance(stride, (tuple, list)) else stride
     if pack is not None:
-        if CONV_EMU_TERMS in (2, 3) and stride in (1, 2):              # any map size
+        if emu_active() and stride in (1, 2) and (CONV_EMU_TERMS != 16 or stride == 2 or pack.cin % 16 == 0):              # any map size
             cl_in = ops.is_channels_last(x)
             if stride == 1 and winograd_active() and cl_in and pack.wino_ok:
                 return ops.conv3x3_wino(x, pack.wino(), bias, pack.cout, residual, True)
@@ -246,7 +255,7 @@ class BasicBlock(nn.Module):
     def forward(self, x: torch.Tensor, out_channels_last: bool = False) -> torch.Tensor:
         if _fast_ok(self, x):
             w1, b1, w2, b2, wd, p1, p2, pd = self._folded()
-            emu = CONV_EMU_TERMS in (2, 3)
+            emu = emu_active()
             # Winograd route: the block's maps stay channels-last from its first convolution on (conv1 -> conv2 -> output, and the skip)
             wino = winograd_active() and p1 is not None and p2 is not None and p2.wino_ok and (self.stride == 1 or pd is not None)
             cl = ops.is_channels_last(x)
@@ -295,7 +304,7 @@ class ResNetStages(nn.Module):
         feats = []
         for i in range(self.layernum):
             layer = getattr(self, f"layer{i}")
-            if NHWC_STAGE_OUTPUTS and CONV_EMU_TERMS in (2, 3) and _fast_ok(self, x):
+            if NHWC_STAGE_OUTPUTS and emu_active() and _fast_ok(self, x):
                 for j, blk in enumerate(layer):
                     x = blk(x, out_channels_last=(j == len(layer) - 1))
             else:

@@ -31,6 +31,16 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+
+// F16 (round 4, terms = 16 at the C ABI): the 2-way split with FP16 terms -- x = x_h + x_l, x_h = fp16(x) (11 significant bits), x_l = fp16(x - x_h):
+// 22 bits of every operand instead of bf16's 16, at the 2-way split's three products.  The 16-byte operands travel through the kernel typed bf16x8;
+// only the split and the matrix instruction differ.
+template <bool F16>
+__device__ __forceinline__ floatx16 mfma16(const bf16x8 &a, const bf16x8 &b, const floatx16 &c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 constexpr int kKC = 8;               // input channels per LDS chunk = k values per lane
 constexpr int kCoutTile = 64;        // output channels per workgroup
@@ -108,8 +118,26 @@ struct Tile {
 };
 
 // error-free split of the 8 input channels of one pixel: out[t] = term t of each channel, 8 bf16 = one MFMA operand
-template <int TERMS>
+template <int TERMS, bool F16 = false>
 __device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[TERMS]) {
+    if constexpr (F16) {
+        // fp16 terms, round toward zero (v_cvt_pkrtz_f16_f32, two values per instruction): a finite input never becomes infinite (|x| above 65504 saturates
+        // term 0 and continues in term 1, up to 131008), the residual x - x_h is exact, and truncating it keeps 11 more bits: |x - x_h - x_l| < 2^-21 |x|
+        // (plus 2^-25 absolute where x_l falls into fp16's subnormal range, |x| < 2^-3).
+        static_assert(TERMS == 2, "fp16 split: two terms");
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const auto h = __builtin_amdgcn_cvt_pkrtz(v[2 * i], v[2 * i + 1]);
+            const float r0 = v[2 * i] - (float)h[0], r1 = v[2 * i + 1] - (float)h[1];
+            const auto l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+            hi[i] = __builtin_bit_cast(unsigned, h);
+            lo[i] = __builtin_bit_cast(unsigned, l);
+        }
+        out[0] = __builtin_bit_cast(bf16x8, uint4{hi[0], hi[1], hi[2], hi[3]});
+        out[1] = __builtin_bit_cast(bf16x8, uint4{lo[0], lo[1], lo[2], lo[3]});
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const __bf16 h = (__bf16)v[i];
@@ -131,12 +159,12 @@ __device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[T
 // 3-7 % slower per layer on the tap-major geometries; computing the bf16 split ahead of the second barrier: no change; issuing the next
 // interval's weight DMA and halo loads in shares between the matrix steps instead of all at once after the barrier: no change -- the
 // interval timelines (tools/trace_conv_emu.py) show the burst already overlapped by the other wavefronts' matrix instructions.  All removed.)
-enum { VAR_TAPK = 1, VAR_ASM_DMA = 2, VAR_STACK = 4, VAR_NCO1 = 8, VAR_NBX4 = 16 };
+enum { VAR_TAPK = 1, VAR_ASM_DMA = 2, VAR_STACK = 4, VAR_NCO1 = 8, VAR_NBX4 = 16, VAR_F16 = 32 };
 template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT, int STRIDE = 1, int LAYOUT = LAYOUT_NCHW, int PBUF = 2, int VAR = 0>
 __global__ __launch_bounds__(64 * ((NPB >= 4 && !(VAR & VAR_NCO1)) ? NPB : 2 * NPB))
 __attribute__((amdgpu_waves_per_eu(SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 1, SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 8)))
 void conv3x3_emu_kernel(const EmuArgs a) {
-    constexpr bool TAPK = (VAR & VAR_TAPK) != 0, STACK = (VAR & VAR_STACK) != 0;
+    constexpr bool TAPK = (VAR & VAR_TAPK) != 0, STACK = (VAR & VAR_STACK) != 0, F16 = (VAR & VAR_F16) != 0;
     using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, TAPK, (VAR >> 2) & 7>;
     static_assert(!(SPLIT && (STRIDE != 1 || LAYOUT != LAYOUT_NCHW || STACK)), "stream-K hand-over only for the plain stride-1 NCHW variant");
     extern __shared__ __attribute__((aligned(1024))) float lds[];
@@ -238,7 +266,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) u[k] = pl.off[j] < 0 ? 0.f : v[j][8 * h + k];
                 bf16x8 o[TERMS];
-                split_pixel<TERMS>(u, o);
+                split_pixel<TERMS, F16>(u, o);
 #pragma unroll
                 for (int t = 0; t < TERMS; ++t) sp[j][h][t] = __builtin_bit_cast(uint4, o[t]);
             }
@@ -440,7 +468,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
-                    for (int q = 0; q < G::NCO; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[q][wi[i]], bc[bi[i]], acc[q], 0, 0, 0);
+                    for (int q = 0; q < G::NCO; ++q) acc[q] = mfma16<F16>(wc[q][wi[i]], bc[bi[i]], acc[q]);
                 if (st + 1 < NS) {
 #pragma unroll
                     for (int t = 0; t < TERMS; ++t) {
@@ -890,8 +918,15 @@ inline int emu_pc_rows(int H) {
     return rows ? rows : (H >= 64 ? 12 : 8);
 }
 
-template <int TERMS>
+template <int TERMS, bool F16 = false>
 int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
+    if constexpr (F16) {                      // fp16 2-way split: the strided layers, 8 output rows per workgroup, double-buffered patch (as the bf16 2-way split)
+        if (stride != 2) return COALIGN_ERR_UNSUPPORTED;
+        if (layout == LAYOUT_NCHW) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_NCHW, 2, VAR_F16>(a, s);
+        if (layout == LAYOUT_IN_NHWC) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_IN_NHWC, 2, VAR_F16>(a, s);
+        if (layout == LAYOUT_NHWC) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_NHWC, 2, VAR_F16>(a, s);
+        return COALIGN_ERR_UNSUPPORTED;
+    }
     if (stride == 2) {
         // the input halo patch of a strided tile is (2 TH + 1) x 65 pixels: 6 rows per workgroup with the 3-way split (142 KB of LDS),
         // 8 with the 2-way split
@@ -1063,8 +1098,13 @@ int tapk_rows(int rows, const EmuArgs &a, int layout, void *ws, size_t ws_bytes,
     }
 }
 
-template <int TERMS>
+template <int TERMS, bool F16 = false>
 int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipStream_t s, Launch *query) {
+    if constexpr (F16) {                      // fp16 2-way split on the tap-major image: 12 / 8 rows per workgroup or the 26 x 16 tiles, as the bf16 2-way split
+        if (a.Cin % (2 * kKC)) return COALIGN_ERR_UNSUPPORTED;
+        const int rows = (a.W % 32 == 16 && a.H > 26 && a.H <= 52) ? 26 : (a.H >= 64 ? 12 : 8);
+        return tapk_rows<2, VAR_TAPK | VAR_ASM_DMA | VAR_F16>(rows, a, layout, ws, ws_bytes, s, query);
+    }
     static const int force = getenv("COALIGN_EMU_TAPK_ROWS") ? atoi(getenv("COALIGN_EMU_TAPK_ROWS")) : 0;      // experiments only
     static const int var = getenv("COALIGN_EMU_TAPK_VAR") ? atoi(getenv("COALIGN_EMU_TAPK_VAR")) : (VAR_TAPK | VAR_ASM_DMA);
     if (a.Cin % (2 * kKC)) return COALIGN_ERR_UNSUPPORTED;
@@ -1116,25 +1156,27 @@ extern "C" void coalign_conv3x3_emu_set_ablate(int v) { g_emu_ablate = v; }
 #endif
 
 extern "C" size_t coalign_conv3x3_emu_weight_bytes(int Cin, int Cout, int terms) {
-    if (Cin < 1 || Cout < 1 || Cin % kKC || Cout % kCoutTile || (terms != 2 && terms != 3)) return 0;
+    if (Cin < 1 || Cout < 1 || Cin % kKC || Cout % kCoutTile || (terms != 2 && terms != 3 && terms != 16)) return 0;
+    if (terms == 16) terms = 2;           // fp16 2-way split: two 16-bit terms
     return (size_t)(Cout / kCoutTile) * (Cin / kKC) * kSteps * terms * 2 * kCoutTile * 16 + 16;      // + one zero group
 }
 
 extern "C" size_t coalign_conv3x3_emu_weight_bytes_ex(int Cin, int Cout, int terms, int tap_major) {
     if (!tap_major) return coalign_conv3x3_emu_weight_bytes(Cin, Cout, terms);
-    if (Cin < 1 || Cout < 1 || Cin % (2 * kKC) || Cout % kCoutTile || (terms != 2 && terms != 3)) return 0;
+    if (Cin < 1 || Cout < 1 || Cin % (2 * kKC) || Cout % kCoutTile || (terms != 2 && terms != 3 && terms != 16)) return 0;
+    if (terms == 16) terms = 2;
     return (size_t)(Cout / kCoutTile) * (Cin / (2 * kKC)) * 9 * terms * 2 * kCoutTile * 16 + 16;
 }
 
 static int check_emu_args(int N, int Cin, int Cout, int H, int W, int terms) {
     if (N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return COALIGN_ERR_BAD_SHAPE;
-    if (Cin % kKC || Cout % kCoutTile || (terms != 2 && terms != 3)) return COALIGN_ERR_UNSUPPORTED;
+    if (Cin % kKC || Cout % kCoutTile || (terms != 2 && terms != 3 && terms != 16)) return COALIGN_ERR_UNSUPPORTED;
     if ((int64_t)N * Cout * H * W > (int64_t)1 << 40 || (int64_t)Cin * H * W > (int64_t)1 << 30) return COALIGN_ERR_UNSUPPORTED;
     return COALIGN_OK;
 }
 
 extern "C" size_t coalign_conv3x3_emu_workspace_bytes(int N, int Cin, int Cout, int H, int W, int terms) {
-    if (check_emu_args(N, Cin, Cout, H, W, terms) != COALIGN_OK || N == 0) return 0;
+    if (check_emu_args(N, Cin, Cout, H, W, terms) != COALIGN_OK || N == 0 || terms == 16) return 0;
     EmuArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, N, Cin, Cout, H, W, 0, 0, 0, 0, H, W, nullptr, nullptr};
     Launch l{};
     const int rc = terms == 3 ? dispatch<3>(a, nullptr, 0, nullptr, &l) : dispatch<2>(a, nullptr, 0, nullptr, &l);
@@ -1146,7 +1188,7 @@ extern "C" size_t coalign_conv3x3_emu_workspace_bytes_ex(int N, int Cin, int Cou
     if (check_emu_args(N, Cin, Cout, H, W, terms) != COALIGN_OK || N == 0) return 0;
     EmuArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, N, Cin, Cout, H, W, 0, 0, 0, 0, H, W, nullptr, nullptr};
     Launch l{};
-    const int rc = terms == 3 ? dispatch_tapk<3>(a, layout & 3, nullptr, 0, nullptr, &l) : dispatch_tapk<2>(a, layout & 3, nullptr, 0, nullptr, &l);
+    const int rc = terms == 3 ? dispatch_tapk<3>(a, layout & 3, nullptr, 0, nullptr, &l) : terms == 16 ? dispatch_tapk<2, true>(a, layout & 3, nullptr, 0, nullptr, &l) : dispatch_tapk<2>(a, layout & 3, nullptr, 0, nullptr, &l);
     return rc == COALIGN_OK && l.split ? l.ws_bytes : 0;
 }
 
@@ -1163,6 +1205,7 @@ extern "C" int coalign_conv3x3_emu_bias_act(const float *x, const void *w_split,
     if (!x || !w_split || !y || !bias) return COALIGN_ERR_NULL_POINTER;
     int rc = check_emu_args(N, Cin, Cout, H, W, terms);
     if (rc != COALIGN_OK) return rc;
+    if (terms == 16) return COALIGN_ERR_UNSUPPORTED;       // the fp16 split serves the tap-major and the strided images only
     if (reinterpret_cast<uintptr_t>(w_split) & 15) return COALIGN_ERR_UNSUPPORTED;
     if (N == 0) return COALIGN_OK;
     EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, H, W, nullptr, nullptr};
@@ -1197,7 +1240,7 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
         a.ablate = g_emu_ablate;
 #endif
         hipStream_t s = static_cast<hipStream_t>(stream);
-        rc = terms == 3 ? dispatch_tapk<3>(a, lay, workspace, workspace_bytes, s, nullptr) : dispatch_tapk<2>(a, lay, workspace, workspace_bytes, s, nullptr);
+        rc = terms == 3 ? dispatch_tapk<3>(a, lay, workspace, workspace_bytes, s, nullptr) : terms == 16 ? dispatch_tapk<2, true>(a, lay, workspace, workspace_bytes, s, nullptr) : dispatch_tapk<2>(a, lay, workspace, workspace_bytes, s, nullptr);
         return rc != COALIGN_OK ? rc : check_launch();
     }
     if (stride != 1 && stride != 2) return COALIGN_ERR_UNSUPPORTED;
@@ -1215,6 +1258,6 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
     a.ablate = g_emu_ablate;
 #endif
     hipStream_t s = static_cast<hipStream_t>(stream);
-    rc = terms == 3 ? dispatch_variant<3>(a, stride, layout, s) : dispatch_variant<2>(a, stride, layout, s);
+    rc = terms == 3 ? dispatch_variant<3>(a, stride, layout, s) : terms == 16 ? dispatch_variant<2, true>(a, stride, layout, s) : dispatch_variant<2>(a, stride, layout, s);
     return rc != COALIGN_OK ? rc : check_launch();
 }

@@ -81,7 +81,7 @@ class PillarVFE(nn.Module):
         pfn = self.pfn_layers[0]
         bn = (pfn.norm.weight, pfn.norm.bias, pfn.norm.running_mean, pfn.norm.running_var) if self.use_norm else None
         from . import backbone                       # the canvas layout follows the convolution route that will read it
-        channels_last = backbone.NHWC_STAGE_OUTPUTS and backbone.CONV_EMU_TERMS in (2, 3) and backbone.FAST_INFERENCE
+        channels_last = backbone.NHWC_STAGE_OUTPUTS and backbone.emu_active() and backbone.FAST_INFERENCE
         count_dev = batch_dict.get("voxel_count_dev")
         if count_dev is not None:
             # the producer (the device voxeliser) left the pillar count on the device: capacity-sized arrays, no host read of the count,

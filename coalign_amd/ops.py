@@ -544,8 +544,8 @@ def pack_conv3x3_emu_weight(weight: torch.Tensor, terms: int = 3, tap_major: boo
     ``tap_major`` (Cin % 16 == 0): [Cout / 64][Cin / 16][9 taps][terms][2 channel halves][64 cout][8 cin] -- one matrix
     instruction = the 16 channels of one tap, no zero tap (COALIGN_LAYOUT_W_TAPMAJOR)."""
     co, ci, kh, kw = weight.shape
-    if (kh, kw) != (3, 3) or co % 64 or ci % (2 * CONV_KC if tap_major else CONV_KC) or terms not in (2, 3):
-        raise ValueError(f"conv3x3_emu needs 3x3 weights with Cout % 64 == 0, Cin % 8 == 0 (16 tap-major) and terms in (2, 3), got {tuple(weight.shape)}, {terms}")
+    if (kh, kw) != (3, 3) or co % 64 or ci % (2 * CONV_KC if tap_major else CONV_KC) or terms not in (2, 3, 16):
+        raise ValueError(f"conv3x3_emu needs 3x3 weights with Cout % 64 == 0, Cin % 8 == 0 (16 tap-major) and terms in (2, 3, 16), got {tuple(weight.shape)}, {terms}")
     if tap_major:
         w = weight.detach().float().reshape(co // 64, 64, ci // (2 * CONV_KC), 2, CONV_KC, 9)
         w = w.permute(0, 2, 5, 3, 1, 4)                                    # [g, interval, tap, channel half, cout, cin]
@@ -554,8 +554,9 @@ def pack_conv3x3_emu_weight(weight: torch.Tensor, terms: int = 3, tap_major: boo
         w = torch.cat([w, torch.zeros_like(w[..., :1])], dim=-1).reshape(co // 64, 64, ci // CONV_KC, CONV_KC, 5, 2)
         w = w.permute(0, 2, 4, 5, 1, 3)                                    # [g, chunk, step, k-group, cout, cin]
     parts, rest = [], w
-    for _ in range(terms):
-        t = rest.bfloat16()
+    half = terms == 16                                                     # terms = 16: the 2-way split with FP16 terms (w_h = fp16(w), w_l = fp16(w - w_h))
+    for _ in range(2 if half else terms):
+        t = rest.half() if half else rest.bfloat16()
         parts.append(t)
         rest = rest - t.float()
     img = torch.stack(parts, dim=3).contiguous()                           # [g, chunk, step, term, k-group, cout, cin]
@@ -577,7 +578,7 @@ def is_channels_last(t: torch.Tensor) -> bool:
 def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Tensor, cout: int, residual: Optional[torch.Tensor] = None,
                          relu: bool = True, terms: int = 3, stride: int = 1, out_channels_last: bool = False) -> torch.Tensor:
     """y = act(conv3x3(x, w, stride, padding 1) + bias (+ residual)) with every fp32 product evaluated as `terms`-way split bf16
-    products on the bf16 matrix cores, fp32 accumulation (csrc/conv3x3_emu.hip).  A channels-last ``x`` is read in place by the
+    products on the bf16 matrix cores, fp32 accumulation (csrc/conv3x3_emu.hip; terms = 16: the 2-way split with fp16 terms, 22 operand bits).  A channels-last ``x`` is read in place by the
     stride-2 variant; ``out_channels_last`` (stride 1) returns a tensor of logical shape [N, C, H, W] in channels-last memory."""
     _need_gpu(x, w_split, bias, residual)
     L = hip.lib()

@@ -39,7 +39,7 @@ def golden():
     return load
 
 
-@pytest.fixture(params=[3, 0], ids=["bf16x3_default", "native_fp32"])
+@pytest.fixture(params=[3, 0, 16], ids=["bf16x3", "native_fp32", "fp16x2"])
 def conv_mode(request):
     """Model-level parity tests run once per 3x3-convolution arithmetic: the product default (3-way split bf16 products, fp32
     accumulation) and the native-fp32 route (COALIGN_CONV_EMU=0); both are held to the same tolerances."""

@@ -74,3 +74,55 @@ def test_winograd_is_deterministic_and_leaves_neighbours_alone():
     a1 = ops.conv3x3_wino(x.to(DEV), u, b.to(DEV), Co, r.to(DEV), True)
     a2 = ops.conv3x3_wino(x.to(DEV), u, b.to(DEV), Co, r.to(DEV), True)
     assert torch.equal(a1, a2)
+
+
+# ---------------------------------------------------------------------------------------------------------------- fp16 2-way split
+FP16_SHAPES = [(5, 64, 64, 100, 352), (5, 128, 128, 50, 176), (5, 256, 256, 25, 88), (1, 384, 256, 100, 352), (1, 256, 256, 100, 352), (2, 64, 64, 100, 252)]
+
+
+@pytest.mark.parametrize("shape", FP16_SHAPES)
+def test_fp16_two_way_split_error_against_float64_is_not_above_the_native_fp32_kernel(shape):
+    """The rule that admitted the 3-way bf16 split: measured against a float64 convolution, the arithmetic must be no worse than the
+    native fp32 matrix-instruction kernel (csrc/conv3x3.hip) on the same data.  Stride-1 backbone shapes, residual + ReLU (resblock.py:53-69)."""
+    N, Ci, Co, H, W = shape
+    x, w, b, r = _case(N, Ci, Co, H, W, seed=sum(shape))
+    xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+    want = torch.relu(F.conv2d(xd.double(), wd.double(), bd.double(), padding=1) + rd.double())
+    scale = float(want.abs().max())
+    err = lambda y: float((y.double() - want).abs().max()) / scale
+    e16 = err(ops.conv3x3_emu_bias_act(xd, ops.pack_conv3x3_emu_weight(wd, 16, True), bd, Co, rd, True, 16))
+    e16cl = err(ops.conv3x3_emu_bias_act(xd, ops.pack_conv3x3_emu_weight(wd, 16, True), bd, Co, rd, True, 16, out_channels_last=True))
+    e3 = err(ops.conv3x3_emu_bias_act(xd, ops.pack_conv3x3_emu_weight(wd, 3, True), bd, Co, rd, True, 3))
+    e2 = err(ops.conv3x3_emu_bias_act(xd, ops.pack_conv3x3_emu_weight(wd, 2, True), bd, Co, rd, True, 2))
+    enat = err(ops.conv3x3_bias_act(xd, ops.pack_conv3x3_weight(wd), bd, rd, True))
+    print(f"\n{shape}: fp16x2 {e16:.2e} (channels-last out {e16cl:.2e}), bf16x3 {e3:.2e}, bf16x2 {e2:.2e}, native fp32 {enat:.2e} of the output scale")
+    assert e16 <= max(enat, 2e-6) and e16cl <= max(enat, 2e-6)
+    assert e16 < 5e-6
+
+
+@pytest.mark.parametrize("layout_in", ["nchw", "nhwc"])
+def test_fp16_two_way_split_strided_layers(layout_in):
+    """The strided first convolution of a stage (resblock.py:150-174) in the fp16 mode: NCHW and channels-last input, NCHW and channels-last output."""
+    for (N, Ci, Co, H, W) in ((5, 64, 64, 200, 704), (5, 64, 128, 100, 352), (2, 128, 256, 50, 126)):
+        x, w, b, _ = _case(N, Ci, Co, H, W, seed=H + Co, res=False)
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+        if layout_in == "nhwc":
+            xd = xd.contiguous(memory_format=torch.channels_last)
+        want = torch.relu(F.conv2d(xd.double(), wd.double(), bd.double(), stride=2, padding=1))
+        scale = float(want.abs().max())
+        ws = ops.pack_conv3x3_emu_weight(wd, 16, False)
+        for cl_out in ((False, True) if layout_in == "nhwc" else (False,)):
+            got = ops.conv3x3_emu_bias_act(xd, ws, bd, Co, None, True, 16, stride=2, out_channels_last=cl_out)
+            assert float((got.double() - want).abs().max()) / scale < 5e-6, (N, Ci, Co, H, W, cl_out)
+
+
+def test_fp16_mode_saturates_instead_of_overflowing():
+    """Operands beyond fp16's range: term 0 saturates at 65504 and term 1 carries the rest with 11 bits (finite up to 131008) -- no infinities, no NaNs;
+    the accuracy degrades to fp16's there (documented operating range of the mode: |x| <= 6.5e4)."""
+    N, Ci, Co, H, W = 1, 16, 64, 8, 32
+    x, w, b, _ = _case(N, Ci, Co, H, W, seed=3, res=False)
+    x = x * 3.0e4                                            # |x| up to ~1.2e5
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    got = ops.conv3x3_emu_bias_act(x.to(DEV), ops.pack_conv3x3_emu_weight(w.to(DEV), 16, True), b.to(DEV), Co, None, False, 16)
+    assert torch.isfinite(got).all()
+    assert float((got.double().cpu() - want).abs().max() / want.abs().max()) < 1e-3
