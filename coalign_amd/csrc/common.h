@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "coalign_amd.h"
 
@@ -27,6 +28,18 @@ inline int hip_call(hipError_t e) {
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Laboratory switches (ablations, alternative tile geometries, measurement aids).  The PRODUCT library reads none of them: lab_env() is the compile-time
+// default there.  Only the laboratory build (`python -m coalign_amd.build --lab`, -DCOALIGN_LAB, loaded with COALIGN_LAB=1 by tools/ and by the tests that
+// compare variants) looks at the environment.  tests/test_host_cpu.py checks the product library's strings.
+#ifdef COALIGN_LAB
+inline int lab_env(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+constexpr int lab_env(const char *, int dflt) { return dflt; }
+#endif
 
 // XCD-aware, bijective block remap (guide T1): blocks are dispatched round-robin over the 8 XCDs, so give
 // each XCD a contiguous chunk of the logical index space -> neighbouring tiles share one L2.

@@ -19,7 +19,7 @@
 //     workgroup per CU (111 KB of double-buffered weights + one 16-channel split patch);
 //   * tap pairs (the strided layers, the original kernel described below): K = 16 = two taps x the 8 input channels of a chunk:
 //     lanes 0-31 (k 0..7) carry tap 2s, lanes 32-63 (k 8..15) tap 2s + 1, s = 0..4 (the tenth tap is zero weights).
-// Plus an opt-in producer / consumer variant on the tap-pair image (conv3x3_emu_pc_kernel).  Measured history: DESIGN.md section 8.  A workgroup (8 or 12 wavefronts) owns 8 / 12 row segments of 32 pixels and 64 output channels; persistent
+// (A producer / consumer variant was measured and removed in round 4: per layer level with the tap-major kernel, whole frame 300 vs 311 frames/s.)  Measured history: DESIGN.md section 8.  A workgroup (8 or 12 wavefronts) owns 8 / 12 row segments of 32 pixels and 64 output channels; persistent
 // workgroups, one barrier per 8-channel chunk, everything one chunk ahead: the split weights of chunk L + 1 arrive by LDS-DMA, the
 // fp32 halo pixels of chunk L + 1 are loaded into registers (one lane = one pixel, coalesced along the patch rows), split ONCE per
 // pixel after the MFMA steps of chunk L and written to LDS as [term][pixel][8 cin] bf16 -- a B operand is then one ds_read_b128
@@ -548,275 +548,6 @@ void conv3x3_emu_kernel(const EmuArgs a) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Producer / consumer variant (stride 1, NCHW in, tap-pair weight image).  The interval timelines and ablations of the kernel above
-// (tools/trace_conv_emu.py, profiles/round2/experiments) show its phases SERIALISED: kernel time = matrix-step time + everything else
-// (barriers, loads, bf16 split, accumulator start / epilogue), with one workgroup per CU by construction and with two because co-resident
-// workgroups fall into phase.  Here the wavefronts of a workgroup have different jobs:
-//   * NC consumer wavefronts (NC output rows x 32 pixels x 64 output channels) run operand reads and matrix instructions only;
-//   * four producer wavefronts (one per SIMD) stage interval L + 1 while the consumers compute interval L: they split the halo pixels
-//     (loaded one interval earlier into registers) into the OTHER split-patch buffer, issue the weight LDS-DMA into the other weight
-//     buffer and start the pixel loads of interval L + 2.
-// One barrier per 8-channel interval; two split-patch buffers and a ring of three weight buffers (138 KB of LDS with 12 consumers and the
-// 3-way split, 125 KB with 8).
-template <int NC, int TERMS>
-struct GeoPC {
-    static constexpr int NP = 4, WAVES = NC + NP, THREADS = 64 * WAVES, PTHREADS = 64 * NP;
-    static constexpr int TH = NC, TW = 32, PH = TH + 2, PW = TW + 2, PIX = PH * PW;
-    static constexpr int SLOTS = (PIX + PTHREADS - 1) / PTHREADS;                 // pixel slots one producer lane stages per interval
-    static constexpr int WQ = kSteps * TERMS * 2 * kCoutTile, WINSTR = WQ / 64;   // 16-byte groups / DMA instructions of one weight chunk
-    static constexpr int WJ = (WINSTR + NP - 1) / NP;
-    static constexpr int WRING = 3;                                               // weight buffers: the DMA runs two intervals ahead
-    static constexpr int WSZ = WQ * 4, BSZ = TERMS * PIX * 4, W_OFF = 0, B_OFF = WRING * WSZ;      // floats
-    static constexpr size_t LDS_BYTES = ((size_t)B_OFF + 2 * (size_t)BSZ) * 4;
-    static_assert(NC % 4 == 0, "consumers and producers are spread evenly over the four SIMDs");
-};
-
-template <int NC, int TERMS, int LAYOUT>
-__global__ __launch_bounds__(64 * (NC + 4)) void conv3x3_emu_pc_kernel(const EmuArgs a) {
-    using G = GeoPC<NC, TERMS>;
-    static_assert(LAYOUT == LAYOUT_NCHW || LAYOUT == LAYOUT_OUT_NHWC, "NCHW input");
-    extern __shared__ __attribute__((aligned(1024))) float lds[];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;
-    const size_t plane = (size_t)a.H * a.W;
-    const int groups = a.Cout / kCoutTile, chunks = a.Cin / kKC;
-    const int g = blockIdx.x, n_wg = gridDim.x;
-    const int n_tiles = (a.total_tiles - g + n_wg - 1) / n_wg;          // whole tiles g, g + n_wg, ...
-    const int n_local = n_tiles * chunks;                               // intervals of this workgroup = barriers every wavefront meets
-    if (n_local <= 0) return;
-    auto decode = [&](int t) {
-        Tile c;
-        c.cg = t % groups;
-        const int sp = t / groups;
-        c.n = sp / a.tiles_per_img;
-        const int r = sp - c.n * a.tiles_per_img, ty = r / a.tiles_x;
-        c.y0 = ty * G::TH;
-        c.x0 = (r - ty * a.tiles_x) * G::TW;
-        return c;
-    };
-    auto tile_of = [&](int l) { return g + (l / chunks) * n_wg; };       // tile of interval l
-
-    if (wave >= NC) {
-        // ------------------------------------------------------------------------------------------------ producers
-        __builtin_amdgcn_s_setprio(3);                                  // their few instructions never wait behind the consumers'
-        const int ptid = tid - 64 * NC, pw = wave - NC;
-        const float *base = nullptr;
-        int off[G::SLOTS];
-        auto make_plan = [&](int l) {                                   // interval l opens (or lies in) tile tile_of(l): halo-pixel offsets
-            const Tile t = decode(tile_of(l));
-            base = a.x + (size_t)t.n * a.Cin * plane;
-#pragma unroll
-            for (int j = 0; j < G::SLOTS; ++j) {
-                const int i = ptid + j * G::PTHREADS;
-                const int y = i / G::PW, xq = i - y * G::PW;
-                const int gy = t.y0 - 1 + y, gx = t.x0 - 1 + xq;
-                off[j] = (i < G::PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? gy * a.W + gx : -1;
-            }
-        };
-        float pv[G::SLOTS][8];
-        int pad = 0;                                                    // bit j: slot j of the pixels in `pv` is zero padding
-        auto load = [&](int l) {                                        // halo pixels of interval l -> registers
-            const float *src = base + (size_t)(l % chunks) * kKC * plane;
-            pad = 0;
-#pragma unroll
-            for (int j = 0; j < G::SLOTS; ++j) {
-                const int o = off[j] < 0 ? 0 : off[j];
-                pad |= (off[j] < 0 ? 1 : 0) << j;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) pv[j][k] = src[(size_t)k * plane + o];
-            }
-        };
-        auto store = [&](int slot) {                                    // ... split into bf16 terms -> split-patch buffer `slot`
-            uint4 *bt = reinterpret_cast<uint4 *>(lds + G::B_OFF + slot * G::BSZ);
-#pragma unroll
-            for (int j = 0; j < G::SLOTS; ++j) {
-                const int i = ptid + j * G::PTHREADS;
-                if (i < G::PIX) {
-                    float u[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) u[k] = ((pad >> j) & 1) ? 0.f : pv[j][k];
-                    bf16x8 o[TERMS];
-                    split_pixel<TERMS>(u, o);
-#pragma unroll
-                    for (int t = 0; t < TERMS; ++t) bt[t * G::PIX + i] = __builtin_bit_cast(uint4, o[t]);
-                }
-            }
-        };
-        auto dma = [&](int l, int slot) {                               // split weights of interval l -> weight buffer `slot` (LDS-DMA, asm: see VAR_ASM_DMA)
-            const Tile t = decode(tile_of(l));
-            const uint4 *wsrc = a.wt + ((size_t)t.cg * chunks + (l % chunks)) * G::WQ + lane;
-            float *wdst = lds + G::W_OFF + slot * G::WSZ;
-#pragma unroll
-            for (int j = 0; j < G::WJ; ++j) {
-                const int ins = pw + G::NP * j;
-                if (ins < G::WINSTR) {
-                    const unsigned dst = (unsigned)(size_t)(lptr_t)(wdst + ins * 256);
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(dst)), "v"(wsrc + ins * 64) : "memory", "m0");
-                }
-            }
-        };
-        // Nothing a producer asks for is awaited in the interval it was asked in: the pixels and the weights of interval L + 2 are
-        // requested during interval L (weight ring of three buffers) and awaited -- by the first use of the pixel registers, the
-        // counter retires in order -- at the start of interval L + 1, when they have had a whole interval to arrive.
-        make_plan(0);
-        load(0);
-        dma(0, 0);
-        store(0);                                                       // (waits for the loads)
-        __builtin_amdgcn_s_waitcnt(0);                                  // once: everything of interval 0 has landed
-        if (n_local > 1) {
-            if (chunks == 1) make_plan(1);
-            load(1);
-            dma(1, 1);
-        }
-        int wslot = 2;                                                  // (L + 2) % 3
-        for (int L = 0; L < n_local; ++L) {
-            __syncthreads();                                            // patch L % 2 / weights L % 3 complete; patch (L + 1) % 2 / weights (L + 2) % 3 free
-            if (L + 1 < n_local) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): what the previous interval requested (pixels and weights of L + 1) is here
-                store((L + 1) & 1);
-                __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the LDS writes are done; nothing requested below is awaited here
-                if (L + 2 < n_local) {
-                    if ((L + 2) % chunks == 0) make_plan(L + 2);
-#ifdef EMU_TRACE
-                    if (!(a.ablate & 2)) load(L + 2);
-                    if (!(a.ablate & 1)) dma(L + 2, wslot);
-#else
-                    load(L + 2);
-                    dma(L + 2, wslot);
-#endif
-                }
-            }
-            wslot = wslot == 2 ? 0 : wslot + 1;
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------------------------------------- consumers
-    if (wave >= NC / 2) __builtin_amdgcn_s_setprio(1);                  // the later-dispatched half loses every arbitration otherwise
-    const int py = wave, px = p;
-    int boff[kSteps];
-#pragma unroll
-    for (int s = 0; s < kSteps; ++s) {
-        const int t = 2 * s + half < 9 ? 2 * s + half : 8;
-        boff[s] = (py + t / 3) * G::PW + px + t % 3;
-    }
-    const int wlane = half * kCoutTile + p;
-    int L = 0;
-    for (int ti = 0; ti < n_tiles; ++ti) {
-        const Tile cur = decode(g + ti * n_wg);
-        const int gy = cur.y0 + py, gx = cur.x0 + px;
-        const bool live = gy < a.H && gx < a.W;
-        const bool wave_live = __builtin_amdgcn_readfirstlane((int)(cur.y0 + py < a.H)) != 0;
-        const size_t obase = ((size_t)cur.n * a.Cout + cur.cg * kCoutTile + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
-        // Tile start and end without exposed memory latency: the accumulators start at zero; the residual values are requested at the
-        // start of the tile's LAST interval (32 registers, in flight beside its matrix steps) and added in the epilogue together with
-        // the bias, which comes through scalar loads (constant address space + wave-uniform address; two candidates per accumulator,
-        // selected by the lane half).  The stores of a tile then drain behind the next tile's matrix steps: nothing in the next
-        // intervals waits on the vector-memory counter.
-        typedef const __attribute__((address_space(4))) float *cfloat_t;
-        const cfloat_t bias_s = (cfloat_t)(uintptr_t)(a.bias + cur.cg * kCoutTile);
-        floatx16 acc[2] = {floatx16{0}, floatx16{0}};
-        float rv[32];
-        for (int chunk = 0; chunk < chunks; ++chunk, ++L) {
-            __syncthreads();
-            if (!wave_live) continue;
-            if (chunk == chunks - 1) {
-#ifdef EMU_TRACE
-                if (a.residual && !(a.ablate & 8)) {
-#else
-                if (a.residual) {
-#endif
-#pragma unroll
-                    for (int q = 0; q < 32; ++q) rv[q] = a.residual[obase + (size_t)((q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4)) * plane];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 32; ++q) rv[q] = 0.f;
-                }
-            }
-#ifdef EMU_TRACE
-            if (a.ablate & 4) continue;
-#endif
-            const uint4 *bq = reinterpret_cast<const uint4 *>(lds + G::B_OFF + (L & 1) * G::BSZ);
-            const uint4 *wq = reinterpret_cast<const uint4 *>(lds + G::W_OFF + (L % G::WRING) * G::WSZ) + wlane;
-            auto load_b = [&](int s, bf16x8 (&b)[TERMS]) {
-#pragma unroll
-                for (int t = 0; t < TERMS; ++t) {
-                    uint4 v = bq[t * G::PIX + boff[s]];
-                    if (s == kSteps - 1 && half) v = uint4{0, 0, 0, 0};       // the tenth tap does not exist
-                    b[t] = __builtin_bit_cast(bf16x8, v);
-                }
-            };
-            auto load_w = [&](int s, bf16x8 (&w)[2][TERMS]) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int t = 0; t < TERMS; ++t) w[q][t] = __builtin_bit_cast(bf16x8, wq[((s * TERMS + t) * 2) * kCoutTile + q * 32]);
-            };
-            bf16x8 bc[TERMS], wc[2][TERMS];
-            load_b(0, bc);
-            load_w(0, wc);
-#pragma unroll
-            for (int st = 0; st < kSteps; ++st) {
-                bf16x8 wn[2][TERMS], bn[TERMS];
-                constexpr int NT = TERMS == 3 ? 6 : 3;
-                constexpr int wi[6] = {0, 1, TERMS == 3 ? 2 : 0, 0, 1, 0};
-                constexpr int bi[6] = {TERMS == 3 ? 2 : 1, TERMS == 3 ? 1 : 0, 0, 1, 0, 0};
-                if (st + 1 < kSteps) {
-                    load_b(st + 1, bn);
-                    load_w(st + 1, wn);
-                }
-#pragma unroll
-                for (int i = 0; i < NT; ++i)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[q][wi[i]], bc[bi[i]], acc[q], 0, 0, 0);
-                if (st + 1 < kSteps) {
-#pragma unroll
-                    for (int t = 0; t < TERMS; ++t) {
-                        bc[t] = bn[t];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) wc[q][t] = wn[q][t];
-                    }
-                }
-            }
-        }
-        if (wave_live) {
-#pragma unroll
-            for (int q = 0; q < 32; ++q) {
-                const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
-                const float b0 = bias_s[c], b1 = bias_s[c + 4];
-                acc[q / 16][q % 16] += rv[q] + (half ? b1 : b0);
-            }
-        }
-#ifdef EMU_TRACE
-        if (live && !(a.ablate & 8)) {
-#else
-        if (live) {
-#endif
-            if constexpr (LAYOUT == LAYOUT_OUT_NHWC) {
-                float *yp = a.y + (((size_t)cur.n * a.H + gy) * a.W + gx) * a.Cout + cur.cg * kCoutTile + 4 * half;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    float4 o;
-                    o.x = acc[r / 4][4 * (r % 4)]; o.y = acc[r / 4][4 * (r % 4) + 1]; o.z = acc[r / 4][4 * (r % 4) + 2]; o.w = acc[r / 4][4 * (r % 4) + 3];
-                    if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-                    *reinterpret_cast<float4 *>(yp + (r / 4) * 32 + 8 * (r % 4)) = o;
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 32; ++q) {
-                    const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
-                    const float v = acc[q / 16][q % 16];
-                    a.y[obase + (size_t)c * plane] = a.relu ? fmaxf(v, 0.f) : v;
-                }
-            }
-        }
-    }
-}
-
-// (A producer / consumer kernel on the TAP-MAJOR image -- 16-channel intervals, weights staged in two halves through a ring of three 30 KB
-// buffers, one barrier per half, 8 + 4 wavefronts, 157 KB -- was written and measured: correct, 139 vs 85 us on the 64-channel layer (85
-// spilled registers at the 168-register budget of 12 wavefronts, twice the barriers).  Removed; profiles/round2/experiments.)
-
 struct Launch {                    // what the host needs to know about one (shape, geometry) pair
     int grid;
     size_t flag_bytes, ws_bytes;
@@ -825,7 +556,7 @@ struct Launch {                    // what the host needs to know about one (sha
 
 // stream-K pays when the whole-tile schedule leaves the last round badly filled; a tile must have at least two chunks to split
 inline bool want_split(int total_tiles, int slots, int chunks, int long_tile = 32) {
-    static const int force = getenv("COALIGN_EMU_SPLIT") ? atoi(getenv("COALIGN_EMU_SPLIT")) : -1;     // experiments only
+    static const int force = coalign::lab_env("COALIGN_EMU_SPLIT", -1);     // laboratory build only
     if (chunks < 2) return false;
     if (force >= 0) return force != 0;
     // measured (tools/bench_conv_emu_geo.py with COALIGN_EMU_SPLIT=0|1): as for the fp32 kernel, splitting pays on long tiles
@@ -879,45 +610,6 @@ int launch_variant(const EmuArgs &a0, hipStream_t s) {
     return COALIGN_OK;
 }
 
-// the producer / consumer kernel: whole tiles, one workgroup per CU
-template <int NC, int TERMS, int LAYOUT>
-int launch_pc(const EmuArgs &a0, hipStream_t s) {
-    using G = GeoPC<NC, TERMS>;
-    static_assert(G::LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
-    static int resident = 0, cus = 0;
-    auto kern = conv3x3_emu_pc_kernel<NC, TERMS, LAYOUT>;
-    if (!resident) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
-        cus = prop.multiProcessorCount;
-        const int rc = coalign::hip_call(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
-        if (rc != COALIGN_OK) {
-            (void)hipGetLastError();
-            return rc;
-        }
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, G::THREADS, G::LDS_BYTES) != hipSuccess || n < 1) n = 1;
-        resident = n;
-    }
-    EmuArgs a = a0;
-    a.tiles_x = (a.W + G::TW - 1) / G::TW;
-    a.tiles_per_img = a.tiles_x * ((a.H + G::TH - 1) / G::TH);
-    a.total_tiles = a.tiles_per_img * (a.Cout / kCoutTile) * a.N;
-    const int slots = cus * resident;
-    const int grid = a.total_tiles < slots ? a.total_tiles : slots;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
-    return COALIGN_OK;
-}
-
-// COALIGN_EMU_PC (experiments): 1 = the producer / consumer kernel serves the stride-1 layers given in the tap-pair weight image
-inline int emu_pc_rows(int H) {
-    static const int pc = getenv("COALIGN_EMU_PC") ? atoi(getenv("COALIGN_EMU_PC")) : 0;
-    static const int rows = getenv("COALIGN_EMU_PC_ROWS") ? atoi(getenv("COALIGN_EMU_PC_ROWS")) : 0;
-    if (!pc) return 0;
-    return rows ? rows : (H >= 64 ? 12 : 8);
-}
-
 template <int TERMS, bool F16 = false>
 int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
     if constexpr (F16) {                      // fp16 2-way split: the strided layers, 8 output rows per workgroup, double-buffered patch (as the bf16 2-way split)
@@ -933,12 +625,7 @@ int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
         constexpr int NPB2 = TERMS == 3 ? 6 : 8;
         // 3-way split: 8 output rows per workgroup with ONE patch buffer (114 KB) instead of 6 rows double buffered (142 KB): 8 wavefronts per
         // CU instead of 6; measured 287.4 -> 291.1 frames/s (tools/ab_bench.sh, same box)
-        static const int s2pb = getenv("COALIGN_EMU_S2_PBUF1") ? atoi(getenv("COALIGN_EMU_S2_PBUF1")) : 1;
-        static const int s2asm = getenv("COALIGN_EMU_S2_ASM") ? atoi(getenv("COALIGN_EMU_S2_ASM")) : 0;      // weight DMA issued from inline assembly (VAR_ASM_DMA)
-        if (TERMS == 3 && s2pb && s2asm) {
-            if (layout == LAYOUT_NCHW) return launch_variant<1, 32, 8, TERMS, 1, 2, LAYOUT_NCHW, 1, VAR_ASM_DMA>(a, s);
-            if (layout == LAYOUT_IN_NHWC) return launch_variant<1, 32, 8, TERMS, 1, 2, LAYOUT_IN_NHWC, 1, VAR_ASM_DMA>(a, s);
-        }
+        static const int s2pb = coalign::lab_env("COALIGN_EMU_S2_PBUF1", 1);
         if (TERMS == 3 && s2pb) {
             if (layout == LAYOUT_NCHW) return launch_variant<1, 32, 8, TERMS, 1, 2, LAYOUT_NCHW, 1>(a, s);
             if (layout == LAYOUT_IN_NHWC) return launch_variant<1, 32, 8, TERMS, 1, 2, LAYOUT_IN_NHWC, 1>(a, s);
@@ -950,8 +637,6 @@ int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
         return COALIGN_ERR_UNSUPPORTED;
     }
     if (layout == LAYOUT_OUT_NHWC) {
-        if (emu_pc_rows(a.H) == 12) return launch_pc<12, TERMS, LAYOUT_OUT_NHWC>(a, s);
-        if (emu_pc_rows(a.H) == 8) return launch_pc<8, TERMS, LAYOUT_OUT_NHWC>(a, s);
         if (rows_per_tile(a.H, TERMS) == 12) return launch_variant<1, 32, 12, TERMS, 1, 1, LAYOUT_OUT_NHWC>(a, s);
         return launch_variant<1, 32, 8, TERMS, 1, 1, LAYOUT_OUT_NHWC>(a, s);
     }
@@ -1019,21 +704,14 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
 
 template <int TERMS>
 int dispatch(const EmuArgs &a, void *ws, size_t ws_bytes, hipStream_t s, Launch *query) {
-    static const int force = getenv("COALIGN_EMU_GEO") ? atoi(getenv("COALIGN_EMU_GEO")) : -1;      // experiments only
-    if (emu_pc_rows(a.H)) {
-        if (query) {
-            *query = Launch{0, 0, 0, false};
-            return COALIGN_OK;
-        }
-        return emu_pc_rows(a.H) == 12 ? launch_pc<12, TERMS, LAYOUT_NCHW>(a, s) : emu_pc_rows(a.H) == 8 ? launch_pc<8, TERMS, LAYOUT_NCHW>(a, s) : COALIGN_ERR_UNSUPPORTED;
-    }
+    static const int force = coalign::lab_env("COALIGN_EMU_GEO", -1);      // laboratory build only
     // geometry code = 10 * (wavefronts per workgroup = output rows per tile) + (8-channel chunks per barrier)
     const bool even = (a.Cin / kKC) % 2 == 0;
     int geo = 10 * rows_per_tile(a.H, TERMS) + 1;
     if (force >= 0) geo = force;
     // 3-way split: 8-wavefront workgroups with ONE split-patch buffer (78 KB of LDS: two workgroups per CU) on every map size.
     // Measured in the pipeline (round 2, same box): 258-262 frames/s against 249-250 with the double-buffered 8 / 12-wavefront geometries.
-    static const int pbuf1 = getenv("COALIGN_EMU_PBUF1") ? atoi(getenv("COALIGN_EMU_PBUF1")) : 2;     // experiments: 0 = off, 1 = small maps only
+    static const int pbuf1 = coalign::lab_env("COALIGN_EMU_PBUF1", 2);     // laboratory build: 0 = off, 1 = small maps only
     if (force < 0 && TERMS == 3 && ((pbuf1 == 1 && geo == 81) || pbuf1 == 2)) geo = 83;
     // (One weight image + one patch buffer -- 47 KB, three workgroups per CU at 80 registers -- measured 157 vs 286 frames/s: 160 B of
     //  scratch per lane in the chunk loop and the weight DMA exposed between the two barriers.)
@@ -1043,13 +721,15 @@ int dispatch(const EmuArgs &a, void *ws, size_t ws_bytes, hipStream_t s, Launch 
     //  spread over four SIMDs at this kernel's 95 registers, the second workgroup does not become resident.)
     if (!even && geo % 10 == 2) geo -= 1;
     switch (geo) {
-        case 81: return launch<1, 32, 8, TERMS, 1>(a, ws, ws_bytes, s, query);
-        case 82: return launch<1, 32, 8, TERMS, 2>(a, ws, ws_bytes, s, query);
+        case 81: return launch<1, 32, 8, TERMS, 1>(a, ws, ws_bytes, s, query);             // (the 2-way split)
         case 83: return launch<1, 32, 8, TERMS, 1, 1>(a, ws, ws_bytes, s, query);          // one patch buffer: two workgroups per CU with the 3-way split
+#ifdef COALIGN_LAB      // geometries measured and not adopted: laboratory build only
+        case 82: return launch<1, 32, 8, TERMS, 2>(a, ws, ws_bytes, s, query);
         case 84: return launch<1, 32, 8, TERMS, 1, 1, VAR_ASM_DMA>(a, ws, ws_bytes, s, query);      // ... with the weight DMA hidden from hipcc's waitcnt pass
         case 121: return launch<1, 32, 12, TERMS, 1>(a, ws, ws_bytes, s, query);
         case 122: return launch<1, 32, 12, TERMS, 2>(a, ws, ws_bytes, s, query);
         case 41: return launch<1, 32, 4, TERMS, 1>(a, ws, ws_bytes, s, query);
+#endif
         default: return COALIGN_ERR_UNSUPPORTED;
     }
 }
@@ -1091,7 +771,9 @@ int tapk_rows(int rows, const EmuArgs &a, int layout, void *ws, size_t ws_bytes,
         case 124: return tapk_stacked<TERMS, 2, 16, 12, VAR | VAR_STACK>(a, layout, s, query);
         // stacked, 32 output channels per wavefront: 6 rows x 32 pixels x 64 channels per workgroup = 12 wavefronts of half a unit (the 25 x 88
         // maps: 21 x 3 x 4 = 252 tiles, three half units per SIMD instead of two whole ones)
+#ifdef COALIGN_LAB      // (opt-in since round 3, never the default: laboratory build only)
         case 106: return tapk_stacked<TERMS, 1, 32, 6, VAR | VAR_STACK | VAR_NCO1>(a, layout, s, query);
+#endif
         // stacked, 4 x 8-pixel blocks in four block columns: 8 x 32 tiles whose fourth block column is idle where the map ends after 88 columns
         case 148: return tapk_stacked<TERMS, 4, 8, 8, VAR | VAR_STACK | VAR_NBX4>(a, layout, s, query);
         default: return COALIGN_ERR_UNSUPPORTED;
@@ -1105,14 +787,13 @@ int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipSt
         const int rows = (a.W % 32 == 16 && a.H > 26 && a.H <= 52) ? 26 : (a.H >= 64 ? 12 : 8);
         return tapk_rows<2, VAR_TAPK | VAR_ASM_DMA | VAR_F16>(rows, a, layout, ws, ws_bytes, s, query);
     }
-    static const int force = getenv("COALIGN_EMU_TAPK_ROWS") ? atoi(getenv("COALIGN_EMU_TAPK_ROWS")) : 0;      // experiments only
-    static const int var = getenv("COALIGN_EMU_TAPK_VAR") ? atoi(getenv("COALIGN_EMU_TAPK_VAR")) : (VAR_TAPK | VAR_ASM_DMA);
+    static const int force = coalign::lab_env("COALIGN_EMU_TAPK_ROWS", 0);      // laboratory build only
     if (a.Cin % (2 * kKC)) return COALIGN_ERR_UNSUPPORTED;
     // measured per layer (tools/bench_conv_tapk.py): 12 rows on the 100-row maps (495 tiles = two full rounds of 256 workgroups), 8 rows
     // on the 25-row maps; 10 rows lose everywhere but on the shrink header (-1 %)
     // 50 x 176 maps (W a multiple of 16, not of 32): 13 wavefronts of 2 rows x 16 pixels = 26 x 16 tiles cover the map exactly (220 tiles =
     // ONE round; 8 x 32 tiles: 420 = 1.6 rounds, 9 % dead columns): 95 vs 108 us per layer
-    static const int t26 = getenv("COALIGN_EMU_TAPK_26") ? atoi(getenv("COALIGN_EMU_TAPK_26")) : 1;
+    static const int t26 = coalign::lab_env("COALIGN_EMU_TAPK_26", 1);
     // Round 3, load balance.  A workgroup owns its CU (143-159 KB of LDS), so a layer costs (busiest SIMD's work) x time: with per-image tiles
     // the 25 x 88 maps of a 5-agent frame are 240 tiles of 8 wavefront units (two per SIMD) of which 60 hold a single live row (the 25th) and
     // still keep their CU for the whole K loop; the 50 x 176 maps 220 tiles of 13 units (four on one SIMD).  Tiling the batch as ONE image
@@ -1130,18 +811,15 @@ int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipSt
     // v_pk_add_f32 instructions (warp_fuse_nhwc: ~1/3 of fused maps differed).  Every kernel of this library is now built without packed fp32
     // instructions (build.py), after which tools/diag_fuse_corun.py and a 3000-frame soak (tools/soak_pipeline.py) show no difference with the
     // variant on; kernels that are not ours and share the GPU may still contain them.
-    static const int stack = getenv("COALIGN_EMU_STACK") ? atoi(getenv("COALIGN_EMU_STACK")) : 5;
+    static const int stack = coalign::lab_env("COALIGN_EMU_STACK", 5);
     int rows = force ? force : (t26 && a.W % 32 == 16 && a.H > 26 && a.H <= 52) ? 26 : (a.H >= 64 ? 12 : 8);
     if (!force && stack && TERMS == 3) {          // (bit 0: the 24 x 16 tiles, bit 1: the 6 x 32 tiles, bit 2: the 4 x 8-pixel blocks -- separately switchable)
         if (rows == 26 && a.H >= 24 && (stack & 1)) rows = 124;
         else if (rows == 8 && a.H >= 8 && a.H <= 32 && a.W % 32 > 0 && a.W % 32 <= 24 && (stack & 4)) rows = 148;
         else if (rows == 8 && a.H >= 6 && a.H <= 32 && (stack & 2)) rows = 106;
     }
-    switch (var) {
-        case VAR_TAPK: return tapk_rows<TERMS, VAR_TAPK>(rows, a, layout, ws, ws_bytes, s, query);
-        case VAR_TAPK | VAR_ASM_DMA: return tapk_rows<TERMS, VAR_TAPK | VAR_ASM_DMA>(rows, a, layout, ws, ws_bytes, s, query);
-        default: return COALIGN_ERR_UNSUPPORTED;
-    }
+    // (the weight DMA is always issued from inline assembly: with the builtin, hipcc waits vmcnt(0) in front of the first matrix step of every interval)
+    return tapk_rows<TERMS, VAR_TAPK | VAR_ASM_DMA>(rows, a, layout, ws, ws_bytes, s, query);
 }
 
 constexpr int kLayoutTapMajor = 4;      // COALIGN_LAYOUT_W_TAPMAJOR: flag bit of `layout`
@@ -1193,8 +871,7 @@ extern "C" size_t coalign_conv3x3_emu_workspace_bytes_ex(int N, int Cin, int Cou
 }
 
 static int emu_prio_mode() {
-    static const int v = (getenv("COALIGN_EMU_PRIO") ? atoi(getenv("COALIGN_EMU_PRIO")) & 7 : 0) |
-                         ((getenv("COALIGN_EMU_XCD") ? atoi(getenv("COALIGN_EMU_XCD")) : 1) ? 8 : 0);      // bit 3: XCD-aware workgroup order (default on)
+    static const int v = (coalign::lab_env("COALIGN_EMU_PRIO", 0) & 7) | (coalign::lab_env("COALIGN_EMU_XCD", 1) ? 8 : 0);      // bit 3: XCD-aware workgroup order (default on)
     return v;
 }
 

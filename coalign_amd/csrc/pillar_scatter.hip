@@ -977,6 +977,11 @@ __global__ __launch_bounds__(256) void pillar_prep_kernel(const int *__restrict_
 //      arithmetic AND the stores switched off -- 4096 waves x 5 dependent passes x one exposed round trip each; one round of five pairs per
 //      wavefront, 4096 wavefronts: 20 us / 12.5 us -- every wavefront still paid prologue + one exposed transfer for five pairs of work.)
 typedef __attribute__((address_space(3))) void *lptr_ps_t;
+#ifdef COALIGN_LAB
+constexpr bool kPillarLab = true;       // the ablation bits of PfnArgs::debug (no arithmetic / no stores) exist in the laboratory build only
+#else
+constexpr bool kPillarLab = false;
+#endif
 constexpr int kRunPairs = 32;                               // pairs per wavefront at most: one lane per pillar in the prologue
 
 // ROUND: pairs per round (ROUND KB of points per wavefront and buffer)
@@ -1053,16 +1058,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pillar_rows_mx_kernel(Pfn
                 in.cd = make_int4(0, r0v.y, r0v.z, r0v.w);
                 const int slot = r1v.x, owner = r1v.y;
                 float y[2];
-                if (a.debug & 4) { y[0] = in.q.x + (float)in.np; y[1] = in.q.y + (float)in.cd.w; }
+                if (kPillarLab && (a.debug & 4)) { y[0] = in.q.x + (float)in.np; y[1] = in.q.y + (float)in.cd.w; }
                 else mx_pair_half<ABS>(a, mc, wave_lds, lane, in, hasB, y);
                 const bool win = live && slot >= 0 && (a.unique || owner == m);
                 if (live) {
-                    if (feat_b && !(a.debug & 1)) {
+                    if (feat_b && !(kPillarLab && (a.debug & 1))) {
                         const unsigned fo = ((unsigned)m * (unsigned)a.C + (unsigned)col) * 4u;
                         if (ch0) *reinterpret_cast<float *>(feat_b + fo) = y[0];
                         if (ch1) *reinterpret_cast<float *>(feat_b + fo + 128u) = y[1];
                     }
-                    if (win && !(a.debug & 2)) {
+                    if (win && !(kPillarLab && (a.debug & 2))) {
                         const unsigned co = ((unsigned)slot * (unsigned)a.C + (unsigned)col) * 4u;
                         if (ch0) *reinterpret_cast<float *>(cv_b + co) = y[0];
                         if (ch1) *reinterpret_cast<float *>(cv_b + co + 128u) = y[1];
@@ -1084,8 +1089,8 @@ bool pillar_mfma_enabled() {
 }
 
 void launch_rows(const PfnArgs &a_in, float *canvas, int *dest, int reset_cellmap, int blocks, hipStream_t stream) {
-    static const int debug = [] { const char *e = getenv("COALIGN_PILLAR_DEBUG"); return e ? atoi(e) : 0; }();
-    static const int blocks_override = [] { const char *e = getenv("COALIGN_PILLAR_BLOCKS"); return e ? atoi(e) : 0; }();
+    static const int debug = coalign::lab_env("COALIGN_PILLAR_DEBUG", 0);                  // laboratory build only (the product kernel has no debug branches: kPillarLab)
+    static const int blocks_override = coalign::lab_env("COALIGN_PILLAR_BLOCKS", 0);
     PfnArgs a = a_in;
     a.debug = debug;
     if (blocks_override > 0 && blocks > blocks_override) blocks = blocks_override;
@@ -1102,7 +1107,7 @@ void launch_rows(const PfnArgs &a_in, float *canvas, int *dest, int reset_cellma
     // 18.9 us; rounds of three pairs -- 129 registers, three workgroups per CU -- 19.1 us; 16 / 20 / 32 pairs per wavefront 23.8 / 23.6 / 32.2 us;
     // without arithmetic and stores 9-10 us, without arithmetic 12.2 us, without stores 16.6 us: the six-product matrix steps and their
     // reductions, ~750 issue cycles per pair and SIMD, are what is left.  profiles/round3/pillar_rows_ablation.txt)
-    static const int pairs_target = [] { const char *e = getenv("COALIGN_PILLAR_PAIRS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= kRunPairs ? v : 0; }();
+    static const int pairs_target = [] { const int v = coalign::lab_env("COALIGN_PILLAR_PAIRS", 0); return v > 0 && v <= kRunPairs ? v : 0; }();
     constexpr int kRound = 5;
     const int target = pairs_target ? pairs_target : 2 * kRound, resident = 512;
     const int pairs = (a.M + 1) / 2;
@@ -1185,7 +1190,7 @@ static int pillar_vfe_scatter_impl(const float *voxel_features, const int32_t *v
             launch_rows(a, canvas, nullptr, 0, want < cap ? want : cap, stream);
             return check_launch();
         }
-        if (P <= 64 && C <= 64 && !getenv("COALIGN_UNFUSED_PILLARS")) {
+        if (P <= 64 && C <= 64 && !coalign::lab_env("COALIGN_UNFUSED_PILLARS", 0)) {
             // cell map first, then ONE fused encoder + canvas pass
             hipLaunchKernelGGL(cellmap_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, (const int4 *)voxel_coords, M, n_agents,
                                ny, nx, cellmap);

@@ -275,7 +275,7 @@ static int pointwise_impl(const float *x, const float *w, const float *bias, flo
     PwArgs a{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu, in_nhwc != 0, 1, out_nhwc};
     if (N > 65535) return COALIGN_ERR_UNSUPPORTED;
     const int pixels = a.Hp * a.Wp;
-    static const int pb_max = getenv("COALIGN_PW_PB") ? atoi(getenv("COALIGN_PW_PB")) : 4;      // experiments: 1 = the round-1 mapping
+    static const int pb_max = coalign::lab_env("COALIGN_PW_PB", 4);      // laboratory build: 1 = the round-1 mapping
     a.pb = M_padded <= 64 ? 4 : M_padded <= 128 ? 2 : 1;
     while (a.pb > 1 && (a.pb > pb_max || Cin * 32 * a.pb > kMaxCin * 32)) a.pb >>= 1;
     if (up == 4 && ((a.Wp * 4) % 4 || (reinterpret_cast<uintptr_t>(y) & 15))) return COALIGN_ERR_UNSUPPORTED;

@@ -172,9 +172,11 @@ def pillar_encode_stream(voxel_features: torch.Tensor, voxel_num_points: torch.T
     dev = vf.device
     if P > 32 or C > 64 or C % 4:
         raise hip.CoalignHipError("pillar_encode_stream: the channels-last encoder needs P <= 32 and C <= 64 (a multiple of 4)")
-    key = ("stream", str(dev), torch.cuda.current_stream(dev).cuda_stream, n_agents, C, ny, nx, bool(unique_cells))
+    # (the capacity is part of the key: the C entry point clears "the rows the previous call wrote" out of a slot list of THIS capacity -- a smaller
+    #  capacity on the same canvas would leave the previous frame's rows beyond it uncleared)
+    key = ("stream", str(dev), torch.cuda.current_stream(dev).cuda_stream, n_agents, C, ny, nx, bool(unique_cells), int(cap))
     entry = canvas_cache.get(key)
-    if entry is None or entry["dest"].numel() < cap + 1:
+    if entry is None:
         entry = canvas_cache[key] = {
             "canvas": torch.empty((n_agents, C, ny, nx), dtype=torch.float32, device=dev, memory_format=torch.channels_last).zero_(),
             "cellmap": None if unique_cells else torch.full((n_agents * ny * nx,), -1, dtype=torch.int32, device=dev),
@@ -483,7 +485,8 @@ def pose_graph_optimize(vertex_offsets: torch.Tensor, edge_offsets: torch.Tensor
 
 CONV_KC, CONV_WSTRIDE = 8, 9 * 64 + 32      # kKC / kWStride of csrc/conv3x3.hip
 _CONV_WS: dict = {}
-_CONV_WS_RETIRED: list = []      # outgrown workspaces stay allocated: HIP graphs captured earlier on the lane still hold their raw pointers
+_CONV_WS_RETIRED: list = []      # outgrown workspaces stay allocated: HIP graphs captured earlier on the lane still hold their raw pointers.  Bounded: a
+                                 # workspace only grows when a LARGER shape arrives on its stream, i.e. at most once per distinct layer shape and stream.
 
 
 def _conv_workspace(key, ws_bytes: int, device) -> torch.Tensor:

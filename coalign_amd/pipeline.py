@@ -67,6 +67,8 @@ class _GraphSlot:
         self.weights_sig = None
         self.canvas_cache: dict = {}
         self.offsets: Optional[List[int]] = None        # points mode: first point slot of every cloud in the static input buffer
+        self.count_host: Optional[torch.Tensor] = None
+        self.capacity: Optional[int] = None             # bucket mode: pillar rows of the static input buffers (the frame's count sits in inputs["count"])
 
 
 class FramePipeline:
@@ -79,8 +81,13 @@ class FramePipeline:
     def __init__(self, model, post_processor: VoxelPostprocessor, anchor_box, *, lanes: int = 4, result_lag: int = 1,
                  graph: bool = False, device=None, transformation_matrix: Optional[torch.Tensor] = None,
                  exchange: Optional[Sequence[Callable]] = None, preprocessor=None, points_per_cloud: int = 131072,
-                 ego_filter: bool = True, filter_range: Optional[Sequence[float]] = None):
+                 ego_filter: bool = True, filter_range: Optional[Sequence[float]] = None, pillar_buckets: bool = True):
         self.model = model
+        self.pillar_buckets = bool(pillar_buckets)               # ragged from-pillars frames share a capacity-sized graph (see _bucket_seen below)
+        self._sig_tensors: Optional[list] = None                 # cached parameter / buffer list of _weights_signature
+        self._sig_age = 0
+        if hasattr(model, "register_load_state_dict_post_hook"):
+            model.register_load_state_dict_post_hook(lambda *_: setattr(self, "_sig_tensors", None))
         self._vfe_flag = None
         if hasattr(model, "pillar_vfe"):
             self._vfe_flag = model.pillar_vfe.persistent_canvas
@@ -106,11 +113,17 @@ class FramePipeline:
         self.pp.buffer_sets = max(int(getattr(self.pp, "buffer_sets", 2)), self.result_lag + 2)
         self._slots: List[Dict[tuple, _GraphSlot]] = [dict() for _ in range(self.n_lanes)]
         self.max_graphs_per_lane = 4                              # distinct input shapes kept captured per lane (oldest evicted)
+        # from-pillars frames whose pillar count changes from frame to frame (real data): the first shape a lane sees is captured exactly (a stream
+        # of equal shapes -- the bench pool -- keeps the graph that bakes its count); the SECOND different shape of the same capacity bucket (next
+        # power of two, >= 4096 rows) captures ONE graph with capacity-sized inputs and the count on the device (PillarVFE's voxel_count_dev
+        # form, cells not assumed unique), which then serves every other count of that bucket: ragged streams settle on <= 2 graphs per lane
+        self._bucket_seen: List[Dict[tuple, tuple]] = [dict() for _ in range(self.n_lanes)]
+        self.graphs_captured = 0
         self._lane_busy: List[Optional[int]] = [None] * self.n_lanes          # frame index whose result still sits in the lane's buffers
         self._pending: "collections.deque" = collections.deque()              # (index, handle, keep-alive)
         self._count = 0
         self.host_enqueue_s = 0.0
-        self.latencies_ms: List[float] = []                      # per collected frame: submit -> detections on the host
+        self.latencies_ms: "collections.deque" = collections.deque(maxlen=65536)      # per collected frame: submit -> detections on the host (bounded: a long-running service)
         # ---- submit_points: the voxeliser in front of the model
         self.preprocessor = preprocessor                          # coalign_amd.preprocess.SpVoxelPreprocessor (grid + voxel limits)
         self.points_per_cloud = int(points_per_cloud)             # slot size of one cloud in the staging buffer (NaN padded)
@@ -153,8 +166,10 @@ class FramePipeline:
         if slot.offsets is not None:
             batch = self._points_batch(slot.inputs["points"], slot.offsets, record, slot.inputs["pairwise_t_matrix"])
         else:
-            batch = {"processed_lidar": {k: slot.inputs[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")},
-                     "record_len": record, "pairwise_t_matrix": slot.inputs["pairwise_t_matrix"]}
+            pl = {k: slot.inputs[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")}
+            if slot.capacity is not None:                       # capacity-sized arrays, the frame's pillar count on the device
+                pl.update(voxel_count_dev=slot.inputs["count"], voxel_cells_unique=False)
+            batch = {"processed_lidar": pl, "record_len": record, "pairwise_t_matrix": slot.inputs["pairwise_t_matrix"]}
         vfe = getattr(self.model, "pillar_vfe", None)
         keep = None if vfe is None else (vfe.persistent_canvas, vfe.__dict__.get("_canvas_cache"))
         try:
@@ -186,6 +201,17 @@ class FramePipeline:
                    "pairwise_t_matrix": batch["pairwise_t_matrix"]}
         key = (tuple(record), None if offsets is None else tuple(offsets)) + tuple((tuple(t.shape), str(t.dtype)) for t in src.values())
         slot = self._slots[k].get(key)
+        M = cap = None
+        if offsets is None and slot is None and self.pillar_buckets:
+            M = int(src["voxel_features"].shape[0])
+            cap = max(4096, 1 << max(M - 1, 0).bit_length())
+            bkey = (tuple(record), "bucket", cap, tuple(src["voxel_features"].shape[1:]), tuple(src["pairwise_t_matrix"].shape))
+            first = self._bucket_seen[k].setdefault(bkey, key)
+            if bkey in self._slots[k] or first != key:           # a second shape of this bucket: the capacity-sized graph from here on
+                key = bkey
+                slot = self._slots[k].get(key)
+            else:
+                cap = None                                       # first shape of its bucket: exact capture
         # a graph holds raw pointers to the folded / packed weight images of the moment it was captured: re-capture when any
         # parameter or buffer of the model has been replaced or written since (load_state_dict, fine-tuning between runs)
         sig = self._weights_signature()
@@ -198,18 +224,32 @@ class FramePipeline:
             slot = _GraphSlot()
             slot.weights_sig = sig
             slot.offsets = None if offsets is None else list(offsets)
+            slot.capacity = cap
             for name, t in src.items():
-                slot.inputs[name] = torch.empty(t.shape, dtype=t.dtype, device=self.device)
-                slot.inputs[name].copy_(t, non_blocking=True)
+                rows = cap if (cap is not None and name != "pairwise_t_matrix") else t.shape[0]
+                slot.inputs[name] = torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+                slot.inputs[name][: t.shape[0]].copy_(t, non_blocking=True)
+            if cap is not None:
+                slot.inputs["count"] = torch.full((1,), M, dtype=torch.int32, device=self.device)
+                slot.count_host = torch.zeros(1, dtype=torch.int32).pin_memory()      # (a 4-byte copy per frame, not a fill kernel)
             self._frame_body(slot, record)                      # eager warm-up on the lane: MIOpen find, weight folds, anchors, buffers
             stream.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream):
                 self._frame_body(slot, record)
             slot.graph = g
+            self.graphs_captured += 1
             self._slots[k][key] = slot                          # only a slot whose capture succeeded is ever looked up again
-        for name, t in src.items():
-            slot.inputs[name].copy_(t, non_blocking=True)
+        if slot.capacity is not None:
+            if M is None:
+                M = int(src["voxel_features"].shape[0])
+            for name, t in src.items():
+                slot.inputs[name][: t.shape[0]].copy_(t, non_blocking=True)      # rows beyond the count are never read
+            slot.count_host[0] = M
+            slot.inputs["count"].copy_(slot.count_host, non_blocking=True)
+        else:
+            for name, t in src.items():
+                slot.inputs[name].copy_(t, non_blocking=True)
         if offsets is not None:
             self._staged[k] = torch.cuda.Event()
             self._staged[k].record(stream)                      # the pinned staging buffer may be refilled once this has passed
@@ -219,8 +259,14 @@ class FramePipeline:
         return PostProcessHandle(self.pp, slot.buf, done)
 
     def _weights_signature(self) -> tuple:
-        # rebuilt on every call: parameters replaced as objects (load_state_dict(assign=True), module surgery) change the list itself
-        return tuple((id(t), t.data_ptr(), t._version) for t in list(self.model.parameters()) + list(self.model.buffers()))
+        # The tensor list is cached (walking the module tree on every frame cost ~50 us of host time): it is rebuilt after a load_state_dict (hook),
+        # and every 256 frames anyway -- parameters replaced as objects by module surgery change the list itself; in-place writes and storage
+        # swaps of the cached tensors show in (data_ptr, _version) at once.
+        self._sig_age += 1
+        if self._sig_tensors is None or self._sig_age >= 256:
+            self._sig_tensors = list(self.model.parameters()) + list(self.model.buffers())
+            self._sig_age = 0
+        return tuple((id(t), t.data_ptr(), t._version) for t in self._sig_tensors)
 
     # ------------------------------------------------------------------------------------------------ the loop
     def submit_points(self, frame: dict) -> List[FrameResult]:

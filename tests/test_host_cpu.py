@@ -443,3 +443,18 @@ def test_xcd_order_of_the_convolution_workgroups_is_a_permutation():
             if k and mine:
                 prev = [ids[b] for b in range(k - 1, n, 8)]
                 assert prev[-1] + 1 == mine[0], (n, k)
+
+
+def test_product_library_reads_no_laboratory_switch():
+    """ablation / debug / geometry switches live behind -DCOALIGN_LAB (coalign_amd/build.py --lab, loaded with COALIGN_LAB=1 by
+    tools/ and the variant tests).  The PRODUCT library contains the names of exactly two environment variables -- the documented encoder / legacy
+    selectors -- and the laboratory library contains the experiment switches."""
+    import re
+    from coalign_amd import build
+    names = lambda path: set(re.findall(rb"COALIGN_[A-Z0-9_]+", open(path, "rb").read()))
+    status = {b"COALIGN_OK", b"COALIGN_ERR_BAD_SHAPE", b"COALIGN_ERR_HIP", b"COALIGN_ERR_NULL_POINTER", b"COALIGN_ERR_UNSUPPORTED", b"COALIGN_ERR_WORKSPACE"}
+    assert names(build.LIB_PATH) - status == {b"COALIGN_PILLAR_MFMA", b"COALIGN_NMS_LEGACY"}
+    if not os.path.exists(build.LAB_LIB_PATH):
+        build.build(lab=True)
+    lab = names(build.LAB_LIB_PATH)
+    assert {b"COALIGN_EMU_STACK", b"COALIGN_EMU_TAPK_ROWS", b"COALIGN_PILLAR_DEBUG", b"COALIGN_WINO_ABL", b"COALIGN_PW_PB"} <= lab

@@ -393,14 +393,14 @@ sys.exit(0 if worst <= 5e-6 else 1)
 """
 
 
-@pytest.mark.parametrize("env", [{"COALIGN_EMU_PC": "1"}, {"COALIGN_EMU_PC": "1", "COALIGN_EMU_PC_ROWS": "12"}, {"COALIGN_EMU_GEO": "84"}, {"COALIGN_EMU_TAPK_VAR": "1"},
-                                 {"COALIGN_EMU_TAPK_ROWS": "8"}, {"COALIGN_EMU_TAPK_ROWS": "12"}, {"COALIGN_EMU_TAPK_ROWS": "26"}, {"COALIGN_EMU_TAPK_26": "0"}, {"COALIGN_EMU_PRIO": "1"}, {"COALIGN_EMU_S2_ASM": "1"}, {"COALIGN_EMU_S2_ASM": "0"}])
+@pytest.mark.parametrize("env", [{"COALIGN_EMU_GEO": "84"}, {"COALIGN_EMU_TAPK_ROWS": "8"}, {"COALIGN_EMU_TAPK_ROWS": "12"}, {"COALIGN_EMU_TAPK_ROWS": "26"}, {"COALIGN_EMU_TAPK_26": "0"},
+                                 {"COALIGN_EMU_PRIO": "1"}, {"COALIGN_EMU_XCD": "0"}])
 def test_conv3x3_emu_kernel_variants_in_a_subprocess(env):
-    """The kernel variants of the split-bf16 convolution that an environment switch selects at library load (the producer / consumer
-    kernel, the asm-issued weight DMA on the tap-pair image, the tap-major image with the builtin DMA or a forced tile height, the strict
-    inter-workgroup priority): each against the fp64 convolution (5e-6 of the output scale) in its own process, both weight images,
-    NCHW and channels-last output, residual / ReLU, ragged maps, determinism."""
+    """The kernel variants of the split-bf16 convolution the LABORATORY build selects by environment switch (COALIGN_LAB=1 loads it; the product
+    library reads none of them): the asm-issued weight DMA on the tap-pair image, forced tile heights on the tap-major image, the strict
+    inter-workgroup priority, the plain workgroup order: each against the fp64 convolution (5e-6 of the output scale) in its own process, both
+    weight images, NCHW and channels-last output, residual / ReLU, ragged maps, determinism."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", _VARIANT_CHECK], env=dict(os.environ, PYTHONPATH=root, **env), capture_output=True, text=True, timeout=600, cwd=root)
+    r = subprocess.run([sys.executable, "-c", _VARIANT_CHECK], env=dict(os.environ, PYTHONPATH=root, COALIGN_LAB="1", **env), capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-800:])

@@ -126,3 +126,39 @@ def test_fp16_mode_saturates_instead_of_overflowing():
     got = ops.conv3x3_emu_bias_act(x.to(DEV), ops.pack_conv3x3_emu_weight(w.to(DEV), 16, True), b.to(DEV), Co, None, False, 16)
     assert torch.isfinite(got).all()
     assert float((got.double().cpu() - want).abs().max() / want.abs().max()) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------- ragged frames, capacity buckets
+def test_ragged_pillar_counts_share_a_capacity_sized_graph():
+    """50 frames of 50 different pillar counts through the HIP-graph pipeline capture at most two graphs per lane (the first shape
+    exactly, then one capacity-sized graph with the count on the device), and every frame's detections equal the eager pipeline's."""
+    from coalign_amd.config import builtin_config
+    from coalign_amd.detector import build_model, to_device
+    from coalign_amd.pipeline import FramePipeline
+    from coalign_amd.postprocess import build_postprocessor
+    from coalign_amd.synthetic import fill_parameters_, make_frame
+    h = builtin_config("mini_coalign")
+    model = build_model(h)
+    fill_parameters_(model, seed=0, cls_bias=-1.0)
+    with torch.no_grad():
+        model.reg_head.weight.mul_(0.01); model.reg_head.bias.zero_(); model.cls_head.weight.mul_(0.05)
+    model = model.to(DEV).eval()
+    pp = build_postprocessor(h["postprocess"], False)
+    anchors = torch.from_numpy(pp.generate_anchor_box())
+    frames = [to_device(make_frame(h, 3, pillars_per_agent=120 + 3 * i, seed=10 + i, spread_xy=(4.0, 2.0), spread_yaw=45.0), DEV) for i in range(50)]
+    assert len({int(f["processed_lidar"]["voxel_features"].shape[0]) for f in frames}) == 50
+    eager = FramePipeline(model, pp, anchors, lanes=2, result_lag=1, graph=False, device=DEV)
+    want = eager.run(frames)
+    eager.close()
+    pipe = FramePipeline(model, build_postprocessor(h["postprocess"], False), anchors, lanes=2, result_lag=1, graph=True, device=DEV)
+    got = pipe.run(frames)
+    assert pipe.graphs_captured <= 2 * 2, pipe.graphs_captured
+    assert all(len(d) <= 2 for d in pipe._slots)
+    pipe.close()
+    n_det = 0
+    for (b0, s0), (b1, s1) in zip(want, got):
+        assert (b0 is None) == (b1 is None)
+        if b0 is not None:
+            assert torch.equal(b0, b1) and torch.equal(s0, s1)
+            n_det += b0.shape[0]
+    assert n_det > 50
