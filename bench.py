@@ -76,8 +76,8 @@ def kernel_trace_us():
     """Average kernel durations (us) of the pillar op and the fusion from the committed rocprofv3 --kernel-trace --stats summary of
     tools/kernels_only.py (same workload as the roofline figures): an independent clock beside the HIP events."""
     import csv
-    path = os.path.join(ROOT, "profiles", "round3", "kernels_isolated_stats.csv")
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", r, "kernels_isolated_stats.csv") for r in ("round4", "round3")) if os.path.exists(q)), "")
+    if not path:
         return None
     out = {}
     for r in csv.DictReader(open(path)):
@@ -108,6 +108,79 @@ def graph_time(fn, dev, iters=10):
     return hip_time(g.replay, iters=iters)
 
 
+def pillar_bytes_moved(M):
+    """Bytes the persistent-canvas pillar op moves per call (the timed configuration; no dense zero-fill): per pillar 532 B in (32 x 16 B points +
+    16 B coordinates + 4 B count), 256 B feature row + 256 B canvas row out, 256 B to clear the row the previous frame wrote, 12 B of slot list / cell map."""
+    return M * (532 + 256 + 256 + 256 + 12)
+
+
+def size_sweep(dev, steps=20):
+    """VERDICT r03 item 3 / SURVEY 8d: the HBM-bound ops where the roofline bites.  Pillar op at M in {8000, 32000, 70000} pillars per agent
+    (max_voxel_train / max_voxel_test of pointpillar_coalign.yaml:52-54) x 5 agents, at N = 2 (cfg 2) and at DAIR-V2X geometry 504 x 200 (cfg 4);
+    the fusion launch per geometry / agent count; whole-path frames/s for cfg 2 and cfg 4.  Times: HIP events around graph replays of the op's
+    launches (as `north_star_hbm`); `frac` = model bytes / time / 8 TB/s -- algorithmic, per launch; PMC traffic lives in profiles/."""
+    out = []
+    cases = [("opv2v_coalign", 5, 8000, False), ("opv2v_coalign", 5, 32000, False), ("opv2v_coalign", 5, 70000, False),
+             ("opv2v_coalign", 2, 8000, True), ("dairv2x_coalign", 2, 8000, True)]
+    models = {}
+    for cfg, n, m, whole in cases:
+        try:
+            hy = builtin_config(cfg)
+            nx, ny, _ = [int(v) for v in hy["model"]["args"]["point_pillar_scatter"]["grid_size"]]
+            if cfg not in models:
+                mdl = build_model(hy)
+                fill_parameters_(mdl, seed=0)
+                models[cfg] = mdl.to(dev).eval()
+            mdl = models[cfg]
+            fr = to_device(make_frame(hy, n, pillars_per_agent=m, seed=303, noise=(0.2, 0.2), infra_agent=cfg.startswith("dair")), dev)
+            fr["record_len"] = [n]
+            M = int(fr["processed_lidar"]["voxel_features"].shape[0])
+            pl_in = dict(fr["processed_lidar"], record_len=[n])
+            keep = mdl.pillar_vfe.persistent_canvas
+            mdl.pillar_vfe.persistent_canvas = True
+            with torch.no_grad():
+                t_p = graph_time(lambda: mdl.pillar_vfe(dict(pl_in)), dev)
+                feats, aff = mdl.encode(fr)
+                t_f = graph_time(lambda: mdl._fuse_scales(list(feats), [n], aff), dev)
+            mdl.pillar_vfe.persistent_canvas = keep
+            fb = sum((n + 1) * int(f.shape[1]) * int(f.shape[2]) * int(f.shape[3]) * 4 for f in feats)
+            pb = pillar_bytes_moved(M)
+            row = {"config": cfg, "canvas": [nx, ny], "agents": n, "pillars_per_agent": m,
+                   "pillar_op": {"us": round(t_p * 1e3, 2), "bytes_moved_model": pb, "GBps": round(pb / t_p / 1e6, 1), "frac": round(pb / t_p / 1e6 / HBM_PEAK_GBPS, 4),
+                                 "read_bytes_survey_8d": M * 532, "frac_read_only": round(M * 532 / t_p / 1e6 / HBM_PEAK_GBPS, 4)},
+                   "fusion": {"us": round(t_f * 1e3, 2), "algorithmic_bytes": fb, "GBps": round(fb / t_f / 1e6, 1), "frac": round(fb / t_f / 1e6 / HBM_PEAK_GBPS, 4)},
+                   "path_frac": round((pb + fb) / (t_p + t_f) / 1e6 / HBM_PEAK_GBPS, 4)}
+            del feats, aff
+            if whole:
+                pp = build_postprocessor(hy["postprocess"], False)
+                anchors = torch.from_numpy(pp.generate_anchor_box())
+                pool = [fr] + [dict(to_device(make_frame(hy, n, pillars_per_agent=m, seed=304 + i, noise=(0.2, 0.2), infra_agent=cfg.startswith("dair")), dev), record_len=[n]) for i in range(3)]
+                import copy
+                mc = copy.deepcopy(mdl)
+                calibrate_heads_(mc, pool[0], pp.params["target_args"]["score_threshold"], 600)
+                pipe = FramePipeline(mc, pp, anchors, lanes=3, result_lag=1, graph=True, device=dev)
+                for i in range(8):
+                    pipe.submit(pool[i % 4])
+                pipe.drain(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = []
+                for i in range(steps):
+                    res += pipe.submit(pool[i % 4])
+                res += pipe.drain(); torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                row["whole_path"] = {"frames_per_s": round(steps / dt, 2), "ms_per_frame": round(dt / steps * 1e3, 4), "frames_in_flight": 3, "hip_graph": True,
+                                     "detections_last_frame": 0 if res[-1][1] is None else int(res[-1][1].shape[0])}
+                pipe.close()
+                del mc, pipe
+            out.append(row)
+            del fr
+            torch.cuda.empty_cache()
+        except Exception as e:      # noqa: BLE001  a side report must never cost the headline line
+            out.append({"config": cfg, "agents": n, "pillars_per_agent": m, "error": f"{type(e).__name__}: {str(e)[:200]}"})
+            torch.cuda.synchronize()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +203,7 @@ def main():
                     "voxeliser + encoder in every frame: `from_points` in the JSON line; `value` stays the from-pillars metric of BASELINE.json); on by default at --gpus 1")
     ap.add_argument("--no-from-points", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-frame-in-flight latency pass")
+    ap.add_argument("--no-size-sweep", action="store_true", help="skip the `size_sweep` report (pillar op / fusion at 8 000 / 32 000 / 70 000 pillars per agent, cfg 2, cfg 4)")
     ap.add_argument("--mode", choices=("ring", "gather"), default="ring", help="multi-GPU schedule: 'ring' = one frame per rank and step, agents routed by all-to-all "
                     "(weak scaling, the default); 'gather' = ONE frame per step, rank r encodes its block of the agents, one all-gather per scale, every rank then "
                     "holds all maps and runs the ego tail (north_star's one-agent-per-GPU wording; strong scaling of a single frame)")
@@ -206,34 +280,70 @@ def main():
     n_lanes = args.lanes if args.lanes > 0 else (3 if use_graph else 4)
     rings = None
     exchanges = None
-    if world > 1:
+    mode = args.mode
+    rccl = None
+    ctl = None
+
+    def agree(ok: bool) -> bool:
+        """All ranks take the same fall-back decision, over a gloo control group that does not depend on the data-plane backend."""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=ctl)
+        return bool(int(t.item()))
+
+    def setup_mode(m):
+        """-> (rings, exchanges, step_batches) of schedule m in {"ring", "gather", "replicas"}."""
         # ONE communicator for all lanes by default: every rank issues its collectives in frame order (frame i -> lane i mod lanes, the
         # exchange enqueued inside submit()), so a single RCCL communicator sees the same sequence everywhere -- deadlock-free by
-        # construction; the lanes' exchanges then serialise on the communicator's stream (0.1 ms each against ~3.7 ms of compute).
+        # construction; the lanes' exchanges then serialise on the communicator's stream (0.1 ms each against ~2 ms of compute).
         # --comm-per-lane restores one communicator per lane (concurrent use of several communicators is documented as deadlock-prone).
+        if m == "replicas":       # no collective at all: every rank runs whole frames out of the common pool (rank r starts at frame r)
+            return None, None, [frames[(i + rank) % len(frames)] for i in range(len(frames))]
         groups = [dist.new_group(backend=backend) for _ in range(n_lanes)] if args.comm_per_lane else [None] * n_lanes
         by_agent = [split_agents(f) for f in frames]
-        if args.mode == "ring":
-            rings = [FrameRing(N, group=g) for g in groups]
-            exchanges = [r.exchange for r in rings]
+        if m == "ring":
+            rs = [FrameRing(N, group=g) for g in groups]
             period = pool_n // world
-            step_batches = [ring_batch(by_agent, [f["pairwise_t_matrix"] for f in frames], rank, world, N, s) for s in range(period)]
-        else:
-            # gather mode: every step is ONE frame; this rank encodes its contiguous block of the agents (empty slots where the block runs past
-            # N), the per-scale maps are all-gathered, and the ego tail runs with all N agents (on every rank: same latency, rank 0 reports)
-            gathers = [AgentGather(N, group=g) for g in groups]
-            rings = gathers
-            exchanges = [(lambda feats, _g=g: (_g.gather(feats), None)) for g in gathers]
-            per = gathers[0].per
-            mine = list(gathers[0].local_agents())
-            step_batches = []
-            for g_, f in enumerate(frames):
-                sets = [by_agent[g_][a] if a < N else None for a in range(rank * per, rank * per + per)]
-                if all(s_ is None for s_ in sets):       # a rank without agents still takes part in the collective: one empty slot set
-                    sets = [{k: v[:0] for k, v in by_agent[g_][0].items()}] + [None] * (per - 1)
-                step_batches.append({"processed_lidar": stack_agents(sets), "record_len": [per], "tail_record_len": [N],
-                                     "pairwise_t_matrix": f["pairwise_t_matrix"]})
-        del by_agent
+            return rs, [r.exchange for r in rs], [ring_batch(by_agent, [f["pairwise_t_matrix"] for f in frames], rank, world, N, s) for s in range(period)]
+        # gather mode: every step is ONE frame; this rank encodes its contiguous block of the agents (empty slots where the block runs past
+        # N), the per-scale maps are all-gathered, and the ego tail runs with all N agents (on every rank: same latency, rank 0 reports)
+        gathers = [AgentGather(N, group=g) for g in groups]
+        per = gathers[0].per
+        sb = []
+        for g_, f in enumerate(frames):
+            sets = [by_agent[g_][a] if a < N else None for a in range(rank * per, rank * per + per)]
+            if all(s_ is None for s_ in sets):       # a rank without agents still takes part in the collective: one empty slot set
+                sets = [{k: v[:0] for k, v in by_agent[g_][0].items()}] + [None] * (per - 1)
+            sb.append({"processed_lidar": stack_agents(sets), "record_len": [per], "tail_record_len": [N], "pairwise_t_matrix": f["pairwise_t_matrix"]})
+        return gathers, [(lambda feats, _g=g: (_g.gather(feats), None)) for g in gathers], sb
+
+    if world > 1:
+        # ---- first contact with RCCL, hardened (VERDICT r03 item 6; the reference's own bring-up: opencood/tools/multi_gpu_utils.py:31-37).
+        #      (1) who is here: every rank's device over the control group; (2) one small all-gather on the data plane; (3) the chosen schedule is
+        #      warmed up inside try / except on every rank and the ranks agree on the outcome: ring -> gather -> independent replicas.
+        ctl = dist.new_group(backend="gloo")
+        props = torch.cuda.get_device_properties(dev)
+        me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(dev), "uuid": str(getattr(props, "uuid", "")),
+              "pci_bus_id": getattr(props, "pci_bus_id", None), "host": os.uname().nodename}
+        seen = [None] * world
+        dist.all_gather_object(seen, me, group=ctl)
+        ok = True
+        try:
+            if backend == "nccl":
+                t = torch.full((4,), rank, dtype=torch.int32, device=dev)
+                o = torch.empty(4 * world, dtype=torch.int32, device=dev)
+                dist.all_gather_into_tensor(o, t)
+                torch.cuda.synchronize()
+                ok = o.view(world, 4)[:, 0].cpu().tolist() == list(range(world))
+        except Exception as e:      # noqa: BLE001
+            print(f"bench[{rank}]: data-plane all-gather failed: {type(e).__name__}: {str(e)[:200]}", file=sys.stderr, flush=True)
+            ok = False
+        rccl = {"world": world, "backend": "RCCL" if backend == "nccl" else backend, "ranks_seen": seen,
+                "distinct_devices": len({(d["host"], d["uuid"] or d["pci_bus_id"] or d["local_rank"]) for d in seen}), "data_plane_all_gather_ok": agree(ok),
+                "requested_mode": args.mode, "fallbacks": []}
+        if not rccl["data_plane_all_gather_ok"]:
+            mode = "replicas"
+            rccl["fallbacks"].append("data-plane all-gather failed -> replicas")
+        rings, exchanges, step_batches = setup_mode(mode)
     else:
         step_batches = frames
     torch.backends.cudnn.benchmark = not args.no_miopen_find     # MIOpen find during warm-up for whatever still runs on it
@@ -255,7 +365,7 @@ def main():
         pipe.drain()
         sync()
         pipe.host_enqueue_s = 0.0
-        pipe.latencies_ms = []               # submit -> detections on the host, per frame of the timed loop
+        pipe.latencies_ms.clear()            # submit -> detections on the host, per frame of the timed loop
         results = []
         base = pipe._count                   # frame indices of the results below are made relative to the timed loop
         t0 = time.perf_counter()
@@ -268,6 +378,44 @@ def main():
 
     pipe = make_pipe(use_graph)
     warm = max(args.warmup, 2 * n_lanes if use_graph else args.warmup)     # every lane captures its graph during the warm-up
+    if world > 1:
+        # the chosen schedule's first exchanges, guarded: any error on any rank moves ALL ranks to the next schedule (ring -> gather -> replicas)
+        while True:
+            ok = True
+            try:
+                for s_ in range(n_lanes):
+                    pipe.submit(step_batches[s_ % len(step_batches)])
+                pipe.drain()
+                torch.cuda.synchronize()
+            except Exception as e:      # noqa: BLE001
+                print(f"bench[{rank}]: schedule '{mode}' failed in its first exchanges: {type(e).__name__}: {str(e)[:200]}", file=sys.stderr, flush=True)
+                ok = False
+            if agree(ok) or mode == "replicas":
+                break
+            nxt = "gather" if mode == "ring" else "replicas"
+            rccl["fallbacks"].append(f"{mode} failed in its first exchanges -> {nxt}")
+            mode = nxt
+            try:
+                torch.cuda.synchronize()
+            except Exception:      # noqa: BLE001
+                pass
+            rings, exchanges, step_batches = setup_mode(mode)
+            pipe = make_pipe(False)
+        rccl["mode_run"] = mode
+        # what one exchange costs on this node: the feature maps of one step through the schedule's collective, HIP events, max over ranks
+        if exchanges is not None:
+            try:
+                with torch.no_grad():
+                    feats_x, _ = model.encode(step_batches[0])
+                    ex_ms = hip_time(lambda: exchanges[0](list(feats_x)), iters=5, warm=2)
+                t = torch.tensor([ex_ms], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+                rccl["exchange_ms_per_frame"] = round(float(t.item()), 4)
+                rccl["bytes_sent_per_rank_per_exchange"] = int(rings[0].bytes_sent_last)
+                rccl["bytes_per_agent_fp32"] = int(sum(f.numel() // max(f.shape[0], 1) for f in feats_x) * 4)
+                del feats_x
+            except Exception as e:      # noqa: BLE001
+                rccl["exchange_timing_error"] = f"{type(e).__name__}: {str(e)[:160]}"
     if use_graph:       # a capture that fails here (driver / allocator state of this box) must not cost the bench line: fall back to eager
         try:
             for s_ in range(n_lanes):
@@ -334,7 +482,7 @@ def main():
     # ---- per-frame detection digests: pool frame -> digest; every recurrence of a pool frame must reproduce it exactly
     digests, consistent, mismatches = {}, True, []
     for idx, boxes, scores in results[-min(len(results), 2 * pool_n):]:
-        g = (idx * world + rank) % pool_n if (world > 1 and args.mode == "ring") else idx % pool_n
+        g = (idx * world + rank) % pool_n if (world > 1 and mode == "ring") else (idx + rank) % pool_n if (world > 1 and mode == "replicas") else idx % pool_n
         d = checksum(boxes, scores)
         if digests.setdefault(g, d) != d:
             consistent = False
@@ -444,7 +592,7 @@ def main():
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        frames_per_step = world if args.mode == "ring" else 1        # gather mode: the ranks share ONE frame per step
+        frames_per_step = world if mode in ("ring", "replicas") else 1        # gather mode: the ranks share ONE frame per step
         fps = frames_per_step * args.steps / dt
         M = int(frames[0]["processed_lidar"]["voxel_features"].shape[0])
         scales = [(64, ny // 2, nx // 2), (128, ny // 4, nx // 4), (256, ny // 8, nx // 8)]
@@ -470,10 +618,8 @@ def main():
         # reads = 2 x FETCH_SIZE (gfx950 tallies the 128-B requests of 16 B/lane streaming loads at 64 B, MI355X_MICROARCH.md
         # "HBM"), writes = WRITE_SIZE; null when no summary is committed for this workload
         pmc, pmc_src = {}, None
-        path = os.path.join(ROOT, "profiles", "round3", "pmc_summary.json")
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", "round2", "pmc_summary.json")
-        if os.path.exists(path) and N == 5 and args.pillars == 8000 and args.config == "opv2v_coalign":
+        path = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_summary.json") for r in ("round4", "round3", "round2")) if os.path.exists(q)), "")
+        if path and N == 5 and args.pillars == 8000 and args.config == "opv2v_coalign":
             pmc, pmc_src = json.load(open(path)), os.path.relpath(path, ROOT)
 
         def traffic_of(op):
@@ -490,14 +636,18 @@ def main():
             return e
 
         persistent = default_terms in (2, 3, 16)
-        # bytes the persistent-canvas pillar op has to move per call (what the timed configuration does; no dense zero-fill): per pillar
-        # 532 B in, 256 B feature row + 256 B canvas row out, 256 B to clear the row the previous frame wrote, 12 B of slot list / cell map
-        pillar_moved_model = M * (532 + 256 + 256 + 256 + 12)
+        # ---- north star: the pillar-scatter + warp path against the HBM roofline.  ADVICE r03: `frac` = ALGORITHMIC bytes / time measured in this
+        #      run, nothing else; HBM traffic from the committed rocprofv3 --pmc passes is reported beside it (`traffic`), never mixed into `frac`.
+        #      Algorithmic bytes of the pillar op = what the timed configuration has to move per call (pillar_bytes_moved: the persistent canvas
+        #      writes and clears rows, never a dense zero-fill); SURVEY 8d's formula, which counts a dense canvas write, is `frac_survey_8d_formula`
+        #      beside the time of the SAME path with a freshly zero-filled canvas per call (rounds 1-2 reported that one).
+        pillar_alg = pillar_bytes_moved(M) if persistent else alg_bytes["pillar_vfe_scatter"]
         pillar = hbm_entry("pillar_vfe_scatter = pillar_prep_kernel + pillar_rows_mx_kernel (persistent channels-last canvas: only the previous frame's rows are cleared)" if persistent
-                           else "pillar_vfe_scatter = memset + cellmap_kernel + pillar_canvas_kernel", iso["pillar_ms"],
-                           pillar_moved_model if persistent else alg_bytes["pillar_vfe_scatter"],
+                           else "pillar_vfe_scatter = memset + cellmap_kernel + pillar_canvas_kernel", iso["pillar_ms"], pillar_alg,
                            traffic_of("pillar_nhwc_persistent" if persistent else "pillar_nchw"), "pillar_vfe_scatter")
         pillar["survey_8d_formula_bytes"] = alg_bytes["pillar_vfe_scatter"]
+        pillar["read_bytes"] = M * 532
+        pillar["frac_read_only"] = round(M * 532 / iso["pillar_ms"] / 1e6 / HBM_PEAK_GBPS, 4)
         north = {"target": 0.40, "pillar_vfe_scatter": pillar}
         if "pillar_fresh_canvas_ms" in iso:
             north["pillar_vfe_scatter_fresh_canvas"] = hbm_entry("pillar_vfe_scatter on a fresh canvas = canvas memset + cell-map memset + cellmap_kernel + pillar_rows_mx_kernel",
@@ -510,23 +660,25 @@ def main():
                              iso["fuse_ms"], fuse_bytes, traffic_of("fuse_nhwc_3scales") if persistent else None)
             north["warp_fuse_all_scales"] = fuse
             tot_ms = iso["pillar_ms"] + iso["fuse_ms"]
-            # `frac`: bytes REALLY moved (PMC traffic where a summary of this round is committed, else the per-pillar model above) / time
-            moved = (pillar["traffic"] or pillar["algorithmic_bytes_per_launch"]) + (fuse["traffic"] or fuse_bytes)
-            north.update({"frac": round(moved / tot_ms / 1e6 / HBM_PEAK_GBPS, 4), "achieved": round(moved / tot_ms / 1e6, 1), "unit": "GB/s",
-                          "bytes_moved": moved, "bytes_source": "rocprofv3 --pmc (corrected)" if pillar["traffic"] and fuse["traffic"] else "model (no PMC summary of this round for this workload)",
-                          "ms": round(tot_ms, 5)})
+            alg = pillar_alg + fuse_bytes
+            north.update({"frac": round(alg / tot_ms / 1e6 / HBM_PEAK_GBPS, 4), "achieved": round(alg / tot_ms / 1e6, 1), "unit": "GB/s",
+                          "algorithmic_bytes": alg, "ms": round(tot_ms, 5)})
+            if pillar["traffic"] and fuse["traffic"]:      # the committed PMC passes of this workload (may predate a kernel change: see its README)
+                north["traffic"] = pillar["traffic"] + fuse["traffic"]
+                north["traffic_over_algorithmic"] = round(north["traffic"] / alg, 3)
+                north["traffic_source"] = pmc_src
             if ktrace and "pillar_op_us" in ktrace and "fuse_us" in ktrace:      # the same bytes over the kernel durations of the committed rocprofv3 trace
-                north["frac_kernel_trace"] = round(moved / ((ktrace["pillar_op_us"] + ktrace["fuse_us"]) * 1e-3) / 1e6 / HBM_PEAK_GBPS, 4)
-            if "pillar_fresh_canvas_ms" in iso:      # SURVEY 8d's formula (dense canvas write counted) only where a dense canvas is really written
+                north["frac_kernel_trace"] = round(alg / ((ktrace["pillar_op_us"] + ktrace["fuse_us"]) * 1e-3) / 1e6 / HBM_PEAK_GBPS, 4)
+            if "pillar_fresh_canvas_ms" in iso:      # SURVEY 8d's formula (dense canvas write counted) where a dense canvas is really written
                 tot_b = alg_bytes["pillar_vfe_scatter"] + fuse_bytes
-                north["frac_fresh_canvas"] = round(tot_b / (iso["pillar_fresh_canvas_ms"] + iso["fuse_ms"]) / 1e6 / HBM_PEAK_GBPS, 4)
+                north["frac_survey_8d_formula"] = round(tot_b / (iso["pillar_fresh_canvas_ms"] + iso["fuse_ms"]) / 1e6 / HBM_PEAK_GBPS, 4)
         else:
             north.update({"frac": pillar["frac"], "note": "fusion timing failed: " + iso.get("fuse_error", "?")})
         north["note"] = ("north_star: >= 40 % of the HBM roofline on the pillar-scatter + warp path.  Each part alone on the GPU (HIP events around "
-                         "10 replays of a HIP graph of the op's launches, right before the timed region).  `frac` = bytes the timed configuration really "
-                         f"moves / time / 8 TB/s: corrected PMC traffic ({pmc_src}) -- the persistent canvas writes no dense zero-fill, so SURVEY 8d's formula "
-                         "(which counts one) is used only in `frac_fresh_canvas`, the same path with a freshly zero-filled canvas per call; "
-                         "`frac_kernel_trace` = the same bytes over the kernel durations of the committed rocprofv3 trace (profiles/round3/kernels_isolated_stats.csv)")
+                         "10 replays of a HIP graph of the op's launches, right before the timed region).  `frac` = algorithmic bytes of the timed "
+                         "configuration / time of this run / 8 TB/s; `traffic` = corrected PMC bytes of the committed profile, reported separately; "
+                         "`frac_survey_8d_formula` = SURVEY 8d's byte formula over the same path with a freshly zero-filled canvas per call; "
+                         "`size_sweep` repeats the figures at 32 000 / 70 000 pillars per agent, N = 2 and DAIR geometry")
 
         # `roofline` = the hand-written kernel the frame spends most of its time in: the 3x3 convolution of the active arithmetic
         if default_terms in (2, 3, 16):
@@ -558,13 +710,14 @@ def main():
         result = {
             "metric": "frames_per_s_5agent_opv2v_synthetic", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": warm, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-            "scaling": "weak" if args.mode == "ring" else "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "scaling": "weak" if mode in ("ring", "replicas") else "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"OPV2V PointPillar + CoAlign multiscale attention fusion ({args.config}.yaml, BASELINE configs[2] "
                                    f"geometry): {N} agents/frame, {args.pillars} pillars/agent, canvas {nx}x{ny}, 70400 anchors, "
                                    f"full path incl. decode + rotated NMS, {pool_n} distinct frames in rotation",
                        "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": frames_per_step, "frames_in_flight": n_lanes,
                        "result_lag_frames": pipe.result_lag, "hip_graph": use_graph, "conv_arithmetic": "native fp32" if default_terms == 0 else "fp16x2" if default_terms == 16 else f"bf16x{default_terms}",
-                       "parallelism": "single GPU" if world == 1 else (f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all" if args.mode == "ring" else
+                       "parallelism": "single GPU" if world == 1 else (f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all" if mode == "ring" else
+                                                                                      f"{world} independent replicas, no collective (fall-back: see `rccl.fallbacks`)" if mode == "replicas" else
                                                                                       f"one frame over {world} ranks (agent blocks), {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-gather, ego tail on every rank") +
                                        (", one communicator per lane" if args.comm_per_lane else ", one communicator"),
                        "detections_last_frame": 0 if last_boxes is None else int(last_boxes.shape[0]),
@@ -576,12 +729,19 @@ def main():
         }
         if rings is not None:
             result["exchange_bytes_sent_per_rank_per_step"] = rings[0].bytes_sent_last
+        if rccl is not None:
+            result["rccl"] = rccl
         if latency is not None:
             result["latency_ms"] = latency
         if from_points is not None:
             result["from_points"] = from_points
         if side is not None:
             result["other_modes"] = side
+        if world == 1 and not args.no_size_sweep:
+            pipe.close()
+            del pipe
+            torch.cuda.empty_cache()
+            result["size_sweep"] = size_sweep(dev)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(hypes, model, frames_cpu, anchors, args.cpu_frames, args.cpu_threads, args.cpu_budget_s)
         print(json.dumps(result), flush=True)

@@ -57,3 +57,12 @@ extern "C" int coalign_bias_act(float *y, const float *bias, const float *residu
     else hipLaunchKernelGGL(bias_act_kernel<false>, grid, dim3(256), 0, stream, y, bias, residual, planes, C, HW, relu);
     return check_launch();
 }
+
+// Clear / fill a small device buffer with a KERNEL on the caller's stream (the per-frame counters of the post-processing buffers): inside a
+// captured frame a hipMemsetAsync node is not reliably ordered against the kernel node behind it on ROCm 7.2 (common.h, fill_words), and a
+// torch fill would be a library launch in the frame.
+extern "C" int coalign_fill_words(void *p, size_t n_words, uint32_t value, void *stream) {
+    if (!p && n_words) return COALIGN_ERR_NULL_POINTER;
+    if (reinterpret_cast<uintptr_t>(p) & 3) return COALIGN_ERR_UNSUPPORTED;
+    return coalign::fill_words(p, n_words, value, static_cast<hipStream_t>(stream));
+}

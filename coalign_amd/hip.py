@@ -48,6 +48,7 @@ SIGNATURES = {
     "coalign_pcdet_nms_workspace_bytes": (c_size_t, [c_int]),
     "coalign_pcdet_nms": (c_int, [P, c_int, c_float, c_int, P, P, P, c_size_t, P]),
     "coalign_bias_act": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "coalign_fill_words": (c_int, [P, c_size_t, c_uint32, P]),
     "coalign_voxelize_capacity": (c_int64, [c_int64, c_int, POINTER(c_double), POINTER(c_double), c_int]),
     "coalign_voxelize_workspace_bytes": (c_size_t, [POINTER(c_int64), c_int, POINTER(c_double), POINTER(c_double), c_int]),
     "coalign_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

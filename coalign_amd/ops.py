@@ -291,8 +291,9 @@ class DecodeBuffers:
     def __init__(self, capacity: int, A: int, H: int, W: int, top: int, device):
         L = hip.lib()
         self.capacity, self.top = capacity, top
-        self.counts = torch.zeros(64, dtype=torch.int32, device=device)       # chained per-agent totals
-        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self.frame_words = torch.zeros(65, dtype=torch.int32, device=device)  # cleared once per frame by ONE launch (reset_frame)
+        self.counts = self.frame_words[:64]                                    # chained per-agent totals
+        self.status = self.frame_words[64:65]
         self.cand_index = torch.empty(capacity, dtype=torch.int32, device=device)
         self.cand_score = torch.empty(capacity, dtype=torch.float32, device=device)
         self.cand_box7 = torch.empty((capacity, 7), dtype=torch.float32, device=device)
@@ -308,6 +309,12 @@ class DecodeBuffers:
         self.out_scores = torch.empty(top, dtype=torch.float32, device=device)
         self.out_count = torch.zeros(1, dtype=torch.int32, device=device)
         self.host = torch.zeros(4, dtype=torch.int32).pin_memory()   # (final, candidates, kept, status) of the last frame
+
+
+    def reset_frame(self) -> None:
+        """counts / status of a new frame: one hand-written fill launch on the current stream (no torch fill in the captured frame)."""
+        with torch.cuda.device(self.frame_words.device):
+            hip.check(hip.lib().coalign_fill_words(_ptr(self.frame_words), self.frame_words.numel(), 0, _stream()), "coalign_fill_words")
 
 
 @_device_op

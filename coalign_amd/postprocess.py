@@ -95,8 +95,7 @@ class VoxelPostprocessor:
             raise ValueError("too many cavs for one post_process call")
         thr = self.params["target_args"]["score_threshold"]
         da = self.params.get("dir_args", {})
-        buf.counts.zero_()
-        buf.status.zero_()
+        buf.reset_frame()
         for slot, cav_id in enumerate(cavs):
             assert cav_id in output_dict
             out = output_dict[cav_id]
@@ -255,8 +254,7 @@ class UncertaintyVoxelPostprocessor(VoxelPostprocessor):
         da = self.params.get("dir_args", {})
         corners, boxes, uncertainty, any_box = [], [], [], False
         for i in range(n_agents):
-            buf.counts.zero_()
-            buf.status.zero_()
+            buf.reset_frame()
             ops.anchor_decode(buf, 0, cls[i], reg[i], None if dirp is None else dirp[i], anchors, thr, da.get("dir_offset", 0.0),
                               da.get("num_bins", 2), self.params["order"], None)
             k_dev = buf.counts[1:2]

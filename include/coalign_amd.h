@@ -368,6 +368,10 @@ size_t coalign_conv3x3_wino_weight_bytes(int Cin, int Cout);
 int coalign_conv3x3_wino(const float *x, const void *u_split, const float *bias, const float *residual, float *y, int N, int Cin, int Cout,
                          int H, int W, int relu, int tile_block_w, void *stream);
 
+/* Fill `n_words` 32-bit words at `p` (4-byte aligned) with `value`, as a kernel on `stream` (the per-frame counters of the post-processing
+ * buffers, voxel_postprocessor.py:243-402's per-frame state; graph-capture safe, no library launch). */
+int coalign_fill_words(void *p, size_t n_words, uint32_t value, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * (10) Pointwise layers of the BEV backbone as one GEMM launch each, bias (+ ReLU) fused, NCHW float32:
  *   up in {1, 2, 4}, in_stride = 1:  ConvTranspose2d(kernel = stride = up) + eval BatchNorm (folded) + ReLU of the up-sampling heads

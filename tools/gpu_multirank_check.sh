@@ -3,15 +3,15 @@
 # per-frame detection digests as the 1-rank run: real frames are routed through the frame ring, not i.i.d. per rank.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/multirank; mkdir -p $OUT; cd $ROOT
-timeout 300 python bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-side-modes > $OUT/n1.json 2> $OUT/n1.err
+timeout 300 python bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-side-modes --no-from-points --no-latency --no-size-sweep > $OUT/n1.json 2> $OUT/n1.err
 for R in 2 4; do
 COALIGN_BENCH_BACKEND=gloo COALIGN_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $R --master-addr 127.0.0.1 --master-port $((29650 + R)) \
-    bench.py --gpus $R --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes > $OUT/n$R.json 2> $OUT/n$R.err
+    bench.py --gpus $R --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes --no-size-sweep > $OUT/n$R.json 2> $OUT/n$R.err
 done
 # north_star's wording: ONE frame, agents split over the ranks, all-gather, ego tail (bench.py --mode gather); 2 and 5 ranks (5 = one agent per rank)
 for R in 2 5; do
 COALIGN_BENCH_BACKEND=gloo COALIGN_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $R --master-addr 127.0.0.1 --master-port $((29670 + R)) \
-    bench.py --gpus $R --mode gather --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes > $OUT/g$R.json 2> $OUT/g$R.err
+    bench.py --gpus $R --mode gather --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes --no-size-sweep > $OUT/g$R.json 2> $OUT/g$R.err
 done
 python - $OUT <<'PY'
 import json,sys
@@ -27,6 +27,9 @@ for R in (2,4):
     same=all(ref["frame_digests"].get(k)==v for k,v in d["frame_digests"].items())
     print(f"N={R} (gloo, one GPU shared; functional only): {d['value']} frames/s, parallelism = {d['config']['parallelism']}, "
           f"bytes sent per rank and step = {d.get('exchange_bytes_sent_per_rank_per_step')}, {len(d['frame_digests'])} pool frames, digests equal to N=1: {same}, reproducible: {d['frame_digests_reproducible']}")
+    r=d.get("rccl") or {}
+    print(f"      rccl key: world {r.get('world')}, backend {r.get('backend')}, ranks seen {[(x['rank'], x['local_rank']) for x in r.get('ranks_seen', [])]}, mode run {r.get('mode_run')}, "
+          f"fallbacks {r.get('fallbacks')}, exchange {r.get('exchange_ms_per_frame')} ms, {r.get('bytes_sent_per_rank_per_exchange')} B sent per rank, {r.get('bytes_per_agent_fp32')} B per agent")
     ok = ok and same
 for R in (2,5):
     try:
