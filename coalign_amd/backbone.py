@@ -252,7 +252,28 @@ class BasicBlock(nn.Module):
             return w1, b1, w2, b2, wd, p1, p2, pd
         return _cache_of(self).get(self, build)
 
+    def takes_sparse_canvas(self) -> bool:
+        """This block reads a ``ops.SparseCanvas`` directly (round 4): strided 3x3 + pointwise skip on the split matrix cores."""
+        if self.training or self.stride != 2 or self.downsample is None or not emu_active() or not NHWC_STAGE_OUTPUTS or not POINTWISE_EMU:
+            return False
+        c1 = self.conv1
+        return c1.out_channels % 64 == 0 and c1.in_channels % 16 == 0 and c1.in_channels <= 256 and self.downsample[0].stride[0] == 2 and self.downsample[0].out_channels % 32 == 0
+
+    def _forward_sparse(self, sc: "ops.SparseCanvas", out_channels_last: bool) -> torch.Tensor:
+        w1, b1, w2, b2, wd, p1, p2, pd = self._folded()
+        wino = winograd_active() and p2 is not None and p2.wino_ok
+        y = ops.conv3x3_emu_sparse(sc, p1.emu(CONV_EMU_TERMS, False), b1, p1.cout, True, CONV_EMU_TERMS, out_channels_last=wino)
+        pw = pd[0].get()
+        if pw.dtype != torch.int16:
+            raise ops.hip.CoalignHipError("sparse canvas: the skip convolution needs the split-bf16 pointwise image")
+        skip = ops.pointwise_conv_sparse(sc, pw, pd[1], wd.shape[0], False, out_channels_last=wino)
+        return conv3x3_fused(y, p2, w2, b2, skip, out_channels_last=(wino or out_channels_last) and p2 is not None and p2.cout % 4 == 0)
+
     def forward(self, x: torch.Tensor, out_channels_last: bool = False) -> torch.Tensor:
+        if isinstance(x, ops.SparseCanvas):
+            if self.takes_sparse_canvas() and self._folded()[5] is not None and self._folded()[7] is not None:
+                return self._forward_sparse(x, out_channels_last)
+            x = x.dense()
         if _fast_ok(self, x):
             w1, b1, w2, b2, wd, p1, p2, pd = self._folded()
             emu = emu_active()
@@ -302,9 +323,11 @@ class ResNetStages(nn.Module):
 
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
         feats = []
+        if isinstance(x, ops.SparseCanvas) and not (NHWC_STAGE_OUTPUTS and emu_active() and FAST_INFERENCE and not self.training):
+            x = x.dense()
         for i in range(self.layernum):
             layer = getattr(self, f"layer{i}")
-            if NHWC_STAGE_OUTPUTS and emu_active() and _fast_ok(self, x):
+            if NHWC_STAGE_OUTPUTS and emu_active() and (isinstance(x, ops.SparseCanvas) or _fast_ok(self, x)):
                 for j, blk in enumerate(layer):
                     x = blk(x, out_channels_last=(j == len(layer) - 1))
             else:

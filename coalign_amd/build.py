@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip.so")
 # builds it, COALIGN_LAB=1 makes coalign_amd.hip load it.
 LAB_LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip_lab.so")
 INCLUDE = os.path.join(REPO, "include")
-SOURCES = ["status.cpp", "pillar_scatter.hip", "warp_fuse.hip", "warp_fuse_nhwc.hip", "decode.hip", "nms.hip", "epilogue.hip", "voxelize.hip", "pose_graph.hip", "conv3x3.hip", "conv3x3_emu.hip", "conv3x3_wino.hip", "pointwise.hip"]
+SOURCES = ["status.cpp", "pillar_scatter.hip", "pillar_sparse.hip", "warp_fuse.hip", "warp_fuse_nhwc.hip", "decode.hip", "nms.hip", "epilogue.hip", "voxelize.hip", "pose_graph.hip", "conv3x3.hip", "conv3x3_emu.hip", "conv3x3_wino.hip", "pointwise.hip"]
 ARCH = "gfx950"
 # per-source extras.  pillar_scatter.hip: its matrix-core encoder reduces the accumulators with VALU right after each instruction
 # pair -- results in VGPRs (not AGPRs) save 64 v_accvgpr_read per pass; -fno-honor-nans drops the canonicalising v_max the compiler
@@ -35,7 +35,8 @@ ARCH = "gfx950"
 # on the MI355X (profiles/round3/README.md, "packed fp32 beside matrix wavefronts"): a wavefront executing them while it shares a SIMD with
 # three densely issuing matrix wavefronts of another kernel got wrong results in lanes 48-63.  Frame rate with / without the flag: equal
 # (309-314 vs 307-312 frames/s, same box, alternating).  (The fp32 VALU pillar encoder's explicit float2 arithmetic was rewritten as scalar chains.)
-EXTRA_FLAGS = {"pillar_scatter.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
+EXTRA_FLAGS = {"pillar_scatter.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
+               "pillar_sparse.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}      # (no NaN test may be written in these two files)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-vectorize", "-Wno-cuda-compat", "-Wno-inline-asm", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 

@@ -59,6 +59,10 @@ struct EmuArgs {
     float *__restrict__ partial;      // [grid][16 * NCO][threads]: accumulators of a tile whose chunks are split over two workgroups
     int *flags;                       // [grid], zeroed per launch: flags[g] = 1 once workgroup g has published its partial tile
     int prio_mode;                    // 1: the first-dispatched half of the grid outranks the second half (see the kernel)
+    // round 4, sparse canvas (csrc/pillar_sparse.hip): x = pillar feature rows [M][Cin]; a pixel (n, y, x) of the logical channels-last input is row
+    // (stamp & 0xffffffff) of x if stamps[(n * Hin + y) * Win + x] >> 32 equals *tag_ptr, else zero.  Channels-last input layouts only.
+    const unsigned long long *__restrict__ stamps;
+    const int *__restrict__ tag_ptr;
 #ifdef EMU_TRACE
     long long *trace;                 // profiling aid (tools/trace_conv_emu.py): [2 workgroups][waves][64 chunks][8 stamps]
     int ablate;                       // 1: no weight DMA, 2: no halo-pixel loads, 4: no matrix steps (wrong results; what each part costs)
@@ -170,6 +174,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;      // wave: scalar
     const size_t plane = (size_t)a.H * a.W, plane_in = (size_t)a.Hin * a.Win;
+    const unsigned sparse_tag = a.stamps ? (unsigned)*a.tag_ptr : 0u;
     const int groups = a.Cout / kCoutTile, chunks = a.Cin / (kKC * KCH);       // `chunks`: barrier intervals per tile, KCH x 8 channels each
     auto decode = [&](int t) {
         Tile c;
@@ -208,7 +213,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     auto make_plan = [&](const Tile &t) {
         Plan pl;
         const int n0 = STACK ? t.y0 / a.H : t.n;
-        pl.base = a.x + (size_t)n0 * a.Cin * plane_in;
+        pl.base = a.stamps ? a.x : a.x + (size_t)n0 * a.Cin * plane_in;
         pl.wsrc = a.wt + (size_t)t.cg * chunks * (G::WUNITS * G::WQ) + lane;
         const int yl0 = t.y0 - n0 * a.H, yb = a.H - yl0;
 #pragma unroll
@@ -227,6 +232,12 @@ void conv3x3_emu_kernel(const EmuArgs a) {
             } else {
                 const int gy = STRIDE * t.y0 - 1 + y;
                 pl.off[j] = (i < G::PIX && xq < G::PWU && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? gy * a.Win + gx : -1;
+                if constexpr ((LAYOUT & LAYOUT_IN_NHWC) != 0) {
+                    if (a.stamps) {                                 // sparse canvas: the pixel's feature row, or nothing
+                        const unsigned long long st = a.stamps[(size_t)n0 * plane_in + (pl.off[j] < 0 ? 0 : pl.off[j])];
+                        pl.off[j] = (pl.off[j] >= 0 && (unsigned)(st >> 32) == sparse_tag) ? (int)(unsigned)st : -1;
+                    }
+                }
             }
         }
         return pl;
@@ -936,5 +947,27 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
 #endif
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = terms == 3 ? dispatch_variant<3>(a, stride, layout, s) : terms == 16 ? dispatch_variant<2, true>(a, stride, layout, s) : dispatch_variant<2>(a, stride, layout, s);
+    return rc != COALIGN_OK ? rc : check_launch();
+}
+
+// Round 4: the strided first convolution of the first ResNet stage reading a SPARSE canvas (csrc/pillar_sparse.hip) instead of the dense zero-filled one:
+// same kernel, the pixel -> row lookup happens once per tile in the patch plan.  Output channels-last (out_nhwc != 0) or NCHW.
+extern "C" int coalign_conv3x3_emu_sparse(const float *feats, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y, int N,
+                                          int Cin, int Cout, int Hin, int Win, int relu, int terms, int out_nhwc, void *stream) {
+    using namespace coalign;
+    if (!feats || !stamps || !state || !w_split || !y || !bias) return COALIGN_ERR_NULL_POINTER;
+    const int H = (Hin + 1) / 2, W = (Win + 1) / 2;
+    int rc = check_emu_args(N, Cin, Cout, Hin, Win, terms);
+    if (rc != COALIGN_OK) return rc;
+    if ((reinterpret_cast<uintptr_t>(w_split) | reinterpret_cast<uintptr_t>(feats) | reinterpret_cast<uintptr_t>(y)) & 15) return COALIGN_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(stamps) & 7) return COALIGN_ERR_UNSUPPORTED;
+    if (N == 0) return COALIGN_OK;
+    EmuArgs a{feats, static_cast<const uint4 *>(w_split), bias, nullptr, y, N, Cin, Cout, H, W, relu, 0, 0, 0, Hin, Win, nullptr, nullptr};
+    a.prio_mode = emu_prio_mode();
+    a.stamps = static_cast<const unsigned long long *>(stamps);
+    a.tag_ptr = state;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int layout = out_nhwc ? LAYOUT_NHWC : LAYOUT_IN_NHWC;
+    rc = terms == 3 ? dispatch_variant<3>(a, 2, layout, s) : terms == 16 ? dispatch_variant<2, true>(a, 2, layout, s) : dispatch_variant<2>(a, 2, layout, s);
     return rc != COALIGN_OK ? rc : check_launch();
 }

@@ -1,0 +1,303 @@
+// PillarVFE + PointPillarScatter as ONE launch with a SPARSE canvas (round 4), gfx950.
+//
+// Reference semantics: opencood/models/sub_modules/pillar_vfe.py:31-53,105-155 and opencood/models/sub_modules/point_pillar_scatter.py:15-72.
+//
+// The dense canvas of the reference is 94 % zeros and exists only to be read by the first strided 3x3 convolution and the 1x1 skip
+// convolution.  Here the "scatter" is 8 bytes per pillar:
+//   feats  [M, C]            the pillar feature rows (pillar_features of the reference; every pillar writes its own row: no write races)
+//   stamps [n_agents*ny*nx]  one 64-bit word per cell = (frame tag << 32) | pillar row, entered with a device-scope atomicMax: two pillars of one
+//                            cell resolve to the larger row index -- the reference's sequential-indexing rule -- without a pre-pass
+//   state  [2]               state[0] = tag of the last completed frame, state[1] = arrival counter of the launch in flight
+// A cell is occupied in the current frame iff its stamp carries the current tag: nothing is ever cleared (the previous frames' stamps are stale by
+// their tag), there is no cell-map pre-pass and no ordering problem between clearing and writing -- one launch.  The consumers
+// (coalign_conv3x3_emu_sparse, coalign_pointwise_conv_emu_sparse) look a pixel up as stamps[cell] -> row of feats, or zero.
+// The tag is advanced by the LAST workgroup to finish (arrival counter), i.e. after every stamp of this frame has been entered and before any consumer
+// (next launch on the stream) reads it; the launch reads state[0] only at its start.
+//
+// Encoder: the PFN input of a point is affine in the point once the pillar is fixed:
+//     W f = (w_abs + w_cluster + w_center) (p - c) + w_i intensity + [w_abs c - w_cluster (mean - c)]
+// a K = 4 contraction per point.  Round 3 ran it as six split-bf16 products; here it runs EXACTLY in fp32 on v_mfma_f32_32x32x2_f32 (two steps of
+// K = 2, a 32-point pillar = the 32 rows of one matrix instruction): no operand splitting, no LDS staging of rows -- the A operands are the
+// point registers after one v_permlane32_swap.  D = fma(d3, w3, fma(d2, w2, fma(d1, w1, d0 w0))) bit for bit.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void *lptr_sp_t;
+
+constexpr int kWaves = 4;                   // wavefronts per workgroup
+constexpr int kRunPairs = 32;               // pillar pairs per wavefront at most (one lane per pillar in the prologue)
+constexpr int kRound = 5;                   // pairs per LDS-DMA round (5 KB per buffer)
+
+struct SparseArgs {
+    const float4 *pts;
+    const int *npts;
+    const int4 *coords;
+    int M, P;
+    const float *weight, *bias, *bn_w, *bn_b, *bn_m, *bn_v;
+    float eps;
+    int C, Cin, use_abs;
+    float vx, vy, vz, xo, yo, zo;
+    int n_agents, ny, nx;
+    float *feats;
+    unsigned long long *stamps;
+    int *state;
+    const int *M_dev;
+};
+
+__device__ __forceinline__ void swap32(float &a, float &b) {       // lanes 32-63 of a <-> lanes 0-31 of b
+    const auto q = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned x = q[0], y = q[1];                              // (bit-casting q[1] directly is miscompiled by hipcc 7.2: go through locals)
+    a = __builtin_bit_cast(float, x);
+    b = __builtin_bit_cast(float, y);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// sum over each 32-lane half, result in every lane of the half
+__device__ __forceinline__ float half_sum_dpp(float v) {
+    v += dppf<0xB1>(v);
+    v += dppf<0x4E>(v);
+    v += dppf<0x141>(v);
+    v += dppf<0x140>(v);
+    const auto q = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    const unsigned x = q[0], y = q[1];
+    return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+}
+
+__device__ __forceinline__ float max16(const floatx16 &v) {
+    const float t0 = fmaxf(fmaxf(v[0], v[1]), v[2]), t1 = fmaxf(fmaxf(v[3], v[4]), v[5]), t2 = fmaxf(fmaxf(v[6], v[7]), v[8]);
+    const float t3 = fmaxf(fmaxf(v[9], v[10]), v[11]), t4 = fmaxf(fmaxf(v[12], v[13]), v[14]);
+    return fmaxf(fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)), fmaxf(t4, v[15]));
+}
+
+// per-lane channel parameters in the half layout: channel 32 g + (lane & 31)
+struct F32Chan {
+    float wb[2][2];                  // B operand of step s for channel group g: W4[2 s + (lane >> 5)][32 g + (lane & 31)] (sign folded)
+    float wc[2][3], wen[2][3];       // weights of the centre term, negated weights of the mean-offset term
+    float alpha[2], shift[2], sgn[2];
+};
+
+template <bool ABS>
+__device__ __forceinline__ F32Chan load_f32(const SparseArgs &a, int lane) {
+    F32Chan fc;
+    constexpr int B = ABS ? 4 : 1;
+    const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int c = g * 32 + col;
+        float w4[4] = {0.f, 0.f, 0.f, 0.f};
+        float alpha = 1.f, shift = 0.f;
+        if (c < a.C) {
+            if (a.bn_w) {
+                const float inv_std = 1.0f / sqrtf(a.bn_v[c] + a.eps);
+                alpha = a.bn_w[c] * inv_std;
+                shift = a.bn_b[c] - a.bn_m[c] * alpha;
+            } else if (a.bias) {
+                shift = a.bias[c];
+            }
+            const float *w = a.weight + (size_t)c * a.Cin;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w4[k] = ((ABS ? w[k] : 0.f) + w[B + k]) + w[B + 3 + k];
+            w4[3] = w[ABS ? 3 : 0];
+        }
+        const float sg = alpha < 0.f ? -1.f : 1.f;       // a negative BatchNorm scale turns the max over the rows into a min: negate the weights instead
+        fc.alpha[g] = alpha; fc.shift[g] = shift; fc.sgn[g] = sg;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            fc.wc[g][k] = (ABS && c < a.C) ? a.weight[(size_t)c * a.Cin + k] : 0.f;
+            fc.wen[g][k] = (c < a.C) ? -a.weight[(size_t)c * a.Cin + B + k] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) fc.wb[g][s] = sg * (half ? w4[2 * s + 1] : w4[2 * s]);
+    }
+    return fc;
+}
+
+// One pillar pair (lanes 0-31: pillar A's points, lanes 32-63: pillar B's) -> y[g]: relu(BN(max over the rows)) of channel 32 g + (lane & 31) in the
+// half layout (lanes 0-31 pillar A, lanes 32-63 pillar B).
+template <bool ABS>
+__device__ __forceinline__ void f32_pair_half(const SparseArgs &a, const F32Chan &fc, int lane, float4 q, int np, int4 cd, bool hasB, float (&y)[2]) {
+    const int np_eff = min(max(np, 0), a.P);
+    // mean over ALL P slots divided by num_points (pillar_vfe.py:118-120)
+    const float rn = __builtin_amdgcn_rcpf((float)np);
+    const float ctr_x = (float)cd.w * a.vx + a.xo, ctr_y = (float)cd.z * a.vy + a.yo, ctr_z = (float)cd.y * a.vz + a.zo;
+    const float ex = half_sum_dpp(q.x) * rn - ctr_x, ey = half_sum_dpp(q.y) * rn - ctr_y, ez = half_sum_dpp(q.z) * rn - ctr_z;
+    float d0 = q.x - ctr_x, d1 = q.y - ctr_y, d2 = q.z - ctr_z, d3 = q.w;
+    // rows at / past the point count repeat row 0 of their pillar: they cannot change the max (their own value, relu(BN(0)), is added below)
+    const int row = lane & 31;
+    const bool pad = row >= np_eff;
+    {
+        auto rl = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+        const float a0 = rl(d0, 0), a1 = rl(d1, 0), a2 = rl(d2, 0), a3 = rl(d3, 0);
+        const float b0 = rl(d0, 32), b1 = rl(d1, 32), b2 = rl(d2, 32), b3 = rl(d3, 32);
+        const bool hb = lane >= 32;
+        d0 = pad ? (hb ? b0 : a0) : d0; d1 = pad ? (hb ? b1 : a1) : d1; d2 = pad ? (hb ? b2 : a2) : d2; d3 = pad ? (hb ? b3 : a3) : d3;
+    }
+    // A operands: lane l holds A[i = l & 31][k = l >> 5].  One swap turns [A.d0 | B.d0], [A.d1 | B.d1] into [A.d0 | A.d1] (pillar A, step 0) and
+    // [B.d0 | B.d1] (pillar B, step 0); likewise d2 / d3 for step 1.
+    swap32(d0, d1);
+    swap32(d2, d3);
+    const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    floatx16 accA[2], accB[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        accA[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, fc.wb[g][0], zero, 0, 0, 0);
+        accB[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, fc.wb[g][0], zero, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        accA[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, fc.wb[g][1], accA[g], 0, 0, 0);
+        accB[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(d3, fc.wb[g][1], accB[g], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        // lane holds 16 of the 32 rows of channel 32 g + (lane & 31): rows 8 (r >> 2) + 4 (lane >> 5) + (r & 3); the two halves complete each other
+        float mA = max16(accA[g]), mB = max16(accB[g]);
+        swap32(mA, mB);                                     // mA = [A.lo | B.lo], mB = [A.hi | B.hi]
+        const float r = fmaxf(mA, mB);                      // lanes 0-31: pillar A, lanes 32-63: pillar B
+        float b = fc.wen[g][0] * ex;
+        b = fmaf(fc.wen[g][1], ey, b); b = fmaf(fc.wen[g][2], ez, b);
+        if constexpr (ABS) { b = fmaf(fc.wc[g][0], ctr_x, b); b = fmaf(fc.wc[g][1], ctr_y, b); b = fmaf(fc.wc[g][2], ctr_z, b); }
+        float v = fmaf(fc.sgn[g] * r + b, fc.alpha[g], fc.shift[g]);
+        if (np_eff < a.P) v = fmaxf(v, fc.shift[g]);        // padded rows: Linear(0) = 0 -> BN -> shift
+        if (np_eff == 0) v = fc.shift[g];                   // (documented deviation: the reference divides by zero here)
+        y[g] = fmaxf(v, 0.f);
+    }
+    (void)hasB;
+}
+
+template <bool ABS>
+__global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a) {
+    constexpr int kWaveLds = 2 * kRound * 1024 + 64 * 32;           // two point buffers | the run's pillar records
+    __shared__ __attribute__((aligned(16))) char lds[kWaves * kWaveLds];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
+    char *pbuf = lds + wv * kWaveLds;
+    char *meta = pbuf + 2 * kRound * 1024;
+    const int gwave = blockIdx.x * kWaves + wv, nwave = gridDim.x * kWaves;
+    if (a.M_dev) a.M = min(max(*a.M_dev, 0), a.M);
+    const unsigned tag = (unsigned)a.state[0] + 1u;                  // this frame's tag (state[0] is written only when the last workgroup has finished)
+    const int npairs = (a.M + 1) / 2;
+    const int per_wave = (npairs + nwave - 1) / nwave;
+    const int p0 = gwave * per_wave, p1 = min(p0 + per_wave, npairs);
+    if (p0 < p1) {
+        const int ncell = a.ny * a.nx;
+        const char *pts_b = reinterpret_cast<const char *>(a.pts);
+        const char *np_b = reinterpret_cast<const char *>(a.npts), *cd_b = reinterpret_cast<const char *>(a.coords);
+        char *feat_b = reinterpret_cast<char *>(a.feats);
+        // a round's points go straight into LDS (global_load_lds issued from inline assembly, see pillar_scatter.hip)
+        auto issue_round = [&](int r0, int buf) {
+            const int nr = min(kRound, p1 - r0);
+#pragma unroll
+            for (int k = 0; k < kRound; ++k) {
+                if (k < nr) {
+                    const int m = min(2 * (r0 + k) + half, a.M - 1);
+                    const char *src = pts_b + (unsigned)(m * a.P + min(col, a.P - 1)) * 16u;
+                    const unsigned dst = (unsigned)(size_t)(lptr_sp_t)(pbuf + (buf * kRound + k) * 1024);
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(dst)), "v"(src) : "memory", "m0");
+                }
+            }
+        };
+        issue_round(p0, 0);
+        if (lane < 2 * (p1 - p0)) {                                  // counts, coordinates, cells of the whole run: once per wavefront; the stamp of every pillar
+            const int m_j = 2 * p0 + lane;
+            const int mj = min(m_j, a.M - 1);
+            const int np_j = *reinterpret_cast<const int *>(np_b + (unsigned)mj * 4u);
+            const int4 cd_j = *reinterpret_cast<const int4 *>(cd_b + (unsigned)mj * 16u);
+            const int cell = cd_j.y + cd_j.z * a.nx + cd_j.w;       // z + y * nx + x (point_pillar_scatter.py:54)
+            const bool ok = m_j < a.M && cd_j.x >= 0 && cd_j.x < a.n_agents && cell >= 0 && cell < ncell;
+            if (ok) atomicMax(a.stamps + (size_t)cd_j.x * ncell + cell, ((unsigned long long)tag << 32) | (unsigned)m_j);      // the larger row of a cell wins
+            *reinterpret_cast<int4 *>(meta + lane * 32) = make_int4(np_j, cd_j.y, cd_j.z, cd_j.w);
+        }
+        const F32Chan fc = load_f32<ABS>(a, lane);
+        const bool ch0 = col < a.C, ch1 = 32 + col < a.C;
+        int buf = 0;
+        for (int r0 = p0; r0 < p1; r0 += kRound, buf ^= 1) {
+            const int nr = min(kRound, p1 - r0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): this round's points are in LDS
+            coalign::wave_lds_sync();
+            if (r0 + kRound < p1) issue_round(r0 + kRound, buf ^ 1);
+            const char *pb = pbuf + buf * (kRound * 1024);
+#pragma unroll
+            for (int k = 0; k < kRound; ++k) {
+                if (k < nr) {
+                    const int pair = r0 + k;
+                    const int m = 2 * pair + half;
+                    const bool live = m < a.M, hasB = 2 * pair + 1 < a.M;
+                    float4 q = *reinterpret_cast<const float4 *>(pb + k * 1024 + lane * 16);
+                    if (a.P < 32 && col >= a.P) q = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int4 rec = *reinterpret_cast<const int4 *>(meta + (2 * (pair - p0) + half) * 32);
+                    float y[2];
+                    f32_pair_half<ABS>(a, fc, lane, q, rec.x, make_int4(0, rec.y, rec.z, rec.w), hasB, y);
+                    // half layout -> lane = channel: [A ch 0-31 | B ch 0-31], [A ch 32-63 | B ch 32-63] -> [A 0-63], [B 0-63]: 256-byte row stores
+                    swap32(y[0], y[1]);
+                    const bool liveA = 2 * pair < a.M;
+                    if (liveA && lane < a.C) *reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair) * (unsigned)a.C + (unsigned)lane) * 4u) = y[0];
+                    if (hasB && lane < a.C) *reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair + 1) * (unsigned)a.C + (unsigned)lane) * 4u) = y[1];
+                    (void)live; (void)ch0; (void)ch1;
+                }
+            }
+        }
+    }
+    // the last workgroup to arrive publishes the tag: every stamp of this frame has been entered by then
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int arrived = atomicAdd(a.state + 1, 1);
+        if (arrived == (int)gridDim.x - 1) {
+            a.state[1] = 0;
+            __threadfence();
+            atomicExch(a.state, (int)tag);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t coalign_sparse_canvas_stamp_bytes(int n_agents, int ny, int nx) {
+    if (n_agents <= 0 || ny <= 0 || nx <= 0) return 0;
+    return (size_t)n_agents * ny * nx * 8;
+}
+
+extern "C" int coalign_pillar_encode_sparse(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M_capacity,
+                                            const int32_t *M_dev, int P, const float *pfn_weight, const float *pfn_bias, const float *bn_weight,
+                                            const float *bn_bias, const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz,
+                                            const double *voxel_size, const double *range_min, int n_agents, int ny, int nx, float *pillar_features,
+                                            void *stamps, int32_t *state, void *stream_) {
+    using namespace coalign;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M_capacity < 0 || P <= 0 || P > 32 || C < 1 || C > 64 || n_agents <= 0 || ny <= 0 || nx <= 0) return COALIGN_ERR_BAD_SHAPE;
+    if (!pfn_weight || !voxel_size || !range_min || !stamps || !state) return COALIGN_ERR_NULL_POINTER;
+    if (M_capacity > 0 && (!voxel_features || !voxel_num_points || !voxel_coords || !pillar_features)) return COALIGN_ERR_NULL_POINTER;
+    const bool has_bn = bn_weight || bn_bias || bn_mean || bn_var;
+    if (has_bn && !(bn_weight && bn_bias && bn_mean && bn_var)) return COALIGN_ERR_NULL_POINTER;
+    if ((size_t)n_agents * ny * nx > (size_t)INT32_MAX || (reinterpret_cast<uintptr_t>(stamps) & 7)) return COALIGN_ERR_BAD_SHAPE;
+    if ((size_t)M_capacity * P * 16 >= ((size_t)1 << 32) || (size_t)M_capacity * C * 4 >= ((size_t)1 << 32)) return COALIGN_ERR_UNSUPPORTED;      // 32-bit byte offsets
+    SparseArgs a{};
+    a.pts = (const float4 *)voxel_features; a.npts = voxel_num_points; a.coords = (const int4 *)voxel_coords;
+    a.M = M_capacity; a.P = P;
+    a.weight = pfn_weight; a.bias = pfn_bias; a.bn_w = bn_weight; a.bn_b = bn_bias; a.bn_m = bn_mean; a.bn_v = bn_var;
+    a.eps = bn_eps; a.C = C; a.Cin = (use_absolute_xyz ? 4 : 1) + 6; a.use_abs = use_absolute_xyz;
+    a.vx = (float)voxel_size[0]; a.vy = (float)voxel_size[1]; a.vz = (float)voxel_size[2];
+    a.xo = (float)(voxel_size[0] / 2 + range_min[0]);
+    a.yo = (float)(voxel_size[1] / 2 + range_min[1]);
+    a.zo = (float)(voxel_size[2] / 2 + range_min[2]);
+    a.n_agents = n_agents; a.ny = ny; a.nx = nx; a.feats = pillar_features;
+    a.stamps = static_cast<unsigned long long *>(stamps); a.state = state; a.M_dev = M_dev;
+    // two workgroups of four wavefronts per CU; a wavefront takes two rounds' pairs unless the capacity asks for more (up to kRunPairs each, then more workgroups)
+    const int pairs = (M_capacity + 1) / 2, resident = 512;
+    int blocks = (pairs + kWaves * 2 * kRound - 1) / (kWaves * 2 * kRound);
+    if (blocks > resident) blocks = resident;
+    const int need = (pairs + kWaves * kRunPairs - 1) / (kWaves * kRunPairs);
+    if (blocks < need) blocks = need;
+    if (blocks < 1) blocks = 1;                               // (M = 0: the launch still advances the frame tag)
+    if (use_absolute_xyz) hipLaunchKernelGGL(pillar_sparse_kernel<true>, dim3(blocks), dim3(kWaves * 64), 0, stream, a);
+    else hipLaunchKernelGGL(pillar_sparse_kernel<false>, dim3(blocks), dim3(kWaves * 64), 0, stream, a);
+    return check_launch();
+}

@@ -29,6 +29,10 @@ struct PwArgs {
     int in_nhwc;          // x is [N, Hin, Win, Cin] (channels-last: the fused maps / stage outputs of the NHWC route)
     int pb;               // pixel blocks of 32 per workgroup: 1, 2 or 4 (see the kernel)
     int out_nhwc;         // y is [N, Hp, Wp, Ctot] (up = 1 only): the skip convolution feeding a channels-last residual add
+    // round 4, sparse canvas (csrc/pillar_sparse.hip; in_nhwc only): x = feature rows [M][Cin], pixel (n, y, x) = row (stamp & 0xffffffff) if
+    // stamps[(n * Hin + y) * Win + x] >> 32 == *tag_ptr, else zero
+    const unsigned long long *stamps;
+    const int *tag_ptr;
 };
 
 // Epilogue shared by both kernels: accumulator r of lane l is GEMM row 8 * (r / 4) + 4 * (l / 32) + r % 4 of its 32-row tile, pixel l % 32
@@ -107,14 +111,20 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
     const int p0 = blockIdx.x * TP, n = blockIdx.z;
     const int m_base = blockIdx.y * (64 * WPB);
     const size_t in_plane = (size_t)a.Hin * a.Win;
-    const float *xin = a.x + (size_t)n * a.Cin * in_plane;
+    const float *xin = a.stamps ? a.x : a.x + (size_t)n * a.Cin * in_plane;
     // stage X[ci][TP pixels]: thread t loads pixel t % TP of channels t / TP, t / TP + 256 / TP, ...
     {
         const int pl = tid & (TP - 1), c0 = tid / TP, cstep = 256 / TP;
         const int px = p0 + pl;
-        const bool ok = px < pixels;
-        const int hp = ok ? px / a.Wp : 0, wp = ok ? px - hp * a.Wp : 0;
-        const size_t off = (size_t)(hp * a.in_stride) * a.Win + (size_t)wp * a.in_stride;
+        const bool ok0 = px < pixels;
+        const int hp = ok0 ? px / a.Wp : 0, wp = ok0 ? px - hp * a.Wp : 0;
+        size_t off = (size_t)(hp * a.in_stride) * a.Win + (size_t)wp * a.in_stride;
+        bool ok = ok0;
+        if (a.stamps) {        // sparse canvas: the pixel's feature row, or nothing
+            const unsigned long long st = a.stamps[(size_t)n * in_plane + off];
+            ok = ok0 && (unsigned)(st >> 32) == (unsigned)*a.tag_ptr;
+            off = ok ? (size_t)(unsigned)st : 0;
+        }
         if (a.in_nhwc) {       // a pixel's channels are contiguous: 16 B per lane, thread t takes channel quads c0, c0 + cstep, ...
             const float4 *xp = reinterpret_cast<const float4 *>(xin + off * a.Cin);
             for (int c4 = c0; c4 < (a.Cin >> 2); c4 += cstep) {
@@ -180,14 +190,20 @@ __global__ __launch_bounds__(256) void pointwise_emu_kernel(const PwArgs a) {
     const int p0 = blockIdx.x * TP, n = blockIdx.z;
     const int m_base = blockIdx.y * (64 * WPB);
     const size_t in_plane = (size_t)a.Hin * a.Win;
-    const float *xin = a.x + (size_t)n * a.Cin * in_plane;
+    const float *xin = a.stamps ? a.x : a.x + (size_t)n * a.Cin * in_plane;
     const int G = a.Cin >> 3;
     {
         const int pl = tid & (TP - 1), g0 = tid / TP, gstep = 256 / TP;
         const int px = p0 + pl;
-        const bool ok = px < pixels;
-        const int hp = ok ? px / a.Wp : 0, wp = ok ? px - hp * a.Wp : 0;
-        const size_t off = (size_t)(hp * a.in_stride) * a.Win + (size_t)wp * a.in_stride;
+        const bool ok0 = px < pixels;
+        const int hp = ok0 ? px / a.Wp : 0, wp = ok0 ? px - hp * a.Wp : 0;
+        size_t off = (size_t)(hp * a.in_stride) * a.Win + (size_t)wp * a.in_stride;
+        bool ok = ok0;
+        if (a.stamps) {        // sparse canvas: the pixel's feature row, or nothing
+            const unsigned long long st = a.stamps[(size_t)n * in_plane + off];
+            ok = ok0 && (unsigned)(st >> 32) == (unsigned)*a.tag_ptr;
+            off = ok ? (size_t)(unsigned)st : 0;
+        }
         for (int g = g0; g < G; g += gstep) {
             float u[8];
             if (a.in_nhwc) {
@@ -257,7 +273,7 @@ extern "C" int coalign_pointwise_conv(const float *x, const float *w, const floa
 
 static int pointwise_impl(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
                           int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, bool emu,
-                          void *stream) {
+                          void *stream, const void *stamps = nullptr, const int32_t *state = nullptr) {
     using namespace coalign;
     if (!x || !w || !bias || !y) return COALIGN_ERR_NULL_POINTER;
     if (emu && ((Cin & 15) || (reinterpret_cast<uintptr_t>(w) & 15))) return COALIGN_ERR_UNSUPPORTED;
@@ -272,7 +288,9 @@ static int pointwise_impl(const float *x, const float *w, const float *bias, flo
     const int out_nhwc = (in_nhwc >> 1) & 1;
     in_nhwc &= 1;
     if (out_nhwc && (up != 1 || (Ctot & 3) || (c_off & 3) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias)) & 15))) return COALIGN_ERR_UNSUPPORTED;
-    PwArgs a{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu, in_nhwc != 0, 1, out_nhwc};
+    PwArgs a{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu, in_nhwc != 0, 1, out_nhwc,
+             static_cast<const unsigned long long *>(stamps), state};
+    if (stamps && (!in_nhwc || !state || (reinterpret_cast<uintptr_t>(stamps) & 7))) return COALIGN_ERR_UNSUPPORTED;
     if (N > 65535) return COALIGN_ERR_UNSUPPORTED;
     const int pixels = a.Hp * a.Wp;
     static const int pb_max = coalign::lab_env("COALIGN_PW_PB", 4);      // laboratory build: 1 = the round-1 mapping
@@ -312,4 +330,13 @@ extern "C" int coalign_pointwise_conv_emu(const float *x, const void *w_split, c
                                           void *stream) {
     return pointwise_impl(x, static_cast<const float *>(w_split), bias, y, N, Cin, Hin, Win, in_stride, Cout, up, M_padded, Ctot, c_off, relu, in_nhwc,
                           true, stream);
+}
+
+// Round 4: the 1 x 1 / stride-2 skip convolution of the first ResNet stage reading the SPARSE canvas of csrc/pillar_sparse.hip (feature rows + cell stamps)
+// instead of the dense canvas.  out_nhwc: bit 0 = channels-last output.
+extern "C" int coalign_pointwise_conv_emu_sparse(const float *feats, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y,
+                                                 int N, int Cin, int Hin, int Win, int Cout, int M_padded, int relu, int out_nhwc, void *stream) {
+    if (!stamps || !state) return COALIGN_ERR_NULL_POINTER;
+    return pointwise_impl(feats, static_cast<const float *>(w_split), bias, y, N, Cin, Hin, Win, 2, Cout, 1, M_padded, Cout, 0, relu, 1 | (out_nhwc ? 2 : 0), true, stream,
+                          stamps, state);
 }

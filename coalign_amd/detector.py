@@ -21,6 +21,13 @@ from .fusion import AttFusion, MaxFusion, fuse_multiscale
 from .pose import normalize_pairwise_tfm
 
 
+import os as _os
+
+# Round 4: PillarVFE + PointPillarScatter as one launch with a sparse canvas (csrc/pillar_sparse.hip) feeding the first ResNet block directly.
+# "0": the dense persistent canvas of rounds 2-3 (measurement aid; module attribute, read at every call).
+SPARSE_CANVAS = _os.environ.get("COALIGN_SPARSE_CANVAS", "1") != "0"
+
+
 def _run_heads(model: nn.Module, x: torch.Tensor) -> dict:
     """cls / reg / dir 1x1 heads.  Inference fast path: one convolution with the concatenated head weights (+ one fused
     bias pass) instead of three convolutions and three bias kernels; the outputs are channel slices of one tensor."""
@@ -103,7 +110,15 @@ class PointPillarBaselineMultiscale(nn.Module):
         for k in ("voxel_count_dev", "voxel_cells_unique", "want_pillar_features"):      # the device voxeliser's streaming form (PillarVFE.forward)
             if k in pl:
                 batch_dict[k] = pl[k]
-        batch_dict = self.scatter(self.pillar_vfe(batch_dict))
+        # round 4: the encoder hands a SparseCanvas (one launch, no dense canvas) to a backbone whose first block reads it
+        resnet = getattr(self.backbone, "resnet", None)
+        first = resnet.layer0[0] if resnet is not None and hasattr(resnet, "layer0") and hasattr(resnet.layer0[0], "takes_sparse_canvas") else None
+        keep_sparse = self.pillar_vfe.sparse_canvas
+        self.pillar_vfe.sparse_canvas = bool(SPARSE_CANVAS and not self.compression and not self.training and first is not None and first.takes_sparse_canvas())
+        try:
+            batch_dict = self.scatter(self.pillar_vfe(batch_dict))
+        finally:
+            self.pillar_vfe.sparse_canvas = keep_sparse
         spatial_features = batch_dict["spatial_features"]
         H0, W0 = spatial_features.shape[2:]
         affine = normalize_pairwise_tfm(data_dict["pairwise_t_matrix"], H0, W0, self.voxel_size[0])

@@ -62,6 +62,9 @@ class PillarVFE(nn.Module):
         # of zero-filling 36 MB per agent every frame.  The returned ``spatial_features`` is then overwritten by the next forward on the
         # same stream -- fine for a detector that runs its backbone right away, wrong for a caller that holds canvases across frames.
         self.persistent_canvas = False
+        # Opt-in (the detector's fused forward turns it on): hand the backbone a SparseCanvas (feature rows + cell stamps, csrc/pillar_sparse.hip) instead
+        # of a dense tensor.  ``spatial_features`` is then a ``ops.SparseCanvas`` (``.shape`` as the tensor's, ``.dense()`` materialises the reference's tensor).
+        self.sparse_canvas = False
         self.nx = int(round((self.point_cloud_range[3] - self.point_cloud_range[0]) / self.voxel_x))
         self.ny = int(round((self.point_cloud_range[4] - self.point_cloud_range[1]) / self.voxel_y))
 
@@ -83,6 +86,14 @@ class PillarVFE(nn.Module):
         from . import backbone                       # the canvas layout follows the convolution route that will read it
         channels_last = backbone.NHWC_STAGE_OUTPUTS and backbone.emu_active() and backbone.FAST_INFERENCE
         count_dev = batch_dict.get("voxel_count_dev")
+        if self.sparse_canvas and channels_last and not self.with_distance and vf.shape[1] <= 32 and self.num_filters[-1] <= 64:
+            # round 4 fast path (the detector switches it on when its first ResNet block consumes it): ONE launch, feature rows + cell stamps, no dense canvas
+            sc = ops.pillar_encode_sparse(vf, npts, coords, pfn.linear.weight, pfn.linear.bias, bn, pfn.norm.eps if self.use_norm else 0.0, self.use_absolute_xyz,
+                                          self.voxel_size, self.point_cloud_range[:3], n_agents, self.ny, self.nx,
+                                          canvas_cache=self.__dict__.setdefault("_canvas_cache", {}), count_dev=count_dev)
+            batch_dict["pillar_features"] = sc.feats
+            batch_dict["_sparse_canvas"] = sc
+            return batch_dict
         if count_dev is not None:
             # the producer (the device voxeliser) left the pillar count on the device: capacity-sized arrays, no host read of the count,
             # always the persistent channels-last canvas (FramePipeline.submit_points; include/coalign_amd.h coalign_pillar_encode_stream)
@@ -115,6 +126,10 @@ class PointPillarScatter(nn.Module):
 
     def forward(self, batch_dict: dict) -> dict:
         feats, coords = batch_dict["pillar_features"], batch_dict["voxel_coords"]
+        sc = batch_dict.pop("_sparse_canvas", None)
+        if sc is not None and sc.feats is feats and sc.shape[1:] == (self.num_bev_features, self.ny, self.nx):
+            batch_dict["spatial_features"] = sc              # (the scatter already happened: 8 bytes per pillar)
+            return batch_dict
         fused = batch_dict.pop("_fused_canvas", None)
         if fused is not None and fused[0] is feats and tuple(fused[1].shape[1:]) == (self.num_bev_features, self.ny, self.nx):
             canvas = fused[1]

@@ -29,6 +29,11 @@ SIGNATURES = {
                                                  POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, c_int, P, P, P]),
     "coalign_pillar_encode_stream": (c_int, [P, P, P, c_int, P, c_int, P, P, P, P, P, P, c_float, c_int, c_int, c_int,
                                              POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, P, P, c_int, P]),
+    "coalign_sparse_canvas_stamp_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "coalign_pillar_encode_sparse": (c_int, [P, P, P, c_int, P, c_int, P, P, P, P, P, P, c_float, c_int, c_int, POINTER(c_double), POINTER(c_double),
+                                             c_int, c_int, c_int, P, P, P, P]),
+    "coalign_conv3x3_emu_sparse": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "coalign_pointwise_conv_emu_sparse": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_scatter_to_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     "coalign_warp_fuse": (c_int, [P, c_int, c_int, c_int, c_int, P, POINTER(c_int32), c_int, c_int, P, c_int, c_int, P]),
     "coalign_normalize_pairwise": (c_int, [P, c_int, c_int, c_int, c_double, c_double, P, P]),

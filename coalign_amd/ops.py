@@ -59,6 +59,8 @@ def _device_op(fn):
         for a in args:
             if isinstance(a, DecodeBuffers):
                 a = a.counts
+            elif isinstance(a, SparseCanvas):
+                a = a.feats
             if torch.is_tensor(a) and a.is_cuda:
                 if a.device.index != torch.cuda.current_device():
                     with torch.cuda.device(a.device):
@@ -191,6 +193,90 @@ def pillar_encode_stream(voxel_features: torch.Tensor, voxel_num_points: torch.T
                                                  _dbl3(range_min), n_agents, ny, nx, _ptr(feats), _ptr(entry["dest"]), _ptr(canvas), _ptr(entry["cellmap"]),
                                                  int(bool(unique_cells)), _stream()), "coalign_pillar_encode_stream")
     return feats, canvas
+
+
+class SparseCanvas:
+    """The BEV canvas of one batch as the sparse pair (feature rows, cell stamps) of csrc/pillar_sparse.hip instead of a dense tensor: what
+    ``PillarVFE`` + ``PointPillarScatter`` hand to the first ResNet stage on the fast path.  ``shape`` is the dense tensor's; ``dense()`` materialises it
+    (the reference's ``spatial_features``) for anyone who needs the tensor."""
+
+    def __init__(self, feats, stamps, state, coords, n_agents, C, ny, nx, count_dev=None):
+        self.feats, self.stamps, self.state, self.coords = feats, stamps, state, coords
+        self.n_agents, self.C, self.ny, self.nx, self.count_dev = n_agents, C, ny, nx, count_dev
+        self.shape = (n_agents, C, ny, nx)
+        self.device, self.dtype = feats.device, feats.dtype
+        self.is_cuda = True
+
+    def dense(self) -> torch.Tensor:
+        if self.count_dev is not None:
+            m = int(self.count_dev[0].item())
+            return scatter_to_bev(self.feats[:m], self.coords[:m], self.n_agents, self.ny, self.nx)
+        return scatter_to_bev(self.feats, self.coords, self.n_agents, self.ny, self.nx)
+
+
+@_device_op
+def pillar_encode_sparse(voxel_features: torch.Tensor, voxel_num_points: torch.Tensor, voxel_coords: torch.Tensor, weight: torch.Tensor,
+                         bias: Optional[torch.Tensor], bn: Optional[Tuple[torch.Tensor, ...]], bn_eps: float, use_absolute_xyz: bool,
+                         voxel_size: Sequence[float], range_min: Sequence[float], n_agents: int, ny: int, nx: int, canvas_cache: dict,
+                         count_dev: Optional[torch.Tensor] = None) -> SparseCanvas:
+    """PillarVFE + PointPillarScatter in ONE launch (include/coalign_amd.h (1b)): feature rows [M, C] + 8-byte cell stamps.  ``canvas_cache`` keeps the
+    stamp map and the frame-tag words of this (device, stream, grid): they persist across frames and are never cleared (a stamp is valid only with
+    the current tag).  ``count_dev``: optional int32 device tensor holding the pillar count (capacity-sized arrays)."""
+    _need_gpu(voxel_features, voxel_num_points, voxel_coords, weight)
+    L = hip.lib()
+    vf = _f32c(voxel_features)
+    if vf.dim() != 3 or vf.shape[2] != 4:
+        raise ValueError(f"voxel_features must be [M, P, 4], got {tuple(vf.shape)}")
+    M, P = vf.shape[0], vf.shape[1]
+    npts = voxel_num_points.to(torch.int32).contiguous()
+    coords = voxel_coords.to(torch.int32).contiguous()
+    w = _f32c(weight)
+    C = w.shape[0]
+    dev = vf.device
+    if P > 32 or C > 64:
+        raise hip.CoalignHipError("pillar_encode_sparse: P <= 32 and C <= 64")
+    key = ("sparse", str(dev), torch.cuda.current_stream(dev).cuda_stream, n_agents, ny, nx)
+    entry = canvas_cache.get(key)
+    if entry is None:
+        entry = canvas_cache[key] = {"stamps": torch.zeros(n_agents * ny * nx, dtype=torch.int64, device=dev), "state": torch.zeros(2, dtype=torch.int32, device=dev)}
+    feats = torch.empty((M, C), dtype=torch.float32, device=dev)
+    bnp = [None] * 4 if bn is None else [_f32c(t) for t in bn]
+    b = None if bias is None else _f32c(bias)
+    with _Timed("pillar_encode_sparse"):
+        hip.check(L.coalign_pillar_encode_sparse(_ptr(vf), _ptr(npts), _ptr(coords), M, _ptr(count_dev), P, _ptr(w), _ptr(b), _ptr(bnp[0]), _ptr(bnp[1]), _ptr(bnp[2]),
+                                                 _ptr(bnp[3]), float(bn_eps), C, int(use_absolute_xyz), _dbl3(voxel_size), _dbl3(range_min), n_agents, ny, nx,
+                                                 _ptr(feats), _ptr(entry["stamps"]), _ptr(entry["state"]), _stream()), "coalign_pillar_encode_sparse")
+    return SparseCanvas(feats, entry["stamps"], entry["state"], coords, n_agents, C, ny, nx, count_dev)
+
+
+@_device_op
+def conv3x3_emu_sparse(sc: SparseCanvas, w_split: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool, terms: int, out_channels_last: bool) -> torch.Tensor:
+    """The strided first convolution of the backbone reading a SparseCanvas (include/coalign_amd.h (9d)); tap-pair weight image."""
+    L = hip.lib()
+    N, Cin, H, W = sc.shape
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    if w_split.numel() != L.coalign_conv3x3_emu_weight_bytes(Cin, cout, terms):
+        raise ValueError("split weight image does not match (Cin, Cout, terms)")
+    y = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=sc.device, memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
+    with _Timed("conv3x3_emu_sparse"):
+        hip.check(L.coalign_conv3x3_emu_sparse(_ptr(sc.feats), _ptr(sc.stamps), _ptr(sc.state), _ptr(w_split), _ptr(_f32c(bias)), _ptr(y), N, Cin, cout, H, W,
+                                               int(relu), terms, int(out_channels_last), _stream()), "coalign_conv3x3_emu_sparse")
+    return y
+
+
+@_device_op
+def pointwise_conv_sparse(sc: SparseCanvas, w_emu: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool, out_channels_last: bool) -> torch.Tensor:
+    """The 1 x 1 / stride-2 skip convolution reading a SparseCanvas (include/coalign_amd.h (10b)); ``w_emu``: ``pack_pointwise_emu_weight`` image."""
+    L = hip.lib()
+    N, Cin, H, W = sc.shape
+    if w_emu.dtype != torch.int16 or w_emu.dim() != 5 or w_emu.shape[1] * 16 != Cin:
+        raise ValueError("pointwise_conv_sparse needs the split-bf16 weight image of this Cin")
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    y = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=sc.device, memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
+    with _Timed("pointwise_conv_sparse"):
+        hip.check(L.coalign_pointwise_conv_emu_sparse(_ptr(sc.feats), _ptr(sc.stamps), _ptr(sc.state), _ptr(w_emu), _ptr(_f32c(bias)), _ptr(y), N, Cin, H, W, cout,
+                                                      w_emu.shape[0] * 32, int(relu), int(out_channels_last), _stream()), "coalign_pointwise_conv_emu_sparse")
+    return y
 
 
 @_device_op

@@ -372,6 +372,25 @@ int coalign_conv3x3_wino(const float *x, const void *u_split, const float *bias,
  * buffers, voxel_postprocessor.py:243-402's per-frame state; graph-capture safe, no library launch). */
 int coalign_fill_words(void *p, size_t n_words, uint32_t value, void *stream);
 
+/* (1b) Round 4: PillarVFE + PointPillarScatter as ONE launch with a SPARSE canvas (csrc/pillar_sparse.hip).  Replaces the same reference modules as (1)
+ * (pillar_vfe.py:31-53,105-155, point_pillar_scatter.py:15-72) for callers that consume the canvas through (9d) / (10b) below.
+ *   pillar_features [M_capacity, C] out: the feature rows (C <= 64, P <= 32; the linearised PFN evaluated exactly in fp32 on v_mfma_f32_32x32x2_f32).
+ *   stamps: coalign_sparse_canvas_stamp_bytes(n_agents, ny, nx) bytes, 8-byte aligned, ZERO-INITIALISED ONCE by the caller and then owned by this
+ *     sequence of calls: 64-bit words (frame tag << 32) | pillar row per cell, entered by atomicMax -- the larger row of a cell wins, the reference's rule.
+ *   state: int32[2], zero-initialised once: state[0] = tag of the last completed call, state[1] = arrival counter.  A cell holds pillar row
+ *     (stamp & 0xffffffff) of THIS frame iff (stamp >> 32) == state[0] after the call; nothing is cleared between frames.
+ *   M_dev (may be NULL): the pillar count on the device (int32), M_capacity then sizes the arrays.  No distance feature (with_distance configs use (1)). */
+size_t coalign_sparse_canvas_stamp_bytes(int n_agents, int ny, int nx);
+int coalign_pillar_encode_sparse(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M_capacity,
+                                 const int32_t *M_dev, int P, const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias,
+                                 const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz, const double *voxel_size,
+                                 const double *range_min, int n_agents, int ny, int nx, float *pillar_features, void *stamps, int32_t *state, void *stream);
+/* (9d) The strided 3x3 convolution of (9b) (stride 2, pad 1, bias + ReLU; resblock.py:150-174) reading the sparse canvas of (1b): feats [M, Cin], pixel
+ * (n, y, x) of the logical [N, Hin, Win, Cin] input = feats row (stamp & 0xffffffff) where the cell's stamp carries state[0], else zero.
+ * y: [N, Cout, ceil(Hin/2), ceil(Win/2)] NCHW, or channels-last if out_nhwc != 0.  terms in {2, 3, 16} with the tap-pair weight image of (9b). */
+int coalign_conv3x3_emu_sparse(const float *feats, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y, int N, int Cin,
+                               int Cout, int Hin, int Win, int relu, int terms, int out_nhwc, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * (10) Pointwise layers of the BEV backbone as one GEMM launch each, bias (+ ReLU) fused, NCHW float32:
  *   up in {1, 2, 4}, in_stride = 1:  ConvTranspose2d(kernel = stride = up) + eval BatchNorm (folded) + ReLU of the up-sampling heads
@@ -400,6 +419,11 @@ int coalign_pointwise_conv_ex(const float *x, const float *w, const float *bias,
 size_t coalign_pointwise_emu_weight_bytes(int Cin, int M_padded);
 int coalign_pointwise_conv_emu(const float *x, const void *w_split, const float *bias, float *y, int N, int Cin, int Hin, int Win, int in_stride,
                                int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, void *stream);
+
+/* (10b) The 1 x 1 / stride-2 skip convolution of (10) on the split-bf16 matrix cores reading the sparse canvas of (1b) (resblock.py:165-174).
+ * y: [N, Cout, ceil(Hin/2), ceil(Win/2)] NCHW, or channels-last if out_nhwc != 0 (Cout % 4 == 0). */
+int coalign_pointwise_conv_emu_sparse(const float *feats, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y, int N,
+                                      int Cin, int Hin, int Win, int Cout, int M_padded, int relu, int out_nhwc, void *stream);
 
 #ifdef __cplusplus
 }
