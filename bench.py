@@ -114,6 +114,11 @@ def pillar_bytes_moved(M):
     return M * (532 + 256 + 256 + 256 + 12)
 
 
+def pillar_bytes_sparse(M):
+    """Bytes of the one-launch sparse-canvas pillar op per call: per pillar 532 B in, 256 B feature row out, one 8-byte stamp read-modify-write (16 B)."""
+    return M * (532 + 256 + 16)
+
+
 def size_sweep(dev, steps=20):
     """VERDICT r03 item 3 / SURVEY 8d: the HBM-bound ops where the roofline bites.  Pillar op at M in {8000, 32000, 70000} pillars per agent
     (max_voxel_train / max_voxel_test of pointpillar_coalign.yaml:52-54) x 5 agents, at N = 2 (cfg 2) and at DAIR-V2X geometry 504 x 200 (cfg 4);
@@ -136,17 +141,21 @@ def size_sweep(dev, steps=20):
             fr["record_len"] = [n]
             M = int(fr["processed_lidar"]["voxel_features"].shape[0])
             pl_in = dict(fr["processed_lidar"], record_len=[n])
-            keep = mdl.pillar_vfe.persistent_canvas
-            mdl.pillar_vfe.persistent_canvas = True
+            from coalign_amd import detector as det_mod
+            rn = getattr(mdl.backbone, "resnet", None)
+            sparse = bool(det_mod.SPARSE_CANVAS and rn is not None and hasattr(rn, "layer0") and rn.layer0[0].takes_sparse_canvas())
+            keep = (mdl.pillar_vfe.persistent_canvas, mdl.pillar_vfe.sparse_canvas)
+            mdl.pillar_vfe.persistent_canvas, mdl.pillar_vfe.sparse_canvas = True, sparse
             with torch.no_grad():
                 t_p = graph_time(lambda: mdl.pillar_vfe(dict(pl_in)), dev)
+                mdl.pillar_vfe.sparse_canvas = keep[1]
                 feats, aff = mdl.encode(fr)
                 t_f = graph_time(lambda: mdl._fuse_scales(list(feats), [n], aff), dev)
-            mdl.pillar_vfe.persistent_canvas = keep
+            mdl.pillar_vfe.persistent_canvas = keep[0]
             fb = sum((n + 1) * int(f.shape[1]) * int(f.shape[2]) * int(f.shape[3]) * 4 for f in feats)
-            pb = pillar_bytes_moved(M)
+            pb = pillar_bytes_sparse(M) if sparse else pillar_bytes_moved(M)
             row = {"config": cfg, "canvas": [nx, ny], "agents": n, "pillars_per_agent": m,
-                   "pillar_op": {"us": round(t_p * 1e3, 2), "bytes_moved_model": pb, "GBps": round(pb / t_p / 1e6, 1), "frac": round(pb / t_p / 1e6 / HBM_PEAK_GBPS, 4),
+                   "pillar_op": {"form": "one launch, sparse canvas" if sparse else "persistent dense canvas, two launches", "us": round(t_p * 1e3, 2), "bytes_moved_model": pb, "GBps": round(pb / t_p / 1e6, 1), "frac": round(pb / t_p / 1e6 / HBM_PEAK_GBPS, 4),
                                  "read_bytes_survey_8d": M * 532, "frac_read_only": round(M * 532 / t_p / 1e6 / HBM_PEAK_GBPS, 4)},
                    "fusion": {"us": round(t_f * 1e3, 2), "algorithmic_bytes": fb, "GBps": round(fb / t_f / 1e6, 1), "frac": round(fb / t_f / 1e6 / HBM_PEAK_GBPS, 4)},
                    "path_frac": round((pb + fb) / (t_p + t_f) / 1e6 / HBM_PEAK_GBPS, 4)}
@@ -433,7 +442,19 @@ def main():
         with torch.no_grad():
             f0 = frames[0]
             pl_in = dict(f0["processed_lidar"], record_len=f0["record_len"])
-            iso["pillar_ms"] = graph_time(lambda: model.pillar_vfe(dict(pl_in)), dev) if world == 1 else hip_time(lambda: model.pillar_vfe(dict(pl_in)))
+            # the pillar op of the timed configuration: the one-launch sparse-canvas encoder when the model's first ResNet block reads it (round 4), else
+            # the persistent dense canvas (two launches); the other forms beside it
+            from coalign_amd import detector as det_mod
+            rn = getattr(model.backbone, "resnet", None)
+            sparse_on = bool(det_mod.SPARSE_CANVAS and rn is not None and hasattr(rn, "layer0") and rn.layer0[0].takes_sparse_canvas() and not getattr(model, "compression", False))
+            tp = (lambda fn: graph_time(fn, dev)) if world == 1 else hip_time
+            if sparse_on:
+                model.pillar_vfe.sparse_canvas = True
+                iso["pillar_ms"] = tp(lambda: model.pillar_vfe(dict(pl_in)))
+                model.pillar_vfe.sparse_canvas = False
+                iso["pillar_dense_persistent_ms"] = tp(lambda: model.pillar_vfe(dict(pl_in)))
+            else:
+                iso["pillar_ms"] = tp(lambda: model.pillar_vfe(dict(pl_in)))
             if model.pillar_vfe.persistent_canvas and world == 1:      # the same op on a fresh canvas every call (dense memset included)
                 model.pillar_vfe.persistent_canvas = False
                 iso["pillar_fresh_canvas_ms"] = graph_time(lambda: model.pillar_vfe(dict(pl_in)), dev)
@@ -606,6 +627,7 @@ def main():
         alg_live = dict(alg_bytes)
         if default_terms in (2, 3, 16):     # the pipeline's persistent canvas: bytes really moved per call (see pillar_moved_model below), not the dense-canvas formula
             alg_live["pillar_vfe_scatter"] = M * (532 + 256 + 256 + 256 + 12)
+            alg_live["pillar_encode_sparse"] = pillar_bytes_sparse(M)
         for name, pairs in sorted(prof.items()):
             ms = sum(s.elapsed_time(e) for s, e in pairs) / len(pairs)
             b = alg_live.get(name)
@@ -641,10 +663,15 @@ def main():
         #      Algorithmic bytes of the pillar op = what the timed configuration has to move per call (pillar_bytes_moved: the persistent canvas
         #      writes and clears rows, never a dense zero-fill); SURVEY 8d's formula, which counts a dense canvas write, is `frac_survey_8d_formula`
         #      beside the time of the SAME path with a freshly zero-filled canvas per call (rounds 1-2 reported that one).
-        pillar_alg = pillar_bytes_moved(M) if persistent else alg_bytes["pillar_vfe_scatter"]
-        pillar = hbm_entry("pillar_vfe_scatter = pillar_prep_kernel + pillar_rows_mx_kernel (persistent channels-last canvas: only the previous frame's rows are cleared)" if persistent
+        sparse_on = "pillar_dense_persistent_ms" in iso
+        pillar_alg = pillar_bytes_sparse(M) if sparse_on else pillar_bytes_moved(M) if persistent else alg_bytes["pillar_vfe_scatter"]
+        pillar = hbm_entry("pillar_vfe_scatter = pillar_sparse_kernel: ONE launch, feature rows + 8-byte cell stamps, no dense canvas, nothing cleared (csrc/pillar_sparse.hip)" if sparse_on else
+                           "pillar_vfe_scatter = pillar_prep_kernel + pillar_rows_mx_kernel (persistent channels-last canvas: only the previous frame's rows are cleared)" if persistent
                            else "pillar_vfe_scatter = memset + cellmap_kernel + pillar_canvas_kernel", iso["pillar_ms"], pillar_alg,
-                           traffic_of("pillar_nhwc_persistent" if persistent else "pillar_nchw"), "pillar_vfe_scatter")
+                           traffic_of("pillar_sparse" if sparse_on else "pillar_nhwc_persistent" if persistent else "pillar_nchw"), "pillar_encode_sparse" if sparse_on else "pillar_vfe_scatter")
+        if sparse_on:
+            pillar["dense_persistent_canvas_form"] = {"avg_launch_ms": round(iso["pillar_dense_persistent_ms"], 5), "bytes_moved_model": pillar_bytes_moved(M),
+                                                      "frac": round(pillar_bytes_moved(M) / iso["pillar_dense_persistent_ms"] / 1e6 / HBM_PEAK_GBPS, 4)}
         pillar["survey_8d_formula_bytes"] = alg_bytes["pillar_vfe_scatter"]
         pillar["read_bytes"] = M * 532
         pillar["frac_read_only"] = round(M * 532 / iso["pillar_ms"] / 1e6 / HBM_PEAK_GBPS, 4)

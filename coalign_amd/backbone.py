@@ -254,7 +254,7 @@ class BasicBlock(nn.Module):
 
     def takes_sparse_canvas(self) -> bool:
         """This block reads a ``ops.SparseCanvas`` directly (round 4): strided 3x3 + pointwise skip on the split matrix cores."""
-        if self.training or self.stride != 2 or self.downsample is None or not emu_active() or not NHWC_STAGE_OUTPUTS or not POINTWISE_EMU:
+        if self.training or self.stride != 2 or self.downsample is None or CONV_EMU_TERMS not in (3, 16) or not NHWC_STAGE_OUTPUTS or not POINTWISE_EMU:      # (the skip convolution's split-bf16 image exists in these two modes)
             return False
         c1 = self.conv1
         return c1.out_channels % 64 == 0 and c1.in_channels % 16 == 0 and c1.in_channels <= 256 and self.downsample[0].stride[0] == 2 and self.downsample[0].out_channels % 32 == 0

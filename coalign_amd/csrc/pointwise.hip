@@ -279,7 +279,7 @@ static int pointwise_impl(const float *x, const float *w, const float *bias, flo
     if (emu && ((Cin & 15) || (reinterpret_cast<uintptr_t>(w) & 15))) return COALIGN_ERR_UNSUPPORTED;
     if (N < 0 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1 || Ctot < Cout || c_off < 0 || c_off + Cout > Ctot) return COALIGN_ERR_BAD_SHAPE;
     if ((in_nhwc & 1) && ((Cin & 3) || (reinterpret_cast<uintptr_t>(x) & 15))) return COALIGN_ERR_UNSUPPORTED;
-    if (Cin > kMaxCin || (Cin & 1) || (up != 1 && up != 2 && up != 4) || (in_stride != 1 && in_stride != 2) || (up != 1 && in_stride != 1))
+    if (Cin > (emu ? 2 * kMaxCin : kMaxCin) || (Cin & 1) || (up != 1 && up != 2 && up != 4) || (in_stride != 1 && in_stride != 2) || (up != 1 && in_stride != 1))
         return COALIGN_ERR_UNSUPPORTED;
     const int M = Cout * up * up;
     if (M_padded < M || M_padded % 32 || (up != 1 && M_padded != M)) return COALIGN_ERR_BAD_SHAPE;
@@ -302,7 +302,20 @@ static int pointwise_impl(const float *x, const float *w, const float *bias, flo
     const dim3 grid((pixels + px_per_wg - 1) / px_per_wg, (M_padded + rows_per_wg - 1) / rows_per_wg, N);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (emu) {
-        const size_t lds = (size_t)Cin * px_per_wg * 6;           // three bf16 terms of the pixel tile (<= 48 KB)
+        const size_t lds = (size_t)Cin * px_per_wg * 6;           // three bf16 terms of the pixel tile (<= 48 KB up to 256 input channels, 96 KB at 512)
+        static bool big_lds = false;                              // (beyond 64 KB of dynamic LDS the kernels need the attribute: the merged heads of a 384-channel map)
+        if (lds > 48 * 1024 && !big_lds) {
+            const void *fns[3] = {reinterpret_cast<const void *>(pointwise_emu_kernel<1>), reinterpret_cast<const void *>(pointwise_emu_kernel<2>),
+                                  reinterpret_cast<const void *>(pointwise_emu_kernel<4>)};
+            for (const void *fn : fns) {
+                const int rc = hip_call(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                if (rc != COALIGN_OK) {
+                    (void)hipGetLastError();
+                    return rc;
+                }
+            }
+            big_lds = true;
+        }
         if (up == 4) hipLaunchKernelGGL(pointwise_emu_kernel<4>, grid, dim3(256), lds, s, a);
         else if (up == 2) hipLaunchKernelGGL(pointwise_emu_kernel<2>, grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL(pointwise_emu_kernel<1>, grid, dim3(256), lds, s, a);
@@ -321,7 +334,7 @@ extern "C" int coalign_pointwise_conv_ex(const float *x, const float *w, const f
 }
 
 extern "C" size_t coalign_pointwise_emu_weight_bytes(int Cin, int M_padded) {
-    if (Cin < 16 || (Cin & 15) || Cin > kMaxCin || M_padded < 32 || (M_padded & 31)) return 0;
+    if (Cin < 16 || (Cin & 15) || Cin > 2 * kMaxCin || M_padded < 32 || (M_padded & 31)) return 0;
     return (size_t)M_padded * Cin * 6;
 }
 

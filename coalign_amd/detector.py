@@ -43,7 +43,7 @@ def _run_heads(model: nn.Module, x: torch.Tensor) -> dict:
         return (torch.cat([h.weight for _, h in heads]).contiguous(), torch.cat([h.bias for _, h in heads]).contiguous())
     w, b = _cache_of(model.cls_head).get([t for _, h in heads for t in (h.weight, h.bias)], build)
     from . import backbone as _bb
-    if _bb.CONV_EMU_TERMS in (3, 16) and _bb.POINTWISE_EMU and w.shape[1] % 16 == 0 and w.shape[1] <= 256:
+    if _bb.CONV_EMU_TERMS in (3, 16) and _bb.POINTWISE_EMU and w.shape[1] % 16 == 0 and w.shape[1] <= 512:
         # round 4: the merged 1x1 heads on the hand-written pointwise kernel (split-bf16 matrix cores; GEMM rows padded to 32), reading the shrink
         # header's map in whatever layout it has and writing the NCHW maps the decode kernel reads -- no rocBLAS / bias pass in the frame
         pk = _cache_of(model.reg_head).get([t for _, h in heads for t in (h.weight, h.bias)], lambda: _bb.PointwisePack(w, False))

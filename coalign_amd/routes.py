@@ -20,7 +20,9 @@ import torch.nn as nn
 from . import backbone as bb
 from .detector import MODEL_REGISTRY, build_model
 
-EMU, F32, MIOPEN, ROCBLAS, POINTWISE = "conv3x3_emu (split-bf16 matrix cores)", "conv3x3 (fp32 matrix cores) / MIOpen by shape", "MIOpen", "rocBLAS (1x1 heads)", "pointwise"
+EMU, F32, MIOPEN, ROCBLAS, POINTWISE = "conv3x3_emu (split 16-bit matrix cores)", "conv3x3 (fp32 matrix cores) / MIOpen by shape", "MIOpen", "rocBLAS (1x1 heads)", "pointwise"
+WINO = "conv3x3_wino (Winograd F(2x2,3x3), split-bf16 matrix cores)"
+DEFAULT_TERMS = 16      # backbone.CONV_EMU_TERMS: the 2-way fp16 split since round 4
 
 
 def _conv3x3_route(conv: nn.Conv2d, terms: int) -> str:
@@ -31,17 +33,21 @@ def _conv3x3_route(conv: nn.Conv2d, terms: int) -> str:
     ok = conv.out_channels % 64 == 0 and conv.in_channels % 8 == 0 and s in (1, 2)
     if not ok:
         return MIOPEN + f" (unpackable: Cout {conv.out_channels} % 64 or Cin {conv.in_channels} % 8 or stride {s})"
-    if terms in (2, 3):
-        return EMU + (", tap-major image" if s == 1 and conv.in_channels % 16 == 0 else ", tap-pair image")
+    if terms in (2, 3, 16):
+        if terms == 16 and s == 1 and conv.in_channels % 16:
+            return F32 + " (the fp16 split serves the tap-major and the strided images)"
+        if terms == 3 and s == 1 and bb.CONV_WINOGRAD and conv.in_channels % 16 == 0:
+            return WINO + " when its input is channels-last (COALIGN_WINOGRAD=1)"
+        return EMU + (", tap-major image" if s == 1 and conv.in_channels % 16 == 0 else ", tap-pair image") + {2: ", bf16 x 2", 3: ", bf16 x 3", 16: ", fp16 x 2"}[terms]
     return F32 if s == 1 else MIOPEN + " (native mode, strided)"
 
 
 def _pointwise_route(cin: int, terms: int) -> str:
     """backbone.PointwisePack.get: split-bf16 image when the 3x3 layers use the 3-way split and Cin % 16 == 0, else the fp32 kernel."""
-    return POINTWISE + (" (split-bf16 matrix cores)" if terms == 3 and cin % 16 == 0 and bb.POINTWISE_EMU else " (fp32 matrix cores)")
+    return POINTWISE + (" (split-bf16 matrix cores)" if terms in (3, 16) and cin % 16 == 0 and bb.POINTWISE_EMU else " (fp32 matrix cores)")
 
 
-def plan(hypes: dict, terms: int = 3) -> Dict[str, object]:
+def plan(hypes: dict, terms: int = DEFAULT_TERMS) -> Dict[str, object]:
     """-> {"model", "layers": {module name: route}, "pillar", "fusion", "fallbacks": [names of 3x3 / pointwise layers NOT on a hand-written
     kernel], "outside_hot_path": reason or None}."""
     name = hypes["model"]["core_method"]
@@ -66,7 +72,9 @@ def plan(hypes: dict, terms: int = 3) -> Dict[str, object]:
                 r = _conv3x3_route(m, terms)
                 note(n, r, r.startswith(MIOPEN))
             elif tuple(m.kernel_size) == (1, 1) and n.endswith("_head"):
-                layers[n] = ROCBLAS
+                # detector._run_heads: the merged 1x1 heads on the pointwise kernel (GEMM rows padded to 32) when the split-bf16 image exists
+                ok = terms in (3, 16) and bb.POINTWISE_EMU and m.in_channels % 16 == 0 and m.in_channels <= 512
+                note(n, _pointwise_route(m.in_channels, terms) + ", merged 1x1 heads" if ok else ROCBLAS, not ok)
             elif tuple(m.kernel_size) == (1, 1) and ".downsample." in n:      # BasicBlock skip: pointwise kernel when stride 2, Cin even and <= 256
                 ok = m.stride[0] == 2 and m.in_channels % 2 == 0 and m.in_channels <= 256
                 note(n, _pointwise_route(m.in_channels, terms) if ok else MIOPEN + " (skip convolution outside the pointwise kernel's shapes)", not ok)
@@ -92,14 +100,19 @@ def plan(hypes: dict, terms: int = 3) -> Dict[str, object]:
         elif vfe.with_distance or P > 32 or C > 64:
             pillar = "fp32 VALU encoder (distance feature / P > 32 / C > 64)"
         else:
-            pillar = "matrix-core encoder (linearised PFN, split-bf16)" if terms in (2, 3) else "matrix-core encoder, NCHW strip writer"
+            rn = getattr(getattr(model, "backbone", None), "resnet", None)
+            first = rn.layer0[0] if rn is not None and hasattr(rn, "layer0") else None
+            sparse = (terms in (3, 16) and first is not None and first.stride == 2 and first.downsample is not None and first.conv1.out_channels % 64 == 0 and
+                      first.conv1.in_channels % 16 == 0 and first.downsample[0].out_channels % 32 == 0 and "compression" not in hypes["model"]["args"])
+            pillar = ("matrix-core encoder (exact fp32 matrix instruction), ONE launch, sparse canvas read by the first ResNet block" if sparse else
+                      "matrix-core encoder (linearised PFN, split-bf16), persistent dense canvas" if terms in (2, 3, 16) else "matrix-core encoder, NCHW strip writer")
     fusion = None
     if hasattr(model, "fusion_net"):
         dims = [int(d) for d in hypes["model"]["args"]["base_bev_backbone"]["num_filters"]]
         if len(model.fusion_net) != len(dims):
             dims = dims[-len(model.fusion_net):]
         feat = [getattr(f, "feature_dims", None) for f in model.fusion_net]
-        if terms in (2, 3) and len(dims) <= 3 and all(d in (64, 128, 256) for d in dims) and all(fd in (None, d) for fd, d in zip(feat, dims)):
+        if terms in (2, 3, 16) and len(dims) <= 3 and all(d in (64, 128, 256) for d in dims) and all(fd in (None, d) for fd, d in zip(feat, dims)):
             fusion = "warp_fuse_nhwc: all scales in one launch (channels-last)"
         else:
             fusion = "warp_fuse: one launch per scale (NCHW, LDS-staged patches)"
