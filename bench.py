@@ -91,10 +91,12 @@ def kernel_trace_us():
     return out
 
 
-def graph_time(fn, dev, iters=10):
-    """GPU-side duration (ms) of the launches ``fn`` makes: captured once into a HIP graph and replayed, so that the host-side gaps
-    between small dependent launches (ctypes + allocator, ~10 us each) do not count as kernel time.  Warm-up and capture run on the same
-    stream (per-stream state such as the persistent canvas must exist before the capture)."""
+def graph_time(fn, dev, iters=10, reps=8):
+    """GPU-side duration (ms) of the launches ONE call of ``fn`` makes: ``reps`` calls are captured into one HIP graph and the graph is replayed, so
+    that neither the host-side gaps between small dependent launches (ctypes + allocator, ~10 us each) nor the fixed cost of a graph replay
+    (measured round 4: 17 us per replay of a graph holding ONE empty kernel -- MI355X_MICROARCH.md "graph-replay-floor") count as kernel time.
+    Rounds 1-3 captured one call per graph: ops shorter than the floor read as the floor.  Warm-up and capture run on the same stream (per-stream
+    state such as the persistent canvas or the sparse canvas's frame tag must exist before the capture)."""
     gs = torch.cuda.Stream(device=dev)
     gs.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(gs):
@@ -102,10 +104,12 @@ def graph_time(fn, dev, iters=10):
         fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
+    keep = []
     with torch.cuda.graph(g, stream=gs):
-        fn()
+        for _ in range(reps):
+            keep.append(fn())
     torch.cuda.synchronize()
-    return hip_time(g.replay, iters=iters)
+    return hip_time(g.replay, iters=iters) / reps
 
 
 def pillar_bytes_moved(M):

@@ -24,6 +24,10 @@ LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip.so")
 # kernel variants (read from COALIGN_* environment variables).  The product library above contains none of them; `python -m coalign_amd.build --lab`
 # builds it, COALIGN_LAB=1 makes coalign_amd.hip load it.
 LAB_LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip_lab.so")
+# A second laboratory build WITHOUT -fno-slp-vectorize / -fno-vectorize (packed fp32 instructions allowed again): exists only to re-examine round 3's
+# "packed fp32 beside matrix wavefronts" finding (the inline-asm LDS-DMA's missing "m0" clobber, fixed in the same commit, is the likelier
+# cause).  `python -m coalign_amd.build --labvec`; COALIGN_LAB=vec loads it.  tools/pk_f32_recheck.sh runs the experiment.
+LABVEC_LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip_labvec.so")
 INCLUDE = os.path.join(REPO, "include")
 SOURCES = ["status.cpp", "pillar_scatter.hip", "pillar_sparse.hip", "warp_fuse.hip", "warp_fuse_nhwc.hip", "decode.hip", "nms.hip", "epilogue.hip", "voxelize.hip", "pose_graph.hip", "conv3x3.hip", "conv3x3_emu.hip", "conv3x3_wino.hip", "pointwise.hip"]
 ARCH = "gfx950"
@@ -51,9 +55,11 @@ def _newest(paths) -> float:
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
-    OBJ = os.path.join(CSRC, "_obj_lab" if lab else "_obj")
-    LIB_PATH = LAB_LIB_PATH if lab else globals()["LIB_PATH"]
+def build(force: bool = False, verbose: bool = False, lab: bool = False, vectorize: bool = False) -> str:
+    OBJ = os.path.join(CSRC, "_obj_labvec" if vectorize else "_obj_lab" if lab else "_obj")
+    LIB_PATH = LABVEC_LIB_PATH if vectorize else LAB_LIB_PATH if lab else globals()["LIB_PATH"]
+    lab = lab or vectorize
+    flags = [f for f in FLAGS if not (vectorize and f in ("-fno-slp-vectorize", "-fno-vectorize"))]
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     headers = [os.path.join(INCLUDE, "coalign_amd.h"), os.path.join(CSRC, "common.h"), os.path.abspath(__file__)]
@@ -63,7 +69,7 @@ def build(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         if force or not os.path.exists(op) or os.path.getmtime(op) < _newest([sp] + headers):
-            cmd = [hipcc, "-x", "hip"] + FLAGS + (["-DCOALIGN_LAB"] if lab else []) + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", op]
+            cmd = [hipcc, "-x", "hip"] + flags + (["-DCOALIGN_LAB"] if lab else []) + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
@@ -80,7 +86,7 @@ def build(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, lab="--lab" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, lab="--lab" in sys.argv, vectorize="--labvec" in sys.argv))
 
 
 def packed_fp32_count(src: str) -> int:

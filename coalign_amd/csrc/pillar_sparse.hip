@@ -30,7 +30,12 @@ typedef __attribute__((address_space(3))) void *lptr_sp_t;
 
 constexpr int kWaves = 4;                   // wavefronts per workgroup
 constexpr int kRunPairs = 32;               // pillar pairs per wavefront at most (one lane per pillar in the prologue)
-constexpr int kRound = 5;                   // pairs per LDS-DMA round (5 KB per buffer)
+constexpr int kRound = 3;                   // pairs per LDS-DMA round (3 KB per buffer: 8 KB of LDS per wavefront, five workgroups per CU)
+#ifdef COALIGN_LAB
+constexpr bool kLab = true;
+#else
+constexpr bool kLab = false;
+#endif
 
 struct SparseArgs {
     const float4 *pts;
@@ -46,6 +51,7 @@ struct SparseArgs {
     unsigned long long *stamps;
     int *state;
     const int *M_dev;
+    int debug;            // laboratory build only (COALIGN_SPARSE_DEBUG): 1 no stamp atomics, 2 no matrix steps, 4 no arrival counter, 8 no feature stores
 };
 
 __device__ __forceinline__ void swap32(float &a, float &b) {       // lanes 32-63 of a <-> lanes 0-31 of b
@@ -84,35 +90,56 @@ struct F32Chan {
     float alpha[2], shift[2], sgn[2];
 };
 
+// raw per-lane channel parameters (loads only) ...
 template <bool ABS>
-__device__ __forceinline__ F32Chan load_f32(const SparseArgs &a, int lane) {
+struct F32Raw {
+    static constexpr int CIN = ABS ? 10 : 7;
+    float w[2][CIN], bw[2], bb[2], bm[2], bv[2], lb[2];
+};
+
+template <bool ABS>
+__device__ __forceinline__ F32Raw<ABS> load_f32_raw(const SparseArgs &a, int lane) {
+    // every load is unconditional on a clamped channel index and independent of the others: the compiler issues them back to back and waits once
+    // (with the loads inside `if (c < C)` blocks this took ten dependent round trips, ~10 000 cycles per wavefront)
+    F32Raw<ABS> r;
+    const int col = lane & 31;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int cc = min(g * 32 + col, a.C - 1);
+#pragma unroll
+        for (int k = 0; k < F32Raw<ABS>::CIN; ++k) r.w[g][k] = a.weight[(size_t)cc * F32Raw<ABS>::CIN + k];
+        r.bw[g] = a.bn_w ? a.bn_w[cc] : 1.f; r.bb[g] = a.bn_w ? a.bn_b[cc] : 0.f; r.bm[g] = a.bn_w ? a.bn_m[cc] : 0.f; r.bv[g] = a.bn_w ? a.bn_v[cc] : 1.f;
+        r.lb[g] = (!a.bn_w && a.bias) ? a.bias[cc] : 0.f;
+    }
+    return r;
+}
+
+// ... and the folded form the pair loop uses
+template <bool ABS>
+__device__ __forceinline__ F32Chan finish_f32(const F32Raw<ABS> &r, const SparseArgs &a, int lane) {
     F32Chan fc;
     constexpr int B = ABS ? 4 : 1;
     const int half = lane >> 5, col = lane & 31;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const int c = g * 32 + col;
-        float w4[4] = {0.f, 0.f, 0.f, 0.f};
-        float alpha = 1.f, shift = 0.f;
-        if (c < a.C) {
-            if (a.bn_w) {
-                const float inv_std = 1.0f / sqrtf(a.bn_v[c] + a.eps);
-                alpha = a.bn_w[c] * inv_std;
-                shift = a.bn_b[c] - a.bn_m[c] * alpha;
-            } else if (a.bias) {
-                shift = a.bias[c];
-            }
-            const float *w = a.weight + (size_t)c * a.Cin;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) w4[k] = ((ABS ? w[k] : 0.f) + w[B + k]) + w[B + 3 + k];
-            w4[3] = w[ABS ? 3 : 0];
+        const bool live = g * 32 + col < a.C;
+        float alpha = 1.f, shift = r.lb[g];
+        if (a.bn_w) {
+            const float inv_std = 1.0f / sqrtf(r.bv[g] + a.eps);
+            alpha = r.bw[g] * inv_std;
+            shift = r.bb[g] - r.bm[g] * alpha;
         }
+        if (!live) { alpha = 1.f; shift = 0.f; }
+        float w4[4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w4[k] = live ? ((ABS ? r.w[g][k] : 0.f) + r.w[g][B + k]) + r.w[g][B + 3 + k] : 0.f;
+        w4[3] = live ? r.w[g][ABS ? 3 : 0] : 0.f;
         const float sg = alpha < 0.f ? -1.f : 1.f;       // a negative BatchNorm scale turns the max over the rows into a min: negate the weights instead
         fc.alpha[g] = alpha; fc.shift[g] = shift; fc.sgn[g] = sg;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            fc.wc[g][k] = (ABS && c < a.C) ? a.weight[(size_t)c * a.Cin + k] : 0.f;
-            fc.wen[g][k] = (c < a.C) ? -a.weight[(size_t)c * a.Cin + B + k] : 0.f;
+            fc.wc[g][k] = (ABS && live) ? r.w[g][k] : 0.f;
+            fc.wen[g][k] = live ? -r.w[g][B + k] : 0.f;
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) fc.wb[g][s] = sg * (half ? w4[2 * s + 1] : w4[2 * s]);
@@ -146,6 +173,10 @@ __device__ __forceinline__ void f32_pair_half(const SparseArgs &a, const F32Chan
     swap32(d2, d3);
     const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     floatx16 accA[2], accB[2];
+    if (kLab && (a.debug & 2)) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) { accA[g] = zero; accB[g] = zero; accA[g][0] = d0 + d2; accB[g][0] = d1 + d3; }
+    } else {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         accA[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, fc.wb[g][0], zero, 0, 0, 0);
@@ -155,6 +186,7 @@ __device__ __forceinline__ void f32_pair_half(const SparseArgs &a, const F32Chan
     for (int g = 0; g < 2; ++g) {
         accA[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, fc.wb[g][1], accA[g], 0, 0, 0);
         accB[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(d3, fc.wb[g][1], accB[g], 0, 0, 0);
+    }
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -181,7 +213,10 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
     char *pbuf = lds + wv * kWaveLds;
     char *meta = pbuf + 2 * kRound * 1024;
     const int gwave = blockIdx.x * kWaves + wv, nwave = gridDim.x * kWaves;
+    if (kLab && (a.debug & 128)) return;
     if (a.M_dev) a.M = min(max(*a.M_dev, 0), a.M);
+    long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (kLab && (a.debug & 256)) ts[0] = (long long)__builtin_amdgcn_s_memtime();
     const unsigned tag = (unsigned)a.state[0] + 1u;                  // this frame's tag (state[0] is written only when the last workgroup has finished)
     const int npairs = (a.M + 1) / 2;
     const int per_wave = (npairs + nwave - 1) / nwave;
@@ -196,7 +231,7 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
             const int nr = min(kRound, p1 - r0);
 #pragma unroll
             for (int k = 0; k < kRound; ++k) {
-                if (k < nr) {
+                if (k < nr && !(kLab && (a.debug & 64))) {
                     const int m = min(2 * (r0 + k) + half, a.M - 1);
                     const char *src = pts_b + (unsigned)(m * a.P + min(col, a.P - 1)) * 16u;
                     const unsigned dst = (unsigned)(size_t)(lptr_sp_t)(pbuf + (buf * kRound + k) * 1024);
@@ -205,23 +240,32 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
             }
         };
         issue_round(p0, 0);
-        if (lane < 2 * (p1 - p0)) {                                  // counts, coordinates, cells of the whole run: once per wavefront; the stamp of every pillar
-            const int m_j = 2 * p0 + lane;
-            const int mj = min(m_j, a.M - 1);
-            const int np_j = *reinterpret_cast<const int *>(np_b + (unsigned)mj * 4u);
-            const int4 cd_j = *reinterpret_cast<const int4 *>(cd_b + (unsigned)mj * 16u);
+        // counts, coordinates, cells of the whole run: once per wavefront (one lane per pillar); the channel parameters' loads go out before anything waits
+        const bool pro = lane < 2 * (p1 - p0);
+        const int m_j = 2 * p0 + lane, mj = min(m_j, a.M - 1);
+        int np_j = 0;
+        int4 cd_j = make_int4(0, 0, 0, 0);
+        if (pro) {
+            np_j = *reinterpret_cast<const int *>(np_b + (unsigned)mj * 4u);
+            cd_j = *reinterpret_cast<const int4 *>(cd_b + (unsigned)mj * 16u);
+        }
+        const F32Raw<ABS> raw = load_f32_raw<ABS>(a, lane);
+        if (pro) {
             const int cell = cd_j.y + cd_j.z * a.nx + cd_j.w;       // z + y * nx + x (point_pillar_scatter.py:54)
             const bool ok = m_j < a.M && cd_j.x >= 0 && cd_j.x < a.n_agents && cell >= 0 && cell < ncell;
-            if (ok) atomicMax(a.stamps + (size_t)cd_j.x * ncell + cell, ((unsigned long long)tag << 32) | (unsigned)m_j);      // the larger row of a cell wins
+            if (ok && !(kLab && (a.debug & 1))) atomicMax(a.stamps + (size_t)cd_j.x * ncell + cell, ((unsigned long long)tag << 32) | (unsigned)m_j);      // the larger row of a cell wins
             *reinterpret_cast<int4 *>(meta + lane * 32) = make_int4(np_j, cd_j.y, cd_j.z, cd_j.w);
         }
-        const F32Chan fc = load_f32<ABS>(a, lane);
+        if (kLab && (a.debug & 256)) ts[1] = (long long)__builtin_amdgcn_s_memtime();
+        const F32Chan fc = finish_f32<ABS>(raw, a, lane);
+        if (kLab && (a.debug & 256)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts[2] = (long long)__builtin_amdgcn_s_memtime(); }
         const bool ch0 = col < a.C, ch1 = 32 + col < a.C;
         int buf = 0;
         for (int r0 = p0; r0 < p1; r0 += kRound, buf ^= 1) {
             const int nr = min(kRound, p1 - r0);
             __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): this round's points are in LDS
             coalign::wave_lds_sync();
+            if (kLab && (a.debug & 256)) ts[r0 == p0 ? 3 : 5] = (long long)__builtin_amdgcn_s_memtime();
             if (r0 + kRound < p1) issue_round(r0 + kRound, buf ^ 1);
             const char *pb = pbuf + buf * (kRound * 1024);
 #pragma unroll
@@ -238,6 +282,7 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
                     // half layout -> lane = channel: [A ch 0-31 | B ch 0-31], [A ch 32-63 | B ch 32-63] -> [A 0-63], [B 0-63]: 256-byte row stores
                     swap32(y[0], y[1]);
                     const bool liveA = 2 * pair < a.M;
+                    if (kLab && (a.debug & 8)) continue;
                     if (liveA && lane < a.C) *reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair) * (unsigned)a.C + (unsigned)lane) * 4u) = y[0];
                     if (hasB && lane < a.C) *reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair + 1) * (unsigned)a.C + (unsigned)lane) * 4u) = y[1];
                     (void)live; (void)ch0; (void)ch1;
@@ -246,14 +291,22 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
         }
     }
     // the last workgroup to arrive publishes the tag: every stamp of this frame has been entered by then
+    if (kLab && (a.debug & 256)) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        ts[6] = (long long)__builtin_amdgcn_s_memtime();
+        if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))
+            printf("block %d: tag %lld  prologue %lld  chan params %lld  round0 landed %lld  round1 start %lld  end %lld  (cycles from kernel entry)\n", (int)blockIdx.x,
+                   0LL, ts[1] - ts[0], ts[2] - ts[0], ts[3] - ts[0], ts[5] - ts[0], ts[6] - ts[0]);
+    }
+    // (No fence: nobody reads the tag inside this launch -- the consumers are later launches on the stream, and a launch boundary publishes every store.  The
+    //  counter only has to order "every workgroup has read state[0]" before "state[0] changes", which arrival itself does.  An agent-scope fence per workgroup
+    //  here wrote back the XCD's dirty L2 lines -- the feature rows just stored -- 500 times: 55 us instead of 12.)
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const int arrived = atomicAdd(a.state + 1, 1);
+    if (threadIdx.x == 0 && !(kLab && (a.debug & 4))) {
+        const int arrived = __hip_atomic_fetch_add(a.state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived == (int)gridDim.x - 1) {
-            a.state[1] = 0;
-            __threadfence();
-            atomicExch(a.state, (int)tag);
+            __hip_atomic_store(a.state + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.state, (int)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -290,8 +343,10 @@ extern "C" int coalign_pillar_encode_sparse(const float *voxel_features, const i
     a.zo = (float)(voxel_size[2] / 2 + range_min[2]);
     a.n_agents = n_agents; a.ny = ny; a.nx = nx; a.feats = pillar_features;
     a.stamps = static_cast<unsigned long long *>(stamps); a.state = state; a.M_dev = M_dev;
-    // two workgroups of four wavefronts per CU; a wavefront takes two rounds' pairs unless the capacity asks for more (up to kRunPairs each, then more workgroups)
-    const int pairs = (M_capacity + 1) / 2, resident = 512;
+    a.debug = coalign::lab_env("COALIGN_SPARSE_DEBUG", 0);
+    // five workgroups of four wavefronts per CU (8 KB of LDS per wavefront, 93 registers): four to five wavefronts per SIMD keep the fp32 matrix pipe fed.  A
+    // wavefront takes two rounds' pairs unless the capacity asks for more (up to kRunPairs each, then more workgroups)
+    const int pairs = (M_capacity + 1) / 2, resident = 1280;
     int blocks = (pairs + kWaves * 2 * kRound - 1) / (kWaves * 2 * kRound);
     if (blocks > resident) blocks = resident;
     const int need = (pairs + kWaves * kRunPairs - 1) / (kWaves * kRunPairs);

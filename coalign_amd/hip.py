@@ -91,11 +91,11 @@ def lib() -> ctypes.CDLL:
     if _LIB is not None:
         return _LIB
     import torch  # noqa: F401  -- load PyTorch-ROCm's HIP runtime first so both share one libamdhip64.so.7
-    lab = os.environ.get("COALIGN_LAB", "0") == "1"      # tools/ only: the laboratory build with its ablation switches (build.py)
-    path = _build.LAB_LIB_PATH if lab else _build.LIB_PATH
+    lab = os.environ.get("COALIGN_LAB", "0")             # tools/ only: "1" = the laboratory build with its ablation switches, "vec" = + packed fp32 allowed (build.py)
+    path = _build.LABVEC_LIB_PATH if lab == "vec" else _build.LAB_LIB_PATH if lab == "1" else _build.LIB_PATH
     if not os.path.exists(path):
         try:
-            _build.build(lab=lab)
+            _build.build(lab=lab == "1", vectorize=lab == "vec")
         except Exception as exc:  # noqa: BLE001
             raise CoalignHipError(
                 f"{path} is missing and could not be built ({exc}); the CoAlign hot path has no CPU fallback") from exc
