@@ -481,14 +481,7 @@ def main():
                     model._fuse_scales(list(feats_iso), [N], affine_iso)
                 torch.cuda.synchronize()
                 if world == 1:
-                    gs = torch.cuda.Stream(device=dev)
-                    gs.wait_stream(torch.cuda.current_stream(dev))
-                    fg = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(fg, stream=gs):
-                        model._fuse_scales(list(feats_iso), [N], affine_iso)
-                    torch.cuda.synchronize()
-                    iso["fuse_ms"] = hip_time(fg.replay)
-                    del fg
+                    iso["fuse_ms"] = graph_time(lambda: model._fuse_scales(list(feats_iso), [N], affine_iso), dev)      # (several calls per graph: no replay floor)
                 else:       # no stream capture next to a live RCCL communicator (its watchdog thread polls events): plain launches
                     iso["fuse_ms"] = hip_time(lambda: model._fuse_scales(list(feats_iso), [N], affine_iso))
                 del feats_iso, affine_iso

@@ -5,15 +5,15 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/round; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
 cd $ROOT
-timeout 300 python bench.py 2> $OUT/bench.err | tee $OUT/bench_n1.json | cut -c1-300
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py --no-cpu-baseline --no-side-modes > $OUT/stats.log 2>&1 )
+timeout 600 python bench.py 2> $OUT/bench.err | tee $OUT/bench_n1.json | cut -c1-300
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py --no-cpu-baseline --no-side-modes --no-size-sweep --no-from-points --no-latency > $OUT/stats.log 2>&1 )
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cp $(find $OUT/stats -name "*domain_stats.csv" | head -1) $OUT/domain_stats.csv
 grep -h '"metric"' $OUT/stats.log > $OUT/bench_n1_under_rocprof.json
 ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/iso -- python $ROOT/tools/kernels_only.py 20 > $OUT/iso.log 2>&1 )
 cp $(find $OUT/iso -name "*kernel_stats.csv" | head -1) $OUT/kernels_isolated_stats.csv
 grep -h '^{' $OUT/iso.log > $OUT/kernels_isolated_events.json
-for op in ${PMC_OPS:-pillar_nhwc_persistent fuse_nhwc_3scales conv_bf16x3_64ch pillar_nhwc}; do
+for op in ${PMC_OPS:-pillar_sparse pillar_nhwc_persistent fuse_nhwc_3scales conv_fp16x2_64ch conv_bf16x3_64ch conv_wino_bf16x3_256ch pillar_nhwc}; do
   i=0
   for ctrs in "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA"; do
     i=$((i+1))

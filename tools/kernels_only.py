@@ -77,6 +77,29 @@ def _nms_two_calls():
 
 
 _cache = {}
+# round 4: the fp16 2-way split (default arithmetic), the Winograd kernel (opt-in), the sparse canvas and its consumers, the merged 1x1 heads
+_w16 = ops.pack_conv3x3_emu_weight(wconv, 16, True)
+_w16_s2 = ops.pack_conv3x3_emu_weight(wconv, 16, False)
+_w128 = torch.randn(128, 128, 3, 3, generator=g).to(dev) / 34.0
+_w256 = torch.randn(256, 256, 3, 3, generator=g).to(dev) / 48.0
+_w16_128, _w16_256 = ops.pack_conv3x3_emu_weight(_w128, 16, True), ops.pack_conv3x3_emu_weight(_w256, 16, True)
+_b128, _b256 = torch.randn(128, generator=g).to(dev), torch.randn(256, generator=g).to(dev)
+_r128, _r256 = torch.randn(N, 128, 50, 176, generator=g).to(dev), torch.randn(N, 256, 25, 88, generator=g).to(dev)
+_wu64, _wu256 = ops.pack_conv3x3_wino_weight(wconv), ops.pack_conv3x3_wino_weight(_w256)
+_rcl64, _rcl256 = rconv.contiguous(memory_format=torch.channels_last), _r256.contiguous(memory_format=torch.channels_last)
+_x256 = torch.randn(1, 256, 100, 352, generator=g).to(dev)
+_whead = ops.pack_pointwise_emu_weight(ops.pack_pointwise_weight(torch.randn(20, 256, 1, 1, generator=g).to(dev) / 16.0, False))
+_bhead = torch.randn(20, generator=g).to(dev)
+_sc_cache = {}
+
+
+def _sc():
+    if "sc" not in _sc_cache:
+        _sc_cache["sc"] = ops.pillar_encode_sparse(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], pfn.linear.weight, None, bn, 1e-3, True,
+                                                   margs["voxel_size"], margs["lidar_range"][:3], N, 200, 704, canvas_cache={})
+    return _sc_cache["sc"]
+
+
 OPS = {
     "nms_gather_K600": _nms_fused,
     "nms_then_gather_K600": _nms_two_calls,
@@ -84,6 +107,16 @@ OPS = {
     "pillar_nhwc": pillar(True),
     "pillar_nhwc_persistent": lambda: ops.pillar_vfe_scatter(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], pfn.linear.weight, None, bn, 1e-3, True, False,
                                                              margs["voxel_size"], margs["lidar_range"][:3], N, 200, 704, channels_last=True, canvas_cache=_cache),
+    "pillar_sparse": lambda: ops.pillar_encode_sparse(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], pfn.linear.weight, None, bn, 1e-3, True,
+                                                      margs["voxel_size"], margs["lidar_range"][:3], N, 200, 704, canvas_cache=_cache),
+    "conv_fp16x2_64ch": lambda: ops.conv3x3_emu_bias_act(xs[0], _w16, bconv, 64, rconv, True, 16),
+    "conv_fp16x2_128ch": lambda: ops.conv3x3_emu_bias_act(xs[1], _w16_128, _b128, 128, _r128, True, 16),
+    "conv_fp16x2_256ch": lambda: ops.conv3x3_emu_bias_act(xs[2], _w16_256, _b256, 256, _r256, True, 16),
+    "conv_wino_bf16x3_64ch": lambda: ops.conv3x3_wino(xcl[0], _wu64, bconv, 64, _rcl64, True),
+    "conv_wino_bf16x3_256ch": lambda: ops.conv3x3_wino(xcl[2], _wu256, _b256, 256, _rcl256, True),
+    "conv_fp16x2_s2_sparse_canvas": lambda: ops.conv3x3_emu_sparse(_sc(), _w16_s2, bconv, 64, True, 16, out_channels_last=False),
+    "pointwise_skip1_sparse_canvas": lambda: ops.pointwise_conv_sparse(_sc(), _pw["skip1"][1], _pw["skip1"][2], 64, False, out_channels_last=False),
+    "heads_1x1_merged_bf16x3": lambda: ops.pointwise_conv(_x256, _whead, _bhead, 20, relu=False),
     "fuse_nchw_C64": lambda: ops.warp_fuse(xs[0], theta, [N], ops.FUSE_ATT),
     "fuse_nchw_C128": lambda: ops.warp_fuse(xs[1], theta, [N], ops.FUSE_ATT),
     "fuse_nchw_C256": lambda: ops.warp_fuse(xs[2], theta, [N], ops.FUSE_ATT),
