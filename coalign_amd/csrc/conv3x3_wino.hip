@@ -39,6 +39,7 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void *lptr_w_t;
 
 constexpr int kCoutUnit = 64;        // output channels per workgroup
 constexpr int kTiles = 64;           // Winograd tiles per workgroup
@@ -53,6 +54,7 @@ struct WinoArgs {
     int N, Cin, Cout, H, W, relu;
     int pitch;                            // rows per image in the stacked image (H + 1 for odd H, H + 2 for even H)
     int blocks_x, blocks, units, xcd;
+    const float *zero16;                  // 16 zero bytes in global memory (the tail of the weight image): the DMA source of padding
 };
 
 template <int TBW>
@@ -65,6 +67,7 @@ struct WGeo {
     static constexpr int RAWSZ = 4 * RAWQ;                          // uint4 per raw buffer
     static constexpr int NU = PR * PC * 4;                          // 16-byte units of one patch, pixel-major, chunk fastest
     static constexpr int NJ = (NU + 511) / 512;
+    static constexpr int ND = (RAWSZ + 511) / 512;                  // LDS-DMA instructions per wavefront and K step (64 slots each, 8 wavefronts)
     static constexpr int V_OFF = 0, R_OFF = 2 * kVBuf;
     static constexpr int ZSTRIDE = 68;                              // floats per (row, b, tile) in the epilogue exchange: 64 couts + 4 of bank shift
     static constexpr size_t LDS_MAIN = (size_t)(2 * kVBuf + 2 * RAWSZ) * 16, LDS_EPI = (size_t)4 * 2 * kTiles * ZSTRIDE * 4;
@@ -95,9 +98,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[3]) {
     for (int t = 0; t < 3; ++t) out[t] = uint4{o[t][0], o[t][1], o[t][2], o[t][3]};
 }
 
-// workgroup barrier that waits for this wavefront's LDS traffic only (the register prefetches of the next half stage stay in flight)
+// workgroup barrier of a half stage: this wavefront's LDS writes AND its LDS-DMA transfers (vmcnt) are complete.  (The operand prefetch issued in the same half
+// stage is needed right behind the barrier anyway.)
 __device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // ABL (lab builds only, -DCOALIGN_LAB): bit 0 = no matrix steps, bit 1 = no transform / split, bit 2 = operands of half stage 0 only (wrong results; what each part costs)
@@ -131,35 +135,28 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoArgs a) {
         const int cg = unit % groups, blk = unit / groups;
         const int by = blk / a.blocks_x, bx = blk - by * a.blocks_x;
         const int ty0 = by * G::TBH, tx0 = bx * TBW;      // first tile of the block (stacked tile rows)
-        // ---- raw patch plan: 16-byte unit e = tid + 512 j: pixel e >> 2 of the patch, chunk e & 3
-        int goff[G::NJ];
+        // ---- raw patch by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land at 64 consecutive LDS slots, no registers, no ds_write, no bank conflicts).
+        // Slot s of a raw buffer = [q][parity][row][column pair] in LDS order; DMA instruction d of this wavefront covers slots 64 (wave + 8 d) ...; every lane
+        // computes the global address of ITS slot's pixel chunk once per unit (padding slots and pixels outside the image read a zero word).
+        int goff[G::ND];
 #pragma unroll
-        for (int j = 0; j < G::NJ; ++j) {
-            const int e = tid + 512 * j, pi = e >> 2, q = e & 3;
-            const int pr = pi / G::PC, pc = pi - pr * G::PC;
-            const int s = 2 * ty0 - 1 + pr, xg = 2 * tx0 - 1 + pc;
-            const int n = s >= 0 ? s / a.pitch : 0, r = s - n * a.pitch;
-            const bool ok = e < G::NU && s >= 0 && n < a.N && r < a.H && xg >= 0 && xg < a.W;
-            goff[j] = ok ? ((n * a.H + r) * a.W + xg) * a.Cin + 4 * q : -1;
+        for (int d = 0; d < G::ND; ++d) {
+            const int sl = 64 * (wave + 8 * d) + lane;
+            const int ch = sl % G::PCH, t1 = sl / G::PCH, pr = t1 % G::PR, t2 = t1 / G::PR, par = t2 & 1, q = t2 >> 1;
+            const int pc = 2 * ch + par;
+            const int st = 2 * ty0 - 1 + pr, xg = 2 * tx0 - 1 + pc;
+            const int n = st >= 0 ? st / a.pitch : 0, r = st - n * a.pitch;
+            const bool ok = sl < G::RAWSZ && pc < G::PC && st >= 0 && n < a.N && r < a.H && xg >= 0 && xg < a.W;
+            goff[d] = ok ? ((n * a.H + r) * a.W + xg) * a.Cin + 4 * q : -1;
         }
-        auto load_raw = [&](int k, uint4 (&rv)[G::NJ]) {
+        auto dma_raw = [&](int k, int buf) {
 #pragma unroll
-            for (int j = 0; j < G::NJ; ++j) {
-                const uint4 t = *reinterpret_cast<const uint4 *>(a.x + (goff[j] < 0 ? 0 : goff[j]) + 16 * k);
-                rv[j] = goff[j] < 0 ? uint4{0, 0, 0, 0} : t;
-            }
-        };
-        auto write_raw = [&](int buf, const uint4 (&rv)[G::NJ]) {
-            uint4 *rbuf = lds + G::R_OFF + buf * G::RAWSZ;
-            unsigned ones = ~0u;
-            asm volatile("" : "+s"(ones));                 // (opaque: keeps the three lines below inside the K loop)
-            const int t = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));      // = tid, from the scalar wave index and the lane count                    // recomputed here on purpose: hoisted out of the K loop the three slot indices are spilled and
-                                                           // every reload costs an s_waitcnt vmcnt(0), i.e. waits for the operand prefetch
-#pragma unroll
-            for (int j = 0; j < G::NJ; ++j) {
-                const int e = t + 512 * j, pi = e >> 2, q = e & 3;
-                const int pr = pi / G::PC, pc = pi - pr * G::PC;
-                if (e < G::NU) rbuf[((q * 2 + (pc & 1)) * G::PR + pr) * G::PCH + (pc >> 1)] = rv[j];
+            for (int d = 0; d < G::ND; ++d) {
+                if (64 * (wave + 8 * d) < G::RAWSZ) {      // (wave-uniform)
+                    const float *src = goff[d] < 0 ? a.zero16 : a.x + goff[d] + 16 * k;
+                    const unsigned dst = (unsigned)(size_t)(lptr_w_t)(lds + G::R_OFF + buf * G::RAWSZ + 64 * (wave + 8 * d));
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(dst)), "v"(src) : "memory", "m0");
+                }
             }
         };
         const uint4 *ubase = a.u + ((size_t)cg * K * 2 * 8 + wave) * (2 * 3 * 64) + lane;        // + (k * 2 + h) * 8 * 384 + (jj * 3 + term) * 64
@@ -255,23 +252,29 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoArgs a) {
         constexpr std::integral_constant<int, 0> H0{};
         constexpr std::integral_constant<int, 1> H1{};
         // ---- prologue
-        uint4 rawv[G::NJ], a0[2][3], a1[2][3];
-        load_raw(0, rawv);
+        uint4 a0[2][3], a1[2][3];
+        dma_raw(0, 0);
         load_a(0, 0, a0);
-        write_raw(0, rawv);
-        if (K > 1) load_raw(1, rawv);
-        lds_barrier();
+        lds_barrier();                                     // (waits for the DMA: vmcnt(0))
         produce(H0, 0, 0);
         // ---- K loop: two half stages per 16 channels; everything one half stage ahead, one barrier per half stage
         for (int k = 0; k < K; ++k) {
             lds_barrier();                                 // V(k, 0) complete; V buffer 1 and raw buffer (k + 1) & 1 free
+            long long tq[4] = {0, 0, 0, 0};
+            if constexpr ((ABL & 8) != 0) tq[0] = (long long)__builtin_amdgcn_s_memtime();
+            if (k + 1 < K) dma_raw(k + 1, (k + 1) & 1);      // raw(k + 1): needed by the transform of half stage (k, 1), i.e. behind the next barrier; its buffer was last read in (k - 1, 0)
             load_a(k, 1, a1);
-            if (k + 1 < K) write_raw((k + 1) & 1, rawv);
             if constexpr (MODE == 0) {
 #pragma nounroll
                 for (int sub = 0; sub < 2; ++sub) {        // the two wavefronts of a SIMD: one transforms while the other runs its matrix steps
                     if (sub == first) consume(H0, 0, a0);
                     else produce(H1, k & 1, 1);
+                    if constexpr ((ABL & 8) != 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq[1 + sub] = (long long)__builtin_amdgcn_s_memtime(); }
+                }
+                if constexpr ((ABL & 8) != 0) {
+                    if (k == 3 && unit == g && (blockIdx.x == 0 || blockIdx.x == 77) && lane == 0)
+                        printf("wg %d wave %d simd %d first %d: barrier exit %lld, role 1 done +%lld, role 2 done +%lld (role 1 = %s)\n", (int)blockIdx.x, wave,
+                               (int)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3), first, tq[0] % 1000000, tq[1] - tq[0], tq[2] - tq[0], first == 0 ? "matrix steps" : "transform");
                 }
             } else {                                       // one basic block: the matrix steps and the transform interleaved inside every wavefront
                 consume(H0, 0, a0);
@@ -280,7 +283,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const WinoArgs a) {
             }
             lds_barrier();                                 // V(k, 1) and raw(k + 1) complete; V buffer 0 free
             if (k + 1 < K) load_a(k + 1, 0, a0);
-            if (k + 2 < K) load_raw(k + 2, rawv);
             if constexpr (MODE == 0) {
 #pragma nounroll
                 for (int sub = 0; sub < 2; ++sub) {
@@ -382,7 +384,7 @@ int launch_wino(const WinoArgs &a0, hipStream_t s) {
 
 extern "C" size_t coalign_conv3x3_wino_weight_bytes(int Cin, int Cout) {
     if (Cin < 16 || Cout < 64 || Cin % 16 || Cout % kCoutUnit) return 0;
-    return (size_t)(Cout / kCoutUnit) * (Cin / 16) * 2 * 8 * 2 * 3 * 64 * 16;
+    return (size_t)(Cout / kCoutUnit) * (Cin / 16) * 2 * 8 * 2 * 3 * 64 * 16 + 16;       // + 16 zero bytes: the LDS-DMA source of the zero padding
 }
 
 extern "C" int coalign_conv3x3_wino(const float *x, const void *u_split, const float *bias, const float *residual, float *y, int N, int Cin, int Cout,
@@ -396,7 +398,8 @@ extern "C" int coalign_conv3x3_wino(const float *x, const void *u_split, const f
          reinterpret_cast<uintptr_t>(residual)) & 15)
         return COALIGN_ERR_UNSUPPORTED;
     if (N == 0) return COALIGN_OK;
-    WinoArgs a{x, static_cast<const uint4 *>(u_split), bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, 0, 1};
+    WinoArgs a{x, static_cast<const uint4 *>(u_split), bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, 0, 1,
+               reinterpret_cast<const float *>(static_cast<const char *>(u_split) + coalign_conv3x3_wino_weight_bytes(Cin, Cout) - 16)};
     hipStream_t s = static_cast<hipStream_t>(stream);
     // block shape: 4 x 16 tiles (8 x 32 pixels) unless the map is narrow or 8 x 8 tiles waste fewer columns
     int tbw = tile_block_w;
@@ -418,6 +421,7 @@ extern "C" int coalign_conv3x3_wino(const float *x, const void *u_split, const f
             case 316: rc = launch_wino<16, 3>(a, s); break;
             case 416: rc = launch_wino<16, 4>(a, s); break;
             case 716: rc = launch_wino<16, 7>(a, s); break;
+            case 816: rc = launch_wino<16, 8>(a, s); break;
             default: return COALIGN_ERR_UNSUPPORTED;
         }
         return rc != COALIGN_OK ? rc : check_launch();

@@ -732,7 +732,7 @@ def pack_conv3x3_wino_weight(weight: torch.Tensor) -> torch.Tensor:
     T = torch.stack(parts, 0)                                                              # [term, i, j, Cout, Cin] bf16
     T = T.view(3, 4, 2, 2, co // 64, 2, 32, ci // 16, 2, 8)                                # [term, i, h, jj, g, c, m, k, half, e]
     img = T.permute(4, 7, 2, 5, 1, 3, 0, 8, 6, 9).contiguous()                             # [g, k, h, c, i, jj, term, half, m, e]
-    out = img.view(torch.uint8).reshape(-1)
+    out = torch.cat([img.view(torch.uint8).reshape(-1), torch.zeros(16, dtype=torch.uint8, device=img.device)])      # + 16 zero bytes (zero padding source)
     assert out.numel() == hip.lib().coalign_conv3x3_wino_weight_bytes(ci, co)
     return out
 

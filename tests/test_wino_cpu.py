@@ -30,7 +30,7 @@ def test_winograd_data_flow_on_the_host(case):
 
 def test_winograd_weight_image_size_and_argument_checks():
     L = hip.lib()
-    assert L.coalign_conv3x3_wino_weight_bytes(64, 64) == 16 * 64 * 64 * 6
+    assert L.coalign_conv3x3_wino_weight_bytes(64, 64) == 16 * 64 * 64 * 6 + 16
     assert L.coalign_conv3x3_wino_weight_bytes(24, 64) == 0 and L.coalign_conv3x3_wino_weight_bytes(64, 96) == 0
     with pytest.raises(ValueError):
         ops.pack_conv3x3_wino_weight(torch.zeros(64, 8, 3, 3))

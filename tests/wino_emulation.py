@@ -10,7 +10,7 @@ import torch
 
 def _bf16_terms_to_f64(img_u8: torch.Tensor) -> np.ndarray:
     """uint8 image -> float64 values of the bf16 entries, flat."""
-    return img_u8.view(torch.bfloat16).double().numpy()
+    return img_u8[:-16].view(torch.bfloat16).double().numpy()      # (the image ends in 16 zero bytes: the kernel's zero-padding source)
 
 
 def emulate(x_nhwc: np.ndarray, u_img: torch.Tensor, bias: np.ndarray, residual, relu: bool, tbw: int) -> np.ndarray:
