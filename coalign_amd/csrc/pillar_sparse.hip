@@ -37,6 +37,10 @@ constexpr bool kLab = true;
 constexpr bool kLab = false;
 #endif
 
+#ifdef COALIGN_LAB
+__device__ long long g_sparse_trace[2048 * 4];      // laboratory build (COALIGN_SPARSE_DEBUG bit 9): per workgroup start / end wall clock, hardware id, round-0 cycles
+#endif
+
 struct SparseArgs {
     const float4 *pts;
     const int *npts;
@@ -51,6 +55,7 @@ struct SparseArgs {
     unsigned long long *stamps;
     int *state;
     const int *M_dev;
+    const float4 *folded;  // the folded channel parameters written by coalign_pillar_fold_params ([6][64] float4)
     int debug;            // laboratory build only (COALIGN_SPARSE_DEBUG): 1 no stamp atomics, 2 no matrix steps, 4 no arrival counter, 8 no feature stores
 };
 
@@ -148,25 +153,13 @@ __device__ __forceinline__ F32Chan finish_f32(const F32Raw<ABS> &r, const Sparse
 }
 
 // One pillar pair (lanes 0-31: pillar A's points, lanes 32-63: pillar B's) -> y[g]: relu(BN(max over the rows)) of channel 32 g + (lane & 31) in the
-// half layout (lanes 0-31 pillar A, lanes 32-63 pillar B).
+// half layout (lanes 0-31 pillar A, lanes 32-63 pillar B).  q: this lane's point as stored (the mean runs over ALL P slots, pillar_vfe.py:118-120);
+// qs: the same with the rows at / past the point count replaced by row 0 of their pillar (they cannot change the max; their own value,
+// relu(BN(0)), is added below) -- the substitution is the address of the LDS read.  rec0 = (num_points, 1 / num_points, -, -), ctr = the cell centre.
 template <bool ABS>
-__device__ __forceinline__ void f32_pair_half(const SparseArgs &a, const F32Chan &fc, int lane, float4 q, int np, int4 cd, bool hasB, float (&y)[2]) {
-    const int np_eff = min(max(np, 0), a.P);
-    // mean over ALL P slots divided by num_points (pillar_vfe.py:118-120)
-    const float rn = __builtin_amdgcn_rcpf((float)np);
-    const float ctr_x = (float)cd.w * a.vx + a.xo, ctr_y = (float)cd.z * a.vy + a.yo, ctr_z = (float)cd.y * a.vz + a.zo;
+__device__ __forceinline__ void f32_pair_half(const SparseArgs &a, const F32Chan &fc, float4 q, float4 qs, int np_eff, float rn, float ctr_x, float ctr_y, float ctr_z, float (&y)[2]) {
     const float ex = half_sum_dpp(q.x) * rn - ctr_x, ey = half_sum_dpp(q.y) * rn - ctr_y, ez = half_sum_dpp(q.z) * rn - ctr_z;
-    float d0 = q.x - ctr_x, d1 = q.y - ctr_y, d2 = q.z - ctr_z, d3 = q.w;
-    // rows at / past the point count repeat row 0 of their pillar: they cannot change the max (their own value, relu(BN(0)), is added below)
-    const int row = lane & 31;
-    const bool pad = row >= np_eff;
-    {
-        auto rl = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
-        const float a0 = rl(d0, 0), a1 = rl(d1, 0), a2 = rl(d2, 0), a3 = rl(d3, 0);
-        const float b0 = rl(d0, 32), b1 = rl(d1, 32), b2 = rl(d2, 32), b3 = rl(d3, 32);
-        const bool hb = lane >= 32;
-        d0 = pad ? (hb ? b0 : a0) : d0; d1 = pad ? (hb ? b1 : a1) : d1; d2 = pad ? (hb ? b2 : a2) : d2; d3 = pad ? (hb ? b3 : a3) : d3;
-    }
+    float d0 = qs.x - ctr_x, d1 = qs.y - ctr_y, d2 = qs.z - ctr_z, d3 = qs.w;
     // A operands: lane l holds A[i = l & 31][k = l >> 5].  One swap turns [A.d0 | B.d0], [A.d1 | B.d1] into [A.d0 | A.d1] (pillar A, step 0) and
     // [B.d0 | B.d1] (pillar B, step 0); likewise d2 / d3 for step 1.
     swap32(d0, d1);
@@ -188,6 +181,7 @@ __device__ __forceinline__ void f32_pair_half(const SparseArgs &a, const F32Chan
         accB[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(d3, fc.wb[g][1], accB[g], 0, 0, 0);
     }
     }
+    const bool padded = np_eff < a.P, empty = np_eff == 0;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         // lane holds 16 of the 32 rows of channel 32 g + (lane & 31): rows 8 (r >> 2) + 4 (lane >> 5) + (r & 3); the two halves complete each other
@@ -197,12 +191,43 @@ __device__ __forceinline__ void f32_pair_half(const SparseArgs &a, const F32Chan
         float b = fc.wen[g][0] * ex;
         b = fmaf(fc.wen[g][1], ey, b); b = fmaf(fc.wen[g][2], ez, b);
         if constexpr (ABS) { b = fmaf(fc.wc[g][0], ctr_x, b); b = fmaf(fc.wc[g][1], ctr_y, b); b = fmaf(fc.wc[g][2], ctr_z, b); }
-        float v = fmaf(fc.sgn[g] * r + b, fc.alpha[g], fc.shift[g]);
-        if (np_eff < a.P) v = fmaxf(v, fc.shift[g]);        // padded rows: Linear(0) = 0 -> BN -> shift
-        if (np_eff == 0) v = fc.shift[g];                   // (documented deviation: the reference divides by zero here)
+        float v = fmaf(fmaf(fc.sgn[g], r, b), fc.alpha[g], fc.shift[g]);      // (sgn = +-1: sgn * r is exact, the fused form rounds once as the separate one did)
+        // padded rows: Linear(0) = 0 -> BN -> shift; no points at all: shift alone (documented deviation: the reference divides by zero there)
+        v = fmaxf(empty ? fc.shift[g] : v, padded ? fc.shift[g] : v);
         y[g] = fmaxf(v, 0.f);
     }
-    (void)hasB;
+}
+
+// the folded parameters of one lane as six float4 (coalign_pillar_fold_params writes them, the kernel reads them back in the same order)
+__device__ __forceinline__ void chan_to_vec(const F32Chan &fc, float4 (&t)[6]) {
+    t[0] = make_float4(fc.wb[0][0], fc.wb[0][1], fc.wb[1][0], fc.wb[1][1]);
+    t[1] = make_float4(fc.wc[0][0], fc.wc[0][1], fc.wc[0][2], fc.wc[1][0]);
+    t[2] = make_float4(fc.wc[1][1], fc.wc[1][2], fc.wen[0][0], fc.wen[0][1]);
+    t[3] = make_float4(fc.wen[0][2], fc.wen[1][0], fc.wen[1][1], fc.wen[1][2]);
+    t[4] = make_float4(fc.alpha[0], fc.alpha[1], fc.shift[0], fc.shift[1]);
+    t[5] = make_float4(fc.sgn[0], fc.sgn[1], 0.f, 0.f);
+}
+__device__ __forceinline__ F32Chan vec_to_chan(const float4 (&t)[6]) {
+    F32Chan fc;
+    fc.wb[0][0] = t[0].x; fc.wb[0][1] = t[0].y; fc.wb[1][0] = t[0].z; fc.wb[1][1] = t[0].w;
+    fc.wc[0][0] = t[1].x; fc.wc[0][1] = t[1].y; fc.wc[0][2] = t[1].z; fc.wc[1][0] = t[1].w;
+    fc.wc[1][1] = t[2].x; fc.wc[1][2] = t[2].y; fc.wen[0][0] = t[2].z; fc.wen[0][1] = t[2].w;
+    fc.wen[0][2] = t[3].x; fc.wen[1][0] = t[3].y; fc.wen[1][1] = t[3].z; fc.wen[1][2] = t[3].w;
+    fc.alpha[0] = t[4].x; fc.alpha[1] = t[4].y; fc.shift[0] = t[4].z; fc.shift[1] = t[4].w;
+    fc.sgn[0] = t[5].x; fc.sgn[1] = t[5].y;
+    return fc;
+}
+
+// the fold as its own one-wavefront launch (once per weight set, like the convolutions' split weight images): the same device code, so the table holds
+// exactly what a wavefront would have computed for itself
+template <bool ABS>
+__global__ __launch_bounds__(64) void pillar_fold_kernel(SparseArgs a, float4 *out) {
+    const int lane = threadIdx.x & 63;
+    const F32Chan fc = finish_f32<ABS>(load_f32_raw<ABS>(a, lane), a, lane);
+    float4 t[6];
+    chan_to_vec(fc, t);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) out[i * 64 + lane] = t[i];
 }
 
 template <bool ABS>
@@ -216,7 +241,7 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
     if (kLab && (a.debug & 128)) return;
     if (a.M_dev) a.M = min(max(*a.M_dev, 0), a.M);
     long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (kLab && (a.debug & 256)) ts[0] = (long long)__builtin_amdgcn_s_memtime();
+    if (kLab && (a.debug & 512)) { ts[0] = (long long)__builtin_amdgcn_s_memtime(); ts[7] = (long long)wall_clock64(); }
     const unsigned tag = (unsigned)a.state[0] + 1u;                  // this frame's tag (state[0] is written only when the last workgroup has finished)
     const int npairs = (a.M + 1) / 2;
     const int per_wave = (npairs + nwave - 1) / nwave;
@@ -249,55 +274,63 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
             np_j = *reinterpret_cast<const int *>(np_b + (unsigned)mj * 4u);
             cd_j = *reinterpret_cast<const int4 *>(cd_b + (unsigned)mj * 16u);
         }
-        const F32Raw<ABS> raw = load_f32_raw<ABS>(a, lane);
+        float4 ft[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ft[i] = a.folded[i * 64 + lane];
         if (pro) {
             const int cell = cd_j.y + cd_j.z * a.nx + cd_j.w;       // z + y * nx + x (point_pillar_scatter.py:54)
             const bool ok = m_j < a.M && cd_j.x >= 0 && cd_j.x < a.n_agents && cell >= 0 && cell < ncell;
             if (ok && !(kLab && (a.debug & 1))) atomicMax(a.stamps + (size_t)cd_j.x * ncell + cell, ((unsigned long long)tag << 32) | (unsigned)m_j);      // the larger row of a cell wins
-            *reinterpret_cast<int4 *>(meta + lane * 32) = make_int4(np_j, cd_j.y, cd_j.z, cd_j.w);
+            // the pillar's record: point count (clamped), 1 / num_points (pillar_vfe.py:118-120 divides by the count as given), cell centre
+            const float rn = __builtin_amdgcn_rcpf((float)np_j);
+            const float ctr_x = (float)cd_j.w * a.vx + a.xo, ctr_y = (float)cd_j.z * a.vy + a.yo, ctr_z = (float)cd_j.y * a.vz + a.zo;
+            float4 *rec = reinterpret_cast<float4 *>(meta + lane * 32);
+            rec[0] = make_float4(__builtin_bit_cast(float, min(max(np_j, 0), a.P)), rn, ctr_x, ctr_y);
+            rec[1] = make_float4(ctr_z, 0.f, 0.f, 0.f);
         }
-        if (kLab && (a.debug & 256)) ts[1] = (long long)__builtin_amdgcn_s_memtime();
-        const F32Chan fc = finish_f32<ABS>(raw, a, lane);
-        if (kLab && (a.debug & 256)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts[2] = (long long)__builtin_amdgcn_s_memtime(); }
-        const bool ch0 = col < a.C, ch1 = 32 + col < a.C;
+        const F32Chan fc = vec_to_chan(ft);
         int buf = 0;
         for (int r0 = p0; r0 < p1; r0 += kRound, buf ^= 1) {
             const int nr = min(kRound, p1 - r0);
             __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): this round's points are in LDS
             coalign::wave_lds_sync();
-            if (kLab && (a.debug & 256)) ts[r0 == p0 ? 3 : 5] = (long long)__builtin_amdgcn_s_memtime();
+            if (kLab && (a.debug & 512)) ts[r0 == p0 ? 3 : 5] = (long long)__builtin_amdgcn_s_memtime();
             if (r0 + kRound < p1) issue_round(r0 + kRound, buf ^ 1);
             const char *pb = pbuf + buf * (kRound * 1024);
 #pragma unroll
             for (int k = 0; k < kRound; ++k) {
                 if (k < nr) {
                     const int pair = r0 + k;
-                    const int m = 2 * pair + half;
-                    const bool live = m < a.M, hasB = 2 * pair + 1 < a.M;
+                    const bool hasB = 2 * pair + 1 < a.M;
+                    const float4 *rec = reinterpret_cast<const float4 *>(meta + (2 * (pair - p0) + half) * 32);
+                    const float4 rec0 = rec[0];
+                    const float ctr_z = rec[1].x;
+                    const int np_eff = __builtin_bit_cast(int, rec0.x);
                     float4 q = *reinterpret_cast<const float4 *>(pb + k * 1024 + lane * 16);
+                    // rows at / past the point count read row 0 of their pillar
+                    float4 qs = *reinterpret_cast<const float4 *>(pb + k * 1024 + (col >= np_eff ? half * 512 : lane * 16));
                     if (a.P < 32 && col >= a.P) q = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const int4 rec = *reinterpret_cast<const int4 *>(meta + (2 * (pair - p0) + half) * 32);
                     float y[2];
-                    f32_pair_half<ABS>(a, fc, lane, q, rec.x, make_int4(0, rec.y, rec.z, rec.w), hasB, y);
+                    f32_pair_half<ABS>(a, fc, q, qs, np_eff, rec0.y, rec0.z, rec0.w, ctr_z, y);
                     // half layout -> lane = channel: [A ch 0-31 | B ch 0-31], [A ch 32-63 | B ch 32-63] -> [A 0-63], [B 0-63]: 256-byte row stores
                     swap32(y[0], y[1]);
-                    const bool liveA = 2 * pair < a.M;
                     if (kLab && (a.debug & 8)) continue;
-                    if (liveA && lane < a.C) *reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair) * (unsigned)a.C + (unsigned)lane) * 4u) = y[0];
+                    if (lane < a.C) *reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair) * (unsigned)a.C + (unsigned)lane) * 4u) = y[0];      // (2 pair < M: p1 ends at the last pair)
                     if (hasB && lane < a.C) *reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair + 1) * (unsigned)a.C + (unsigned)lane) * 4u) = y[1];
-                    (void)live; (void)ch0; (void)ch1;
                 }
             }
         }
     }
     // the last workgroup to arrive publishes the tag: every stamp of this frame has been entered by then
-    if (kLab && (a.debug & 256)) {
+#ifdef COALIGN_LAB
+    if ((a.debug & 512) && threadIdx.x == 0 && blockIdx.x < 2048) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        ts[6] = (long long)__builtin_amdgcn_s_memtime();
-        if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))
-            printf("block %d: tag %lld  prologue %lld  chan params %lld  round0 landed %lld  round1 start %lld  end %lld  (cycles from kernel entry)\n", (int)blockIdx.x,
-                   0LL, ts[1] - ts[0], ts[2] - ts[0], ts[3] - ts[0], ts[5] - ts[0], ts[6] - ts[0]);
+        g_sparse_trace[blockIdx.x * 4 + 0] = ts[7];
+        g_sparse_trace[blockIdx.x * 4 + 1] = (long long)wall_clock64();
+        g_sparse_trace[blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID
+        g_sparse_trace[blockIdx.x * 4 + 3] = ts[5] - ts[3];
     }
+#endif
     // (No fence: nobody reads the tag inside this launch -- the consumers are later launches on the stream, and a launch boundary publishes every store.  The
     //  counter only has to order "every workgroup has read state[0]" before "state[0] changes", which arrival itself does.  An agent-scope fence per workgroup
     //  here wrote back the XCD's dirty L2 lines -- the feature rows just stored -- 500 times: 55 us instead of 12.)
@@ -318,25 +351,50 @@ extern "C" size_t coalign_sparse_canvas_stamp_bytes(int n_agents, int ny, int nx
     return (size_t)n_agents * ny * nx * 8;
 }
 
-extern "C" int coalign_pillar_encode_sparse(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M_capacity,
-                                            const int32_t *M_dev, int P, const float *pfn_weight, const float *pfn_bias, const float *bn_weight,
-                                            const float *bn_bias, const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz,
-                                            const double *voxel_size, const double *range_min, int n_agents, int ny, int nx, float *pillar_features,
-                                            void *stamps, int32_t *state, void *stream_) {
-    using namespace coalign;
-    hipStream_t stream = (hipStream_t)stream_;
-    if (M_capacity < 0 || P <= 0 || P > 32 || C < 1 || C > 64 || n_agents <= 0 || ny <= 0 || nx <= 0) return COALIGN_ERR_BAD_SHAPE;
-    if (!pfn_weight || !voxel_size || !range_min || !stamps || !state) return COALIGN_ERR_NULL_POINTER;
-    if (M_capacity > 0 && (!voxel_features || !voxel_num_points || !voxel_coords || !pillar_features)) return COALIGN_ERR_NULL_POINTER;
+static int fill_sparse_params(SparseArgs &a, int P, const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias, const float *bn_mean,
+                              const float *bn_var, float bn_eps, int C, int use_absolute_xyz) {
+    if (P <= 0 || P > 32 || C < 1 || C > 64) return COALIGN_ERR_BAD_SHAPE;
+    if (!pfn_weight) return COALIGN_ERR_NULL_POINTER;
     const bool has_bn = bn_weight || bn_bias || bn_mean || bn_var;
     if (has_bn && !(bn_weight && bn_bias && bn_mean && bn_var)) return COALIGN_ERR_NULL_POINTER;
-    if ((size_t)n_agents * ny * nx > (size_t)INT32_MAX || (reinterpret_cast<uintptr_t>(stamps) & 7)) return COALIGN_ERR_BAD_SHAPE;
+    a.P = P;
+    a.weight = pfn_weight; a.bias = pfn_bias; a.bn_w = bn_weight; a.bn_b = bn_bias; a.bn_m = bn_mean; a.bn_v = bn_var;
+    a.eps = bn_eps; a.C = C; a.Cin = (use_absolute_xyz ? 4 : 1) + 6; a.use_abs = use_absolute_xyz;
+    return COALIGN_OK;
+}
+
+extern "C" size_t coalign_pillar_folded_param_bytes(void) { return 6 * 64 * sizeof(float4); }
+
+// Once per weight set: the encoder's channel parameters in the form the pair loop uses (BatchNorm folded, the three weight groups summed, signs folded), one
+// record per lane of a wavefront.  coalign_pillar_encode_sparse then reads 96 bytes per lane instead of 30 scalars + a square root and a division per channel.
+extern "C" int coalign_pillar_fold_params(const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias, const float *bn_mean,
+                                          const float *bn_var, float bn_eps, int C, int use_absolute_xyz, float *folded, void *stream_) {
+    using namespace coalign;
+    if (!folded || (reinterpret_cast<uintptr_t>(folded) & 15)) return folded ? COALIGN_ERR_UNSUPPORTED : COALIGN_ERR_NULL_POINTER;
+    SparseArgs a{};
+    const int rc = fill_sparse_params(a, 32, pfn_weight, pfn_bias, bn_weight, bn_bias, bn_mean, bn_var, bn_eps, C, use_absolute_xyz);
+    if (rc != COALIGN_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (use_absolute_xyz) hipLaunchKernelGGL(pillar_fold_kernel<true>, dim3(1), dim3(64), 0, stream, a, reinterpret_cast<float4 *>(folded));
+    else hipLaunchKernelGGL(pillar_fold_kernel<false>, dim3(1), dim3(64), 0, stream, a, reinterpret_cast<float4 *>(folded));
+    return check_launch();
+}
+
+extern "C" int coalign_pillar_encode_sparse(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M_capacity,
+                                            const int32_t *M_dev, int P, const float *folded, int C, int use_absolute_xyz, const double *voxel_size,
+                                            const double *range_min, int n_agents, int ny, int nx, float *pillar_features, void *stamps, int32_t *state,
+                                            void *stream_) {
+    using namespace coalign;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M_capacity < 0 || n_agents <= 0 || ny <= 0 || nx <= 0 || P <= 0 || P > 32 || C < 1 || C > 64) return COALIGN_ERR_BAD_SHAPE;
+    if (!folded || !voxel_size || !range_min || !stamps || !state) return COALIGN_ERR_NULL_POINTER;
+    if (M_capacity > 0 && (!voxel_features || !voxel_num_points || !voxel_coords || !pillar_features)) return COALIGN_ERR_NULL_POINTER;
+    if ((size_t)n_agents * ny * nx > (size_t)INT32_MAX || (reinterpret_cast<uintptr_t>(stamps) & 7) || (reinterpret_cast<uintptr_t>(folded) & 15)) return COALIGN_ERR_BAD_SHAPE;
     if ((size_t)M_capacity * P * 16 >= ((size_t)1 << 32) || (size_t)M_capacity * C * 4 >= ((size_t)1 << 32)) return COALIGN_ERR_UNSUPPORTED;      // 32-bit byte offsets
     SparseArgs a{};
     a.pts = (const float4 *)voxel_features; a.npts = voxel_num_points; a.coords = (const int4 *)voxel_coords;
-    a.M = M_capacity; a.P = P;
-    a.weight = pfn_weight; a.bias = pfn_bias; a.bn_w = bn_weight; a.bn_b = bn_bias; a.bn_m = bn_mean; a.bn_v = bn_var;
-    a.eps = bn_eps; a.C = C; a.Cin = (use_absolute_xyz ? 4 : 1) + 6; a.use_abs = use_absolute_xyz;
+    a.M = M_capacity; a.P = P; a.C = C; a.use_abs = use_absolute_xyz;
+    a.folded = reinterpret_cast<const float4 *>(folded);
     a.vx = (float)voxel_size[0]; a.vy = (float)voxel_size[1]; a.vz = (float)voxel_size[2];
     a.xo = (float)(voxel_size[0] / 2 + range_min[0]);
     a.yo = (float)(voxel_size[1] / 2 + range_min[1]);
@@ -344,10 +402,11 @@ extern "C" int coalign_pillar_encode_sparse(const float *voxel_features, const i
     a.n_agents = n_agents; a.ny = ny; a.nx = nx; a.feats = pillar_features;
     a.stamps = static_cast<unsigned long long *>(stamps); a.state = state; a.M_dev = M_dev;
     a.debug = coalign::lab_env("COALIGN_SPARSE_DEBUG", 0);
-    // five workgroups of four wavefronts per CU (8 KB of LDS per wavefront, 93 registers): four to five wavefronts per SIMD keep the fp32 matrix pipe fed.  A
+    // five workgroups of four wavefronts per CU (8 KB of LDS per wavefront): four to five wavefronts per SIMD keep the fp32 matrix pipe fed.  A
     // wavefront takes two rounds' pairs unless the capacity asks for more (up to kRunPairs each, then more workgroups)
     const int pairs = (M_capacity + 1) / 2, resident = 1280;
-    int blocks = (pairs + kWaves * 2 * kRound - 1) / (kWaves * 2 * kRound);
+    const int per_wave_target = coalign::lab_env("COALIGN_SPARSE_PAIRS", 2 * kRound);      // laboratory build: pairs per wavefront the grid is sized for
+    int blocks = (pairs + kWaves * per_wave_target - 1) / (kWaves * per_wave_target);
     if (blocks > resident) blocks = resident;
     const int need = (pairs + kWaves * kRunPairs - 1) / (kWaves * kRunPairs);
     if (blocks < need) blocks = need;
@@ -356,3 +415,9 @@ extern "C" int coalign_pillar_encode_sparse(const float *voxel_features, const i
     else hipLaunchKernelGGL(pillar_sparse_kernel<false>, dim3(blocks), dim3(kWaves * 64), 0, stream, a);
     return check_launch();
 }
+
+#ifdef COALIGN_LAB
+extern "C" int coalign_lab_sparse_trace(long long *host_dst) {      // laboratory build only: copy the per-workgroup trace out (synchronises the device)
+    return coalign::hip_call(hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_sparse_trace), sizeof(long long) * 2048 * 4));
+}
+#endif

@@ -88,9 +88,15 @@ class PillarVFE(nn.Module):
         count_dev = batch_dict.get("voxel_count_dev")
         if self.sparse_canvas and channels_last and not self.with_distance and vf.shape[1] <= 32 and self.num_filters[-1] <= 64:
             # round 4 fast path (the detector switches it on when its first ResNet block consumes it): ONE launch, feature rows + cell stamps, no dense canvas
-            sc = ops.pillar_encode_sparse(vf, npts, coords, pfn.linear.weight, pfn.linear.bias, bn, pfn.norm.eps if self.use_norm else 0.0, self.use_absolute_xyz,
+            eps = pfn.norm.eps if self.use_norm else 0.0
+            cache = self.__dict__.get("_folded_cache")
+            if cache is None:
+                cache = self.__dict__["_folded_cache"] = backbone._FoldCache()
+            # the folded channel parameters: once per weight set (refreshed when a tensor of the PFN layer is replaced or written in place)
+            folded = cache.get(pfn, lambda: ops.pillar_fold_params(pfn.linear.weight, pfn.linear.bias, bn, eps, self.use_absolute_xyz))
+            sc = ops.pillar_encode_sparse(vf, npts, coords, pfn.linear.weight, pfn.linear.bias, bn, eps, self.use_absolute_xyz,
                                           self.voxel_size, self.point_cloud_range[:3], n_agents, self.ny, self.nx,
-                                          canvas_cache=self.__dict__.setdefault("_canvas_cache", {}), count_dev=count_dev)
+                                          canvas_cache=self.__dict__.setdefault("_canvas_cache", {}), count_dev=count_dev, folded=folded)
             batch_dict["pillar_features"] = sc.feats
             batch_dict["_sparse_canvas"] = sc
             return batch_dict

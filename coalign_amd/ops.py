@@ -215,13 +215,29 @@ class SparseCanvas:
 
 
 @_device_op
+def pillar_fold_params(weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[Tuple[torch.Tensor, ...]], bn_eps: float, use_absolute_xyz: bool) -> torch.Tensor:
+    """The encoder's channel parameters in the form ``pillar_encode_sparse`` uses (include/coalign_amd.h (1b)): once per weight set, like the split
+    weight images of the convolutions."""
+    _need_gpu(weight)
+    L = hip.lib()
+    w = _f32c(weight)
+    out = torch.empty(L.coalign_pillar_folded_param_bytes() // 4, dtype=torch.float32, device=w.device)
+    bnp = [None] * 4 if bn is None else [_f32c(t) for t in bn]
+    b = None if bias is None else _f32c(bias)
+    hip.check(L.coalign_pillar_fold_params(_ptr(w), _ptr(b), _ptr(bnp[0]), _ptr(bnp[1]), _ptr(bnp[2]), _ptr(bnp[3]), float(bn_eps), w.shape[0], int(use_absolute_xyz),
+                                           _ptr(out), _stream()), "coalign_pillar_fold_params")
+    return out
+
+
+@_device_op
 def pillar_encode_sparse(voxel_features: torch.Tensor, voxel_num_points: torch.Tensor, voxel_coords: torch.Tensor, weight: torch.Tensor,
                          bias: Optional[torch.Tensor], bn: Optional[Tuple[torch.Tensor, ...]], bn_eps: float, use_absolute_xyz: bool,
                          voxel_size: Sequence[float], range_min: Sequence[float], n_agents: int, ny: int, nx: int, canvas_cache: dict,
-                         count_dev: Optional[torch.Tensor] = None) -> SparseCanvas:
+                         count_dev: Optional[torch.Tensor] = None, folded: Optional[torch.Tensor] = None) -> SparseCanvas:
     """PillarVFE + PointPillarScatter in ONE launch (include/coalign_amd.h (1b)): feature rows [M, C] + 8-byte cell stamps.  ``canvas_cache`` keeps the
     stamp map and the frame-tag words of this (device, stream, grid): they persist across frames and are never cleared (a stamp is valid only with
-    the current tag).  ``count_dev``: optional int32 device tensor holding the pillar count (capacity-sized arrays)."""
+    the current tag).  ``count_dev``: optional int32 device tensor holding the pillar count (capacity-sized arrays).  ``folded``: ``pillar_fold_params``
+    of the same weights; a caller that keeps none gets them folded here (one more small launch per call)."""
     _need_gpu(voxel_features, voxel_num_points, voxel_coords, weight)
     L = hip.lib()
     vf = _f32c(voxel_features)
@@ -230,22 +246,23 @@ def pillar_encode_sparse(voxel_features: torch.Tensor, voxel_num_points: torch.T
     M, P = vf.shape[0], vf.shape[1]
     npts = voxel_num_points.to(torch.int32).contiguous()
     coords = voxel_coords.to(torch.int32).contiguous()
-    w = _f32c(weight)
-    C = w.shape[0]
+    C = weight.shape[0]
     dev = vf.device
     if P > 32 or C > 64:
         raise hip.CoalignHipError("pillar_encode_sparse: P <= 32 and C <= 64")
+    if folded is None:
+        folded = pillar_fold_params(weight, bias, bn, bn_eps, use_absolute_xyz)
+    if folded.dtype != torch.float32 or folded.numel() * 4 != L.coalign_pillar_folded_param_bytes() or folded.device != dev:
+        raise ValueError("folded: the tensor pillar_fold_params returned for these weights")
     key = ("sparse", str(dev), torch.cuda.current_stream(dev).cuda_stream, n_agents, ny, nx)
     entry = canvas_cache.get(key)
     if entry is None:
         entry = canvas_cache[key] = {"stamps": torch.zeros(n_agents * ny * nx, dtype=torch.int64, device=dev), "state": torch.zeros(2, dtype=torch.int32, device=dev)}
     feats = torch.empty((M, C), dtype=torch.float32, device=dev)
-    bnp = [None] * 4 if bn is None else [_f32c(t) for t in bn]
-    b = None if bias is None else _f32c(bias)
     with _Timed("pillar_encode_sparse"):
-        hip.check(L.coalign_pillar_encode_sparse(_ptr(vf), _ptr(npts), _ptr(coords), M, _ptr(count_dev), P, _ptr(w), _ptr(b), _ptr(bnp[0]), _ptr(bnp[1]), _ptr(bnp[2]),
-                                                 _ptr(bnp[3]), float(bn_eps), C, int(use_absolute_xyz), _dbl3(voxel_size), _dbl3(range_min), n_agents, ny, nx,
-                                                 _ptr(feats), _ptr(entry["stamps"]), _ptr(entry["state"]), _stream()), "coalign_pillar_encode_sparse")
+        hip.check(L.coalign_pillar_encode_sparse(_ptr(vf), _ptr(npts), _ptr(coords), M, _ptr(count_dev), P, _ptr(folded), C, int(use_absolute_xyz), _dbl3(voxel_size),
+                                                 _dbl3(range_min), n_agents, ny, nx, _ptr(feats), _ptr(entry["stamps"]), _ptr(entry["state"]), _stream()),
+                  "coalign_pillar_encode_sparse")
     return SparseCanvas(feats, entry["stamps"], entry["state"], coords, n_agents, C, ny, nx, count_dev)
 
 

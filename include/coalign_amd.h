@@ -379,11 +379,16 @@ int coalign_fill_words(void *p, size_t n_words, uint32_t value, void *stream);
  *     sequence of calls: 64-bit words (frame tag << 32) | pillar row per cell, entered by atomicMax -- the larger row of a cell wins, the reference's rule.
  *   state: int32[2], zero-initialised once: state[0] = tag of the last completed call, state[1] = arrival counter.  A cell holds pillar row
  *     (stamp & 0xffffffff) of THIS frame iff (stamp >> 32) == state[0] after the call; nothing is cleared between frames.
- *   M_dev (may be NULL): the pillar count on the device (int32), M_capacity then sizes the arrays.  No distance feature (with_distance configs use (1)). */
+ *   M_dev (may be NULL): the pillar count on the device (int32), M_capacity then sizes the arrays.  No distance feature (with_distance configs use (1)).
+ *   folded: coalign_pillar_folded_param_bytes() bytes (16-byte aligned) written ONCE per weight set by coalign_pillar_fold_params from the PFN layer's
+ *     Linear weight [C, 10 or 7] (+ bias when there is no BatchNorm) and its eval BatchNorm tensors: the channel parameters in the form the kernel's pair
+ *     loop uses (the three weight groups summed, BatchNorm folded to scale / shift, signs folded) -- the counterpart of the convolutions' split weight images. */
 size_t coalign_sparse_canvas_stamp_bytes(int n_agents, int ny, int nx);
+size_t coalign_pillar_folded_param_bytes(void);
+int coalign_pillar_fold_params(const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias, const float *bn_mean,
+                               const float *bn_var, float bn_eps, int C, int use_absolute_xyz, float *folded, void *stream);
 int coalign_pillar_encode_sparse(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M_capacity,
-                                 const int32_t *M_dev, int P, const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias,
-                                 const float *bn_mean, const float *bn_var, float bn_eps, int C, int use_absolute_xyz, const double *voxel_size,
+                                 const int32_t *M_dev, int P, const float *folded, int C, int use_absolute_xyz, const double *voxel_size,
                                  const double *range_min, int n_agents, int ny, int nx, float *pillar_features, void *stamps, int32_t *state, void *stream);
 /* (9d) The strided 3x3 convolution of (9b) (stride 2, pad 1, bias + ReLU; resblock.py:150-174) reading the sparse canvas of (1b): feats [M, Cin], pixel
  * (n, y, x) of the logical [N, Hin, Win, Cin] input = feats row (stamp & 0xffffffff) where the cell's stamp carries state[0], else zero.

@@ -211,6 +211,43 @@ def test_sparse_canvas_encoder_against_float64_and_oracle_scatter(pillars):
     assert torch.equal(dense.cpu(), oracle.scatter(sc.feats.cpu(), pl["voxel_coords"], 5, 704, 200))
 
 
+def test_pillar_fold_params_table_and_reuse():
+    """coalign_pillar_fold_params: the per-lane table (scale / shift of the folded BatchNorm at their slots) against torch, and the encoder with a kept
+    table bit-equal to the encoder that folds per call; a table of the wrong size is refused on the host, a NULL table at the C ABI."""
+    from coalign_amd import hip
+    from coalign_amd.synthetic import make_frame
+    h, model = _opv2v_model()
+    margs = h["model"]["args"]
+    model = model.to(DEV).eval()
+    pfn = model.pillar_vfe.pfn_layers[0]
+    bn = (pfn.norm.weight, pfn.norm.bias, pfn.norm.running_mean, pfn.norm.running_var)
+    folded = ops.pillar_fold_params(pfn.linear.weight, None, bn, 1e-3, True)
+    t = folded.view(6, 64, 4).cpu()
+    alpha = (pfn.norm.weight / torch.sqrt(pfn.norm.running_var + 1e-3)).cpu()
+    shift = (pfn.norm.bias - pfn.norm.running_mean * (pfn.norm.weight / torch.sqrt(pfn.norm.running_var + 1e-3))).cpu()
+    lanes = torch.arange(64)
+    for g in range(2):
+        ch = 32 * g + (lanes & 31)
+        assert torch.allclose(t[4, :, g], alpha[ch], rtol=2e-7, atol=0) and torch.allclose(t[4, :, 2 + g], shift[ch], rtol=1e-6, atol=1e-7)
+        assert torch.equal(t[5, :, g], torch.where(alpha[ch] < 0, -1.0, 1.0))
+    pl = make_frame(h, 2, pillars_per_agent=3000, seed=5)["processed_lidar"]
+    cache = {}
+    a = _sparse_encode(model, margs, pl, 2, cache)
+    nx, ny, _ = [int(v) for v in margs["point_pillar_scatter"]["grid_size"]]
+    b = ops.pillar_encode_sparse(pl["voxel_features"].to(DEV), pl["voxel_num_points"].to(DEV), pl["voxel_coords"].to(DEV), pfn.linear.weight, None, bn, 1e-3, True,
+                                 margs["voxel_size"], margs["lidar_range"][:3], 2, ny, nx, canvas_cache=cache, folded=folded)
+    assert torch.equal(a.feats, b.feats)
+    with pytest.raises(ValueError):
+        ops.pillar_encode_sparse(pl["voxel_features"].to(DEV), pl["voxel_num_points"].to(DEV), pl["voxel_coords"].to(DEV), pfn.linear.weight, None, bn, 1e-3, True,
+                                 margs["voxel_size"], margs["lidar_range"][:3], 2, ny, nx, canvas_cache=cache, folded=folded[:-4])
+    L = hip.lib()
+    import ctypes
+    z = torch.zeros(16, device=DEV)
+    dbl = (ctypes.c_double * 3)(0.4, 0.4, 4.0)
+    rc = L.coalign_pillar_encode_sparse(z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, None, 32, None, 64, 1, dbl, dbl, 1, 8, 8, z.data_ptr(), z.data_ptr(), z.data_ptr(), None)
+    assert rc == -1                      # COALIGN_ERR_NULL_POINTER
+
+
 def test_sparse_canvas_duplicates_stale_frames_and_device_count():
     """Duplicate cells (the larger row wins), out-of-canvas pillars, several frames through ONE stamp map without clearing (a cell occupied in frame 1 and
     empty in frame 2 must read as empty), the pillar count on the device with capacity-sized arrays."""

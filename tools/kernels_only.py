@@ -100,6 +100,13 @@ def _sc():
     return _sc_cache["sc"]
 
 
+_fold_cache = {}
+def _folded():
+    if "f" not in _fold_cache:
+        _fold_cache["f"] = ops.pillar_fold_params(pfn.linear.weight, None, bn, 1e-3, True)
+    return _fold_cache["f"]
+
+
 OPS = {
     "nms_gather_K600": _nms_fused,
     "nms_then_gather_K600": _nms_two_calls,
@@ -108,7 +115,7 @@ OPS = {
     "pillar_nhwc_persistent": lambda: ops.pillar_vfe_scatter(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], pfn.linear.weight, None, bn, 1e-3, True, False,
                                                              margs["voxel_size"], margs["lidar_range"][:3], N, 200, 704, channels_last=True, canvas_cache=_cache),
     "pillar_sparse": lambda: ops.pillar_encode_sparse(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], pfn.linear.weight, None, bn, 1e-3, True,
-                                                      margs["voxel_size"], margs["lidar_range"][:3], N, 200, 704, canvas_cache=_cache),
+                                                      margs["voxel_size"], margs["lidar_range"][:3], N, 200, 704, canvas_cache=_cache, folded=_folded()),
     "conv_fp16x2_64ch": lambda: ops.conv3x3_emu_bias_act(xs[0], _w16, bconv, 64, rconv, True, 16),
     "conv_fp16x2_128ch": lambda: ops.conv3x3_emu_bias_act(xs[1], _w16_128, _b128, 128, _r128, True, 16),
     "conv_fp16x2_256ch": lambda: ops.conv3x3_emu_bias_act(xs[2], _w16_256, _b256, 256, _r256, True, 16),
