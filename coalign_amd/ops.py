@@ -394,7 +394,7 @@ class DecodeBuffers:
     def __init__(self, capacity: int, A: int, H: int, W: int, top: int, device):
         L = hip.lib()
         self.capacity, self.top = capacity, top
-        self.frame_words = torch.zeros(65, dtype=torch.int32, device=device)  # cleared once per frame by ONE launch (reset_frame)
+        self.frame_words = torch.zeros(67, dtype=torch.int32, device=device)  # cleared once per frame by ONE launch (reset_frame); copied to the host as ONE block
         self.counts = self.frame_words[:64]                                    # chained per-agent totals
         self.status = self.frame_words[64:65]
         self.cand_index = torch.empty(capacity, dtype=torch.int32, device=device)
@@ -407,11 +407,11 @@ class DecodeBuffers:
         self.nms_ws_bytes = L.coalign_nms_rotated_workspace_bytes(capacity, top)
         self.nms_ws = torch.empty(max(1, self.nms_ws_bytes), dtype=torch.uint8, device=device)
         self.keep = torch.empty(top, dtype=torch.int32, device=device)
-        self.keep_count = torch.zeros(1, dtype=torch.int32, device=device)
+        self.keep_count = self.frame_words[65:66]
         self.out_corners = torch.empty((top, 8, 3), dtype=torch.float32, device=device)
         self.out_scores = torch.empty(top, dtype=torch.float32, device=device)
-        self.out_count = torch.zeros(1, dtype=torch.int32, device=device)
-        self.host = torch.zeros(4, dtype=torch.int32).pin_memory()   # (final, candidates, kept, status) of the last frame
+        self.out_count = self.frame_words[66:67]
+        self.host = torch.zeros(67, dtype=torch.int32).pin_memory()  # the frame words of the last frame: chained totals | status | kept | final
 
 
     def reset_frame(self) -> None:

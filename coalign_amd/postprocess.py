@@ -132,11 +132,9 @@ class VoxelPostprocessor:
                                    k_dev=total_dev, keep=buf.keep, keep_count=buf.keep_count, ws=buf.nms_ws)
             ops.gather_in_range(buf.cand_corners, buf.cand_score, buf.keep, buf.keep_count, self.params["gt_range"],
                                 buf.out_corners, buf.out_scores, buf.out_count)
-        # the frame's four scalars travel to pinned host memory behind the kernels: one small async copy each
-        buf.host[0:1].copy_(buf.out_count, non_blocking=True)
-        buf.host[1:2].copy_(total_dev, non_blocking=True)
-        buf.host[2:3].copy_(buf.keep_count, non_blocking=True)
-        buf.host[3:4].copy_(buf.status, non_blocking=True)
+        # the frame's scalars (chained candidate totals, status, kept, final) are one 268-byte block: ONE async copy to pinned host memory behind the kernels
+        buf.n_cavs = len(cavs)
+        buf.host.copy_(buf.frame_words, non_blocking=True)
 
     def post_process_async(self, data_dict: dict, output_dict: dict, side_stream: bool = True) -> "PostProcessHandle":
         """Enqueue decode + NMS + range filter and return immediately.  With ``side_stream`` the kernels run on a
@@ -221,7 +219,8 @@ class PostProcessHandle:
 
     def result(self) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
         self.done.synchronize()
-        n_out, n_cand, n_keep, status = [int(v) for v in self.buf.host.tolist()]
+        words = self.buf.host.tolist()
+        n_out, n_cand, n_keep, status = int(words[66]), int(words[self.buf.n_cavs]), int(words[65]), int(words[64])
         if status & 1:
             raise RuntimeError("post_process: candidate buffer overflow")
         self.owner.last_counts = {"candidates": n_cand, "kept": n_keep, "final": n_out}
