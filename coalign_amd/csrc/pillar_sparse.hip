@@ -244,8 +244,8 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
     if (kLab && (a.debug & 512)) { ts[0] = (long long)__builtin_amdgcn_s_memtime(); ts[7] = (long long)wall_clock64(); }
     const unsigned tag = (unsigned)a.state[0] + 1u;                  // this frame's tag (state[0] is written only when the last workgroup has finished)
     const int npairs = (a.M + 1) / 2;
-    const int per_wave = (npairs + nwave - 1) / nwave;
-    const int p0 = gwave * per_wave, p1 = min(p0 + per_wave, npairs);
+    // even shares (+-1 pair): with a grid that is a whole number of workgroups per CU every SIMD gets the same work
+    const int p0 = (int)((long long)gwave * npairs / nwave), p1 = (int)((long long)(gwave + 1) * npairs / nwave);
     if (p0 < p1) {
         const int ncell = a.ny * a.nx;
         const char *pts_b = reinterpret_cast<const char *>(a.pts);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         g_sparse_trace[blockIdx.x * 4 + 0] = ts[7];
         g_sparse_trace[blockIdx.x * 4 + 1] = (long long)wall_clock64();
-        g_sparse_trace[blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID
+        g_sparse_trace[blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32);      // HW_ID | XCC_ID << 32
         g_sparse_trace[blockIdx.x * 4 + 3] = ts[5] - ts[3];
     }
 #endif
@@ -402,14 +402,25 @@ extern "C" int coalign_pillar_encode_sparse(const float *voxel_features, const i
     a.n_agents = n_agents; a.ny = ny; a.nx = nx; a.feats = pillar_features;
     a.stamps = static_cast<unsigned long long *>(stamps); a.state = state; a.M_dev = M_dev;
     a.debug = coalign::lab_env("COALIGN_SPARSE_DEBUG", 0);
-    // five workgroups of four wavefronts per CU (8 KB of LDS per wavefront): four to five wavefronts per SIMD keep the fp32 matrix pipe fed.  A
-    // wavefront takes two rounds' pairs unless the capacity asks for more (up to kRunPairs each, then more workgroups)
-    const int pairs = (M_capacity + 1) / 2, resident = 1280;
+    // Grid = a WHOLE number of workgroups per CU (the dispatcher spreads resident workgroups evenly: measured 3 or 4 per CU for 834 workgroups, and the CUs with
+    // 4 finish 3.5 us after those with 3 -- the kernel is bound by each SIMD's issue, so the launch ends with the busiest SIMD), pairs shared out evenly
+    // (+-1): k = 1..3 workgroups per CU (32 KB of LDS each), about 2 * kRound pairs per wavefront; larger inputs: runs of at most kRunPairs pairs, more rounds
+    // of workgroups.
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    const int pairs = (M_capacity + 1) / 2;
     const int per_wave_target = coalign::lab_env("COALIGN_SPARSE_PAIRS", 2 * kRound);      // laboratory build: pairs per wavefront the grid is sized for
-    int blocks = (pairs + kWaves * per_wave_target - 1) / (kWaves * per_wave_target);
-    if (blocks > resident) blocks = resident;
+    const int unit = cus * kWaves * per_wave_target;
+    int k = (pairs + unit / 2) / unit;
+    k = k < 1 ? 1 : k > 3 ? 3 : k;       // (four per CU fit on paper -- 128 KB of LDS -- but a grid that needs EVERY slot waits a whole workgroup lifetime for a straggler: 31 vs 20 us)
+    int blocks = k * cus;
+    if (pairs < blocks * kWaves) blocks = (pairs + kWaves - 1) / kWaves;                   // small inputs: one pair per wavefront
     const int need = (pairs + kWaves * kRunPairs - 1) / (kWaves * kRunPairs);
-    if (blocks < need) blocks = need;
+    if (blocks < need) blocks = (need + cus - 1) / cus * cus;
     if (blocks < 1) blocks = 1;                               // (M = 0: the launch still advances the frame tag)
     if (use_absolute_xyz) hipLaunchKernelGGL(pillar_sparse_kernel<true>, dim3(blocks), dim3(kWaves * 64), 0, stream, a);
     else hipLaunchKernelGGL(pillar_sparse_kernel<false>, dim3(blocks), dim3(kWaves * 64), 0, stream, a);

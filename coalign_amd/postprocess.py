@@ -121,7 +121,12 @@ class VoxelPostprocessor:
                 fac = torch.pow((torch.clamp(torch.sigmoid(out["iou_preds"].permute(0, 2, 3, 1).contiguous()).reshape(-1), min=0.0, max=1.0) + 1) * 0.5, 4)
                 rows = torch.arange(buf.capacity, device=device, dtype=torch.int32)
                 sel = (rows >= buf.counts[slot]) & (rows < buf.counts[slot + 1])
-                idx = buf.cand_index.long().clamp_(0, fac.numel() - 1)
+                raw = buf.cand_index.long()
+                # rows outside this cav's range hold stale indices and only need SOME valid address; an index of a SELECTED row outside the head's anchors means
+                # the candidate layout and the head disagree: that is reported through the status word (bit 1), not hidden by the clamp
+                bad = sel & ((raw < 0) | (raw >= fac.numel()))
+                buf.status.bitwise_or_(bad.any().to(torch.int32).reshape(1) * 2)
+                idx = raw.clamp(0, fac.numel() - 1)
                 buf.cand_score.copy_(torch.where(sel, buf.cand_score * fac[idx], buf.cand_score))
         total_dev = buf.counts[len(cavs): len(cavs) + 1]
         if NMS_TOP <= 1024:        # rank, bitmask, walk + in-range gather: three launches (coalign_nms_rotated_gather)
@@ -223,6 +228,8 @@ class PostProcessHandle:
         n_out, n_cand, n_keep, status = int(words[66]), int(words[self.buf.n_cavs]), int(words[65]), int(words[64])
         if status & 1:
             raise RuntimeError("post_process: candidate buffer overflow")
+        if status & 2:
+            raise RuntimeError("post_process: iou_preds rescoring met a candidate index outside the head's anchors (candidate layout and head disagree)")
         self.owner.last_counts = {"candidates": n_cand, "kept": n_keep, "final": n_out}
         if n_cand == 0:
             return None, None
