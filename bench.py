@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from coalign_amd import ops  # noqa: E402
+from coalign_amd import sharded  # noqa: E402
 from coalign_amd import backbone as backbone_mod  # noqa: E402
 from coalign_amd.config import builtin_config  # noqa: E402
 from coalign_amd.detector import build_model, to_device  # noqa: E402
@@ -254,10 +255,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a collective a peer never enters must end as an exception, not as a hang until the driver's clock runs out: 10 minutes (default 30)
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("COALIGN_BENCH_PG_TIMEOUT_S", "600")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
 
     if args.conv_emu is not None:
         backbone_mod.CONV_EMU_TERMS = args.conv_emu
@@ -299,9 +303,7 @@ def main():
 
     def agree(ok: bool) -> bool:
         """All ranks take the same fall-back decision, over a gloo control group that does not depend on the data-plane backend."""
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=ctl)
-        return bool(int(t.item()))
+        return sharded.control_agree(ok, ctl)
 
     def setup_mode(m):
         """-> (rings, exchanges, step_batches) of schedule m in {"ring", "gather", "replicas"}."""
@@ -392,28 +394,36 @@ def main():
     pipe = make_pipe(use_graph)
     warm = max(args.warmup, 2 * n_lanes if use_graph else args.warmup)     # every lane captures its graph during the warm-up
     if world > 1:
-        # the chosen schedule's first exchanges, guarded: any error on any rank moves ALL ranks to the next schedule (ring -> gather -> replicas)
-        while True:
-            ok = True
-            try:
-                for s_ in range(n_lanes):
-                    pipe.submit(step_batches[s_ % len(step_batches)])
-                pipe.drain()
-                torch.cuda.synchronize()
-            except Exception as e:      # noqa: BLE001
-                print(f"bench[{rank}]: schedule '{mode}' failed in its first exchanges: {type(e).__name__}: {str(e)[:200]}", file=sys.stderr, flush=True)
-                ok = False
-            if agree(ok) or mode == "replicas":
-                break
-            nxt = "gather" if mode == "ring" else "replicas"
-            rccl["fallbacks"].append(f"{mode} failed in its first exchanges -> {nxt}")
-            mode = nxt
-            try:
-                torch.cuda.synchronize()
-            except Exception:      # noqa: BLE001
-                pass
-            rings, exchanges, step_batches = setup_mode(mode)
-            pipe = make_pipe(False)
+        # the chosen schedule's first exchanges, guarded: any error on any rank moves ALL ranks to the next schedule (ring -> gather -> replicas;
+        # coalign_amd.sharded.negotiate_schedule, CPU-tested with gloo ranks in tests/test_sharded_cpu.py)
+        state = {"mode": mode}
+
+        def attempt(m):
+            nonlocal rings, exchanges, step_batches, pipe
+            if m != state["mode"]:                   # a fall-back: rebuild the schedule and an eager pipeline around it
+                try:
+                    torch.cuda.synchronize()
+                except Exception:      # noqa: BLE001
+                    pass
+                rings, exchanges, step_batches = setup_mode(m)
+                pipe = make_pipe(False)
+                state["mode"] = m
+            # fault injection for the fall-back chain's own test (tools/gpu_multirank_check.sh): COALIGN_BENCH_INJECT_FAIL="ring:1,gather:0" makes the first
+            # exchanges of schedule `ring` raise on rank 1 and of `gather` on rank 0
+            for item in filter(None, os.environ.get("COALIGN_BENCH_INJECT_FAIL", "").split(",")):
+                sched, r_ = item.split(":")
+                if sched == m and int(r_) == rank:
+                    raise RuntimeError(f"injected failure of schedule '{m}' on rank {rank}")
+            for s_ in range(n_lanes):
+                pipe.submit(step_batches[s_ % len(step_batches)])
+            pipe.drain()
+            torch.cuda.synchronize()
+
+        def report(m, e):
+            print(f"bench[{rank}]: schedule '{m}' failed in its first exchanges: {type(e).__name__}: {str(e)[:200]}", file=sys.stderr, flush=True)
+
+        mode, taken = sharded.negotiate_schedule(mode, attempt, agree, report)
+        rccl["fallbacks"] += taken
         rccl["mode_run"] = mode
         # what one exchange costs on this node: the feature maps of one step through the schedule's collective, HIP events, max over ranks
         if exchanges is not None:

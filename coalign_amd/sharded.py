@@ -290,3 +290,39 @@ def preflight(world: int, n_agents: int, feature_shapes: Sequence[Tuple[int, int
         report.update({"per": per, "blocks": [list(b) for b in blocks], "bytes_sent_per_rank_per_step": [(world - 1) * per * sum(row_bytes)] * world,
                        "buffers_per_lane": {"recv_bytes": world * per * sum(row_bytes)}})
     return report
+
+
+# ---- first contact with a collective backend, hardened (the reference's own bring-up: opencood/tools/multi_gpu_utils.py:31-37) ----
+
+SCHEDULES = ("ring", "gather", "replicas")          # fall-back order: frame ring -> one-frame agent gather -> N independent replicas (no collective)
+
+
+def control_agree(ok: bool, group=None) -> bool:
+    """True iff EVERY rank reports ok.  ``group``: a control group that does not depend on the data-plane backend (gloo next to RCCL): a rank whose
+    collective raised must not leave the others waiting inside the next one."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
+def negotiate_schedule(start: str, attempt, agree, report=None) -> Tuple[str, List[str]]:
+    """Run ``attempt(mode)`` -- the mode's set-up and first exchanges on THIS rank, raising on any failure -- for ``start`` and, whenever ANY rank failed
+    (``agree(ok)`` = logical AND over the ranks), for the next schedule of ``SCHEDULES``; ``"replicas"`` is terminal.  Every rank takes the same decisions.
+    Returns (schedule that runs, list of fall-backs taken)."""
+    if start not in SCHEDULES:
+        raise ValueError(f"schedule must be one of {SCHEDULES}")
+    mode, fallbacks = start, []
+    while True:
+        ok = True
+        try:
+            attempt(mode)
+        except Exception as e:      # noqa: BLE001 -- whatever the backend throws
+            ok = False
+            if report is not None:
+                report(mode, e)
+        if agree(ok) or mode == "replicas":
+            return mode, fallbacks
+        nxt = SCHEDULES[SCHEDULES.index(mode) + 1]
+        fallbacks.append(f"{mode} failed in its first exchanges -> {nxt}")
+        mode = nxt
+

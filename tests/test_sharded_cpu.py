@@ -9,8 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from coalign_amd.sharded import (AgentGather, FrameRing, agent_blocks, encode_assignments, recv_plan, ring_batch, send_plan, split_agents,
-                                 stack_agents)
+from coalign_amd.sharded import (AgentGather, FrameRing, agent_blocks, control_agree, encode_assignments, negotiate_schedule, recv_plan, ring_batch,
+                                 send_plan, split_agents, stack_agents)
 
 SHAPES = [(4, 6, 8), (8, 3, 4), (16, 2, 2)]
 
@@ -174,3 +174,48 @@ def test_exchange_preflight_every_world_size():
         preflight(2, 5, [(3, 5, 7)])                    # 105 floats per row: not a multiple of 16 bytes
     with pytest.raises(ValueError):
         preflight(2, 5, opv2v, mode="scatter")
+
+
+def _negotiate_worker(rank, world, failing, port, q):
+    """``failing``: {schedule: ranks whose first exchanges raise}.  Every rank must end on the same schedule with the same fall-back list, and a rank
+    that did NOT fail must not be left inside a collective the failing rank never entered (the all-reduce of the control group is the only rendezvous)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctl = dist.new_group(backend="gloo")
+        tried, reported = [], []
+
+        def attempt(mode):
+            tried.append(mode)
+            if rank in failing.get(mode, ()):
+                raise RuntimeError(f"injected failure of '{mode}' on rank {rank}")
+            # (a real schedule enters its data-plane collective here; this worker only records the attempt: the control group's all-reduce is the rendezvous)
+
+        mode, fallbacks = negotiate_schedule("ring", attempt, lambda ok: control_agree(ok, ctl), lambda m, e: reported.append(m))
+        out = [None] * world
+        dist.all_gather_object(out, (mode, fallbacks, tried))
+        want_mode = "ring" if not failing.get("ring") else "gather" if not failing.get("gather") else "replicas"
+        ok = all(o == out[0] for o in out) and mode == want_mode and len(fallbacks) == ("ring", "gather", "replicas").index(want_mode)
+        ok = ok and reported == [m for m in tried if rank in failing.get(m, ())]
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("failing", [{}, {"ring": (1,)}, {"ring": (0, 1), "gather": (0,)}, {"ring": (1,), "gather": (1,), "replicas": (1,)}])
+def test_schedule_fallback_chain_is_taken_by_all_ranks_together(failing):
+    """bench.py's RCCL bring-up: ring -> gather -> replicas, decided over a control group; world size 2, gloo."""
+    _spawn(_negotiate_worker, 2, (failing,))
+
+
+def test_negotiate_schedule_single_process_contract():
+    calls = []
+    def attempt(m):
+        calls.append(m)
+        if m == "ring":
+            raise ValueError("no")
+    assert negotiate_schedule("ring", attempt, lambda ok: ok) == ("gather", ["ring failed in its first exchanges -> gather"]) and calls == ["ring", "gather"]
+    assert negotiate_schedule("replicas", lambda m: 1 / 0, lambda ok: ok) == ("replicas", [])      # terminal: nothing left to fall back to
+    with pytest.raises(ValueError):
+        negotiate_schedule("mesh", attempt, lambda ok: ok)
+

@@ -13,6 +13,12 @@ for R in 2 5; do
 COALIGN_BENCH_BACKEND=gloo COALIGN_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $R --master-addr 127.0.0.1 --master-port $((29670 + R)) \
     bench.py --gpus $R --mode gather --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes --no-size-sweep > $OUT/g$R.json 2> $OUT/g$R.err
 done
+# the fall-back chain with injected failures (raised on EVERY rank before the schedule's first collective: with host-blocking gloo collectives a failure on
+# one rank only would leave its peer inside the collective until the process-group timeout): ring fails -> gather; ring and gather fail -> independent replicas
+COALIGN_BENCH_INJECT_FAIL="ring:0,ring:1" COALIGN_BENCH_BACKEND=gloo COALIGN_BENCH_ONE_GPU=1 timeout 150 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29691 \
+    bench.py --gpus 2 --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes --no-size-sweep > $OUT/f1.json 2> $OUT/f1.err
+COALIGN_BENCH_INJECT_FAIL="ring:0,ring:1,gather:0,gather:1" COALIGN_BENCH_BACKEND=gloo COALIGN_BENCH_ONE_GPU=1 timeout 150 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29692 \
+    bench.py --gpus 2 --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes --no-size-sweep > $OUT/f2.json 2> $OUT/f2.err
 python - $OUT <<'PY'
 import json,sys
 out=sys.argv[1]
@@ -40,6 +46,15 @@ for R in (2,5):
     print(f"gather N={R} (gloo, one GPU shared; functional only): {d['value']} frames/s ({d['scaling']}), parallelism = {d['config']['parallelism']}, "
           f"{len(d['frame_digests'])} pool frames, digests equal to N=1: {same}")
     ok = ok and same
+for name, want in (("f1", "gather"), ("f2", "replicas")):
+    try:
+        d=json.loads([l for l in open(f"{out}/{name}.json") if l.startswith("{")][-1])
+    except Exception as e:
+        print(f"fall-back run {name}: no result ({e})"); ok=False; continue
+    r=d.get("rccl") or {}
+    same=all(ref["frame_digests"].get(k)==v for k,v in d["frame_digests"].items())
+    print(f"injected failure -> requested {r.get('requested_mode')}, ran {r.get('mode_run')} (expected {want}), fall-backs {r.get('fallbacks')}, {d['value']} frames/s, digests equal to N=1: {same}")
+    ok = ok and r.get("mode_run") == want and same
 print("N=1 digests:", ref["frame_digests"])
 print("MULTIRANK_CHECK", "PASS" if ok else "FAIL")
 PY
