@@ -214,6 +214,24 @@ class SparseCanvas:
         return scatter_to_bev(self.feats, self.coords, self.n_agents, self.ny, self.nx)
 
 
+# The frame tag of a sparse canvas is 32 bits and stamps are ordered by (tag, row) through atomicMax: a tag that wrapped would lose against the stale stamps of
+# the frames before it.  A stamp map is therefore re-zeroed (stamps + frame words, on the launching stream) after this many launches -- 2^31 frames are 50 days
+# of one lane at 500 frames/s; callers that replay a captured launch count the replays themselves (FramePipeline does) and call reset_sparse_canvases.
+SPARSE_TAG_RESET_AFTER = 1 << 31
+
+
+def reset_sparse_canvases(canvas_cache: dict) -> int:
+    """Zero the stamps and frame words of every sparse canvas of ``canvas_cache`` on the current stream; -> number of canvases reset."""
+    n = 0
+    for key, entry in canvas_cache.items():
+        if isinstance(key, tuple) and key and key[0] == "sparse":
+            entry["stamps"].zero_()
+            entry["state"].zero_()
+            entry["calls"] = 0
+            n += 1
+    return n
+
+
 @_device_op
 def pillar_fold_params(weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[Tuple[torch.Tensor, ...]], bn_eps: float, use_absolute_xyz: bool) -> torch.Tensor:
     """The encoder's channel parameters in the form ``pillar_encode_sparse`` uses (include/coalign_amd.h (1b)): once per weight set, like the split
@@ -258,6 +276,11 @@ def pillar_encode_sparse(voxel_features: torch.Tensor, voxel_num_points: torch.T
     entry = canvas_cache.get(key)
     if entry is None:
         entry = canvas_cache[key] = {"stamps": torch.zeros(n_agents * ny * nx, dtype=torch.int64, device=dev), "state": torch.zeros(2, dtype=torch.int32, device=dev)}
+    entry["calls"] = entry.get("calls", 0) + 1
+    if entry["calls"] >= SPARSE_TAG_RESET_AFTER:             # (never inside a captured frame: a capture happens in a map's first calls)
+        entry["stamps"].zero_()
+        entry["state"].zero_()
+        entry["calls"] = 1
     feats = torch.empty((M, C), dtype=torch.float32, device=dev)
     with _Timed("pillar_encode_sparse"):
         hip.check(L.coalign_pillar_encode_sparse(_ptr(vf), _ptr(npts), _ptr(coords), M, _ptr(count_dev), P, _ptr(folded), C, int(use_absolute_xyz), _dbl3(voxel_size),

@@ -69,6 +69,7 @@ class _GraphSlot:
         self.offsets: Optional[List[int]] = None        # points mode: first point slot of every cloud in the static input buffer
         self.count_host: Optional[torch.Tensor] = None
         self.capacity: Optional[int] = None             # bucket mode: pillar rows of the static input buffers (the frame's count sits in inputs["count"])
+        self.replays = 0                                # launches through this slot's sparse canvas since its stamps were last zeroed (ops.SPARSE_TAG_RESET_AFTER)
 
 
 class FramePipeline:
@@ -253,6 +254,11 @@ class FramePipeline:
         if offsets is not None:
             self._staged[k] = torch.cuda.Event()
             self._staged[k].record(stream)                      # the pinned staging buffer may be refilled once this has passed
+        slot.replays += 1
+        if slot.replays >= ops.SPARSE_TAG_RESET_AFTER:          # the 32-bit frame tag of the slot's sparse canvas must not wrap: re-zero the stamp map between replays
+            with torch.cuda.stream(stream):
+                ops.reset_sparse_canvases(slot.canvas_cache)
+            slot.replays = 0
         slot.graph.replay()
         done = torch.cuda.Event()
         done.record(stream)

@@ -378,7 +378,8 @@ int coalign_fill_words(void *p, size_t n_words, uint32_t value, void *stream);
  *   stamps: coalign_sparse_canvas_stamp_bytes(n_agents, ny, nx) bytes, 8-byte aligned, ZERO-INITIALISED ONCE by the caller and then owned by this
  *     sequence of calls: 64-bit words (frame tag << 32) | pillar row per cell, entered by atomicMax -- the larger row of a cell wins, the reference's rule.
  *   state: int32[2], zero-initialised once: state[0] = tag of the last completed call, state[1] = arrival counter.  A cell holds pillar row
- *     (stamp & 0xffffffff) of THIS frame iff (stamp >> 32) == state[0] after the call; nothing is cleared between frames.
+ *     (stamp & 0xffffffff) of THIS frame iff (stamp >> 32) == state[0] after the call; nothing is cleared between frames.  The tag is 32 bits and stamps are
+ *     ordered by (tag, row): the caller re-zeroes stamps and state before 2^32 - 1 calls have gone through one stamp map (coalign_amd/ops.py does after 2^31).
  *   M_dev (may be NULL): the pillar count on the device (int32), M_capacity then sizes the arrays.  No distance feature (with_distance configs use (1)).
  *   folded: coalign_pillar_folded_param_bytes() bytes (16-byte aligned) written ONCE per weight set by coalign_pillar_fold_params from the PFN layer's
  *     Linear weight [C, 10 or 7] (+ bias when there is no BatchNorm) and its eval BatchNorm tensors: the channel parameters in the form the kernel's pair

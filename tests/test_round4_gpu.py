@@ -287,6 +287,62 @@ def test_sparse_canvas_duplicates_stale_frames_and_device_count():
     assert torch.equal(sc.dense(), full.dense())
 
 
+def test_sparse_canvas_stamp_map_is_rezeroed_before_the_frame_tag_can_wrap(monkeypatch):
+    """The 32-bit frame tag orders stamps through atomicMax, so a wrapped tag would lose against stale stamps: ops re-zeroes a stamp map after
+    SPARSE_TAG_RESET_AFTER launches (2^31 in the product; 3 here), FramePipeline counts graph replays per slot and does the same between replays.  Every
+    frame of a sequence crossing several resets still densifies to the oracle's scatter, and the pipeline's detections equal the un-reset run's."""
+    from oracle import coalign_oracle as oracle
+    from coalign_amd.pipeline import FramePipeline
+    from coalign_amd.postprocess import build_postprocessor
+    from coalign_amd.synthetic import make_frame
+    h, model = _opv2v_model()
+    margs = h["model"]["args"]
+    model = model.to(DEV).eval()
+    frames = [make_frame(h, 2, pillars_per_agent=1500 + 100 * i, seed=40 + i) for i in range(8)]
+    monkeypatch.setattr(ops, "SPARSE_TAG_RESET_AFTER", 3)
+    cache = {}
+    tags = []
+    for f in frames:
+        pl = f["processed_lidar"]
+        sc = _sparse_encode(model, margs, pl, 2, cache)
+        tags.append(int(sc.state[0].item()))
+        assert torch.equal(sc.dense().cpu(), oracle.scatter(sc.feats.cpu(), pl["voxel_coords"], 2, 704, 200))
+    assert max(tags) <= 3 and tags.count(1) >= 2, tags              # the tag restarted: the map was re-zeroed on the way
+    # ... and through the graph pipeline (mini model, the detector's sparse route): replays counted per slot, the stamp map re-zeroed between replays
+    from coalign_amd.config import builtin_config
+    from coalign_amd.detector import build_model, to_device
+    from coalign_amd.synthetic import fill_parameters_
+    hm = builtin_config("mini_coalign")
+    mini = build_model(hm)
+    fill_parameters_(mini, seed=0, cls_bias=-1.0)
+    with torch.no_grad():
+        mini.reg_head.weight.mul_(0.01); mini.reg_head.bias.zero_(); mini.cls_head.weight.mul_(0.05)
+    mini = mini.to(DEV).eval()
+    ppm = build_postprocessor(hm["postprocess"], False)
+    anchors = torch.from_numpy(ppm.generate_anchor_box())
+    two = [to_device(make_frame(hm, 3, pillars_per_agent=150 + 30 * i, seed=60 + i, spread_xy=(4.0, 2.0), spread_yaw=45.0), DEV) for i in range(2)]
+
+    def run(reset_after):
+        monkeypatch.setattr(ops, "SPARSE_TAG_RESET_AFTER", reset_after)
+        pipe = FramePipeline(mini, build_postprocessor(hm["postprocess"], False), anchors, lanes=1, result_lag=0, graph=True, device=DEV)
+        out = pipe.run([two[i % 2] for i in range(11)])              # two input shapes -> two slots, several resets each at reset_after = 3
+        resets = [sl.replays for d in pipe._slots for sl in d.values()]
+        assert any(isinstance(k, tuple) and k[0] == "sparse" for d in pipe._slots for sl in d.values() for k in sl.canvas_cache)      # the route under test
+        pipe.close()
+        return out, resets
+
+    (a, ra), (b, rb) = run(3), run(1 << 31)
+    assert max(ra) < 3 and sum(rb) == 11, (ra, rb)                  # counters were reset on the way in the first run, never in the second
+    n_det = 0
+    for (ba, sa), (bb, sb) in zip(a, b):
+        assert (ba is None) == (bb is None)
+        if ba is not None:
+            assert torch.equal(ba, bb) and torch.equal(sa, sb)
+            n_det += ba.shape[0]
+    assert len(a) == 11 and n_det > 10
+
+
+
 def test_first_resnet_block_reads_the_sparse_canvas_bit_equal_to_the_dense_canvas(conv_mode):
     """The consumers' cell lookup (coalign_conv3x3_emu_sparse, coalign_pointwise_conv_emu_sparse): the multiscale features computed from the SparseCanvas
     equal, bit for bit, those computed from its densified channels-last canvas (same kernels, same arithmetic, zeros where no pillar lives)."""
