@@ -795,7 +795,13 @@ template <int TERMS, bool F16 = false>
 int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipStream_t s, Launch *query) {
     if constexpr (F16) {                      // fp16 2-way split on the tap-major image: 12 / 8 rows per workgroup or the 26 x 16 tiles, as the bf16 2-way split
         if (a.Cin % (2 * kKC)) return COALIGN_ERR_UNSUPPORTED;
-        const int rows = (a.W % 32 == 16 && a.H > 26 && a.H <= 52) ? 26 : (a.H >= 64 ? 12 : 8);
+        int rows = (a.W % 32 == 16 && a.H > 26 && a.H <= 52) ? 26 : (a.H >= 64 ? 12 : 8);
+        // stacked tiles as for the 3-way split (see below): the 24 x 16 tiles on the 50 x 176 maps (bit 0), the 4 x 8-pixel blocks on the 25 x 88 maps (bit 2).
+        // Measured with the fp16 split (round 4, same box, alternating; bit-equal outputs): 50 x 176 layer 62.1 -> 57.0 us alone; whole frame 486 / 494 (off)
+        // -> 496 / 501 frames/s (both bits), one frame in flight 2.57 -> 2.55 ms; bit 0 alone 480 / 491.
+        static const int stack16 = coalign::lab_env("COALIGN_EMU_STACK16", 5);
+        if (rows == 26 && a.H >= 24 && (stack16 & 1)) rows = 124;
+        else if (rows == 8 && a.H >= 8 && a.H <= 32 && a.W % 32 > 0 && a.W % 32 <= 24 && (stack16 & 4)) rows = 148;
         return tapk_rows<2, VAR_TAPK | VAR_ASM_DMA | VAR_F16>(rows, a, layout, ws, ws_bytes, s, query);
     }
     static const int force = coalign::lab_env("COALIGN_EMU_TAPK_ROWS", 0);      // laboratory build only

@@ -547,9 +547,10 @@ def test_pcdet_nms_beyond_the_device_walk_limit(monkeypatch):
 
 # ------------------------------------------------------------------------------------------------ stacked convolution tiles
 _STACK_CHECK = r"""
-import hashlib, sys, torch
+import hashlib, os, sys, torch
 import torch.nn.functional as F
 from coalign_amd import ops
+T = int(os.environ.get("STACK_CHECK_TERMS", "3"))
 h = hashlib.sha256()
 worst = 0.0
 # (N, C, H, W): the detector's stage-2 / stage-3 maps at 5 and 2 agents, DAIR and LSS sizes, one image, ragged sizes, a tile height that divides H
@@ -558,13 +559,13 @@ for (N, C, H, W) in ((5, 256, 25, 88), (5, 128, 50, 176), (2, 256, 25, 88), (2, 
     g = torch.Generator().manual_seed(N * 1000 + C + H)
     x = torch.randn(N, C, H, W, generator=g).cuda(); w = (torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).cuda()
     b = torch.randn(C, generator=g).cuda(); r = torch.randn(N, C, H, W, generator=g).cuda()
-    ws = ops.pack_conv3x3_emu_weight(w, 3, True)
+    ws = ops.pack_conv3x3_emu_weight(w, T, True)
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     for res, relu in ((None, False), (r, True)):
         want = ref if res is None else ref + res.double()
         want = torch.relu(want) if relu else want
         for cl in (False, True):
-            got = ops.conv3x3_emu_bias_act(x, ws, b, C, res, relu, 3, out_channels_last=cl)
+            got = ops.conv3x3_emu_bias_act(x, ws, b, C, res, relu, T, out_channels_last=cl)
             worst = max(worst, float((got.double() - want).abs().max() / want.abs().max()))
             h.update(got.contiguous().cpu().numpy().tobytes())
 print("WORST", worst, "SHA", h.hexdigest())
@@ -583,6 +584,14 @@ def test_stacked_convolution_tiles_equal_per_image_tiles_bit_for_bit():
         assert r.returncode == 0, (stack, r.stdout[-300:], r.stderr[-800:])
         outs[stack] = r.stdout.strip().split("SHA")[-1].strip()
     assert outs["5"] == outs["3"] == outs["1"] == outs["0"], outs
+    # the fp16 2-way split (round 4): stacked tiles are its default too (COALIGN_EMU_STACK16 = 5: bits 0 and 2)
+    outs = {}
+    for stack in ("5", "1", "4", "0"):
+        r = subprocess.run([sys.executable, "-c", _STACK_CHECK], env=dict(os.environ, PYTHONPATH=ROOT, COALIGN_LAB="1", COALIGN_EMU_STACK16=stack, STACK_CHECK_TERMS="16"),
+                           capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, (stack, r.stdout[-300:], r.stderr[-800:])
+        outs[stack] = r.stdout.strip().split("SHA")[-1].strip()
+    assert outs["5"] == outs["1"] == outs["4"] == outs["0"], outs
 
 
 _CORUN_CHECK = r"""

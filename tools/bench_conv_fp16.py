@@ -39,7 +39,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             out[key] = f"fail: {e}"
     print(json.dumps(out))
 else:
-    settings = [("product", {}), ("prio1", {"COALIGN_EMU_PRIO": "1"}), ("xcd_order_off", {"COALIGN_EMU_XCD": "0"})]
+    settings = [("product", {}), ("per_image_tiles", {"COALIGN_EMU_STACK16": "0"}), ("stack_50_only", {"COALIGN_EMU_STACK16": "1"}), ("prio1", {"COALIGN_EMU_PRIO": "1"})]
     if os.environ.get("SETTINGS"):
         settings = [(t.split(":")[0], dict(kv.split("=") for kv in t.split(":")[1].split(",") if kv)) for t in os.environ["SETTINGS"].split(";")]
     rows = {}
