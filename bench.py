@@ -576,7 +576,7 @@ def main():
                            "detections_last_frame": 0 if not rp or rp[-1][1] is None else int(rp[-1][1].shape[0]),
                            "input": f"{N} raw 64-beam sweeps per frame (coalign_amd.synthetic.make_point_cloud) in pinned host memory, "
                                     f"{POOL} distinct frames in rotation; per frame: async copy of {N} x {slot} point slots, coalign_voxelize (4 launches), "
-                                    "coalign_pillar_encode_stream with the pillar count on the device, then the same path as `value`"}
+                                    "coalign_pillar_encode_sparse with the pillar count on the device (capacity-sized arrays), then the same path as `value`"}
             fp.close()
             if not args.no_latency:
                 fp1 = FramePipeline(model_p, pp_p, anchors, lanes=1, result_lag=0, graph=use_graph, device=dev, preprocessor=pre, points_per_cloud=slot)

@@ -30,7 +30,7 @@ typedef __attribute__((address_space(3))) void *lptr_sp_t;
 
 constexpr int kWaves = 4;                   // wavefronts per workgroup
 constexpr int kRunPairs = 32;               // pillar pairs per wavefront at most (one lane per pillar in the prologue)
-constexpr int kRound = 3;                   // pairs per LDS-DMA round (3 KB per buffer: 8 KB of LDS per wavefront, five workgroups per CU)
+constexpr int kRound = 3;                   // pairs per LDS-DMA round (3 KB per buffer: 8 KB of LDS per wavefront, 32 KB per workgroup; the grid puts three workgroups on a CU)
 #ifdef COALIGN_LAB
 constexpr bool kLab = true;
 #else
@@ -244,8 +244,11 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
     if (kLab && (a.debug & 512)) { ts[0] = (long long)__builtin_amdgcn_s_memtime(); ts[7] = (long long)wall_clock64(); }
     const unsigned tag = (unsigned)a.state[0] + 1u;                  // this frame's tag (state[0] is written only when the last workgroup has finished)
     const int npairs = (a.M + 1) / 2;
-    // even shares (+-1 pair): with a grid that is a whole number of workgroups per CU every SIMD gets the same work
-    const int p0 = (int)((long long)gwave * npairs / nwave), p1 = (int)((long long)(gwave + 1) * npairs / nwave);
+    // even shares (+-1 pair): with a grid that is a whole number of workgroups per CU every SIMD gets the same work.  The grid is sized for the CAPACITY of the
+    // arrays; when the device-side count is far below it (the voxeliser's route: room for 5 x 70 000 pillars, ~36 000 present) only as many wavefronts as give
+    // each about 2 * kRound pairs take part -- a wavefront's prologue is not worth one or two pairs
+    const int active = max(1, min(nwave, (npairs + 2 * kRound - 1) / (2 * kRound)));
+    const int p0 = gwave < active ? (int)((long long)gwave * npairs / active) : 0, p1 = gwave < active ? (int)((long long)(gwave + 1) * npairs / active) : 0;
     if (p0 < p1) {
         const int ncell = a.ny * a.nx;
         const char *pts_b = reinterpret_cast<const char *>(a.pts);
