@@ -124,7 +124,7 @@ def pillar_bytes_sparse(M):
     return M * (532 + 256 + 16)
 
 
-def size_sweep(dev, steps=20):
+def size_sweep(dev, steps=20, streams=None):
     """VERDICT r03 item 3 / SURVEY 8d: the HBM-bound ops where the roofline bites.  Pillar op at M in {8000, 32000, 70000} pillars per agent
     (max_voxel_train / max_voxel_test of pointpillar_coalign.yaml:52-54) x 5 agents, at N = 2 (cfg 2) and at DAIR-V2X geometry 504 x 200 (cfg 4);
     the fusion launch per geometry / agent count; whole-path frames/s for cfg 2 and cfg 4.  Times: HIP events around graph replays of the op's
@@ -172,7 +172,7 @@ def size_sweep(dev, steps=20):
                 import copy
                 mc = copy.deepcopy(mdl)
                 calibrate_heads_(mc, pool[0], pp.params["target_args"]["score_threshold"], 600)
-                pipe = FramePipeline(mc, pp, anchors, lanes=3, result_lag=1, graph=True, device=dev)
+                pipe = FramePipeline(mc, pp, anchors, lanes=3, result_lag=1, graph=True, device=dev, streams=streams if streams is not None and len(streams) >= 3 else None)
                 for i in range(8):
                     pipe.submit(pool[i % 4])
                 pipe.drain(); torch.cuda.synchronize()
@@ -363,9 +363,12 @@ def main():
         step_batches = frames
     torch.backends.cudnn.benchmark = not args.no_miopen_find     # MIOpen find during warm-up for whatever still runs on it
 
+    # every pipeline of this process runs on the SAME lane streams (FramePipeline(streams=...)): streams share a handful of hardware queues
+    lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
+
     def make_pipe(graph):
         return FramePipeline(model, pp, anchors, lanes=n_lanes, result_lag=args.result_lag, graph=graph, device=dev,
-                             exchange=exchanges)
+                             exchange=exchanges, streams=lane_streams)
 
     def sync():
         if world > 1:
@@ -540,9 +543,10 @@ def main():
     if world == 1 and not args.no_latency:
         latency = {"default_pipeline": dict(latency_stats(lat_default), frames_in_flight=n_lanes, result_lag_frames=pipe.result_lag)}
         try:
-            p1 = FramePipeline(model, pp, anchors, lanes=1, result_lag=0, graph=use_graph, device=dev)
+            p1 = FramePipeline(model, pp, anchors, lanes=1, result_lag=0, graph=use_graph, device=dev, streams=lane_streams)
             d1, _, _ = timed_run(p1, args.steps, max(4, args.warmup))
             latency["one_frame_in_flight"] = dict(latency_stats(p1.latencies_ms), frames_per_s=round(args.steps / d1, 3))
+            p1.close()               # (gives the model's encoder flags back and drops the lane's captured graphs: the sections below start from the same state)
             del p1
         except Exception as e:      # noqa: BLE001
             latency["error"] = f"{type(e).__name__}: {str(e)[:200]}"
@@ -568,7 +572,7 @@ def main():
             slot = 1 << (max(max(len(c) for c in f["clouds"]) for f in pframes) - 1).bit_length()
             pp_p = build_postprocessor(hypes["postprocess"], False)
             fp = FramePipeline(model_p, pp_p, anchors, lanes=n_lanes, result_lag=args.result_lag, graph=use_graph, device=dev, preprocessor=pre,
-                               points_per_cloud=slot)
+                               points_per_cloud=slot, streams=lane_streams)
             dp, tip, rp = timed_run(fp, args.steps, warm, batches=pframes, points=True)
             from_points = {"value": round(args.steps / dp, 3), "unit": "frames/s", "ms_per_step": round(dp / args.steps * 1e3, 4),
                            "host_enqueue_ms_per_step": round(tip / args.steps * 1e3, 4), "latency_ms": latency_stats(fp.latencies_ms),
@@ -579,7 +583,8 @@ def main():
                                     "coalign_pillar_encode_sparse with the pillar count on the device (capacity-sized arrays), then the same path as `value`"}
             fp.close()
             if not args.no_latency:
-                fp1 = FramePipeline(model_p, pp_p, anchors, lanes=1, result_lag=0, graph=use_graph, device=dev, preprocessor=pre, points_per_cloud=slot)
+                fp1 = FramePipeline(model_p, pp_p, anchors, lanes=1, result_lag=0, graph=use_graph, device=dev, preprocessor=pre, points_per_cloud=slot,
+                                    streams=lane_streams)
                 d1, _, _ = timed_run(fp1, args.steps, max(4, args.warmup), batches=pframes, points=True)
                 from_points["one_frame_in_flight"] = dict(latency_stats(fp1.latencies_ms), frames_per_s=round(args.steps / d1, 3))
                 fp1.close()
@@ -775,7 +780,7 @@ def main():
             pipe.close()
             del pipe
             torch.cuda.empty_cache()
-            result["size_sweep"] = size_sweep(dev)
+            result["size_sweep"] = size_sweep(dev, streams=lane_streams)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(hypes, model, frames_cpu, anchors, args.cpu_frames, args.cpu_threads, args.cpu_budget_s)
         print(json.dumps(result), flush=True)

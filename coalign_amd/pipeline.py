@@ -82,17 +82,14 @@ class FramePipeline:
     def __init__(self, model, post_processor: VoxelPostprocessor, anchor_box, *, lanes: int = 4, result_lag: int = 1,
                  graph: bool = False, device=None, transformation_matrix: Optional[torch.Tensor] = None,
                  exchange: Optional[Sequence[Callable]] = None, preprocessor=None, points_per_cloud: int = 131072,
-                 ego_filter: bool = True, filter_range: Optional[Sequence[float]] = None, pillar_buckets: bool = True):
+                 ego_filter: bool = True, filter_range: Optional[Sequence[float]] = None, pillar_buckets: bool = True,
+                 streams: Optional[Sequence[torch.cuda.Stream]] = None):
         self.model = model
         self.pillar_buckets = bool(pillar_buckets)               # ragged from-pillars frames share a capacity-sized graph (see _bucket_seen below)
         self._sig_tensors: Optional[list] = None                 # cached parameter / buffer list of _weights_signature
         self._sig_age = 0
         if hasattr(model, "register_load_state_dict_post_hook"):
             model.register_load_state_dict_post_hook(lambda *_: setattr(self, "_sig_tensors", None))
-        self._vfe_flag = None
-        if hasattr(model, "pillar_vfe"):
-            self._vfe_flag = model.pillar_vfe.persistent_canvas
-            model.pillar_vfe.persistent_canvas = True        # every lane runs its backbone before it encodes its next frame (close() restores)
         self.pp = post_processor
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
         if self.device.type != "cuda":
@@ -109,8 +106,22 @@ class FramePipeline:
         a = anchor_box if torch.is_tensor(anchor_box) else torch.from_numpy(np.asarray(anchor_box))
         T = torch.eye(4) if transformation_matrix is None else torch.as_tensor(transformation_matrix)
         self.meta = {"ego": {"transformation_matrix": T.to(device=self.device, dtype=torch.float32), "anchor_box": a}}
-        with torch.cuda.device(self.device):
-            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_lanes)]
+        # One HIP stream per lane.  ``streams``: lane streams to REUSE (>= lanes of them) -- a process that builds several pipelines one after the other
+        # (the bench's sections, a service swapping models) should hand the same streams to each: the runtime maps streams onto a small number of
+        # hardware queues (four by default), and lanes of a new pipeline that land on a queue an older pipeline's idle stream still owns, or on each
+        # other's, serialise (measured: the same from-points loop 441 vs 493 frames/s depending on how many streams earlier sections had left behind).
+        if streams is not None:
+            if len(streams) < self.n_lanes:
+                raise ValueError(f"{self.n_lanes} lanes need {self.n_lanes} streams, got {len(streams)}")
+            self.streams = list(streams[: self.n_lanes])
+        else:
+            with torch.cuda.device(self.device):
+                self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_lanes)]
+        # (only now, with every argument validated, is the model touched)
+        self._vfe_flag = None
+        if hasattr(model, "pillar_vfe"):
+            self._vfe_flag = model.pillar_vfe.persistent_canvas
+            model.pillar_vfe.persistent_canvas = True        # every lane runs its backbone before it encodes its next frame (close() restores)
         self.pp.buffer_sets = max(int(getattr(self.pp, "buffer_sets", 2)), self.result_lag + 2)
         self._slots: List[Dict[tuple, _GraphSlot]] = [dict() for _ in range(self.n_lanes)]
         self.max_graphs_per_lane = 4                              # distinct input shapes kept captured per lane (oldest evicted)
