@@ -55,13 +55,13 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 struct Taps {
-    const float4 *p00, *p01, *p10, *p11;   // this lane's low channel group at the four (clamped) taps
+    int o00, o01, o10, o11;                // element offsets of the four (clamped) taps inside the agent's plane (channel 0 of the pixel)
     float w00, w01, w10, w11;              // masked bilinear weights (zero padding)
 };
 
 // grid_sample geometry of output pixel (ox, oy) in agent n's plane, reference arithmetic (identical to warp_fuse.hip):
 // F.affine_grid on a float64 theta -> .to(float32) -> (g + 1) * (size / 2) - 0.5 -> floor / floor + 1 taps, masked weights
-__device__ __forceinline__ Taps make_taps(const ScaleArgs &a, const double *theta, int n, int row, int ox, int oy, int c_lo) {
+__device__ __forceinline__ Taps make_taps(const ScaleArgs &a, const double *theta, int n, int ox, int oy) {
     const double xn = (2.0 * ox + 1.0) / a.Wo - 1.0;
     const double yn = (2.0 * oy + 1.0) / a.Ho - 1.0;
     const double *th = theta + n * 6;
@@ -84,17 +84,50 @@ __device__ __forceinline__ Taps make_taps(const ScaleArgs &a, const double *thet
     }
     const int xc0 = min(max(x0, 0), a.W - 1), xc1 = min(max(x0 + 1, 0), a.W - 1);
     const int yc0 = min(max(y0, 0), a.H - 1), yc1 = min(max(y0 + 1, 0), a.H - 1);
-    const float *base = a.x + (size_t)row * a.H * a.W * a.C + c_lo;
-    t.p00 = reinterpret_cast<const float4 *>(base + ((size_t)yc0 * a.W + xc0) * a.C);
-    t.p01 = reinterpret_cast<const float4 *>(base + ((size_t)yc0 * a.W + xc1) * a.C);
-    t.p10 = reinterpret_cast<const float4 *>(base + ((size_t)yc1 * a.W + xc0) * a.C);
-    t.p11 = reinterpret_cast<const float4 *>(base + ((size_t)yc1 * a.W + xc1) * a.C);
+    t.o00 = (yc0 * a.W + xc0) * a.C;       // (C * H * W <= INT32_MAX is checked by the entry point)
+    t.o01 = (yc0 * a.W + xc1) * a.C;
+    t.o10 = (yc1 * a.W + xc0) * a.C;
+    t.o11 = (yc1 * a.W + xc1) * a.C;
     return t;
 }
 
-__device__ __forceinline__ void issue(const Taps &t, int hi4, float4 (&v)[8]) {   // hi4 = C / 8: float4 index of the high channel group
-    v[0] = t.p00[0]; v[1] = t.p01[0]; v[2] = t.p10[0]; v[3] = t.p11[0];
-    v[4] = t.p00[hi4]; v[5] = t.p01[hi4]; v[6] = t.p10[hi4]; v[7] = t.p11[hi4];
+// Round 4: the LPP >= 8 lanes of a pixel used to compute the SAME taps for every agent (float64 grid + clamps: ~60 VALU instructions per agent and lane, a
+// third of the kernel's instructions, and the kernel is half issue-bound).  Now lane li of a pixel computes the taps of agent li once (N <= 8 <= LPP), and
+// agent n's taps reach the pixel's other lanes through the LDS crossbar: ds_swizzle in bit-mask mode, new lane = (lane & ~(LPP - 1)) | n inside each half.
+template <int LPP, int N>
+__device__ __forceinline__ int from_lane(int v) {
+    return __builtin_amdgcn_ds_swizzle(v, ((~(LPP - 1)) & 0x1f) | (N << 5));
+}
+template <int LPP>
+__device__ __forceinline__ int from_lane_n(int v, int n) {          // n is a constant after unrolling: the switch folds
+    switch (n) {
+        case 0: return from_lane<LPP, 0>(v);
+        case 1: return from_lane<LPP, 1>(v);
+        case 2: return from_lane<LPP, 2>(v);
+        case 3: return from_lane<LPP, 3>(v);
+        case 4: return from_lane<LPP, 4>(v);
+        case 5: return from_lane<LPP, 5>(v);
+        case 6: return from_lane<LPP, 6>(v);
+        default: return from_lane<LPP, 7>(v);
+    }
+}
+template <int LPP>
+__device__ __forceinline__ Taps taps_of_agent(const Taps &mine, int n) {
+    Taps t;
+    t.o00 = from_lane_n<LPP>(mine.o00, n); t.o01 = from_lane_n<LPP>(mine.o01, n); t.o10 = from_lane_n<LPP>(mine.o10, n); t.o11 = from_lane_n<LPP>(mine.o11, n);
+    t.w00 = __builtin_bit_cast(float, from_lane_n<LPP>(__builtin_bit_cast(int, mine.w00), n));
+    t.w01 = __builtin_bit_cast(float, from_lane_n<LPP>(__builtin_bit_cast(int, mine.w01), n));
+    t.w10 = __builtin_bit_cast(float, from_lane_n<LPP>(__builtin_bit_cast(int, mine.w10), n));
+    t.w11 = __builtin_bit_cast(float, from_lane_n<LPP>(__builtin_bit_cast(int, mine.w11), n));
+    return t;
+}
+
+// base: channel c_lo of pixel (0, 0) of the agent's plane (wave-uniform pointer + this lane's channel slice); hi4 = C / 8: float4 index of the high channel group
+__device__ __forceinline__ void issue(const Taps &t, const float *base, int hi4, float4 (&v)[8]) {
+    const float4 *p00 = reinterpret_cast<const float4 *>(base + t.o00), *p01 = reinterpret_cast<const float4 *>(base + t.o01);
+    const float4 *p10 = reinterpret_cast<const float4 *>(base + t.o10), *p11 = reinterpret_cast<const float4 *>(base + t.o11);
+    v[0] = p00[0]; v[1] = p01[0]; v[2] = p10[0]; v[3] = p11[0];
+    v[4] = p00[hi4]; v[5] = p01[hi4]; v[6] = p10[hi4]; v[7] = p11[hi4];
 }
 
 __device__ __forceinline__ void blend(const Taps &t, const float4 (&v)[8], float (&X)[8]) {
@@ -118,15 +151,17 @@ __device__ __forceinline__ void fuse_tile(const FuseArgs &f, const ScaleArgs &a,
         const bool pix_ok = ox_raw < a.Wo;
         const int ox = pix_ok ? ox_raw : a.Wo - 1;
         float X[NA][8];
-        Taps cur = make_taps(a, f.theta, 0, f.rows[0], ox, oy, c_lo), nxt;
+        const size_t plane = (size_t)a.H * a.W * a.C;
+        const Taps mine = make_taps(a, f.theta, min(li, f.n - 1), ox, oy);           // lane li of the pixel: agent li's taps
+        Taps cur = taps_of_agent<LPP>(mine, 0), nxt;
         float4 vc[8], vn[8];
-        issue(cur, hi4, vc);
+        issue(cur, a.x + f.rows[0] * plane + c_lo, hi4, vc);
 #pragma unroll
         for (int n = 0; n < NA; ++n) {
             if (n < f.n) {
                 if (n + 1 < NA && n + 1 < f.n) {   // the next agent's taps are in flight while this one is blended
-                    nxt = make_taps(a, f.theta, n + 1, f.rows[(n + 1) % 8], ox, oy, c_lo);
-                    issue(nxt, hi4, vn);
+                    nxt = taps_of_agent<LPP>(mine, n + 1);
+                    issue(nxt, a.x + f.rows[(n + 1) % 8] * plane + c_lo, hi4, vn);
                 }
                 blend(cur, vc, X[n]);
                 if (n + 1 < NA && n + 1 < f.n) {
