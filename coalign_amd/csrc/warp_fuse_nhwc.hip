@@ -28,7 +28,7 @@ struct ScaleArgs {
     const float *x;       // [n, H, W, C] of this frame
     float *out;           // ATT / MAX: [Ho, Wo, C]; NONE: [n, Ho, Wo, C]
     int C, H, W, Ho, Wo, tiles_x, ntiles, first_block, n_blocks;   // n_blocks = ntiles rounded up to a multiple of 8 (XCD remap)
-    float sqrt_dim;
+    float sqrt_dim, inv_sqrt_dim;   // inv_sqrt_dim is used only where sqrt_dim is a power of two (C = 64, 256)
 };
 
 struct FuseArgs {
@@ -183,7 +183,9 @@ __device__ __forceinline__ void fuse_tile(const FuseArgs &f, const ScaleArgs &a,
                 float p = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) p = fmaf(X[0][j], X[n][j], p);
-                s[n] = group_sum<LPP>(p) / a.sqrt_dim;           // score / np.sqrt(C)   (att_fuse.py:44)
+                // score / np.sqrt(C) (att_fuse.py:44).  C = 64 and C = 256: sqrt(C) is a power of two, the division is exact and equals the product with
+                // 1 / sqrt(C) bit for bit (one instruction instead of the ten of a correctly rounded division); C = 128: the division
+                s[n] = (LPP == 16) ? group_sum<LPP>(p) / a.sqrt_dim : group_sum<LPP>(p) * a.inv_sqrt_dim;
                 if (n < f.n) smax = fmaxf(smax, s[n]);
             }
             float den = 0.f;
@@ -292,6 +294,7 @@ extern "C" int coalign_warp_fuse_nhwc(int n_scales, const float *const *x, const
         a.n_blocks = (a.ntiles + 7) / 8 * 8;
         a.first_block = next_block;
         a.sqrt_dim = (float)sqrt((double)C[i]);
+        a.inv_sqrt_dim = 1.0f / a.sqrt_dim;
         next_block += a.n_blocks;
     }
     for (int k = n_scales; k < kMaxScales; ++k) f.s[k] = f.s[0];
