@@ -59,6 +59,29 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- sp16, the "split pair": an fp32 value on the fp16 matrix cores (round 5; csrc/conv3x3_emu.hip, csrc/conv3x3_sp.hip) ------------------------------
+// x~ = x rounded to 22 significant bits (ties away from zero) = h + 2^-10 l, where h = the leading 11 bits of x~ as an fp16 number (an exact truncation) and
+// l = (x~ - h) * 2^10 = the following 11 bits, scaled by 2^10 so that they are a NORMAL fp16 number whenever |x| >= 2^-14 (unscaled, x - h is subnormal below
+// |x| = 2^-3 and what it keeps shrinks to an absolute 2^-25: round 4's precision hole).  Exact for 2^-14 <= |x| <= 65504; smaller values keep an absolute
+// 2^-34; larger ones clamp (h and l saturate at 65504: x~ <= 65504 + 63.97) -- finite, and reported by the producing kernels' range word where they have one.
+// A pair is canonical: splitting x~ again returns the same (h, l), so a kernel that splits fp32 inputs itself and a kernel that reads stored pairs see the
+// same operands bit for bit.  In a product sum_k w_k x_k the terms w_h x_h go to one fp32 accumulator, w_h x_l + w_l x_h (both carrying 2^10) to a second one
+// that enters with 2^-10 at the end; w_l x_l (< 2^-20 |w x|, zero mean: the weights' h is rounded to nearest on the host) is dropped.
+constexpr float kSp16LowScale = 1024.f, kSp16LowInv = 1.f / 1024.f;
+
+__device__ __forceinline__ float sp16_round(float x) { return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, x) + 2u) & ~3u); }
+
+// two values -> (h0 | h1 << 16, l0 | l1 << 16), the operand order of the 16-bit matrix instructions
+__device__ __forceinline__ void sp16_split2(float a, float b, unsigned &hi, unsigned &lo) {
+    const float ar = sp16_round(a), br = sp16_round(b);
+    const auto h = __builtin_amdgcn_cvt_pkrtz(ar, br);
+    const auto l = __builtin_amdgcn_cvt_pkrtz((ar - (float)h[0]) * kSp16LowScale, (br - (float)h[1]) * kSp16LowScale);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+__device__ __forceinline__ float sp16_join(_Float16 h, _Float16 l) { return fmaf((float)l, kSp16LowInv, (float)h); }      // exact
+
 // Workspace / flag clearing as a KERNEL instead of hipMemsetAsync.  Under HIP-graph replay (ROCm 7.2) a memset node followed by a kernel
 // that polls or accumulates into the cleared words was observed to race from an idle GPU (wrong stream-K hand-overs in the first replays
 // after a device synchronise, tools/diag_graph.py); a kernel node is ordered like every other kernel of the capture.

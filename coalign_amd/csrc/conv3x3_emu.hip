@@ -63,6 +63,9 @@ struct EmuArgs {
     // (stamp & 0xffffffff) of x if stamps[(n * Hin + y) * Win + x] >> 32 equals *tag_ptr, else zero.  Channels-last input layouts only.
     const unsigned long long *__restrict__ stamps;
     const int *__restrict__ tag_ptr;
+    // round 5, fp16 split only: the per-output-channel power-of-two scale the weight image was multiplied with before it was split (its tail:
+    // [Cout] 2^-k_c, then [Cout] 2^k_c).  bias + residual enter the accumulator times 2^k_c, the tile leaves it times 2^-k_c: both exact.
+    const float *__restrict__ wscale;
 #ifdef EMU_TRACE
     long long *trace;                 // profiling aid (tools/trace_conv_emu.py): [2 workgroups][waves][64 chunks][8 stamps]
     int ablate;                       // 1: no weight DMA, 2: no halo-pixel loads, 4: no matrix steps (wrong results; what each part costs)
@@ -125,19 +128,14 @@ struct Tile {
 template <int TERMS, bool F16 = false>
 __device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[TERMS]) {
     if constexpr (F16) {
-        // fp16 terms, round toward zero (v_cvt_pkrtz_f16_f32, two values per instruction): a finite input never becomes infinite (|x| above 65504 saturates
-        // term 0 and continues in term 1, up to 131008), the residual x - x_h is exact, and truncating it keeps 11 more bits: |x - x_h - x_l| < 2^-21 |x|
-        // (plus 2^-25 absolute where x_l falls into fp16's subnormal range, |x| < 2^-3).
+        // The "split pair" of common.h (sp16): the operand rounded to 22 significant bits, x~ = x_h + 2^-10 x_l', x_h = the leading 11 bits as an fp16 number
+        // (exact truncation), x_l' = (x~ - x_h) * 2^10 -- the next 11 bits, SCALED into fp16's normal range so that they survive for every |x| >= 2^-14
+        // (unscaled, x - x_h is an fp16 subnormal for |x| < 2^-3 and the split degrades to an absolute 2^-25: round 4's hole).  Products with an x_l' or
+        // w_l' factor are summed in their own accumulator and enter with 2^-10 at the end of the tile (see the kernel).
         static_assert(TERMS == 2, "fp16 split: two terms");
         unsigned hi[4], lo[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const auto h = __builtin_amdgcn_cvt_pkrtz(v[2 * i], v[2 * i + 1]);
-            const float r0 = v[2 * i] - (float)h[0], r1 = v[2 * i + 1] - (float)h[1];
-            const auto l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-            hi[i] = __builtin_bit_cast(unsigned, h);
-            lo[i] = __builtin_bit_cast(unsigned, l);
-        }
+        for (int i = 0; i < 4; ++i) coalign::sp16_split2(v[2 * i], v[2 * i + 1], hi[i], lo[i]);
         out[0] = __builtin_bit_cast(bf16x8, uint4{hi[0], hi[1], hi[2], hi[3]});
         out[1] = __builtin_bit_cast(bf16x8, uint4{lo[0], lo[1], lo[2], lo[3]});
         return;
@@ -169,6 +167,7 @@ __global__ __launch_bounds__(64 * ((NPB >= 4 && !(VAR & VAR_NCO1)) ? NPB : 2 * N
 __attribute__((amdgpu_waves_per_eu(SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 1, SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 8)))
 void conv3x3_emu_kernel(const EmuArgs a) {
     constexpr bool TAPK = (VAR & VAR_TAPK) != 0, STACK = (VAR & VAR_STACK) != 0, F16 = (VAR & VAR_F16) != 0;
+    constexpr bool DUAL = F16;          // sp16 operands (common.h): a second accumulator for the products that carry 2^10, per-channel weight scale
     using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, TAPK, (VAR >> 2) & 7>;
     static_assert(!(SPLIT && (STRIDE != 1 || LAYOUT != LAYOUT_NCHW || STACK)), "stream-K hand-over only for the plain stride-1 NCHW variant");
     extern __shared__ __attribute__((aligned(1024))) float lds[];
@@ -395,10 +394,13 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         // (a lane without an output pixel reads the residual of pixel 0 of image 0: a block of several rows may end past the last image)
         const size_t obase = ((size_t)(live ? out_n : 0) * a.Cout + cur.cg * kCoutTile + cb + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
         const float *bias = a.bias + cur.cg * kCoutTile + cb + 4 * half;
+        const float *winv = DUAL ? a.wscale + cur.cg * kCoutTile + cb + 4 * half : nullptr, *wsc = DUAL ? winv + a.Cout : nullptr;
         // a wavefront whose output rows lie below the map (the last row tile: 108 rows for 100, 56 for 50, 32 for 25) still stages pixels,
         // issues weight transfers and meets the barriers, but runs no matrix steps: its share of the padded work costs no energy
         const bool wave_live = __builtin_amdgcn_readfirstlane((int)(cur.y0 + blk_y * BH < (STACK ? a.N * a.H : a.H) && cur.x0 + blk_x * BW < a.W)) != 0;
-        floatx16 acc[G::NCO];
+        floatx16 acc[G::NCO], accl[DUAL ? G::NCO : 1];
+#pragma unroll
+        for (int q = 0; q < (DUAL ? G::NCO : 1); ++q) accl[q] = floatx16{0};
         if ((SPLIT && !head) || !wave_live) {
 #pragma unroll
             for (int q = 0; q < G::NCO; ++q) acc[q] = floatx16{0};
@@ -407,10 +409,14 @@ void conv3x3_emu_kernel(const EmuArgs a) {
             for (int q = 0; q < 16 * G::NCO; ++q) {
                 const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
                 acc[q / 16][q % 16] = a.residual[obase + (size_t)c * plane] + bias[c];
+                if constexpr (DUAL) acc[q / 16][q % 16] *= wsc[c];
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 16 * G::NCO; ++q) acc[q / 16][q % 16] = bias[(q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4)];
+            for (int q = 0; q < 16 * G::NCO; ++q) {
+                const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
+                acc[q / 16][q % 16] = DUAL ? bias[c] * wsc[c] : bias[c];
+            }
         }
         Tile next = cur;
         Plan nplan = plan;
@@ -479,7 +485,10 @@ void conv3x3_emu_kernel(const EmuArgs a) {
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
-                    for (int q = 0; q < G::NCO; ++q) acc[q] = mfma16<F16>(wc[q][wi[i]], bc[bi[i]], acc[q]);
+                    for (int q = 0; q < G::NCO; ++q) {
+                        if (DUAL && i < 2) accl[q] = mfma16<F16>(wc[q][wi[i]], bc[bi[i]], accl[q]);       // w_h x_l', w_l' x_h: both carry 2^10
+                        else acc[q] = mfma16<F16>(wc[q][wi[i]], bc[bi[i]], acc[q]);
+                    }
                 if (st + 1 < NS) {
 #pragma unroll
                     for (int t = 0; t < TERMS; ++t) {
@@ -512,6 +521,10 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         // bit-equality every time); the same argument and test cover conv3x3.hip.
         // slot layout [wave][q][lane]: one base pointer per 16 values + immediate offsets (q x 256 B), so the 32 addresses cost
         // four registers, not sixty-four
+        if constexpr (DUAL) {
+#pragma unroll
+            for (int q = 0; q < 16 * G::NCO; ++q) acc[q / 16][q % 16] = fmaf(accl[q / 16][q % 16], coalign::kSp16LowInv, acc[q / 16][q % 16]);
+        }
         if (SPLIT && !head) {              // contributor: publish the partial sums of the tile's last chunks (slot g)
             float *slot = a.partial + (size_t)g * (16 * G::NCO * G::THREADS) + (size_t)wave * (16 * G::NCO * 64) + lane;
 #pragma unroll
@@ -537,6 +550,10 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                     for (int r = 0; r < 4 * G::NCO; ++r) {
                         float4 o;
                         o.x = acc[r / 4][4 * (r % 4)]; o.y = acc[r / 4][4 * (r % 4) + 1]; o.z = acc[r / 4][4 * (r % 4) + 2]; o.w = acc[r / 4][4 * (r % 4) + 3];
+                        if constexpr (DUAL) {
+                            const float *wi4 = winv + (r / 4) * 32 + 8 * (r % 4);
+                            o.x *= wi4[0]; o.y *= wi4[1]; o.z *= wi4[2]; o.w *= wi4[3];
+                        }
                         if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
                         *reinterpret_cast<float4 *>(yp + (r / 4) * 32 + 8 * (r % 4)) = o;
                     }
@@ -544,7 +561,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
 #pragma unroll
                     for (int q = 0; q < 16 * G::NCO; ++q) {
                         const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
-                        const float v = acc[q / 16][q % 16];
+                        const float v = DUAL ? acc[q / 16][q % 16] * winv[c] : acc[q / 16][q % 16];
                         a.y[obase + (size_t)c * plane] = a.relu ? fmaxf(v, 0.f) : v;
                     }
                 }
@@ -852,15 +869,23 @@ extern "C" void coalign_conv3x3_emu_set_ablate(int v) { g_emu_ablate = v; }
 
 extern "C" size_t coalign_conv3x3_emu_weight_bytes(int Cin, int Cout, int terms) {
     if (Cin < 1 || Cout < 1 || Cin % kKC || Cout % kCoutTile || (terms != 2 && terms != 3 && terms != 16)) return 0;
-    if (terms == 16) terms = 2;           // fp16 2-way split: two 16-bit terms
-    return (size_t)(Cout / kCoutTile) * (Cin / kKC) * kSteps * terms * 2 * kCoutTile * 16 + 16;      // + one zero group
+    const size_t tail = terms == 16 ? (size_t)Cout * 8 : 0;      // fp16 split: + [Cout] 2^-k_c + [Cout] 2^k_c (float), the per-channel weight scale
+    if (terms == 16) terms = 2;           // two 16-bit terms
+    return (size_t)(Cout / kCoutTile) * (Cin / kKC) * kSteps * terms * 2 * kCoutTile * 16 + 16 + tail;      // + one zero group
 }
 
 extern "C" size_t coalign_conv3x3_emu_weight_bytes_ex(int Cin, int Cout, int terms, int tap_major) {
     if (!tap_major) return coalign_conv3x3_emu_weight_bytes(Cin, Cout, terms);
     if (Cin < 1 || Cout < 1 || Cin % (2 * kKC) || Cout % kCoutTile || (terms != 2 && terms != 3 && terms != 16)) return 0;
+    const size_t tail = terms == 16 ? (size_t)Cout * 8 : 0;
     if (terms == 16) terms = 2;
-    return (size_t)(Cout / kCoutTile) * (Cin / (2 * kKC)) * 9 * terms * 2 * kCoutTile * 16 + 16;
+    return (size_t)(Cout / kCoutTile) * (Cin / (2 * kKC)) * 9 * terms * 2 * kCoutTile * 16 + 16 + tail;
+}
+
+// where the fp16 image's scale tail starts (nullptr for the bf16 splits, which are scale-free)
+static const float *emu_wscale(const void *w_split, int Cin, int Cout, int terms, int tap_major) {
+    if (terms != 16) return nullptr;
+    return reinterpret_cast<const float *>(static_cast<const char *>(w_split) + coalign_conv3x3_emu_weight_bytes_ex(Cin, Cout, 16, tap_major) - (size_t)Cout * 8);
 }
 
 static int check_emu_args(int N, int Cin, int Cout, int H, int W, int terms) {
@@ -929,6 +954,7 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
         if (N == 0) return COALIGN_OK;
         EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, Hin, Win, relu, 0, 0, 0, Hin, Win, nullptr, nullptr};
         a.prio_mode = emu_prio_mode();
+        a.wscale = emu_wscale(w_split, Cin, Cout, terms, 1);
 #ifdef EMU_TRACE
         a.trace = g_emu_trace;
         a.ablate = g_emu_ablate;
@@ -947,6 +973,7 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
     if (N == 0) return COALIGN_OK;
     EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, Hin, Win, nullptr, nullptr};
     a.prio_mode = emu_prio_mode();
+    a.wscale = emu_wscale(w_split, Cin, Cout, terms, 0);
 #ifdef EMU_TRACE
     a.trace = g_emu_trace;
     a.ablate = g_emu_ablate;
@@ -970,6 +997,7 @@ extern "C" int coalign_conv3x3_emu_sparse(const float *feats, const void *stamps
     if (N == 0) return COALIGN_OK;
     EmuArgs a{feats, static_cast<const uint4 *>(w_split), bias, nullptr, y, N, Cin, Cout, H, W, relu, 0, 0, 0, Hin, Win, nullptr, nullptr};
     a.prio_mode = emu_prio_mode();
+    a.wscale = emu_wscale(w_split, Cin, Cout, terms, 0);
     a.stamps = static_cast<const unsigned long long *>(stamps);
     a.tag_ptr = state;
     hipStream_t s = static_cast<hipStream_t>(stream);

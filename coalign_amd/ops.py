@@ -676,7 +676,8 @@ def conv3x3_bias_act(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[tor
 def pack_conv3x3_emu_weight(weight: torch.Tensor, terms: int = 3, tap_major: bool = False) -> torch.Tensor:
     """[Cout, Cin, 3, 3] fp32 -> the split-bf16 LDS image of csrc/conv3x3_emu.hip, as uint8:
     [Cout / 64][Cin / 8][5 steps][terms][2 k-groups][64 cout][8 cin] bf16 (tap = 2 * step + k-group, the tenth tap is zero;
-    term 0 = bf16(w), term 1 = bf16(w - term 0), term 2 = bf16(w - term 0 - term 1)) followed by 16 zero bytes.
+    term 0 = bf16(w), term 1 = bf16(w - term 0), term 2 = bf16(w - term 0 - term 1)) followed by 16 zero bytes; ``terms`` = 16: two fp16 terms of the
+    per-channel scaled weights (below) followed by 16 zero bytes, [Cout] float32 2^-k_c and [Cout] float32 2^k_c.
     ``tap_major`` (Cin % 16 == 0): [Cout / 64][Cin / 16][9 taps][terms][2 channel halves][64 cout][8 cin] -- one matrix
     instruction = the 16 channels of one tap, no zero tap (COALIGN_LAYOUT_W_TAPMAJOR)."""
     co, ci, kh, kw = weight.shape
@@ -689,15 +690,31 @@ def pack_conv3x3_emu_weight(weight: torch.Tensor, terms: int = 3, tap_major: boo
         w = weight.detach().float().reshape(co // 64, 64, ci // CONV_KC, CONV_KC, 9)
         w = torch.cat([w, torch.zeros_like(w[..., :1])], dim=-1).reshape(co // 64, 64, ci // CONV_KC, CONV_KC, 5, 2)
         w = w.permute(0, 2, 4, 5, 1, 3)                                    # [g, chunk, step, k-group, cout, cin]
-    parts, rest = [], w
-    half = terms == 16                                                     # terms = 16: the 2-way split with FP16 terms (w_h = fp16(w), w_l = fp16(w - w_h))
-    for _ in range(2 if half else terms):
-        t = rest.half() if half else rest.bfloat16()
-        parts.append(t)
-        rest = rest - t.float()
+    tail = []
+    if terms == 16:
+        # fp16 split = sp16 pairs (csrc/common.h).  Every output channel is first multiplied by the power of two 2^k_c that puts its largest weight into
+        # [2^13, 2^14) (exact), so that both terms are normal fp16 numbers whatever the channel's scale (BatchNorm-folded weights are mostly below 2^-3, where
+        # an unscaled second term is an fp16 subnormal); the kernel multiplies bias + residual by 2^k_c and the finished tile by 2^-k_c (both exact).
+        # w~ = w 2^k_c rounded to 22 significant bits; term 0 = fp16(w~) to nearest, term 1 = (w~ - term 0) * 2^10, exact.
+        amax = weight.detach().float().abs().reshape(co, -1).amax(dim=1)
+        k = torch.where(amax > 0, 14 - torch.frexp(amax)[1], torch.zeros_like(amax, dtype=torch.int32)).clamp(-60, 60).to(torch.int32)
+        scale = torch.ldexp(torch.ones_like(amax), k)
+        cshape = (co // 64, 1, 1, 1, 64, 1)                                # the output channel sits on axis 4 of both images
+        ws = (w * scale.reshape(cshape)).contiguous()
+        ws = ((ws.view(torch.int32) + 2) & -4).view(torch.float32)         # 22 significant bits, ties away from zero (sp16_round)
+        hi = ws.half()
+        lo = ((ws - hi.float()) * 1024.0).half()
+        parts = [hi, lo]
+        tail = [torch.ldexp(torch.ones_like(amax), -k).contiguous().view(torch.uint8).reshape(-1), scale.contiguous().view(torch.uint8).reshape(-1)]
+    else:
+        parts, rest = [], w
+        for _ in range(terms):
+            t = rest.bfloat16()
+            parts.append(t)
+            rest = rest - t.float()
     img = torch.stack(parts, dim=3).contiguous()                           # [g, chunk, step, term, k-group, cout, cin]
     flat = img.view(torch.uint8).reshape(-1)
-    out = torch.cat([flat, torch.zeros(16, dtype=torch.uint8, device=flat.device)])
+    out = torch.cat([flat, torch.zeros(16, dtype=torch.uint8, device=flat.device)] + tail)
     assert out.numel() == hip.lib().coalign_conv3x3_emu_weight_bytes_ex(ci, co, terms, int(tap_major))
     return out
 

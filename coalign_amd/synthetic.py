@@ -122,6 +122,116 @@ def fill_parameters_(module: torch.nn.Module, seed: int = 0, cls_bias: float = -
             t.copy_(v.to(t.dtype))
 
 
+def fill_parameters_trained_like_(model: torch.nn.Module, seed: int = 0, cls_bias: float = -2.0, log2_lo: float = -8.0, log2_hi: float = 4.0,
+                                  dead_fraction: float = 0.3, tiny_gamma_fraction: float = 0.05) -> Dict[str, float]:
+    """A second deterministic parameter set that has the statistics of a TRAINED checkpoint where ``fill_parameters_`` has those of an initialisation
+    (what really gets loaded: opencood/tools/train_utils.py:29-74):
+
+    * convolution / deconvolution weights are Student-t (nu = 3, heavy tailed) instead of Gaussian, same variance;
+    * every BatchNorm-folded convolution has its own scale: the map behind BN layer ``l`` lives at 2^c_l, c_l a clipped random walk with steps drawn
+      uniformly from [``log2_lo``, ``log2_hi``] (folded weight scale 2^(c_l - c_(l-1)): 2^-8 ... 2^4 around the initialisation's), the running statistics
+      track the data as they do after training (running_mean ~ 2^c_in, running_var ~ 4^c_in);
+    * ``tiny_gamma_fraction`` of every layer's BN weights are 1e-3 of their neighbours (channels training has switched off by shrinking gamma);
+    * ``dead_fraction`` of the channels carry a BN bias three scales below zero: dead behind the ReLU;
+    * the shrink header's biased convolutions are rescaled the same way.
+
+    The heads are left to ``calibrate_heads_``.  Returns {BN / conv name: log2 scale of the map behind it} (what the tests print)."""
+    from .backbone import BasicBlock, DoubleConv
+    import zlib
+    fill_parameters_(model, seed=seed, cls_bias=cls_bias)
+
+    def gen(name):
+        return torch.Generator().manual_seed((zlib.crc32(("trained:" + name).encode()) + seed) & 0x7FFFFFFF)
+
+    def student_t_(w: torch.Tensor, name: str):
+        g = gen(name)
+        z = torch.randn(w.shape, generator=g)
+        chi = (torch.randn((3,) + tuple(w.shape), generator=g) ** 2).sum(0) / 3.0
+        t = z / chi.sqrt() / 3.0 ** 0.5                                   # Student-t(3), unit variance
+        w.copy_((t * w.float().std()).to(w.dtype))
+
+    names = {m: n for n, m in model.named_modules()}
+    scales: Dict[str, float] = {}
+
+    def step(c_in: float, name: str) -> float:
+        g = gen("step:" + name)
+        t = log2_lo + (log2_hi - log2_lo) * float(torch.rand((), generator=g))
+        return min(max(c_in + t, log2_lo), log2_hi)
+
+    def set_bn(bn, conv_w, c_in: float, c_out: float):
+        name = names[bn]
+        g = gen(name)
+        ch = bn.weight.shape[0]
+        student_t_(conv_w, name + ".conv")
+        bn.running_mean.copy_(torch.randn(ch, generator=g) * 0.1 * 2.0 ** c_in)
+        bn.running_var.copy_((torch.rand(ch, generator=g) + 0.5) * 4.0 ** c_in)
+        gamma = (torch.rand(ch, generator=g) + 0.5) * 2.0 ** c_out
+        tiny = torch.rand(ch, generator=g) < tiny_gamma_fraction
+        gamma = torch.where(tiny, gamma * 1e-3, gamma)
+        beta = torch.randn(ch, generator=g) * 0.1 * 2.0 ** c_out
+        dead = torch.rand(ch, generator=g) < dead_fraction
+        beta = torch.where(dead, -3.0 * gamma.abs() - 0.1 * 2.0 ** c_out, beta)
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+        scales[name] = c_out
+
+    with torch.no_grad():
+        c = 0.0
+        stage_c: List[float] = []
+        last_stage = None
+        for mod in model.modules():
+            if isinstance(mod, BasicBlock):
+                stage = names[mod].rsplit(".", 1)[0]
+                if last_stage is not None and stage != last_stage:
+                    stage_c.append(c)
+                last_stage = stage
+                c1 = step(c, names[mod.bn1])
+                set_bn(mod.bn1, mod.conv1.weight, c, c1)
+                c2 = step(c1, names[mod.bn2])
+                set_bn(mod.bn2, mod.conv2.weight, c1, c2)
+                skip = c
+                if mod.downsample is not None:
+                    skip = step(c, names[mod.downsample[1]])
+                    set_bn(mod.downsample[1], mod.downsample[0].weight, c, skip)
+                c = max(c2, skip)
+        if last_stage is not None:
+            stage_c.append(c)
+        backbone = getattr(model, "backbone", None)
+        if backbone is not None and hasattr(backbone, "blocks"):            # the plain conv-BN-ReLU stacks of BaseBEVBackbone
+            c, stage_c = 0.0, []
+            for blk in backbone.blocks:
+                mods = list(blk)
+                for k, m in enumerate(mods):
+                    if isinstance(m, torch.nn.BatchNorm2d):
+                        c2 = step(c, names[m])
+                        set_bn(m, mods[k - 1].weight, c, c2)
+                        c = c2
+                stage_c.append(c)
+        c_cat = c
+        if backbone is not None and len(getattr(backbone, "deblocks", [])):
+            outs = []
+            for i, blk in enumerate(backbone.deblocks):
+                c_in = stage_c[i] if i < len(stage_c) else c
+                c_out = step(c_in, names[blk[1]])
+                set_bn(blk[1], blk[0].weight, c_in, c_out)
+                outs.append(c_out)
+            c_cat = max(outs)
+        for mod in model.modules():
+            if isinstance(mod, DoubleConv):
+                for conv in (mod.double_conv[0], mod.double_conv[2]):
+                    name = names[conv]
+                    c_out = step(c_cat, name)
+                    student_t_(conv.weight, name)
+                    conv.weight.mul_(2.0 ** (c_out - c_cat))
+                    g = gen(name + ".bias")
+                    b = torch.randn(conv.bias.shape, generator=g) * 0.1 * 2.0 ** c_out
+                    dead = torch.rand(conv.bias.shape, generator=g) < dead_fraction
+                    conv.bias.copy_(torch.where(dead, -3.0 * 2.0 ** c_out * torch.ones_like(b), b))
+                    scales[name] = c_out
+                    c_cat = c_out
+    return scales
+
+
 def calibrate_heads_(model: torch.nn.Module, batch: Dict, score_threshold: float, target: int = 600) -> None:
     """Make a random-init detector's heads behave like a trained one's on ``batch`` ("head biases shifted so K ~ 300-1000
     candidates"): box deltas of std 0.1 (decoded boxes stay car sized and pass the size / z sanity filters, neighbouring anchors
