@@ -86,6 +86,17 @@ CONV_EMU_TAP_MAJOR = os.environ.get("COALIGN_EMU_TAPK", "1") != "0"
 CONV_WINOGRAD = os.environ.get("COALIGN_WINOGRAD", "0") != "0"
 
 
+# Round 5: in the fp16 mode the 3x3 convolutions INSIDE a ResNet stage (and the two of the shrink header) hand each other ``ops.SplitMap``s -- the activations as
+# sp16 pairs in the matrix instruction's operand order, written by the producer's epilogue and read by ``coalign_conv3x3_sp`` with LDS-DMA only (csrc/conv3x3_sp.hip).
+# The strided first convolution of a stage and the shrink header's first convolution (float32 inputs) write the first SplitMap of their chain; the last
+# convolution of a stage writes channels-last float32 for the fusion kernel and the next stage, as before.  "0": the consumer-split kernels everywhere (round 4's route).
+SPLIT_MAPS = os.environ.get("COALIGN_SPLIT_MAPS", "1") != "0"
+
+
+def split_maps_active() -> bool:
+    return SPLIT_MAPS and CONV_EMU_TERMS == 16 and NHWC_STAGE_OUTPUTS and CONV_EMU_TAP_MAJOR and POINTWISE_EMU
+
+
 def winograd_active() -> bool:
     return CONV_WINOGRAD and CONV_EMU_TERMS == 3 and NHWC_STAGE_OUTPUTS      # (COALIGN_NHWC_STAGES=0 is the all-NCHW measurement route)
 
@@ -259,6 +270,36 @@ class BasicBlock(nn.Module):
         c1 = self.conv1
         return c1.out_channels % 64 == 0 and c1.in_channels % 16 == 0 and c1.in_channels <= 256 and self.downsample[0].stride[0] == 2 and self.downsample[0].out_channels % 32 == 0
 
+    def takes_split_maps(self) -> bool:
+        """This block runs on the SplitMap route (round 5): producer-split 3x3 convolutions, channels-last float32 skip."""
+        if self.training or not FAST_INFERENCE or not split_maps_active():
+            return False
+        c1, c2 = self.conv1, self.conv2
+        if c1.out_channels % 64 or c2.out_channels % 64 or c2.in_channels % 16 or tuple(c1.kernel_size) != (3, 3) or tuple(c2.kernel_size) != (3, 3):
+            return False
+        if self.stride == 2:
+            d = self.downsample
+            return d is not None and c1.in_channels % 8 == 0 and d[0].stride[0] == 2 and d[0].in_channels % 16 == 0 and d[0].in_channels <= 256 and d[0].out_channels % 32 == 0
+        return self.stride == 1 and self.downsample is None and c1.in_channels % 16 == 0
+
+    def _forward_split(self, x, out_channels_last: bool):
+        """conv1 -> SplitMap -> conv2 (+ skip) -> SplitMap, or channels-last float32 at the end of a stage (resblock.py:53-69)."""
+        w1, b1, w2, b2, wd, p1, p2, pd = self._folded()
+        if self.stride == 2:
+            if isinstance(x, ops.SparseCanvas):
+                y = ops.conv3x3_emu_sparse(x, p1.emu(16, False), b1, p1.cout, True, 16, out_channels_last=False, out_split=True)
+                skip = ops.pointwise_conv_sparse(x, pd[0].get(), pd[1], wd.shape[0], False, out_channels_last=True)
+            else:
+                if isinstance(x, ops.SplitMap):
+                    x = x.dense(channels_last=True)
+                y = ops.conv3x3_emu_bias_act(x, p1.emu(16, False), b1, p1.cout, None, True, 16, stride=2, out_split=True)
+                skip = ops.pointwise_conv(x, pd[0].get(), pd[1], wd.shape[0], in_stride=2, relu=False, out_channels_last=True)
+        else:
+            xs = x if isinstance(x, ops.SplitMap) else ops.SplitMap.pack(x)
+            y = ops.conv3x3_sp(xs, p1.emu(16, True), b1, p1.cout, None, True, out_split=True)
+            skip = xs
+        return ops.conv3x3_sp(y, p2.emu(16, True), b2, p2.cout, skip, True, out_split=not out_channels_last)
+
     def _forward_sparse(self, sc: "ops.SparseCanvas", out_channels_last: bool) -> torch.Tensor:
         w1, b1, w2, b2, wd, p1, p2, pd = self._folded()
         wino = winograd_active() and p2 is not None and p2.wino_ok
@@ -270,6 +311,12 @@ class BasicBlock(nn.Module):
         return conv3x3_fused(y, p2, w2, b2, skip, out_channels_last=(wino or out_channels_last) and p2 is not None and p2.cout % 4 == 0)
 
     def forward(self, x: torch.Tensor, out_channels_last: bool = False) -> torch.Tensor:
+        if self.takes_split_maps() and x.is_cuda:
+            f = self._folded()
+            if f[5] is not None and f[6] is not None and (self.stride == 1 or f[7] is not None):
+                return self._forward_split(x, out_channels_last)
+        if isinstance(x, ops.SplitMap):
+            x = x.dense()
         if isinstance(x, ops.SparseCanvas):
             if self.takes_sparse_canvas() and self._folded()[5] is not None and self._folded()[7] is not None:
                 return self._forward_sparse(x, out_channels_last)
@@ -520,6 +567,11 @@ class DoubleConv(nn.Module):
                 return (Conv3x3Pack(c1.weight.detach()) if ok(c1) else None, Conv3x3Pack(c2.weight.detach()) if ok(c2) else None)
             p1, p2 = _cache_of(self).get([c1.weight, c2.weight], build)
             x = x.contiguous()
+            if split_maps_active() and p1 is not None and p2 is not None and p1.cin % 16 == 0 and p2.cin % 16 == 0:
+                # round 5: the first convolution splits its own (float32, concatenated) input and writes a SplitMap, the second one reads it by LDS-DMA and
+                # writes the channels-last float32 map the 1x1 heads read
+                y = ops.conv3x3_emu_bias_act(x, p1.emu(16, True), c1.bias, p1.cout, None, True, 16, out_split=True)
+                return ops.conv3x3_sp(y, p2.emu(16, True), c2.bias, p2.cout, None, True, out_split=False)
             if p1 is not None:
                 y = conv3x3_fused(x, p1, c1.weight, c1.bias, None, out_channels_last=winograd_active() and p2 is not None and p2.wino_ok)
             else:

@@ -29,7 +29,7 @@ LAB_LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip_lab.so")
 # cause).  `python -m coalign_amd.build --labvec`; COALIGN_LAB=vec loads it.  tools/pk_f32_recheck.sh runs the experiment.
 LABVEC_LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip_labvec.so")
 INCLUDE = os.path.join(REPO, "include")
-SOURCES = ["status.cpp", "pillar_scatter.hip", "pillar_sparse.hip", "warp_fuse.hip", "warp_fuse_nhwc.hip", "decode.hip", "nms.hip", "epilogue.hip", "voxelize.hip", "pose_graph.hip", "conv3x3.hip", "conv3x3_emu.hip", "conv3x3_wino.hip", "pointwise.hip"]
+SOURCES = ["status.cpp", "pillar_scatter.hip", "pillar_sparse.hip", "warp_fuse.hip", "warp_fuse_nhwc.hip", "decode.hip", "nms.hip", "epilogue.hip", "voxelize.hip", "pose_graph.hip", "conv3x3.hip", "conv3x3_emu.hip", "conv3x3_sp.hip", "conv3x3_wino.hip", "pointwise.hip"]
 ARCH = "gfx950"
 # per-source extras.  pillar_scatter.hip: its matrix-core encoder reduces the accumulators with VALU right after each instruction
 # pair -- results in VGPRs (not AGPRs) save 64 v_accvgpr_read per pass; -fno-honor-nans drops the canonicalising v_max the compiler

@@ -80,7 +80,7 @@ struct EmuArgs {
 #define EMU_STAMP(k)
 #endif
 
-enum { LAYOUT_NCHW = 0, LAYOUT_OUT_NHWC = 1, LAYOUT_IN_NHWC = 2, LAYOUT_NHWC = 3 };      // bits: 1 = channels-last output, 2 = channels-last input
+enum { LAYOUT_NCHW = 0, LAYOUT_OUT_NHWC = 1, LAYOUT_IN_NHWC = 2, LAYOUT_NHWC = 3, LAYOUT_OUT_SP = 4 };      // bits: 1 = channels-last output, 2 = channels-last input, 4 (round 5, fp16 split) = the output is an SP map (csrc/conv3x3_sp.hip)
 
 // TAPK ("K = 144"): a barrier interval is 16 input channels x 9 taps = nine MFMA steps whose K = 16 is the 16 channels of ONE tap (lanes
 // 0-31 channels 0-7, lanes 32-63 channels 8-15) -- no zero tenth tap, 10 % fewer MFMAs.  Weight image [9 taps][term][2 channel halves]
@@ -543,7 +543,34 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                 for (int q = 0; q < 16 * G::NCO; ++q)
                     acc[q / 16][q % 16] += __hip_atomic_load(slot + (q / 16) * 1024 + (q % 16) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (live) {
+            if constexpr ((LAYOUT & LAYOUT_OUT_SP) != 0) {
+                // SP map output (csrc/conv3x3_sp.hip): the sp16 pair of every value, [N][Cout / 16][2 * channel half + term][H][W][8 x fp16].  A lane holds 4 of a
+                // group's 8 channels (its partner lane, 32 further, the other 4): one v_permlane32_swap per dword makes lanes 0-31 hold the h terms of all 8,
+                // lanes 32-63 the l terms -- one 16-byte store per lane and group.
+                static_assert(DUAL, "SP maps belong to the fp16 split");
+                uint4 *ysp = reinterpret_cast<uint4 *>(a.y);
+                const size_t pix = live ? (size_t)gy * a.W + gx : 0;
+                const int on = live ? out_n : 0;
+#pragma unroll
+                for (int r = 0; r < 4 * G::NCO; ++r) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[r / 4][4 * (r % 4) + j] * winv[(r / 4) * 32 + 8 * (r % 4) + j];
+                        if (a.relu) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    unsigned h01, l01, h23, l23;
+                    coalign::sp16_split2(v[0], v[1], h01, l01);
+                    coalign::sp16_split2(v[2], v[3], h23, l23);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(h01, l01, false, false);
+                    const unsigned a0 = s0[0], b0 = s0[1];
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(h23, l23, false, false);
+                    const unsigned a1 = s1[0], b1 = s1[1];
+                    const int g8 = (cur.cg * kCoutTile + cb + (r / 4) * 32) / 8 + r % 4;          // 8-channel group of the output
+                    const size_t idx = ((size_t)(on * (a.Cout / 16) + g8 / 2) * 4 + (g8 % 2) * 2 + half) * plane + pix;
+                    if (live) ysp[idx] = uint4{a0, a1, b0, b1};
+                }
+            } else if (live) {
                 if constexpr ((LAYOUT & LAYOUT_OUT_NHWC) != 0) {      // channels-last output: accumulators 4 r .. 4 r + 3 are 4 consecutive channels
                     float *yp = a.y + (((size_t)out_n * a.H + gy) * a.W + gx) * a.Cout + cur.cg * kCoutTile + cb + 4 * half;
 #pragma unroll
@@ -645,6 +672,8 @@ int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
         if (layout == LAYOUT_NCHW) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_NCHW, 2, VAR_F16>(a, s);
         if (layout == LAYOUT_IN_NHWC) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_IN_NHWC, 2, VAR_F16>(a, s);
         if (layout == LAYOUT_NHWC) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_NHWC, 2, VAR_F16>(a, s);
+        if (layout == LAYOUT_OUT_SP) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_OUT_SP, 2, VAR_F16>(a, s);
+        if (layout == (LAYOUT_IN_NHWC | LAYOUT_OUT_SP)) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_IN_NHWC | LAYOUT_OUT_SP, 2, VAR_F16>(a, s);
         return COALIGN_ERR_UNSUPPORTED;
     }
     if (stride == 2) {
@@ -773,6 +802,15 @@ int tapk_launch(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipStre
         }
         return launch_variant<BH, BW, NPB, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, VAR>(a, s);
     }
+    if constexpr ((VAR & VAR_F16) != 0) {
+        if (layout == LAYOUT_OUT_SP) {
+            if (query) {
+                *query = Launch{0, 0, 0, false};
+                return COALIGN_OK;
+            }
+            return launch_variant<BH, BW, NPB, TERMS, 2, 1, LAYOUT_OUT_SP, 1, VAR>(a, s);
+        }
+    }
     if (layout != LAYOUT_NCHW) return COALIGN_ERR_UNSUPPORTED;
     return launch<BH, BW, NPB, TERMS, 2, 1, VAR>(a, ws, ws_bytes, s, query);
 }
@@ -786,6 +824,9 @@ int tapk_stacked(const EmuArgs &a, int layout, hipStream_t s, Launch *query) {
     }
     if (layout == LAYOUT_OUT_NHWC) return launch_variant<BH, BW, NPB, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, VAR>(a, s);
     if (layout == LAYOUT_NCHW) return launch_variant<BH, BW, NPB, TERMS, 2, 1, LAYOUT_NCHW, 1, VAR>(a, s);
+    if constexpr ((VAR & VAR_F16) != 0) {
+        if (layout == LAYOUT_OUT_SP) return launch_variant<BH, BW, NPB, TERMS, 2, 1, LAYOUT_OUT_SP, 1, VAR>(a, s);
+    }
     return COALIGN_ERR_UNSUPPORTED;
 }
 
@@ -857,6 +898,7 @@ int dispatch_tapk(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipSt
 }
 
 constexpr int kLayoutTapMajor = 4;      // COALIGN_LAYOUT_W_TAPMAJOR: flag bit of `layout`
+constexpr int kLayoutOutSp = 8;         // COALIGN_LAYOUT_OUT_SP: flag bit of `layout` (the kernels' template bit is LAYOUT_OUT_SP = 4)
 
 }  // namespace
 
@@ -946,8 +988,12 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
         return coalign_conv3x3_emu_bias_act(x, w_split, bias, residual, y, N, Cin, Cout, Hin, Win, relu, terms, workspace, workspace_bytes, stream);
     if (!x || !w_split || !y || !bias) return COALIGN_ERR_NULL_POINTER;
     if (layout >= 0 && (layout & kLayoutTapMajor)) {          // tap-major weight image: stride 1, NCHW in, NCHW or channels-last out
-        const int lay = layout & 3;
-        if (stride != 1 || (lay != LAYOUT_NCHW && lay != LAYOUT_OUT_NHWC) || layout > (kLayoutTapMajor | 3)) return COALIGN_ERR_UNSUPPORTED;
+        int lay = layout & 3;
+        if (stride != 1 || (lay != LAYOUT_NCHW && lay != LAYOUT_OUT_NHWC) || layout > (kLayoutTapMajor | kLayoutOutSp | 3)) return COALIGN_ERR_UNSUPPORTED;
+        if (layout & kLayoutOutSp) {                          // SP map output: fp16 split, NCHW input
+            if (terms != 16 || lay != LAYOUT_NCHW || residual || (reinterpret_cast<uintptr_t>(y) & 15)) return COALIGN_ERR_UNSUPPORTED;
+            lay = LAYOUT_OUT_SP;
+        }
         int rc = check_emu_args(N, Cin, Cout, Hin, Win, terms);
         if (rc != COALIGN_OK) return rc;
         if ((reinterpret_cast<uintptr_t>(w_split) & 15) || (lay != LAYOUT_NCHW && (reinterpret_cast<uintptr_t>(y) & 15))) return COALIGN_ERR_UNSUPPORTED;
@@ -964,7 +1010,10 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
         return rc != COALIGN_OK ? rc : check_launch();
     }
     if (stride != 1 && stride != 2) return COALIGN_ERR_UNSUPPORTED;
-    if (layout != LAYOUT_NCHW && layout != LAYOUT_OUT_NHWC && layout != LAYOUT_IN_NHWC && !(layout == LAYOUT_NHWC && stride == 2)) return COALIGN_ERR_UNSUPPORTED;
+    if (layout >= 0 && (layout & kLayoutOutSp)) {             // SP map output of the strided fp16 variants (NCHW or channels-last input)
+        if (terms != 16 || stride != 2 || residual || (layout & ~(kLayoutOutSp | LAYOUT_IN_NHWC))) return COALIGN_ERR_UNSUPPORTED;
+        layout = (layout & LAYOUT_IN_NHWC) | LAYOUT_OUT_SP;
+    } else if (layout != LAYOUT_NCHW && layout != LAYOUT_OUT_NHWC && layout != LAYOUT_IN_NHWC && !(layout == LAYOUT_NHWC && stride == 2)) return COALIGN_ERR_UNSUPPORTED;
     const int H = (Hin + stride - 1) / stride, W = (Win + stride - 1) / stride;          // 3x3, pad 1: floor((n + 2 - 3) / s) + 1
     int rc = check_emu_args(N, Cin, Cout, Hin, Win, terms);
     if (rc != COALIGN_OK) return rc;
@@ -1001,7 +1050,8 @@ extern "C" int coalign_conv3x3_emu_sparse(const float *feats, const void *stamps
     a.stamps = static_cast<const unsigned long long *>(stamps);
     a.tag_ptr = state;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int layout = out_nhwc ? LAYOUT_NHWC : LAYOUT_IN_NHWC;
+    if (out_nhwc == 2 && terms != 16) return COALIGN_ERR_UNSUPPORTED;      // SP map output: fp16 split only
+    const int layout = out_nhwc == 2 ? (LAYOUT_IN_NHWC | LAYOUT_OUT_SP) : out_nhwc ? LAYOUT_NHWC : LAYOUT_IN_NHWC;
     rc = terms == 3 ? dispatch_variant<3>(a, 2, layout, s) : terms == 16 ? dispatch_variant<2, true>(a, 2, layout, s) : dispatch_variant<2>(a, 2, layout, s);
     return rc != COALIGN_OK ? rc : check_launch();
 }

@@ -1,0 +1,437 @@
+// 3x3 / stride 1 / pad 1 convolution whose INPUT MAP ARRIVES ALREADY SPLIT (round 5), gfx950.  Same layers and arithmetic as the fp16 mode of
+// conv3x3_emu.hip (opencood/models/sub_modules/resblock.py:53-69, base_bev_backbone_resnet.py:59-138, downsample_conv.py:7-50): every fp32 product is
+// evaluated on v_mfma_f32_32x32x16_f16 from sp16 pairs (common.h), fp32 accumulation, bias + residual + ReLU in the epilogue -- but the operand split
+// has left the consumer.  Round 4's interval timelines (profiles/round4/experiments/conv_interval_timeline_fp16x2_bf16x3.txt) showed half of every
+// convolution going into work a consumer repeats per layer: 16 dword loads per lane, the VALU split, ds_write of the split patch, a second barrier.
+// Here a layer's epilogue writes its output map as an "SP map": the pair (h, l) of every value in the 32 bits the fp32 value would occupy, laid out
+// in the matrix instruction's operand order,
+//     SP map of a logical [N, C, H, W] tensor (C % 16 == 0):   [N][C / 16][4 planes][H][W][8 x fp16],   plane = 2 * (channel half of the 16) + term,
+// i.e. one 16-byte group = one B operand (8 consecutive input channels of one pixel, one term).  The consumer's halo patch of a 16-channel interval is then
+// four planes of PH x PW groups that travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: 64 consecutive groups of a plane per instruction, rows of
+// the patch contiguous in memory), next to the weight image's DMA: the K loop contains NO VALU work, no register staging, ONE barrier per interval, both
+// operands double buffered.  Zero padding = lanes whose group lies outside the image fetch the weight image's 16 zero bytes instead.
+//
+// Weight image: the tap-major fp16 image of conv3x3_emu.hip (coalign_conv3x3_emu_weight_bytes_ex(Cin, Cout, 16, 1): [Cout / 64][Cin / 16][9 taps][2 terms]
+// [2 channel halves][64 cout][8 cin] + 16 zero bytes + the per-channel scale tail).  Products: w_h x_h -> accumulator `acc`; w_h x_l', w_l' x_h (both
+// carry 2^10) -> accumulator `accl`; tile = (acc + 2^-10 accl) * 2^-k_c, with (bias + residual) * 2^k_c as acc's start value: the SAME operations in
+// the same order as the fp16 mode of conv3x3_emu.hip, so the two kernels agree bit for bit on the same (22-bit) inputs (tests/test_round5_gpu.py).
+//
+// Tiles: the batch is tiled as ONE image of N * H rows (as conv3x3_emu.hip's stacked variants: a tile may straddle two images, two zero rows in the
+// patch stand in for the padding between them); a workgroup = NPB wavefronts, each owning a BH x BW block of 32 pixels x 64 output channels (two 32 x 32
+// accumulator tiles x two accumulators); persistent workgroups over (tile, interval) steps, XCD-aware tile order.
+#include "common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+constexpr int kCoutTile = 64;
+
+struct SpArgs {
+    const uint4 *__restrict__ x;        // SP map of the input
+    const uint4 *__restrict__ wt;       // tap-major fp16 weight image
+    const uint4 *__restrict__ zero;     // 16 zero bytes (the weight image's zero group)
+    const float *__restrict__ bias, *__restrict__ wscale;      // wscale: [Cout] 2^-k_c, [Cout] 2^k_c
+    const void *__restrict__ residual;  // SP map or channels-last fp32, per res_kind
+    void *__restrict__ y;               // SP map or channels-last fp32, per the OUT template argument
+    int *range_flag;                    // may be NULL: bit 0 is set when an SP output value exceeds the pair's range (|y| > 65504)
+    int N, Cin, Cout, H, W, relu, res_kind, stack, tiles_x, tiles_y, total_tiles, xcd;
+};
+
+template <int BH, int BW, int NPB, int NBX>
+struct Geo {
+    static_assert(BH * BW == 32 && NPB % NBX == 0, "a wavefront owns 32 pixels; whole block rows");
+    static constexpr int WAVES = NPB, THREADS = 64 * NPB;
+    static constexpr int TH = BH * NPB / NBX, TW = BW * NBX;                   // output tile
+    static constexpr int PWU = TW + 2;                                         // patch columns in use
+    static constexpr int PW = NBX == 1 ? PWU : (PWU + 7) / 16 * 16 + 8;        // (as conv3x3_emu.hip: rows of a 4 x 8 block in alternating bank halves)
+    static constexpr int PH = TH + 4;                                          // halo + the two zero rows of an image boundary inside the tile
+    static constexpr int PIX = PH * PW, PIXP = (PIX + 63) / 64 * 64;           // groups per plane, padded to whole DMA instructions
+    static constexpr int PINS = PIXP / 64, PJ = (PINS + WAVES - 1) / WAVES;    // DMA instructions per plane / per wavefront and plane
+    static constexpr int WQ = 9 * 2 * 2 * kCoutTile;                           // 16-byte groups of one interval's weights
+    static constexpr int WINS = WQ / 64, WJ = (WINS + WAVES - 1) / WAVES;
+    static constexpr int W_BYTES = WQ * 16, B_BYTES = 4 * PIXP * 16;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)W_BYTES + 2 * (size_t)B_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
+};
+
+struct Tile {
+    int cg, n0, yl0, yb, x0;      // output-channel group; image of the tile's first row, that row inside the image, rows left in the image (H - yl0; huge if not stacked); first column
+};
+
+__device__ __forceinline__ void swap32(unsigned &a, unsigned &b) {       // lanes 32-63 of a <-> lanes 0-31 of b
+    const auto q = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    const unsigned x = q[0], y = q[1];
+    a = x;
+    b = y;
+}
+
+__device__ __forceinline__ void dma16(const uint4 *src, unsigned lds_byte) {      // 64 lanes x 16 bytes -> LDS [lds_byte, + 1024): lane l lands at + 16 l
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds_byte)), "v"(src) : "memory", "m0");
+}
+
+enum { SP_OUT_SP = 1, SP_OUT_NHWC = 2 };
+enum { SP_RES_NONE = 0, SP_RES_SP = 1, SP_RES_NHWC = 2 };
+
+template <int BH, int BW, int NPB, int NBX, int OUT>
+__global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
+    using G = Geo<BH, BW, NPB, NBX>;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;
+    const int HW = a.H * a.W, CI16 = a.Cin / 16, CO16 = a.Cout / 16, groups = a.Cout / kCoutTile, chunks = CI16;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
+    // LDS map: weight buffers 0 | 1, patch buffers 0 | 1
+
+    const int blk_y = wave / NBX, blk_x = wave - blk_y * NBX;                 // this wavefront's pixel block inside the tile
+    const int py = blk_y * BH + p / BW, px = blk_x * BW + p % BW;
+    int boff[9];                                                              // group of this lane's pixel under tap s, inside plane (2 * half + term 0)
+#pragma unroll
+    for (int s = 0; s < 9; ++s) boff[s] = 2 * half * G::PIXP + (py + s / 3) * G::PW + px + s % 3;
+    const int wlane = half * kCoutTile + p;                                   // this lane's group inside one (tap, term) weight block
+
+    auto decode = [&](int t) {
+        Tile c;
+        c.cg = t % groups;
+        const int sp = t / groups, ty = sp / a.tiles_x;
+        c.x0 = (sp - ty * a.tiles_x) * G::TW;
+        if (a.stack) {
+            const int y0 = ty * G::TH;
+            c.n0 = y0 / a.H;
+            c.yl0 = y0 - c.n0 * a.H;
+            c.yb = a.H - c.yl0;
+        } else {
+            c.n0 = ty / a.tiles_y;
+            c.yl0 = (ty - c.n0 * a.tiles_y) * G::TH;
+            c.yb = 1 << 24;
+        }
+        return c;
+    };
+    // Patch plan of a tile: the lane's group of DMA instruction (wave + WAVES * j) of a plane = patch pixel 64 * (wave + WAVES * j) + lane; its offset (in
+    // 16-byte groups) inside plane 0 of interval 0, or -1 for zero padding.  Patch rows (see conv3x3_emu.hip): 0 .. yb rows yl0 - 1 .. H - 1 of image n0,
+    // yb + 1 and yb + 2 zero, yb + 3 .. rows 0 .. of image n0 + 1; without a boundary inside the tile (yb >= TH) rows yl0 - 1 .. yl0 + TH.
+    struct Plan {
+        int off[G::PJ];
+        const uint4 *wsrc;
+    };
+    auto make_plan = [&](const Tile &t) {
+        Plan pl;
+        pl.wsrc = a.wt + (size_t)t.cg * chunks * G::WQ + lane;
+#pragma unroll
+        for (int j = 0; j < G::PJ; ++j) {
+            const int i = (wave + G::WAVES * j) * 64 + lane;
+            const int y = i / G::PW, xq = i - y * G::PW, gx = t.x0 - 1 + xq;
+            bool ok = i < G::PIX && xq < G::PWU && gx >= 0 && gx < a.W;
+            int gy, img = 0;
+            if (t.yb >= G::TH) { gy = t.yl0 - 1 + y; ok = ok && y < G::TH + 2; }
+            else if (y <= t.yb) gy = t.yl0 - 1 + y;
+            else if (y <= t.yb + 2) { gy = 0; ok = false; }
+            else { gy = y - (t.yb + 3); img = 1; ok = ok && t.n0 + 1 < a.N; }
+            ok = ok && gy >= 0 && gy < a.H;
+            pl.off[j] = ok ? (t.n0 + img) * CI16 * 4 * HW + gy * a.W + gx : -1;
+        }
+        return pl;
+    };
+    // everything interval c of the tile needs, by LDS-DMA into buffer `slot`: the weights (36 instructions per workgroup) and the four patch planes
+    auto issue = [&](const Plan &pl, int c, int slot) {
+        const uint4 *wsrc = pl.wsrc + (size_t)c * G::WQ;
+#pragma unroll
+        for (int j = 0; j < G::WJ; ++j) {
+            const int ins = wave + G::WAVES * j;
+            if (ins < G::WINS) dma16(wsrc + ins * 64, lds0 + slot * G::W_BYTES + ins * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < G::PJ; ++j) {
+            const int ins = wave + G::WAVES * j;
+            if (ins < G::PINS) {
+                const uint4 *src0 = a.x + (size_t)(pl.off[j] < 0 ? 0 : pl.off[j]) + (size_t)c * 4 * HW;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dma16(pl.off[j] < 0 ? a.zero : src0 + (size_t)q * HW, lds0 + 2 * G::W_BYTES + slot * G::B_BYTES + (q * G::PIXP + ins * 64) * 16);
+            }
+        }
+    };
+
+    // persistent workgroups over whole tiles g, g + n, ...; XCD k takes the k-th eighth of the logical ids (neighbouring tiles share input rows and weights in its L2)
+    const int n_wg = gridDim.x;
+    int g = blockIdx.x;
+    if (a.xcd) {
+        const int q = n_wg >> 3, r = n_wg & 7, k = g & 7, j = g >> 3;
+        g = k * q + (k < r ? k : r) + j;
+    }
+    const int n_local = ((a.total_tiles - g + n_wg - 1) / n_wg) * chunks;
+    if (n_local <= 0) return;
+    int tile = g;
+    Tile cur = decode(tile);
+    Plan plan = make_plan(cur);
+    issue(plan, 0, 0);
+    if (wave >= G::WAVES / 2) __builtin_amdgcn_s_setprio(1);      // (as conv3x3_emu.hip: the later-dispatched half of the wavefronts loses every arbitration otherwise)
+    int L = 0;
+    while (L < n_local) {
+        // this lane's output pixel: image out_n, row gy, column gx; rows at / past an image boundary read the patch two rows lower
+        const bool lower = py >= cur.yb;
+        const int out_n = cur.n0 + (lower ? 1 : 0), gy = lower ? py - cur.yb : cur.yl0 + py, gx = cur.x0 + px;
+        const int bshift = lower ? 2 * G::PW : 0;
+        const bool live = out_n < a.N && gy < a.H && gx < a.W;
+        const bool wave_live = __builtin_amdgcn_readfirstlane((int)(cur.n0 * a.H + cur.yl0 + blk_y * BH < (a.stack ? a.N * a.H : cur.n0 * a.H + a.H) && cur.x0 + blk_x * BW < a.W)) != 0;
+        const size_t pix = live ? (size_t)gy * a.W + gx : 0;
+        const int on = live ? out_n : 0;
+        const float *bias = a.bias + cur.cg * kCoutTile + 4 * half, *winv = a.wscale + cur.cg * kCoutTile + 4 * half, *wsc = winv + a.Cout;
+        floatx16 acc[2], accl[2];
+        accl[0] = floatx16{0};
+        accl[1] = floatx16{0};
+        if (!wave_live) {
+            acc[0] = floatx16{0};
+            acc[1] = floatx16{0};
+        } else {
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) {                       // 8 groups of 4 consecutive channels per lane: channel = 8 g8 + 4 half + j
+                float r[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.res_kind == SP_RES_SP) {
+                    const size_t idx = ((size_t)(on * CO16 + cur.cg * 4 + g8 / 2) * 4 + (g8 % 2) * 2) * HW + pix;
+                    const uint2 *rp = reinterpret_cast<const uint2 *>(a.residual);
+                    const halfx4 h = __builtin_bit_cast(halfx4, rp[idx * 2 + half]), l = __builtin_bit_cast(halfx4, rp[(idx + HW) * 2 + half]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r[j] = coalign::sp16_join(h[j], l[j]);
+                } else if (a.res_kind == SP_RES_NHWC) {
+                    const float4 v = *reinterpret_cast<const float4 *>(static_cast<const float *>(a.residual) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half + 8 * g8);
+                    r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[g8 / 4][4 * (g8 % 4) + j] = (r[j] + bias[8 * g8 + j]) * wsc[8 * g8 + j];
+            }
+        }
+        Tile next = cur;
+        Plan nplan = plan;
+        int ntile = tile;
+        for (int chunk = 0; chunk < chunks; ++chunk, ++L) {
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (L + 1 < n_local) {
+                int nc = chunk + 1;
+                if (nc == chunks) {                                // the next interval opens this workgroup's next tile
+                    nc = 0;
+                    ntile = tile + n_wg;
+                    next = decode(ntile);
+                    nplan = make_plan(next);
+                }
+                issue(nplan, nc, (L + 1) & 1);
+            }
+            if (wave_live) {
+                const uint4 *bq = reinterpret_cast<const uint4 *>(lds + 2 * G::W_BYTES + (L & 1) * G::B_BYTES) + bshift, *wq = reinterpret_cast<const uint4 *>(lds + (L & 1) * G::W_BYTES) + wlane;
+                auto load_b = [&](int s, halfx8 (&b)[2]) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) b[t] = __builtin_bit_cast(halfx8, bq[t * G::PIXP + boff[s]]);
+                };
+                auto load_w = [&](int s, halfx8 (&w)[2][2]) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) w[q][t] = __builtin_bit_cast(halfx8, wq[((s * 2 + t) * 2) * kCoutTile + q * 32]);
+                };
+                halfx8 bc[2], wc[2][2];
+                load_b(0, bc);
+                load_w(0, wc);
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {
+                    halfx8 bn[2], wn[2][2];
+                    if (s + 1 < 9) {                               // operands of the next tap are in flight while this tap's matrix instructions issue
+                        load_b(s + 1, bn);
+                        load_w(s + 1, wn);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) accl[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[q][0], bc[1], accl[q], 0, 0, 0);      // w_h x_l'
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) accl[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[q][1], bc[0], accl[q], 0, 0, 0);      // w_l' x_h
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[q][0], bc[0], acc[q], 0, 0, 0);        // w_h x_h
+                    if (s + 1 < 9) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            bc[t] = bn[t];
+                            wc[0][t] = wn[0][t];
+                            wc[1][t] = wn[1][t];
+                        }
+                    }
+                }
+            }
+        }
+        // ---- epilogue: tile = (acc + 2^-10 accl) * 2^-k_c, ReLU, stored as an SP map or as channels-last fp32
+        bool big = false;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = g8 / 4, r = 4 * (g8 % 4) + j;
+                v[j] = fmaf(accl[q][r], coalign::kSp16LowInv, acc[q][r]) * winv[8 * g8 + j];
+                if (a.relu) v[j] = fmaxf(v[j], 0.f);
+            }
+            if constexpr (OUT == SP_OUT_NHWC) {
+                if (live) *reinterpret_cast<float4 *>(static_cast<float *>(a.y) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half + 8 * g8) = float4{v[0], v[1], v[2], v[3]};
+            } else {
+                big = big || fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > 65504.f;
+                unsigned h01, l01, h23, l23;
+                coalign::sp16_split2(v[0], v[1], h01, l01);
+                coalign::sp16_split2(v[2], v[3], h23, l23);
+                swap32(h01, l01);          // lanes 0-31: h of channels 0,1 | 4,5 of the 8-channel group; lanes 32-63: l of the same channels
+                swap32(h23, l23);
+                const size_t idx = ((size_t)(on * CO16 + cur.cg * 4 + g8 / 2) * 4 + (g8 % 2) * 2 + half) * HW + pix;      // plane = 2 * channel half + term: lanes 32-63 hold term 1
+                if (live) static_cast<uint4 *>(a.y)[idx] = uint4{h01, h23, l01, l23};
+            }
+        }
+        if constexpr (OUT == SP_OUT_SP) {
+            if (a.range_flag && live && big) atomicOr(a.range_flag, 1);
+        }
+        cur = next;
+        plan = nplan;
+        tile = ntile;
+    }
+}
+
+// fp32 (NCHW or channels-last) -> SP map and back: the entry / exit of a chain of SP layers where no kernel epilogue does it, and the tests' yardstick
+__global__ void sp_pack_kernel(const float *__restrict__ x, uint4 *__restrict__ y, int N, int C, int HW, int in_nhwc, int *range_flag) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // (n, c16, pixel)
+    const int C16 = C / 16;
+    if (i >= (size_t)N * C16 * HW) return;
+    const int pixel = (int)(i % HW), c16 = (int)((i / HW) % C16), n = (int)(i / ((size_t)HW * C16));
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = in_nhwc ? x[((size_t)n * HW + pixel) * C + c16 * 16 + k] : x[((size_t)n * C + c16 * 16 + k) * HW + pixel];
+    bool big = false;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            coalign::sp16_split2(v[8 * hh + 2 * k], v[8 * hh + 2 * k + 1], h[k], l[k]);
+            big = big || fabsf(v[8 * hh + 2 * k]) > 65504.f || fabsf(v[8 * hh + 2 * k + 1]) > 65504.f;
+        }
+        const size_t base = ((size_t)(n * C16 + c16) * 4 + hh * 2) * HW + pixel;
+        y[base] = uint4{h[0], h[1], h[2], h[3]};
+        y[base + HW] = uint4{l[0], l[1], l[2], l[3]};
+    }
+    if (range_flag && big) atomicOr(range_flag, 1);
+}
+
+__global__ void sp_unpack_kernel(const uint4 *__restrict__ x, float *__restrict__ y, int N, int C, int HW, int out_nhwc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C16 = C / 16;
+    if (i >= (size_t)N * C16 * HW) return;
+    const int pixel = (int)(i % HW), c16 = (int)((i / HW) % C16), n = (int)(i / ((size_t)HW * C16));
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const size_t base = ((size_t)(n * C16 + c16) * 4 + hh * 2) * HW + pixel;
+        const halfx8 h = __builtin_bit_cast(halfx8, x[base]), l = __builtin_bit_cast(halfx8, x[base + HW]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = coalign::sp16_join(h[k], l[k]);
+            if (out_nhwc) y[((size_t)n * HW + pixel) * C + c16 * 16 + 8 * hh + k] = v;
+            else y[((size_t)n * C + c16 * 16 + 8 * hh + k) * HW + pixel] = v;
+        }
+    }
+}
+
+template <int BH, int BW, int NPB, int NBX>
+int launch_geo(SpArgs a, int out_kind, hipStream_t s) {
+    using G = Geo<BH, BW, NPB, NBX>;
+    constexpr int kMaxDev = 16;
+    static int resident[kMaxDev] = {0}, cus[kMaxDev] = {0};          // per device: the function attribute belongs to the device's code object
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+    auto k_sp = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP>;
+    auto k_cl = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC>;
+    if (!resident[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+        for (const void *fn : {reinterpret_cast<const void *>(k_sp), reinterpret_cast<const void *>(k_cl)}) {
+            const int rc = coalign::hip_call(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+            if (rc != COALIGN_OK) {
+                (void)hipGetLastError();
+                return rc;
+            }
+        }
+        cus[dev] = prop.multiProcessorCount;
+        resident[dev] = 1;                                            // 111-147 KB of LDS: one workgroup per CU
+    }
+    a.stack = (a.N > 1 && G::TH <= a.H) ? 1 : 0;
+    a.tiles_x = (a.W + G::TW - 1) / G::TW;
+    a.tiles_y = (a.H + G::TH - 1) / G::TH;                            // per image (not stacked)
+    const int row_tiles = a.stack ? (a.N * a.H + G::TH - 1) / G::TH : a.N * a.tiles_y;
+    a.total_tiles = a.tiles_x * row_tiles * (a.Cout / kCoutTile);
+    const int slots = cus[dev] * resident[dev];
+    const int grid = a.total_tiles < slots ? a.total_tiles : slots;
+    if (out_kind == SP_OUT_SP) hipLaunchKernelGGL(k_sp, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(k_cl, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+    return COALIGN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t coalign_sp_map_bytes(int N, int C, int H, int W) {
+    if (N < 0 || C < 1 || H < 1 || W < 1 || C % 16) return 0;
+    return (size_t)N * C * H * W * 4;
+}
+
+extern "C" int coalign_sp_pack(const float *x, int in_nhwc, void *y_sp, int N, int C, int H, int W, int32_t *range_flag, void *stream) {
+    if (!x || !y_sp) return COALIGN_ERR_NULL_POINTER;
+    if (N < 0 || C < 1 || H < 1 || W < 1) return COALIGN_ERR_BAD_SHAPE;
+    if (C % 16 || (reinterpret_cast<uintptr_t>(y_sp) & 15)) return COALIGN_ERR_UNSUPPORTED;
+    const size_t n = (size_t)N * (C / 16) * H * W;
+    if (n == 0) return COALIGN_OK;
+    hipLaunchKernelGGL(sp_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<uint4 *>(y_sp), N, C, H * W, in_nhwc, range_flag);
+    return coalign::check_launch();
+}
+
+extern "C" int coalign_sp_unpack(const void *x_sp, float *y, int out_nhwc, int N, int C, int H, int W, void *stream) {
+    if (!x_sp || !y) return COALIGN_ERR_NULL_POINTER;
+    if (N < 0 || C < 1 || H < 1 || W < 1) return COALIGN_ERR_BAD_SHAPE;
+    if (C % 16 || (reinterpret_cast<uintptr_t>(x_sp) & 15)) return COALIGN_ERR_UNSUPPORTED;
+    const size_t n = (size_t)N * (C / 16) * H * W;
+    if (n == 0) return COALIGN_OK;
+    hipLaunchKernelGGL(sp_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint4 *>(x_sp), y, N, C, H * W, out_nhwc);
+    return coalign::check_launch();
+}
+
+extern "C" int coalign_conv3x3_sp(const void *x_sp, const void *w_split, const float *bias, const void *residual, int residual_kind, void *y, int out_kind,
+                                  int N, int Cin, int Cout, int H, int W, int relu, int geometry, int32_t *range_flag, void *stream) {
+    using namespace coalign;
+    if (!x_sp || !w_split || !bias || !y || (residual_kind != SP_RES_NONE && !residual)) return COALIGN_ERR_NULL_POINTER;
+    if (N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return COALIGN_ERR_BAD_SHAPE;
+    if (Cin % 16 || Cout % kCoutTile || (out_kind != SP_OUT_SP && out_kind != SP_OUT_NHWC) || residual_kind < 0 || residual_kind > SP_RES_NHWC) return COALIGN_ERR_UNSUPPORTED;
+    if ((int64_t)N * (Cin > Cout ? Cin : Cout) * H * W > (int64_t)1 << 32) return COALIGN_ERR_UNSUPPORTED;      // group offsets are 32-bit
+    if ((reinterpret_cast<uintptr_t>(x_sp) | reinterpret_cast<uintptr_t>(w_split) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) return COALIGN_ERR_UNSUPPORTED;
+    if (N == 0) return COALIGN_OK;
+    const size_t wbytes = coalign_conv3x3_emu_weight_bytes_ex(Cin, Cout, 16, 1), tail = (size_t)Cout * 8;
+    const char *wb = static_cast<const char *>(w_split);
+    SpArgs a{};
+    a.x = static_cast<const uint4 *>(x_sp);
+    a.wt = static_cast<const uint4 *>(w_split);
+    a.zero = reinterpret_cast<const uint4 *>(wb + wbytes - tail - 16);
+    a.bias = bias;
+    a.wscale = reinterpret_cast<const float *>(wb + wbytes - tail);
+    a.residual = residual;
+    a.y = y;
+    a.range_flag = range_flag;
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.relu = relu; a.res_kind = residual_kind;
+    a.xcd = 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // geometry: 0 = chosen from the map size (the rules measured for conv3x3_emu.hip's fp16 mode), else 81 / 121 / 124 / 148 as there
+    int geo = geometry;
+    if (geo == 0) {
+        if (W % 32 == 16 && H > 26 && H <= 52 && N * H >= 24) geo = 124;
+        else if (H >= 64) geo = 121;
+        else if (H >= 8 && H <= 32 && W % 32 > 0 && W % 32 <= 24) geo = 148;
+        else geo = 81;
+    }
+    int rc;
+    switch (geo) {
+        case 81: rc = launch_geo<1, 32, 8, 1>(a, out_kind, s); break;       // 8 rows x 32 columns
+        case 121: rc = launch_geo<1, 32, 12, 1>(a, out_kind, s); break;     // 12 x 32
+        case 124: rc = launch_geo<2, 16, 12, 1>(a, out_kind, s); break;     // 24 x 16 (2 x 16 blocks)
+        case 148: rc = launch_geo<4, 8, 8, 4>(a, out_kind, s); break;       // 8 x 32 in 4 x 8 blocks, four block columns
+        default: return COALIGN_ERR_UNSUPPORTED;
+    }
+    return rc != COALIGN_OK ? rc : check_launch();
+}

@@ -195,6 +195,77 @@ def pillar_encode_stream(voxel_features: torch.Tensor, voxel_num_points: torch.T
     return feats, canvas
 
 
+_SP_RANGE_FLAGS: dict = {}
+
+
+def sp_range_flag(device, create: bool = True) -> Optional[torch.Tensor]:
+    """The device word every SplitMap-producing kernel ORs bit 0 into when a value left the pair's range (|x| > 65504; include/coalign_amd.h (9e)).  One per
+    device, never cleared by the kernels.  Created on first use outside a graph capture (``FramePipeline`` creates it before capturing); ``None`` if it does not
+    exist yet and ``create`` is false or a capture is running (the kernels then skip the report)."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    f = _SP_RANGE_FLAGS.get(key)
+    if f is None and create and not torch.cuda.is_current_stream_capturing():
+        f = _SP_RANGE_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return f
+
+
+def sp_range_exceeded(device, clear: bool = True) -> bool:
+    """True if a SplitMap value exceeded the fp16 split's operating range since the last clearing call (synchronises the device)."""
+    f = sp_range_flag(device, create=False)
+    if f is None:
+        return False
+    hit = bool(int(f.item()) & 1)
+    if hit and clear:
+        f.zero_()
+    return hit
+
+
+class SplitMap:
+    """An activation map stored as sp16 pairs in the matrix instructions' operand order (csrc/conv3x3_sp.hip, include/coalign_amd.h (9e)): what the 3x3
+    convolutions of the fp16 mode hand to each other inside a ResNet stage.  ``shape`` is the logical [N, C, H, W]; ``data`` the float16 tensor
+    [N, C / 16, 4, H, W, 8] (plane = 2 * channel half + term); ``dense()`` returns the float32 tensor the pairs stand for (the values rounded to 22 bits)."""
+
+    def __init__(self, data: torch.Tensor):
+        if data.dtype != torch.float16 or data.dim() != 6 or data.shape[2] != 4 or data.shape[5] != 8 or not data.is_contiguous():
+            raise ValueError("SplitMap data: contiguous float16 [N, C / 16, 4, H, W, 8]")
+        self.data = data
+        self.shape = (data.shape[0], data.shape[1] * 16, data.shape[3], data.shape[4])
+        self.device, self.dtype, self.is_cuda = data.device, torch.float32, data.is_cuda
+
+    @staticmethod
+    def empty(N: int, C: int, H: int, W: int, device) -> "SplitMap":
+        if C % 16:
+            raise ValueError("SplitMap: C % 16 == 0")
+        return SplitMap(torch.empty((N, C // 16, 4, H, W, 8), dtype=torch.float16, device=device))
+
+    @staticmethod
+    def pack(x: torch.Tensor) -> "SplitMap":
+        """float32 [N, C, H, W] (NCHW or channels-last memory) -> SplitMap (``coalign_sp_pack``)."""
+        _need_gpu(x)
+        nhwc = x.dtype == torch.float32 and is_channels_last(x)
+        xc = x if nhwc else _f32c(x)
+        N, C, H, W = xc.shape
+        out = SplitMap.empty(N, C, H, W, xc.device)
+        hip.check(hip.lib().coalign_sp_pack(_ptr(xc), int(nhwc), _ptr(out.data), N, C, H, W, _ptr(sp_range_flag(xc.device)), _stream()), "coalign_sp_pack")
+        return out
+
+    def dense(self, channels_last: bool = False) -> torch.Tensor:
+        N, C, H, W = self.shape
+        y = torch.empty((N, C, H, W), dtype=torch.float32, device=self.device, memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+        if channels_last and not nhwc_memory(y):
+            y = torch.empty((N, H, W, C), dtype=torch.float32, device=self.device).permute(0, 3, 1, 2)
+        hip.check(hip.lib().coalign_sp_unpack(_ptr(self.data), _ptr(y), int(channels_last), N, C, H, W, _stream()), "coalign_sp_unpack")
+        return y
+
+    def dense_reference(self) -> torch.Tensor:
+        """The same values computed with torch ops from ``data`` (tests: the layout's definition, independent of the unpack kernel)."""
+        d = self.data.float()
+        v = d[:, :, 0::2] + d[:, :, 1::2] / 1024.0                    # [N, C/16, 2 halves, H, W, 8]
+        N, C, H, W = self.shape
+        return v.permute(0, 1, 2, 5, 3, 4).reshape(N, C, H, W)
+
+
 class SparseCanvas:
     """The BEV canvas of one batch as the sparse pair (feature rows, cell stamps) of csrc/pillar_sparse.hip instead of a dense tensor: what
     ``PillarVFE`` + ``PointPillarScatter`` hand to the first ResNet stage on the fast path.  ``shape`` is the dense tensor's; ``dense()`` materialises it
@@ -290,18 +361,25 @@ def pillar_encode_sparse(voxel_features: torch.Tensor, voxel_num_points: torch.T
 
 
 @_device_op
-def conv3x3_emu_sparse(sc: SparseCanvas, w_split: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool, terms: int, out_channels_last: bool) -> torch.Tensor:
-    """The strided first convolution of the backbone reading a SparseCanvas (include/coalign_amd.h (9d)); tap-pair weight image."""
+def conv3x3_emu_sparse(sc: SparseCanvas, w_split: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool, terms: int, out_channels_last: bool, out_split: bool = False):
+    """The strided first convolution of the backbone reading a SparseCanvas (include/coalign_amd.h (9d)); tap-pair weight image.  ``out_split`` (terms 16):
+    the result is a ``SplitMap`` (the input of ``conv3x3_sp``)."""
     L = hip.lib()
     N, Cin, H, W = sc.shape
     Ho, Wo = (H + 1) // 2, (W + 1) // 2
     if w_split.numel() != L.coalign_conv3x3_emu_weight_bytes(Cin, cout, terms):
         raise ValueError("split weight image does not match (Cin, Cout, terms)")
-    y = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=sc.device, memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
+    if out_split:
+        if terms != 16:
+            raise ValueError("SplitMap outputs belong to the fp16 split (terms = 16)")
+        out = SplitMap.empty(N, cout, Ho, Wo, sc.device)
+        y = out.data
+    else:
+        out = y = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=sc.device, memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
     with _Timed("conv3x3_emu_sparse"):
         hip.check(L.coalign_conv3x3_emu_sparse(_ptr(sc.feats), _ptr(sc.stamps), _ptr(sc.state), _ptr(w_split), _ptr(_f32c(bias)), _ptr(y), N, Cin, cout, H, W,
-                                               int(relu), terms, int(out_channels_last), _stream()), "coalign_conv3x3_emu_sparse")
-    return y
+                                               int(relu), terms, 2 if out_split else int(out_channels_last), _stream()), "coalign_conv3x3_emu_sparse")
+    return out
 
 
 @_device_op
@@ -719,7 +797,7 @@ def pack_conv3x3_emu_weight(weight: torch.Tensor, terms: int = 3, tap_major: boo
     return out
 
 
-LAYOUT_NCHW, LAYOUT_OUT_NHWC, LAYOUT_IN_NHWC, LAYOUT_W_TAPMAJOR = 0, 1, 2, 4      # COALIGN_LAYOUT_* of include/coalign_amd.h
+LAYOUT_NCHW, LAYOUT_OUT_NHWC, LAYOUT_IN_NHWC, LAYOUT_W_TAPMAJOR, LAYOUT_OUT_SP = 0, 1, 2, 4, 8      # COALIGN_LAYOUT_* of include/coalign_amd.h
 
 
 def is_channels_last(t: torch.Tensor) -> bool:
@@ -729,10 +807,11 @@ def is_channels_last(t: torch.Tensor) -> bool:
 
 @_device_op
 def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Tensor, cout: int, residual: Optional[torch.Tensor] = None,
-                         relu: bool = True, terms: int = 3, stride: int = 1, out_channels_last: bool = False) -> torch.Tensor:
+                         relu: bool = True, terms: int = 3, stride: int = 1, out_channels_last: bool = False, out_split: bool = False):
     """y = act(conv3x3(x, w, stride, padding 1) + bias (+ residual)) with every fp32 product evaluated as `terms`-way split bf16
     products on the bf16 matrix cores, fp32 accumulation (csrc/conv3x3_emu.hip; terms = 16: the 2-way split with fp16 terms, 22 operand bits).  A channels-last ``x`` is read in place by the
-    stride-2 variant; ``out_channels_last`` (stride 1) returns a tensor of logical shape [N, C, H, W] in channels-last memory."""
+    stride-2 variant; ``out_channels_last`` (stride 1) returns a tensor of logical shape [N, C, H, W] in channels-last memory; ``out_split`` (terms 16, no
+    residual: the strided layers and the tap-major stride-1 image on an NCHW input) returns a ``SplitMap``."""
     _need_gpu(x, w_split, bias, residual)
     L = hip.lib()
     layout = LAYOUT_NCHW
@@ -749,7 +828,14 @@ def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Ten
     if stride not in (1, 2) or (stride == 2 and (residual is not None or (out_channels_last and layout != LAYOUT_IN_NHWC))):
         raise ValueError("stride 2 takes no residual and writes NCHW (channels-last only from a channels-last input)")
     Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
-    if out_channels_last:
+    out = None
+    if out_split:
+        if terms != 16 or residual is not None or out_channels_last or (stride == 1 and (not tapk or layout != LAYOUT_NCHW)):
+            raise ValueError("SplitMap output: terms 16, no residual; stride 2, or stride 1 with the tap-major image on an NCHW input")
+        layout |= LAYOUT_OUT_SP
+        out = SplitMap.empty(N, cout, Ho, Wo, xc.device)
+        y = out.data
+    elif out_channels_last:
         layout |= LAYOUT_OUT_NHWC
         y = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=xc.device, memory_format=torch.channels_last)
     else:
@@ -759,7 +845,7 @@ def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Ten
         raise ValueError("residual shape mismatch")
     ws, ws_bytes = None, 0
     layout |= tapk
-    if stride == 1 and (layout & 3) == LAYOUT_NCHW:
+    if stride == 1 and (layout & 3) == LAYOUT_NCHW and not out_split:
         ws_bytes = L.coalign_conv3x3_emu_workspace_bytes_ex(N, Cin, cout, H, W, terms, layout)
     if ws_bytes:
         key = (xc.device, torch.cuda.current_stream(xc.device).cuda_stream, "emu")
@@ -768,7 +854,46 @@ def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Ten
         hip.check(L.coalign_conv3x3_emu_ex(_ptr(xc), _ptr(w_split), _ptr(_f32c(bias)), _ptr(res), _ptr(y), N, Cin, cout, H, W, int(stride),
                                            int(relu), terms, layout, _ptr(ws), 0 if ws is None else ws.numel(), _stream()),
                   "coalign_conv3x3_emu_ex")
-    return y
+    return y if out is None else out
+
+
+SP_RES_NONE, SP_RES_SP, SP_RES_NHWC = 0, 1, 2      # residual_kind of coalign_conv3x3_sp
+SP_OUT_SP, SP_OUT_NHWC = 1, 2                      # out_kind
+
+
+@_device_op
+def conv3x3_sp(x: "SplitMap", w_split: torch.Tensor, bias: torch.Tensor, cout: int, residual=None, relu: bool = True, out_split: bool = True, geometry: int = 0):
+    """y = act(conv3x3(x, w, stride 1, padding 1) + bias (+ residual)) on a ``SplitMap`` input (include/coalign_amd.h (9e), csrc/conv3x3_sp.hip): the fp16
+    mode's arithmetic with the operand split done by the producer.  ``w_split``: the tap-major terms-16 image of ``pack_conv3x3_emu_weight``; ``residual``: a
+    SplitMap, a float32 tensor (converted to channels-last memory if it is not) or None; returns a SplitMap (``out_split``) or a float32 tensor of logical
+    shape [N, C, H, W] in channels-last memory."""
+    if not isinstance(x, SplitMap):
+        raise TypeError("conv3x3_sp reads a SplitMap")
+    _need_gpu(x.data, w_split, bias)
+    L = hip.lib()
+    N, Cin, H, W = x.shape
+    if w_split.numel() != L.coalign_conv3x3_emu_weight_bytes_ex(Cin, cout, 16, 1):
+        raise ValueError("conv3x3_sp needs the tap-major terms-16 weight image of (Cin, Cout)")
+    res_kind, res_t = SP_RES_NONE, None
+    if isinstance(residual, SplitMap):
+        res_kind, res_t = SP_RES_SP, residual.data
+        if residual.shape != (N, cout, H, W):
+            raise ValueError("residual shape mismatch")
+    elif residual is not None:
+        res_kind, res_t = SP_RES_NHWC, to_nhwc(residual)
+        if tuple(res_t.shape) != (N, cout, H, W):
+            raise ValueError("residual shape mismatch")
+    if out_split:
+        out = SplitMap.empty(N, cout, H, W, x.device)
+        y = out.data
+    else:
+        out = y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        if not nhwc_memory(y):
+            out = y = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+    with _Timed("conv3x3_sp"):
+        hip.check(L.coalign_conv3x3_sp(_ptr(x.data), _ptr(w_split), _ptr(_f32c(bias)), _ptr(res_t), res_kind, _ptr(y), SP_OUT_SP if out_split else SP_OUT_NHWC,
+                                       N, Cin, cout, H, W, int(relu), int(geometry), _ptr(sp_range_flag(x.device)) if out_split else None, _stream()), "coalign_conv3x3_sp")
+    return out
 
 
 def pack_conv3x3_wino_weight(weight: torch.Tensor) -> torch.Tensor:

@@ -117,6 +117,8 @@ class FramePipeline:
         else:
             with torch.cuda.device(self.device):
                 self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_lanes)]
+        with torch.cuda.device(self.device):
+            ops.sp_range_flag(self.device)                        # the SplitMap range word exists before any graph is captured (its pointer is baked into the capture)
         # (only now, with every argument validated, is the model touched)
         self._vfe_flag = None
         if hasattr(model, "pillar_vfe"):

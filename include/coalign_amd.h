@@ -341,7 +341,9 @@ int coalign_conv3x3_emu_bias_act(const float *x, const void *w_split, const floa
  * (NHWC) out (stride 1 only: the last convolution of a stage, whose map the fusion kernel and the next stage read), 2 = NHWC in /
  * NCHW out (stride 2 only).  residual (stride 1) is always NCHW.  workspace as coalign_conv3x3_emu_workspace_bytes for
  * (stride 1, layout 0); the other variants need none. */
-enum { COALIGN_LAYOUT_NCHW = 0, COALIGN_LAYOUT_OUT_NHWC = 1, COALIGN_LAYOUT_IN_NHWC = 2, COALIGN_LAYOUT_W_TAPMAJOR = 4 };
+enum { COALIGN_LAYOUT_NCHW = 0, COALIGN_LAYOUT_OUT_NHWC = 1, COALIGN_LAYOUT_IN_NHWC = 2, COALIGN_LAYOUT_W_TAPMAJOR = 4, COALIGN_LAYOUT_OUT_SP = 8 };
+/* COALIGN_LAYOUT_OUT_SP (round 5; flag, terms = 16 only, no residual): y is an SP map (9e) instead of a float32 tensor -- with stride 2 (NCHW or
+ * channels-last input, tap-pair image) and with COALIGN_LAYOUT_W_TAPMAJOR (stride 1, NCHW input): the layers in front of a chain of coalign_conv3x3_sp. */
 /* Round 4: layout 3 (= IN_NHWC | OUT_NHWC) with stride 2: channels-last in AND out -- the strided first convolution of a ResNet stage in front of
  * the Winograd layers (9c), which read and write channels-last. */
 /* COALIGN_LAYOUT_W_TAPMAJOR (flag, or-ed into layout 0 or 1, stride 1, Cin % 16 == 0): w_split is the TAP-MAJOR image
@@ -353,6 +355,31 @@ size_t coalign_conv3x3_emu_workspace_bytes_ex(int N, int Cin, int Cout, int H, i
 int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const float *bias, const float *residual, float *y, int N, int Cin,
                            int Cout, int Hin, int Win, int stride, int relu, int terms, int layout, void *workspace,
                            size_t workspace_bytes, void *stream);
+
+/* terms = 16 (round 4; scale free since round 5): the fp16 split.  Every operand is an "sp16 pair" (csrc/common.h): the value rounded to 22 significant bits,
+ * h = its leading 11 bits as fp16, l = the following 11 bits times 2^10 (a normal fp16 number for every |value| >= 2^-14); products w_h x_h in one fp32
+ * accumulator, w_h x_l + w_l x_h in a second one that enters with 2^-10; w_l x_l (< 2^-20 |w x|) dropped.  The weight image is built from the weights
+ * multiplied per OUTPUT CHANNEL by the power of two that puts the channel's largest weight into [2^13, 2^14), and ends in [Cout] float32 2^-k_c and [Cout]
+ * float32 2^k_c (coalign_conv3x3_emu_weight_bytes* include them): exact, so the result does not depend on the scale of the weights.  Operating range of the
+ * activations: |x| <= 65504 (beyond it operands clamp, finite).  Against a float64 convolution the error is <= the native fp32 kernel's (9) over weight scales
+ * 2e-4 ... 2e-1 x activation scales 1e-2 ... 1e2, Gaussian and Student-t (tests/test_round5_gpu.py). */
+
+/* (9e) Round 5: 3x3 / stride 1 convolutions whose input (and usually output) is an SP MAP -- the activations stored as sp16 pairs in the matrix
+ * instruction's operand order, so that the consumer's K loop is LDS-DMA + matrix instructions only (csrc/conv3x3_sp.hip).  Same layers as (9b):
+ * BasicBlock.forward opencood/models/sub_modules/resblock.py:53-69, the ResNet stages base_bev_backbone_resnet.py:59-119, DoubleConv downsample_conv.py:7-27.
+ *   SP map of a logical [N, C, H, W] tensor, C % 16 == 0: [N][C / 16][4][H][W][8] fp16, plane index = 2 * (channel / 8 % 2) + term; element e of a
+ *   16-byte group = channel 16 (c / 16) + 8 (plane / 2) + e; coalign_sp_map_bytes = N * C * H * W * 4 bytes, 16-byte aligned.
+ *   coalign_sp_pack / coalign_sp_unpack: float32 (NCHW, or channels-last if *_nhwc != 0) <-> SP map (unpack(pack(x)) = x rounded to 22 significant bits).
+ *   coalign_conv3x3_sp: y = relu?(conv3x3(x, w) + bias + residual);  w_split = the TAP-MAJOR terms-16 image of (9b);
+ *     residual_kind 0 none | 1 SP map [N, Cout, H, W] | 2 channels-last float32;  out_kind 1 SP map | 2 channels-last float32;
+ *     geometry 0 = chosen from the shape, 81 / 121 / 124 / 148 = a fixed tile geometry (8 x 32, 12 x 32, 24 x 16, 8 x 32 in 4 x 8 blocks);
+ *     range_flag (may be NULL): bit 0 is set when a value written to an SP map exceeded 65504 in magnitude.
+ *   Bit-identical to coalign_conv3x3_emu_ex(terms 16, tap-major) on the unpacked input. */
+size_t coalign_sp_map_bytes(int N, int C, int H, int W);
+int coalign_sp_pack(const float *x, int in_nhwc, void *y_sp, int N, int C, int H, int W, int32_t *range_flag, void *stream);
+int coalign_sp_unpack(const void *x_sp, float *y, int out_nhwc, int N, int C, int H, int W, void *stream);
+int coalign_conv3x3_sp(const void *x_sp, const void *w_split, const float *bias, const void *residual, int residual_kind, void *y, int out_kind,
+                       int N, int Cin, int Cout, int H, int W, int relu, int geometry, int32_t *range_flag, void *stream);
 
 /* (9c) Round 4: the stride-1 3x3 convolutions as Winograd F(2x2, 3x3) on the bf16 matrix cores -- 16 instead of 36 products per 2 x 2 outputs and
  * (cin, cout), fp32 operands by the same 3-way error-free bf16 split, fp32 accumulation (csrc/conv3x3_wino.hip).  Same layers as (9b):
@@ -393,7 +420,7 @@ int coalign_pillar_encode_sparse(const float *voxel_features, const int32_t *vox
                                  const double *range_min, int n_agents, int ny, int nx, float *pillar_features, void *stamps, int32_t *state, void *stream);
 /* (9d) The strided 3x3 convolution of (9b) (stride 2, pad 1, bias + ReLU; resblock.py:150-174) reading the sparse canvas of (1b): feats [M, Cin], pixel
  * (n, y, x) of the logical [N, Hin, Win, Cin] input = feats row (stamp & 0xffffffff) where the cell's stamp carries state[0], else zero.
- * y: [N, Cout, ceil(Hin/2), ceil(Win/2)] NCHW, or channels-last if out_nhwc != 0.  terms in {2, 3, 16} with the tap-pair weight image of (9b). */
+ * y: [N, Cout, ceil(Hin/2), ceil(Win/2)] NCHW, channels-last if out_nhwc == 1, an SP map (9e) if out_nhwc == 2 (terms 16).  terms in {2, 3, 16} with the tap-pair weight image of (9b). */
 int coalign_conv3x3_emu_sparse(const float *feats, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y, int N, int Cin,
                                int Cout, int Hin, int Win, int relu, int terms, int out_nhwc, void *stream);
 

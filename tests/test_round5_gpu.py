@@ -177,3 +177,129 @@ def test_trained_like_parameters_vs_oracle_default_arithmetic(case):
     assert boxes.shape == rb.shape and rb.shape[0] > 20
     np.testing.assert_allclose(scores.cpu().numpy(), rs.numpy(), rtol=3e-7, atol=0)
     np.testing.assert_allclose(boxes.cpu().numpy(), rb.numpy(), rtol=2e-6, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ SplitMaps and the producer-split convolution
+def round22(x):
+    return ((x.contiguous().view(torch.int32) + 2) & -4).view(torch.float32)
+
+
+def test_split_map_pack_unpack_and_layout():
+    """unpack(pack(x)) = x rounded to 22 significant bits (ties away), from NCHW and channels-last inputs, to both output layouts; the unpack kernel agrees
+    with the layout's definition evaluated in torch (SplitMap.dense_reference); re-packing a packed map reproduces it bit for bit (pairs are canonical)."""
+    g = torch.Generator(device=DEV).manual_seed(1)
+    for shape in ((2, 32, 7, 13), (1, 16, 1, 1), (3, 64, 25, 88)):
+        x = torch.randn(shape, generator=g, device=DEV) * torch.logspace(-3, 3, shape[1], device=DEV).view(1, -1, 1, 1)
+        x[0, 0, 0, 0] = 0.0
+        want = round22(x)
+        for xin in (x, x.contiguous(memory_format=torch.channels_last)):
+            sm = ops.SplitMap.pack(xin)
+            assert sm.shape == tuple(shape)
+            assert torch.equal(sm.dense(), want) and torch.equal(sm.dense(channels_last=True), want)
+            assert torch.equal(sm.dense_reference(), want)
+            assert torch.equal(ops.SplitMap.pack(sm.dense()).data, sm.data)
+        assert float((want - x).abs().max() / x.abs().max()) < 2.0 ** -22
+    assert not ops.sp_range_exceeded(DEV)
+    ops.SplitMap.pack(torch.full((1, 16, 2, 2), 7.0e4, device=DEV))
+    assert ops.sp_range_exceeded(DEV) and not ops.sp_range_exceeded(DEV)          # reported once, then cleared
+
+
+SP_SHAPES = [(1, 16, 64, 4, 4), (2, 16, 64, 5, 6), (1, 32, 128, 6, 35), (3, 16, 64, 9, 18), (2, 48, 64, 25, 88), (2, 64, 64, 16, 33), (1, 16, 192, 1, 1),
+             (5, 32, 64, 7, 3), (3, 32, 64, 26, 40), (2, 32, 64, 50, 48)]
+
+
+@pytest.mark.parametrize("geometry", [81, 121, 124, 148])
+@pytest.mark.parametrize("shape", SP_SHAPES)
+def test_conv3x3_sp_equals_consumer_split_kernel_bit_for_bit(shape, geometry):
+    """The producer-split kernel (csrc/conv3x3_sp.hip) against the fp16 mode of csrc/conv3x3_emu.hip on the same 22-bit inputs: identical bits, for every
+    tile geometry, batches tiled as one tall image (boundaries inside tiles) and per image, ragged widths, no / SplitMap / channels-last float32 residual,
+    SplitMap and channels-last float32 outputs, with and without ReLU (resblock.py:53-69)."""
+    N, Ci, Co, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(sum(shape) + geometry)
+    x = round22(torch.randn((N, Ci, H, W), generator=g, device=DEV))
+    w = torch.randn((Co, Ci, 3, 3), generator=g, device=DEV) / (9 * Ci) ** 0.5
+    b = torch.randn(Co, generator=g, device=DEV)
+    r = round22(torch.randn((N, Co, H, W), generator=g, device=DEV))
+    w16 = ops.pack_conv3x3_emu_weight(w, 16, True)
+    xs, rs = ops.SplitMap.pack(x), ops.SplitMap.pack(r)
+    assert torch.equal(xs.dense(), x)
+    for res_kind, relu in (("none", True), ("split", True), ("nhwc", False)):
+        res_old = None if res_kind == "none" else r
+        res_new = None if res_kind == "none" else rs if res_kind == "split" else r.contiguous(memory_format=torch.channels_last)
+        want = ops.conv3x3_emu_bias_act(x, w16, b, Co, res_old, relu, 16)
+        got_cl = ops.conv3x3_sp(xs, w16, b, Co, res_new, relu, out_split=False, geometry=geometry)
+        assert got_cl.shape == want.shape and torch.equal(got_cl, want), (shape, geometry, res_kind, float((got_cl - want).abs().max()))
+        got_sp = ops.conv3x3_sp(xs, w16, b, Co, res_new, relu, out_split=True, geometry=geometry)
+        assert torch.equal(got_sp.dense(), round22(want)), (shape, geometry, res_kind)
+    assert not ops.sp_range_exceeded(DEV)
+
+
+@pytest.mark.parametrize("shape", [(5, 64, 64, 100, 352), (5, 128, 128, 50, 176), (5, 256, 256, 25, 88), (1, 256, 256, 100, 352), (2, 64, 64, 100, 252), (2, 256, 256, 25, 63)])
+def test_conv3x3_sp_backbone_shapes_bit_equal_and_against_float64(shape):
+    """The stride-1 backbone shapes with the geometry the product picks: bit-equal to the consumer-split kernel, error against float64 <= 2e-6 of the scale."""
+    N, Ci, Co, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = round22(torch.relu(torch.randn((N, Ci, H, W), generator=g, device=DEV)))
+    w = torch.randn((Co, Ci, 3, 3), generator=g, device=DEV) / (9 * Ci) ** 0.5
+    b = torch.randn(Co, generator=g, device=DEV)
+    r = round22(torch.randn((N, Co, H, W), generator=g, device=DEV))
+    w16 = ops.pack_conv3x3_emu_weight(w, 16, True)
+    xs, rs = ops.SplitMap.pack(x), ops.SplitMap.pack(r)
+    want = ops.conv3x3_emu_bias_act(x, w16, b, Co, r, True, 16)
+    got = ops.conv3x3_sp(xs, w16, b, Co, rs, True, out_split=False)
+    assert torch.equal(got, want)
+    ref = conv64(x, w, b, r)
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    got_sp = ops.conv3x3_sp(xs, w16, b, Co, rs, True, out_split=True)
+    assert torch.equal(got_sp.dense(), round22(want))
+
+
+def test_consumer_split_kernels_write_split_maps():
+    """The layers in front of a SplitMap chain: the strided kernels (NCHW / channels-last input) and the tap-major stride-1 kernel on an NCHW input with
+    ``out_split``: the SplitMap holds exactly the float32 output of the same kernel rounded to 22 bits."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for (N, Ci, Co, H, W) in ((2, 64, 64, 20, 70), (5, 64, 128, 100, 352), (2, 128, 256, 50, 126)):
+        x = torch.randn((N, Ci, H, W), generator=g, device=DEV)
+        w = torch.randn((Co, Ci, 3, 3), generator=g, device=DEV) / (9 * Ci) ** 0.5
+        b = torch.randn(Co, generator=g, device=DEV)
+        ws = ops.pack_conv3x3_emu_weight(w, 16, False)
+        for xin in (x, x.contiguous(memory_format=torch.channels_last)):
+            want = ops.conv3x3_emu_bias_act(xin, ws, b, Co, None, True, 16, stride=2)
+            got = ops.conv3x3_emu_bias_act(xin, ws, b, Co, None, True, 16, stride=2, out_split=True)
+            assert isinstance(got, ops.SplitMap) and got.shape == tuple(want.shape)
+            assert torch.equal(got.dense(), round22(want)), (N, Ci, Co, H, W)
+    for (N, Ci, Co, H, W) in ((1, 384, 256, 100, 352), (2, 32, 64, 9, 40), (5, 128, 128, 50, 176), (5, 256, 256, 25, 88)):
+        x = torch.randn((N, Ci, H, W), generator=g, device=DEV)
+        w = torch.randn((Co, Ci, 3, 3), generator=g, device=DEV) / (9 * Ci) ** 0.5
+        b = torch.randn(Co, generator=g, device=DEV)
+        wt = ops.pack_conv3x3_emu_weight(w, 16, True)
+        want = ops.conv3x3_emu_bias_act(x, wt, b, Co, None, True, 16)
+        got = ops.conv3x3_emu_bias_act(x, wt, b, Co, None, True, 16, out_split=True)
+        assert torch.equal(got.dense(), round22(want)), (N, Ci, Co, H, W)
+
+
+def test_split_map_route_equals_consumer_split_route_on_the_model():
+    """The whole detector on the SplitMap route (default) against the same model with COALIGN_SPLIT_MAPS off: the stage outputs differ only by the 22-bit
+    rounding of the intermediate maps (the consumer-split kernels round the same values when they read them, so the heads agree to ~1e-6), and both meet
+    the oracle bound."""
+    from coalign_amd import backbone as bb_mod
+    h = builtin_config("opv2v_coalign")
+    model = build_model(h)
+    from coalign_amd.synthetic import fill_parameters_
+    fill_parameters_(model, seed=0, cls_bias=-1.5)
+    model = model.to(DEV).eval()
+    fd = to_device(make_frame(h, 2, pillars_per_agent=6000, seed=77, noise=(0.2, 0.2)), DEV)
+    assert bb_mod.split_maps_active()
+    with torch.no_grad():
+        out_sp = model(fd)
+        saved = bb_mod.SPLIT_MAPS
+        try:
+            bb_mod.SPLIT_MAPS = False
+            out_cs = model(fd)
+        finally:
+            bb_mod.SPLIT_MAPS = saved
+    for k in ("cls_preds", "reg_preds", "dir_preds"):
+        e = rel_err(out_sp[k], out_cs[k])
+        print(f"\nsplit-map route vs consumer-split route {k}: {e:.2e}", end="")
+        assert e < 2e-5, k
+    assert not ops.sp_range_exceeded(DEV)
