@@ -394,14 +394,14 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         // (a lane without an output pixel reads the residual of pixel 0 of image 0: a block of several rows may end past the last image)
         const size_t obase = ((size_t)(live ? out_n : 0) * a.Cout + cur.cg * kCoutTile + cb + 4 * half) * plane + (live ? (size_t)gy * a.W + gx : 0);
         const float *bias = a.bias + cur.cg * kCoutTile + cb + 4 * half;
-        const float *winv = DUAL ? a.wscale + cur.cg * kCoutTile + cb + 4 * half : nullptr, *wsc = DUAL ? winv + a.Cout : nullptr;
+        const float *winv = DUAL ? a.wscale + cur.cg * kCoutTile + cb + 4 * half : nullptr;
         // a wavefront whose output rows lie below the map (the last row tile: 108 rows for 100, 56 for 50, 32 for 25) still stages pixels,
         // issues weight transfers and meets the barriers, but runs no matrix steps: its share of the padded work costs no energy
         const bool wave_live = __builtin_amdgcn_readfirstlane((int)(cur.y0 + blk_y * BH < (STACK ? a.N * a.H : a.H) && cur.x0 + blk_x * BW < a.W)) != 0;
         floatx16 acc[G::NCO], accl[DUAL ? G::NCO : 1];
 #pragma unroll
         for (int q = 0; q < (DUAL ? G::NCO : 1); ++q) accl[q] = floatx16{0};
-        if ((SPLIT && !head) || !wave_live) {
+        if ((SPLIT && !head) || !wave_live || DUAL) {      // (fp16 split: bias + residual are added in the epilogue, y = tile * 2^-k_c + (residual + bias), as conv3x3_sp.hip)
 #pragma unroll
             for (int q = 0; q < G::NCO; ++q) acc[q] = floatx16{0};
         } else if (a.residual) {
@@ -409,13 +409,12 @@ void conv3x3_emu_kernel(const EmuArgs a) {
             for (int q = 0; q < 16 * G::NCO; ++q) {
                 const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
                 acc[q / 16][q % 16] = a.residual[obase + (size_t)c * plane] + bias[c];
-                if constexpr (DUAL) acc[q / 16][q % 16] *= wsc[c];
             }
         } else {
 #pragma unroll
             for (int q = 0; q < 16 * G::NCO; ++q) {
                 const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
-                acc[q / 16][q % 16] = DUAL ? bias[c] * wsc[c] : bias[c];
+                acc[q / 16][q % 16] = bias[c];
             }
         }
         Tile next = cur;
@@ -556,7 +555,8 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        v[j] = acc[r / 4][4 * (r % 4) + j] * winv[(r / 4) * 32 + 8 * (r % 4) + j];
+                        const int c = (r / 4) * 32 + 8 * (r % 4) + j;
+                        v[j] = acc[r / 4][4 * (r % 4) + j] * winv[c] + bias[c];       // (SP outputs take no residual)
                         if (a.relu) v[j] = fmaxf(v[j], 0.f);
                     }
                     unsigned h01, l01, h23, l23;
@@ -578,8 +578,14 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                         float4 o;
                         o.x = acc[r / 4][4 * (r % 4)]; o.y = acc[r / 4][4 * (r % 4) + 1]; o.z = acc[r / 4][4 * (r % 4) + 2]; o.w = acc[r / 4][4 * (r % 4) + 3];
                         if constexpr (DUAL) {
-                            const float *wi4 = winv + (r / 4) * 32 + 8 * (r % 4);
-                            o.x *= wi4[0]; o.y *= wi4[1]; o.z *= wi4[2]; o.w *= wi4[3];
+                            const int c0 = (r / 4) * 32 + 8 * (r % 4);
+                            const float *wi4 = winv + c0, *b4 = bias + c0;
+                            float r4[4] = {0.f, 0.f, 0.f, 0.f};
+                            if (a.residual) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) r4[j] = a.residual[obase + (size_t)(c0 + j) * plane];
+                            }
+                            o.x = o.x * wi4[0] + (r4[0] + b4[0]); o.y = o.y * wi4[1] + (r4[1] + b4[1]); o.z = o.z * wi4[2] + (r4[2] + b4[2]); o.w = o.w * wi4[3] + (r4[3] + b4[3]);
                         }
                         if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
                         *reinterpret_cast<float4 *>(yp + (r / 4) * 32 + 8 * (r % 4)) = o;
@@ -588,7 +594,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
 #pragma unroll
                     for (int q = 0; q < 16 * G::NCO; ++q) {
                         const int c = (q / 16) * 32 + 8 * ((q % 16) / 4) + (q % 4);
-                        const float v = DUAL ? acc[q / 16][q % 16] * winv[c] : acc[q / 16][q % 16];
+                        const float v = DUAL ? acc[q / 16][q % 16] * winv[c] + ((a.residual ? a.residual[obase + (size_t)c * plane] : 0.f) + bias[c]) : acc[q / 16][q % 16];
                         a.y[obase + (size_t)c * plane] = a.relu ? fmaxf(v, 0.f) : v;
                     }
                 }

@@ -39,7 +39,21 @@ struct SpArgs {
     void *__restrict__ y;               // SP map or channels-last fp32, per the OUT template argument
     int *range_flag;                    // may be NULL: bit 0 is set when an SP output value exceeds the pair's range (|y| > 65504)
     int N, Cin, Cout, H, W, relu, res_kind, stack, tiles_x, tiles_y, total_tiles, xcd;
+#ifdef SP_TRACE
+    long long *trace;                   // profiling aid (tools/trace_conv_sp.py): [2 workgroups][16 waves][64 intervals][8 stamps] + [grid][2] wall clocks
+    int ablate;                         // 1: no weight DMA, 2: no patch DMA, 4: no matrix steps (no LDS reads either), 8: no residual / bias start, 16: no stores
+#endif
 };
+
+#ifdef SP_TRACE
+#define SP_STAMP(k)                                                                                              \
+    if ((g == 0 || g == 100) && lane == 0 && L < 64)                                                             \
+        a.trace[((((g ? 1 : 0) * 16 + wave) * 64) + L) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime()
+#define SP_ABLATE(bit) (a.ablate & (bit))
+#else
+#define SP_STAMP(k)
+#define SP_ABLATE(bit) 0
+#endif
 
 template <int BH, int BW, int NPB, int NBX>
 struct Geo {
@@ -50,9 +64,9 @@ struct Geo {
     static constexpr int PW = NBX == 1 ? PWU : (PWU + 7) / 16 * 16 + 8;        // (as conv3x3_emu.hip: rows of a 4 x 8 block in alternating bank halves)
     static constexpr int PH = TH + 4;                                          // halo + the two zero rows of an image boundary inside the tile
     static constexpr int PIX = PH * PW, PIXP = (PIX + 63) / 64 * 64;           // groups per plane, padded to whole DMA instructions
-    static constexpr int PINS = PIXP / 64, PJ = (PINS + WAVES - 1) / WAVES;    // DMA instructions per plane / per wavefront and plane
+    static constexpr int PINS = PIXP / 64;                                     // DMA instructions per plane
     static constexpr int WQ = 9 * 2 * 2 * kCoutTile;                           // 16-byte groups of one interval's weights
-    static constexpr int WINS = WQ / 64, WJ = (WINS + WAVES - 1) / WAVES;
+    static constexpr int WINS = WQ / 64;
     static constexpr int W_BYTES = WQ * 16, B_BYTES = 4 * PIXP * 16;
     static constexpr size_t LDS_BYTES = 2 * (size_t)W_BYTES + 2 * (size_t)B_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
@@ -76,14 +90,28 @@ __device__ __forceinline__ void dma16(const uint4 *src, unsigned lds_byte) {    
 enum { SP_OUT_SP = 1, SP_OUT_NHWC = 2 };
 enum { SP_RES_NONE = 0, SP_RES_SP = 1, SP_RES_NHWC = 2 };
 
-template <int BH, int BW, int NPB, int NBX, int OUT>
+// MODE: who issues the LDS-DMA of the next interval, and when (measured: tools/trace_conv_sp.py)
+//   0  every wavefront its share, all at once behind the interval's barrier (the matrix pipe idles until the texture addresser has taken the ~70 instructions);
+//   1  every wavefront its share, one or two instructions behind each tap's matrix instructions;
+//   2  LOADER wavefronts: the first four wavefronts (one per SIMD) issue everything, the others start their matrix steps straight away -- a SIMD's
+//      loader runs its steps when its partners have finished theirs, the pipe never waits for the addresser.
+template <int BH, int BW, int NPB, int NBX, int MODE>
+struct Work {
+    using G = Geo<BH, BW, NPB, NBX>;
+    static constexpr int LOADERS = MODE == 2 ? 4 : G::WAVES;
+    static constexpr int WJ = (G::WINS + LOADERS - 1) / LOADERS, PJ = (G::PINS + LOADERS - 1) / LOADERS, OPS = WJ + 4 * PJ;
+};
+
+template <int BH, int BW, int NPB, int NBX, int OUT, int MODE>
 __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
     using G = Geo<BH, BW, NPB, NBX>;
+    using K = Work<BH, BW, NPB, NBX, MODE>;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;
     const int HW = a.H * a.W, CI16 = a.Cin / 16, CO16 = a.Cout / 16, groups = a.Cout / kCoutTile, chunks = CI16;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
     // LDS map: weight buffers 0 | 1, patch buffers 0 | 1
+    const bool loader = wave < K::LOADERS;
 
     const int blk_y = wave / NBX, blk_x = wave - blk_y * NBX;                 // this wavefront's pixel block inside the tile
     const int py = blk_y * BH + p / BW, px = blk_x * BW + p % BW;
@@ -109,19 +137,19 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
         }
         return c;
     };
-    // Patch plan of a tile: the lane's group of DMA instruction (wave + WAVES * j) of a plane = patch pixel 64 * (wave + WAVES * j) + lane; its offset (in
+    // Patch plan of a tile: the lane's group of DMA instruction (wave + LOADERS * j) of a plane = patch pixel 64 * (wave + LOADERS * j) + lane; its offset (in
     // 16-byte groups) inside plane 0 of interval 0, or -1 for zero padding.  Patch rows (see conv3x3_emu.hip): 0 .. yb rows yl0 - 1 .. H - 1 of image n0,
     // yb + 1 and yb + 2 zero, yb + 3 .. rows 0 .. of image n0 + 1; without a boundary inside the tile (yb >= TH) rows yl0 - 1 .. yl0 + TH.
     struct Plan {
-        int off[G::PJ];
+        int off[K::PJ];
         const uint4 *wsrc;
     };
     auto make_plan = [&](const Tile &t) {
         Plan pl;
         pl.wsrc = a.wt + (size_t)t.cg * chunks * G::WQ + lane;
 #pragma unroll
-        for (int j = 0; j < G::PJ; ++j) {
-            const int i = (wave + G::WAVES * j) * 64 + lane;
+        for (int j = 0; j < K::PJ; ++j) {
+            const int i = (wave + K::LOADERS * j) * 64 + lane;
             const int y = i / G::PW, xq = i - y * G::PW, gx = t.x0 - 1 + xq;
             bool ok = i < G::PIX && xq < G::PWU && gx >= 0 && gx < a.W;
             int gy, img = 0;
@@ -134,23 +162,20 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
         }
         return pl;
     };
-    // everything interval c of the tile needs, by LDS-DMA into buffer `slot`: the weights (36 instructions per workgroup) and the four patch planes
-    auto issue = [&](const Plan &pl, int c, int slot) {
-        const uint4 *wsrc = pl.wsrc + (size_t)c * G::WQ;
-#pragma unroll
-        for (int j = 0; j < G::WJ; ++j) {
-            const int ins = wave + G::WAVES * j;
-            if (ins < G::WINS) dma16(wsrc + ins * 64, lds0 + slot * G::W_BYTES + ins * 1024);
+    // DMA operation k of this wavefront for interval c into buffer `slot`: k < WJ a 1 KB piece of the weights, then the four planes of patch piece j
+    auto issue_op = [&](const Plan &pl, int c, int slot, int k) {
+        if (k < K::WJ) {
+            const int ins = wave + K::LOADERS * k;
+            if (ins < G::WINS && !SP_ABLATE(1)) dma16(pl.wsrc + (size_t)c * G::WQ + ins * 64, lds0 + slot * G::W_BYTES + ins * 1024);
+        } else {
+            const int j = (k - K::WJ) / 4, q = (k - K::WJ) % 4, ins = wave + K::LOADERS * j;
+            if (ins < G::PINS && !SP_ABLATE(2))
+                dma16(pl.off[j] < 0 ? a.zero : a.x + (size_t)pl.off[j] + ((size_t)c * 4 + q) * HW, lds0 + 2 * G::W_BYTES + slot * G::B_BYTES + (q * G::PIXP + ins * 64) * 16);
         }
+    };
+    auto issue_all = [&](const Plan &pl, int c, int slot) {
 #pragma unroll
-        for (int j = 0; j < G::PJ; ++j) {
-            const int ins = wave + G::WAVES * j;
-            if (ins < G::PINS) {
-                const uint4 *src0 = a.x + (size_t)(pl.off[j] < 0 ? 0 : pl.off[j]) + (size_t)c * 4 * HW;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dma16(pl.off[j] < 0 ? a.zero : src0 + (size_t)q * HW, lds0 + 2 * G::W_BYTES + slot * G::B_BYTES + (q * G::PIXP + ins * 64) * 16);
-            }
-        }
+        for (int k = 0; k < K::OPS; ++k) issue_op(pl, c, slot, k);
     };
 
     // persistent workgroups over whole tiles g, g + n, ...; XCD k takes the k-th eighth of the logical ids (neighbouring tiles share input rows and weights in its L2)
@@ -162,11 +187,17 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
     }
     const int n_local = ((a.total_tiles - g + n_wg - 1) / n_wg) * chunks;
     if (n_local <= 0) return;
+#ifdef SP_TRACE
+    if (tid == 0) a.trace[2 * 16 * 64 * 8 + 2 * g] = wall_clock64();
+#endif
     int tile = g;
     Tile cur = decode(tile);
-    Plan plan = make_plan(cur);
-    issue(plan, 0, 0);
-    if (wave >= G::WAVES / 2) __builtin_amdgcn_s_setprio(1);      // (as conv3x3_emu.hip: the later-dispatched half of the wavefronts loses every arbitration otherwise)
+    Plan plan{};
+    if (loader) {
+        plan = make_plan(cur);
+        issue_all(plan, 0, 0);
+    }
+    if (MODE != 2 && wave >= G::WAVES / 2) __builtin_amdgcn_s_setprio(1);      // (as conv3x3_emu.hip: the later-dispatched half of the wavefronts loses every arbitration otherwise)
     int L = 0;
     while (L < n_local) {
         // this lane's output pixel: image out_n, row gy, column gx; rows at / past an image boundary read the patch two rows lower
@@ -177,48 +208,49 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
         const bool wave_live = __builtin_amdgcn_readfirstlane((int)(cur.n0 * a.H + cur.yl0 + blk_y * BH < (a.stack ? a.N * a.H : cur.n0 * a.H + a.H) && cur.x0 + blk_x * BW < a.W)) != 0;
         const size_t pix = live ? (size_t)gy * a.W + gx : 0;
         const int on = live ? out_n : 0;
-        const float *bias = a.bias + cur.cg * kCoutTile + 4 * half, *winv = a.wscale + cur.cg * kCoutTile + 4 * half, *wsc = winv + a.Cout;
         floatx16 acc[2], accl[2];
+        acc[0] = floatx16{0};
+        acc[1] = floatx16{0};
         accl[0] = floatx16{0};
         accl[1] = floatx16{0};
-        if (!wave_live) {
-            acc[0] = floatx16{0};
-            acc[1] = floatx16{0};
-        } else {
+        uint4 rraw[8];                                             // the residual of this lane's 32 outputs, fetched behind the barrier of the tile's LAST interval
 #pragma unroll
-            for (int g8 = 0; g8 < 8; ++g8) {                       // 8 groups of 4 consecutive channels per lane: channel = 8 g8 + 4 half + j
-                float r[4] = {0.f, 0.f, 0.f, 0.f};
-                if (a.res_kind == SP_RES_SP) {
-                    const size_t idx = ((size_t)(on * CO16 + cur.cg * 4 + g8 / 2) * 4 + (g8 % 2) * 2) * HW + pix;
-                    const uint2 *rp = reinterpret_cast<const uint2 *>(a.residual);
-                    const halfx4 h = __builtin_bit_cast(halfx4, rp[idx * 2 + half]), l = __builtin_bit_cast(halfx4, rp[(idx + HW) * 2 + half]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) r[j] = coalign::sp16_join(h[j], l[j]);
-                } else if (a.res_kind == SP_RES_NHWC) {
-                    const float4 v = *reinterpret_cast<const float4 *>(static_cast<const float *>(a.residual) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half + 8 * g8);
-                    r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[g8 / 4][4 * (g8 % 4) + j] = (r[j] + bias[8 * g8 + j]) * wsc[8 * g8 + j];
-            }
-        }
+        for (int g8 = 0; g8 < 8; ++g8) rraw[g8] = uint4{0, 0, 0, 0};
         Tile next = cur;
         Plan nplan = plan;
         int ntile = tile;
         for (int chunk = 0; chunk < chunks; ++chunk, ++L) {
+            SP_STAMP(0);
             __builtin_amdgcn_s_waitcnt(0);
+            SP_STAMP(1);
             __syncthreads();
-            if (L + 1 < n_local) {
-                int nc = chunk + 1;
-                if (nc == chunks) {                                // the next interval opens this workgroup's next tile
-                    nc = 0;
-                    ntile = tile + n_wg;
-                    next = decode(ntile);
-                    nplan = make_plan(next);
-                }
-                issue(nplan, nc, (L + 1) & 1);
+            SP_STAMP(2);
+            const bool more = L + 1 < n_local;
+            int nc = chunk + 1;
+            if (more && nc == chunks) {                            // the next interval opens this workgroup's next tile
+                nc = 0;
+                ntile = tile + n_wg;
+                next = decode(ntile);
+                if (loader) nplan = make_plan(next);
             }
-            if (wave_live) {
+            if (MODE != 1 && more && loader) issue_all(nplan, nc, (L + 1) & 1);
+            if (chunk == chunks - 1 && wave_live && !SP_ABLATE(8)) {
+                if (a.res_kind == SP_RES_SP) {                     // h groups | l groups: 8 bytes each per (lane, 8-channel group)
+                    const uint2 *rp = reinterpret_cast<const uint2 *>(a.residual);
+#pragma unroll
+                    for (int g8 = 0; g8 < 8; ++g8) {
+                        const size_t idx = ((size_t)(on * CO16 + cur.cg * 4 + g8 / 2) * 4 + (g8 % 2) * 2) * HW + pix;
+                        const uint2 h = rp[idx * 2 + half], l = rp[(idx + HW) * 2 + half];
+                        rraw[g8] = uint4{h.x, h.y, l.x, l.y};
+                    }
+                } else if (a.res_kind == SP_RES_NHWC) {
+                    const uint4 *rp = reinterpret_cast<const uint4 *>(static_cast<const float *>(a.residual) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half);
+#pragma unroll
+                    for (int g8 = 0; g8 < 8; ++g8) rraw[g8] = rp[2 * g8];
+                }
+            }
+            SP_STAMP(3);
+            if (wave_live && !SP_ABLATE(4)) {
                 const uint4 *bq = reinterpret_cast<const uint4 *>(lds + 2 * G::W_BYTES + (L & 1) * G::B_BYTES) + bshift, *wq = reinterpret_cast<const uint4 *>(lds + (L & 1) * G::W_BYTES) + wlane;
                 auto load_b = [&](int s, halfx8 (&b)[2]) {
 #pragma unroll
@@ -246,6 +278,12 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
                     for (int q = 0; q < 2; ++q) accl[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[q][1], bc[0], accl[q], 0, 0, 0);      // w_l' x_h
 #pragma unroll
                     for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[q][0], bc[0], acc[q], 0, 0, 0);        // w_h x_h
+                    if constexpr (MODE == 1) {
+                        if (more) {
+#pragma unroll
+                            for (int k = s; k < K::OPS; k += 9) issue_op(nplan, nc, (L + 1) & 1, k);
+                        }
+                    }
                     if (s + 1 < 9) {
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
@@ -255,21 +293,36 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
                         }
                     }
                 }
+            } else if (MODE == 1 && more) {
+                issue_all(nplan, nc, (L + 1) & 1);
             }
+            SP_STAMP(4);
         }
-        // ---- epilogue: tile = (acc + 2^-10 accl) * 2^-k_c, ReLU, stored as an SP map or as channels-last fp32
+        // ---- epilogue: y = (acc + 2^-10 accl) * 2^-k_c + (residual + bias), ReLU, stored as an SP map or as channels-last fp32
+        const float4 *bias4 = reinterpret_cast<const float4 *>(a.bias + cur.cg * kCoutTile + 4 * half), *winv4 = reinterpret_cast<const float4 *>(a.wscale + cur.cg * kCoutTile + 4 * half);
         bool big = false;
 #pragma unroll
-        for (int g8 = 0; g8 < 8; ++g8) {
+        for (int g8 = 0; g8 < 8; ++g8) {                           // 8 groups of 4 consecutive channels per lane: channel = 8 g8 + 4 half + j
+            const float4 b4 = bias4[2 * g8], i4 = winv4[2 * g8];
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
+            float r[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.res_kind == SP_RES_SP) {
+                const halfx4 h = __builtin_bit_cast(halfx4, uint2{rraw[g8].x, rraw[g8].y}), l = __builtin_bit_cast(halfx4, uint2{rraw[g8].z, rraw[g8].w});
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = coalign::sp16_join(h[j], l[j]);
+            } else if (a.res_kind == SP_RES_NHWC) {
+                r[0] = __builtin_bit_cast(float, rraw[g8].x); r[1] = __builtin_bit_cast(float, rraw[g8].y);
+                r[2] = __builtin_bit_cast(float, rraw[g8].z); r[3] = __builtin_bit_cast(float, rraw[g8].w);
+            }
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int q = g8 / 4, r = 4 * (g8 % 4) + j;
-                v[j] = fmaf(accl[q][r], coalign::kSp16LowInv, acc[q][r]) * winv[8 * g8 + j];
+                const int q = g8 / 4, e = 4 * (g8 % 4) + j;
+                v[j] = fmaf(accl[q][e], coalign::kSp16LowInv, acc[q][e]) * ii[j] + (r[j] + bb[j]);
                 if (a.relu) v[j] = fmaxf(v[j], 0.f);
             }
             if constexpr (OUT == SP_OUT_NHWC) {
-                if (live) *reinterpret_cast<float4 *>(static_cast<float *>(a.y) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half + 8 * g8) = float4{v[0], v[1], v[2], v[3]};
+                if (live && !SP_ABLATE(16)) *reinterpret_cast<float4 *>(static_cast<float *>(a.y) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half + 8 * g8) = float4{v[0], v[1], v[2], v[3]};
             } else {
                 big = big || fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > 65504.f;
                 unsigned h01, l01, h23, l23;
@@ -278,7 +331,7 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
                 swap32(h01, l01);          // lanes 0-31: h of channels 0,1 | 4,5 of the 8-channel group; lanes 32-63: l of the same channels
                 swap32(h23, l23);
                 const size_t idx = ((size_t)(on * CO16 + cur.cg * 4 + g8 / 2) * 4 + (g8 % 2) * 2 + half) * HW + pix;      // plane = 2 * channel half + term: lanes 32-63 hold term 1
-                if (live) static_cast<uint4 *>(a.y)[idx] = uint4{h01, h23, l01, l23};
+                if (live && !SP_ABLATE(16)) static_cast<uint4 *>(a.y)[idx] = uint4{h01, h23, l01, l23};
             }
         }
         if constexpr (OUT == SP_OUT_SP) {
@@ -288,6 +341,9 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
         plan = nplan;
         tile = ntile;
     }
+#ifdef SP_TRACE
+    if (tid == 0) a.trace[2 * 16 * 64 * 8 + 2 * g + 1] = wall_clock64();
+#endif
 }
 
 // fp32 (NCHW or channels-last) -> SP map and back: the entry / exit of a chain of SP layers where no kernel epilogue does it, and the tests' yardstick
@@ -333,16 +389,16 @@ __global__ void sp_unpack_kernel(const uint4 *__restrict__ x, float *__restrict_
     }
 }
 
-template <int BH, int BW, int NPB, int NBX>
+template <int BH, int BW, int NPB, int NBX, int MODE>
 int launch_geo(SpArgs a, int out_kind, hipStream_t s) {
     using G = Geo<BH, BW, NPB, NBX>;
     constexpr int kMaxDev = 16;
-    static int resident[kMaxDev] = {0}, cus[kMaxDev] = {0};          // per device: the function attribute belongs to the device's code object
+    static int cus[kMaxDev] = {0};                                    // per device: the function attribute belongs to the device's code object
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
-    auto k_sp = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP>;
-    auto k_cl = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC>;
-    if (!resident[dev]) {
+    auto k_sp = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP, MODE>;
+    auto k_cl = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC, MODE>;
+    if (!cus[dev]) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
         for (const void *fn : {reinterpret_cast<const void *>(k_sp), reinterpret_cast<const void *>(k_cl)}) {
@@ -353,21 +409,38 @@ int launch_geo(SpArgs a, int out_kind, hipStream_t s) {
             }
         }
         cus[dev] = prop.multiProcessorCount;
-        resident[dev] = 1;                                            // 111-147 KB of LDS: one workgroup per CU
     }
     a.stack = (a.N > 1 && G::TH <= a.H) ? 1 : 0;
     a.tiles_x = (a.W + G::TW - 1) / G::TW;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;                            // per image (not stacked)
     const int row_tiles = a.stack ? (a.N * a.H + G::TH - 1) / G::TH : a.N * a.tiles_y;
     a.total_tiles = a.tiles_x * row_tiles * (a.Cout / kCoutTile);
-    const int slots = cus[dev] * resident[dev];
+    const int slots = cus[dev];                                       // 111-147 KB of LDS: one workgroup per CU
     const int grid = a.total_tiles < slots ? a.total_tiles : slots;
     if (out_kind == SP_OUT_SP) hipLaunchKernelGGL(k_sp, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
     else hipLaunchKernelGGL(k_cl, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
     return COALIGN_OK;
 }
 
+template <int MODE>
+int launch_mode(int geo, const SpArgs &a, int out_kind, hipStream_t s) {
+    switch (geo) {
+        case 81: return launch_geo<1, 32, 8, 1, MODE>(a, out_kind, s);       // 8 rows x 32 columns
+        case 121: return launch_geo<1, 32, 12, 1, MODE>(a, out_kind, s);     // 12 x 32
+        case 124: return launch_geo<2, 16, 12, 1, MODE>(a, out_kind, s);     // 24 x 16 (2 x 16 blocks)
+        case 148: return launch_geo<4, 8, 8, 4, MODE>(a, out_kind, s);       // 8 x 32 in 4 x 8 blocks, four block columns
+        default: return COALIGN_ERR_UNSUPPORTED;
+    }
+}
+
 }  // namespace
+
+#ifdef SP_TRACE
+static long long *g_sp_trace = nullptr;
+static int g_sp_ablate = 0;
+extern "C" void coalign_conv3x3_sp_set_trace(long long *p) { g_sp_trace = p; }
+extern "C" void coalign_conv3x3_sp_set_ablate(int v) { g_sp_ablate = v; }
+#endif
 
 extern "C" size_t coalign_sp_map_bytes(int N, int C, int H, int W) {
     if (N < 0 || C < 1 || H < 1 || W < 1 || C % 16) return 0;
@@ -416,9 +489,15 @@ extern "C" int coalign_conv3x3_sp(const void *x_sp, const void *w_split, const f
     a.range_flag = range_flag;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.relu = relu; a.res_kind = residual_kind;
     a.xcd = 1;
+#ifdef SP_TRACE
+    a.trace = g_sp_trace;
+    a.ablate = g_sp_ablate;
+#endif
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // geometry: 0 = chosen from the map size (the rules measured for conv3x3_emu.hip's fp16 mode), else 81 / 121 / 124 / 148 as there
-    int geo = geometry;
+    // geometry: 0 = chosen from the map size (the rules measured for conv3x3_emu.hip's fp16 mode), else 81 / 121 / 124 / 148 as there; + 1000 * issue mode
+    // (laboratory: 1000 = mode 0, 2000 = mode 1, 3000 = mode 2; see the kernel) -- the product uses kDefaultMode
+    constexpr int kDefaultMode = 2;
+    int geo = geometry % 1000, mode = geometry >= 1000 ? geometry / 1000 - 1 : kDefaultMode;
     if (geo == 0) {
         if (W % 32 == 16 && H > 26 && H <= 52 && N * H >= 24) geo = 124;
         else if (H >= 64) geo = 121;
@@ -426,12 +505,11 @@ extern "C" int coalign_conv3x3_sp(const void *x_sp, const void *w_split, const f
         else geo = 81;
     }
     int rc;
-    switch (geo) {
-        case 81: rc = launch_geo<1, 32, 8, 1>(a, out_kind, s); break;       // 8 rows x 32 columns
-        case 121: rc = launch_geo<1, 32, 12, 1>(a, out_kind, s); break;     // 12 x 32
-        case 124: rc = launch_geo<2, 16, 12, 1>(a, out_kind, s); break;     // 24 x 16 (2 x 16 blocks)
-        case 148: rc = launch_geo<4, 8, 8, 4>(a, out_kind, s); break;       // 8 x 32 in 4 x 8 blocks, four block columns
-        default: return COALIGN_ERR_UNSUPPORTED;
-    }
+#if defined(COALIGN_LAB) || defined(SP_TRACE)      // laboratory / trace builds carry all three issue modes
+    rc = mode == 0 ? launch_mode<0>(geo, a, out_kind, s) : mode == 1 ? launch_mode<1>(geo, a, out_kind, s) : launch_mode<2>(geo, a, out_kind, s);
+#else
+    (void)mode;
+    rc = launch_mode<kDefaultMode>(geo, a, out_kind, s);
+#endif
     return rc != COALIGN_OK ? rc : check_launch();
 }

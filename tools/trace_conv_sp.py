@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Per-interval timeline + ablations of conv3x3_sp_kernel (profiling aid): builds csrc/conv3x3_sp.hip with -DSP_TRACE into a private library
+(coalign_amd/lib/libsp_trace.so, built on the CPU side) and prints, per barrier interval of workgroup 0 (first and last wavefront), the shader clocks spent in
+  wait  : s_waitcnt(0) at the top (own DMA of this interval, own stores of a finished tile)      barrier : the interval's one barrier
+  issue : LDS-DMA of the next interval (+ next tile's plan at a tile's last interval)           steps   : LDS reads + matrix instructions
+  gap   : end of the steps to the top of the next interval (tile epilogue + next tile's start value, when a tile ends)
+and the kernel time with parts switched off.  Usage: python tools/trace_conv_sp.py N Cin Cout H W [geometry]"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+src = os.path.join(ROOT, "coalign_amd", "csrc")
+lib = os.path.join(ROOT, "coalign_amd", "lib", "libsp_trace.so")
+if not os.path.exists(lib) or os.environ.get("REBUILD"):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-vectorize", "--offload-arch=gfx950", "-shared", "-fPIC",
+                           "-DSP_TRACE", "-I", src, "-I", os.path.join(ROOT, "include"), os.path.join(src, "conv3x3_sp.hip"), os.path.join(src, "conv3x3_emu.hip"),
+                           os.path.join(src, "status.cpp"), "-o", lib])
+if not torch.cuda.is_available():
+    sys.exit(0)
+from coalign_amd import ops  # noqa: E402
+
+N, Ci, Co, H, W = [int(v) for v in sys.argv[1:6]] if len(sys.argv) > 5 else (5, 256, 256, 25, 88)
+geo = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+L = ctypes.CDLL(lib)
+P, I = ctypes.c_void_p, ctypes.c_int
+L.coalign_conv3x3_sp.argtypes = [P, P, P, P, I, P, I, I, I, I, I, I, I, I, P, P]
+x = torch.relu(torch.randn(N, Ci, H, W, device="cuda"))
+w = torch.randn(Co, Ci, 3, 3, device="cuda") / (Ci * 9) ** 0.5
+b = torch.randn(Co, device="cuda")
+r = torch.randn(N, Co, H, W, device="cuda")
+w16 = ops.pack_conv3x3_emu_weight(w, 16, True)
+xs, rs = ops.SplitMap.pack(x), ops.SplitMap.pack(r)
+out = ops.SplitMap.empty(N, Co, H, W, "cuda")
+waves, S = 16, 8
+tr = torch.zeros(2 * waves * 64 * S + 2 * 4096, dtype=torch.int64, device="cuda")
+L.coalign_conv3x3_sp_set_trace(P(tr.data_ptr()))
+
+
+def run(ablate=0, n=1):
+    L.coalign_conv3x3_sp_set_ablate(ablate)
+    for _ in range(n):
+        rc = L.coalign_conv3x3_sp(xs.data.data_ptr(), w16.data_ptr(), b.data_ptr(), rs.data.data_ptr(), 1, out.data.data_ptr(), 1, N, Ci, Co, H, W, 1, geo, None, None)
+        assert rc == 0, rc
+
+
+for _ in range(3):
+    tr.zero_()
+    run()
+    torch.cuda.synchronize()
+span = tr.cpu()[2 * waves * 64 * S:].view(-1, 2)
+span = span[span[:, 1] > 0]
+t0 = int(span[:, 0].min())
+st, en = (span[:, 0] - t0).float() / 100.0, (span[:, 1] - t0).float() / 100.0
+print(f"conv3x3_sp {N}x{Ci}->{Co} {H}x{W} geometry {geo}: {len(span)} workgroups: start median {st.median():.1f} max {st.max():.1f} us; end min {en.min():.1f} median {en.median():.1f} max {en.max():.1f} us")
+t = tr.cpu()[: 2 * waves * 64 * S].view(2, waves, 64, S)
+nw = int((t[0, :, 0, 0] > 0).sum())
+for wg in (0, 1):
+    for wv in (0, nw - 1):
+        if int(t[wg, wv, 0, 0]) == 0:
+            continue
+        print(f"workgroup {'0' if wg == 0 else '100'} wave {wv}: interval   wait barrier  issue  steps    gap | total (clocks)")
+        for c in range(40):
+            s = t[wg, wv, c]
+            if int(s[0]) == 0:
+                break
+            nxt = int(t[wg, wv, c + 1, 0]) if c + 1 < 64 and int(t[wg, wv, c + 1, 0]) else int(s[4])
+            d = [int(s[1] - s[0]), int(s[2] - s[1]), int(s[3] - s[2]), int(s[4] - s[3]), nxt - int(s[4])]
+            print(f"   {c:3d} " + " ".join(f"{v:7d}" for v in d) + f" | {nxt - int(s[0]):7d}")
+
+
+def timed(ablate):
+    run(ablate, 3)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    run(ablate, 20)
+    e.record()
+    torch.cuda.synchronize()
+    return round(s.elapsed_time(e) / 20 * 1e3, 1)
+
+
+names = {0: "all", 1: "no weight DMA", 2: "no patch DMA", 3: "no DMA", 4: "no matrix steps / LDS reads", 7: "barriers + tile start / end only", 8: "no residual / bias start", 16: "no stores",
+         24: "no tile start / stores", 28: "DMA + barriers only"}
+print("kernel us by ablation (trace build with the stamps on, eager launches):", {v: timed(k) for k, v in names.items()})
