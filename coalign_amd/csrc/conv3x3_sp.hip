@@ -496,7 +496,7 @@ extern "C" int coalign_conv3x3_sp(const void *x_sp, const void *w_split, const f
     hipStream_t s = static_cast<hipStream_t>(stream);
     // geometry: 0 = chosen from the map size (the rules measured for conv3x3_emu.hip's fp16 mode), else 81 / 121 / 124 / 148 as there; + 1000 * issue mode
     // (laboratory: 1000 = mode 0, 2000 = mode 1, 3000 = mode 2; see the kernel) -- the product uses kDefaultMode
-    constexpr int kDefaultMode = 2;
+    constexpr int kDefaultMode = 1;
     int geo = geometry % 1000, mode = geometry >= 1000 ? geometry / 1000 - 1 : kDefaultMode;
     if (geo == 0) {
         if (W % 32 == 16 && H > 26 && H <= 52 && N * H >= 24) geo = 124;

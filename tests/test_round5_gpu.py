@@ -229,9 +229,10 @@ def test_conv3x3_sp_equals_consumer_split_kernel_bit_for_bit(shape, geometry):
     x = round22(torch.randn((N, Ci, H, W), generator=g, device=DEV))
     w = torch.randn((Co, Ci, 3, 3), generator=g, device=DEV) / (9 * Ci) ** 0.5
     b = torch.randn(Co, generator=g, device=DEV)
-    r = round22(torch.randn((N, Co, H, W), generator=g, device=DEV))
+    rs = ops.SplitMap.pack(torch.randn((N, Co, H, W), generator=g, device=DEV))
+    r = rs.dense()                                     # (what the pairs hold: values below 2^-13 are not exactly the 22-bit rounding)
     w16 = ops.pack_conv3x3_emu_weight(w, 16, True)
-    xs, rs = ops.SplitMap.pack(x), ops.SplitMap.pack(r)
+    xs = ops.SplitMap.pack(x)
     for res_kind, relu in (("none", True), ("split", True), ("nhwc", False)):
         res_old = None if res_kind == "none" else r
         res_new = None if res_kind == "none" else rs if res_kind == "split" else r.contiguous(memory_format=torch.channels_last)
@@ -251,9 +252,10 @@ def test_conv3x3_sp_backbone_shapes_bit_equal_and_against_float64(shape):
     x = round22(torch.relu(torch.randn((N, Ci, H, W), generator=g, device=DEV)))
     w = torch.randn((Co, Ci, 3, 3), generator=g, device=DEV) / (9 * Ci) ** 0.5
     b = torch.randn(Co, generator=g, device=DEV)
-    r = round22(torch.randn((N, Co, H, W), generator=g, device=DEV))
+    rs = ops.SplitMap.pack(torch.randn((N, Co, H, W), generator=g, device=DEV))
+    r = rs.dense()                                     # (what the pairs hold: values below 2^-13 are not exactly the 22-bit rounding)
     w16 = ops.pack_conv3x3_emu_weight(w, 16, True)
-    xs, rs = ops.SplitMap.pack(x), ops.SplitMap.pack(r)
+    xs = ops.SplitMap.pack(x)
     want = ops.conv3x3_emu_bias_act(x, w16, b, Co, r, True, 16)
     got = ops.conv3x3_sp(xs, w16, b, Co, rs, True, out_split=False)
     assert torch.equal(got, want)
