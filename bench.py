@@ -9,7 +9,9 @@ Metric (BASELINE.json): frames/s on synthetic 5-agent OPV2V-shaped scenes.  A st
 path (pillar encode + scatter -> BEV backbone -> pose-aware warp + attention fusion at 3 scales -> heads ->
 decode + rotated NMS) over one frame per rank; inputs are resident in HBM before the timed region and the timed loop
 ROTATES over a pool of distinct frames.  The loop is ``coalign_amd.pipeline.FramePipeline`` -- the product's frame runner
-(4 frames in flight on separate HIP streams, one HIP graph replay per frame), the same object the parity tests drive.  With R ranks a step
+(3 frames in flight on separate HIP streams, one HIP graph replay per frame; with R > 1 ranks two replays -- encoder, ego tail -- around the lane's
+collective), the same object the parity tests drive.  ``python bench.py --gpus N`` without a launcher starts its N ranks itself (torch.distributed.run,
+127.0.0.1) and refuses to run when fewer than N devices are visible.  With R ranks a step
 processes R frames in the agent-sharded "frame ring" of coalign_amd/sharded.py (weak scaling): every rank encodes the
 agents the ring assigns to it out of the SAME frame pool, so the per-frame detection checksums printed here are equal
 for every --gpus value.  Rank 0 prints ONE JSON line; it carries the roofline of the dominant hand-written kernel, the
@@ -21,11 +23,33 @@ import os
 import sys
 import time
 
-# Multi-rank runs are eager (collectives between encoder and tail): four lanes + their post-processing side streams are more HIP streams than the runtime's
-# default four hardware queues, and streams that share a queue serialise (498 -> 514 frames/s for four lanes on one GPU with eight
+# Multi-rank runs: lanes + the collective backend's streams (+ the post-processing side streams of an eager fall-back) are more HIP streams than the runtime's
+# default four hardware queues, and streams that share a queue serialise (498 -> 514 frames/s for four eager lanes on one GPU with eight
 # queues; three graph lanes -- the single-GPU default -- are not affected and keep the runtime's default).  Must be set before the HIP runtime starts.
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+def self_launch(n: int) -> None:
+    """``python bench.py --gpus N`` (N > 1) without a launcher: become ``torch.distributed.run --nproc-per-node N`` of this very command line (the reference's
+    own bring-up is a launcher too: opencood/tools/multi_gpu_utils.py:31-37).  Never returns.  Fewer than N visible devices: exit 2 with the reason -- an
+    N = 1 line for an N = 8 request would be worse than no line."""
+    import socket
+    import torch
+    one_gpu = os.environ.get("COALIGN_BENCH_ONE_GPU") == "1" or "--launch-check" in sys.argv      # functional tests: ranks share device 0 / need no device
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not one_gpu and have < n:
+        print(f"bench: --gpus {n} requested but {have} GPU(s) are visible to this process: not launching (a smaller run would print a misleading line)", file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, COALIGN_BENCH_SELF_LAUNCHED="1", GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "8"), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench: self-launch: " + " ".join(cmd), file=sys.stderr, flush=True)
+    os.execvpe(sys.executable, cmd, env)
 
 import torch
 import torch.distributed as dist
@@ -231,6 +255,8 @@ def main():
                     "on every rank, so one communicator is deadlock-free by construction; several communicators used concurrently are not)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: build the exchange plans and shape-only buffers of EVERY rank for --gpus N and validate them against what "
                     "RCCL's all_to_all_single / all_gather_into_tensor require (coalign_amd.sharded.preflight); prints the report as one JSON line")
+    ap.add_argument("--launch-check", action="store_true", help="no GPU work: bring the ranks up (self-launch included), one all-reduce over gloo, rank 0 prints {launch_check, world, "
+                    "n_gpus} as one JSON line -- the CPU test of `python bench.py --gpus N` launching N ranks by itself (tests/test_sharded_cpu.py)")
     ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the oracle (0 = best of the committed sweep, else 16)")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
@@ -247,11 +273,25 @@ def main():
         print(json.dumps(rep), flush=True)
         return
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)                                     # (does not return)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    if args.launch_check:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        ok = int(t.item()) == world * (world + 1) // 2
+        if rank == 0:
+            print(json.dumps({"launch_check": bool(ok), "world": world, "n_gpus": world, "launcher": "self" if os.environ.get("COALIGN_BENCH_SELF_LAUNCHED") == "1" else "external"}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        if not ok:
+            raise SystemExit(3)
+        return
     # COALIGN_BENCH_BACKEND=gloo + COALIGN_BENCH_ONE_GPU=1: functional test of the multi-rank code path on a single
     # GPU (ranks share device 0, the exchange is staged through host memory).  Never used for reported numbers.
     backend = os.environ.get("COALIGN_BENCH_BACKEND", "nccl")
@@ -299,7 +339,7 @@ def main():
                 dist.broadcast(buf, 0)
                 p.data.copy_(buf)
 
-    use_graph = (not args.no_graph) and world == 1
+    use_graph = not args.no_graph          # (multi-rank: two graphs per lane and frame around the collective, coalign_amd/pipeline.py)
     n_lanes = args.lanes if args.lanes > 0 else (3 if use_graph else 4)
     rings = None
     exchanges = None
@@ -408,14 +448,14 @@ def main():
         state = {"mode": mode}
 
         def attempt(m):
-            nonlocal rings, exchanges, step_batches, pipe
-            if m != state["mode"]:                   # a fall-back: rebuild the schedule and an eager pipeline around it
+            nonlocal rings, exchanges, step_batches, pipe, use_graph
+            if m != state["mode"]:                   # a fall-back: rebuild the schedule and a pipeline around it
                 try:
                     torch.cuda.synchronize()
                 except Exception:      # noqa: BLE001
                     pass
                 rings, exchanges, step_batches = setup_mode(m)
-                pipe = make_pipe(False)
+                pipe = make_pipe(use_graph)
                 state["mode"] = m
             # fault injection for the fall-back chain's own test (tools/gpu_multirank_check.sh): COALIGN_BENCH_INJECT_FAIL="ring:1,gather:0" makes the first
             # exchanges of schedule `ring` raise on rank 1 and of `gather` on rank 0
@@ -423,10 +463,30 @@ def main():
                 sched, r_ = item.split(":")
                 if sched == m and int(r_) == rank:
                     raise RuntimeError(f"injected failure of schedule '{m}' on rank {rank}")
-            for s_ in range(n_lanes):
-                pipe.submit(step_batches[s_ % len(step_batches)])
-            pipe.drain()
-            torch.cuda.synchronize()
+            ok_g = True
+            try:
+                for s_ in range(n_lanes):
+                    pipe.submit(step_batches[s_ % len(step_batches)])
+                pipe.drain()
+                torch.cuda.synchronize()
+            except Exception as e:      # noqa: BLE001
+                if not use_graph:
+                    raise
+                ok_g = False
+                print(f"bench[{rank}]: schedule '{m}' with HIP graphs failed ({type(e).__name__}: {str(e)[:160]}); trying eager launches", file=sys.stderr, flush=True)
+            if use_graph and not agree(ok_g):        # any rank's capture failed: every rank runs this schedule with eager launches
+                try:
+                    torch.cuda.synchronize()
+                except Exception:      # noqa: BLE001
+                    pass
+                use_graph = False
+                rccl["fallbacks"].append(f"{m}: HIP-graph capture failed on some rank -> eager launches")
+                rings, exchanges, step_batches = setup_mode(m)
+                pipe = make_pipe(False)
+                for s_ in range(n_lanes):
+                    pipe.submit(step_batches[s_ % len(step_batches)])
+                pipe.drain()
+                torch.cuda.synchronize()
 
         def report(m, e):
             print(f"bench[{rank}]: schedule '{m}' failed in its first exchanges: {type(e).__name__}: {str(e)[:200]}", file=sys.stderr, flush=True)
@@ -448,7 +508,7 @@ def main():
                 del feats_x
             except Exception as e:      # noqa: BLE001
                 rccl["exchange_timing_error"] = f"{type(e).__name__}: {str(e)[:160]}"
-    if use_graph:       # a capture that fails here (driver / allocator state of this box) must not cost the bench line: fall back to eager
+    if use_graph and world == 1:       # a capture that fails here (driver / allocator state of this box) must not cost the bench line: fall back to eager
         try:
             for s_ in range(n_lanes):
                 pipe.submit(step_batches[s_ % len(step_batches)])

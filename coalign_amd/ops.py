@@ -74,6 +74,14 @@ def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+def _rows_ptr(t: torch.Tensor) -> ctypes.c_void_p:
+    """Pointer to the storage position of a (possibly zero-row) row tensor: ``data_ptr()`` of an empty view may be reported as NULL."""
+    p = t.data_ptr()
+    if p == 0 and t.untyped_storage().nbytes() > 0:
+        p = t.untyped_storage().data_ptr() + t.storage_offset() * t.element_size()
+    return ctypes.c_void_p(p)
+
+
 def _need_gpu(*tensors: torch.Tensor) -> None:
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -273,6 +281,8 @@ class SparseCanvas:
 
     def __init__(self, feats, stamps, state, coords, n_agents, C, ny, nx, count_dev=None):
         self.feats, self.stamps, self.state, self.coords = feats, stamps, state, coords
+        if feats.numel() == 0 and feats.untyped_storage().nbytes() == 0:      # the consumers take a non-NULL row pointer even when every stamp is stale
+            self.feats = torch.empty((1, C), dtype=torch.float32, device=feats.device)[:0]
         self.n_agents, self.C, self.ny, self.nx, self.count_dev = n_agents, C, ny, nx, count_dev
         self.shape = (n_agents, C, ny, nx)
         self.device, self.dtype = feats.device, feats.dtype
@@ -352,7 +362,7 @@ def pillar_encode_sparse(voxel_features: torch.Tensor, voxel_num_points: torch.T
         entry["stamps"].zero_()
         entry["state"].zero_()
         entry["calls"] = 1
-    feats = torch.empty((M, C), dtype=torch.float32, device=dev)
+    feats = torch.empty((max(M, 1), C), dtype=torch.float32, device=dev)[:M]      # (an empty frame still hands its consumers a valid row pointer: ADVICE r04)
     with _Timed("pillar_encode_sparse"):
         hip.check(L.coalign_pillar_encode_sparse(_ptr(vf), _ptr(npts), _ptr(coords), M, _ptr(count_dev), P, _ptr(folded), C, int(use_absolute_xyz), _dbl3(voxel_size),
                                                  _dbl3(range_min), n_agents, ny, nx, _ptr(feats), _ptr(entry["stamps"]), _ptr(entry["state"]), _stream()),
@@ -377,7 +387,7 @@ def conv3x3_emu_sparse(sc: SparseCanvas, w_split: torch.Tensor, bias: torch.Tens
     else:
         out = y = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=sc.device, memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
     with _Timed("conv3x3_emu_sparse"):
-        hip.check(L.coalign_conv3x3_emu_sparse(_ptr(sc.feats), _ptr(sc.stamps), _ptr(sc.state), _ptr(w_split), _ptr(_f32c(bias)), _ptr(y), N, Cin, cout, H, W,
+        hip.check(L.coalign_conv3x3_emu_sparse(_rows_ptr(sc.feats), _ptr(sc.stamps), _ptr(sc.state), _ptr(w_split), _ptr(_f32c(bias)), _ptr(y), N, Cin, cout, H, W,
                                                int(relu), terms, 2 if out_split else int(out_channels_last), _stream()), "coalign_conv3x3_emu_sparse")
     return out
 
@@ -392,7 +402,7 @@ def pointwise_conv_sparse(sc: SparseCanvas, w_emu: torch.Tensor, bias: torch.Ten
     Ho, Wo = (H + 1) // 2, (W + 1) // 2
     y = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=sc.device, memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
     with _Timed("pointwise_conv_sparse"):
-        hip.check(L.coalign_pointwise_conv_emu_sparse(_ptr(sc.feats), _ptr(sc.stamps), _ptr(sc.state), _ptr(w_emu), _ptr(_f32c(bias)), _ptr(y), N, Cin, H, W, cout,
+        hip.check(L.coalign_pointwise_conv_emu_sparse(_rows_ptr(sc.feats), _ptr(sc.stamps), _ptr(sc.state), _ptr(w_emu), _ptr(_f32c(bias)), _ptr(y), N, Cin, H, W, cout,
                                                       w_emu.shape[0] * 32, int(relu), int(out_channels_last), _stream()), "coalign_pointwise_conv_emu_sparse")
     return y
 

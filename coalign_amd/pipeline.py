@@ -70,6 +70,13 @@ class _GraphSlot:
         self.count_host: Optional[torch.Tensor] = None
         self.capacity: Optional[int] = None             # bucket mode: pillar rows of the static input buffers (the frame's count sits in inputs["count"])
         self.replays = 0                                # launches through this slot's sparse canvas since its stamps were last zeroed (ops.SPARSE_TAG_RESET_AFTER)
+        # multi-rank frames (an `exchange` between encoder and tail): `graph` holds the encoder, `tail` the ego tail; the collective runs between the two replays
+        self.tail = None
+        self.feats: Optional[list] = None               # the encoder graph's output maps (the collective's send buffers) and pose matrices
+        self.affine = None
+        self.recv_ptrs: Optional[tuple] = None          # data pointers of the collective's output maps the tail graph was captured on
+        self.rows = None
+        self.tail_record: Optional[List[int]] = None
 
 
 class FramePipeline:
@@ -77,7 +84,9 @@ class FramePipeline:
     returns the frames that completed; ``drain()`` returns the rest.  ``run(frames)`` = the whole loop, results in order.
 
     ``exchange``: optional per-lane callables ``feats -> (feats, rows)`` (``FrameRing.exchange``) placed between the per-agent encoder and the ego tail (the
-    agent-sharded multi-GPU schedules of ``coalign_amd.sharded`` plug in here; eager mode only)."""
+    agent-sharded multi-GPU schedules of ``coalign_amd.sharded`` plug in here).  With ``graph`` a lane then replays TWO graphs per frame -- the encoder
+    and the ego tail -- with the collective enqueued between them (round 5: ~150 eager launches per frame were 1.35 ms of host time beside a 1.9 ms frame);
+    the exchange must return the same buffers on every call (FrameRing / AgentGather without a wire dtype do)."""
 
     def __init__(self, model, post_processor: VoxelPostprocessor, anchor_box, *, lanes: int = 4, result_lag: int = 1,
                  graph: bool = False, device=None, transformation_matrix: Optional[torch.Tensor] = None,
@@ -96,8 +105,6 @@ class FramePipeline:
             raise ops.hip.CoalignHipError("FramePipeline runs on the MI355X only (the hot path has no CPU implementation)")
         self.n_lanes = max(1, int(lanes))
         self.graph = bool(graph)
-        if exchange is not None and self.graph:
-            raise ValueError("collectives between encoder and tail are not captured: use eager mode with `exchange`")
         if exchange is not None and len(exchange) != self.n_lanes:
             raise ValueError("one exchange callable per lane")
         self.exchange = exchange
@@ -176,23 +183,24 @@ class FramePipeline:
                                     "voxel_count_dev": counts[n_clouds:], "voxel_cells_unique": True},
                 "record_len": record, "pairwise_t_matrix": pairwise}
 
-    def _frame_body(self, slot: _GraphSlot, record: List[int]) -> None:
+    def _slot_batch(self, slot: _GraphSlot, record: List[int]) -> dict:
         if slot.offsets is not None:
-            batch = self._points_batch(slot.inputs["points"], slot.offsets, record, slot.inputs["pairwise_t_matrix"])
-        else:
-            pl = {k: slot.inputs[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")}
-            if slot.capacity is not None:                       # capacity-sized arrays, the frame's pillar count on the device
-                pl.update(voxel_count_dev=slot.inputs["count"], voxel_cells_unique=False)
-            batch = {"processed_lidar": pl, "record_len": record, "pairwise_t_matrix": slot.inputs["pairwise_t_matrix"]}
+            return self._points_batch(slot.inputs["points"], slot.offsets, record, slot.inputs["pairwise_t_matrix"])
+        pl = {k: slot.inputs[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")}
+        if slot.capacity is not None:                       # capacity-sized arrays, the frame's pillar count on the device
+            pl.update(voxel_count_dev=slot.inputs["count"], voxel_cells_unique=False)
+        return {"processed_lidar": pl, "record_len": record, "pairwise_t_matrix": slot.inputs["pairwise_t_matrix"]}
+
+    def _with_slot_canvas(self, slot: _GraphSlot, fn):
+        """Run ``fn()`` with the encoder's canvas bookkeeping pointed at the slot's own: a graph bakes its launches, the persistent canvas's "rows of the
+        previous frame" bookkeeping included, so every captured frame gets a canvas / cell map / slot list of its own, touched by nothing but its own
+        replays (warm-up call first: the capture then bakes "clear M rows, encode M pillars", which is what every replay needs)."""
         vfe = getattr(self.model, "pillar_vfe", None)
         keep = None if vfe is None else (vfe.persistent_canvas, vfe.__dict__.get("_canvas_cache"))
         try:
             if vfe is not None:
-                # a graph bakes its launches, the persistent canvas's "rows of the previous frame" bookkeeping included: every captured
-                # frame gets a canvas / cell map / slot list of its own, touched by nothing but its own replays (warm-up call first:
-                # the capture then bakes "clear M rows, encode M pillars", which is what every replay needs)
                 vfe.persistent_canvas, vfe.__dict__["_canvas_cache"] = GRAPH_PERSISTENT_CANVAS, slot.canvas_cache
-            out = self.model(batch)
+            return fn()
         finally:
             if vfe is not None:
                 vfe.persistent_canvas = keep[0]
@@ -200,9 +208,42 @@ class FramePipeline:
                     vfe.__dict__.pop("_canvas_cache", None)
                 else:
                     vfe.__dict__["_canvas_cache"] = keep[1]
+
+    def _frame_body(self, slot: _GraphSlot, record: List[int]) -> None:
+        out = self._with_slot_canvas(slot, lambda: self.model(self._slot_batch(slot, record)))
         if slot.buf is None:
             slot.buf = self.pp.decode_buffers({"ego": out})
         self.pp.enqueue(self.meta, {"ego": out}, slot.buf)
+
+    def _encode_body(self, slot: _GraphSlot, record: List[int]) -> None:
+        slot.feats, slot.affine = self._with_slot_canvas(slot, lambda: self.model.encode(self._slot_batch(slot, record)))
+        slot.feats = list(slot.feats)
+
+    def _tail_body(self, slot: _GraphSlot, feats, rows) -> None:
+        out = self.model.fuse_and_head(list(feats), slot.tail_record, slot.affine, rows)
+        if slot.buf is None:
+            slot.buf = self.pp.decode_buffers({"ego": out})
+        self.pp.enqueue(self.meta, {"ego": out}, slot.buf)
+
+    def _capture_split(self, k: int, slot: _GraphSlot, record: List[int]) -> None:
+        """Encoder graph | collective (eager, on the lane's stream) | tail graph.  Captured with thread-local error mode: a collective backend's watchdog
+        thread polls events while we capture."""
+        stream = self.streams[k]
+        self._encode_body(slot, record)                         # eager warm-up: weight folds, canvases, the exchange's receive buffers
+        feats, rows = self.exchange[k](slot.feats)
+        self._tail_body(slot, feats, rows)
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+            self._encode_body(slot, record)
+        feats, rows = self.exchange[k](slot.feats)              # on the capture's output maps: these are the send buffers of every replay
+        slot.recv_ptrs, slot.rows = tuple(f.data_ptr() for f in feats), None if rows is None else list(rows)
+        stream.synchronize()
+        t = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(t, stream=stream, capture_error_mode="thread_local"):
+            self._tail_body(slot, feats, rows)
+        slot.graph, slot.tail = g, t
+        slot._recv_keep = feats                                 # (the tail graph reads these buffers: keep them referenced)
 
     def _graphed(self, k: int, batch: dict, record: List[int]) -> PostProcessHandle:
         stream = self.streams[k]
@@ -246,12 +287,16 @@ class FramePipeline:
             if cap is not None:
                 slot.inputs["count"] = torch.full((1,), M, dtype=torch.int32, device=self.device)
                 slot.count_host = torch.zeros(1, dtype=torch.int32).pin_memory()      # (a 4-byte copy per frame, not a fill kernel)
-            self._frame_body(slot, record)                      # eager warm-up on the lane: MIOpen find, weight folds, anchors, buffers
-            stream.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=stream):
-                self._frame_body(slot, record)
-            slot.graph = g
+            if self.exchange is not None:
+                slot.tail_record = host_ints(batch["tail_record_len"]) if "tail_record_len" in batch else list(record)
+                self._capture_split(k, slot, record)
+            else:
+                self._frame_body(slot, record)                  # eager warm-up on the lane: MIOpen find, weight folds, anchors, buffers
+                stream.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    self._frame_body(slot, record)
+                slot.graph = g
             self.graphs_captured += 1
             self._slots[k][key] = slot                          # only a slot whose capture succeeded is ever looked up again
         if slot.capacity is not None:
@@ -273,6 +318,12 @@ class FramePipeline:
                 ops.reset_sparse_canvases(slot.canvas_cache)
             slot.replays = 0
         slot.graph.replay()
+        if slot.tail is not None:                               # multi-rank frame: the collective between the encoder's and the tail's replay
+            feats, rows = self.exchange[k](slot.feats)
+            if tuple(f.data_ptr() for f in feats) != slot.recv_ptrs or (None if rows is None else list(rows)) != slot.rows:
+                raise ops.hip.CoalignHipError("the exchange returned other buffers / another row table than the tail graph was captured on "
+                                              "(a wire dtype or a changing schedule): run this pipeline with graph=False")
+            slot.tail.replay()
         done = torch.cuda.Event()
         done.record(stream)
         return PostProcessHandle(self.pp, slot.buf, done)

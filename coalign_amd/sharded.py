@@ -307,21 +307,24 @@ def control_agree(ok: bool, group=None) -> bool:
 
 def negotiate_schedule(start: str, attempt, agree, report=None) -> Tuple[str, List[str]]:
     """Run ``attempt(mode)`` -- the mode's set-up and first exchanges on THIS rank, raising on any failure -- for ``start`` and, whenever ANY rank failed
-    (``agree(ok)`` = logical AND over the ranks), for the next schedule of ``SCHEDULES``; ``"replicas"`` is terminal.  Every rank takes the same decisions.
+    (``agree(ok)`` = logical AND over the ranks), for the next schedule of ``SCHEDULES``; ``"replicas"`` is terminal: if it fails too, every rank raises.
+    Every rank takes the same decisions.
     Returns (schedule that runs, list of fall-backs taken)."""
     if start not in SCHEDULES:
         raise ValueError(f"schedule must be one of {SCHEDULES}")
     mode, fallbacks = start, []
     while True:
-        ok = True
+        ok, err = True, None
         try:
             attempt(mode)
         except Exception as e:      # noqa: BLE001 -- whatever the backend throws
-            ok = False
+            ok, err = False, e
             if report is not None:
                 report(mode, e)
-        if agree(ok) or mode == "replicas":
+        if agree(ok):
             return mode, fallbacks
+        if mode == "replicas":      # nothing left to fall back to: every rank raises (the one that failed with its own error)
+            raise RuntimeError(f"the terminal schedule 'replicas' failed{'' if err is None else ' on this rank: ' + repr(err)}") from err
         nxt = SCHEDULES[SCHEDULES.index(mode) + 1]
         fallbacks.append(f"{mode} failed in its first exchanges -> {nxt}")
         mode = nxt

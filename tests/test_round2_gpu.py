@@ -263,8 +263,9 @@ def test_nhwc_route_equals_nchw_route_end_to_end():
     model = model.to(DEV).eval()
     frame = to_device(make_frame(h, 3, pillars_per_agent=5000, seed=21, noise=(0.2, 0.2)), DEV)
     from coalign_amd import detector as det
-    saved, saved_sparse = bb.NHWC_STAGE_OUTPUTS, det.SPARSE_CANVAS
+    saved, saved_sparse, saved_split = bb.NHWC_STAGE_OUTPUTS, det.SPARSE_CANVAS, bb.SPLIT_MAPS
     det.SPARSE_CANVAS = False        # (round 4's sparse canvas brings its own exact-fp32 encoder: this test compares LAYOUTS of one arithmetic)
+    bb.SPLIT_MAPS = False            # (round 5's SplitMaps round the maps inside a stage to 22 bits: tests/test_round5_gpu.py compares that route)
     try:
         with torch.no_grad():
             bb.NHWC_STAGE_OUTPUTS = True
@@ -274,7 +275,7 @@ def test_nhwc_route_equals_nchw_route_end_to_end():
             f0, _ = model.encode(frame)
             o0 = model(frame)
     finally:
-        bb.NHWC_STAGE_OUTPUTS, det.SPARSE_CANVAS = saved, saved_sparse
+        bb.NHWC_STAGE_OUTPUTS, det.SPARSE_CANVAS, bb.SPLIT_MAPS = saved, saved_sparse, saved_split
     assert all(ops.is_channels_last(f) for f in f1) and all(f.is_contiguous() for f in f0)
     for a, b in zip(f1, f0):
         assert torch.equal(a.contiguous(), b)

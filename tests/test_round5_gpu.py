@@ -258,11 +258,15 @@ def test_conv3x3_sp_backbone_shapes_bit_equal_and_against_float64(shape):
     xs = ops.SplitMap.pack(x)
     want = ops.conv3x3_emu_bias_act(x, w16, b, Co, r, True, 16)
     got = ops.conv3x3_sp(xs, w16, b, Co, rs, True, out_split=False)
-    assert torch.equal(got, want)
     ref = conv64(x, w, b, r)
-    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    scale = float(ref.abs().max())
+    if N * H * W * Co // (256 * 64) > 256 and Ci >= 256:          # the consumer-split kernel hands long tiles over between workgroups here (stream-K): another summation order
+        assert float((got - want).abs().max()) / scale < 1e-6
+    else:
+        assert torch.equal(got, want)
+    assert float((got.double() - ref).abs().max()) / scale < 2e-6
     got_sp = ops.conv3x3_sp(xs, w16, b, Co, rs, True, out_split=True)
-    assert_split_map_holds(got_sp, want)
+    assert_split_map_holds(got_sp, got)
 
 
 def test_consumer_split_kernels_write_split_maps():
@@ -284,9 +288,9 @@ def test_consumer_split_kernels_write_split_maps():
         w = torch.randn((Co, Ci, 3, 3), generator=g, device=DEV) / (9 * Ci) ** 0.5
         b = torch.randn(Co, generator=g, device=DEV)
         wt = ops.pack_conv3x3_emu_weight(w, 16, True)
-        want = ops.conv3x3_emu_bias_act(x, wt, b, Co, None, True, 16)
+        want = ops.conv3x3_emu_bias_act(x, wt, b, Co, None, True, 16, out_channels_last=True)      # (the same whole-tile variant; the NCHW output may take the stream-K one)
         got = ops.conv3x3_emu_bias_act(x, wt, b, Co, None, True, 16, out_split=True)
-        assert_split_map_holds(got, want, (N, Ci, Co, H, W))
+        assert_split_map_holds(got, want.contiguous(), (N, Ci, Co, H, W))
 
 
 def test_split_map_route_equals_consumer_split_route_on_the_model():
@@ -314,3 +318,30 @@ def test_split_map_route_equals_consumer_split_route_on_the_model():
         print(f"\nsplit-map route vs consumer-split route {k}: {e:.2e}", end="")
         assert e < 2e-5, k
     assert not ops.sp_range_exceeded(DEV)
+
+
+def test_empty_frame_and_empty_agent_on_the_sparse_canvas_route():
+    """a frame (or a rank's block of agents: bench.py --mode gather with more ranks than agents) without a single pillar goes through the default
+    sparse-canvas route -- every stamp stale, the maps are what the biases make of an all-zero canvas -- and equals the dense-canvas route."""
+    from coalign_amd import detector as det
+    from coalign_amd.synthetic import fill_parameters_
+    h = builtin_config("mini_coalign")
+    model = build_model(h)
+    fill_parameters_(model, seed=0)
+    model = model.to(DEV).eval()
+    full = to_device(make_frame(h, 2, pillars_per_agent=60, seed=9, noise=(0.2, 0.2)), DEV)
+    pl = full["processed_lidar"]
+    only_ego = pl["voxel_coords"][:, 0] == 0
+    cases = {"empty frame": {k: v[:0] for k, v in pl.items()}, "agent 1 empty": {k: v[only_ego] for k, v in pl.items()}}
+    for name, sub in cases.items():
+        fr = dict(full, processed_lidar=sub)
+        with torch.no_grad():
+            out = model(fr)
+            saved = det.SPARSE_CANVAS
+            try:
+                det.SPARSE_CANVAS = False
+                ref = model(fr)
+            finally:
+                det.SPARSE_CANVAS = saved
+        for k in out:
+            assert torch.isfinite(out[k]).all() and rel_err(out[k], ref[k]) < 1e-5, (name, k)

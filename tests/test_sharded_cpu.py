@@ -191,6 +191,13 @@ def _negotiate_worker(rank, world, failing, port, q):
                 raise RuntimeError(f"injected failure of '{mode}' on rank {rank}")
             # (a real schedule enters its data-plane collective here; this worker only records the attempt: the control group's all-reduce is the rendezvous)
 
+        if failing.get("ring") and failing.get("gather") and failing.get("replicas"):      # nothing runs: EVERY rank must raise, none may return "replicas"
+            try:
+                negotiate_schedule("ring", attempt, lambda ok: control_agree(ok, ctl), lambda m, e: reported.append(m))
+                q.put((rank, False))
+            except RuntimeError:
+                q.put((rank, tried == ["ring", "gather", "replicas"]))
+            return
         mode, fallbacks = negotiate_schedule("ring", attempt, lambda ok: control_agree(ok, ctl), lambda m, e: reported.append(m))
         out = [None] * world
         dist.all_gather_object(out, (mode, fallbacks, tried))
@@ -215,7 +222,27 @@ def test_negotiate_schedule_single_process_contract():
         if m == "ring":
             raise ValueError("no")
     assert negotiate_schedule("ring", attempt, lambda ok: ok) == ("gather", ["ring failed in its first exchanges -> gather"]) and calls == ["ring", "gather"]
-    assert negotiate_schedule("replicas", lambda m: 1 / 0, lambda ok: ok) == ("replicas", [])      # terminal: nothing left to fall back to
+    with pytest.raises(RuntimeError):      # terminal: nothing left to fall back to -- a failed 'replicas' attempt is an error, not a schedule that "ran"
+        negotiate_schedule("replicas", lambda m: 1 / 0, lambda ok: ok)
+    assert negotiate_schedule("replicas", lambda m: None, lambda ok: ok) == ("replicas", [])
     with pytest.raises(ValueError):
         negotiate_schedule("mesh", attempt, lambda ok: ok)
 
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher starts two ranks by itself (torch.distributed.run on 127.0.0.1) and rank 0
+    reports world 2; with more GPUs requested than visible it exits non-zero instead of printing a one-GPU line (no GPU in this container: --gpus 8)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=300, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-800:]
+    rep = json.loads(lines[0])
+    assert rep == {"launch_check": True, "world": 2, "n_gpus": 2, "launcher": "self"}
+    if not __import__("torch").cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 2 and "not launching" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
