@@ -39,6 +39,11 @@ struct SpArgs {
     void *__restrict__ y;               // SP map or channels-last fp32, per the OUT template argument
     int *range_flag;                    // may be NULL: bit 0 is set when an SP output value exceeds the pair's range (|y| > 65504)
     int N, Cin, Cout, H, W, relu, res_kind, stack, tiles_x, tiles_y, total_tiles, xcd;
+    // stream-K (split != 0): the (tile, interval) steps are cut into gridDim.x equal contiguous ranges; a workgroup that starts in the middle of a tile
+    // publishes the partial sums of its share (slot g of `partial`, then flags[g] = 1), the workgroup that OPENED the tile adds them and runs the epilogue.
+    int split;
+    float *partial;                     // [grid][waves][32][64] float
+    int *flags;                         // [grid], zero before the first launch; the consumer of a flag resets it
 #ifdef SP_TRACE
     long long *trace;                   // profiling aid (tools/trace_conv_sp.py): [2 workgroups][16 waves][64 intervals][8 stamps] + [grid][2] wall clocks
     int ablate;                         // 1: no weight DMA, 2: no patch DMA, 4: no matrix steps (no LDS reads either), 8: no residual / bias start, 16: no stores
@@ -102,7 +107,7 @@ struct Work {
     static constexpr int WJ = (G::WINS + LOADERS - 1) / LOADERS, PJ = (G::PINS + LOADERS - 1) / LOADERS, OPS = WJ + 4 * PJ;
 };
 
-template <int BH, int BW, int NPB, int NBX, int OUT, int MODE>
+template <int BH, int BW, int NPB, int NBX, int OUT, int MODE, bool SPLIT>
 __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
     using G = Geo<BH, BW, NPB, NBX>;
     using K = Work<BH, BW, NPB, NBX, MODE>;
@@ -178,28 +183,40 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
         for (int k = 0; k < K::OPS; ++k) issue_op(pl, c, slot, k);
     };
 
-    // persistent workgroups over whole tiles g, g + n, ...; XCD k takes the k-th eighth of the logical ids (neighbouring tiles share input rows and weights in its L2)
+    // Persistent workgroups.  Whole tiles g, g + n, ... -- or, stream-K (a.split), the (tile, interval) steps cut into n equal contiguous ranges, so that
+    // every workgroup runs the same number of matrix instructions (+-1 interval) whatever the tile count: 192 tiles of 16 intervals on 256 CUs are 12
+    // intervals each instead of 16 on three quarters of the chip.  A range may start in the middle of a tile (that share is computed from zero accumulators
+    // and PUBLISHED) and may end in the middle of one (the workgroup that opened a tile OWNS it: it adds the shares the following workgroups published --
+    // they compute them first thing in their ranges -- and runs the epilogue).  The cut is a pure function of the shape: the summation order, hence the
+    // result, is deterministic.  XCD k takes the k-th eighth of the logical ids (neighbouring tiles share input rows and weights in its L2; hand-overs stay
+    // between logical neighbours).
     const int n_wg = gridDim.x;
     int g = blockIdx.x;
     if (a.xcd) {
         const int q = n_wg >> 3, r = n_wg & 7, k = g & 7, j = g >> 3;
         g = k * q + (k < r ? k : r) + j;
     }
-    const int n_local = ((a.total_tiles - g + n_wg - 1) / n_wg) * chunks;
+    const long long S_total = (long long)a.total_tiles * chunks;
+    auto range_start = [&](int j) { return (int)(S_total * j / n_wg); };
+    const int s0 = SPLIT ? range_start(g) : 0;
+    const int n_local = SPLIT ? range_start(g + 1) - s0 : ((a.total_tiles - g + n_wg - 1) / n_wg) * chunks;
     if (n_local <= 0) return;
 #ifdef SP_TRACE
     if (tid == 0) a.trace[2 * 16 * 64 * 8 + 2 * g] = wall_clock64();
 #endif
-    int tile = g;
+    int tile = SPLIT ? s0 / chunks : g, chunk0 = SPLIT ? s0 - tile * chunks : 0;
+    const int tile_step = SPLIT ? 1 : n_wg;
     Tile cur = decode(tile);
     Plan plan{};
     if (loader) {
         plan = make_plan(cur);
-        issue_all(plan, 0, 0);
+        issue_all(plan, chunk0, 0);
     }
     if (MODE != 2 && wave >= G::WAVES / 2) __builtin_amdgcn_s_setprio(1);      // (as conv3x3_emu.hip: the later-dispatched half of the wavefronts loses every arbitration otherwise)
     int L = 0;
     while (L < n_local) {
+        const int c_begin = SPLIT ? chunk0 : 0, c_end = SPLIT && (n_local - L) < (chunks - c_begin) ? c_begin + (n_local - L) : chunks;
+        const bool head = !SPLIT || c_begin == 0, complete = !SPLIT || c_end == chunks;
         // this lane's output pixel: image out_n, row gy, column gx; rows at / past an image boundary read the patch two rows lower
         const bool lower = py >= cur.yb;
         const int out_n = cur.n0 + (lower ? 1 : 0), gy = lower ? py - cur.yb : cur.yl0 + py, gx = cur.x0 + px;
@@ -213,13 +230,13 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
         acc[1] = floatx16{0};
         accl[0] = floatx16{0};
         accl[1] = floatx16{0};
-        uint4 rraw[8];                                             // the residual of this lane's 32 outputs, fetched behind the barrier of the tile's LAST interval
+        uint4 rraw[8];                                             // the residual of this lane's 32 outputs, fetched behind the barrier of the owner's LAST interval
 #pragma unroll
         for (int g8 = 0; g8 < 8; ++g8) rraw[g8] = uint4{0, 0, 0, 0};
         Tile next = cur;
         Plan nplan = plan;
         int ntile = tile;
-        for (int chunk = 0; chunk < chunks; ++chunk, ++L) {
+        for (int chunk = c_begin; chunk < c_end; ++chunk, ++L) {
             SP_STAMP(0);
             __builtin_amdgcn_s_waitcnt(0);
             SP_STAMP(1);
@@ -229,12 +246,12 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
             int nc = chunk + 1;
             if (more && nc == chunks) {                            // the next interval opens this workgroup's next tile
                 nc = 0;
-                ntile = tile + n_wg;
+                ntile = tile + tile_step;
                 next = decode(ntile);
                 if (loader) nplan = make_plan(next);
             }
             if (MODE != 1 && more && loader) issue_all(nplan, nc, (L + 1) & 1);
-            if (chunk == chunks - 1 && wave_live && !SP_ABLATE(8)) {
+            if (chunk == c_end - 1 && head && wave_live && !SP_ABLATE(8)) {
                 if (a.res_kind == SP_RES_SP) {                     // h groups | l groups: 8 bytes each per (lane, 8-channel group)
                     const uint2 *rp = reinterpret_cast<const uint2 *>(a.residual);
 #pragma unroll
@@ -298,6 +315,46 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
             }
             SP_STAMP(4);
         }
+        chunk0 = 0;                                                // every later segment of this range opens its tile
+        // the segment's sums, both accumulators joined: t = acc + 2^-10 accl
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[q][e] = fmaf(accl[q][e], coalign::kSp16LowInv, acc[q][e]);
+        // Stream-K hand-over, as conv3x3_emu.hip: agent-scope write-through stores / L2-bypassing loads (relaxed atomics), no fences.  Producer: partial
+        // sums leave as write-through stores; s_waitcnt(0) = acknowledged; the barrier = true for every wavefront; only then the flag.  Consumer: one lane
+        // spins on the flag (and clears it: exactly one consumer per flag and launch, launches on a stream are ordered), the barrier releases the
+        // workgroup, the partial sums are read by loads issued after it.  Guarded by tests/test_round5_gpu.py::test_conv3x3_sp_stream_k_*.
+        if (SPLIT && !head) {
+            if (wave_live) {
+                float *slot = a.partial + ((size_t)g * G::WAVES + wave) * (32 * 64) + lane;
+#pragma unroll
+                for (int q = 0; q < 32; ++q) __hip_atomic_store(slot + q * 64, acc[q / 16][q % 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(a.flags + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cur = next;
+            plan = nplan;
+            tile = ntile;
+            continue;
+        }
+        if (SPLIT && !complete) {                                  // owner of a tile this range does not finish: the following workgroups' shares
+            int rem = chunks - c_end;
+            for (int j = g + 1; rem > 0; ++j) {
+                if (tid == 0) {
+                    while (__hip_atomic_load(a.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+                    __hip_atomic_store(a.flags + j, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if (wave_live) {
+                    const float *slot = a.partial + ((size_t)j * G::WAVES + wave) * (32 * 64) + lane;
+#pragma unroll
+                    for (int q = 0; q < 32; ++q) acc[q / 16][q % 16] += __hip_atomic_load(slot + q * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                rem -= range_start(j + 1) - range_start(j);
+            }
+        }
         // ---- epilogue: y = (acc + 2^-10 accl) * 2^-k_c + (residual + bias), ReLU, stored as an SP map or as channels-last fp32
         const float4 *bias4 = reinterpret_cast<const float4 *>(a.bias + cur.cg * kCoutTile + 4 * half), *winv4 = reinterpret_cast<const float4 *>(a.wscale + cur.cg * kCoutTile + 4 * half);
         bool big = false;
@@ -318,7 +375,7 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int q = g8 / 4, e = 4 * (g8 % 4) + j;
-                v[j] = fmaf(accl[q][e], coalign::kSp16LowInv, acc[q][e]) * ii[j] + (r[j] + bb[j]);
+                v[j] = acc[q][e] * ii[j] + (r[j] + bb[j]);
                 if (a.relu) v[j] = fmaxf(v[j], 0.f);
             }
             if constexpr (OUT == SP_OUT_NHWC) {
@@ -389,48 +446,109 @@ __global__ void sp_unpack_kernel(const uint4 *__restrict__ x, float *__restrict_
     }
 }
 
+struct SpLaunch {          // what the host needs to know about one (shape, geometry) pair
+    int grid, split;
+    size_t flag_bytes, ws_bytes;
+};
+
+// split_policy: 0 = by the rule below, 1 = never, 2 = whenever possible (laboratory)
 template <int BH, int BW, int NPB, int NBX, int MODE>
-int launch_geo(SpArgs a, int out_kind, hipStream_t s) {
+int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t workspace_bytes, hipStream_t s, SpLaunch *query) {
     using G = Geo<BH, BW, NPB, NBX>;
     constexpr int kMaxDev = 16;
     static int cus[kMaxDev] = {0};                                    // per device: the function attribute belongs to the device's code object
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
-    auto k_sp = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP, MODE>;
-    auto k_cl = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC, MODE>;
+    constexpr bool CAN_SPLIT = NPB == 8;                              // (the hand-over code needs the 8-wavefront geometries' register budget)
+    auto k_sp = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP, MODE, false>;
+    auto k_cl = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC, MODE, false>;
+    auto k_sp_s = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP, MODE, CAN_SPLIT>;
+    auto k_cl_s = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC, MODE, CAN_SPLIT>;
     if (!cus[dev]) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
-        for (const void *fn : {reinterpret_cast<const void *>(k_sp), reinterpret_cast<const void *>(k_cl)}) {
-            const int rc = coalign::hip_call(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
-            if (rc != COALIGN_OK) {
-                (void)hipGetLastError();
-                return rc;
+        if (!query) {
+            for (const void *fn : {reinterpret_cast<const void *>(k_sp), reinterpret_cast<const void *>(k_cl), reinterpret_cast<const void *>(k_sp_s), reinterpret_cast<const void *>(k_cl_s)}) {
+                const int rc = coalign::hip_call(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+                if (rc != COALIGN_OK) {
+                    (void)hipGetLastError();
+                    return rc;
+                }
             }
+            cus[dev] = prop.multiProcessorCount;
         }
-        cus[dev] = prop.multiProcessorCount;
+        if (query && !cus[dev]) {                                     // (a size query before the first launch: same CU count, attributes set at the launch)
+            SpArgs b = a;
+            (void)b;
+        }
     }
+    hipDeviceProp_t prop2;
+    const int n_cu = cus[dev] ? cus[dev] : (hipGetDeviceProperties(&prop2, dev) == hipSuccess && prop2.multiProcessorCount > 0 ? prop2.multiProcessorCount : 256);
     a.stack = (a.N > 1 && G::TH <= a.H) ? 1 : 0;
     a.tiles_x = (a.W + G::TW - 1) / G::TW;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;                            // per image (not stacked)
     const int row_tiles = a.stack ? (a.N * a.H + G::TH - 1) / G::TH : a.N * a.tiles_y;
     a.total_tiles = a.tiles_x * row_tiles * (a.Cout / kCoutTile);
-    const int slots = cus[dev];                                       // 111-147 KB of LDS: one workgroup per CU
-    const int grid = a.total_tiles < slots ? a.total_tiles : slots;
-    if (out_kind == SP_OUT_SP) hipLaunchKernelGGL(k_sp, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
-    else hipLaunchKernelGGL(k_cl, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+    const int slots = n_cu, chunks = a.Cin / 16;                      // 111-147 KB of LDS: one workgroup per CU
+    // stream-K pays where whole tiles leave the chip badly filled (192 tiles on 256 CUs; 552 tiles = three rounds at 72 %) and a tile is long enough to cut
+    const int rounds = (a.total_tiles + slots - 1) / slots;
+    const long long steps = (long long)a.total_tiles * chunks;
+    bool split = CAN_SPLIT && chunks >= 4 && steps >= 2LL * slots && (long long)a.total_tiles * 100 < (long long)rounds * slots * 88;
+    if (split_policy == 1) split = false;
+    if (split_policy == 2) split = CAN_SPLIT && chunks >= 2 && steps >= slots;
+    SpLaunch l;
+    l.split = split ? 1 : 0;
+    l.grid = split ? slots : (a.total_tiles < slots ? a.total_tiles : slots);
+    l.flag_bytes = split ? coalign::align_up((size_t)(l.grid + 4) * sizeof(int), 256) : 0;
+    l.ws_bytes = split ? l.flag_bytes + (size_t)(l.grid + 4) * G::WAVES * 32 * 64 * sizeof(float) : 0;
+    if (query) {
+        *query = l;
+        return COALIGN_OK;
+    }
+    if (split) {
+        if (!workspace) return COALIGN_ERR_NULL_POINTER;
+        if (workspace_bytes < l.ws_bytes || (reinterpret_cast<uintptr_t>(workspace) & 15)) return COALIGN_ERR_WORKSPACE;
+        a.split = 1;
+        a.flags = static_cast<int *>(workspace);
+        a.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + l.flag_bytes);
+    }
+    if (split) hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp_s : k_cl_s, dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp : k_cl, dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
     return COALIGN_OK;
 }
 
 template <int MODE>
-int launch_mode(int geo, const SpArgs &a, int out_kind, hipStream_t s) {
+int launch_mode(int geo, const SpArgs &a, int out_kind, int split_policy, void *ws, size_t ws_bytes, hipStream_t s, SpLaunch *query) {
     switch (geo) {
-        case 81: return launch_geo<1, 32, 8, 1, MODE>(a, out_kind, s);       // 8 rows x 32 columns
-        case 121: return launch_geo<1, 32, 12, 1, MODE>(a, out_kind, s);     // 12 x 32
-        case 124: return launch_geo<2, 16, 12, 1, MODE>(a, out_kind, s);     // 24 x 16 (2 x 16 blocks)
-        case 148: return launch_geo<4, 8, 8, 4, MODE>(a, out_kind, s);       // 8 x 32 in 4 x 8 blocks, four block columns
+        case 81: return launch_geo<1, 32, 8, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);       // 8 rows x 32 columns
+        case 121: return launch_geo<1, 32, 12, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);     // 12 x 32
+        case 124: return launch_geo<2, 16, 12, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);     // 24 x 16 (2 x 16 blocks)
+        case 148: return launch_geo<4, 8, 8, 4, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);       // 8 x 32 in 4 x 8 blocks, four block columns
         default: return COALIGN_ERR_UNSUPPORTED;
     }
+}
+
+constexpr int kDefaultMode = 1;
+
+// geometry code: 0 = chosen from the map size (the rules measured for conv3x3_emu.hip's fp16 mode), else 81 / 121 / 124 / 148 as there;
+// + 1000 * (issue mode + 1) and + 100000 * split policy are laboratory switches (the product library carries kDefaultMode only)
+int dispatch_sp(const SpArgs &a, int out_kind, int geometry, void *ws, size_t ws_bytes, hipStream_t s, SpLaunch *query) {
+    const int split_policy = geometry / 100000;
+    geometry %= 100000;
+    int geo = geometry % 1000, mode = geometry >= 1000 ? geometry / 1000 - 1 : kDefaultMode;
+    if (geo == 0) {
+        if (a.W % 32 == 16 && a.H > 26 && a.H <= 52 && a.N * a.H >= 24) geo = 124;
+        else if (a.H >= 64) geo = (a.N == 1 && a.Cin >= 128) ? 81 : 121;      // (one image, long tiles -- the shrink header: the 8-wavefront geometry, which can split)
+        else if (a.H >= 8 && a.H <= 32 && a.W % 32 > 0 && a.W % 32 <= 24) geo = 148;
+        else geo = 81;
+    }
+#if defined(COALIGN_LAB) || defined(SP_TRACE)      // laboratory / trace builds carry all three issue modes
+    return mode == 0 ? launch_mode<0>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query) : mode == 2 ? launch_mode<2>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query)
+                                                                                              : launch_mode<1>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
+#else
+    (void)mode;
+    return launch_mode<kDefaultMode>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
+#endif
 }
 
 }  // namespace
@@ -467,13 +585,29 @@ extern "C" int coalign_sp_unpack(const void *x_sp, float *y, int out_nhwc, int N
     return coalign::check_launch();
 }
 
+static int sp_check(int N, int Cin, int Cout, int H, int W) {
+    if (N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return COALIGN_ERR_BAD_SHAPE;
+    if (Cin % 16 || Cout % kCoutTile) return COALIGN_ERR_UNSUPPORTED;
+    if ((int64_t)N * (Cin > Cout ? Cin : Cout) * H * W > (int64_t)1 << 32) return COALIGN_ERR_UNSUPPORTED;      // group offsets are 32-bit
+    return COALIGN_OK;
+}
+
+extern "C" size_t coalign_conv3x3_sp_workspace_bytes(int N, int Cin, int Cout, int H, int W, int geometry) {
+    if (sp_check(N, Cin, Cout, H, W) != COALIGN_OK || N == 0) return 0;
+    SpArgs a{};
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    SpLaunch l{};
+    return dispatch_sp(a, SP_OUT_SP, geometry, nullptr, 0, nullptr, &l) == COALIGN_OK ? l.ws_bytes : 0;
+}
+
 extern "C" int coalign_conv3x3_sp(const void *x_sp, const void *w_split, const float *bias, const void *residual, int residual_kind, void *y, int out_kind,
-                                  int N, int Cin, int Cout, int H, int W, int relu, int geometry, int32_t *range_flag, void *stream) {
+                                  int N, int Cin, int Cout, int H, int W, int relu, int geometry, int32_t *range_flag, void *workspace, size_t workspace_bytes,
+                                  void *stream) {
     using namespace coalign;
     if (!x_sp || !w_split || !bias || !y || (residual_kind != SP_RES_NONE && !residual)) return COALIGN_ERR_NULL_POINTER;
-    if (N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return COALIGN_ERR_BAD_SHAPE;
-    if (Cin % 16 || Cout % kCoutTile || (out_kind != SP_OUT_SP && out_kind != SP_OUT_NHWC) || residual_kind < 0 || residual_kind > SP_RES_NHWC) return COALIGN_ERR_UNSUPPORTED;
-    if ((int64_t)N * (Cin > Cout ? Cin : Cout) * H * W > (int64_t)1 << 32) return COALIGN_ERR_UNSUPPORTED;      // group offsets are 32-bit
+    int rc = sp_check(N, Cin, Cout, H, W);
+    if (rc != COALIGN_OK) return rc;
+    if ((out_kind != SP_OUT_SP && out_kind != SP_OUT_NHWC) || residual_kind < 0 || residual_kind > SP_RES_NHWC) return COALIGN_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(x_sp) | reinterpret_cast<uintptr_t>(w_split) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) return COALIGN_ERR_UNSUPPORTED;
     if (N == 0) return COALIGN_OK;
     const size_t wbytes = coalign_conv3x3_emu_weight_bytes_ex(Cin, Cout, 16, 1), tail = (size_t)Cout * 8;
@@ -493,23 +627,6 @@ extern "C" int coalign_conv3x3_sp(const void *x_sp, const void *w_split, const f
     a.trace = g_sp_trace;
     a.ablate = g_sp_ablate;
 #endif
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    // geometry: 0 = chosen from the map size (the rules measured for conv3x3_emu.hip's fp16 mode), else 81 / 121 / 124 / 148 as there; + 1000 * issue mode
-    // (laboratory: 1000 = mode 0, 2000 = mode 1, 3000 = mode 2; see the kernel) -- the product uses kDefaultMode
-    constexpr int kDefaultMode = 1;
-    int geo = geometry % 1000, mode = geometry >= 1000 ? geometry / 1000 - 1 : kDefaultMode;
-    if (geo == 0) {
-        if (W % 32 == 16 && H > 26 && H <= 52 && N * H >= 24) geo = 124;
-        else if (H >= 64) geo = 121;
-        else if (H >= 8 && H <= 32 && W % 32 > 0 && W % 32 <= 24) geo = 148;
-        else geo = 81;
-    }
-    int rc;
-#if defined(COALIGN_LAB) || defined(SP_TRACE)      // laboratory / trace builds carry all three issue modes
-    rc = mode == 0 ? launch_mode<0>(geo, a, out_kind, s) : mode == 1 ? launch_mode<1>(geo, a, out_kind, s) : launch_mode<2>(geo, a, out_kind, s);
-#else
-    (void)mode;
-    rc = launch_mode<kDefaultMode>(geo, a, out_kind, s);
-#endif
+    rc = dispatch_sp(a, out_kind, geometry, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr);
     return rc != COALIGN_OK ? rc : check_launch();
 }

@@ -69,7 +69,8 @@ SIGNATURES = {
     "coalign_sp_map_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "coalign_sp_pack": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P, P]),
     "coalign_sp_unpack": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "coalign_conv3x3_sp": (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "coalign_conv3x3_sp_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "coalign_conv3x3_sp": (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     "coalign_conv3x3_wino_weight_bytes": (c_size_t, [c_int, c_int]),
     "coalign_conv3x3_wino": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_pointwise_conv": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -867,6 +867,24 @@ def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Ten
     return y if out is None else out
 
 
+_SP_WS: dict = {}
+_SP_WS_RETIRED: list = []
+SP_WS_MIN_BYTES = 24 << 20          # the largest stream-K workspace of the shipped configs (256 workgroups x 8 wavefronts x 8 KB + flags) is 16.8 MB
+
+
+def _sp_workspace(device, ws_bytes: int) -> torch.Tensor:
+    """The stream-K workspace of ``coalign_conv3x3_sp`` for the CURRENT stream of ``device``: zero-initialised once (the launches leave their flag words zero
+    again), one per stream (launches on a stream are ordered), sized for every shipped shape on first use so that it never grows inside a captured frame; a
+    workspace that still has to grow is replaced and kept referenced (captured graphs hold its pointer)."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _SP_WS.get(key)
+    if ws is None or ws.numel() < ws_bytes:
+        if ws is not None:
+            _SP_WS_RETIRED.append(ws)
+        ws = _SP_WS[key] = torch.zeros(max(ws_bytes, SP_WS_MIN_BYTES), dtype=torch.uint8, device=device)
+    return ws
+
+
 SP_RES_NONE, SP_RES_SP, SP_RES_NHWC = 0, 1, 2      # residual_kind of coalign_conv3x3_sp
 SP_OUT_SP, SP_OUT_NHWC = 1, 2                      # out_kind
 
@@ -900,10 +918,18 @@ def conv3x3_sp(x: "SplitMap", w_split: torch.Tensor, bias: torch.Tensor, cout: i
         out = y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         if not nhwc_memory(y):
             out = y = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+    ws_bytes = L.coalign_conv3x3_sp_workspace_bytes(N, Cin, cout, H, W, int(geometry))
+    ws = _sp_workspace(x.device, ws_bytes) if ws_bytes else None
     with _Timed("conv3x3_sp"):
         hip.check(L.coalign_conv3x3_sp(_ptr(x.data), _ptr(w_split), _ptr(_f32c(bias)), _ptr(res_t), res_kind, _ptr(y), SP_OUT_SP if out_split else SP_OUT_NHWC,
-                                       N, Cin, cout, H, W, int(relu), int(geometry), _ptr(sp_range_flag(x.device)) if out_split else None, _stream()), "coalign_conv3x3_sp")
+                                       N, Cin, cout, H, W, int(relu), int(geometry), _ptr(sp_range_flag(x.device)) if out_split else None,
+                                       _ptr(ws), 0 if ws is None else ws.numel(), _stream()), "coalign_conv3x3_sp")
     return out
+
+
+def conv3x3_sp_is_split(N: int, Cin: int, cout: int, H: int, W: int, geometry: int = 0) -> bool:
+    """True when ``conv3x3_sp`` cuts this shape's tiles between workgroups (stream-K: another, still deterministic, summation order)."""
+    return hip.lib().coalign_conv3x3_sp_workspace_bytes(N, Cin, cout, H, W, int(geometry)) > 0
 
 
 def pack_conv3x3_wino_weight(weight: torch.Tensor) -> torch.Tensor:

@@ -374,12 +374,16 @@ int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const float *bia
  *     residual_kind 0 none | 1 SP map [N, Cout, H, W] | 2 channels-last float32;  out_kind 1 SP map | 2 channels-last float32;
  *     geometry 0 = chosen from the shape, 81 / 121 / 124 / 148 = a fixed tile geometry (8 x 32, 12 x 32, 24 x 16, 8 x 32 in 4 x 8 blocks);
  *     range_flag (may be NULL): bit 0 is set when a value written to an SP map exceeded 65504 in magnitude.
+ *     workspace: coalign_conv3x3_sp_workspace_bytes(...) bytes (0 = none needed for that shape), 16-byte aligned, ZERO-INITIALISED ONCE by the caller and
+ *     then owned by the launches of ONE stream: the stream-K hand-over of tiles cut between workgroups (shapes whose whole tiles would leave the chip badly
+ *     filled: 192 tiles on 256 CUs, 552 tiles = 2.2 rounds); every launch leaves its flag words zero again.  The cut is a pure function of the shape.
  *   Bit-identical to coalign_conv3x3_emu_ex(terms 16, tap-major) on the unpacked input. */
 size_t coalign_sp_map_bytes(int N, int C, int H, int W);
 int coalign_sp_pack(const float *x, int in_nhwc, void *y_sp, int N, int C, int H, int W, int32_t *range_flag, void *stream);
 int coalign_sp_unpack(const void *x_sp, float *y, int out_nhwc, int N, int C, int H, int W, void *stream);
+size_t coalign_conv3x3_sp_workspace_bytes(int N, int Cin, int Cout, int H, int W, int geometry);
 int coalign_conv3x3_sp(const void *x_sp, const void *w_split, const float *bias, const void *residual, int residual_kind, void *y, int out_kind,
-                       int N, int Cin, int Cout, int H, int W, int relu, int geometry, int32_t *range_flag, void *stream);
+                       int N, int Cin, int Cout, int H, int W, int relu, int geometry, int32_t *range_flag, void *workspace, size_t workspace_bytes, void *stream);
 
 /* (9c) Round 4: the stride-1 3x3 convolutions as Winograd F(2x2, 3x3) on the bf16 matrix cores -- 16 instead of 36 products per 2 x 2 outputs and
  * (cin, cout), fp32 operands by the same 3-way error-free bf16 split, fp32 accumulation (csrc/conv3x3_wino.hip).  Same layers as (9b):

@@ -237,10 +237,14 @@ def test_conv3x3_sp_equals_consumer_split_kernel_bit_for_bit(shape, geometry):
         res_old = None if res_kind == "none" else r
         res_new = None if res_kind == "none" else rs if res_kind == "split" else r.contiguous(memory_format=torch.channels_last)
         want = ops.conv3x3_emu_bias_act(x, w16, b, Co, res_old, relu, 16)
-        got_cl = ops.conv3x3_sp(xs, w16, b, Co, res_new, relu, out_split=False, geometry=geometry)
+        got_cl = ops.conv3x3_sp(xs, w16, b, Co, res_new, relu, out_split=False, geometry=100000 + geometry)        # (100000: whole tiles, no stream-K cut)
         assert got_cl.shape == want.shape and torch.equal(got_cl, want), (shape, geometry, res_kind, float((got_cl - want).abs().max()))
-        got_sp = ops.conv3x3_sp(xs, w16, b, Co, res_new, relu, out_split=True, geometry=geometry)
+        got_sp = ops.conv3x3_sp(xs, w16, b, Co, res_new, relu, out_split=True, geometry=100000 + geometry)
         assert_split_map_holds(got_sp, want, (shape, geometry, res_kind))
+        if geometry in (81, 148) and Ci >= 32:                  # the same launch with its tiles cut between workgroups (stream-K): another summation order, same sums
+            cut = ops.conv3x3_sp(xs, w16, b, Co, res_new, relu, out_split=False, geometry=200000 + geometry)
+            assert float((cut - want).abs().max()) <= 2e-6 * float(want.abs().max()), (shape, geometry, res_kind)
+            assert torch.equal(cut, ops.conv3x3_sp(xs, w16, b, Co, res_new, relu, out_split=False, geometry=200000 + geometry))
     assert not ops.sp_range_exceeded(DEV)
 
 
@@ -260,10 +264,15 @@ def test_conv3x3_sp_backbone_shapes_bit_equal_and_against_float64(shape):
     got = ops.conv3x3_sp(xs, w16, b, Co, rs, True, out_split=False)
     ref = conv64(x, w, b, r)
     scale = float(ref.abs().max())
-    if N * H * W * Co // (256 * 64) > 256 and Ci >= 256:          # the consumer-split kernel hands long tiles over between workgroups here (stream-K): another summation order
-        assert float((got - want).abs().max()) / scale < 1e-6
+    whole = ops.conv3x3_sp(xs, w16, b, Co, rs, True, out_split=False, geometry=100000)
+    if shape != (1, 256, 256, 100, 352):                          # (there the consumer-split kernel itself hands long tiles over between workgroups: another summation order)
+        assert torch.equal(whole, want)
+    assert float((whole - want).abs().max()) / scale < 1e-6
+    if ops.conv3x3_sp_is_split(N, Ci, Co, H, W):                  # the product's launch cuts this shape's tiles (stream-K): same sums, another order, deterministic
+        assert float((got - whole).abs().max()) / scale < 1e-6
+        assert torch.equal(got, ops.conv3x3_sp(xs, w16, b, Co, rs, True, out_split=False))
     else:
-        assert torch.equal(got, want)
+        assert torch.equal(got, whole)
     assert float((got.double() - ref).abs().max()) / scale < 2e-6
     got_sp = ops.conv3x3_sp(xs, w16, b, Co, rs, True, out_split=True)
     assert_split_map_holds(got_sp, got)
@@ -345,3 +354,36 @@ def test_empty_frame_and_empty_agent_on_the_sparse_canvas_route():
                 det.SPARSE_CANVAS = saved
         for k in out:
             assert torch.isfinite(out[k]).all() and rel_err(out[k], ref[k]) < 1e-5, (name, k)
+
+
+def test_conv3x3_sp_stream_k_hand_over_stress():
+    """The stream-K hand-over (partial sums through L2-bypassing stores / loads, flags the consumers reset) under load: hundreds of launches on two streams
+    at once, each with its own workspace, every result bit-equal to the first; the flag words are zero again after every launch."""
+    shapes = [(5, 256, 256, 25, 88), (2, 128, 128, 30, 50)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    cases = []
+    for (N, Ci, Co, H, W), st in zip(shapes, streams):
+        g = torch.Generator(device=DEV).manual_seed(H)
+        x = ops.SplitMap.pack(torch.relu(torch.randn((N, Ci, H, W), generator=g, device=DEV)))
+        w16 = ops.pack_conv3x3_emu_weight(torch.randn((Co, Ci, 3, 3), generator=g, device=DEV) / (9 * Ci) ** 0.5, 16, True)
+        b = torch.randn(Co, generator=g, device=DEV)
+        geo = 200000 + (148 if H == 25 else 81)
+        assert ops.conv3x3_sp_is_split(N, Ci, Co, H, W, geo)
+        cases.append((x, w16, b, Co, geo, st))
+    torch.cuda.synchronize()
+    first, outs = [], [[], []]
+    for i, (x, w16, b, Co, geo, st) in enumerate(cases):
+        with torch.cuda.stream(st):
+            first.append(ops.conv3x3_sp(x, w16, b, Co, None, True, out_split=False, geometry=geo))
+    torch.cuda.synchronize()
+    for rep in range(150):
+        for i, (x, w16, b, Co, geo, st) in enumerate(cases):
+            with torch.cuda.stream(st):
+                outs[i].append(ops.conv3x3_sp(x, w16, b, Co, None, True, out_split=False, geometry=geo))
+        if rep % 50 == 49:
+            torch.cuda.synchronize()
+            for i in range(2):
+                assert all(torch.equal(o, first[i]) for o in outs[i]), (rep, i)
+                outs[i].clear()
+    for ws in ops._SP_WS.values():
+        assert int(ws[:2048].view(torch.int32).abs().sum()) == 0          # every flag consumed and reset

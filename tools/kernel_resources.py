@@ -16,10 +16,14 @@ def main():
     sub = sys.argv[2] if len(sys.argv) > 2 else ""
     cmd = [B._hipcc(), "-x", "hip"] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + (["-DCOALIGN_LAB"] if os.environ.get("LAB") else []) + \
           ["--cuda-device-only", "-c", os.path.join(B.CSRC, src), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
-    text = subprocess.run(cmd, capture_output=True, text=True).stderr
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL)
+    text = res.stderr
     blocks = re.split(r"remark: [^\n]*Function Name: ", text)[1:]
+    if res.returncode != 0 or not blocks:
+        print("\n".join(l for l in text.splitlines() if "error" in l or "Error" in l)[:4000] or text[-2000:])
+        raise SystemExit(f"compile failed (rc {res.returncode})")
     names = [b.split("\n")[0].split()[0] for b in blocks]
-    dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.strip().split("\n")
+    dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=60).stdout.strip().split("\n")
     for b, d in zip(blocks, dem):
         if sub not in d:
             continue
