@@ -107,16 +107,18 @@ def kernel_trace_us():
     """Average kernel durations (us) of the pillar op and the fusion from the committed rocprofv3 --kernel-trace --stats summary of
     tools/kernels_only.py (same workload as the roofline figures): an independent clock beside the HIP events."""
     import csv
-    path = next((q for q in (os.path.join(ROOT, "profiles", r, "kernels_isolated_stats.csv") for r in ("round4", "round3")) if os.path.exists(q)), "")
+    path = next((q for q in (os.path.join(ROOT, "profiles", r, "kernels_isolated_stats.csv") for r in ("round5", "round4", "round3")) if os.path.exists(q)), "")
     if not path:
         return None
     out = {}
     for r in csv.DictReader(open(path)):
         n, us = r["Name"], float(r["AverageNs"]) / 1e3
-        for key, tag in (("pillar_prep_kernel", "pillar_prep_us"), ("pillar_rows_mx_kernel", "pillar_rows_us"), ("warp_fuse_nhwc_kernel", "fuse_us")):
+        for key, tag in (("pillar_prep_kernel", "pillar_prep_us"), ("pillar_rows_mx_kernel", "pillar_rows_us"), ("warp_fuse_nhwc_kernel", "fuse_us"), ("pillar_sparse_kernel", "pillar_sparse_us")):
             if key in n:
                 out[tag] = round(us, 2)
-    if "pillar_prep_us" in out and "pillar_rows_us" in out:
+    if "pillar_sparse_us" in out:                                  # the timed configuration's pillar op since round 4
+        out["pillar_op_us"] = out["pillar_sparse_us"]
+    elif "pillar_prep_us" in out and "pillar_rows_us" in out:
         out["pillar_op_us"] = round(out["pillar_prep_us"] + out["pillar_rows_us"], 2)
     out["source"] = os.path.relpath(path, ROOT)
     return out
@@ -152,6 +154,56 @@ def pillar_bytes_moved(M):
 def pillar_bytes_sparse(M):
     """Bytes of the one-launch sparse-canvas pillar op per call: per pillar 532 B in, 256 B feature row out, one 8-byte stamp read-modify-write (16 B)."""
     return M * (532 + 256 + 16)
+
+
+def conv_layer_rooflines(dev, N, ny, nx, pmc):
+    """the five 3x3 layer shapes of the frame, each alone on the GPU (HIP events around graph replays of 8 launches): executed 16-bit
+    TFLOP/s against the 2.5 PFLOP/s dense fp16 matrix peak, algorithmic HBM bytes (maps in + residual + out + weights once), launches per frame, and -- from the
+    committed rocprofv3 --pmc passes where present -- the matrix-pipe busy share and the corrected HBM bytes.  Kernels: coalign_conv3x3_sp on SplitMaps (the
+    stride-1 layers inside a stage and the shrink header's second convolution) and the consumer-split fp16 kernel of csrc/conv3x3_emu.hip (the layers that
+    start a SplitMap chain from float32 input)."""
+    H1, W1 = ny // 2, nx // 2
+    cases = [("stage 1: 64 -> 64 @ %dx%d x %d agents" % (H1, W1, N), "conv_sp_64ch", N, 64, 64, H1, W1, True, 5),
+             ("stage 2: 128 -> 128 @ %dx%d x %d" % (H1 // 2, W1 // 2, N), "conv_sp_128ch", N, 128, 128, H1 // 2, W1 // 2, True, 9),
+             ("stage 3: 256 -> 256 @ %dx%d x %d" % (H1 // 4, W1 // 4, N), "conv_sp_256ch", N, 256, 256, H1 // 4, W1 // 4, True, 15),
+             ("shrink header 2nd: 256 -> 256 @ %dx%d x 1" % (H1, W1), "conv_sp_shrink2_256ch_100x352", 1, 256, 256, H1, W1, True, 1),
+             ("shrink header 1st: 384 -> 256 @ %dx%d x 1 (consumer-split kernel, float32 NCHW in, SplitMap out)" % (H1, W1), "conv_fp16x2_shrink1_384ch_split_out", 1, 384, 256, H1, W1, False, 1)]
+    rows = []
+    for name, key, n, ci, co, H, W, sp, per_frame in cases:
+        try:
+            g = torch.Generator(device=dev).manual_seed(ci + H)
+            x = torch.relu(torch.randn((n, ci, H, W), generator=g, device=dev))
+            w16 = ops.pack_conv3x3_emu_weight(torch.randn((co, ci, 3, 3), generator=g, device=dev) / (9 * ci) ** 0.5, 16, True)
+            b = torch.randn(co, generator=g, device=dev)
+            if sp:
+                res = None if n == 1 else ops.SplitMap.pack(torch.randn((n, co, H, W), generator=g, device=dev))
+                xs_ = ops.SplitMap.pack(x)
+                fn = lambda: ops.conv3x3_sp(xs_, w16, b, co, res, True, out_split=n > 1)
+                kern = "conv3x3_sp_kernel (csrc/conv3x3_sp.hip)" + (", stream-K" if ops.conv3x3_sp_is_split(n, ci, co, H, W) else "")
+            else:
+                res = None
+                fn = lambda: ops.conv3x3_emu_bias_act(x, w16, b, co, None, True, 16, out_split=True)
+                kern = "conv3x3_emu_kernel, fp16 split (csrc/conv3x3_emu.hip)"
+            ms = graph_time(fn, dev)
+            executed = 3 * 2 * 9 * ci * co * H * W * n
+            hbm = 4 * n * H * W * (ci + co + (co if res is not None else 0)) + w16.numel()
+            row = {"layer": name, "kernel": kern, "launches_per_frame": per_frame, "us": round(ms * 1e3, 2), "executed_TFLOPs": round(executed / ms / 1e9, 1),
+                   "frac_of_fp16_peak": round(executed / ms / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4), "fp32_equivalent_TFLOPs": round(executed / 3 / ms / 1e9, 1),
+                   "algorithmic_hbm_MB": round(hbm / 1e6, 2), "hbm_GBps_if_streamed_once": round(hbm / ms / 1e6, 1)}
+            e = pmc.get(key) if pmc else None
+            if e:
+                c = e.get("per_op_call", {})
+                if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+                    row["pmc_mfma_busy_share"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"]), 4)      # busy cycles summed over 1024 SIMDs / kernel cycles
+                if "hbm_bytes_read_x2" in e:
+                    row["pmc_hbm_MB"] = round(e["hbm_bytes_read_x2"] / 1e6, 2)
+            rows.append(row)
+            del x, w16, b, res
+        except Exception as exc:      # noqa: BLE001  a side report must never cost the headline line
+            rows.append({"layer": name, "error": f"{type(exc).__name__}: {str(exc)[:160]}"})
+            torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    return rows
 
 
 def size_sweep(dev, steps=20, streams=None):
@@ -718,7 +770,7 @@ def main():
         # reads = 2 x FETCH_SIZE (gfx950 tallies the 128-B requests of 16 B/lane streaming loads at 64 B, MI355X_MICROARCH.md
         # "HBM"), writes = WRITE_SIZE; null when no summary is committed for this workload
         pmc, pmc_src = {}, None
-        path = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_summary.json") for r in ("round4", "round3", "round2")) if os.path.exists(q)), "")
+        path = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_summary.json") for r in ("round5", "round4", "round3", "round2")) if os.path.exists(q)), "")
         if path and N == 5 and args.pillars == 8000 and args.config == "opv2v_coalign":
             pmc, pmc_src = json.load(open(path)), os.path.relpath(path, ROOT)
 
@@ -768,6 +820,10 @@ def main():
             alg = pillar_alg + fuse_bytes
             north.update({"frac": round(alg / tot_ms / 1e6 / HBM_PEAK_GBPS, 4), "achieved": round(alg / tot_ms / 1e6, 1), "unit": "GB/s",
                           "algorithmic_bytes": alg, "ms": round(tot_ms, 5)})
+            # north_star's literal wording is the HBM-READ roofline: bytes READ by the path (532 B per pillar; every agent's map at the three scales) / the same time
+            read_bytes = M * 532 + sum(N * C * H * W * 4 for C, H, W in scales)
+            north["read_bytes"] = read_bytes
+            north["frac_read_only"] = round(read_bytes / tot_ms / 1e6 / HBM_PEAK_GBPS, 4)
             if pillar["traffic"] and fuse["traffic"]:      # the committed PMC passes of this workload (may predate a kernel change: see its README)
                 north["traffic"] = pillar["traffic"] + fuse["traffic"]
                 north["traffic_over_algorithmic"] = round(north["traffic"] / alg, 3)
@@ -785,12 +841,26 @@ def main():
                          "`frac_survey_8d_formula` = SURVEY 8d's byte formula over the same path with a freshly zero-filled canvas per call; "
                          "`size_sweep` repeats the figures at 32 000 / 70 000 pillars per agent, N = 2 and DAIR geometry")
 
-        # `roofline` = the hand-written kernel the frame spends most of its time in: the 3x3 convolution of the active arithmetic
-        if default_terms in (2, 3, 16):
+        # `roofline` = the hand-written kernel the frame spends most of its time in.  Round 5: with the SplitMap route (fp16 split) that is coalign_conv3x3_sp at
+        # the stage-3 shape (256 -> 256 channels at ny/8 x nx/8, N agents: 15 launches per frame); `roofline_by_layer` lists all five 3x3 layer shapes.
+        layer_rows = conv_layer_rooflines(dev, N, ny, nx, pmc) if (default_terms == 16 and backbone_mod.split_maps_active()) else None
+        dom = next((r for r in (layer_rows or []) if r.get("layer", "").startswith("stage 3") and "us" in r), None)
+        if dom is not None:
+            executed = 3 * 2 * 9 * 256 * 256 * (ny // 8) * (nx // 8) * N
+            roofline = {"kernel": f"coalign_conv3x3_sp (csrc/conv3x3_sp.hip: v_mfma_f32_32x32x16_f16 on sp16 pairs, operands by LDS-DMA from the producer's SplitMap; "
+                                  f"256->256 channels at {ny // 8}x{nx // 8}, N={N}; {dom['launches_per_frame']} launches per frame)",
+                        "bound": "mfma", "achieved": dom["executed_TFLOPs"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac_of_fp16_peak"],
+                        "avg_launch_ms": round(dom["us"] / 1e3, 5), "algorithmic_flops_per_launch": executed, "fp32_equivalent_flops_per_launch": executed // 3,
+                        "fp32_equivalent_TFLOPs": dom["fp32_equivalent_TFLOPs"], "traffic": int(dom["pmc_hbm_MB"] * 1e6) if "pmc_hbm_MB" in dom else None,
+                        "note": "executed 16-bit products = 3 per fp32 product (w_h x_h, w_h x_l, w_l x_h of 22-bit operands); peak = dense fp16 MFMA (MI355X_MICROARCH.md); "
+                                "192 tiles of 16 intervals on 256 CUs: alone on the GPU a quarter of the CUs idle (in the 3-lane pipeline other frames' kernels take them)"}
+            if "pmc_mfma_busy_share" in dom:
+                roofline["pmc_mfma_busy_share"] = dom["pmc_mfma_busy_share"]
+        elif default_terms in (2, 3, 16):
             t = default_terms
             ms = iso["conv_fp16x2_ms" if t == 16 else f"conv_bf16x{t}_ms"]
             executed = conv_flops * (6 if t == 3 else 3)
-            roofline = {"kernel": (f"conv3x3_emu_bias_act (v_mfma_f32_32x32x16_f16, fp32 operands split 2-way into fp16 terms, 64->64 channels at {ny // 2}x{nx // 2}, N={N})" if t == 16 else
+            roofline = {"kernel": (f"conv3x3_emu_bias_act (v_mfma_f32_32x32x16_f16, fp32 operands as sp16 pairs split by the consumer, 64->64 channels at {ny // 2}x{nx // 2}, N={N})" if t == 16 else
                                    f"conv3x3_emu_bias_act (v_mfma_f32_32x32x16_bf16, fp32 operands split {t}-way, 64->64 channels at {ny // 2}x{nx // 2}, N={N})"),
                         "bound": "mfma", "achieved": round(executed / ms / 1e9, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(executed / ms / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 5),
@@ -807,8 +877,10 @@ def main():
         roofline["hbm_bound_kernel"] = pillar
 
         if default_terms == 16:
-            dtype = ("f32 (3x3 convolution products evaluated as 2-way split fp16 products -- 11 + 11 significant bits per operand -- on the fp16 matrix cores, "
-                     "f32 accumulation; dropped terms <= 2^-21 |w x|; measured against float64 no worse than the native fp32 matrix kernel)")
+            dtype = ("f32 (3x3 convolutions: every operand rounded to 22 significant bits and split into two fp16 terms, the low term scaled by 2^10 and the "
+                     "weights by a per-output-channel power of two so that both terms are normal fp16 numbers at any scale; three fp16 matrix products per fp32 "
+                     "product, f32 accumulation; maps between the 3x3 layers of a stage are stored as such 22-bit pairs; error against float64 <= the native fp32 "
+                     "matrix kernel's over weight scales 2e-4..2e-1 x activation scales 1e-2..1e2, tests/test_round5_gpu.py)")
         else:
             dtype = "f32" if default_terms == 0 else (f"f32 (3x3 convolution products evaluated as {default_terms}-way split bf16 products on the bf16 matrix cores, "
                                                       "f32 accumulation" + ("; dropped terms <= 2^-24 |w x|, i.e. fp32-width arithmetic)" if default_terms == 3 else ")"))
@@ -820,14 +892,14 @@ def main():
                                    f"geometry): {N} agents/frame, {args.pillars} pillars/agent, canvas {nx}x{ny}, 70400 anchors, "
                                    f"full path incl. decode + rotated NMS, {pool_n} distinct frames in rotation",
                        "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": frames_per_step, "frames_in_flight": n_lanes,
-                       "result_lag_frames": pipe.result_lag, "hip_graph": use_graph, "conv_arithmetic": "native fp32" if default_terms == 0 else "fp16x2" if default_terms == 16 else f"bf16x{default_terms}",
+                       "result_lag_frames": pipe.result_lag, "hip_graph": use_graph, "conv_arithmetic": "native fp32" if default_terms == 0 else ("fp16 split (sp16 pairs)" + (", SplitMaps between the 3x3 layers" if backbone_mod.split_maps_active() else "")) if default_terms == 16 else f"bf16x{default_terms}",
                        "parallelism": "single GPU" if world == 1 else (f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all" if mode == "ring" else
                                                                                       f"{world} independent replicas, no collective (fall-back: see `rccl.fallbacks`)" if mode == "replicas" else
                                                                                       f"one frame over {world} ranks (agent blocks), {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-gather, ego tail on every rank") +
                                        (", one communicator per lane" if args.comm_per_lane else ", one communicator"),
                        "detections_last_frame": 0 if last_boxes is None else int(last_boxes.shape[0]),
                        "candidates_last_frame": pp.last_counts["candidates"]},
-            "roofline": roofline, "north_star_hbm": north, "kernels": kernels,
+            "roofline": roofline, "roofline_by_layer": layer_rows, "north_star_hbm": north, "kernels": kernels,
             "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
             "frame_digests": {str(k): digests[k] for k in sorted(digests)}, "frame_digests_reproducible": bool(consistent),
             "frame_digest_mismatches": mismatches[:8],

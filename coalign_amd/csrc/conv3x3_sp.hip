@@ -490,10 +490,13 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
     const int row_tiles = a.stack ? (a.N * a.H + G::TH - 1) / G::TH : a.N * a.tiles_y;
     a.total_tiles = a.tiles_x * row_tiles * (a.Cout / kCoutTile);
     const int slots = n_cu, chunks = a.Cin / 16;                      // 111-147 KB of LDS: one workgroup per CU
-    // stream-K pays where whole tiles leave the chip badly filled (192 tiles on 256 CUs; 552 tiles = three rounds at 72 %) and a tile is long enough to cut
+    // Stream-K pays where whole tiles leave the last round badly filled AND a workgroup's range spans whole tiles, i.e. at most one hand-over per workgroup
+    // (the shrink header: 572 tiles of 16 intervals = three rounds at 74 %: 132 -> 125 us).  Measured where a tile is cut into several shares
+    // (profiles/round5/conv_sp_layers.json): 5 x 256 x 25 x 88 (192 tiles on 256 CUs, 12 of 16 intervals each) 42.6 -> 49.7 us, 2 x 256 x 25 x 63 (56 tiles)
+    // 38.6 -> 67.9 us -- a hand-over (32 L2-bypassing 4-byte stores and loads per lane + the flag) costs more than the intervals it saves.
     const int rounds = (a.total_tiles + slots - 1) / slots;
     const long long steps = (long long)a.total_tiles * chunks;
-    bool split = CAN_SPLIT && chunks >= 4 && steps >= 2LL * slots && (long long)a.total_tiles * 100 < (long long)rounds * slots * 88;
+    bool split = CAN_SPLIT && chunks >= 16 && a.total_tiles > slots && (long long)a.total_tiles * 100 < (long long)rounds * slots * 88;
     if (split_policy == 1) split = false;
     if (split_policy == 2) split = CAN_SPLIT && chunks >= 2 && steps >= slots;
     SpLaunch l;

@@ -107,7 +107,30 @@ def _folded():
     return _fold_cache["f"]
 
 
+# round 5: the producer-split convolutions on SplitMaps (csrc/conv3x3_sp.hip) and the layers that write the first SplitMap of a chain
+_sp = {}
+def _spx(i):
+    if i not in _sp:
+        _sp[i] = (ops.SplitMap.pack(torch.relu(xs[i])), ops.SplitMap.pack((rconv, _r128, _r256)[i]))
+    return _sp[i]
+_x256s = {}
+def _x256sp():
+    if "x" not in _x256s:
+        _x256s["x"] = ops.SplitMap.pack(torch.relu(_x256))
+    return _x256s["x"]
+_x384 = torch.randn(1, 384, 100, 352, generator=g).to(dev)
+_w384 = ops.pack_conv3x3_emu_weight(torch.randn(256, 384, 3, 3, generator=g).to(dev) / 59.0, 16, True)
+_w16_s2_128 = ops.pack_conv3x3_emu_weight(torch.randn(128, 64, 3, 3, generator=g).to(dev) / 24.0, 16, False)
+
 OPS = {
+    "conv_sp_64ch": lambda: ops.conv3x3_sp(_spx(0)[0], _w16, bconv, 64, _spx(0)[1], True, out_split=True),
+    "conv_sp_128ch": lambda: ops.conv3x3_sp(_spx(1)[0], _w16_128, _b128, 128, _spx(1)[1], True, out_split=True),
+    "conv_sp_256ch": lambda: ops.conv3x3_sp(_spx(2)[0], _w16_256, _b256, 256, _spx(2)[1], True, out_split=True),
+    "conv_sp_256ch_nhwc_out": lambda: ops.conv3x3_sp(_spx(2)[0], _w16_256, _b256, 256, _spx(2)[1], True, out_split=False),
+    "conv_sp_shrink2_256ch_100x352": lambda: ops.conv3x3_sp(_x256sp(), _w16_256, _b256, 256, None, True, out_split=False),
+    "conv_fp16x2_shrink1_384ch_split_out": lambda: ops.conv3x3_emu_bias_act(_x384, _w384, _b256, 256, None, True, 16, out_split=True),
+    "conv_fp16x2_s2_64to128_nhwc_in_split_out": lambda: ops.conv3x3_emu_bias_act(xcl[0], _w16_s2_128, _b128, 128, None, True, 16, stride=2, out_split=True),
+    "conv_fp16x2_s2_sparse_canvas_split_out": lambda: ops.conv3x3_emu_sparse(_sc(), _w16_s2, bconv, 64, True, 16, out_channels_last=False, out_split=True),
     "nms_gather_K600": _nms_fused,
     "nms_then_gather_K600": _nms_two_calls,
     "pillar_nchw": pillar(False),
