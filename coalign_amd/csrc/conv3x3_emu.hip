@@ -169,7 +169,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     constexpr bool TAPK = (VAR & VAR_TAPK) != 0, STACK = (VAR & VAR_STACK) != 0, F16 = (VAR & VAR_F16) != 0;
     constexpr bool DUAL = F16;          // sp16 operands (common.h): a second accumulator for the products that carry 2^10, per-channel weight scale
     using G = Geo<BH, BW, NPB, TERMS, KCH, STRIDE, PBUF, TAPK, (VAR >> 2) & 7>;
-    static_assert(!(SPLIT && (STRIDE != 1 || LAYOUT != LAYOUT_NCHW || STACK)), "stream-K hand-over only for the plain stride-1 NCHW variant");
+    static_assert(!(SPLIT && (STRIDE != 1 || (LAYOUT != LAYOUT_NCHW && LAYOUT != LAYOUT_OUT_SP) || STACK)), "stream-K hand-over only for the plain stride-1 NCHW-input variants");
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;      // wave: scalar
     const size_t plane = (size_t)a.H * a.W, plane_in = (size_t)a.Hin * a.Win;
@@ -706,7 +706,7 @@ int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
     return COALIGN_ERR_UNSUPPORTED;
 }
 
-template <int BH, int BW, int NPB, int TERMS, int KCH, int PBUF = 2, int VAR = 0>
+template <int BH, int BW, int NPB, int TERMS, int KCH, int PBUF = 2, int VAR = 0, int LAYOUT = LAYOUT_NCHW>
 int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream_t s, Launch *query) {
     constexpr bool TAPK = (VAR & VAR_TAPK) != 0;
     static_assert(!(VAR & (VAR_STACK | VAR_NCO1)), "stacked / 32-channel variants go through launch_variant (whole tiles)");
@@ -719,8 +719,8 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
         cus = prop.multiProcessorCount;
         for (int sp = 0; sp < 2; ++sp) {
-            const void *fn = sp ? reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT_NCHW, PBUF, VAR>)
-                                : reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, 1, LAYOUT_NCHW, PBUF, VAR>);
+            const void *fn = sp ? reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT, PBUF, VAR>)
+                                : reinterpret_cast<const void *>(conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, 1, LAYOUT, PBUF, VAR>);
             const int rc = coalign::hip_call(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
             if (rc != COALIGN_OK) {                // geometry does not fit this device's LDS: report, leave no sticky error behind
                 (void)hipGetLastError();
@@ -728,7 +728,7 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
             }
         }
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT_NCHW, PBUF, VAR>, G::THREADS, G::LDS_BYTES) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT, PBUF, VAR>, G::THREADS, G::LDS_BYTES) != hipSuccess || n < 1) n = 1;
         resident = n;
     }
     EmuArgs a = a0;
@@ -758,9 +758,9 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
         a.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + l.flag_bytes);
         const int rc = coalign::fill_words(workspace, l.flag_bytes / 4, 0u, s);
         if (rc != COALIGN_OK) return rc;
-        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT_NCHW, PBUF, VAR>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, true, 1, LAYOUT, PBUF, VAR>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
     } else {
-        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, 1, LAYOUT_NCHW, PBUF, VAR>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+        hipLaunchKernelGGL((conv3x3_emu_kernel<BH, BW, NPB, TERMS, KCH, false, 1, LAYOUT, PBUF, VAR>), dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
     }
     return COALIGN_OK;
 }
@@ -808,14 +808,8 @@ int tapk_launch(const EmuArgs &a, int layout, void *ws, size_t ws_bytes, hipStre
         }
         return launch_variant<BH, BW, NPB, TERMS, 2, 1, LAYOUT_OUT_NHWC, 1, VAR>(a, s);
     }
-    if constexpr ((VAR & VAR_F16) != 0) {
-        if (layout == LAYOUT_OUT_SP) {
-            if (query) {
-                *query = Launch{0, 0, 0, false};
-                return COALIGN_OK;
-            }
-            return launch_variant<BH, BW, NPB, TERMS, 2, 1, LAYOUT_OUT_SP, 1, VAR>(a, s);
-        }
+    if constexpr ((VAR & VAR_F16) != 0) {          // SplitMap output: the same whole-tile / stream-K choice as the NCHW output (the shrink header's first convolution)
+        if (layout == LAYOUT_OUT_SP) return launch<BH, BW, NPB, TERMS, 2, 1, VAR, LAYOUT_OUT_SP>(a, ws, ws_bytes, s, query);
     }
     if (layout != LAYOUT_NCHW) return COALIGN_ERR_UNSUPPORTED;
     return launch<BH, BW, NPB, TERMS, 2, 1, VAR>(a, ws, ws_bytes, s, query);
@@ -956,7 +950,9 @@ extern "C" size_t coalign_conv3x3_emu_workspace_bytes_ex(int N, int Cin, int Cou
     if (check_emu_args(N, Cin, Cout, H, W, terms) != COALIGN_OK || N == 0) return 0;
     EmuArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, N, Cin, Cout, H, W, 0, 0, 0, 0, H, W, nullptr, nullptr};
     Launch l{};
-    const int rc = terms == 3 ? dispatch_tapk<3>(a, layout & 3, nullptr, 0, nullptr, &l) : terms == 16 ? dispatch_tapk<2, true>(a, layout & 3, nullptr, 0, nullptr, &l) : dispatch_tapk<2>(a, layout & 3, nullptr, 0, nullptr, &l);
+    const int lay = (layout & kLayoutOutSp) ? LAYOUT_OUT_SP : (layout & 3);
+    if (lay == LAYOUT_OUT_SP && terms != 16) return 0;
+    const int rc = terms == 3 ? dispatch_tapk<3>(a, lay, nullptr, 0, nullptr, &l) : terms == 16 ? dispatch_tapk<2, true>(a, lay, nullptr, 0, nullptr, &l) : dispatch_tapk<2>(a, lay, nullptr, 0, nullptr, &l);
     return rc == COALIGN_OK && l.split ? l.ws_bytes : 0;
 }
 

@@ -855,7 +855,7 @@ def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Ten
         raise ValueError("residual shape mismatch")
     ws, ws_bytes = None, 0
     layout |= tapk
-    if stride == 1 and (layout & 3) == LAYOUT_NCHW and not out_split:
+    if stride == 1 and (layout & 3) == LAYOUT_NCHW:
         ws_bytes = L.coalign_conv3x3_emu_workspace_bytes_ex(N, Cin, cout, H, W, terms, layout)
     if ws_bytes:
         key = (xc.device, torch.cuda.current_stream(xc.device).cuda_stream, "emu")
