@@ -16,9 +16,17 @@
 //
 // Encoder: the PFN input of a point is affine in the point once the pillar is fixed:
 //     W f = (w_abs + w_cluster + w_center) (p - c) + w_i intensity + [w_abs c - w_cluster (mean - c)]
-// a K = 4 contraction per point.  Round 3 ran it as six split-bf16 products; here it runs EXACTLY in fp32 on v_mfma_f32_32x32x2_f32 (two steps of
-// K = 2, a 32-point pillar = the 32 rows of one matrix instruction): no operand splitting, no LDS staging of rows -- the A operands are the
-// point registers after one v_permlane32_swap.  D = fma(d3, w3, fma(d2, w2, fma(d1, w1, d0 w0))) bit for bit.
+// a K = 4 contraction per point and channel; the bracket is evaluated per pillar in fp32.  Round 4 ran the contraction exactly in fp32 on
+// v_mfma_f32_32x32x2_f32: 8 instructions of 64 cycles per pillar pair on the port the kernel's VALU work needs too (pmc_summary.json: the kernel was
+// VALU-bound at 0.21 of the HBM roofline).  Round 5: ONE v_mfma_f32_32x32x16_f16 per (pillar, 32 channels): the 16 K slots hold the three product groups of
+// a 22-bit operand split,
+//     lanes 0-31  (k 0-7):   A = [dh0 dh1 dh2 dh3 | dh0 dh1 dh2 dh3]    B = [wh0 wh1 wh2 wh3 | wl0 wl1 wl2 wl3]
+//     lanes 32-63 (k 8-15):  A = [dl0 dl1 dl2 dl3 |  0   0   0   0 ]    B = [wh0 wh1 wh2 wh3 |  0   0   0   0 ]
+// d = (p - c) * 2^6 and the intensity * 2^6 (the offsets inside a 0.4 m cell are small: scaled, the low terms stay normal fp16 numbers down to offsets of
+// 2 mm, below that they keep an absolute 5e-10 m), dh = fp16(d), dl = fp16(d - dh) (exact remainder); w = the summed weights times the per-channel power of
+// two that puts the largest of the four into [2^13, 2^14), wh = fp16(w), wl = fp16(w - wh).  sum_k (dh wh + dh wl + dl wh) in the fp32 accumulator drops only
+// dl wl (< 2^-20 of a product); 2^-(k_c + 6) rides on the sign factor of the epilogue (exact).  The A operands are the lane's own point after two
+// v_permlane32_swap.  Against float64 the features stay within 2e-6 of their scale (the bracket, evaluated in fp32 as before, carries the magnitude).
 #include <stdlib.h>
 
 #include "common.h"
@@ -30,6 +38,7 @@ typedef __attribute__((address_space(3))) void *lptr_sp_t;
 
 constexpr int kWaves = 4;                   // wavefronts per workgroup
 constexpr int kRunPairs = 32;               // pillar pairs per wavefront at most (one lane per pillar in the prologue)
+constexpr int kPointShift = 6;              // the point offsets enter the fp16 contraction times 2^6 (see the header)
 constexpr int kRound = 3;                   // pairs per LDS-DMA round (3 KB per buffer: 8 KB of LDS per wavefront, 32 KB per workgroup; the grid puts three workgroups on a CU)
 #ifdef COALIGN_LAB
 constexpr bool kLab = true;
@@ -55,7 +64,7 @@ struct SparseArgs {
     unsigned long long *stamps;
     int *state;
     const int *M_dev;
-    const float4 *folded;  // the folded channel parameters written by coalign_pillar_fold_params ([6][64] float4)
+    const float4 *folded;  // the folded channel parameters written by coalign_pillar_fold_params ([7][64] float4)
     int debug;            // laboratory build only (COALIGN_SPARSE_DEBUG): 1 no stamp atomics, 2 no matrix steps, 4 no arrival counter, 8 no feature stores
 };
 
@@ -90,7 +99,7 @@ __device__ __forceinline__ float max16(const floatx16 &v) {
 
 // per-lane channel parameters in the half layout: channel 32 g + (lane & 31)
 struct F32Chan {
-    float wb[2][2];                  // B operand of step s for channel group g: W4[2 s + (lane >> 5)][32 g + (lane & 31)] (sign folded)
+    unsigned wq[2][4];               // B operand of channel group g: 8 fp16 = the lane's K slots (see the header), sign and 2^k_c folded
     float wc[2][3], wen[2][3];       // weights of the centre term, negated weights of the mean-offset term
     float alpha[2], shift[2], sgn[2];
 };
@@ -140,14 +149,29 @@ __device__ __forceinline__ F32Chan finish_f32(const F32Raw<ABS> &r, const Sparse
         for (int k = 0; k < 3; ++k) w4[k] = live ? ((ABS ? r.w[g][k] : 0.f) + r.w[g][B + k]) + r.w[g][B + 3 + k] : 0.f;
         w4[3] = live ? r.w[g][ABS ? 3 : 0] : 0.f;
         const float sg = alpha < 0.f ? -1.f : 1.f;       // a negative BatchNorm scale turns the max over the rows into a min: negate the weights instead
-        fc.alpha[g] = alpha; fc.shift[g] = shift; fc.sgn[g] = sg;
+        // per-channel power of two: the largest of the four weights into [2^13, 2^14) (exact); with the 2^6 of the point offsets it leaves through `sgn`
+        const float wmax = fmaxf(fmaxf(fabsf(w4[0]), fabsf(w4[1])), fmaxf(fabsf(w4[2]), fabsf(w4[3])));
+        int kc = wmax > 0.f ? 13 - (int)(((__builtin_bit_cast(unsigned, wmax) >> 23) & 0xffu) - 127u) : 0;
+        kc = kc < -60 ? -60 : kc > 60 ? 60 : kc;
+        const float wsc = __builtin_bit_cast(float, (unsigned)(127 + kc) << 23), winv = __builtin_bit_cast(float, (unsigned)(127 - kc - kPointShift) << 23);
+        fc.alpha[g] = alpha; fc.shift[g] = shift; fc.sgn[g] = sg * winv;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             fc.wc[g][k] = (ABS && live) ? r.w[g][k] : 0.f;
             fc.wen[g][k] = live ? -r.w[g][B + k] : 0.f;
         }
+        _Float16 wh[4], wl[4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) fc.wb[g][s] = sg * (half ? w4[2 * s + 1] : w4[2 * s]);
+        for (int k = 0; k < 4; ++k) {
+            const float ws = sg * w4[k] * wsc;
+            wh[k] = (_Float16)ws;
+            wl[k] = (_Float16)(ws - (float)wh[k]);
+        }
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        fc.wq[g][0] = __builtin_bit_cast(unsigned, h2{wh[0], wh[1]});
+        fc.wq[g][1] = __builtin_bit_cast(unsigned, h2{wh[2], wh[3]});
+        fc.wq[g][2] = half ? 0u : __builtin_bit_cast(unsigned, h2{wl[0], wl[1]});
+        fc.wq[g][3] = half ? 0u : __builtin_bit_cast(unsigned, h2{wl[2], wl[3]});
     }
     return fc;
 }
@@ -159,11 +183,26 @@ __device__ __forceinline__ F32Chan finish_f32(const F32Raw<ABS> &r, const Sparse
 template <bool ABS>
 __device__ __forceinline__ void f32_pair_half(const SparseArgs &a, const F32Chan &fc, float4 q, float4 qs, int np_eff, float rn, float ctr_x, float ctr_y, float ctr_z, float (&y)[2]) {
     const float ex = half_sum_dpp(q.x) * rn - ctr_x, ey = half_sum_dpp(q.y) * rn - ctr_y, ez = half_sum_dpp(q.z) * rn - ctr_z;
-    float d0 = qs.x - ctr_x, d1 = qs.y - ctr_y, d2 = qs.z - ctr_z, d3 = qs.w;
-    // A operands: lane l holds A[i = l & 31][k = l >> 5].  One swap turns [A.d0 | B.d0], [A.d1 | B.d1] into [A.d0 | A.d1] (pillar A, step 0) and
-    // [B.d0 | B.d1] (pillar B, step 0); likewise d2 / d3 for step 1.
-    swap32(d0, d1);
-    swap32(d2, d3);
+    // this lane's point as the scaled offset d = (p - c) * 2^6, split into fp16 terms: dh = fp16(d), dl = fp16(d - dh)
+    constexpr float kS = (float)(1 << kPointShift);
+    const float d0 = (qs.x - ctr_x) * kS, d1 = (qs.y - ctr_y) * kS, d2 = (qs.z - ctr_z) * kS, d3 = qs.w * kS;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const h2 h01 = __builtin_convertvector(f2{d0, d1}, h2), h23 = __builtin_convertvector(f2{d2, d3}, h2);
+    const h2 l01 = __builtin_convertvector(f2{d0 - (float)h01[0], d1 - (float)h01[1]}, h2), l23 = __builtin_convertvector(f2{d2 - (float)h23[0], d3 - (float)h23[1]}, h2);
+    // A operands: lanes 0-31 carry [dh | dh] of the pillar's point l & 31, lanes 32-63 [dl | 0].  One swap per dword turns the lane's own
+    // (dh, dl) = ([A.dh | B.dh], [A.dl | B.dl]) into pillar A's operand [A.dh | A.dl] and pillar B's [B.dh | B.dl].
+    unsigned pa0 = __builtin_bit_cast(unsigned, h01), pb0 = __builtin_bit_cast(unsigned, l01), pa1 = __builtin_bit_cast(unsigned, h23), pb1 = __builtin_bit_cast(unsigned, l23);
+    {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pa0, pb0, false, false);
+        const unsigned x0 = s0[0], y0 = s0[1];
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pa1, pb1, false, false);
+        const unsigned x1 = s1[0], y1 = s1[1];
+        pa0 = x0; pb0 = y0; pa1 = x1; pb1 = y1;
+    }
+    const bool hi = (threadIdx.x & 32) != 0;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const h8 opA = __builtin_bit_cast(h8, uint4{pa0, pa1, hi ? 0u : pa0, hi ? 0u : pa1}), opB = __builtin_bit_cast(h8, uint4{pb0, pb1, hi ? 0u : pb0, hi ? 0u : pb1});
     const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     floatx16 accA[2], accB[2];
     if (kLab && (a.debug & 2)) {
@@ -171,15 +210,11 @@ __device__ __forceinline__ void f32_pair_half(const SparseArgs &a, const F32Chan
         for (int g = 0; g < 2; ++g) { accA[g] = zero; accB[g] = zero; accA[g][0] = d0 + d2; accB[g][0] = d1 + d3; }
     } else {
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        accA[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, fc.wb[g][0], zero, 0, 0, 0);
-        accB[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, fc.wb[g][0], zero, 0, 0, 0);
-    }
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        accA[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, fc.wb[g][1], accA[g], 0, 0, 0);
-        accB[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(d3, fc.wb[g][1], accB[g], 0, 0, 0);
-    }
+        for (int g = 0; g < 2; ++g) {
+            const h8 w = __builtin_bit_cast(h8, uint4{fc.wq[g][0], fc.wq[g][1], fc.wq[g][2], fc.wq[g][3]});
+            accA[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(opA, w, zero, 0, 0, 0);
+            accB[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(opB, w, zero, 0, 0, 0);
+        }
     }
     const bool padded = np_eff < a.P, empty = np_eff == 0;
 #pragma unroll
@@ -199,17 +234,22 @@ __device__ __forceinline__ void f32_pair_half(const SparseArgs &a, const F32Chan
 }
 
 // the folded parameters of one lane as six float4 (coalign_pillar_fold_params writes them, the kernel reads them back in the same order)
-__device__ __forceinline__ void chan_to_vec(const F32Chan &fc, float4 (&t)[6]) {
-    t[0] = make_float4(fc.wb[0][0], fc.wb[0][1], fc.wb[1][0], fc.wb[1][1]);
+constexpr int kFoldVecs = 7;
+__device__ __forceinline__ void chan_to_vec(const F32Chan &fc, float4 (&t)[kFoldVecs]) {
+    auto f = [](unsigned u) { return __builtin_bit_cast(float, u); };
+    t[0] = make_float4(f(fc.wq[0][0]), f(fc.wq[0][1]), f(fc.wq[0][2]), f(fc.wq[0][3]));
+    t[6] = make_float4(f(fc.wq[1][0]), f(fc.wq[1][1]), f(fc.wq[1][2]), f(fc.wq[1][3]));
     t[1] = make_float4(fc.wc[0][0], fc.wc[0][1], fc.wc[0][2], fc.wc[1][0]);
     t[2] = make_float4(fc.wc[1][1], fc.wc[1][2], fc.wen[0][0], fc.wen[0][1]);
     t[3] = make_float4(fc.wen[0][2], fc.wen[1][0], fc.wen[1][1], fc.wen[1][2]);
     t[4] = make_float4(fc.alpha[0], fc.alpha[1], fc.shift[0], fc.shift[1]);
     t[5] = make_float4(fc.sgn[0], fc.sgn[1], 0.f, 0.f);
 }
-__device__ __forceinline__ F32Chan vec_to_chan(const float4 (&t)[6]) {
+__device__ __forceinline__ F32Chan vec_to_chan(const float4 (&t)[kFoldVecs]) {
     F32Chan fc;
-    fc.wb[0][0] = t[0].x; fc.wb[0][1] = t[0].y; fc.wb[1][0] = t[0].z; fc.wb[1][1] = t[0].w;
+    auto u = [](float f) { return __builtin_bit_cast(unsigned, f); };
+    fc.wq[0][0] = u(t[0].x); fc.wq[0][1] = u(t[0].y); fc.wq[0][2] = u(t[0].z); fc.wq[0][3] = u(t[0].w);
+    fc.wq[1][0] = u(t[6].x); fc.wq[1][1] = u(t[6].y); fc.wq[1][2] = u(t[6].z); fc.wq[1][3] = u(t[6].w);
     fc.wc[0][0] = t[1].x; fc.wc[0][1] = t[1].y; fc.wc[0][2] = t[1].z; fc.wc[1][0] = t[1].w;
     fc.wc[1][1] = t[2].x; fc.wc[1][2] = t[2].y; fc.wen[0][0] = t[2].z; fc.wen[0][1] = t[2].w;
     fc.wen[0][2] = t[3].x; fc.wen[1][0] = t[3].y; fc.wen[1][1] = t[3].z; fc.wen[1][2] = t[3].w;
@@ -224,10 +264,10 @@ template <bool ABS>
 __global__ __launch_bounds__(64) void pillar_fold_kernel(SparseArgs a, float4 *out) {
     const int lane = threadIdx.x & 63;
     const F32Chan fc = finish_f32<ABS>(load_f32_raw<ABS>(a, lane), a, lane);
-    float4 t[6];
+    float4 t[kFoldVecs];
     chan_to_vec(fc, t);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) out[i * 64 + lane] = t[i];
+    for (int i = 0; i < kFoldVecs; ++i) out[i * 64 + lane] = t[i];
 }
 
 template <bool ABS>
@@ -277,9 +317,9 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
             np_j = *reinterpret_cast<const int *>(np_b + (unsigned)mj * 4u);
             cd_j = *reinterpret_cast<const int4 *>(cd_b + (unsigned)mj * 16u);
         }
-        float4 ft[6];
+        float4 ft[kFoldVecs];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) ft[i] = a.folded[i * 64 + lane];
+        for (int i = 0; i < kFoldVecs; ++i) ft[i] = a.folded[i * 64 + lane];
         if (pro) {
             const int cell = cd_j.y + cd_j.z * a.nx + cd_j.w;       // z + y * nx + x (point_pillar_scatter.py:54)
             const bool ok = m_j < a.M && cd_j.x >= 0 && cd_j.x < a.n_agents && cell >= 0 && cell < ncell;
@@ -366,7 +406,7 @@ static int fill_sparse_params(SparseArgs &a, int P, const float *pfn_weight, con
     return COALIGN_OK;
 }
 
-extern "C" size_t coalign_pillar_folded_param_bytes(void) { return 6 * 64 * sizeof(float4); }
+extern "C" size_t coalign_pillar_folded_param_bytes(void) { return kFoldVecs * 64 * sizeof(float4); }
 
 // Once per weight set: the encoder's channel parameters in the form the pair loop uses (BatchNorm folded, the three weight groups summed, signs folded), one
 // record per lane of a wavefront.  coalign_pillar_encode_sparse then reads 96 bytes per lane instead of 30 scalars + a square root and a division per channel.

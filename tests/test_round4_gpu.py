@@ -207,7 +207,7 @@ def _sparse_encode(model, margs, pl, n_agents, cache, count_dev=None):
 
 @pytest.mark.parametrize("pillars", [8000, 70000])
 def test_sparse_canvas_encoder_against_float64_and_oracle_scatter(pillars):
-    """coalign_pillar_encode_sparse (exact-fp32 matrix-instruction PFN, one launch) at the benchmarked size and at max_voxel_test = 70 000 pillars per
+    """coalign_pillar_encode_sparse (the PFN contraction as ONE fp16 matrix instruction on 22-bit operand splits, the per-pillar terms in fp32; one launch) at the benchmarked size and at max_voxel_test = 70 000 pillars per
     agent x 5 (pointpillar_coalign.yaml:52-54): feature rows against a float64 evaluation of pillar_vfe.py:105-155 (<= 2e-6 of the scale, negative
     BatchNorm scales included), the densified canvas bit-equal to the oracle's scatter of those rows (point_pillar_scatter.py:15-72)."""
     from oracle import coalign_oracle as oracle
@@ -244,14 +244,15 @@ def test_pillar_fold_params_table_and_reuse():
     pfn = model.pillar_vfe.pfn_layers[0]
     bn = (pfn.norm.weight, pfn.norm.bias, pfn.norm.running_mean, pfn.norm.running_var)
     folded = ops.pillar_fold_params(pfn.linear.weight, None, bn, 1e-3, True)
-    t = folded.view(6, 64, 4).cpu()
+    t = folded.view(7, 64, 4).cpu()
     alpha = (pfn.norm.weight / torch.sqrt(pfn.norm.running_var + 1e-3)).cpu()
     shift = (pfn.norm.bias - pfn.norm.running_mean * (pfn.norm.weight / torch.sqrt(pfn.norm.running_var + 1e-3))).cpu()
     lanes = torch.arange(64)
     for g in range(2):
         ch = 32 * g + (lanes & 31)
         assert torch.allclose(t[4, :, g], alpha[ch], rtol=2e-7, atol=0) and torch.allclose(t[4, :, 2 + g], shift[ch], rtol=1e-6, atol=1e-7)
-        assert torch.equal(t[5, :, g], torch.where(alpha[ch] < 0, -1.0, 1.0))
+        # slot 5: the sign of the BatchNorm scale times the power of two 2^-(k_c + 6) that takes the fp16 contraction's scaling out again (round 5)
+        assert torch.equal(torch.sign(t[5, :, g]), torch.where(alpha[ch] < 0, -1.0, 1.0)) and torch.equal(torch.frexp(t[5, :, g].abs())[0], torch.full((64,), 0.5))
     pl = make_frame(h, 2, pillars_per_agent=3000, seed=5)["processed_lidar"]
     cache = {}
     a = _sparse_encode(model, margs, pl, 2, cache)
