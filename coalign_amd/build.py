@@ -29,7 +29,10 @@ LAB_LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip_lab.so")
 # cause).  `python -m coalign_amd.build --labvec`; COALIGN_LAB=vec loads it.  tools/pk_f32_recheck.sh runs the experiment.
 LABVEC_LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip_labvec.so")
 INCLUDE = os.path.join(REPO, "include")
-SOURCES = ["status.cpp", "pillar_scatter.hip", "pillar_sparse.hip", "warp_fuse.hip", "warp_fuse_nhwc.hip", "decode.hip", "nms.hip", "epilogue.hip", "voxelize.hip", "pose_graph.hip", "conv3x3.hip", "conv3x3_emu.hip", "conv3x3_sp.hip", "conv3x3_wino.hip", "pointwise.hip"]
+SOURCES = ["status.cpp", "pillar_scatter.hip", "pillar_sparse.hip", "warp_fuse.hip", "warp_fuse_nhwc.hip", "decode.hip", "nms.hip", "epilogue.hip", "voxelize.hip", "pose_graph.hip", "conv3x3.hip", "conv3x3_emu.hip", "conv3x3_sp.hip", "pointwise.hip"]
+# Kernels that were measured and NOT adopted live in the laboratory library only: the Winograd F(2x2, 3x3) convolution (1.14 x / 0.89 x / 1.05 x
+# against the direct kernel per stage) -- include/coalign_amd_lab.h, coalign_amd.hip.lab_lib(), tests/test_round4_gpu.py keep it testable.
+LAB_ONLY_SOURCES = ["conv3x3_wino.hip"]
 ARCH = "gfx950"
 # per-source extras.  pillar_scatter.hip: its matrix-core encoder reduces the accumulators with VALU right after each instruction
 # pair -- results in VGPRs (not AGPRs) save 64 v_accvgpr_read per pass; -fno-honor-nans drops the canonicalising v_max the compiler
@@ -62,7 +65,7 @@ def build(force: bool = False, verbose: bool = False, lab: bool = False, vectori
     flags = [f for f in FLAGS if not (vectorize and f in ("-fno-slp-vectorize", "-fno-vectorize"))]
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    headers = [os.path.join(INCLUDE, "coalign_amd.h"), os.path.join(CSRC, "common.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(INCLUDE, "coalign_amd.h"), os.path.join(INCLUDE, "coalign_amd_lab.h"), os.path.join(CSRC, "common.h"), os.path.abspath(__file__)]
     hipcc = _hipcc()
 
     def compile_one(src: str) -> str:
@@ -75,8 +78,9 @@ def build(force: bool = False, verbose: bool = False, lab: bool = False, vectori
             subprocess.check_call(cmd)
         return op
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    sources = SOURCES + (LAB_ONLY_SOURCES if lab else [])
+    with ThreadPoolExecutor(max_workers=len(sources)) as ex:
+        objs = list(ex.map(compile_one, sources))
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < _newest(objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}"] + objs + ["-o", LIB_PATH]
         if verbose:

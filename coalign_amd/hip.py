@@ -71,8 +71,6 @@ SIGNATURES = {
     "coalign_sp_unpack": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_conv3x3_sp_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "coalign_conv3x3_sp": (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
-    "coalign_conv3x3_wino_weight_bytes": (c_size_t, [c_int, c_int]),
-    "coalign_conv3x3_wino": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_pointwise_conv": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_pointwise_conv_ex": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_pointwise_emu_weight_bytes": (c_size_t, [c_int, c_int]),
@@ -82,6 +80,15 @@ SIGNATURES = {
     "coalign_voxelize": (c_int, [P, POINTER(c_int64), c_int, POINTER(c_double), POINTER(c_double), c_int, c_int, c_int,
                                  POINTER(c_double), P, P, P, c_int64, P, P, c_size_t, P]),
 }
+
+
+# include/coalign_amd_lab.h: entry points of the laboratory library only (measured, not adopted)
+LAB_SIGNATURES = {
+    "coalign_conv3x3_wino_weight_bytes": (c_size_t, [c_int, c_int]),
+    "coalign_conv3x3_wino": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+}
+
+_LAB_LIB = None
 
 
 class CoalignHipError(RuntimeError):
@@ -114,6 +121,28 @@ def lib() -> ctypes.CDLL:
     if handle.coalign_abi_version() != 1:
         raise CoalignHipError(f"ABI version mismatch: library reports {handle.coalign_abi_version()}, binding expects 1")
     _LIB = handle
+    return handle
+
+
+def lab_lib() -> ctypes.CDLL:
+    """The laboratory library (product sources + -DCOALIGN_LAB + include/coalign_amd_lab.h's kernels), loaded beside the product library: the Winograd tests
+    and tools call through it; nothing in the detector's default routes does."""
+    global _LAB_LIB
+    if _LAB_LIB is not None:
+        return _LAB_LIB
+    import torch  # noqa: F401
+    path = _build.LAB_LIB_PATH
+    if not os.path.exists(path):
+        try:
+            _build.build(lab=True)
+        except Exception as exc:  # noqa: BLE001
+            raise CoalignHipError(f"{path} is missing and could not be built ({exc})") from exc
+    handle = ctypes.CDLL(path)
+    for name, (res, args) in {**SIGNATURES, **LAB_SIGNATURES}.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LAB_LIB = handle
     return handle
 
 

@@ -933,7 +933,7 @@ def conv3x3_sp_is_split(N: int, Cin: int, cout: int, H: int, W: int, geometry: i
 
 
 def pack_conv3x3_wino_weight(weight: torch.Tensor) -> torch.Tensor:
-    """[Cout, Cin, 3, 3] fp32 (BatchNorm folded) -> the operand image of ``coalign_conv3x3_wino`` (include/coalign_amd.h (9c)), uint8:
+    """[Cout, Cin, 3, 3] fp32 (BatchNorm folded) -> the operand image of ``coalign_conv3x3_wino`` (include/coalign_amd_lab.h, laboratory library), uint8:
     U = G g G^T in float64, split into three bf16 terms (term 0 = bf16(U), term 1 = bf16(U - term 0), term 2 = bf16(U - term 0 - term 1), the
     residuals exact in float64), stored [Cout / 64][Cin / 16][h][wave = 4 c + i][jj][term][lane][8]: the 16 bytes lane ``l`` of wavefront (i, c) loads for
     transform position (i, 2 h + jj) are U[i, 2 h + jj, 64 g + 32 c + l % 32, 16 k + 8 (l // 32) : + 8]."""
@@ -951,7 +951,7 @@ def pack_conv3x3_wino_weight(weight: torch.Tensor) -> torch.Tensor:
     T = T.view(3, 4, 2, 2, co // 64, 2, 32, ci // 16, 2, 8)                                # [term, i, h, jj, g, c, m, k, half, e]
     img = T.permute(4, 7, 2, 5, 1, 3, 0, 8, 6, 9).contiguous()                             # [g, k, h, c, i, jj, term, half, m, e]
     out = torch.cat([img.view(torch.uint8).reshape(-1), torch.zeros(16, dtype=torch.uint8, device=img.device)])      # + 16 zero bytes (zero padding source)
-    assert out.numel() == hip.lib().coalign_conv3x3_wino_weight_bytes(ci, co)
+    assert out.numel() == hip.lab_lib().coalign_conv3x3_wino_weight_bytes(ci, co)
     return out
 
 
@@ -970,7 +970,7 @@ def conv3x3_wino(x: torch.Tensor, u_split: torch.Tensor, bias: torch.Tensor, cou
     """y = act(conv3x3(x, w, stride 1, padding 1) + bias (+ residual)) as Winograd F(2x2, 3x3) on the split-bf16 matrix cores
     (csrc/conv3x3_wino.hip).  x / residual / y: logical [N, C, H, W] in channels-last memory (x and residual are converted if they are not)."""
     _need_gpu(x, u_split, bias, residual)
-    L = hip.lib()
+    L = hip.lab_lib()          # laboratory library only (include/coalign_amd_lab.h)
     xc = to_nhwc(x)
     N, Cin, H, W = xc.shape
     if u_split.numel() != L.coalign_conv3x3_wino_weight_bytes(Cin, cout):

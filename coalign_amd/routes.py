@@ -22,6 +22,7 @@ from .detector import MODEL_REGISTRY, build_model
 
 EMU, F32, MIOPEN, ROCBLAS, POINTWISE = "conv3x3_emu (split 16-bit matrix cores)", "conv3x3 (fp32 matrix cores) / MIOpen by shape", "MIOpen", "rocBLAS (1x1 heads)", "pointwise"
 WINO = "conv3x3_wino (Winograd F(2x2,3x3), split-bf16 matrix cores)"
+SP = "conv3x3_sp (SplitMap input: operands by LDS-DMA, fp16 x 2)"
 DEFAULT_TERMS = 16      # backbone.CONV_EMU_TERMS: the 2-way fp16 split since round 4
 
 
@@ -80,6 +81,21 @@ def plan(hypes: dict, terms: int = DEFAULT_TERMS) -> Dict[str, object]:
                 note(n, _pointwise_route(m.in_channels, terms) if ok else MIOPEN + " (skip convolution outside the pointwise kernel's shapes)", not ok)
             else:
                 note(n, MIOPEN, True)
+    # round 5: inside a ResNet stage and in the shrink header the fp16 mode hands SplitMaps from 3x3 layer to 3x3 layer (backbone.BasicBlock.takes_split_maps,
+    # DoubleConv.forward): the stride-1 layers read them with coalign_conv3x3_sp, the layer in front of a chain writes the first one
+    if terms == 16 and bb.SPLIT_MAPS and bb.NHWC_STAGE_OUTPUTS and bb.CONV_EMU_TAP_MAJOR and bb.POINTWISE_EMU:
+        for n, m in model.named_modules():
+            if isinstance(m, bb.BasicBlock):
+                m.eval()
+                if m.takes_split_maps() and f"{n}.conv1" in layers and f"{n}.conv2" in layers:
+                    layers[f"{n}.conv1"] = SP if m.stride == 1 else layers[f"{n}.conv1"] + ", SplitMap out"
+                    layers[f"{n}.conv2"] = SP
+            elif isinstance(m, bb.DoubleConv):
+                c1, c2 = m.double_conv[0], m.double_conv[2]
+                ok = all(tuple(c.kernel_size) == (3, 3) and c.stride == (1, 1) and c.out_channels % 64 == 0 and c.in_channels % 16 == 0 for c in (c1, c2))
+                if ok and f"{n}.double_conv.0" in layers:
+                    layers[f"{n}.double_conv.0"] += ", SplitMap out"
+                    layers[f"{n}.double_conv.2"] = SP
     backbone = getattr(model, "backbone", None)
     if backbone is not None and len(getattr(backbone, "deblocks", [])):
         ok = True
@@ -104,7 +120,7 @@ def plan(hypes: dict, terms: int = DEFAULT_TERMS) -> Dict[str, object]:
             first = rn.layer0[0] if rn is not None and hasattr(rn, "layer0") else None
             sparse = (terms in (3, 16) and first is not None and first.stride == 2 and first.downsample is not None and first.conv1.out_channels % 64 == 0 and
                       first.conv1.in_channels % 16 == 0 and first.downsample[0].out_channels % 32 == 0 and "compression" not in hypes["model"]["args"])
-            pillar = ("matrix-core encoder (exact fp32 matrix instruction), ONE launch, sparse canvas read by the first ResNet block" if sparse else
+            pillar = ("matrix-core encoder (one fp16 matrix instruction per pillar and 32 channels on a 22-bit operand split), ONE launch, sparse canvas read by the first ResNet block" if sparse else
                       "matrix-core encoder (linearised PFN, split-bf16), persistent dense canvas" if terms in (2, 3, 16) else "matrix-core encoder, NCHW strip writer")
     fusion = None
     if hasattr(model, "fusion_net"):

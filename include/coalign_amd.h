@@ -385,19 +385,7 @@ size_t coalign_conv3x3_sp_workspace_bytes(int N, int Cin, int Cout, int H, int W
 int coalign_conv3x3_sp(const void *x_sp, const void *w_split, const float *bias, const void *residual, int residual_kind, void *y, int out_kind,
                        int N, int Cin, int Cout, int H, int W, int relu, int geometry, int32_t *range_flag, void *workspace, size_t workspace_bytes, void *stream);
 
-/* (9c) Round 4: the stride-1 3x3 convolutions as Winograd F(2x2, 3x3) on the bf16 matrix cores -- 16 instead of 36 products per 2 x 2 outputs and
- * (cin, cout), fp32 operands by the same 3-way error-free bf16 split, fp32 accumulation (csrc/conv3x3_wino.hip).  Same layers as (9b):
- * BasicBlock.forward opencood/models/sub_modules/resblock.py:53-69 and DoubleConv downsample_conv.py:7-27.
- *   x, residual (may be NULL), y: CHANNELS-LAST, [N][H][W][C] float32, 16-byte aligned; Cin % 16 == 0, Cout % 64 == 0, any H, W.
- *   u_split: coalign_conv3x3_wino_weight_bytes(Cin, Cout) bytes: the transformed weights U = G g G^T (float64 on the host, G = [1 0 0; .5 .5 .5;
- *   .5 -.5 .5; 0 0 1]) as three bf16 terms in the order the kernel's wavefronts load them:
- *   [Cout / 64][Cin / 16][h 2][wave 8 = (c, i)][jj 2][term 3][lane 64][8] bf16 = term of U[i][2 h + jj][64 g + 32 c + lane % 32][16 k + 8 (lane / 32) + e].
- *   tile_block_w: 0 = chosen from W, 8 = blocks of 8 x 8 Winograd tiles, 16 = 4 x 16 tiles per workgroup.
- * No workspace.  y = relu?(conv3x3(x, g) + bias (+ residual)); against a float64 convolution the error is of the size of the direct
- * split-bf16 kernel's (measured: tests/test_round4_gpu.py). */
-size_t coalign_conv3x3_wino_weight_bytes(int Cin, int Cout);
-int coalign_conv3x3_wino(const float *x, const void *u_split, const float *bias, const float *residual, float *y, int N, int Cin, int Cout,
-                         int H, int W, int relu, int tile_block_w, void *stream);
+/* (9c) The Winograd F(2x2, 3x3) convolution of round 4 (measured, not adopted) is exported by the LABORATORY library only: include/coalign_amd_lab.h. */
 
 /* Fill `n_words` 32-bit words at `p` (4-byte aligned) with `value`, as a kernel on `stream` (the per-frame counters of the post-processing
  * buffers, voxel_postprocessor.py:243-402's per-frame state; graph-capture safe, no library launch). */

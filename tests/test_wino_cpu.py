@@ -29,7 +29,7 @@ def test_winograd_data_flow_on_the_host(case):
 
 
 def test_winograd_weight_image_size_and_argument_checks():
-    L = hip.lib()
+    L = hip.lab_lib()          # (the Winograd kernel lives in the laboratory library: include/coalign_amd_lab.h)
     assert L.coalign_conv3x3_wino_weight_bytes(64, 64) == 16 * 64 * 64 * 6 + 16
     assert L.coalign_conv3x3_wino_weight_bytes(24, 64) == 0 and L.coalign_conv3x3_wino_weight_bytes(64, 96) == 0
     with pytest.raises(ValueError):
