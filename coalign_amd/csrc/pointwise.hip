@@ -303,7 +303,10 @@ static int pointwise_impl(const float *x, const float *w, const float *bias, flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (emu) {
         const size_t lds = (size_t)Cin * px_per_wg * 6;           // three bf16 terms of the pixel tile (<= 48 KB up to 256 input channels, 96 KB at 512)
-        static bool big_lds = false;                              // (beyond 64 KB of dynamic LDS the kernels need the attribute: the merged heads of a 384-channel map)
+        static bool big_lds_dev[16] = {false};                    // (beyond 64 KB of dynamic LDS the kernels need the attribute -- the merged heads of a 384-channel
+        int dev = 0;                                              //  map -- and the attribute belongs to the DEVICE's code object: one flag per device)
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+        bool &big_lds = big_lds_dev[dev];
         if (lds > 48 * 1024 && !big_lds) {
             const void *fns[3] = {reinterpret_cast<const void *>(pointwise_emu_kernel<1>), reinterpret_cast<const void *>(pointwise_emu_kernel<2>),
                                   reinterpret_cast<const void *>(pointwise_emu_kernel<4>)};

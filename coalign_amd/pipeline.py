@@ -97,8 +97,16 @@ class FramePipeline:
         self.pillar_buckets = bool(pillar_buckets)               # ragged from-pillars frames share a capacity-sized graph (see _bucket_seen below)
         self._sig_tensors: Optional[list] = None                 # cached parameter / buffer list of _weights_signature
         self._sig_age = 0
+        self._sd_hook = None                                     # removed again in close(): a hook on the model must not keep every pipeline built on it alive
         if hasattr(model, "register_load_state_dict_post_hook"):
-            model.register_load_state_dict_post_hook(lambda *_: setattr(self, "_sig_tensors", None))
+            import weakref
+            me = weakref.ref(self)
+
+            def _on_load(*_):
+                p = me()
+                if p is not None:
+                    p._sig_tensors = None
+            self._sd_hook = model.register_load_state_dict_post_hook(_on_load)
         self.pp = post_processor
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
         if self.device.type != "cuda":
@@ -439,6 +447,9 @@ class FramePipeline:
         self.synchronize()
         for d in self._slots:
             d.clear()
+        if self._sd_hook is not None:
+            self._sd_hook.remove()
+            self._sd_hook = None
         if self._vfe_flag is not None and hasattr(self.model, "pillar_vfe"):
             self.model.pillar_vfe.persistent_canvas = self._vfe_flag
             self.model.pillar_vfe.__dict__.pop("_canvas_cache", None)
