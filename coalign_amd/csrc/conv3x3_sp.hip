@@ -99,16 +99,19 @@ enum { SP_RES_NONE = 0, SP_RES_SP = 1, SP_RES_NHWC = 2 };
 //   0  every wavefront its share, all at once behind the interval's barrier (the matrix pipe idles until the texture addresser has taken the ~70 instructions);
 //   1  every wavefront its share, one or two instructions behind each tap's matrix instructions;
 //   2  LOADER wavefronts: the first four wavefronts (one per SIMD) issue everything, the others start their matrix steps straight away -- a SIMD's
-//      loader runs its steps when its partners have finished theirs, the pipe never waits for the addresser.
+//      loader runs its steps when its partners have finished theirs, the pipe never waits for the addresser;
+//   3  one EXTRA wavefront per workgroup that only issues the DMA (8-wavefront geometries: 9 wavefronts = three per SIMD within the register budget):
+//      the computing wavefronts' instruction streams are ds_read + matrix instructions only.
 template <int BH, int BW, int NPB, int NBX, int MODE>
 struct Work {
     using G = Geo<BH, BW, NPB, NBX>;
-    static constexpr int LOADERS = MODE == 2 ? 4 : G::WAVES;
+    static constexpr int LOADERS = MODE == 2 ? 4 : MODE == 3 ? 1 : G::WAVES;
+    static constexpr int THREADS = G::THREADS + (MODE == 3 ? 64 : 0);
     static constexpr int WJ = (G::WINS + LOADERS - 1) / LOADERS, PJ = (G::PINS + LOADERS - 1) / LOADERS, OPS = WJ + 4 * PJ;
 };
 
 template <int BH, int BW, int NPB, int NBX, int OUT, int MODE, bool SPLIT>
-__global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
+__global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_kernel(const SpArgs a) {
     using G = Geo<BH, BW, NPB, NBX>;
     using K = Work<BH, BW, NPB, NBX, MODE>;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -116,7 +119,8 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
     const int HW = a.H * a.W, CI16 = a.Cin / 16, CO16 = a.Cout / 16, groups = a.Cout / kCoutTile, chunks = CI16;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
     // LDS map: weight buffers 0 | 1, patch buffers 0 | 1
-    const bool loader = wave < K::LOADERS;
+    const bool loader = MODE == 3 ? wave == G::WAVES : wave < K::LOADERS, compute = wave < G::WAVES;
+    const int lw = MODE == 3 ? 0 : wave;                                      // index among the loaders
 
     const int blk_y = wave / NBX, blk_x = wave - blk_y * NBX;                 // this wavefront's pixel block inside the tile
     const int py = blk_y * BH + p / BW, px = blk_x * BW + p % BW;
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
         pl.wsrc = a.wt + (size_t)t.cg * chunks * G::WQ + lane;
 #pragma unroll
         for (int j = 0; j < K::PJ; ++j) {
-            const int i = (wave + K::LOADERS * j) * 64 + lane;
+            const int i = (lw + K::LOADERS * j) * 64 + lane;
             const int y = i / G::PW, xq = i - y * G::PW, gx = t.x0 - 1 + xq;
             bool ok = i < G::PIX && xq < G::PWU && gx >= 0 && gx < a.W;
             int gy, img = 0;
@@ -170,10 +174,10 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
     // DMA operation k of this wavefront for interval c into buffer `slot`: k < WJ a 1 KB piece of the weights, then the four planes of patch piece j
     auto issue_op = [&](const Plan &pl, int c, int slot, int k) {
         if (k < K::WJ) {
-            const int ins = wave + K::LOADERS * k;
+            const int ins = lw + K::LOADERS * k;
             if (ins < G::WINS && !SP_ABLATE(1)) dma16(pl.wsrc + (size_t)c * G::WQ + ins * 64, lds0 + slot * G::W_BYTES + ins * 1024);
         } else {
-            const int j = (k - K::WJ) / 4, q = (k - K::WJ) % 4, ins = wave + K::LOADERS * j;
+            const int j = (k - K::WJ) / 4, q = (k - K::WJ) % 4, ins = lw + K::LOADERS * j;
             if (ins < G::PINS && !SP_ABLATE(2))
                 dma16(pl.off[j] < 0 ? a.zero : a.x + (size_t)pl.off[j] + ((size_t)c * 4 + q) * HW, lds0 + 2 * G::W_BYTES + slot * G::B_BYTES + (q * G::PIXP + ins * 64) * 16);
         }
@@ -207,8 +211,31 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
     int tile = SPLIT ? s0 / chunks : g, chunk0 = SPLIT ? s0 - tile * chunks : 0;
     const int tile_step = SPLIT ? 1 : n_wg;
     Tile cur = decode(tile);
+    if constexpr (MODE == 3) {
+        static_assert(!SPLIT, "the loader wavefront mirrors the whole-tile schedule only (its barriers must match the computing wavefronts')");
+        if (wave == G::WAVES) {                                    // the loader wavefront: one barrier per interval like everybody else, nothing but DMA issue
+            __builtin_amdgcn_s_setprio(3);
+            Plan pl = make_plan(cur);
+            issue_all(pl, 0, 0);
+            int chunk = 0;
+            for (int l = 0; l < n_local; ++l) {
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
+                if (l + 1 < n_local) {
+                    if (++chunk == chunks) {
+                        chunk = 0;
+                        tile += tile_step;
+                        pl = make_plan(decode(tile));
+                    }
+                    issue_all(pl, chunk, (l + 1) & 1);
+                }
+            }
+            return;
+        }
+    }
+    const bool loader_here = MODE == 3 ? false : loader;           // (MODE 3: the computing wavefronts carry no plan and issue nothing)
     Plan plan{};
-    if (loader) {
+    if (loader_here) {
         plan = make_plan(cur);
         issue_all(plan, chunk0, 0);
     }
@@ -221,8 +248,8 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
         const bool lower = py >= cur.yb;
         const int out_n = cur.n0 + (lower ? 1 : 0), gy = lower ? py - cur.yb : cur.yl0 + py, gx = cur.x0 + px;
         const int bshift = lower ? 2 * G::PW : 0;
-        const bool live = out_n < a.N && gy < a.H && gx < a.W;
-        const bool wave_live = __builtin_amdgcn_readfirstlane((int)(cur.n0 * a.H + cur.yl0 + blk_y * BH < (a.stack ? a.N * a.H : cur.n0 * a.H + a.H) && cur.x0 + blk_x * BW < a.W)) != 0;
+        const bool live = compute && out_n < a.N && gy < a.H && gx < a.W;
+        const bool wave_live = compute && __builtin_amdgcn_readfirstlane((int)(cur.n0 * a.H + cur.yl0 + blk_y * BH < (a.stack ? a.N * a.H : cur.n0 * a.H + a.H) && cur.x0 + blk_x * BW < a.W)) != 0;
         const size_t pix = live ? (size_t)gy * a.W + gx : 0;
         const int on = live ? out_n : 0;
         floatx16 acc[2], accl[2];
@@ -248,9 +275,9 @@ __global__ __launch_bounds__(64 * NPB) void conv3x3_sp_kernel(const SpArgs a) {
                 nc = 0;
                 ntile = tile + tile_step;
                 next = decode(ntile);
-                if (loader) nplan = make_plan(next);
+                if (loader_here) nplan = make_plan(next);
             }
-            if (MODE != 1 && more && loader) issue_all(nplan, nc, (L + 1) & 1);
+            if (MODE != 1 && more && loader_here) issue_all(nplan, nc, (L + 1) & 1);
             if (chunk == c_end - 1 && head && wave_live && !SP_ABLATE(8)) {
                 if (a.res_kind == SP_RES_SP) {                     // h groups | l groups: 8 bytes each per (lane, 8-channel group)
                     const uint2 *rp = reinterpret_cast<const uint2 *>(a.residual);
@@ -459,7 +486,7 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
     static int cus[kMaxDev] = {0};                                    // per device: the function attribute belongs to the device's code object
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
-    constexpr bool CAN_SPLIT = NPB == 8;                              // (the hand-over code needs the 8-wavefront geometries' register budget)
+    constexpr bool CAN_SPLIT = NPB == 8 && MODE != 3;                 // (the hand-over code needs the 8-wavefront geometries' register budget; the loader wavefront of MODE 3 mirrors whole tiles only)
     auto k_sp = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP, MODE, false>;
     auto k_cl = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC, MODE, false>;
     auto k_sp_s = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP, MODE, CAN_SPLIT>;
@@ -515,8 +542,9 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
         a.flags = static_cast<int *>(workspace);
         a.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + l.flag_bytes);
     }
-    if (split) hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp_s : k_cl_s, dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
-    else hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp : k_cl, dim3(l.grid), dim3(G::THREADS), G::LDS_BYTES, s, a);
+    constexpr int kThreads = Work<BH, BW, NPB, NBX, MODE>::THREADS;
+    if (split) hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp_s : k_cl_s, dim3(l.grid), dim3(kThreads), G::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp : k_cl, dim3(l.grid), dim3(kThreads), G::LDS_BYTES, s, a);
     return COALIGN_OK;
 }
 
@@ -546,6 +574,7 @@ int dispatch_sp(const SpArgs &a, int out_kind, int geometry, void *ws, size_t ws
         else geo = 81;
     }
 #if defined(COALIGN_LAB) || defined(SP_TRACE)      // laboratory / trace builds carry all three issue modes
+    if (mode == 3 && (geo == 81 || geo == 148)) return launch_mode<3>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
     return mode == 0 ? launch_mode<0>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query) : mode == 2 ? launch_mode<2>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query)
                                                                                               : launch_mode<1>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
 #else
