@@ -193,8 +193,8 @@ def conv_layer_rooflines(dev, N, ny, nx, pmc):
             e = pmc.get(key) if pmc else None
             if e:
                 c = e.get("per_op_call", {})
-                if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
-                    row["pmc_mfma_busy_share"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"]), 4)      # busy cycles summed over 1024 SIMDs / kernel cycles
+                if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):      # busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+                    row["pmc_mfma_busy_share"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * c["GRBM_GUI_ACTIVE"]), 4)
                 if "hbm_bytes_read_x2" in e:
                     row["pmc_hbm_MB"] = round(e["hbm_bytes_read_x2"] / 1e6, 2)
             rows.append(row)

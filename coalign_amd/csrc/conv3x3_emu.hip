@@ -675,6 +675,10 @@ template <int TERMS, bool F16 = false>
 int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
     if constexpr (F16) {                      // fp16 2-way split: the strided layers, 8 output rows per workgroup, double-buffered patch (as the bf16 2-way split)
         if (stride != 2) return COALIGN_ERR_UNSUPPORTED;
+#ifdef COALIGN_LAB      // laboratory: 16 channels per barrier interval (64 contiguous bytes per channels-last pixel, half the barriers) with ONE patch buffer (151 KB of LDS)
+        static const int kch2 = coalign::lab_env("COALIGN_EMU_S2_KCH2", 0);
+        if (kch2 && a.Cin % 16 == 0 && layout == (LAYOUT_IN_NHWC | LAYOUT_OUT_SP)) return launch_variant<1, 32, 8, 2, 2, 2, LAYOUT_IN_NHWC | LAYOUT_OUT_SP, 1, VAR_F16>(a, s);
+#endif
         if (layout == LAYOUT_NCHW) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_NCHW, 2, VAR_F16>(a, s);
         if (layout == LAYOUT_IN_NHWC) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_IN_NHWC, 2, VAR_F16>(a, s);
         if (layout == LAYOUT_NHWC) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_NHWC, 2, VAR_F16>(a, s);

@@ -123,7 +123,11 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
     const int lw = MODE == 3 ? 0 : wave;                                      // index among the loaders
 
     const int blk_y = wave / NBX, blk_x = wave - blk_y * NBX;                 // this wavefront's pixel block inside the tile
-    const int py = blk_y * BH + p / BW, px = blk_x * BW + p % BW;
+    // Lane -> pixel inside the block.  2 x 16 blocks (PW = 18: a patch row is 288 bytes = 256 + 32): row 1's columns are rotated by two, so that the four lane
+    // groups a ds_read_b128 is served in ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...) touch disjoint banks -- unrotated, row 1 sits 32 bytes into row 0's
+    // banks: SQ_LDS_BANK_CONFLICT was 25 % of the LDS cycles of the 50 x 176 layers (profiles/round5/pmc_summary.json, first pass).  Which lane owns which pixel of
+    // its block is free: addresses in and out follow (py, px).
+    const int py = blk_y * BH + p / BW, px = blk_x * BW + ((BW == 16 && NBX == 1) ? ((p % 16) + 16 - 2 * (p / 16)) % 16 : p % BW);
     int boff[9];                                                              // group of this lane's pixel under tap s, inside plane (2 * half + term 0)
 #pragma unroll
     for (int s = 0; s < 9; ++s) boff[s] = 2 * half * G::PIXP + (py + s / 3) * G::PW + px + s % 3;

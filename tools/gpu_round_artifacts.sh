@@ -43,8 +43,8 @@ for d in sorted(glob.glob(out+"/pmc_*_1")):
     # rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies the 128-B requests of wide (16 B/lane) streaming reads at 64 B
     # (MI355X_MICROARCH.md, "HBM"): reads are doubled, writes taken as reported
     fs, ws = op_tot.get("FETCH_SIZE",0.0), op_tot.get("WRITE_SIZE",0.0)
-    if op_tot.get("SQ_VALU_MFMA_BUSY_CYCLES") and op_tot.get("GRBM_GUI_ACTIVE"):      # busy cycles are summed over the 1024 SIMDs; GRBM_GUI_ACTIVE = the kernel's cycles
-        op_tot["mfma_busy_share"] = op_tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * op_tot["GRBM_GUI_ACTIVE"])
+    if op_tot.get("SQ_VALU_MFMA_BUSY_CYCLES") and op_tot.get("GRBM_GUI_ACTIVE"):      # busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs: share = busy / (1024 * active / 8)
+        op_tot["mfma_busy_share"] = op_tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * op_tot["GRBM_GUI_ACTIVE"])
     res[op]={"per_op_call": dict(op_tot), "kernels": kern, "hbm_bytes_raw": (fs+ws)*1024, "hbm_bytes_read_x2": (2*fs+ws)*1024,
              "hbm_read_bytes_x2": 2*fs*1024, "hbm_write_bytes": ws*1024}
 json.dump(res, open(out+"/pmc_summary.json","w"), indent=1)
