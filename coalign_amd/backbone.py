@@ -1,9 +1,11 @@
 """Dense BEV CNN stages of the hot path: the reference's modules with the reference's parameter names, every
 layer routed to a hand-written gfx950 kernel where one takes its shape.
 
-* 3x3 convolutions (stride 1 / 2, BatchNorm folded, ReLU and the residual add in the epilogue): ``coalign_conv3x3_emu_ex`` -- fp32 products
-  as 3-way split bf16 products on the bf16 matrix cores (``csrc/conv3x3_emu.hip``; ``COALIGN_CONV_EMU=0``: ``coalign_conv3x3_bias_act``
-  on the fp32 matrix cores, ``csrc/conv3x3.hip``).  ``conv3x3_fused`` picks; ``Conv3x3Pack`` holds the weight images.
+* 3x3 convolutions (stride 1 / 2, BatchNorm folded, ReLU and the residual add in the epilogue): fp32 products from 16-bit terms on the matrix cores.
+  Default (``COALIGN_CONV_EMU=16``): sp16 pairs on the fp16 cores; inside a ResNet stage and in the shrink header the layers hand each other ``ops.SplitMap``s and run
+  on ``coalign_conv3x3_sp`` (``csrc/conv3x3_sp.hip``, ``BasicBlock._forward_split``), the layers in front of a chain on ``coalign_conv3x3_emu_ex`` /
+  ``_sparse`` (``csrc/conv3x3_emu.hip``); ``=3`` / ``=2``: bf16 splits on the latter; ``=0``: ``coalign_conv3x3_bias_act`` on the fp32 matrix cores
+  (``csrc/conv3x3.hip``).  ``conv3x3_fused`` picks; ``Conv3x3Pack`` holds the weight images.
 * the stride-2 1x1 skip convolutions and the up-sampling heads (ConvTranspose2d with kernel = stride, written straight into their
   slice of the concatenated map): ``coalign_pointwise_conv_emu`` / ``coalign_pointwise_conv`` (``csrc/pointwise.hip``, ``PointwisePack``).
 * the last convolution of every ResNet stage writes channels-last for the one-launch fusion kernel (``NHWC_STAGE_OUTPUTS``).
@@ -62,10 +64,10 @@ HIP_CONV_POLICY = os.environ.get("COALIGN_HIP_CONV", "stage1")      # measuremen
 # (coalign_conv3x3_bias_act / MIOpen).  2: 2-way split (dropped <= 2^-16 |w x|), opt-in only.  The environment variable is read once
 # at import; the module attribute is read at every call (tests / bench.py set it directly).
 CONV_EMU_TERMS = int(os.environ.get("COALIGN_CONV_EMU", "16"))
-# 16 (round 4): the 2-way split with FP16 terms -- x = x_h + x_l, 11 + 11 significant bits of every operand, three products on
-# v_mfma_f32_32x32x16_f16, fp32 accumulation: what is dropped is <= 2^-21 |w x| per product (the bf16 2-way split: 2^-16; the 3-way split: 2^-24), at the
-# 2-way split's speed.  Not scale-free like the bf16 splits: operands above 1.3e5 saturate, term x_l of operands below 2^-3 loses bits to fp16's
-# subnormal range (absolute error 2^-25 per operand).  DESIGN.md section 8 has the measured error against the float64 convolution.
+# 16 (round 4; scale free since round 5): sp16 pairs (csrc/common.h) -- every operand rounded to 22 significant bits, x~ = x_h + 2^-10 x_l with the low term
+# scaled into fp16's normal range and the weights scaled per output channel by a power of two; three products on v_mfma_f32_32x32x16_f16 into two fp32
+# accumulators; what is dropped is w_l x_l < 2^-20 |w x| per product (the bf16 2-way split: 2^-16; the 3-way split: 2^-24).  Operating range of the activations:
+# |x| <= 65504 (22 bits down to 2^-14).  DESIGN.md section 4 has the measured error against the float64 convolution over weight and activation scales.
 EMU_MODES = (2, 3, 16)
 
 

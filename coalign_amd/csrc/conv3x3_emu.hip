@@ -1,17 +1,18 @@
-// 3x3 / pad 1 convolution (stride 1 or 2) with fused bias (+ residual) (+ ReLU), fp32 in / fp32 out, computed on the BF16 matrix
-// cores by error-free operand splitting ("fp32 emulation"), gfx950.  The 3-way split is the product default (COALIGN_CONV_EMU,
-// backbone.py) for every 3x3 convolution of the detector; NCHW in and out by default, optionally channels-last (NHWC) on the input or the output side (LAYOUT): the last
-// convolution of a ResNet stage writes its map channels-last for the fusion kernel and the next stage's strided convolution reads it.
+// 3x3 / pad 1 convolution (stride 1 or 2) with fused bias (+ residual) (+ ReLU), fp32 in / fp32 (or SplitMap) out, computed on the 16-bit matrix cores by
+// operand splitting in the CONSUMER ("fp32 emulation"), gfx950.  Since round 5 the detector's default route uses this kernel only where a chain of SplitMap
+// layers (csrc/conv3x3_sp.hip) STARTS from float32 input -- the strided first convolution of a ResNet stage (channels-last or sparse-canvas input) and the shrink
+// header's first convolution -- and for the arithmetics other than the default; rounds 2-4 ran every 3x3 layer of the model here.  NCHW in and out by default,
+// optionally channels-last (NHWC) on the input or the output side, or a SplitMap on the output side (LAYOUT).
 //
 // Same layers and semantics as conv3x3.hip (opencood/models/sub_modules/resblock.py:53-69, base_bev_backbone_resnet.py:59-138,
-// downsample_conv.py:7-50).  The fp32 MFMA runs at the VALU rate (157 TFLOP/s); v_mfma_f32_32x32x16_bf16 is 16x faster and
-// accumulates in fp32.  Every fp32 operand is written as an exact sum of bf16 numbers
-//     x = x_h + x_m + x_l,   x_h = bf16(x),  x_m = bf16(x - x_h),  x_l = bf16(x - x_h - x_m)      (the subtractions are exact)
-// and the product w * x is evaluated as the sum of the cross terms, smallest first, each one exact in the fp32 accumulator:
-//   TERMS = 3:  w_h x_l + w_m x_m + w_l x_h + w_h x_m + w_m x_h + w_h x_h     dropped terms <= 2^-24 |w x|: fp32-level accuracy
-//   TERMS = 2:  w_h x_l + w_l x_h + w_h x_h   (x_l = bf16(x - x_h))           dropped terms <= 2^-16 |w x|
-// i.e. 6 (or 3) bf16 MFMAs replace 8 fp32 MFMAs of the same K: 2.7x (5.3x) less matrix-pipe time.  The weights are split on the
-// host once; the input pixels are split in registers, once per pixel and chunk (v_cvt_pk_bf16_f32 + exact subtractions).
+// downsample_conv.py:7-50).  The fp32 MFMA runs at the VALU rate (157 TFLOP/s); the 16-bit matrix instructions are 16x faster and accumulate in fp32.
+// Arithmetics (TERMS / VAR_F16; `terms` at the C ABI):
+//   terms = 16 (the product default, COALIGN_CONV_EMU, backbone.py): sp16 pairs on v_mfma_f32_32x32x16_f16 -- every operand rounded to 22 significant bits,
+//     x~ = x_h + 2^-10 x_l (common.h), weights scaled per output channel by a power of two; products w_h x_h in `acc`, w_h x_l + w_l x_h in `accl` (DUAL),
+//     y = (acc + 2^-10 accl) 2^-k_c + (residual + bias); scale free;
+//   terms = 3 (default of rounds 2-3): x = x_h + x_m + x_l, three bf16 terms, error-free; six products per fp32 product, dropped terms <= 2^-24 |w x|;
+//   terms = 2: two bf16 terms, three products, dropped terms <= 2^-16 |w x| (opt-in).
+// The weights are split on the host once; the input pixels are split in registers, once per pixel and chunk.
 //
 // GEMM view per image:  D[cout, pixel] = sum_{cin, tap} W[cout, cin, tap] * X[cin, pixel + tap].  Two weight images:
 //   * tap-major (the detector's stride-1 layers, COALIGN_LAYOUT_W_TAPMAJOR, template bit VAR_TAPK): one MFMA has K = 16 = the 16 input

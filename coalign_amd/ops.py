@@ -818,8 +818,9 @@ def is_channels_last(t: torch.Tensor) -> bool:
 @_device_op
 def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Tensor, cout: int, residual: Optional[torch.Tensor] = None,
                          relu: bool = True, terms: int = 3, stride: int = 1, out_channels_last: bool = False, out_split: bool = False):
-    """y = act(conv3x3(x, w, stride, padding 1) + bias (+ residual)) with every fp32 product evaluated as `terms`-way split bf16
-    products on the bf16 matrix cores, fp32 accumulation (csrc/conv3x3_emu.hip; terms = 16: the 2-way split with fp16 terms, 22 operand bits).  A channels-last ``x`` is read in place by the
+    """y = act(conv3x3(x, w, stride, padding 1) + bias (+ residual)) with every fp32 product evaluated from 16-bit terms on the matrix cores, fp32 accumulation
+    (csrc/conv3x3_emu.hip): ``terms`` = 16 -- the detector's default arithmetic -- sp16 pairs on the fp16 cores (22-bit operands, scale free), 3 / 2 = 3- / 2-way
+    bf16 split (the signature's default of 3 dates from rounds 2-3; the detector passes ``backbone.CONV_EMU_TERMS``).  A channels-last ``x`` is read in place by the
     stride-2 variant; ``out_channels_last`` (stride 1) returns a tensor of logical shape [N, C, H, W] in channels-last memory; ``out_split`` (terms 16, no
     residual: the strided layers and the tap-major stride-1 image on an NCHW input) returns a ``SplitMap``."""
     _need_gpu(x, w_split, bias, residual)

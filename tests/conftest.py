@@ -41,8 +41,8 @@ def golden():
 
 @pytest.fixture(params=[3, 0, 16], ids=["bf16x3", "native_fp32", "fp16x2"])
 def conv_mode(request):
-    """Model-level parity tests run once per 3x3-convolution arithmetic: the product default (3-way split bf16 products, fp32
-    accumulation) and the native-fp32 route (COALIGN_CONV_EMU=0); both are held to the same tolerances."""
+    """Model-level parity tests run once per 3x3-convolution arithmetic: the product default (16: sp16 pairs on the fp16 matrix cores, SplitMaps between
+    the layers of a stage), the 3-way bf16 split of rounds 2-3 and the native-fp32 route (COALIGN_CONV_EMU=0); all are held to the same tolerances."""
     from coalign_amd import backbone
     saved = backbone.CONV_EMU_TERMS
     backbone.CONV_EMU_TERMS = request.param
