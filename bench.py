@@ -623,6 +623,7 @@ def main():
 
     dt, t_issue, results = timed_run(pipe, args.steps, warm)
     lat_default = list(pipe.latencies_ms)
+    range_hit = pipe.range_exceeded()          # (outside the bracket) did any SplitMap value leave the fp16 split's operating range?
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -903,6 +904,7 @@ def main():
             "host_enqueue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
             "frame_digests": {str(k): digests[k] for k in sorted(digests)}, "frame_digests_reproducible": bool(consistent),
             "frame_digest_mismatches": mismatches[:8],
+            "split_map_range_exceeded": bool(range_hit),
         }
         if rings is not None:
             result["exchange_bytes_sent_per_rank_per_step"] = rings[0].bytes_sent_last

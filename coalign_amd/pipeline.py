@@ -441,6 +441,12 @@ class FramePipeline:
         for s in self.streams:
             s.synchronize()
 
+    def range_exceeded(self, clear: bool = True) -> bool:
+        """True if, since the last clearing call, a 3x3 layer wrote a value beyond the fp16 split's operating range (|x| > 65504) into a SplitMap: the
+        default arithmetic clamps there instead of overflowing, and a model that does so wants ``COALIGN_CONV_EMU=3``.  Synchronises."""
+        self.synchronize()
+        return ops.sp_range_exceeded(self.device, clear=clear)
+
     def close(self) -> None:
         """Collect what is pending, drop the captured graphs (and the canvases they own) and give the model's ``persistent_canvas`` flag back."""
         self.drain()
