@@ -42,6 +42,9 @@ ARCH = "gfx950"
 # on the MI355X (profiles/round3/README.md, "packed fp32 beside matrix wavefronts"): a wavefront executing them while it shares a SIMD with
 # three densely issuing matrix wavefronts of another kernel got wrong results in lanes 48-63.  Frame rate with / without the flag: equal
 # (309-314 vs 307-312 frames/s, same box, alternating).  (The fp32 VALU pillar encoder's explicit float2 arithmetic was rewritten as scalar chains.)
+# Status of that finding: observed twice -- round 3, and round 4's re-run with the inline-asm m0 clobber in place (0 / 2700 vs 356 / 2700 fused
+# maps differing, profiles/round4/experiments/pk_f32_recheck.txt) -- and mitigated by these flags; there is no standalone victim / aggressor reproducer, so it
+# is recorded as an observation with a mitigation, not as a characterised hardware behaviour.
 EXTRA_FLAGS = {"pillar_scatter.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
                "pillar_sparse.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}      # (no NaN test may be written in these two files)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-vectorize", "-Wno-cuda-compat", "-Wno-inline-asm", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}"]
