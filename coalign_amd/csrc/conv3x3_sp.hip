@@ -101,11 +101,13 @@ enum { SP_RES_NONE = 0, SP_RES_SP = 1, SP_RES_NHWC = 2 };
 //   2  LOADER wavefronts: the first four wavefronts (one per SIMD) issue everything, the others start their matrix steps straight away -- a SIMD's
 //      loader runs its steps when its partners have finished theirs, the pipe never waits for the addresser;
 //   3  one EXTRA wavefront per workgroup that only issues the DMA (8-wavefront geometries: 9 wavefronts = three per SIMD within the register budget):
-//      the computing wavefronts' instruction streams are ds_read + matrix instructions only.
+//      the computing wavefronts' instruction streams are ds_read + matrix instructions only;
+//   4  as 1, the tap's DMA instructions IN FRONT of its matrix instructions;   5  as 1, front-loaded: two instructions behind each of the first taps.
 template <int BH, int BW, int NPB, int NBX, int MODE>
 struct Work {
     using G = Geo<BH, BW, NPB, NBX>;
     static constexpr int LOADERS = MODE == 2 ? 4 : MODE == 3 ? 1 : G::WAVES;
+    static constexpr bool INTERLEAVED = MODE == 1 || MODE == 4 || MODE == 5;
     static constexpr int THREADS = G::THREADS + (MODE == 3 ? 64 : 0);
     static constexpr int WJ = (G::WINS + LOADERS - 1) / LOADERS, PJ = (G::PINS + LOADERS - 1) / LOADERS, OPS = WJ + 4 * PJ;
 };
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
                 next = decode(ntile);
                 if (loader_here) nplan = make_plan(next);
             }
-            if (MODE != 1 && more && loader_here) issue_all(nplan, nc, (L + 1) & 1);
+            if (!K::INTERLEAVED && more && loader_here) issue_all(nplan, nc, (L + 1) & 1);
             if (chunk == c_end - 1 && head && wave_live && !SP_ABLATE(8)) {
                 if (a.res_kind == SP_RES_SP) {                     // h groups | l groups: 8 bytes each per (lane, 8-channel group)
                     const uint2 *rp = reinterpret_cast<const uint2 *>(a.residual);
@@ -320,6 +322,12 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
                         load_b(s + 1, bn);
                         load_w(s + 1, wn);
                     }
+                    if constexpr (MODE == 4) {
+                        if (more) {
+#pragma unroll
+                            for (int k = s; k < K::OPS; k += 9) issue_op(nplan, nc, (L + 1) & 1, k);
+                        }
+                    }
 #pragma unroll
                     for (int q = 0; q < 2; ++q) accl[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[q][0], bc[1], accl[q], 0, 0, 0);      // w_h x_l'
 #pragma unroll
@@ -332,6 +340,13 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
                             for (int k = s; k < K::OPS; k += 9) issue_op(nplan, nc, (L + 1) & 1, k);
                         }
                     }
+                    if constexpr (MODE == 5) {
+                        if (more) {
+#pragma unroll
+                            for (int k = 2 * s; k < 2 * s + 2; ++k)
+                                if (k < K::OPS) issue_op(nplan, nc, (L + 1) & 1, k);
+                        }
+                    }
                     if (s + 1 < 9) {
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
                         }
                     }
                 }
-            } else if (MODE == 1 && more) {
+            } else if (K::INTERLEAVED && more) {
                 issue_all(nplan, nc, (L + 1) & 1);
             }
             SP_STAMP(4);
@@ -579,6 +594,8 @@ int dispatch_sp(const SpArgs &a, int out_kind, int geometry, void *ws, size_t ws
     }
 #if defined(COALIGN_LAB) || defined(SP_TRACE)      // laboratory / trace builds carry all three issue modes
     if (mode == 3 && (geo == 81 || geo == 148)) return launch_mode<3>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
+    if (mode == 4) return launch_mode<4>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
+    if (mode == 5) return launch_mode<5>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
     return mode == 0 ? launch_mode<0>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query) : mode == 2 ? launch_mode<2>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query)
                                                                                               : launch_mode<1>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
 #else
