@@ -28,7 +28,9 @@ N, Ci, Co, H, W = [int(v) for v in sys.argv[1:6]] if len(sys.argv) > 5 else (5, 
 geo = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 L = ctypes.CDLL(lib)
 P, I = ctypes.c_void_p, ctypes.c_int
-L.coalign_conv3x3_sp.argtypes = [P, P, P, P, I, P, I, I, I, I, I, I, I, I, P, P]
+L.coalign_conv3x3_sp.argtypes = [P, P, P, P, I, P, I, I, I, I, I, I, I, I, P, P, ctypes.c_size_t, P]
+L.coalign_conv3x3_sp_workspace_bytes.restype = ctypes.c_size_t
+L.coalign_conv3x3_sp_workspace_bytes.argtypes = [I] * 6
 x = torch.relu(torch.randn(N, Ci, H, W, device="cuda"))
 w = torch.randn(Co, Ci, 3, 3, device="cuda") / (Ci * 9) ** 0.5
 b = torch.randn(Co, device="cuda")
@@ -41,10 +43,15 @@ tr = torch.zeros(2 * waves * 64 * S + 2 * 4096, dtype=torch.int64, device="cuda"
 L.coalign_conv3x3_sp_set_trace(P(tr.data_ptr()))
 
 
+wsb = L.coalign_conv3x3_sp_workspace_bytes(N, Ci, Co, H, W, geo)
+ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device="cuda")
+
+
 def run(ablate=0, n=1):
     L.coalign_conv3x3_sp_set_ablate(ablate)
     for _ in range(n):
-        rc = L.coalign_conv3x3_sp(xs.data.data_ptr(), w16.data_ptr(), b.data_ptr(), rs.data.data_ptr(), 1, out.data.data_ptr(), 1, N, Ci, Co, H, W, 1, geo, None, None)
+        rc = L.coalign_conv3x3_sp(xs.data.data_ptr(), w16.data_ptr(), b.data_ptr(), rs.data.data_ptr(), 1, out.data.data_ptr(), 1, N, Ci, Co, H, W, 1, geo, None,
+                                  ws.data_ptr() if wsb else None, wsb, None)
         assert rc == 0, rc
 
 
