@@ -176,10 +176,11 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     const size_t plane = (size_t)a.H * a.W, plane_in = (size_t)a.Hin * a.Win;
     const unsigned sparse_tag = a.stamps ? (unsigned)*a.tag_ptr : 0u;
     const int groups = a.Cout / kCoutTile, chunks = a.Cin / (kKC * KCH);       // `chunks`: barrier intervals per tile, KCH x 8 channels each
+    int member_cg = 0;
     auto decode = [&](int t) {
         Tile c;
-        c.cg = t % groups;
-        const int sp = t / groups;
+        c.cg = SPLIT ? member_cg : t % groups;             // stream-K: t is the spatial tile, the output-channel group is the workgroup's member index in its gang (below)
+        const int sp = SPLIT ? t : t / groups;
         c.n = sp / a.tiles_per_img;
         const int r = sp - c.n * a.tiles_per_img, ty = r / a.tiles_x;
         c.y0 = ty * G::TH;
@@ -338,9 +339,15 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         const int q = n_wg >> 3, r = n_wg & 7, k = g & 7, j = g >> 3;
         g = k * q + (k < r ? k : r) + j;
     }
-    const long long S = (long long)a.total_tiles * chunks;
-    const int s0 = SPLIT ? (int)(S * g / n_wg) : 0;
-    const int n_local = SPLIT ? (int)(S * (g + 1) / n_wg) - s0 : ((a.total_tiles - g + n_wg - 1) / n_wg) * chunks;
+    // Round 5: stream-K in GANGS -- the `groups` workgroups gang * groups + member working on the output-channel groups of the same spatial tiles take the SAME
+    // range of (spatial tile, chunk) steps: they read the same input patch at the same time, so the XCD's L2 serves all but one of those reads (cut per
+    // workgroup over the flat tile list, neighbours sat in different chunks of different tiles: 1142 MB of HBM traffic for the shrink header's 54 MB input,
+    // L2 hit 10 %, profiles/round5/pmc_summary.json).  Hand-overs go to the same member of the previous gang; the grid is a whole number of gangs.
+    const int gangs = SPLIT ? n_wg / groups : 1, gang = SPLIT ? g / groups : 0, hand = SPLIT ? groups : 1;
+    member_cg = SPLIT ? g - gang * groups : 0;
+    const long long S = (long long)(SPLIT ? a.total_tiles / groups : a.total_tiles) * chunks;
+    const int s0 = SPLIT ? (int)(S * gang / gangs) : 0;
+    const int n_local = SPLIT ? (int)(S * (gang + 1) / gangs) - s0 : ((a.total_tiles - g + n_wg - 1) / n_wg) * chunks;
     auto global_step = [&](int l) { return SPLIT ? s0 + l : (g + (l / chunks) * n_wg) * chunks + l % chunks; };
     if (n_local <= 0) return;
 #ifdef EMU_TRACE
@@ -536,9 +543,9 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         } else {
             if (SPLIT && !complete) {      // owner of a split tile: add what workgroup g + 1 published
                 if (tid == 0)
-                    while (__hip_atomic_load(a.flags + g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+                    while (__hip_atomic_load(a.flags + g + hand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
                 __syncthreads();
-                const float *slot = a.partial + (size_t)(g + 1) * (16 * G::NCO * G::THREADS) + (size_t)wave * (16 * G::NCO * 64) + lane;
+                const float *slot = a.partial + (size_t)(g + hand) * (16 * G::NCO * G::THREADS) + (size_t)wave * (16 * G::NCO * 64) + lane;
 #pragma unroll
                 for (int q = 0; q < 16 * G::NCO; ++q)
                     acc[q / 16][q % 16] += __hip_atomic_load(slot + (q / 16) * 1024 + (q % 16) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -750,8 +757,13 @@ int launch(const EmuArgs &a0, void *workspace, size_t workspace_bytes, hipStream
         if (2 * a.total_tiles <= slots && chunks % 2 == 0) l.grid = 2 * a.total_tiles;
         else l.split = false;
     }
-    l.flag_bytes = coalign::align_up((size_t)(l.grid + 1) * sizeof(int), 256);
-    l.ws_bytes = l.flag_bytes + (size_t)(l.grid + 1) * 16 * G::NCO * G::THREADS * sizeof(float);
+    const int n_groups = a.Cout / kCoutTile;
+    if (l.split) {                                                // stream-K runs in gangs of one workgroup per output-channel group (see the kernel): whole gangs only
+        l.grid = l.grid / n_groups * n_groups;
+        if (l.grid < n_groups) l.split = false, l.grid = a.total_tiles < slots ? a.total_tiles : slots;
+    }
+    l.flag_bytes = coalign::align_up((size_t)(l.grid + n_groups) * sizeof(int), 256);
+    l.ws_bytes = l.flag_bytes + (size_t)(l.grid + n_groups) * 16 * G::NCO * G::THREADS * sizeof(float);
     if (query) {
         *query = l;
         return COALIGN_OK;

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
     const int HW = a.H * a.W, CI16 = a.Cin / 16, CO16 = a.Cout / 16, groups = a.Cout / kCoutTile, chunks = CI16;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
     // LDS map: weight buffers 0 | 1, patch buffers 0 | 1
+    int member_cg = 0;                                                        // (set below, before decode() is first called)
     const bool loader = MODE == 3 ? wave == G::WAVES : wave < K::LOADERS, compute = wave < G::WAVES;
     const int lw = MODE == 3 ? 0 : wave;                                      // index among the loaders
 
@@ -135,10 +136,12 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
     for (int s = 0; s < 9; ++s) boff[s] = 2 * half * G::PIXP + (py + s / 3) * G::PW + px + s % 3;
     const int wlane = half * kCoutTile + p;                                   // this lane's group inside one (tap, term) weight block
 
+    // tile id t: whole-tile schedule = spatial tile * groups + output-channel group (the groups of one spatial tile are neighbours: they read the same patch);
+    // stream-K = spatial tile only, the group is the workgroup's MEMBER index inside its gang (below)
     auto decode = [&](int t) {
         Tile c;
-        c.cg = t % groups;
-        const int sp = t / groups, ty = sp / a.tiles_x;
+        c.cg = SPLIT ? member_cg : t % groups;
+        const int sp = SPLIT ? t : t / groups, ty = sp / a.tiles_x;
         c.x0 = (sp - ty * a.tiles_x) * G::TW;
         if (a.stack) {
             const int y0 = ty * G::TH;
@@ -206,10 +209,17 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
         const int q = n_wg >> 3, r = n_wg & 7, k = g & 7, j = g >> 3;
         g = k * q + (k < r ? k : r) + j;
     }
-    const long long S_total = (long long)a.total_tiles * chunks;
-    auto range_start = [&](int j) { return (int)(S_total * j / n_wg); };
-    const int s0 = SPLIT ? range_start(g) : 0;
-    const int n_local = SPLIT ? range_start(g + 1) - s0 : ((a.total_tiles - g + n_wg - 1) / n_wg) * chunks;
+    // Stream-K runs in GANGS (round 5): the `groups` workgroups g = gang * groups + member that work on the output-channel groups of the SAME spatial tiles take
+    // the SAME range of (spatial tile, interval) steps, so they read the same input patch at the same time and the XCD's L2 serves three of the four reads.
+    // (Cut per workgroup over the flat tile list -- the first version, and conv3x3_emu.hip's -- neighbouring workgroups sat in different intervals of different
+    // tiles: PMC HBM traffic of the shrink header's second convolution 425 MB for 74 MB algorithmic, L2 hit 44 %.)  A share is handed to the workgroup of the
+    // same member one gang earlier.
+    const int gangs = SPLIT ? n_wg / groups : 1, gang = SPLIT ? g / groups : 0;
+    member_cg = SPLIT ? g - gang * groups : 0;
+    const long long S_total = (long long)(a.total_tiles / groups) * chunks;
+    auto range_start = [&](int j) { return (int)(S_total * j / gangs); };
+    const int s0 = SPLIT ? range_start(gang) : 0;
+    const int n_local = SPLIT ? range_start(gang + 1) - s0 : ((a.total_tiles - g + n_wg - 1) / n_wg) * chunks;
     if (n_local <= 0) return;
 #ifdef SP_TRACE
     if (tid == 0) a.trace[2 * 16 * 64 * 8 + 2 * g] = wall_clock64();
@@ -387,7 +397,8 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
         }
         if (SPLIT && !complete) {                                  // owner of a tile this range does not finish: the following workgroups' shares
             int rem = chunks - c_end;
-            for (int j = g + 1; rem > 0; ++j) {
+            for (int jg = gang + 1; rem > 0; ++jg) {
+                const int j = jg * groups + member_cg;             // the same member of the next gang
                 if (tid == 0) {
                     while (__hip_atomic_load(a.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
                     __hip_atomic_store(a.flags + j, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
 #pragma unroll
                     for (int q = 0; q < 32; ++q) acc[q / 16][q % 16] += __hip_atomic_load(slot + q * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                rem -= range_start(j + 1) - range_start(j);
+                rem -= range_start(jg + 1) - range_start(jg);
             }
         }
         // ---- epilogue: y = (acc + 2^-10 accl) * 2^-k_c + (residual + bias), ReLU, stored as an SP map or as channels-last fp32
@@ -545,9 +556,11 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
     bool split = CAN_SPLIT && chunks >= 16 && a.total_tiles > slots && (long long)a.total_tiles * 100 < (long long)rounds * slots * 88;
     if (split_policy == 1) split = false;
     if (split_policy == 2) split = CAN_SPLIT && chunks >= 2 && steps >= slots;
+    const int n_groups = a.Cout / kCoutTile;
+    if (split && (slots < n_groups || steps / n_groups < slots / n_groups)) split = false;      // (every gang needs at least one step)
     SpLaunch l;
     l.split = split ? 1 : 0;
-    l.grid = split ? slots : (a.total_tiles < slots ? a.total_tiles : slots);
+    l.grid = split ? slots / n_groups * n_groups : (a.total_tiles < slots ? a.total_tiles : slots);      // stream-K: whole gangs (one workgroup per output-channel group)
     l.flag_bytes = split ? coalign::align_up((size_t)(l.grid + 4) * sizeof(int), 256) : 0;
     l.ws_bytes = split ? l.flag_bytes + (size_t)(l.grid + 4) * G::WAVES * 32 * 64 * sizeof(float) : 0;
     if (query) {

@@ -85,7 +85,11 @@ _w256 = torch.randn(256, 256, 3, 3, generator=g).to(dev) / 48.0
 _w16_128, _w16_256 = ops.pack_conv3x3_emu_weight(_w128, 16, True), ops.pack_conv3x3_emu_weight(_w256, 16, True)
 _b128, _b256 = torch.randn(128, generator=g).to(dev), torch.randn(256, generator=g).to(dev)
 _r128, _r256 = torch.randn(N, 128, 50, 176, generator=g).to(dev), torch.randn(N, 256, 25, 88, generator=g).to(dev)
-_wu64, _wu256 = ops.pack_conv3x3_wino_weight(wconv), ops.pack_conv3x3_wino_weight(_w256)
+_wino = {}
+def _wu(name, w):                                  # (the laboratory library is loaded only when a Winograd op is asked for)
+    if name not in _wino:
+        _wino[name] = ops.pack_conv3x3_wino_weight(w)
+    return _wino[name]
 _rcl64, _rcl256 = rconv.contiguous(memory_format=torch.channels_last), _r256.contiguous(memory_format=torch.channels_last)
 _x256 = torch.randn(1, 256, 100, 352, generator=g).to(dev)
 _whead = ops.pack_pointwise_emu_weight(ops.pack_pointwise_weight(torch.randn(20, 256, 1, 1, generator=g).to(dev) / 16.0, False))
@@ -142,8 +146,8 @@ OPS = {
     "conv_fp16x2_64ch": lambda: ops.conv3x3_emu_bias_act(xs[0], _w16, bconv, 64, rconv, True, 16),
     "conv_fp16x2_128ch": lambda: ops.conv3x3_emu_bias_act(xs[1], _w16_128, _b128, 128, _r128, True, 16),
     "conv_fp16x2_256ch": lambda: ops.conv3x3_emu_bias_act(xs[2], _w16_256, _b256, 256, _r256, True, 16),
-    "conv_wino_bf16x3_64ch": lambda: ops.conv3x3_wino(xcl[0], _wu64, bconv, 64, _rcl64, True),
-    "conv_wino_bf16x3_256ch": lambda: ops.conv3x3_wino(xcl[2], _wu256, _b256, 256, _rcl256, True),
+    "conv_wino_bf16x3_64ch": lambda: ops.conv3x3_wino(xcl[0], _wu("64", wconv), bconv, 64, _rcl64, True),
+    "conv_wino_bf16x3_256ch": lambda: ops.conv3x3_wino(xcl[2], _wu("256", _w256), _b256, 256, _rcl256, True),
     "conv_fp16x2_s2_sparse_canvas": lambda: ops.conv3x3_emu_sparse(_sc(), _w16_s2, bconv, 64, True, 16, out_channels_last=False),
     "pointwise_skip1_sparse_canvas": lambda: ops.pointwise_conv_sparse(_sc(), _pw["skip1"][1], _pw["skip1"][2], 64, False, out_channels_last=False),
     "heads_1x1_merged_bf16x3": lambda: ops.pointwise_conv(_x256, _whead, _bhead, 20, relu=False),
