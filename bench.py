@@ -380,6 +380,7 @@ def main():
     for f in frames_cpu:
         d = to_device(f, dev)
         d["record_len"] = [N]                      # host-side agent counts: no device->host sync per frame
+        d["pairwise_t_matrix_host"] = f["pairwise_t_matrix"]      # the dataset's host copy of the 5 x 5 pose matrices travels with the batch (normalised on the host, pipeline.py)
         frames.append(d)
     calibrate_heads_(model, frames[0], pp.params["target_args"]["score_threshold"], 600)     # same frame, same weights on every rank
     if world > 1:   # identical weights everywhere, bit for bit
@@ -426,7 +427,8 @@ def main():
             sets = [by_agent[g_][a] if a < N else None for a in range(rank * per, rank * per + per)]
             if all(s_ is None for s_ in sets):       # a rank without agents still takes part in the collective: one empty slot set
                 sets = [{k: v[:0] for k, v in by_agent[g_][0].items()}] + [None] * (per - 1)
-            sb.append({"processed_lidar": stack_agents(sets), "record_len": [per], "tail_record_len": [N], "pairwise_t_matrix": f["pairwise_t_matrix"]})
+            sb.append({"processed_lidar": stack_agents(sets), "record_len": [per], "tail_record_len": [N], "pairwise_t_matrix": f["pairwise_t_matrix"],
+                       "pairwise_t_matrix_host": f["pairwise_t_matrix_host"]})
         return gathers, [(lambda feats, _g=g: (_g.gather(feats), None)) for g in gathers], sb
 
     if world > 1:
@@ -893,7 +895,9 @@ def main():
                                    f"geometry): {N} agents/frame, {args.pillars} pillars/agent, canvas {nx}x{ny}, 70400 anchors, "
                                    f"full path incl. decode + rotated NMS, {pool_n} distinct frames in rotation",
                        "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": frames_per_step, "frames_in_flight": n_lanes,
-                       "result_lag_frames": pipe.result_lag, "hip_graph": use_graph, "conv_arithmetic": "native fp32" if default_terms == 0 else ("fp16 split (sp16 pairs)" + (", SplitMaps between the 3x3 layers" if backbone_mod.split_maps_active() else "")) if default_terms == 16 else f"bf16x{default_terms}",
+                       "result_lag_frames": pipe.result_lag, "hip_graph": use_graph,
+                       "inputs": ("resident in HBM, read in place through a 32-byte device record; pose matrices normalised on the host; one small host-to-device transfer per frame"
+                                  if pipe.frames_in_place and not pipe.frames_copied else "resident in HBM, copied into the captured graph's input buffers every frame" if use_graph else "resident in HBM"), "conv_arithmetic": "native fp32" if default_terms == 0 else ("fp16 split (sp16 pairs)" + (", SplitMaps between the 3x3 layers" if backbone_mod.split_maps_active() else "")) if default_terms == 16 else f"bf16x{default_terms}",
                        "parallelism": "single GPU" if world == 1 else (f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all" if mode == "ring" else
                                                                                       f"{world} independent replicas, no collective (fall-back: see `rccl.fallbacks`)" if mode == "replicas" else
                                                                                       f"one frame over {world} ranks (agent blocks), {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-gather, ego tail on every rank") +

@@ -64,6 +64,7 @@ struct SparseArgs {
     unsigned long long *stamps;
     int *state;
     const int *M_dev;
+    const coalign_pillar_frame *frame;      // non-NULL: the three input arrays and the pillar count are read from this DEVICE record (coalign_pillar_encode_sparse_frame)
     const float4 *folded;  // the folded channel parameters written by coalign_pillar_fold_params ([7][64] float4)
     int debug;            // laboratory build only (COALIGN_SPARSE_DEBUG): 1 no stamp atomics, 2 no matrix steps, 4 no arrival counter, 8 no feature stores
 };
@@ -279,6 +280,12 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
     char *meta = pbuf + 2 * kRound * 1024;
     const int gwave = blockIdx.x * kWaves + wv, nwave = gridDim.x * kWaves;
     if (kLab && (a.debug & 128)) return;
+    if (a.frame) {      // a replayed graph reads whatever arrays the frame record names NOW: no copy of the inputs into launch-time addresses
+        a.pts = reinterpret_cast<const float4 *>(a.frame->voxel_features);
+        a.npts = a.frame->voxel_num_points;
+        a.coords = reinterpret_cast<const int4 *>(a.frame->voxel_coords);
+        a.M = min(max(a.frame->M, 0), a.M);
+    }
     if (a.M_dev) a.M = min(max(*a.M_dev, 0), a.M);
     long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (kLab && (a.debug & 512)) { ts[0] = (long long)__builtin_amdgcn_s_memtime(); ts[7] = (long long)wall_clock64(); }
@@ -423,15 +430,16 @@ extern "C" int coalign_pillar_fold_params(const float *pfn_weight, const float *
     return check_launch();
 }
 
-extern "C" int coalign_pillar_encode_sparse(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M_capacity,
-                                            const int32_t *M_dev, int P, const float *folded, int C, int use_absolute_xyz, const double *voxel_size,
-                                            const double *range_min, int n_agents, int ny, int nx, float *pillar_features, void *stamps, int32_t *state,
-                                            void *stream_) {
+namespace {
+int encode_sparse(const coalign_pillar_frame *frame, const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M_capacity,
+                  const int32_t *M_dev, int P, const float *folded, int C, int use_absolute_xyz, const double *voxel_size, const double *range_min, int n_agents, int ny,
+                  int nx, float *pillar_features, void *stamps, int32_t *state, void *stream_) {
     using namespace coalign;
     hipStream_t stream = (hipStream_t)stream_;
     if (M_capacity < 0 || n_agents <= 0 || ny <= 0 || nx <= 0 || P <= 0 || P > 32 || C < 1 || C > 64) return COALIGN_ERR_BAD_SHAPE;
     if (!folded || !voxel_size || !range_min || !stamps || !state) return COALIGN_ERR_NULL_POINTER;
-    if (M_capacity > 0 && (!voxel_features || !voxel_num_points || !voxel_coords || !pillar_features)) return COALIGN_ERR_NULL_POINTER;
+    if (M_capacity > 0 && ((!frame && (!voxel_features || !voxel_num_points || !voxel_coords)) || !pillar_features)) return COALIGN_ERR_NULL_POINTER;
+    if (frame && (reinterpret_cast<uintptr_t>(frame) & 7)) return COALIGN_ERR_BAD_SHAPE;
     if ((size_t)n_agents * ny * nx > (size_t)INT32_MAX || (reinterpret_cast<uintptr_t>(stamps) & 7) || (reinterpret_cast<uintptr_t>(folded) & 15)) return COALIGN_ERR_BAD_SHAPE;
     if ((size_t)M_capacity * P * 16 >= ((size_t)1 << 32) || (size_t)M_capacity * C * 4 >= ((size_t)1 << 32)) return COALIGN_ERR_UNSUPPORTED;      // 32-bit byte offsets
     SparseArgs a{};
@@ -443,7 +451,7 @@ extern "C" int coalign_pillar_encode_sparse(const float *voxel_features, const i
     a.yo = (float)(voxel_size[1] / 2 + range_min[1]);
     a.zo = (float)(voxel_size[2] / 2 + range_min[2]);
     a.n_agents = n_agents; a.ny = ny; a.nx = nx; a.feats = pillar_features;
-    a.stamps = static_cast<unsigned long long *>(stamps); a.state = state; a.M_dev = M_dev;
+    a.stamps = static_cast<unsigned long long *>(stamps); a.state = state; a.M_dev = M_dev; a.frame = frame;
     a.debug = coalign::lab_env("COALIGN_SPARSE_DEBUG", 0);
     // Grid = a WHOLE number of workgroups per CU (the dispatcher spreads resident workgroups evenly: measured 3 or 4 per CU for 834 workgroups, and the CUs with
     // 4 finish 3.5 us after those with 3 -- the kernel is bound by each SIMD's issue, so the launch ends with the busiest SIMD), pairs shared out evenly
@@ -468,6 +476,23 @@ extern "C" int coalign_pillar_encode_sparse(const float *voxel_features, const i
     if (use_absolute_xyz) hipLaunchKernelGGL(pillar_sparse_kernel<true>, dim3(blocks), dim3(kWaves * 64), 0, stream, a);
     else hipLaunchKernelGGL(pillar_sparse_kernel<false>, dim3(blocks), dim3(kWaves * 64), 0, stream, a);
     return check_launch();
+}
+}  // namespace
+
+extern "C" int coalign_pillar_encode_sparse(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M_capacity,
+                                            const int32_t *M_dev, int P, const float *folded, int C, int use_absolute_xyz, const double *voxel_size,
+                                            const double *range_min, int n_agents, int ny, int nx, float *pillar_features, void *stamps, int32_t *state,
+                                            void *stream_) {
+    return encode_sparse(nullptr, voxel_features, voxel_num_points, voxel_coords, M_capacity, M_dev, P, folded, C, use_absolute_xyz, voxel_size, range_min, n_agents, ny, nx,
+                         pillar_features, stamps, state, stream_);
+}
+
+extern "C" int coalign_pillar_encode_sparse_frame(const coalign_pillar_frame *frame, int M_capacity, int P, const float *folded, int C, int use_absolute_xyz,
+                                                  const double *voxel_size, const double *range_min, int n_agents, int ny, int nx, float *pillar_features,
+                                                  void *stamps, int32_t *state, void *stream_) {
+    if (!frame) return COALIGN_ERR_NULL_POINTER;
+    return encode_sparse(frame, nullptr, nullptr, nullptr, M_capacity, nullptr, P, folded, C, use_absolute_xyz, voxel_size, range_min, n_agents, ny, nx, pillar_features,
+                         stamps, state, stream_);
 }
 
 #ifdef COALIGN_LAB

@@ -101,13 +101,15 @@ class PointPillarBaselineMultiscale(nn.Module):
                 p.requires_grad = False
 
     # -- stages, exposed separately so the sharded runner can place them on different ranks ----------------
+    accepts_normalized_affine = True      # encode() takes data_dict['normalized_affine_matrix'] in place of normalising pairwise_t_matrix itself (FramePipeline)
+
     def encode(self, data_dict: dict):
         """Per-agent part: pillars -> canvas -> multiscale features.  Returns (feature list, normalised affine)."""
         pl = data_dict["processed_lidar"]
         record_len = host_ints(data_dict["record_len"])
         batch_dict = {"voxel_features": pl["voxel_features"], "voxel_coords": pl["voxel_coords"],
                       "voxel_num_points": pl["voxel_num_points"], "record_len": record_len}
-        for k in ("voxel_count_dev", "voxel_cells_unique", "want_pillar_features"):      # the device voxeliser's streaming form (PillarVFE.forward)
+        for k in ("voxel_count_dev", "voxel_cells_unique", "want_pillar_features", "pillar_frame"):      # the device voxeliser's streaming form (PillarVFE.forward); FramePipeline's frame record
             if k in pl:
                 batch_dict[k] = pl[k]
         # round 4: the encoder hands a SparseCanvas (one launch, no dense canvas) to a backbone whose first block reads it
@@ -121,7 +123,9 @@ class PointPillarBaselineMultiscale(nn.Module):
             self.pillar_vfe.sparse_canvas = keep_sparse
         spatial_features = batch_dict["spatial_features"]
         H0, W0 = spatial_features.shape[2:]
-        affine = normalize_pairwise_tfm(data_dict["pairwise_t_matrix"], H0, W0, self.voxel_size[0])
+        affine = data_dict.get("normalized_affine_matrix")      # FramePipeline: normalised on the host from the dataset's host copy of the matrix (same float64 steps)
+        if affine is None:
+            affine = normalize_pairwise_tfm(data_dict["pairwise_t_matrix"], H0, W0, self.voxel_size[0])
         if self.compression:
             spatial_features = self.naive_compressor(spatial_features)
         return self.backbone.get_multiscale_feature(spatial_features), affine

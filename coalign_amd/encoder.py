@@ -96,10 +96,15 @@ class PillarVFE(nn.Module):
             folded = cache.get(pfn, lambda: ops.pillar_fold_params(pfn.linear.weight, pfn.linear.bias, bn, eps, self.use_absolute_xyz))
             sc = ops.pillar_encode_sparse(vf, npts, coords, pfn.linear.weight, pfn.linear.bias, bn, eps, self.use_absolute_xyz,
                                           self.voxel_size, self.point_cloud_range[:3], n_agents, self.ny, self.nx,
-                                          canvas_cache=self.__dict__.setdefault("_canvas_cache", {}), count_dev=count_dev, folded=folded)
+                                          canvas_cache=self.__dict__.setdefault("_canvas_cache", {}), count_dev=count_dev, folded=folded,
+                                          frame=batch_dict.get("pillar_frame"))
             batch_dict["pillar_features"] = sc.feats
             batch_dict["_sparse_canvas"] = sc
             return batch_dict
+        if batch_dict.get("pillar_frame") is not None:
+            # (any other route would read the tensors in batch_dict, which a frame record's owner passes for their SHAPES only)
+            raise ops.FrameRecordUnsupported("a pillar frame record is consumed by the sparse-canvas route only (eval, channels-last fp16/bf16 convolutions, "
+                                             "P <= 32, C <= 64, no distance feature)")
         if count_dev is not None:
             # the producer (the device voxeliser) left the pillar count on the device: capacity-sized arrays, no host read of the count,
             # always the persistent channels-last canvas (FramePipeline.submit_points; include/coalign_amd.h coalign_pillar_encode_stream)

@@ -34,6 +34,7 @@ SIGNATURES = {
     "coalign_pillar_fold_params": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, P, P]),
     "coalign_pillar_encode_sparse": (c_int, [P, P, P, c_int, P, c_int, P, c_int, c_int, POINTER(c_double), POINTER(c_double),
                                              c_int, c_int, c_int, P, P, P, P]),
+    "coalign_pillar_encode_sparse_frame": (c_int, [P, c_int, c_int, P, c_int, c_int, POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, P, P]),
     "coalign_conv3x3_emu_sparse": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_pointwise_conv_emu_sparse": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_scatter_to_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),

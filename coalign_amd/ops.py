@@ -289,6 +289,8 @@ class SparseCanvas:
         self.is_cuda = True
 
     def dense(self) -> torch.Tensor:
+        if self.coords is None:
+            raise hip.CoalignHipError("a SparseCanvas encoded through a frame record has no coordinate array of its own: densify from the frame's voxel_coords")
         if self.count_dev is not None:
             m = int(self.count_dev[0].item())
             return scatter_to_bev(self.feats[:m], self.coords[:m], self.n_agents, self.ny, self.nx)
@@ -328,23 +330,58 @@ def pillar_fold_params(weight: torch.Tensor, bias: Optional[torch.Tensor], bn: O
     return out
 
 
+class FrameRecordUnsupported(hip.CoalignHipError):
+    """The configured route cannot read its inputs through a ``PillarFrameRecord``; the caller copies the frame into the graph's buffers instead."""
+
+
+class PillarFrameRecord:
+    """``coalign_pillar_frame`` (include/coalign_amd.h (1c)) for a replayed graph: ``words`` is a 4-word int64 DEVICE view (array pointers | pillar count) the
+    pillar launch reads when it starts, ``host`` the pinned words the owner fills per frame (``set``) and copies over as part of ONE small host-to-device
+    transfer.  ``capacity`` sizes the launch; a frame may hold fewer pillars, never more."""
+
+    def __init__(self, words: torch.Tensor, host: torch.Tensor, capacity: int):
+        if words.dtype != torch.int64 or words.numel() != 4 or not words.is_cuda or host.dtype != torch.int64 or host.numel() != 4:
+            raise ValueError("a frame record is four int64 words on the device and four on the (pinned) host")
+        self.words, self.host, self.capacity = words, host, int(capacity)
+        self._host_np = host.numpy()
+
+    @staticmethod
+    def admits(vf: torch.Tensor, npts: torch.Tensor, coords: torch.Tensor, device) -> bool:
+        """The arrays are read IN PLACE: float32 / int32, contiguous, on the launch's device (anything else takes the copying route)."""
+        return (vf.is_cuda and vf.device == device and npts.device == device and coords.device == device and vf.dtype == torch.float32 and vf.dim() == 3
+                and vf.shape[2] == 4 and npts.dtype == torch.int32 and coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
+                and vf.is_contiguous() and npts.is_contiguous() and coords.is_contiguous() and npts.shape[0] == vf.shape[0] == coords.shape[0])
+
+    def set(self, vf: torch.Tensor, npts: torch.Tensor, coords: torch.Tensor) -> None:
+        M = int(vf.shape[0])
+        if M > self.capacity:
+            raise ValueError(f"{M} pillars in a frame record of capacity {self.capacity}")
+        self._host_np[:] = (_rows_ptr(vf).value or 0, _rows_ptr(npts).value or 0, _rows_ptr(coords).value or 0, M)      # (little endian: the count is the low half of word 3)
+
+
 @_device_op
 def pillar_encode_sparse(voxel_features: torch.Tensor, voxel_num_points: torch.Tensor, voxel_coords: torch.Tensor, weight: torch.Tensor,
                          bias: Optional[torch.Tensor], bn: Optional[Tuple[torch.Tensor, ...]], bn_eps: float, use_absolute_xyz: bool,
                          voxel_size: Sequence[float], range_min: Sequence[float], n_agents: int, ny: int, nx: int, canvas_cache: dict,
-                         count_dev: Optional[torch.Tensor] = None, folded: Optional[torch.Tensor] = None) -> SparseCanvas:
+                         count_dev: Optional[torch.Tensor] = None, folded: Optional[torch.Tensor] = None, frame: Optional[PillarFrameRecord] = None) -> SparseCanvas:
     """PillarVFE + PointPillarScatter in ONE launch (include/coalign_amd.h (1b)): feature rows [M, C] + 8-byte cell stamps.  ``canvas_cache`` keeps the
     stamp map and the frame-tag words of this (device, stream, grid): they persist across frames and are never cleared (a stamp is valid only with
     the current tag).  ``count_dev``: optional int32 device tensor holding the pillar count (capacity-sized arrays).  ``folded``: ``pillar_fold_params``
-    of the same weights; a caller that keeps none gets them folded here (one more small launch per call)."""
+    of the same weights; a caller that keeps none gets them folded here (one more small launch per call).  ``frame``: the launch reads its three arrays and the
+    count through this device record (include/coalign_amd.h (1c)); the tensors passed here then only give the shapes."""
     _need_gpu(voxel_features, voxel_num_points, voxel_coords, weight)
     L = hip.lib()
     vf = _f32c(voxel_features)
     if vf.dim() != 3 or vf.shape[2] != 4:
         raise ValueError(f"voxel_features must be [M, P, 4], got {tuple(vf.shape)}")
     M, P = vf.shape[0], vf.shape[1]
-    npts = voxel_num_points.to(torch.int32).contiguous()
-    coords = voxel_coords.to(torch.int32).contiguous()
+    if frame is not None:
+        if count_dev is not None:
+            raise ValueError("a frame record carries the pillar count itself")
+        M, npts, coords = frame.capacity, None, None
+    else:
+        npts = voxel_num_points.to(torch.int32).contiguous()
+        coords = voxel_coords.to(torch.int32).contiguous()
     C = weight.shape[0]
     dev = vf.device
     if P > 32 or C > 64:
@@ -363,6 +400,11 @@ def pillar_encode_sparse(voxel_features: torch.Tensor, voxel_num_points: torch.T
         entry["state"].zero_()
         entry["calls"] = 1
     feats = torch.empty((max(M, 1), C), dtype=torch.float32, device=dev)[:M]      # (an empty frame still hands its consumers a valid row pointer: ADVICE r04)
+    if frame is not None:
+        with _Timed("pillar_encode_sparse"):
+            hip.check(L.coalign_pillar_encode_sparse_frame(_ptr(frame.words), M, P, _ptr(folded), C, int(use_absolute_xyz), _dbl3(voxel_size), _dbl3(range_min), n_agents,
+                                                           ny, nx, _ptr(feats), _ptr(entry["stamps"]), _ptr(entry["state"]), _stream()), "coalign_pillar_encode_sparse_frame")
+        return SparseCanvas(feats, entry["stamps"], entry["state"], None, n_agents, C, ny, nx, None)
     with _Timed("pillar_encode_sparse"):
         hip.check(L.coalign_pillar_encode_sparse(_ptr(vf), _ptr(npts), _ptr(coords), M, _ptr(count_dev), P, _ptr(folded), C, int(use_absolute_xyz), _dbl3(voxel_size),
                                                  _dbl3(range_min), n_agents, ny, nx, _ptr(feats), _ptr(entry["stamps"]), _ptr(entry["state"]), _stream()),
@@ -519,8 +561,9 @@ class DecodeBuffers:
         self.nms_ws = torch.empty(max(1, self.nms_ws_bytes), dtype=torch.uint8, device=device)
         self.keep = torch.empty(top, dtype=torch.int32, device=device)
         self.keep_count = self.frame_words[65:66]
-        self.out_corners = torch.empty((top, 8, 3), dtype=torch.float32, device=device)
-        self.out_scores = torch.empty(top, dtype=torch.float32, device=device)
+        self.out_flat = torch.empty(top * 25, dtype=torch.float32, device=device)      # corners | scores in ONE allocation: a finished frame is taken out with one copy launch
+        self.out_corners = self.out_flat[: top * 24].view(top, 8, 3)
+        self.out_scores = self.out_flat[top * 24:]
         self.out_count = self.frame_words[66:67]
         self.host = torch.zeros(67, dtype=torch.int32).pin_memory()  # the frame words of the last frame: chained totals | status | kept | final
 

@@ -12,9 +12,11 @@ Two launch modes:
 * eager               ~150 host-side launches per frame through the C ABI (1.5 ms of host time); decode + NMS on a side stream.
 * HIP graph (``graph=True``)  encode -> fuse -> heads -> decode -> NMS -> range filter -> the four result scalars'
   copy to pinned host memory are captured ONCE per (lane, input shape) and replayed with one host call per frame
-  (every kernel has static launch geometry; data-dependent sizes live in device memory).  Inputs are copied into the
-  graph's static buffers on the lane's stream.  A new input shape triggers a new capture; callers with ragged pillar
-  counts should pad ``processed_lidar`` to a bucket size with ``pad_pillars`` (padding rows are ignored by the kernels).
+  (every kernel has static launch geometry; data-dependent sizes live in device memory).  Round 5: a from-pillars frame is read IN PLACE -- the pillar launch
+  takes its three arrays and the count through a 32-byte device record (include/coalign_amd.h (1c)) that travels, with the host-normalised pose matrices when
+  the batch carries ``pairwise_t_matrix_host`` (the dataset's float64 host copy), as ONE small host-to-device transfer per frame; frames in other dtypes /
+  layouts, and models whose encoder does not take a record, are copied into the graph's static buffers as before.  A new input shape triggers a new capture;
+  ragged pillar counts share a capacity-sized graph per power-of-two bucket.
 
 Both modes produce bit-identical detections to ``model(batch)`` + ``post_processor.post_process`` (tests/test_pipeline_gpu.py).
 
@@ -39,6 +41,7 @@ from .postprocess import PostProcessHandle, VoxelPostprocessor
 import os as _os
 POST_PROCESS_SIDE_STREAM = _os.environ.get("COALIGN_PP_SIDE", "1") != "0"       # measurement switch (tools/ab_bench.sh)
 GRAPH_PERSISTENT_CANVAS = _os.environ.get("COALIGN_GRAPH_PERSIST", "1") != "0"  # measurement switch
+FRAME_RECORDS = _os.environ.get("COALIGN_FRAME_RECORDS", "1") != "0"            # measurement switch: 0 = every frame is copied into the graph's input buffers (rounds 2-4)
 
 FrameResult = Tuple[int, Optional[torch.Tensor], Optional[torch.Tensor]]      # (frame index, pred_box3d [K', 8, 3], scores [K'])
 
@@ -77,6 +80,14 @@ class _GraphSlot:
         self.recv_ptrs: Optional[tuple] = None          # data pointers of the collective's output maps the tail graph was captured on
         self.rows = None
         self.tail_record: Optional[List[int]] = None
+        # round 5: the frame is read IN PLACE through a device record (ops.PillarFrameRecord) instead of being copied into `inputs`: `blob` = record words |
+        # normalised pose matrices, filled in the pinned `blob_host` and moved with ONE host-to-device transfer per frame
+        self.record: Optional[ops.PillarFrameRecord] = None
+        self.blob: Optional[torch.Tensor] = None
+        self.blob_host: Optional[torch.Tensor] = None
+        self.proto: Optional[dict] = None               # the capture-time arrays (shapes / dtypes only)
+        self.affine_view: Optional[torch.Tensor] = None # [B, L, L, 2, 3] float64 view of the device blob (host-normalised poses), else None
+        self.affine_host: Optional[np.ndarray] = None
 
 
 class FramePipeline:
@@ -147,6 +158,10 @@ class FramePipeline:
         # power of two, >= 4096 rows) captures ONE graph with capacity-sized inputs and the count on the device (PillarVFE's voxel_count_dev
         # form, cells not assumed unique), which then serves every other count of that bucket: ragged streams settle on <= 2 graphs per lane
         self._bucket_seen: List[Dict[tuple, tuple]] = [dict() for _ in range(self.n_lanes)]
+        # frames read in place through a device record (no input copies); switched off for good when the model's route turns out not to take one
+        self._records_ok = FRAME_RECORDS and hasattr(model, "pillar_vfe") and hasattr(model, "scatter")
+        self.frames_in_place = self.frames_copied = 0             # graph-mode frames read through a device record / copied into the graph's input buffers
+        self._host_poses = self._records_ok and bool(getattr(model, "accepts_normalized_affine", False)) and hasattr(model, "voxel_size")
         self.graphs_captured = 0
         self._lane_busy: List[Optional[int]] = [None] * self.n_lanes          # frame index whose result still sits in the lane's buffers
         self._pending: "collections.deque" = collections.deque()              # (index, handle, keep-alive)
@@ -194,6 +209,11 @@ class FramePipeline:
     def _slot_batch(self, slot: _GraphSlot, record: List[int]) -> dict:
         if slot.offsets is not None:
             return self._points_batch(slot.inputs["points"], slot.offsets, record, slot.inputs["pairwise_t_matrix"])
+        if slot.record is not None:
+            b = {"processed_lidar": dict(slot.proto, pillar_frame=slot.record), "record_len": record, "pairwise_t_matrix": slot.inputs.get("pairwise_t_matrix")}
+            if slot.affine_view is not None:
+                b["normalized_affine_matrix"] = slot.affine_view
+            return b
         pl = {k: slot.inputs[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")}
         if slot.capacity is not None:                       # capacity-sized arrays, the frame's pillar count on the device
             pl.update(voxel_count_dev=slot.inputs["count"], voxel_cells_unique=False)
@@ -262,13 +282,17 @@ class FramePipeline:
             pl = batch["processed_lidar"]
             src = {"voxel_features": pl["voxel_features"], "voxel_coords": pl["voxel_coords"], "voxel_num_points": pl["voxel_num_points"],
                    "pairwise_t_matrix": batch["pairwise_t_matrix"]}
-        key = (tuple(record), None if offsets is None else tuple(offsets)) + tuple((tuple(t.shape), str(t.dtype)) for t in src.values())
+        direct = offsets is None and self._records_ok and ops.PillarFrameRecord.admits(src["voxel_features"], src["voxel_num_points"], src["voxel_coords"], self.device)
+        pose_host = batch.get("pairwise_t_matrix_host") if direct and self._host_poses else None
+        if pose_host is not None and (pose_host.is_cuda or pose_host.dtype != torch.float64 or tuple(pose_host.shape) != tuple(src["pairwise_t_matrix"].shape)):
+            pose_host = None
+        key = (tuple(record), None if offsets is None else tuple(offsets), direct, pose_host is not None) + tuple((tuple(t.shape), str(t.dtype)) for t in src.values())
         slot = self._slots[k].get(key)
         M = cap = None
         if offsets is None and slot is None and self.pillar_buckets:
             M = int(src["voxel_features"].shape[0])
             cap = max(4096, 1 << max(M - 1, 0).bit_length())
-            bkey = (tuple(record), "bucket", cap, tuple(src["voxel_features"].shape[1:]), tuple(src["pairwise_t_matrix"].shape))
+            bkey = (tuple(record), "bucket", cap, direct, pose_host is not None, tuple(src["voxel_features"].shape[1:]), tuple(src["pairwise_t_matrix"].shape))
             first = self._bucket_seen[k].setdefault(bkey, key)
             if bkey in self._slots[k] or first != key:           # a second shape of this bucket: the capacity-sized graph from here on
                 key = bkey
@@ -288,26 +312,50 @@ class FramePipeline:
             slot.weights_sig = sig
             slot.offsets = None if offsets is None else list(offsets)
             slot.capacity = cap
-            for name, t in src.items():
-                rows = cap if (cap is not None and name != "pairwise_t_matrix") else t.shape[0]
-                slot.inputs[name] = torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
-                slot.inputs[name][: t.shape[0]].copy_(t, non_blocking=True)
-            if cap is not None:
-                slot.inputs["count"] = torch.full((1,), M, dtype=torch.int32, device=self.device)
-                slot.count_host = torch.zeros(1, dtype=torch.int32).pin_memory()      # (a 4-byte copy per frame, not a fill kernel)
-            if self.exchange is not None:
-                slot.tail_record = host_ints(batch["tail_record_len"]) if "tail_record_len" in batch else list(record)
-                self._capture_split(k, slot, record)
+            if direct:
+                pw = src["pairwise_t_matrix"]
+                n_aff = pw.numel() // 16 * 6 if pose_host is not None else 0
+                slot.blob_host = torch.zeros(4 + n_aff, dtype=torch.int64).pin_memory()
+                slot.blob = torch.zeros(4 + n_aff, dtype=torch.int64, device=self.device)
+                slot.record = ops.PillarFrameRecord(slot.blob[:4], slot.blob_host[:4], cap if cap is not None else int(src["voxel_features"].shape[0]))
+                slot.proto = {name: src[name] for name in ("voxel_features", "voxel_coords", "voxel_num_points")}
+                if pose_host is not None:
+                    shape = tuple(pw.shape[:-2]) + (2, 3)
+                    slot.affine_view = slot.blob[4:].view(torch.float64).view(shape)
+                    slot.affine_host = slot.blob_host[4:].view(torch.float64).numpy().reshape(shape)
+                else:
+                    slot.inputs["pairwise_t_matrix"] = torch.zeros_like(pw, device=self.device)
+                self._stage_record(slot, src, pose_host)
             else:
-                self._frame_body(slot, record)                  # eager warm-up on the lane: MIOpen find, weight folds, anchors, buffers
-                stream.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream):
-                    self._frame_body(slot, record)
-                slot.graph = g
+                for name, t in src.items():
+                    rows = cap if (cap is not None and name != "pairwise_t_matrix") else t.shape[0]
+                    slot.inputs[name] = torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+                    slot.inputs[name][: t.shape[0]].copy_(t, non_blocking=True)
+                if cap is not None:
+                    slot.inputs["count"] = torch.full((1,), M, dtype=torch.int32, device=self.device)
+                    slot.count_host = torch.zeros(1, dtype=torch.int32).pin_memory()      # (a 4-byte copy per frame, not a fill kernel)
+            try:
+                if self.exchange is not None:
+                    slot.tail_record = host_ints(batch["tail_record_len"]) if "tail_record_len" in batch else list(record)
+                    self._capture_split(k, slot, record)
+                else:
+                    self._frame_body(slot, record)                  # eager warm-up on the lane: MIOpen find, weight folds, anchors, buffers
+                    stream.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=stream):
+                        self._frame_body(slot, record)
+                    slot.graph = g
+            except ops.FrameRecordUnsupported:
+                # (raised by the eager warm-up, before any capture has begun: this model's encoder reads its arrays directly -- copy frames in from now on)
+                self._records_ok = self._host_poses = False
+                return self._graphed(k, batch, record)
             self.graphs_captured += 1
             self._slots[k][key] = slot                          # only a slot whose capture succeeded is ever looked up again
-        if slot.capacity is not None:
+        self.frames_in_place += slot.record is not None
+        self.frames_copied += slot.record is None
+        if slot.record is not None:
+            self._stage_record(slot, src, pose_host)
+        elif slot.capacity is not None:
             if M is None:
                 M = int(src["voxel_features"].shape[0])
             for name, t in src.items():
@@ -335,6 +383,20 @@ class FramePipeline:
         done = torch.cuda.Event()
         done.record(stream)
         return PostProcessHandle(self.pp, slot.buf, done)
+
+    def _stage_record(self, slot: _GraphSlot, src: dict, pose_host: Optional[torch.Tensor]) -> None:
+        """This frame's record (array pointers | pillar count) and, when the caller kept the dataset's host copy of the pose matrices, their normalised form
+        (transformation_utils.py:69-91 in numpy float64: the device kernel's operations, bit for bit) go to the device as ONE transfer out of pinned memory; the
+        arrays themselves are read where they are (the batch stays referenced until its frame has completed).  The slot's previous frame has been collected
+        before the lane is reused, so the pinned words are free to be rewritten."""
+        slot.record.set(src["voxel_features"], src["voxel_num_points"], src["voxel_coords"])
+        if slot.affine_host is not None:
+            from .pose import normalize_pairwise_np
+            sc = self.model.scatter
+            normalize_pairwise_np(pose_host.numpy(), sc.ny, sc.nx, float(self.model.voxel_size[0]), out=slot.affine_host)
+        else:
+            slot.inputs["pairwise_t_matrix"].copy_(src["pairwise_t_matrix"], non_blocking=True)
+        slot.blob.copy_(slot.blob_host, non_blocking=True)
 
     def _weights_signature(self) -> tuple:
         # The tensor list is cached (walking the module tree on every frame cost ~50 us of host time): it is rebuilt after a load_state_dict (hook),

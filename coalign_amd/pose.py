@@ -67,6 +67,22 @@ def normalize_pairwise_tfm(pairwise_t_matrix: torch.Tensor, H: int, W: int, disc
     return m
 
 
+def normalize_pairwise_np(pairwise_t_matrix: np.ndarray, H: int, W: int, discrete_ratio: float, downsample_rate: float = 1, out: np.ndarray = None) -> np.ndarray:
+    """``normalize_pairwise_tfm`` on the HOST in numpy float64 (opencood/utils/transformation_utils.py:69-91): the same operations in the same order as the
+    torch route and the device kernel, hence the same bits.  ``out`` ([..., 2, 3] float64, e.g. a view of a pinned staging buffer) is written in place."""
+    m = np.asarray(pairwise_t_matrix, dtype=np.float64)
+    if out is None:
+        out = np.empty(m.shape[:-2] + (2, 3), dtype=np.float64)
+    out[..., 0] = m[..., :2, 0]
+    out[..., 1] = m[..., :2, 1]
+    out[..., 2] = m[..., :2, 3]
+    out[..., 0, 1] = out[..., 0, 1] * H / W
+    out[..., 1, 0] = out[..., 1, 0] * W / H
+    out[..., 0, 2] = out[..., 0, 2] / (downsample_rate * discrete_ratio * W) * 2
+    out[..., 1, 2] = out[..., 1, 2] / (downsample_rate * discrete_ratio * H) * 2
+    return out
+
+
 def generate_noise_laplace(pos_b: float, rot_b: float, pos_mu: float = 0, rot_mu: float = 0, rng=np.random) -> np.ndarray:
     """Laplace localisation noise on (x, y, yaw) (opencood/utils/pose_utils.py:77-105): ``laplace(size=2)`` then ``laplace(size=1)``,
     the reference's draw order."""

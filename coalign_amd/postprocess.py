@@ -233,7 +233,8 @@ class PostProcessHandle:
         self.owner.last_counts = {"candidates": n_cand, "kept": n_keep, "final": n_out}
         if n_cand == 0:
             return None, None
-        return self.buf.out_corners[:n_out].clone(), self.buf.out_scores[:n_out].clone()
+        flat, top = self.buf.out_flat.clone(), self.buf.top          # (one copy launch for both arrays: the buffers are rewritten by the lane's next frame)
+        return flat[: top * 24].view(top, 8, 3)[:n_out], flat[top * 24:][:n_out]
 
 
 class UncertaintyVoxelPostprocessor(VoxelPostprocessor):

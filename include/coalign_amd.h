@@ -410,6 +410,21 @@ int coalign_pillar_fold_params(const float *pfn_weight, const float *pfn_bias, c
 int coalign_pillar_encode_sparse(const float *voxel_features, const int32_t *voxel_num_points, const int32_t *voxel_coords, int M_capacity,
                                  const int32_t *M_dev, int P, const float *folded, int C, int use_absolute_xyz, const double *voxel_size,
                                  const double *range_min, int n_agents, int ny, int nx, float *pillar_features, void *stamps, int32_t *state, void *stream);
+/* (1c) Round 5: the same launch reading its inputs through a FRAME RECORD in device memory.  A captured HIP graph bakes the pointers of its launches; a
+ * caller that replays one graph per frame on frames living at different addresses either copies every frame into the graph's buffers (20 MB per 5-agent
+ * frame) or -- this entry -- writes 32 bytes: the kernel loads the three array pointers and the pillar count from `frame` when it starts.  The arrays
+ * named by the record must stay valid and unchanged until the launch has completed; M_capacity sizes the grid and pillar_features ([M_capacity, C]);
+ * rows at and beyond frame->M are never read.  Everything else as (1b). */
+typedef struct coalign_pillar_frame {
+    const float *voxel_features;          /* [M, P, 4] float32 (processed_lidar.voxel_features, pillar_vfe.py:105-155) */
+    const int32_t *voxel_num_points;      /* [M] */
+    const int32_t *voxel_coords;          /* [M, 4] (agent, z, y, x) */
+    int32_t M;                            /* pillars of this frame, clamped to [0, M_capacity] by the kernel */
+    int32_t reserved;
+} coalign_pillar_frame;
+int coalign_pillar_encode_sparse_frame(const coalign_pillar_frame *frame, int M_capacity, int P, const float *folded, int C, int use_absolute_xyz,
+                                       const double *voxel_size, const double *range_min, int n_agents, int ny, int nx, float *pillar_features, void *stamps,
+                                       int32_t *state, void *stream);
 /* (9d) The strided 3x3 convolution of (9b) (stride 2, pad 1, bias + ReLU; resblock.py:150-174) reading the sparse canvas of (1b): feats [M, Cin], pixel
  * (n, y, x) of the logical [N, Hin, Win, Cin] input = feats row (stamp & 0xffffffff) where the cell's stamp carries state[0], else zero.
  * y: [N, Cout, ceil(Hin/2), ceil(Win/2)] NCHW, channels-last if out_nhwc == 1, an SP map (9e) if out_nhwc == 2 (terms 16).  terms in {2, 3, 16} with the tap-pair weight image of (9b). */

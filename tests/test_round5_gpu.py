@@ -387,3 +387,119 @@ def test_conv3x3_sp_stream_k_hand_over_stress():
                 outs[i].clear()
     for ws in ops._SP_WS.values():
         assert int(ws[:2048].view(torch.int32).abs().sum()) == 0          # every flag consumed and reset
+
+
+# ------------------------------------------------------------------------------------------------ frames read in place (include/coalign_amd.h (1c))
+def _record_case(M, cap, seed):
+    from coalign_amd.config import builtin_config
+    from coalign_amd.synthetic import make_frame
+    h = builtin_config("opv2v_coalign")
+    margs = h["model"]["args"]
+    fr = make_frame(h, 2, pillars_per_agent=max((M + 1) // 2, 1), seed=seed)["processed_lidar"]
+    pl = {k: v[:M].to(DEV) for k, v in fr.items()}
+    g = torch.Generator().manual_seed(seed)
+    w = (torch.randn(64, 10, generator=g) * 0.3).to(DEV)
+    bn = tuple(t.to(DEV) for t in (torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5))
+    return margs, pl, w, bn
+
+
+@pytest.mark.parametrize("M,cap", [(5000, 5000), (3001, 4096), (1, 4096), (0, 4096)])
+def test_pillar_frame_record_equals_direct_launch(M, cap):
+    """coalign_pillar_encode_sparse_frame reads (arrays, count) from a device record: same feature rows and the same cells as the direct launch, for a count below
+    the capacity, a single pillar and an empty frame; a second frame at OTHER addresses through the same record words (what a replayed graph does)."""
+    margs, pl, w, bn = _record_case(M, cap, 11)
+    args = (w, None, bn, 1e-3, True, margs["voxel_size"], margs["lidar_range"][:3], 2, 200, 704)
+    want = ops.pillar_encode_sparse(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], *args, canvas_cache={})
+    blob, host = torch.zeros(4, dtype=torch.int64, device=DEV), torch.zeros(4, dtype=torch.int64).pin_memory()
+    rec = ops.PillarFrameRecord(blob, host, cap)
+    assert ops.PillarFrameRecord.admits(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], torch.device(DEV))
+    cache = {}
+    for rnd in range(2):
+        cur = pl if rnd == 0 else {k: v.clone() for k, v in pl.items()}
+        rec.set(cur["voxel_features"], cur["voxel_num_points"], cur["voxel_coords"])
+        blob.copy_(host, non_blocking=True)
+        got = ops.pillar_encode_sparse(pl["voxel_features"][:0] if rnd else pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], *args, canvas_cache=cache, frame=rec)
+        torch.cuda.synchronize()
+        assert got.feats.shape[0] == cap and torch.equal(got.feats[:M], want.feats)
+        tag_g, tag_w = int(got.state[0]), int(want.state[0])
+        live_g, live_w = (got.stamps >> 32) == tag_g, (want.stamps >> 32) == tag_w
+        assert torch.equal(live_g, live_w) and torch.equal(got.stamps[live_g] & 0xffffffff, want.stamps[live_w] & 0xffffffff)
+    with pytest.raises(ValueError):
+        big = torch.zeros((cap + 1, 32, 4), device=DEV)
+        rec.set(big, torch.zeros(cap + 1, dtype=torch.int32, device=DEV), torch.zeros((cap + 1, 4), dtype=torch.int32, device=DEV))
+    assert not ops.PillarFrameRecord.admits(pl["voxel_features"], pl["voxel_num_points"].long(), pl["voxel_coords"], torch.device(DEV))
+
+
+def _pipeline_world(n_frames=6):
+    from coalign_amd.config import builtin_config
+    from coalign_amd.detector import build_model, to_device
+    from coalign_amd.postprocess import build_postprocessor
+    from coalign_amd.synthetic import calibrate_heads_, fill_parameters_, make_frame
+    h = builtin_config("opv2v_coalign")
+    counts = (8000, 8000, 7300, 7800, 8000, 6900)[:n_frames]
+    cpu = [make_frame(h, 5, pillars_per_agent=m, seed=700 + i, noise=(0.2, 0.2)) for i, m in enumerate(counts)]
+    frames = []
+    for f in cpu:
+        d = to_device(f, DEV)
+        d["record_len"] = [5]
+        d["pairwise_t_matrix_host"] = f["pairwise_t_matrix"]
+        frames.append(d)
+    model = build_model(h)
+    fill_parameters_(model, seed=0)
+    model = model.to(DEV).eval()
+    pp = build_postprocessor(h["postprocess"], False)
+    calibrate_heads_(model, frames[0], pp.params["target_args"]["score_threshold"], 600)
+    return model, pp, torch.from_numpy(pp.generate_anchor_box()), frames
+
+
+def test_pipeline_frame_records_equal_copied_inputs_bit_for_bit():
+    """FramePipeline(graph=True) on frames read in place (device record + host-normalised poses, ONE small transfer per frame) returns what the copying route of
+    rounds 2-4 returns, bit for bit: equal shapes (exact capture), ragged counts (the capacity-sized bucket graph), with and without the host copy of the poses,
+    and across recurrences of the same slot."""
+    from coalign_amd import pipeline as pl_mod
+    model, pp, anchors, frames = _pipeline_world()
+    order = [0, 1, 2, 3, 4, 5, 1, 3, 0, 5, 2, 4]
+    keep = pl_mod.FRAME_RECORDS
+    try:
+        pl_mod.FRAME_RECORDS = False
+        ref_pipe = pl_mod.FramePipeline(model, pp, anchors, lanes=2, result_lag=1, graph=True)
+        want = ref_pipe.run([frames[i] for i in order])
+        assert all(s.record is None for d in ref_pipe._slots for s in d.values())
+        ref_pipe.close()
+        pl_mod.FRAME_RECORDS = True
+        for host_pose in (True, False):
+            fs = frames if host_pose else [{k: v for k, v in f.items() if k != "pairwise_t_matrix_host"} for f in frames]
+            pipe = pl_mod.FramePipeline(model, pp, anchors, lanes=2, result_lag=1, graph=True)
+            got = pipe.run([fs[i] for i in order])
+            slots = [s for d in pipe._slots for s in d.values()]
+            assert slots and all(s.record is not None and (s.affine_view is not None) == host_pose and not any(k.startswith("voxel") for k in s.inputs) for s in slots)
+            assert any(s.capacity is not None for s in slots)                  # the ragged frames went through a bucket graph
+            assert pipe.frames_in_place == len(order) and pipe.frames_copied == 0
+            for i, ((b, s), (wb, ws)) in enumerate(zip(got, want)):
+                assert wb is not None and torch.equal(b, wb) and torch.equal(s, ws), f"frame {i} (host poses {host_pose})"
+            pipe.close()
+    finally:
+        pl_mod.FRAME_RECORDS = keep
+
+
+def test_pipeline_falls_back_to_copies_when_the_encoder_takes_no_record():
+    """A model configured off the sparse-canvas route (native fp32 convolutions) raises FrameRecordUnsupported in the warm-up; the pipeline then copies frames
+    into the graph's buffers, for good, and the detections equal the synchronous path's."""
+    from coalign_amd import backbone as bb
+    from coalign_amd import pipeline as pl_mod
+    model, pp, anchors, frames = _pipeline_world(2)             # (equal pillar counts: the capacity-sized bucket graph needs the channels-last routes)
+    saved = bb.CONV_EMU_TERMS
+    try:
+        bb.CONV_EMU_TERMS = 0
+        meta = {"ego": {"transformation_matrix": torch.eye(4, device=DEV), "anchor_box": anchors}}
+        with torch.no_grad():
+            want = [pp.post_process(meta, {"ego": model(f)}) for f in frames]
+        pipe = pl_mod.FramePipeline(model, pp, anchors, lanes=2, result_lag=1, graph=True)
+        assert pipe._records_ok
+        got = pipe.run(frames)
+        assert not pipe._records_ok and all(s.record is None for d in pipe._slots for s in d.values())
+        for (b, s), (wb, ws) in zip(got, want):
+            assert torch.equal(b, wb) and torch.equal(s, ws)
+        pipe.close()
+    finally:
+        bb.CONV_EMU_TERMS = saved
