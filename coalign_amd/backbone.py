@@ -93,6 +93,9 @@ CONV_WINOGRAD = os.environ.get("COALIGN_WINOGRAD", "0") != "0"
 # The strided first convolution of a stage and the shrink header's first convolution (float32 inputs) write the first SplitMap of their chain; the last
 # convolution of a stage writes channels-last float32 for the fusion kernel and the next stage, as before.  "0": the consumer-split kernels everywhere (round 4's route).
 SPLIT_MAPS = os.environ.get("COALIGN_SPLIT_MAPS", "1") != "0"
+# ... and (second half of round 5) the up-sampling heads write the concatenated map as a SplitMap, so that the shrink header's FIRST convolution runs on conv3x3_sp
+# too (csrc/pointwise.hip's SP epilogue).  "0": float32 concatenation + consumer-split kernel for that layer (measurement switch).
+HEAD_SPLIT_MAPS = os.environ.get("COALIGN_HEAD_SPLIT_MAPS", "1") != "0"
 
 
 def split_maps_active() -> bool:
@@ -437,7 +440,9 @@ class _MultiscaleDecodeMixin:
             sizes.add((f.shape[2] * op.stride[0], f.shape[3] * op.stride[0]))
         return len(sizes) == 1
 
-    def _upsample_concat(self, feats: Sequence[torch.Tensor]) -> torch.Tensor:
+    def _upsample_concat(self, feats: Sequence[torch.Tensor], out_split: bool = False):
+        """``out_split`` (round 5): the caller's next layer reads SplitMaps (the shrink header on the fp16 route): the heads then write the concatenated map as
+        one (``ops.SplitMap``) -- granted only on the pointwise route with split-bf16 weight images; otherwise the float32 tensor comes back as always."""
         if self._pointwise_ok(feats):
             # every head writes its channel slice of the concatenated tensor directly (one GEMM launch each, bias + ReLU fused)
             ops_, c_tot = [], 0
@@ -448,9 +453,14 @@ class _MultiscaleDecodeMixin:
                 ops_.append((f, w, b, op.out_channels, op.stride[0], c_tot))
                 c_tot += op.out_channels
             f0, s0 = feats[0], self.deblocks[0][0].stride[0]
-            x = torch.empty((f0.shape[0], c_tot, f0.shape[2] * s0, f0.shape[3] * s0), dtype=torch.float32, device=f0.device)
-            for f, w, b, cout, up, off in ops_:
-                ops.pointwise_conv(f, w.get(), b, cout, up=up, relu=True, out=x, c_off=off)
+            images = [w.get() for _, w, _, _, _, _ in ops_]
+            if (out_split and len(self.deblocks) == self.num_levels and all(im.dtype == torch.int16 for im in images)
+                    and all(cout % 16 == 0 and off % 16 == 0 and im.shape[0] * 32 == cout * up * up for (_, _, _, cout, up, off), im in zip(ops_, images))):
+                x = ops.SplitMap.empty(f0.shape[0], c_tot, f0.shape[2] * s0, f0.shape[3] * s0, f0.device)
+            else:
+                x = torch.empty((f0.shape[0], c_tot, f0.shape[2] * s0, f0.shape[3] * s0), dtype=torch.float32, device=f0.device)
+            for (f, w, b, cout, up, off), im in zip(ops_, images):
+                ops.pointwise_conv(f, im, b, cout, up=up, relu=True, out=x, c_off=off)
             if len(self.deblocks) > self.num_levels:
                 x = self._deblock(len(self.deblocks) - 1, x)
             return x
@@ -460,8 +470,8 @@ class _MultiscaleDecodeMixin:
             x = self._deblock(len(self.deblocks) - 1, x)
         return x
 
-    def decode_multiscale_feature(self, feats: Sequence[torch.Tensor]) -> torch.Tensor:
-        return self._upsample_concat(feats)
+    def decode_multiscale_feature(self, feats: Sequence[torch.Tensor], out_split: bool = False):
+        return self._upsample_concat(feats, out_split)
 
     def forward(self, data_dict: dict) -> dict:
         feats = self.get_multiscale_feature(data_dict["spatial_features"])
@@ -560,7 +570,22 @@ class DoubleConv(nn.Module):
             nn.Conv2d(cin, cout, kernel_size, stride=stride, padding=padding), nn.ReLU(inplace=True),
             nn.Conv2d(cout, cout, 3, padding=1), nn.ReLU(inplace=True))
 
+    def takes_split_maps(self) -> bool:
+        """Both layers are 3x3 / stride 1 / pad 1 with channel counts the SplitMap kernel serves, and the fp16 route is on: forward() then accepts an
+        ``ops.SplitMap`` (the up-sampling heads' output, round 5) and runs BOTH convolutions on ``conv3x3_sp``."""
+        c1, c2 = self.double_conv[0], self.double_conv[2]
+        ok = lambda c: c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.out_channels % 64 == 0 and c.in_channels % 16 == 0
+        return bool(HEAD_SPLIT_MAPS and split_maps_active() and not self.training and ok(c1) and ok(c2) and c1.weight.is_cuda)
+
     def forward(self, x):
+        if isinstance(x, ops.SplitMap):
+            if not self.takes_split_maps():
+                x = x.dense()
+            else:
+                c1, c2 = self.double_conv[0], self.double_conv[2]
+                p1, p2 = _cache_of(self).get([c1.weight, c2.weight], lambda: (Conv3x3Pack(c1.weight.detach()), Conv3x3Pack(c2.weight.detach())))
+                y = ops.conv3x3_sp(x, p1.emu(16, True), c1.bias, p1.cout, None, True, out_split=True)
+                return ops.conv3x3_sp(y, p2.emu(16, True), c2.bias, p2.cout, None, True, out_split=False)
         if _fast_ok(self, x):
             c1, c2 = self.double_conv[0], self.double_conv[2]
 
@@ -593,6 +618,9 @@ class DownsampleConv(nn.Module):
         for k, dim, s, p in zip(config["kernal_size"], config["dim"], config["stride"], config["padding"]):
             self.layers.append(DoubleConv(cin, dim, k, s, p))
             cin = dim
+
+    def takes_split_maps(self) -> bool:
+        return len(self.layers) > 0 and self.layers[0].takes_split_maps()
 
     def forward(self, x):
         for layer in self.layers:

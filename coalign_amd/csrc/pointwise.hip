@@ -33,6 +33,10 @@ struct PwArgs {
     // stamps[(n * Hin + y) * Win + x] >> 32 == *tag_ptr, else zero
     const unsigned long long *stamps;
     const int *tag_ptr;
+    // round 5: y is an SP map (csrc/conv3x3_sp.hip: [N][Ctot / 16][4 planes][Ho][Wo][8 x fp16]) -- the up-sampling heads write the input of the shrink header's
+    // first convolution already split; range_flag as there (bit 0: a value beyond the pair's range)
+    int out_sp;
+    int *range_flag;
 };
 
 // Epilogue shared by both kernels: accumulator r of lane l is GEMM row 8 * (r / 4) + 4 * (l / 32) + r % 4 of its 32-row tile, pixel l % 32
@@ -144,7 +148,8 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
     // this wavefront's pixel block and its two m-tiles
     const int pbk = wave / WPB, rt = wave - pbk * WPB;
     const int m0 = m_base + rt * 64;
-    if (m0 >= a.M) return;
+    const bool active = m0 < a.M;
+    if (!active && !a.out_sp) return;                     // (the SP epilogue below has workgroup barriers: idle wavefronts stay for them)
     const bool second = m0 + 32 < a.M;
     floatx16 acc0 = {0}, acc1 = {0};
     const float *w0 = a.w + m0 + p;
@@ -158,6 +163,65 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
     }
     pw_store<UP>(a, n, m0, second, p0 + pbk * 32 + p, half, acc0, acc1);
+}
+
+// SP-map epilogue (round 5).  The 8 consecutive channels of one 16-byte group of an SP map are spread over the accumulators of both lane halves (UP = 1, 2)
+// or of two wavefronts (UP = 4: a wavefront's 64 GEMM rows are 4 output channels): the workgroup parks its [rows][32 pixels] float tile in LDS (the X tile is
+// dead by then) and every thread then assembles whole groups: item = (pixel block, 8-channel group, ky, kx, pixel), kx and the pixel fastest, so that a
+// wavefront's 16-byte stores run along output rows.  Bias, ReLU and the sp16 split (common.h) happen on the way out: the same values, bit for bit, as
+// coalign_sp_pack of the float32 result.
+template <int UP>
+__device__ __forceinline__ void pw_store_sp(const PwArgs &a, float *stage, int n, int m_base, int p0, int RW, int PB, int tid, int pbk, int rt, int lane, bool active, bool second,
+                                            const floatx16 &acc0, const floatx16 &acc1) {
+    constexpr int UU = UP * UP;
+    const int half = lane >> 5, p = lane & 31;
+    __syncthreads();                                       // every wavefront has read its last X operands
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t == 1 && !second) break;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * 64 + t * 32 + 8 * (r / 4) + 4 * half + r % 4;
+                stage[(pbk * RW + row) * 33 + p] = t == 0 ? acc0[r] : acc1[r];
+            }
+        }
+    }
+    __syncthreads();
+    const int pixels = a.Hp * a.Wp, Ho = a.Hp * UP, Wo = a.Wp * UP;
+    const size_t HWo = (size_t)Ho * Wo;
+    const int c8n = RW / (8 * UU);                         // 8-channel groups of the workgroup's rows
+    const int items = PB * c8n * UU * 32;
+    uint4 *ysp = reinterpret_cast<uint4 *>(a.y);
+    bool big = false;
+    for (int it = tid; it < items; it += 256) {
+        const int kx = it % UP, pp = (it / UP) & 31;
+        int rest = it / (32 * UP);
+        const int ky = rest % UP;
+        rest /= UP;
+        const int c8 = rest % c8n, pb = rest / c8n;
+        const int co0 = m_base / UU + 8 * c8;              // first of the 8 output channels (layer-local)
+        const int px = p0 + pb * 32 + pp;
+        if (co0 >= a.Cout || px >= pixels) continue;
+        const int hp = px / a.Wp, wp = px - hp * a.Wp;
+        const float4 b0 = *reinterpret_cast<const float4 *>(a.bias + co0), b1 = *reinterpret_cast<const float4 *>(a.bias + co0 + 4);
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = stage[(pb * RW + (8 * c8 + j) * UU + ky * UP + kx) * 33 + pp] + bb[j];
+            if (a.relu) v[j] = fmaxf(v[j], 0.f);
+            big = big || fabsf(v[j]) > 65504.f;
+        }
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) coalign::sp16_split2(v[2 * k], v[2 * k + 1], h[k], l[k]);
+        const int cg = a.c_off + co0;                      // channel inside the concatenated map
+        const size_t idx = ((size_t)(n * (a.Ctot / 16) + cg / 16) * 4 + ((cg >> 3) & 1) * 2) * HWo + (size_t)(hp * UP + ky) * Wo + wp * UP + kx;
+        ysp[idx] = uint4{h[0], h[1], h[2], h[3]};
+        ysp[idx + HWo] = uint4{l[0], l[1], l[2], l[3]};
+    }
+    if (a.range_flag && big) atomicOr(a.range_flag, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -227,10 +291,11 @@ __global__ __launch_bounds__(256) void pointwise_emu_kernel(const PwArgs a) {
     __syncthreads();
     const int pbk = wave / WPB, rt = wave - pbk * WPB;
     const int m0 = m_base + rt * 64;
-    if (m0 >= a.M) return;
+    const bool active = m0 < a.M;
+    if (!active && !a.out_sp) return;                     // (the SP epilogue below has workgroup barriers: idle wavefronts stay for them)
     const bool second = m0 + 32 < a.M;
     const int S = a.Cin >> 4;
-    const uint4 *w0 = reinterpret_cast<const uint4 *>(a.w) + (size_t)(m0 >> 5) * S * 192 + lane;      // 3 terms x 64 lanes per (tile, step)
+    const uint4 *w0 = reinterpret_cast<const uint4 *>(a.w) + (size_t)((active ? m0 : 0) >> 5) * S * 192 + lane;      // 3 terms x 64 lanes per (tile, step)
     const uint4 *w1 = w0 + (second ? (size_t)S * 192 : 0);
     const uint4 *xb = xs + pbk * 32 + p;
     floatx16 acc0 = {0}, acc1 = {0};
@@ -243,8 +308,9 @@ __global__ __launch_bounds__(256) void pointwise_emu_kernel(const PwArgs a) {
         wb[t] = __builtin_bit_cast(bf16x8, w1[t * 64]);
         bc[t] = __builtin_bit_cast(bf16x8, xb[(t * G + half) * TP]);
     }
+    const int steps = active ? S : 0;
 #pragma unroll 2
-    for (int s = 0; s < S; ++s) {
+    for (int s = 0; s < steps; ++s) {
         bf16x8 na[3], nb[3], nc[3];
         const int sn = s + 1 < S ? s + 1 : s;             // (the last step reloads itself: no branch in the stream)
 #pragma unroll
@@ -261,7 +327,8 @@ __global__ __launch_bounds__(256) void pointwise_emu_kernel(const PwArgs a) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) { wa[t] = na[t]; wb[t] = nb[t]; bc[t] = nc[t]; }
     }
-    pw_store<UP>(a, n, m0, second, p0 + pbk * 32 + p, half, acc0, acc1);
+    if (a.out_sp) pw_store_sp<UP>(a, reinterpret_cast<float *>(xs), n, m_base, p0, 64 * WPB, PB, tid, pbk, rt, lane, active, second, acc0, acc1);
+    else pw_store<UP>(a, n, m0, second, p0 + pbk * 32 + p, half, acc0, acc1);
 }
 
 }  // namespace
@@ -273,7 +340,7 @@ extern "C" int coalign_pointwise_conv(const float *x, const float *w, const floa
 
 static int pointwise_impl(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
                           int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, bool emu,
-                          void *stream, const void *stamps = nullptr, const int32_t *state = nullptr) {
+                          void *stream, const void *stamps = nullptr, const int32_t *state = nullptr, bool out_sp = false, int32_t *range_flag = nullptr) {
     using namespace coalign;
     if (!x || !w || !bias || !y) return COALIGN_ERR_NULL_POINTER;
     if (emu && ((Cin & 15) || (reinterpret_cast<uintptr_t>(w) & 15))) return COALIGN_ERR_UNSUPPORTED;
@@ -289,7 +356,10 @@ static int pointwise_impl(const float *x, const float *w, const float *bias, flo
     in_nhwc &= 1;
     if (out_nhwc && (up != 1 || (Ctot & 3) || (c_off & 3) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias)) & 15))) return COALIGN_ERR_UNSUPPORTED;
     PwArgs a{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu, in_nhwc != 0, 1, out_nhwc,
-             static_cast<const unsigned long long *>(stamps), state};
+             static_cast<const unsigned long long *>(stamps), state, out_sp ? 1 : 0, range_flag};
+    if (out_sp && (!emu || out_nhwc || (Cout & 15) || (Ctot & 15) || (c_off & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15) ||
+                   M_padded != Cout * up * up || (size_t)N * Ctot * a.Hp * up * a.Wp * up >= ((size_t)1 << 33)))
+        return COALIGN_ERR_UNSUPPORTED;
     if (stamps && (!in_nhwc || !state || (reinterpret_cast<uintptr_t>(stamps) & 7))) return COALIGN_ERR_UNSUPPORTED;
     if (N > 65535) return COALIGN_ERR_UNSUPPORTED;
     const int pixels = a.Hp * a.Wp;
@@ -302,7 +372,8 @@ static int pointwise_impl(const float *x, const float *w, const float *bias, flo
     const dim3 grid((pixels + px_per_wg - 1) / px_per_wg, (M_padded + rows_per_wg - 1) / rows_per_wg, N);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (emu) {
-        const size_t lds = (size_t)Cin * px_per_wg * 6;           // three bf16 terms of the pixel tile (<= 48 KB up to 256 input channels, 96 KB at 512)
+        size_t lds = (size_t)Cin * px_per_wg * 6;                 // three bf16 terms of the pixel tile (<= 48 KB up to 256 input channels, 96 KB at 512)
+        if (out_sp && lds < (size_t)256 * 33 * 4) lds = (size_t)256 * 33 * 4;      // the SP epilogue parks the workgroup's 256 rows x 32 pixels of floats there
         static bool big_lds_dev[16] = {false};                    // (beyond 64 KB of dynamic LDS the kernels need the attribute -- the merged heads of a 384-channel
         int dev = 0;                                              //  map -- and the attribute belongs to the DEVICE's code object: one flag per device)
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
@@ -355,4 +426,13 @@ extern "C" int coalign_pointwise_conv_emu_sparse(const float *feats, const void 
     if (!stamps || !state) return COALIGN_ERR_NULL_POINTER;
     return pointwise_impl(feats, static_cast<const float *>(w_split), bias, y, N, Cin, Hin, Win, 2, Cout, 1, M_padded, Cout, 0, relu, 1 | (out_nhwc ? 2 : 0), true, stream,
                           stamps, state);
+}
+
+// Round 5: the up-sampling heads writing their channel slice of the concatenated map as an SP map (include/coalign_amd.h (9e)): the shrink header's first
+// 3 x 3 convolution then reads it by LDS-DMA (coalign_conv3x3_sp) instead of splitting 54 MB of float32 in its own K loop.  Cout, Ctot, c_off multiples of 16.
+extern "C" int coalign_pointwise_conv_emu_sp(const float *x, const void *w_split, const float *bias, void *y_sp, int N, int Cin, int Hin, int Win, int in_stride,
+                                             int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, int32_t *range_flag, void *stream) {
+    if (in_nhwc & ~1) return COALIGN_ERR_UNSUPPORTED;
+    return pointwise_impl(x, static_cast<const float *>(w_split), bias, static_cast<float *>(y_sp), N, Cin, Hin, Win, in_stride, Cout, up, M_padded, Ctot, c_off, relu, in_nhwc,
+                          true, stream, nullptr, nullptr, true, range_flag);
 }

@@ -57,6 +57,10 @@ def _run_heads(model: nn.Module, x: torch.Tensor) -> dict:
     return out
 
 
+def x_is_cuda(maps) -> bool:
+    return len(maps) > 0 and all(getattr(m, "is_cuda", False) for m in maps)
+
+
 class PointPillarBaselineMultiscale(nn.Module):
     def __init__(self, args: dict):
         super().__init__()
@@ -167,9 +171,13 @@ class PointPillarBaselineMultiscale(nn.Module):
     def fuse_and_head(self, feature_list, record_len, affine, rows=None) -> dict:
         """Ego part: per-scale warp + fusion, deblocks, shrink header, heads.  ``rows``: see ``AttFusion.forward``."""
         fused = self._fuse_scales(feature_list, record_len, affine, rows)
-        x = self.backbone.decode_multiscale_feature(fused)
+        # round 5: a shrink header on the SplitMap route gets the concatenated map from the up-sampling heads already split
+        want_split = bool(self.shrink_flag and x_is_cuda(fused) and self.shrink_conv.takes_split_maps())
+        x = self.backbone.decode_multiscale_feature(fused, out_split=True) if want_split else self.backbone.decode_multiscale_feature(fused)
         if self.shrink_flag:
             x = self.shrink_conv(x)
+        elif isinstance(x, ops.SplitMap):
+            x = x.dense()
         return _run_heads(self, x)
 
     def forward(self, data_dict: dict) -> dict:

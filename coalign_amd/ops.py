@@ -1075,6 +1075,15 @@ def pointwise_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
     xc = x if nhwc else _f32c(x)
     N, Cin, Hin, Win = xc.shape
     Ho, Wo = (Hin + in_stride - 1) // in_stride * up, (Win + in_stride - 1) // in_stride * up
+    if isinstance(out, SplitMap):                          # round 5: the layer writes its channel slice of a SplitMap (the shrink header's input)
+        if not emu or out_channels_last or tuple(out.shape[2:]) != (Ho, Wo) or out.shape[0] != N or cout % 16 or c_off % 16 or c_off + cout > out.shape[1]:
+            raise ValueError("SplitMap output: split-bf16 weight image, [N, Ctot, Ho, Wo] map, Cout and c_off multiples of 16")
+        if w_packed.dim() != 5 or w_packed.shape[1] * 16 != Cin or not w_packed.is_contiguous() or w_packed.shape[0] * 32 != cout * up * up:
+            raise ValueError("split weight image does not match (Cin, Cout * up * up)")
+        with _Timed("pointwise_conv"):
+            hip.check(L.coalign_pointwise_conv_emu_sp(_ptr(xc), _ptr(w_packed), _ptr(_f32c(bias)), _ptr(out.data), N, Cin, Hin, Win, in_stride, cout, up, w_packed.shape[0] * 32,
+                                                      out.shape[1], c_off, int(relu), int(nhwc), _ptr(sp_range_flag(xc.device)), _stream()), "coalign_pointwise_conv_emu_sp")
+        return out
     if out_channels_last:                                  # (up = 1) a fresh [N, cout, Ho, Wo] tensor in channels-last memory
         if out is not None or up != 1 or cout % 4:
             raise ValueError("channels-last output: up = 1, Cout % 4 == 0, no output slice")

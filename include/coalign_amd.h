@@ -465,6 +465,13 @@ int coalign_pointwise_conv_emu(const float *x, const void *w_split, const float 
 int coalign_pointwise_conv_emu_sparse(const float *feats, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y, int N,
                                       int Cin, int Hin, int Win, int Cout, int M_padded, int relu, int out_nhwc, void *stream);
 
+/* (10c) Round 5: (10) on the split-bf16 matrix cores writing its channel slice [c_off, c_off + Cout) of an SP map (9e) of Ctot channels instead of float32 --
+ * the three up-sampling heads of base_bev_backbone_resnet.py:121-138 hand the concatenated map to the shrink header's first 3 x 3 convolution
+ * (downsample_conv.py:7-27) already split, which then runs on coalign_conv3x3_sp.  Same values, bit for bit, as coalign_sp_pack of (10)'s float32 result.
+ * Cout, Ctot, c_off multiples of 16; M_padded == Cout * up * up; in_nhwc: 0 / 1 (input layout); range_flag as in (9e), may be NULL. */
+int coalign_pointwise_conv_emu_sp(const float *x, const void *w_split, const float *bias, void *y_sp, int N, int Cin, int Hin, int Win, int in_stride, int Cout,
+                                  int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, int32_t *range_flag, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

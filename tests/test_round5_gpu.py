@@ -483,23 +483,74 @@ def test_pipeline_frame_records_equal_copied_inputs_bit_for_bit():
 
 
 def test_pipeline_falls_back_to_copies_when_the_encoder_takes_no_record():
-    """A model configured off the sparse-canvas route (native fp32 convolutions) raises FrameRecordUnsupported in the warm-up; the pipeline then copies frames
-    into the graph's buffers, for good, and the detections equal the synchronous path's."""
-    from coalign_amd import backbone as bb
+    """A model configured off the sparse-canvas route (COALIGN_SPARSE_CANVAS=0: the dense persistent canvas of round 3) raises FrameRecordUnsupported in the
+    warm-up; the pipeline then copies frames into the graph's buffers, for good, and the detections equal the synchronous path's."""
+    from coalign_amd import detector as det
     from coalign_amd import pipeline as pl_mod
-    model, pp, anchors, frames = _pipeline_world(2)             # (equal pillar counts: the capacity-sized bucket graph needs the channels-last routes)
-    saved = bb.CONV_EMU_TERMS
+    model, pp, anchors, frames = _pipeline_world(3)
+    saved = det.SPARSE_CANVAS
     try:
-        bb.CONV_EMU_TERMS = 0
+        det.SPARSE_CANVAS = False
         meta = {"ego": {"transformation_matrix": torch.eye(4, device=DEV), "anchor_box": anchors}}
         with torch.no_grad():
             want = [pp.post_process(meta, {"ego": model(f)}) for f in frames]
         pipe = pl_mod.FramePipeline(model, pp, anchors, lanes=2, result_lag=1, graph=True)
         assert pipe._records_ok
         got = pipe.run(frames)
-        assert not pipe._records_ok and all(s.record is None for d in pipe._slots for s in d.values())
+        assert not pipe._records_ok and pipe.frames_in_place == 0 and pipe.frames_copied == len(frames) and all(s.record is None for d in pipe._slots for s in d.values())
         for (b, s), (wb, ws) in zip(got, want):
             assert torch.equal(b, wb) and torch.equal(s, ws)
         pipe.close()
     finally:
-        bb.CONV_EMU_TERMS = saved
+        det.SPARSE_CANVAS = saved
+
+
+# ------------------------------------------------------------------------------------------------ up-sampling heads writing SplitMaps (include/coalign_amd.h (10c))
+@pytest.mark.parametrize("up,cin,hw,n,nhwc", [(1, 64, (100, 352), 1, True), (2, 128, (50, 176), 1, True), (4, 256, (25, 88), 1, True),
+                                               (1, 64, (13, 37), 2, False), (2, 128, (9, 21), 2, False), (4, 256, (7, 11), 3, True), (2, 64, (5, 40), 1, False)])
+def test_pointwise_heads_write_split_maps_bit_for_bit(up, cin, hw, n, nhwc):
+    """coalign_pointwise_conv_emu_sp: a head's channel slice of the concatenated SplitMap holds exactly coalign_sp_pack of the float32 layer's output; the other
+    slices are untouched; full-size head shapes of the bench and ragged small ones (pixel counts off the 32-pixel tiles, batch > 1, both input layouts)."""
+    g = torch.Generator().manual_seed(31 * up + cin)
+    H, W = hw
+    cout, ctot, c_off = 128, 384, {1: 0, 2: 128, 4: 256}[up]
+    x = torch.randn(n, cin, H, W, generator=g).to(DEV)
+    if nhwc:
+        x = x.contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cin, cout, up, up, generator=g) / math.sqrt(cin)).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    im = ops.pack_pointwise_emu_weight(ops.pack_pointwise_weight(w, True))
+    ref = torch.zeros(n, ctot, H * up, W * up, device=DEV)
+    ops.pointwise_conv(x, im, b, cout, up=up, relu=True, out=ref, c_off=c_off)
+    want = ops.SplitMap.pack(ref)
+    got = ops.SplitMap(torch.zeros_like(want.data))
+    out = ops.pointwise_conv(x, im, b, cout, up=up, relu=True, out=got, c_off=c_off)
+    torch.cuda.synchronize()
+    assert out is got and float(ref.abs().max()) > 0.5
+    assert torch.equal(got.data.view(torch.int16), want.data.view(torch.int16))
+    with pytest.raises(ValueError):
+        ops.pointwise_conv(x, im, b, cout, up=up, relu=True, out=got, c_off=8)
+
+
+def test_shrink_header_on_split_maps_from_the_heads_equals_float_route():
+    """Detector tail (up-sampling heads -> shrink header -> 1x1 heads) with the heads writing the concatenated map as a SplitMap and BOTH shrink convolutions on
+    conv3x3_sp, against the route of the first half of round 5 (float32 concatenation, consumer-split kernel for the first convolution): the same 22-bit inputs,
+    the same products; only the stream-K cut of the first convolution (hence its summation order) differs."""
+    from coalign_amd import backbone as bb
+    h = builtin_config("opv2v_coalign")
+    model = build_model(h)
+    fill_parameters_trained_like_(model, seed=5)
+    model = model.to(DEV).eval()
+    g = torch.Generator().manual_seed(77)
+    fused = [torch.relu(torch.randn(1, c, hh, ww, generator=g)).to(DEV).contiguous(memory_format=torch.channels_last) for c, hh, ww in ((64, 100, 352), (128, 50, 176), (256, 25, 88))]
+    with torch.no_grad():
+        assert model.shrink_flag and model.shrink_conv.takes_split_maps()
+        sm = model.backbone.decode_multiscale_feature(fused, out_split=True)
+        assert isinstance(sm, ops.SplitMap) and sm.shape == (1, 384, 100, 352)
+        dense = model.backbone.decode_multiscale_feature(fused)
+        assert torch.equal(sm.data.view(torch.int16), ops.SplitMap.pack(dense).data.view(torch.int16))
+        y_new = model.shrink_conv(sm)
+        y_old = model.shrink_conv(dense)
+        torch.cuda.synchronize()
+    scale = float(y_old.abs().max())
+    assert scale > 0 and float((y_new - y_old).abs().max()) <= 2e-6 * scale
