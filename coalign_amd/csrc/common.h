@@ -75,7 +75,8 @@ __device__ __forceinline__ float sp16_round(float x) { return __builtin_bit_cast
 __device__ __forceinline__ void sp16_split2(float a, float b, unsigned &hi, unsigned &lo) {
     const float ar = sp16_round(a), br = sp16_round(b);
     const auto h = __builtin_amdgcn_cvt_pkrtz(ar, br);
-    const auto l = __builtin_amdgcn_cvt_pkrtz((ar - (float)h[0]) * kSp16LowScale, (br - (float)h[1]) * kSp16LowScale);
+    // (x~ - h as fmaf(h, -1, x~): the same correctly rounded difference, but ONE v_fma_mix_f32 reading h's half of the packed register instead of a conversion + a subtraction)
+    const auto l = __builtin_amdgcn_cvt_pkrtz(fmaf((float)h[0], -1.0f, ar) * kSp16LowScale, fmaf((float)h[1], -1.0f, br) * kSp16LowScale);
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
 }

@@ -54,9 +54,13 @@ struct SpArgs {
 #define SP_STAMP(k)                                                                                              \
     if ((g == 0 || g == 100) && lane == 0 && L < 64)                                                             \
         a.trace[((((g ? 1 : 0) * 16 + wave) * 64) + L) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime()
+#define SP_STAMP_AT(k, idx)                                                                                      \
+    if ((g == 0 || g == 100) && lane == 0 && (idx) >= 0 && (idx) < 64)                                           \
+        a.trace[((((g ? 1 : 0) * 16 + wave) * 64) + (idx)) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime()
 #define SP_ABLATE(bit) (a.ablate & (bit))
 #else
 #define SP_STAMP(k)
+#define SP_STAMP_AT(k, idx)
 #define SP_ABLATE(bit) 0
 #endif
 
@@ -279,6 +283,24 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
         Tile next = cur;
         Plan nplan = plan;
         int ntile = tile;
+        // (The residual fetch steps a base pointer: two instructions per load instead of ten.  Moving it, or the next tile's plan, behind different taps per
+        //  wavefront -- so that a SIMD's other wavefronts keep the matrix pipe fed -- was tried: behind a tap the 32 residual registers are live together with the
+        //  prefetched operands, the 12-wavefront geometries spill, and the plan needs a third plan record; no gain measured, dropped.)
+        auto fetch_residual = [&]() {
+            if (a.res_kind == SP_RES_SP) {                         // h groups | l groups: 8 bytes each per (lane, 8-channel group); consecutive groups lie two planes apart
+                const uint2 *rb = reinterpret_cast<const uint2 *>(a.residual) + (((size_t)(on * CO16 + cur.cg * 4) * 4) * HW + pix) * 2 + half;
+                const size_t step = 4 * (size_t)HW, lo = 2 * (size_t)HW;
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8) {
+                    const uint2 h = rb[g8 * step], l = rb[g8 * step + lo];
+                    rraw[g8] = uint4{h.x, h.y, l.x, l.y};
+                }
+            } else if (a.res_kind == SP_RES_NHWC) {
+                const uint4 *rp = reinterpret_cast<const uint4 *>(static_cast<const float *>(a.residual) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half);
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8) rraw[g8] = rp[2 * g8];
+            }
+        };
         for (int chunk = c_begin; chunk < c_end; ++chunk, ++L) {
             SP_STAMP(0);
             __builtin_amdgcn_s_waitcnt(0);
@@ -294,21 +316,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
                 if (loader_here) nplan = make_plan(next);
             }
             if (!K::INTERLEAVED && more && loader_here) issue_all(nplan, nc, (L + 1) & 1);
-            if (chunk == c_end - 1 && head && wave_live && !SP_ABLATE(8)) {
-                if (a.res_kind == SP_RES_SP) {                     // h groups | l groups: 8 bytes each per (lane, 8-channel group)
-                    const uint2 *rp = reinterpret_cast<const uint2 *>(a.residual);
-#pragma unroll
-                    for (int g8 = 0; g8 < 8; ++g8) {
-                        const size_t idx = ((size_t)(on * CO16 + cur.cg * 4 + g8 / 2) * 4 + (g8 % 2) * 2) * HW + pix;
-                        const uint2 h = rp[idx * 2 + half], l = rp[(idx + HW) * 2 + half];
-                        rraw[g8] = uint4{h.x, h.y, l.x, l.y};
-                    }
-                } else if (a.res_kind == SP_RES_NHWC) {
-                    const uint4 *rp = reinterpret_cast<const uint4 *>(static_cast<const float *>(a.residual) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half);
-#pragma unroll
-                    for (int g8 = 0; g8 < 8; ++g8) rraw[g8] = rp[2 * g8];
-                }
-            }
+            if (chunk == c_end - 1 && head && wave_live && !SP_ABLATE(8)) fetch_residual();
             SP_STAMP(3);
             if (wave_live && !SP_ABLATE(4)) {
                 const uint4 *bq = reinterpret_cast<const uint4 *>(lds + 2 * G::W_BYTES + (L & 1) * G::B_BYTES) + bshift, *wq = reinterpret_cast<const uint4 *>(lds + (L & 1) * G::W_BYTES) + wlane;
@@ -372,6 +380,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
             SP_STAMP(4);
         }
         chunk0 = 0;                                                // every later segment of this range opens its tile
+        SP_STAMP_AT(5, L - 1);                                     // (epilogue stamps land in the record of the tile's last interval: 5 start, 6 residual in float, 7 stored)
         // the segment's sums, both accumulators joined: t = acc + 2^-10 accl
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -412,45 +421,65 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
                 rem -= range_start(jg + 1) - range_start(jg);
             }
         }
-        // ---- epilogue: y = (acc + 2^-10 accl) * 2^-k_c + (residual + bias), ReLU, stored as an SP map or as channels-last fp32
+        // ---- epilogue: y = (acc + 2^-10 accl) * 2^-k_c + (residual + bias), ReLU, stored as an SP map or as channels-last fp32.  It is VALU bound (two or
+        // three wavefronts per SIMD all arrive here together, the matrix pipe idles): ~700 vector instructions per wavefront in the first version = 8400 cycles
+        // per tile on the 12-wavefront geometries (profiles/round5/experiments/conv_sp_interval_timeline_stage1_stage2.txt, the "gap" of a tile's last interval).
+        // Hence: the residual is converted to float ONCE, outside the channel-group loop (no per-group branches on its kind), ReLU is one v_max against a floor,
+        // the range check one running maximum, the store address a running pointer, each group's bias / scale loads are issued one group ahead.
         const float4 *bias4 = reinterpret_cast<const float4 *>(a.bias + cur.cg * kCoutTile + 4 * half), *winv4 = reinterpret_cast<const float4 *>(a.wscale + cur.cg * kCoutTile + 4 * half);
-        bool big = false;
+        float rr[8][4];
+        if (a.res_kind == SP_RES_SP) {
 #pragma unroll
-        for (int g8 = 0; g8 < 8; ++g8) {                           // 8 groups of 4 consecutive channels per lane: channel = 8 g8 + 4 half + j
-            const float4 b4 = bias4[2 * g8], i4 = winv4[2 * g8];
-            const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
-            float r[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.res_kind == SP_RES_SP) {
+            for (int g8 = 0; g8 < 8; ++g8) {
                 const halfx4 h = __builtin_bit_cast(halfx4, uint2{rraw[g8].x, rraw[g8].y}), l = __builtin_bit_cast(halfx4, uint2{rraw[g8].z, rraw[g8].w});
 #pragma unroll
-                for (int j = 0; j < 4; ++j) r[j] = coalign::sp16_join(h[j], l[j]);
-            } else if (a.res_kind == SP_RES_NHWC) {
-                r[0] = __builtin_bit_cast(float, rraw[g8].x); r[1] = __builtin_bit_cast(float, rraw[g8].y);
-                r[2] = __builtin_bit_cast(float, rraw[g8].z); r[3] = __builtin_bit_cast(float, rraw[g8].w);
+                for (int j = 0; j < 4; ++j) rr[g8][j] = coalign::sp16_join(h[j], l[j]);
+            }
+        } else {                                                   // channels-last float32, or none (rraw is zero)
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) {
+                rr[g8][0] = __builtin_bit_cast(float, rraw[g8].x); rr[g8][1] = __builtin_bit_cast(float, rraw[g8].y);
+                rr[g8][2] = __builtin_bit_cast(float, rraw[g8].z); rr[g8][3] = __builtin_bit_cast(float, rraw[g8].w);
+            }
+        }
+        SP_STAMP_AT(6, L - 1);
+        const float floor_v = a.relu ? 0.f : -__builtin_inff();   // (a NaN leaves as the floor: v_max returns the other operand, as fmaxf(v, 0) always did under ReLU)
+        float vmax = 0.f;
+        // first store position of this lane: group 0 of the tile's 64 channels; every further 8-channel group lies 2 planes (SP) / 8 floats (channels-last) on
+        uint4 *ysp = static_cast<uint4 *>(a.y) + ((size_t)(on * CO16 + cur.cg * 4) * 4 + half) * HW + pix;
+        float4 *ycl = reinterpret_cast<float4 *>(static_cast<float *>(a.y) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half);
+        const size_t sp_step = 2 * (size_t)HW;
+        float4 b4 = bias4[0], i4 = winv4[0];
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) {                           // 8 groups of 4 consecutive channels per lane: channel = 8 g8 + 4 half + j
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
+            if (g8 + 1 < 8) {
+                b4 = bias4[2 * (g8 + 1)];
+                i4 = winv4[2 * (g8 + 1)];
             }
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int q = g8 / 4, e = 4 * (g8 % 4) + j;
-                v[j] = acc[q][e] * ii[j] + (r[j] + bb[j]);
-                if (a.relu) v[j] = fmaxf(v[j], 0.f);
+                v[j] = fmaxf(acc[q][e] * ii[j] + (rr[g8][j] + bb[j]), floor_v);
             }
             if constexpr (OUT == SP_OUT_NHWC) {
-                if (live && !SP_ABLATE(16)) *reinterpret_cast<float4 *>(static_cast<float *>(a.y) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half + 8 * g8) = float4{v[0], v[1], v[2], v[3]};
+                if (live && !SP_ABLATE(16)) ycl[2 * g8] = float4{v[0], v[1], v[2], v[3]};
             } else {
-                big = big || fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > 65504.f;
+                vmax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), vmax));
                 unsigned h01, l01, h23, l23;
                 coalign::sp16_split2(v[0], v[1], h01, l01);
                 coalign::sp16_split2(v[2], v[3], h23, l23);
                 swap32(h01, l01);          // lanes 0-31: h of channels 0,1 | 4,5 of the 8-channel group; lanes 32-63: l of the same channels
                 swap32(h23, l23);
-                const size_t idx = ((size_t)(on * CO16 + cur.cg * 4 + g8 / 2) * 4 + (g8 % 2) * 2 + half) * HW + pix;      // plane = 2 * channel half + term: lanes 32-63 hold term 1
-                if (live && !SP_ABLATE(16)) static_cast<uint4 *>(a.y)[idx] = uint4{h01, h23, l01, l23};
+                if (live && !SP_ABLATE(16)) *ysp = uint4{h01, h23, l01, l23};      // plane = 2 * channel half + term: lanes 32-63 hold term 1 (the `half` in ysp)
+                ysp += sp_step;
             }
         }
         if constexpr (OUT == SP_OUT_SP) {
-            if (a.range_flag && live && big) atomicOr(a.range_flag, 1);
+            if (a.range_flag && live && vmax > 65504.f) atomicOr(a.range_flag, 1);
         }
+        SP_STAMP_AT(7, L - 1);
         cur = next;
         plan = nplan;
         tile = ntile;

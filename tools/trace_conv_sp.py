@@ -77,7 +77,10 @@ for wg in (0, 1):
                 break
             nxt = int(t[wg, wv, c + 1, 0]) if c + 1 < 64 and int(t[wg, wv, c + 1, 0]) else int(s[4])
             d = [int(s[1] - s[0]), int(s[2] - s[1]), int(s[3] - s[2]), int(s[4] - s[3]), nxt - int(s[4])]
-            print(f"   {c:3d} " + " ".join(f"{v:7d}" for v in d) + f" | {nxt - int(s[0]):7d}")
+            epi = ""
+            if int(s[5]) and int(s[7]):      # a tile's last interval: the gap in parts (accumulator join + hand-over | residual wait + conversion | the 8 channel groups: scale, split, stores | to the next top)
+                epi = f"   epilogue: join {int(s[5] - s[4])} residual {int(s[6] - s[5])} groups {int(s[7] - s[6])} rest {nxt - int(s[7])}"
+            print(f"   {c:3d} " + " ".join(f"{v:7d}" for v in d) + f" | {nxt - int(s[0]):7d}" + epi)
 
 
 def timed(ablate):
