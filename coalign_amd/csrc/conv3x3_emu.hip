@@ -162,10 +162,10 @@ __device__ __forceinline__ void split_pixel(const float (&v)[8], bf16x8 (&out)[T
 // 3-7 % slower per layer on the tap-major geometries; computing the bf16 split ahead of the second barrier: no change; issuing the next
 // interval's weight DMA and halo loads in shares between the matrix steps instead of all at once after the barrier: no change -- the
 // interval timelines (tools/trace_conv_emu.py) show the burst already overlapped by the other wavefronts' matrix instructions.  All removed.)
-enum { VAR_TAPK = 1, VAR_ASM_DMA = 2, VAR_STACK = 4, VAR_NCO1 = 8, VAR_NBX4 = 16, VAR_F16 = 32 };
+enum { VAR_TAPK = 1, VAR_ASM_DMA = 2, VAR_STACK = 4, VAR_NCO1 = 8, VAR_NBX4 = 16, VAR_F16 = 32, VAR_QUAD = 64 };
 template <int BH, int BW, int NPB, int TERMS, int KCH, bool SPLIT, int STRIDE = 1, int LAYOUT = LAYOUT_NCHW, int PBUF = 2, int VAR = 0>
 __global__ __launch_bounds__(64 * ((NPB >= 4 && !(VAR & VAR_NCO1)) ? NPB : 2 * NPB))
-__attribute__((amdgpu_waves_per_eu(SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 1, SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 8)))
+__attribute__((amdgpu_waves_per_eu(SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : (VAR & 64) ? 4 : 1, SPLIT ? ((VAR & 1) ? (NPB + 3) / 4 : NPB == 12 ? 3 : 4) : 8)))
 void conv3x3_emu_kernel(const EmuArgs a) {
     constexpr bool TAPK = (VAR & VAR_TAPK) != 0, STACK = (VAR & VAR_STACK) != 0, F16 = (VAR & VAR_F16) != 0;
     constexpr bool DUAL = F16;          // sp16 operands (common.h): a second accumulator for the products that carry 2^10, per-channel weight scale
@@ -202,10 +202,23 @@ void conv3x3_emu_kernel(const EmuArgs a) {
 
     // Patch plan of a tile: thread t owns pixel slots t, t + THREADS, ... of the halo patch; per slot the offset of that pixel
     // inside an input plane, or -1 for the zero padding outside the image.  Computed once per tile.
+    // QUAD (round 5, the strided fp16 layers on channels-last / sparse input): a lane stages FOUR channels of a pixel (one float4) instead of eight or sixteen,
+    // slot = (pixel, channel quad), the quads of a pixel in neighbouring lanes.  The interval timelines of the strided layers (tools/trace_conv_emu.py STRIDE=2,
+    // profiles/round5/experiments/conv_strided_timeline.txt) showed 2400-3500 clocks of "issue" per interval against 2200 of matrix steps: with one pixel per lane
+    // every 16-byte load of a wavefront touches 64 different 256-byte pixel records -- the texture addresser takes them one cache line per cycle.  Two / four
+    // lanes per pixel are 32 / 16 lines per instruction for the same bytes.
+    // Together with ONE patch buffer (75 KB of LDS) and the registers capped at 128 (80 bytes of scratch outside the interval loop) TWO workgroups share a CU: the
+    // staging phases of one run under the matrix steps of the other.  Dense channels-last input 64.0 -> 54.3 us (5 x 64 -> 128 @ 100 x 352, same box); the
+    // SPARSE canvas loses (73 -> 81 us: most of its slots are empty cells, five slots per thread instead of three only add instructions) and keeps the
+    // pixel-per-lane staging with two patch buffers.
+    constexpr bool QUAD = (VAR & VAR_QUAD) != 0;
+    static_assert(!QUAD || (F16 && STRIDE == 2 && (LAYOUT & LAYOUT_IN_NHWC) != 0 && !TAPK), "quad staging: the strided fp16 layers on channels-last input");
+    constexpr int QN = 2 * KCH;                                                // channel quads per pixel and interval
+    constexpr int PSLOTS = QUAD ? (G::PIX * QN + G::THREADS - 1) / G::THREADS : G::SLOTS, PVW = QUAD ? 4 : 8 * KCH;
     struct Plan {
         const float *base;     // first input plane of the tile's image
         const uint4 *wsrc;     // this lane inside the tile's first weight chunk
-        int off[G::SLOTS];
+        int off[PSLOTS];
     };
     // STACK: t.y0 is a row of the stacked image (N * H rows).  n0 = its image, yl0 = its row inside that image, yb = H - yl0 = how many
     // of the tile's rows still belong to image n0 (yb >= TH: no image boundary inside the tile).  Patch rows with a boundary inside:
@@ -218,8 +231,8 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         pl.wsrc = a.wt + (size_t)t.cg * chunks * (G::WUNITS * G::WQ) + lane;
         const int yl0 = t.y0 - n0 * a.H, yb = a.H - yl0;
 #pragma unroll
-        for (int j = 0; j < G::SLOTS; ++j) {
-            const int i = tid + j * G::THREADS;
+        for (int j = 0; j < PSLOTS; ++j) {
+            const int i = QUAD ? (tid + j * G::THREADS) / QN : tid + j * G::THREADS;
             const int y = i / G::PW, xq = i - y * G::PW;
             const int gx = STRIDE * t.x0 - 1 + xq;
             if constexpr (STACK) {
@@ -245,8 +258,16 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     };
     // chunk c of the tile: the 8 input channels of this thread's pixel slots -> registers (plain coalesced loads: consecutive
     // lanes = consecutive pixels of a patch row; clamped address + zero select, no divergent branch around the loads)
-    auto load_patch = [&](const Plan &pl, int c, float (&v)[G::SLOTS][8 * KCH]) {
-        if constexpr ((LAYOUT & LAYOUT_IN_NHWC) != 0) {          // channels-last input: the 8 channels of a pixel are 32 contiguous bytes
+    auto load_patch = [&](const Plan &pl, int c, float (&v)[PSLOTS][PVW]) {
+        if constexpr (QUAD) {
+            const float *src = pl.base + (size_t)c * (kKC * KCH) + 4 * (tid & (QN - 1));      // (THREADS % QN == 0: a thread's quad is the same in every slot)
+#pragma unroll
+            for (int j = 0; j < PSLOTS; ++j) {
+                const int o = pl.off[j] < 0 ? 0 : pl.off[j];
+                const float4 t = *reinterpret_cast<const float4 *>(src + (size_t)o * a.Cin);
+                v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
+            }
+        } else if constexpr ((LAYOUT & LAYOUT_IN_NHWC) != 0) {          // channels-last input: the 8 channels of a pixel are 32 contiguous bytes
             const float *src = pl.base + (size_t)c * (kKC * KCH);
 #pragma unroll
             for (int j = 0; j < G::SLOTS; ++j) {
@@ -269,14 +290,14 @@ void conv3x3_emu_kernel(const EmuArgs a) {
         }
     };
     // ... split into bf16 terms and written as [term][pixel slot][8 cin] into split-patch buffer `slot`
-    auto split_patch = [&](const Plan &pl, float (&v)[G::SLOTS][8 * KCH], uint4 (&sp)[G::SLOTS][KCH][TERMS]) {
+    auto split_patch = [&](const Plan &pl, float (&v)[PSLOTS][PVW], uint4 (&sp)[G::SLOTS][KCH][TERMS]) {
 #pragma unroll
         for (int j = 0; j < G::SLOTS; ++j) {
 #pragma unroll
             for (int h = 0; h < KCH; ++h) {
                 float u[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) u[k] = pl.off[j] < 0 ? 0.f : v[j][8 * h + k];
+                for (int k = 0; k < 8; ++k) u[k] = pl.off[j] < 0 ? 0.f : v[j][QUAD ? 0 : 8 * h + k];      // (QUAD never comes here)
                 bf16x8 o[TERMS];
                 split_pixel<TERMS, F16>(u, o);
 #pragma unroll
@@ -297,10 +318,27 @@ void conv3x3_emu_kernel(const EmuArgs a) {
             }
         }
     };
-    auto store_patch = [&](const Plan &pl, int slot, float (&v)[G::SLOTS][8 * KCH]) {
-        uint4 sp[G::SLOTS][KCH][TERMS];
-        split_patch(pl, v, sp);
-        write_patch(slot, sp);
+    auto store_patch = [&](const Plan &pl, int slot, float (&v)[PSLOTS][PVW]) {
+        if constexpr (QUAD) {      // four channels -> 8 bytes of h and 8 bytes of l, each into its half of the 16-byte operand group [8-channel half][term][pixel]
+            uint2 *bt = reinterpret_cast<uint2 *>(lds + G::B_OFF + (PBUF == 2 ? slot : 0) * G::BSZ);
+            const int quad = tid & (QN - 1);
+#pragma unroll
+            for (int j = 0; j < PSLOTS; ++j) {
+                const int i = (tid + j * G::THREADS) / QN;
+                unsigned h01, l01, h23, l23;
+                coalign::sp16_split2(pl.off[j] < 0 ? 0.f : v[j][0], pl.off[j] < 0 ? 0.f : v[j][1], h01, l01);
+                coalign::sp16_split2(pl.off[j] < 0 ? 0.f : v[j][2], pl.off[j] < 0 ? 0.f : v[j][3], h23, l23);
+                if (i < G::PIX) {
+                    const int grp = ((quad >> 1) * TERMS) * G::PIX + i;
+                    bt[(size_t)grp * 2 + (quad & 1)] = uint2{h01, h23};
+                    bt[(size_t)(grp + G::PIX) * 2 + (quad & 1)] = uint2{l01, l23};
+                }
+            }
+        } else {
+            uint4 sp[G::SLOTS][KCH][TERMS];
+            split_patch(pl, v, sp);
+            write_patch(slot, sp);
+        }
     };
     // LDS-DMA of weight chunk c of the tile into weight buffer `slot` (scalar LDS addresses, every lane active)
     constexpr int WJ = (G::WUNITS * G::WINSTR + G::WAVES - 1) / G::WAVES;
@@ -364,7 +402,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
     int tile = global_step(0) / chunks;
     Tile cur = decode(tile);
     Plan plan = make_plan(cur);
-    float pv[G::SLOTS][8 * KCH];
+    float pv[PSLOTS][PVW];
     load_patch(plan, global_step(0) - tile * chunks, pv);
     issue_weights(plan, global_step(0) - tile * chunks, 0);
     store_patch(plan, 0, pv);
@@ -691,7 +729,10 @@ int dispatch_variant(const EmuArgs &a, int stride, int layout, hipStream_t s) {
         if (layout == LAYOUT_IN_NHWC) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_IN_NHWC, 2, VAR_F16>(a, s);
         if (layout == LAYOUT_NHWC) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_NHWC, 2, VAR_F16>(a, s);
         if (layout == LAYOUT_OUT_SP) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_OUT_SP, 2, VAR_F16>(a, s);
-        if (layout == (LAYOUT_IN_NHWC | LAYOUT_OUT_SP)) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_IN_NHWC | LAYOUT_OUT_SP, 2, VAR_F16>(a, s);
+        if (layout == (LAYOUT_IN_NHWC | LAYOUT_OUT_SP)) {       // the product's strided layers: dense input -> quad staging, one patch buffer, two workgroups per CU (see the kernel)
+            if (a.stamps) return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_IN_NHWC | LAYOUT_OUT_SP, 2, VAR_F16>(a, s);
+            return launch_variant<1, 32, 8, 2, 1, 2, LAYOUT_IN_NHWC | LAYOUT_OUT_SP, 1, VAR_F16 | VAR_QUAD>(a, s);
+        }
         return COALIGN_ERR_UNSUPPORTED;
     }
     if (stride == 2) {

@@ -9,7 +9,7 @@ library and prints, per barrier interval of workgroup 0 (first and last wavefron
   store  : fp32 -> bf16 split + LDS writes of the next interval's pixels
   gap    : from the end of this interval to the top of the next (tile epilogue + next tile's accumulator start, when a tile ends)
 Usage: python tools/trace_conv_emu.py [terms] [N Cin Cout H W] ; TAPK=1 selects the tap-major image (COALIGN_EMU_TAPK_ROWS / _VAR apply),
-RESIDUAL=1 adds a residual input."""
+RESIDUAL=1 adds a residual input, STRIDE=2 traces the strided layers (channels-last in, SplitMap out)."""
 import ctypes, os, subprocess, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,12 +26,18 @@ terms = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 N, Ci, Co, H, W = [int(v) for v in sys.argv[2:7]] if len(sys.argv) > 6 else (5, 64, 64, 100, 352)
 tapk = os.environ.get("TAPK", "0") == "1"
 layout = 4 if tapk else 0
+stride = int(os.environ.get("STRIDE", "1"))      # STRIDE=2: the first convolution of a stage as the product runs it (channels-last input, SplitMap output, terms 16)
+if stride == 2:
+    layout = 2 | 8
 L = ctypes.CDLL(lib)
 L.coalign_conv3x3_emu_ex.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 9 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
 L.coalign_conv3x3_emu_workspace_bytes_ex.restype = ctypes.c_size_t
 L.coalign_conv3x3_emu_workspace_bytes_ex.argtypes = [ctypes.c_int] * 7
-x = torch.randn(N, Ci, H, W, device="cuda"); w = torch.randn(Co, Ci, 3, 3, device="cuda") / (Ci * 9) ** 0.5
-b = torch.randn(Co, device="cuda"); y = torch.empty(N, Co, H, W, device="cuda")
+x = torch.randn(N, Ci, H, W, device="cuda")
+if stride == 2:
+    x = x.contiguous(memory_format=torch.channels_last)
+w = torch.randn(Co, Ci, 3, 3, device="cuda") / (Ci * 9) ** 0.5
+b = torch.randn(Co, device="cuda"); y = torch.empty(N, Co, (H + stride - 1) // stride, (W + stride - 1) // stride, device="cuda")
 res = torch.randn(N, Co, H, W, device="cuda") if os.environ.get("RESIDUAL", "0") == "1" else None
 ws = ops.pack_conv3x3_emu_weight(w, terms, tapk)
 waves, S = 16, 8
@@ -40,7 +46,7 @@ L.coalign_conv3x3_emu_set_trace(ctypes.c_void_p(tr.data_ptr()))
 scratch = torch.empty(max(1, L.coalign_conv3x3_emu_workspace_bytes_ex(N, Ci, Co, H, W, terms, layout)), dtype=torch.uint8, device="cuda")
 for _ in range(3):
     tr.zero_()
-    rc = L.coalign_conv3x3_emu_ex(x.data_ptr(), ws.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(), N, Ci, Co, H, W, 1, 1, terms, layout,
+    rc = L.coalign_conv3x3_emu_ex(x.data_ptr(), ws.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(), N, Ci, Co, H, W, stride, 1, terms, layout,
                                   scratch.data_ptr(), scratch.numel(), None)
     torch.cuda.synchronize()
 assert rc == 0, rc
@@ -68,7 +74,7 @@ else:
 L.coalign_conv3x3_emu_set_ablate.argtypes = [ctypes.c_int]
 L.coalign_conv3x3_emu_set_trace(None)
 def run():
-    return L.coalign_conv3x3_emu_ex(x.data_ptr(), ws.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(), N, Ci, Co, H, W, 1, 1, terms, layout,
+    return L.coalign_conv3x3_emu_ex(x.data_ptr(), ws.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(), N, Ci, Co, H, W, stride, 1, terms, layout,
                                     scratch.data_ptr(), scratch.numel(), None)
 tr.zero_()
 L.coalign_conv3x3_emu_set_trace(ctypes.c_void_p(tr.data_ptr()))
