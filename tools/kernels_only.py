@@ -123,6 +123,14 @@ def _x256sp():
         _x256s["x"] = ops.SplitMap.pack(torch.relu(_x256))
     return _x256s["x"]
 _x384 = torch.randn(1, 384, 100, 352, generator=g).to(dev)
+def _x384sp():
+    if "x384" not in _x256s:
+        _x256s["x384"] = ops.SplitMap.pack(torch.relu(_x384))
+    return _x256s["x384"]
+def _headmap():
+    if "heads" not in _x256s:
+        _x256s["heads"] = ops.SplitMap.empty(1, 384, 100, 352, dev)
+    return _x256s["heads"]
 _w384 = ops.pack_conv3x3_emu_weight(torch.randn(256, 384, 3, 3, generator=g).to(dev) / 59.0, 16, True)
 _w16_s2_128 = ops.pack_conv3x3_emu_weight(torch.randn(128, 64, 3, 3, generator=g).to(dev) / 24.0, 16, False)
 
@@ -132,6 +140,10 @@ OPS = {
     "conv_sp_256ch": lambda: ops.conv3x3_sp(_spx(2)[0], _w16_256, _b256, 256, _spx(2)[1], True, out_split=True),
     "conv_sp_256ch_nhwc_out": lambda: ops.conv3x3_sp(_spx(2)[0], _w16_256, _b256, 256, _spx(2)[1], True, out_split=False),
     "conv_sp_shrink2_256ch_100x352": lambda: ops.conv3x3_sp(_x256sp(), _w16_256, _b256, 256, None, True, out_split=False),
+    "conv_sp_shrink1_384ch_100x352": lambda: ops.conv3x3_sp(_x384sp(), _w384, _b256, 256, None, True, out_split=True),
+    "pointwise_up1_split_out": lambda: ops.pointwise_conv(xs[0][:1], _pw["up1"][1], _pw["up1"][2], 128, up=1, out=_headmap(), c_off=0),
+    "pointwise_up2_split_out": lambda: ops.pointwise_conv(xs[1][:1], _pw["up2"][1], _pw["up2"][2], 128, up=2, out=_headmap(), c_off=128),
+    "pointwise_up4_split_out": lambda: ops.pointwise_conv(xs[2][:1], wtp_emu, bconv.repeat(2), 128, up=4, out=_headmap(), c_off=256),
     "conv_fp16x2_shrink1_384ch_split_out": lambda: ops.conv3x3_emu_bias_act(_x384, _w384, _b256, 256, None, True, 16, out_split=True),
     "conv_fp16x2_s2_64to128_nhwc_in_split_out": lambda: ops.conv3x3_emu_bias_act(xcl[0], _w16_s2_128, _b128, 128, None, True, 16, stride=2, out_split=True),
     "conv_fp16x2_s2_sparse_canvas_split_out": lambda: ops.conv3x3_emu_sparse(_sc(), _w16_s2, bconv, 64, True, 16, out_channels_last=False, out_split=True),
