@@ -83,6 +83,17 @@ def plan(hypes: dict, terms: int = DEFAULT_TERMS) -> Dict[str, object]:
                 note(n, MIOPEN, True)
     # round 5: inside a ResNet stage and in the shrink header the fp16 mode hands SplitMaps from 3x3 layer to 3x3 layer (backbone.BasicBlock.takes_split_maps,
     # DoubleConv.forward): the stride-1 layers read them with coalign_conv3x3_sp, the layer in front of a chain writes the first one
+    backbone = getattr(model, "backbone", None)
+    heads_ok = backbone is not None and len(getattr(backbone, "deblocks", [])) > 0          # the up-sampling heads are on the pointwise kernel (rule of _pointwise_ok)
+    if heads_ok:
+        for i in range(backbone.num_levels):
+            op = backbone.deblocks[i][0]
+            heads_ok = heads_ok and isinstance(op, nn.ConvTranspose2d) and op.kernel_size == op.stride and op.stride[0] == op.stride[1] and op.stride[0] in (1, 2, 4)
+            heads_ok = heads_ok and op.in_channels <= 256 and op.in_channels % 2 == 0 and (op.out_channels * op.stride[0] ** 2) % 32 == 0
+    # second half of round 5: the heads write the concatenated map as ONE SplitMap when the shrink header's first DoubleConv takes it (detector.fuse_and_head)
+    first_shrink = getattr(model, "shrink_conv", None)
+    first_shrink = first_shrink.layers[0] if getattr(model, "shrink_flag", False) and first_shrink is not None and len(first_shrink.layers) else None
+    heads_split = False
     if terms == 16 and bb.SPLIT_MAPS and bb.NHWC_STAGE_OUTPUTS and bb.CONV_EMU_TAP_MAJOR and bb.POINTWISE_EMU:
         for n, m in model.named_modules():
             if isinstance(m, bb.BasicBlock):
@@ -94,18 +105,16 @@ def plan(hypes: dict, terms: int = DEFAULT_TERMS) -> Dict[str, object]:
                 c1, c2 = m.double_conv[0], m.double_conv[2]
                 ok = all(tuple(c.kernel_size) == (3, 3) and c.stride == (1, 1) and c.out_channels % 64 == 0 and c.in_channels % 16 == 0 for c in (c1, c2))
                 if ok and f"{n}.double_conv.0" in layers:
-                    layers[f"{n}.double_conv.0"] += ", SplitMap out"
+                    from_heads = (m is first_shrink and bb.HEAD_SPLIT_MAPS and heads_ok and len(backbone.deblocks) == backbone.num_levels
+                                  and all(backbone.deblocks[i][0].in_channels % 16 == 0 and backbone.deblocks[i][0].out_channels % 16 == 0 for i in range(backbone.num_levels)))
+                    heads_split = heads_split or from_heads
+                    layers[f"{n}.double_conv.0"] = SP if from_heads else layers[f"{n}.double_conv.0"] + ", SplitMap out"
                     layers[f"{n}.double_conv.2"] = SP
-    backbone = getattr(model, "backbone", None)
     if backbone is not None and len(getattr(backbone, "deblocks", [])):
-        ok = True
-        for i in range(backbone.num_levels):
-            op = backbone.deblocks[i][0]
-            ok = ok and isinstance(op, nn.ConvTranspose2d) and op.kernel_size == op.stride and op.stride[0] == op.stride[1] and op.stride[0] in (1, 2, 4)
-            ok = ok and op.in_channels <= 256 and op.in_channels % 2 == 0 and (op.out_channels * op.stride[0] ** 2) % 32 == 0
+        ok = heads_ok
         for i in range(len(backbone.deblocks)):
-            note(f"backbone.deblocks.{i}", _pointwise_route(backbone.deblocks[i][0].in_channels, terms) + ", writes its slice of the concatenation" if ok and i < backbone.num_levels else MIOPEN + " + bias_act",
-                 not (ok and i < backbone.num_levels))
+            note(f"backbone.deblocks.{i}", _pointwise_route(backbone.deblocks[i][0].in_channels, terms) + (", writes its slice of the concatenated SplitMap" if heads_split else ", writes its slice of the concatenation")
+                 if ok and i < backbone.num_levels else MIOPEN + " + bias_act", not (ok and i < backbone.num_levels))
     vfe = getattr(model, "pillar_vfe", None)
     pillar = None
     if vfe is not None:
