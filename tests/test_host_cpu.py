@@ -66,6 +66,14 @@ def test_pose_algebra_matches_reference(golden):
     np.testing.assert_allclose(pose.normalize_pairwise_tfm(pt, 32, 64, 0.4).numpy(), g["normalized_32x64"], rtol=0, atol=1e-15)
     assert torch.equal(pt, before) and pose.normalize_pairwise_tfm(pt, 32, 64, 0.4).dtype == torch.float64
     assert np.array_equal(pose.get_pairwise_transformation(g["poses"], 5, proj_first=True), np.tile(np.eye(4), (5, 5, 1, 1)))
+    # the host-side form FramePipeline stages with its frame record (numpy, written into a pinned view): the torch route's bits, golden included, batch > 1 too
+    for H, W, key in ((200, 704, "normalized_200x704"), (32, 64, "normalized_32x64")):
+        assert np.array_equal(pose.normalize_pairwise_np(g["pairwise"][None], H, W, 0.4), pose.normalize_pairwise_tfm(pt, H, W, 0.4).numpy())
+        np.testing.assert_allclose(pose.normalize_pairwise_np(g["pairwise"][None], H, W, 0.4), g[key], rtol=0, atol=1e-15)
+    rq = np.random.RandomState(5)
+    many = np.stack([pose.get_pairwise_transformation([[rq.randn() * 40, rq.randn() * 15, rq.randn(), rq.randn() * 3, rq.randn() * 90, rq.randn() * 3] for _ in range(4)], 5) for _ in range(3)])
+    out = np.full(many.shape[:-2] + (2, 3), np.nan)
+    assert pose.normalize_pairwise_np(many, 100, 252, 0.4, out=out) is out and np.array_equal(out, pose.normalize_pairwise_tfm(T(many), 100, 252, 0.4).numpy())
     rs = np.random.RandomState(303)
     n = pose.generate_noise(0.2, 0.2, rng=rs)
     rs2 = np.random.RandomState(303)
