@@ -13,7 +13,11 @@ FRAMES, POOL, LANES = int(os.environ.get("FRAMES", 3000)), 8, int(os.environ.get
 h = builtin_config("opv2v_coalign")
 frames = []
 for i in range(POOL):
-    d = to_device(make_frame(h, 5, pillars_per_agent=8000, seed=303 + i, noise=(0.2, 0.2)), dev); d["record_len"] = [5]; frames.append(d)
+    c = make_frame(h, 5, pillars_per_agent=8000, seed=303 + i, noise=(0.2, 0.2))
+    d = to_device(c, dev); d["record_len"] = [5]
+    if os.environ.get("HOST_POSES", "1") == "1":      # the bench's form: the dataset's host copy of the pose matrices travels with the batch (frame record + host-normalised poses)
+        d["pairwise_t_matrix_host"] = c["pairwise_t_matrix"]
+    frames.append(d)
 model = build_model(h); fill_parameters_(model, seed=0); model = model.to(dev).eval()
 pp = build_postprocessor(h["postprocess"], False)
 calibrate_heads_(model, frames[0], 0.2, 600)
@@ -36,5 +40,6 @@ for i in range(FRAMES):
     check(pipe.submit(frames[i % POOL]))
 check(pipe.drain())
 torch.cuda.synchronize()
-print(f"soak: {n} frames in {time.time() - t0:.1f} s, lanes {LANES}, COALIGN_EMU_STACK={os.environ.get('COALIGN_EMU_STACK', 'default')}: {len(bad)} frames differ from the synchronous path {bad[:10]}")
+print(f"soak: {n} frames in {time.time() - t0:.1f} s, lanes {LANES}, frames read in place {pipe.frames_in_place}, copied {pipe.frames_copied}, graphs captured {pipe.graphs_captured}, "
+      f"split-map range exceeded {pipe.range_exceeded()}: {len(bad)} frames differ from the synchronous path {bad[:10]}")
 pipe.close()
