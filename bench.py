@@ -211,7 +211,7 @@ def conv_layer_rooflines(dev, N, ny, nx, pmc):
     return rows
 
 
-def size_sweep(dev, steps=20, streams=None):
+def size_sweep(dev, steps=20, streams=None, lanes=3, result_lag=1, queue_depth=1):
     """VERDICT r03 item 3 / SURVEY 8d: the HBM-bound ops where the roofline bites.  Pillar op at M in {8000, 32000, 70000} pillars per agent
     (max_voxel_train / max_voxel_test of pointpillar_coalign.yaml:52-54) x 5 agents, at N = 2 (cfg 2) and at DAIR-V2X geometry 504 x 200 (cfg 4);
     the fusion launch per geometry / agent count; whole-path frames/s for cfg 2 and cfg 4.  Times: HIP events around graph replays of the op's
@@ -259,7 +259,7 @@ def size_sweep(dev, steps=20, streams=None):
                 import copy
                 mc = copy.deepcopy(mdl)
                 calibrate_heads_(mc, pool[0], pp.params["target_args"]["score_threshold"], 600)
-                pipe = FramePipeline(mc, pp, anchors, lanes=3, result_lag=1, graph=True, device=dev, streams=streams if streams is not None and len(streams) >= 3 else None)
+                pipe = FramePipeline(mc, pp, anchors, lanes=lanes, queue_depth=queue_depth, result_lag=result_lag, graph=True, device=dev, streams=streams if streams is not None and len(streams) >= lanes else None)
                 for i in range(8):
                     pipe.submit(pool[i % 4])
                 pipe.drain(); torch.cuda.synchronize()
@@ -269,7 +269,7 @@ def size_sweep(dev, steps=20, streams=None):
                     res += pipe.submit(pool[i % 4])
                 res += pipe.drain(); torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
-                row["whole_path"] = {"frames_per_s": round(steps / dt, 2), "ms_per_frame": round(dt / steps * 1e3, 4), "frames_in_flight": 3, "hip_graph": True,
+                row["whole_path"] = {"frames_per_s": round(steps / dt, 2), "ms_per_frame": round(dt / steps * 1e3, 4), "frames_in_flight": lanes * queue_depth, "hip_graph": True,
                                      "detections_last_frame": 0 if res[-1][1] is None else int(res[-1][1].shape[0])}
                 pipe.close()
                 del mc, pipe
@@ -292,7 +292,8 @@ def main():
     ap.add_argument("--config", default="opv2v_coalign")
     ap.add_argument("--lanes", type=int, default=0, help="frames in flight on separate HIP streams (0 = 3 with HIP-graph replays, 4 with eager launches: "
                     "measured 288 / 288 / 282 / 267 frames/s for 2 / 3 / 4 / 6 lanes with graphs, 255 / 255-272 for 2 / 4 lanes eager)")
-    ap.add_argument("--result-lag", type=int, default=1, help="frames between enqueueing a frame and collecting its detections on the host")
+    ap.add_argument("--result-lag", type=int, default=-1, help="frames between enqueueing a frame and collecting its detections on the host (-1: 1, or lanes x depth - 1 with a queue depth > 1: the host waits for the OLDEST queued frame only)")
+    ap.add_argument("--queue-depth", type=int, default=0, help="frames queued per lane stream: lanes x depth pipeline lanes share `lanes` HIP streams -- a stream's next frames are enqueued before its current one has finished, so no stream waits for the host between frames (0: 3 for the single-GPU graph pipeline, else 1)")
     ap.add_argument("--no-miopen-find", action="store_true", help="leave torch.backends.cudnn.benchmark off (MIOpen immediate mode)")
     ap.add_argument("--no-graph", action="store_true", help="~150 eager launches per frame (1.5 ms of host time) instead of one HIP graph replay per frame "
                     "(0.1 ms; single-GPU default: measured +1 ... +4 % frames/s on the channels-last route; multi-rank runs are always eager)")
@@ -398,7 +399,11 @@ def main():
                 p.data.copy_(buf)
 
     use_graph = not args.no_graph          # (multi-rank: two graphs per lane and frame around the collective, coalign_amd/pipeline.py)
-    n_lanes = args.lanes if args.lanes > 0 else (3 if use_graph else 4)
+    # Single GPU, HIP graphs (the headline configuration, second half of round 5): TWO streams, THREE frames queued on each.  Two frames running side by side is what the
+    # GPU takes (3 / 4 concurrent frames measure -0 / -7 %); what the earlier "3 lanes, result lag 1" left on the table was the host round trip between a stream's frames
+    # (collect, stage, launch: 0.15-0.2 ms during which the other frame ran alone).  Same box, 300 steps: 639-642 -> 650-659 frames/s; 20 steps: 597-600 -> 622-628.
+    n_lanes = args.lanes if args.lanes > 0 else ((2 if world == 1 else 3) if use_graph else 4)
+    queue_depth = args.queue_depth if args.queue_depth > 0 else (3 if use_graph and world == 1 else 1)
     rings = None
     exchanges = None
     mode = args.mode
@@ -469,10 +474,15 @@ def main():
     torch.backends.cudnn.benchmark = not args.no_miopen_find     # MIOpen find during warm-up for whatever still runs on it
 
     # every pipeline of this process runs on the SAME lane streams (FramePipeline(streams=...)): streams share a handful of hardware queues
-    lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
+    n_streams = n_lanes
+    if world > 1:
+        queue_depth = 1                                          # (multi-rank lanes own an exchange each: one frame per stream there)
+    n_lanes = n_streams * queue_depth                            # pipeline lanes = frames queued or running; lane i runs on stream i mod n_streams (FramePipeline(queue_depth=...))
+    result_lag = args.result_lag if args.result_lag >= 0 else (n_lanes - 1 if queue_depth > 1 else 1)
+    lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
 
     def make_pipe(graph):
-        return FramePipeline(model, pp, anchors, lanes=n_lanes, result_lag=args.result_lag, graph=graph, device=dev,
+        return FramePipeline(model, pp, anchors, lanes=n_streams, queue_depth=queue_depth, result_lag=result_lag, graph=graph, device=dev,
                              exchange=exchanges, streams=lane_streams)
 
     def sync():
@@ -667,7 +677,7 @@ def main():
     #      serial loop, opencood/tools/inference.py:125-179) -- what a 10 Hz LiDAR consumer sees
     latency = None
     if world == 1 and not args.no_latency:
-        latency = {"default_pipeline": dict(latency_stats(lat_default), frames_in_flight=n_lanes, result_lag_frames=pipe.result_lag)}
+        latency = {"default_pipeline": dict(latency_stats(lat_default), frames_in_flight=n_lanes, streams=n_streams, frames_queued_per_stream=n_lanes // n_streams, result_lag_frames=pipe.result_lag)}
         try:
             p1 = FramePipeline(model, pp, anchors, lanes=1, result_lag=0, graph=use_graph, device=dev, streams=lane_streams)
             d1, _, _ = timed_run(p1, args.steps, max(4, args.warmup))
@@ -697,7 +707,7 @@ def main():
             del pv
             slot = 1 << (max(max(len(c) for c in f["clouds"]) for f in pframes) - 1).bit_length()
             pp_p = build_postprocessor(hypes["postprocess"], False)
-            fp = FramePipeline(model_p, pp_p, anchors, lanes=n_lanes, result_lag=args.result_lag, graph=use_graph, device=dev, preprocessor=pre,
+            fp = FramePipeline(model_p, pp_p, anchors, lanes=n_streams, queue_depth=queue_depth, result_lag=result_lag, graph=use_graph, device=dev, preprocessor=pre,
                                points_per_cloud=slot, streams=lane_streams)
             dp, tip, rp = timed_run(fp, args.steps, warm, batches=pframes, points=True)
             from_points = {"value": round(args.steps / dp, 3), "unit": "frames/s", "ms_per_step": round(dp / args.steps * 1e3, 4),
@@ -899,7 +909,7 @@ def main():
             "config": {"workload": f"OPV2V PointPillar + CoAlign multiscale attention fusion ({args.config}.yaml, BASELINE configs[2] "
                                    f"geometry): {N} agents/frame, {args.pillars} pillars/agent, canvas {nx}x{ny}, 70400 anchors, "
                                    f"full path incl. decode + rotated NMS, {pool_n} distinct frames in rotation",
-                       "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": frames_per_step, "frames_in_flight": n_lanes,
+                       "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": frames_per_step, "frames_in_flight": n_lanes, "streams": n_streams, "frames_queued_per_stream": n_lanes // n_streams,
                        "result_lag_frames": pipe.result_lag, "hip_graph": use_graph,
                        "inputs": ("resident in HBM, read in place through a 32-byte device record; pose matrices normalised on the host; one small host-to-device transfer per frame"
                                   if pipe.frames_in_place and not pipe.frames_copied else "resident in HBM, copied into the captured graph's input buffers every frame" if use_graph else "resident in HBM"), "conv_arithmetic": "native fp32" if default_terms == 0 else ("fp16 split (sp16 pairs)" + (", SplitMaps between the 3x3 layers" if backbone_mod.split_maps_active() else "")) if default_terms == 16 else f"bf16x{default_terms}",
@@ -929,7 +939,7 @@ def main():
             pipe.close()
             del pipe
             torch.cuda.empty_cache()
-            result["size_sweep"] = size_sweep(dev, streams=lane_streams)
+            result["size_sweep"] = size_sweep(dev, streams=lane_streams, lanes=n_streams if use_graph else 3, result_lag=result_lag if use_graph else 1, queue_depth=queue_depth if use_graph else 1)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(hypes, model, frames_cpu, anchors, args.cpu_frames, args.cpu_threads, args.cpu_budget_s)
         print(json.dumps(result), flush=True)

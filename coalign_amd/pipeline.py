@@ -103,7 +103,7 @@ class FramePipeline:
                  graph: bool = False, device=None, transformation_matrix: Optional[torch.Tensor] = None,
                  exchange: Optional[Sequence[Callable]] = None, preprocessor=None, points_per_cloud: int = 131072,
                  ego_filter: bool = True, filter_range: Optional[Sequence[float]] = None, pillar_buckets: bool = True,
-                 streams: Optional[Sequence[torch.cuda.Stream]] = None):
+                 streams: Optional[Sequence[torch.cuda.Stream]] = None, queue_depth: int = 1):
         self.model = model
         self.pillar_buckets = bool(pillar_buckets)               # ragged from-pillars frames share a capacity-sized graph (see _bucket_seen below)
         self._sig_tensors: Optional[list] = None                 # cached parameter / buffer list of _weights_signature
@@ -122,7 +122,12 @@ class FramePipeline:
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
         if self.device.type != "cuda":
             raise ops.hip.CoalignHipError("FramePipeline runs on the MI355X only (the hot path has no CPU implementation)")
-        self.n_lanes = max(1, int(lanes))
+        # ``queue_depth`` (round 5): frames QUEUED per HIP stream.  ``lanes`` streams x ``queue_depth`` pipeline lanes: lane i runs on stream i mod lanes with graphs and
+        # result buffers of its own, so a stream's next frames are enqueued while its current one still runs -- the stream never waits for the host between frames
+        # (collect, stage, launch: 0.15-0.2 ms per frame otherwise).  With ``result_lag = lanes * queue_depth - 1`` the host only ever waits for the oldest frame.
+        self.n_streams = max(1, int(lanes))
+        self.queue_depth = max(1, int(queue_depth))
+        self.n_lanes = self.n_streams * self.queue_depth
         self.graph = bool(graph)
         if exchange is not None and len(exchange) != self.n_lanes:
             raise ValueError("one exchange callable per lane")
@@ -137,12 +142,13 @@ class FramePipeline:
         # hardware queues (four by default), and lanes of a new pipeline that land on a queue an older pipeline's idle stream still owns, or on each
         # other's, serialise (measured: the same from-points loop 441 vs 493 frames/s depending on how many streams earlier sections had left behind).
         if streams is not None:
-            if len(streams) < self.n_lanes:
-                raise ValueError(f"{self.n_lanes} lanes need {self.n_lanes} streams, got {len(streams)}")
-            self.streams = list(streams[: self.n_lanes])
+            if len(streams) < self.n_streams:
+                raise ValueError(f"{self.n_streams} lane streams needed, got {len(streams)}")
+            base = list(streams[: self.n_streams])
         else:
             with torch.cuda.device(self.device):
-                self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_lanes)]
+                base = [torch.cuda.Stream(device=self.device) for _ in range(self.n_streams)]
+        self.streams = [base[i % self.n_streams] for i in range(self.n_lanes)]
         with torch.cuda.device(self.device):
             ops.sp_range_flag(self.device)                        # the SplitMap range word exists before any graph is captured (its pointer is baked into the capture)
         # (only now, with every argument validated, is the model touched)

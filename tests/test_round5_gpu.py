@@ -554,3 +554,30 @@ def test_shrink_header_on_split_maps_from_the_heads_equals_float_route():
         torch.cuda.synchronize()
     scale = float(y_old.abs().max())
     assert scale > 0 and float((y_new - y_old).abs().max()) <= 2e-6 * scale
+
+
+def test_pipeline_queue_depth_equals_synchronous_path_bit_for_bit():
+    """FramePipeline(lanes=2, queue_depth=3): six pipeline lanes on two HIP streams (a stream's next frames are enqueued while its current one runs; the host only waits for
+    the oldest frame) return the synchronous path's detections bit for bit, in order, for equal and ragged pillar counts, with every result-lag setting, and through the
+    bench's phases (submit bursts separated by drains from an idle GPU)."""
+    from coalign_amd import pipeline as pl_mod
+    model, pp, anchors, frames = _pipeline_world()
+    meta = {"ego": {"transformation_matrix": torch.eye(4, device=DEV), "anchor_box": anchors}}
+    with torch.no_grad():
+        want = [pp.post_process(meta, {"ego": model(f)}) for f in frames]
+    torch.cuda.synchronize()
+    for lag in (5, 2, 0):
+        pipe = pl_mod.FramePipeline(model, pp, anchors, lanes=2, queue_depth=3, result_lag=lag, graph=True)
+        assert pipe.n_lanes == 6 and pipe.n_streams == 2 and len({s.cuda_stream for s in pipe.streams}) == 2 and pipe.streams[0] is pipe.streams[2] is pipe.streams[4]
+        order, got = [], []
+        for phase in ([0, 1, 2, 3, 4, 5], [i % 6 for i in range(13)], [5, 4, 3, 2, 1, 0, 0, 1, 2]):
+            for i in phase:
+                got += pipe.submit(frames[i])
+            got += pipe.drain()
+            torch.cuda.synchronize()
+            order += phase
+        assert [idx for idx, _, _ in got] == list(range(len(order)))
+        for i, (_, b, s) in zip(order, got):
+            assert torch.equal(b, want[i][0]) and torch.equal(s, want[i][1]), f"frame {i}, result lag {lag}"
+        assert pipe.frames_in_place == len(order)
+        pipe.close()
