@@ -482,6 +482,10 @@ def main():
     lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
 
     def make_pipe(graph):
+        if not graph and use_graph and world == 1:               # the eager side mode / profile pass of a graph run: host-bound launches want one frame per stream (rounds 3-4's form)
+            while len(lane_streams) < 3:
+                lane_streams.append(torch.cuda.Stream(device=dev))
+            return FramePipeline(model, pp, anchors, lanes=3, result_lag=1, graph=False, device=dev, streams=lane_streams)
         return FramePipeline(model, pp, anchors, lanes=n_streams, queue_depth=queue_depth, result_lag=result_lag, graph=graph, device=dev,
                              exchange=exchanges, streams=lane_streams)
 
@@ -707,11 +711,17 @@ def main():
             del pv
             slot = 1 << (max(max(len(c) for c in f["clouds"]) for f in pframes) - 1).bit_length()
             pp_p = build_postprocessor(hypes["postprocess"], False)
-            fp = FramePipeline(model_p, pp_p, anchors, lanes=n_streams, queue_depth=queue_depth, result_lag=result_lag, graph=use_graph, device=dev, preprocessor=pre,
+            # (the feeder path moves 10.5 MB host -> device per frame on the frame's own stream: a third stream lets that copy run beside two computing frames;
+            #  COALIGN_BENCH_FP="streams,depth,lag" overrides for measurements)
+            fps_, fpd_, fpl_ = [int(v) for v in os.environ.get("COALIGN_BENCH_FP", "3,2,3" if use_graph and world == 1 and args.lanes <= 0 and args.queue_depth <= 0 else f"{n_streams},{queue_depth},{result_lag}").split(",")]
+            while len(lane_streams) < fps_:
+                lane_streams.append(torch.cuda.Stream(device=dev))
+            fp = FramePipeline(model_p, pp_p, anchors, lanes=fps_, queue_depth=fpd_, result_lag=fpl_, graph=use_graph, device=dev, preprocessor=pre,
                                points_per_cloud=slot, streams=lane_streams)
             dp, tip, rp = timed_run(fp, args.steps, warm, batches=pframes, points=True)
             from_points = {"value": round(args.steps / dp, 3), "unit": "frames/s", "ms_per_step": round(dp / args.steps * 1e3, 4),
                            "host_enqueue_ms_per_step": round(tip / args.steps * 1e3, 4), "latency_ms": latency_stats(fp.latencies_ms),
+                           "streams": fps_, "frames_queued_per_stream": fpd_, "result_lag_frames": fpl_,
                            "points_per_frame": n_pts[0], "pillars_frame0": m_pillars, "h2d_bytes_per_frame": N * slot * 16,
                            "detections_last_frame": 0 if not rp or rp[-1][1] is None else int(rp[-1][1].shape[0]),
                            "input": f"{N} raw 64-beam sweeps per frame (coalign_amd.synthetic.make_point_cloud) in pinned host memory, "
