@@ -6,6 +6,9 @@ strictly one frame after the other on the default stream, with a device->host sy
 ``lanes`` of them in flight, each on its own HIP stream ("lane"): the partial last wave of every convolution launch
 and the small latency-bound fusion / head / decode / NMS kernels of one frame overlap the other frames' work.
 Results come back in submission order, ``result_lag`` frames late (the host waits for the OLDEST frame only).
+``queue_depth`` (round 5) queues that many frames per stream -- ``lanes x queue_depth`` pipeline lanes, lane i on stream
+i mod lanes, each with graphs and result buffers of its own --, so a stream's next frame is already enqueued when its
+current one finishes: the throughput configuration is ``lanes=2, queue_depth=3, result_lag=5`` (bench.py).
 
 Two launch modes:
 

@@ -26,7 +26,8 @@ meta = {"ego": {"transformation_matrix": torch.eye(4, device=dev), "anchor_box":
 with torch.no_grad():
     sync = [pp.post_process(meta, {"ego": model(f)}) for f in frames]
     sync = [(b.clone(), s.clone()) for b, s in sync]
-pipe = FramePipeline(model, pp, anchors, lanes=LANES, result_lag=1, graph=os.environ.get("GRAPH", "1") == "1")
+DEPTH = int(os.environ.get("DEPTH", 1))             # LANES=2 DEPTH=3: the bench's throughput configuration (frames queued per stream)
+pipe = FramePipeline(model, pp, anchors, lanes=LANES, queue_depth=DEPTH, result_lag=LANES * DEPTH - 1 if DEPTH > 1 else 1, graph=os.environ.get("GRAPH", "1") == "1")
 bad, n = [], 0
 t0 = time.time()
 def check(results):
@@ -40,6 +41,6 @@ for i in range(FRAMES):
     check(pipe.submit(frames[i % POOL]))
 check(pipe.drain())
 torch.cuda.synchronize()
-print(f"soak: {n} frames in {time.time() - t0:.1f} s, lanes {LANES}, frames read in place {pipe.frames_in_place}, copied {pipe.frames_copied}, graphs captured {pipe.graphs_captured}, "
+print(f"soak: {n} frames in {time.time() - t0:.1f} s, streams {LANES} x {DEPTH} queued, frames read in place {pipe.frames_in_place}, copied {pipe.frames_copied}, graphs captured {pipe.graphs_captured}, "
       f"split-map range exceeded {pipe.range_exceeded()}: {len(bad)} frames differ from the synchronous path {bad[:10]}")
 pipe.close()
