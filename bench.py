@@ -9,8 +9,8 @@ Metric (BASELINE.json): frames/s on synthetic 5-agent OPV2V-shaped scenes.  A st
 path (pillar encode + scatter -> BEV backbone -> pose-aware warp + attention fusion at 3 scales -> heads ->
 decode + rotated NMS) over one frame per rank; inputs are resident in HBM before the timed region and the timed loop
 ROTATES over a pool of distinct frames.  The loop is ``coalign_amd.pipeline.FramePipeline`` -- the product's frame runner
-(3 frames in flight on separate HIP streams, one HIP graph replay per frame; with R > 1 ranks two replays -- encoder, ego tail -- around the lane's
-collective), the same object the parity tests drive.  ``python bench.py --gpus N`` without a launcher starts its N ranks itself (torch.distributed.run,
+(single GPU: two HIP streams with three frames queued on each, one HIP graph replay per frame; with R > 1 ranks three streams, one frame each, two replays --
+encoder, ego tail -- around the lane's collective), the same object the parity tests drive.  ``python bench.py --gpus N`` without a launcher starts its N ranks itself (torch.distributed.run,
 127.0.0.1) and refuses to run when fewer than N devices are visible.  With R ranks a step
 processes R frames in the agent-sharded "frame ring" of coalign_amd/sharded.py (weak scaling): every rank encodes the
 agents the ring assigns to it out of the SAME frame pool, so the per-frame detection checksums printed here are equal
@@ -290,8 +290,8 @@ def main():
     ap.add_argument("--agents", type=int, default=5)
     ap.add_argument("--pillars", type=int, default=8000)
     ap.add_argument("--config", default="opv2v_coalign")
-    ap.add_argument("--lanes", type=int, default=0, help="frames in flight on separate HIP streams (0 = 3 with HIP-graph replays, 4 with eager launches: "
-                    "measured 288 / 288 / 282 / 267 frames/s for 2 / 3 / 4 / 6 lanes with graphs, 255 / 255-272 for 2 / 4 lanes eager)")
+    ap.add_argument("--lanes", type=int, default=0, help="HIP streams that carry frames (0 = 2 for the single-GPU graph pipeline, 3 for multi-rank graph runs, 4 with eager launches; "
+                    "final code, 300 steps: 2 x 3 queued 650-659, 3 x 2 queued 649, 3 x 1 (lag 2) 646-648, 3 x 1 (lag 1) 639-642, 4 x 1 (lag 3) 593 frames/s)")
     ap.add_argument("--result-lag", type=int, default=-1, help="frames between enqueueing a frame and collecting its detections on the host (-1: 1, or lanes x depth - 1 with a queue depth > 1: the host waits for the OLDEST queued frame only)")
     ap.add_argument("--queue-depth", type=int, default=0, help="frames queued per lane stream: lanes x depth pipeline lanes share `lanes` HIP streams -- a stream's next frames are enqueued before its current one has finished, so no stream waits for the host between frames (0: 3 for the single-GPU graph pipeline, else 1)")
     ap.add_argument("--no-miopen-find", action="store_true", help="leave torch.backends.cudnn.benchmark off (MIOpen immediate mode)")
