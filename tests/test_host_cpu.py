@@ -42,6 +42,19 @@ def test_argument_validation_without_a_gpu():
     assert lib.coalign_nms_rotated(null, 8, 3, null, null, 5, null, 0.15, 5000, null, null, null, 0, null) == -3     # top > 4096
     assert lib.coalign_pillar_scatter_workspace_bytes(5, 200, 704) >= 5 * 200 * 704 * 4
     assert lib.coalign_nms_rotated_workspace_bytes(1000, 1000) >= 1000 * 16 * 8
+    # round 5's entry points: the frame-record pillar launch, the SplitMap convolution, the up-sampling heads' SplitMap epilogue
+    d3 = (ctypes.c_double * 3)(0.4, 0.4, 4.0)
+    one = ctypes.c_void_p(16)                                # (a non-NULL, 16-byte aligned token: none of these calls gets as far as touching memory)
+    assert lib.coalign_pillar_encode_sparse_frame(null, 100, 32, one, 64, 1, d3, d3, 2, 200, 704, one, one, one, null) == -1          # no frame record
+    assert lib.coalign_pillar_encode_sparse_frame(one, 100, 33, one, 64, 1, d3, d3, 2, 200, 704, one, one, one, null) == -2           # P > 32
+    assert lib.coalign_pillar_encode_sparse_frame(ctypes.c_void_p(20), 100, 32, one, 64, 1, d3, d3, 2, 200, 704, one, one, one, null) == -2      # record not 8-byte aligned
+    assert lib.coalign_conv3x3_sp(null, one, one, null, 0, one, 1, 1, 64, 64, 8, 8, 1, 0, null, null, 0, null) == -1                    # no input map
+    assert lib.coalign_conv3x3_sp(one, one, one, null, 0, one, 1, 1, 24, 64, 8, 8, 1, 0, null, null, 0, null) == -3                     # Cin % 16: unsupported
+    assert lib.coalign_conv3x3_sp(one, one, one, null, 0, one, 3, 1, 64, 64, 8, 8, 1, 0, null, null, 0, null) == -3                     # unknown output kind
+    assert lib.coalign_sp_map_bytes(5, 256, 25, 88) == 5 * 256 * 25 * 88 * 4 and lib.coalign_sp_map_bytes(5, 24, 25, 88) == 0
+    assert lib.coalign_pointwise_conv_emu_sp(one, one, one, one, 1, 64, 8, 8, 1, 120, 1, 128, 384, 0, 1, 1, null, null) == -3          # Cout % 16
+    assert lib.coalign_pointwise_conv_emu_sp(one, one, one, one, 1, 64, 8, 8, 1, 128, 1, 128, 384, 8, 1, 1, null, null) == -3          # c_off % 16
+    assert lib.coalign_pointwise_conv_emu_sp(one, one, one, one, 1, 64, 8, 8, 1, 128, 2, 128, 384, 0, 1, 1, null, null) == -2          # M_padded != Cout * up * up
 
 
 def test_ops_have_no_cpu_fallback():
