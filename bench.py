@@ -311,6 +311,9 @@ def main():
                     "holds all maps and runs the ego tail (north_star's one-agent-per-GPU wording; strong scaling of a single frame)")
     ap.add_argument("--comm-per-lane", action="store_true", help="one RCCL communicator per lane instead of ONE shared by all lanes (collectives are issued in frame order "
                     "on every rank, so one communicator is deadlock-free by construction; several communicators used concurrently are not)")
+    ap.add_argument("--force-dist", action="store_true", help="run the MULTI-RANK path with whatever world size there is -- at --gpus 1: init_process_group('nccl', world_size=1), "
+                    "FrameRing / AgentGather execute their collective as a self exchange on RCCL, two HIP graphs per lane around it (first contact with RCCL on a 1-GPU box; "
+                    "the line's `rccl` key reports it; not the headline configuration)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: build the exchange plans and shape-only buffers of EVERY rank for --gpus N and validate them against what "
                     "RCCL's all_to_all_single / all_gather_into_tensor require (coalign_amd.sharded.preflight); prints the report as one JSON line")
     ap.add_argument("--launch-check", action="store_true", help="no GPU work: bring the ranks up (self-launch included), one all-reduce over gloo, rank 0 prints {launch_check, world, "
@@ -336,6 +339,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # --force-dist (round 6): the multi-rank code path -- process group, control group, schedule negotiation, two graphs per lane around the collective -- with a
+    # world of ONE, the collectives running as self all-to-all / self all-gather on the real backend: how RCCL is exercised on a 1-GPU box
+    multi = world > 1 or args.force_dist
+    if args.force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     if args.launch_check:
@@ -357,7 +366,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # a collective a peer never enters must end as an exception, not as a hang until the driver's clock runs out: 10 minutes (default 30)
         import datetime
@@ -380,7 +389,7 @@ def main():
     anchors = torch.from_numpy(pp.generate_anchor_box())
 
     # the frame pool: POOL distinct 5-agent frames (seed 303 + i, pose noise 0.2 m / 0.2 deg), identical on every rank
-    pool_n = POOL if world == 1 else world * max(1, POOL // world)
+    pool_n = POOL if (not multi) else world * max(1, POOL // world)
     frames_cpu = [make_frame(hypes, N, pillars_per_agent=args.pillars, seed=303 + i, noise=(0.2, 0.2)) for i in range(pool_n)]
     frames = []
     for f in frames_cpu:
@@ -389,7 +398,7 @@ def main():
         d["pairwise_t_matrix_host"] = f["pairwise_t_matrix"]      # the dataset's host copy of the 5 x 5 pose matrices travels with the batch (normalised on the host, pipeline.py)
         frames.append(d)
     calibrate_heads_(model, frames[0], pp.params["target_args"]["score_threshold"], 600)     # same frame, same weights on every rank
-    if world > 1:   # identical weights everywhere, bit for bit
+    if multi:   # identical weights everywhere, bit for bit
         for p in model.parameters():
             if backend == "nccl":
                 dist.broadcast(p.data, 0)
@@ -402,8 +411,8 @@ def main():
     # Single GPU, HIP graphs (the headline configuration, second half of round 5): TWO streams, THREE frames queued on each.  Two frames running side by side is what the
     # GPU takes (3 / 4 concurrent frames measure -0 / -7 %); what the earlier "3 lanes, result lag 1" left on the table was the host round trip between a stream's frames
     # (collect, stage, launch: 0.15-0.2 ms during which the other frame ran alone).  Same box, 300 steps: 639-642 -> 650-659 frames/s; 20 steps: 597-600 -> 622-628.
-    n_lanes = args.lanes if args.lanes > 0 else ((2 if world == 1 else 3) if use_graph else 4)
-    queue_depth = args.queue_depth if args.queue_depth > 0 else (3 if use_graph and world == 1 else 1)
+    n_lanes = args.lanes if args.lanes > 0 else ((2 if (not multi) else 3) if use_graph else 4)
+    queue_depth = args.queue_depth if args.queue_depth > 0 else (3 if use_graph and (not multi) else 1)
     rings = None
     exchanges = None
     mode = args.mode
@@ -425,12 +434,12 @@ def main():
         groups = [dist.new_group(backend=backend) for _ in range(n_lanes)] if args.comm_per_lane else [None] * n_lanes
         by_agent = [split_agents(f) for f in frames]
         if m == "ring":
-            rs = [FrameRing(N, group=g) for g in groups]
+            rs = [FrameRing(N, group=g, force_collective=args.force_dist) for g in groups]
             period = pool_n // world
             return rs, [r.exchange for r in rs], [ring_batch(by_agent, [f["pairwise_t_matrix"] for f in frames], rank, world, N, s) for s in range(period)]
         # gather mode: every step is ONE frame; this rank encodes its contiguous block of the agents (empty slots where the block runs past
         # N), the per-scale maps are all-gathered, and the ego tail runs with all N agents (on every rank: same latency, rank 0 reports)
-        gathers = [AgentGather(N, group=g) for g in groups]
+        gathers = [AgentGather(N, group=g, force_collective=args.force_dist) for g in groups]
         per = gathers[0].per
         sb = []
         for g_, f in enumerate(frames):
@@ -441,7 +450,7 @@ def main():
                        "pairwise_t_matrix_host": f["pairwise_t_matrix_host"]})
         return gathers, [(lambda feats, _g=g: (_g.gather(feats), None)) for g in gathers], sb
 
-    if world > 1:
+    if multi:
         # ---- first contact with RCCL, hardened (the reference's own bring-up: opencood/tools/multi_gpu_utils.py:31-37).
         #      (1) who is here: every rank's device over the control group; (2) one small all-gather on the data plane; (3) the chosen schedule is
         #      warmed up inside try / except on every rank and the ranks agree on the outcome: ring -> gather -> independent replicas.
@@ -464,7 +473,7 @@ def main():
             ok = False
         rccl = {"world": world, "backend": "RCCL" if backend == "nccl" else backend, "ranks_seen": seen,
                 "distinct_devices": len({(d["host"], d["uuid"] or d["pci_bus_id"] or d["local_rank"]) for d in seen}), "data_plane_all_gather_ok": agree(ok),
-                "requested_mode": args.mode, "fallbacks": []}
+                "requested_mode": args.mode, "fallbacks": [], "forced_world_one": bool(args.force_dist and world == 1)}
         if not rccl["data_plane_all_gather_ok"]:
             mode = "replicas"
             rccl["fallbacks"].append("data-plane all-gather failed -> replicas")
@@ -475,14 +484,14 @@ def main():
 
     # every pipeline of this process runs on the SAME lane streams (FramePipeline(streams=...)): streams share a handful of hardware queues
     n_streams = n_lanes
-    if world > 1:
+    if multi:
         queue_depth = 1                                          # (multi-rank lanes own an exchange each: one frame per stream there)
     n_lanes = n_streams * queue_depth                            # pipeline lanes = frames queued or running; lane i runs on stream i mod n_streams (FramePipeline(queue_depth=...))
     result_lag = args.result_lag if args.result_lag >= 0 else (n_lanes - 1 if queue_depth > 1 else 1)
     lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
 
     def make_pipe(graph):
-        if not graph and use_graph and world == 1:               # the eager side mode / profile pass of a graph run: host-bound launches want one frame per stream (rounds 3-4's form)
+        if not graph and use_graph and (not multi):               # the eager side mode / profile pass of a graph run: host-bound launches want one frame per stream (rounds 3-4's form)
             while len(lane_streams) < 3:
                 lane_streams.append(torch.cuda.Stream(device=dev))
             return FramePipeline(model, pp, anchors, lanes=3, result_lag=1, graph=False, device=dev, streams=lane_streams)
@@ -490,7 +499,7 @@ def main():
                              exchange=exchanges, streams=lane_streams)
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -515,7 +524,7 @@ def main():
 
     pipe = make_pipe(use_graph)
     warm = max(args.warmup, 2 * n_lanes if use_graph else args.warmup)     # every lane captures its graph during the warm-up
-    if world > 1:
+    if multi:
         # the chosen schedule's first exchanges, guarded: any error on any rank moves ALL ranks to the next schedule (ring -> gather -> replicas;
         # coalign_amd.sharded.negotiate_schedule, CPU-tested with gloo ranks in tests/test_sharded_cpu.py)
         state = {"mode": mode}
@@ -581,7 +590,7 @@ def main():
                 del feats_x
             except Exception as e:      # noqa: BLE001
                 rccl["exchange_timing_error"] = f"{type(e).__name__}: {str(e)[:160]}"
-    if use_graph and world == 1:       # a capture that fails here (driver / allocator state of this box) must not cost the bench line: fall back to eager
+    if use_graph and (not multi):       # a capture that fails here (driver / allocator state of this box) must not cost the bench line: fall back to eager
         try:
             for s_ in range(n_lanes):
                 pipe.submit(step_batches[s_ % len(step_batches)])
@@ -603,7 +612,7 @@ def main():
             from coalign_amd import detector as det_mod
             rn = getattr(model.backbone, "resnet", None)
             sparse_on = bool(det_mod.SPARSE_CANVAS and rn is not None and hasattr(rn, "layer0") and rn.layer0[0].takes_sparse_canvas() and not getattr(model, "compression", False))
-            tp = (lambda fn: graph_time(fn, dev)) if world == 1 else hip_time
+            tp = (lambda fn: graph_time(fn, dev)) if (not multi) else hip_time
             if sparse_on:
                 model.pillar_vfe.sparse_canvas = True
                 iso["pillar_ms"] = tp(lambda: model.pillar_vfe(dict(pl_in)))
@@ -611,7 +620,7 @@ def main():
                 iso["pillar_dense_persistent_ms"] = tp(lambda: model.pillar_vfe(dict(pl_in)))
             else:
                 iso["pillar_ms"] = tp(lambda: model.pillar_vfe(dict(pl_in)))
-            if model.pillar_vfe.persistent_canvas and world == 1:      # the same op on a fresh canvas every call (dense memset included)
+            if model.pillar_vfe.persistent_canvas and (not multi):      # the same op on a fresh canvas every call (dense memset included)
                 model.pillar_vfe.persistent_canvas = False
                 iso["pillar_fresh_canvas_ms"] = graph_time(lambda: model.pillar_vfe(dict(pl_in)), dev)
                 model.pillar_vfe.persistent_canvas = True
@@ -632,7 +641,7 @@ def main():
                 for _ in range(3):
                     model._fuse_scales(list(feats_iso), [N], affine_iso)
                 torch.cuda.synchronize()
-                if world == 1:
+                if (not multi):
                     iso["fuse_ms"] = graph_time(lambda: model._fuse_scales(list(feats_iso), [N], affine_iso), dev)      # (several calls per graph: no replay floor)
                 else:       # no stream capture next to a live RCCL communicator (its watchdog thread polls events): plain launches
                     iso["fuse_ms"] = hip_time(lambda: model._fuse_scales(list(feats_iso), [N], affine_iso))
@@ -645,7 +654,7 @@ def main():
     dt, t_issue, results = timed_run(pipe, args.steps, warm)
     lat_default = list(pipe.latencies_ms)
     range_hit = pipe.range_exceeded()          # (outside the bracket) did any SplitMap value leave the fp16 split's operating range?
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -653,12 +662,12 @@ def main():
     # ---- per-frame detection digests: pool frame -> digest; every recurrence of a pool frame must reproduce it exactly
     digests, consistent, mismatches = {}, True, []
     for idx, boxes, scores in results[-min(len(results), 2 * pool_n):]:
-        g = (idx * world + rank) % pool_n if (world > 1 and mode == "ring") else (idx + rank) % pool_n if (world > 1 and mode == "replicas") else idx % pool_n
+        g = (idx * world + rank) % pool_n if (multi and mode == "ring") else (idx + rank) % pool_n if (multi and mode == "replicas") else idx % pool_n
         d = checksum(boxes, scores)
         if digests.setdefault(g, d) != d:
             consistent = False
             mismatches.append([idx, g, digests[g], d])
-    if world > 1:
+    if multi:
         allg = [None] * world
         dist.all_gather_object(allg, (digests, consistent))
         digests = {}
@@ -680,7 +689,7 @@ def main():
     # ---- per-frame latency: ONE frame in flight, detections collected before the next frame is submitted (the reference's strictly
     #      serial loop, opencood/tools/inference.py:125-179) -- what a 10 Hz LiDAR consumer sees
     latency = None
-    if world == 1 and not args.no_latency:
+    if (not multi) and not args.no_latency:
         latency = {"default_pipeline": dict(latency_stats(lat_default), frames_in_flight=n_lanes, streams=n_streams, frames_queued_per_stream=n_lanes // n_streams, result_lag_frames=pipe.result_lag)}
         try:
             p1 = FramePipeline(model, pp, anchors, lanes=1, result_lag=0, graph=use_graph, device=dev, streams=lane_streams)
@@ -695,7 +704,7 @@ def main():
     # ---- the loop fed from RAW POINTS in host memory: pinned staging -> async H2D -> coalign_voxelize -> encoder (count on the device)
     #      -> the same frame.  A second reported mode; `value` stays the from-pillars metric BASELINE.json names.
     from_points = None
-    if world == 1 and (args.from_points or not args.no_from_points):
+    if (not multi) and (args.from_points or not args.no_from_points):
         try:
             from coalign_amd.preprocess import build_preprocessor
             pre = build_preprocessor(hypes["preprocess"], False, dev)
@@ -713,7 +722,7 @@ def main():
             pp_p = build_postprocessor(hypes["postprocess"], False)
             # (the feeder path moves 10.5 MB host -> device per frame on the frame's own stream: a third stream lets that copy run beside two computing frames;
             #  COALIGN_BENCH_FP="streams,depth,lag" overrides for measurements)
-            fps_, fpd_, fpl_ = [int(v) for v in os.environ.get("COALIGN_BENCH_FP", "3,2,3" if use_graph and world == 1 and args.lanes <= 0 and args.queue_depth <= 0 else f"{n_streams},{queue_depth},{result_lag}").split(",")]
+            fps_, fpd_, fpl_ = [int(v) for v in os.environ.get("COALIGN_BENCH_FP", "3,2,3" if use_graph and (not multi) and args.lanes <= 0 and args.queue_depth <= 0 else f"{n_streams},{queue_depth},{result_lag}").split(",")]
             while len(lane_streams) < fps_:
                 lane_streams.append(torch.cuda.Stream(device=dev))
             fp = FramePipeline(model_p, pp_p, anchors, lanes=fps_, queue_depth=fpd_, result_lag=fpl_, graph=use_graph, device=dev, preprocessor=pre,
@@ -743,7 +752,7 @@ def main():
 
     # ---- the same bracket with the other convolution arithmetics (reported beside `value`, never as `value`)
     side = None
-    if world == 1 and not args.no_side_modes:
+    if (not multi) and not args.no_side_modes:
         side = {}
         try:
             for terms in (0, 3, 16, 2):
@@ -923,7 +932,7 @@ def main():
                        "result_lag_frames": pipe.result_lag, "hip_graph": use_graph,
                        "inputs": ("resident in HBM, read in place through a 32-byte device record; pose matrices normalised on the host; one small host-to-device transfer per frame"
                                   if pipe.frames_in_place and not pipe.frames_copied else "resident in HBM, copied into the captured graph's input buffers every frame" if use_graph else "resident in HBM"), "conv_arithmetic": "native fp32" if default_terms == 0 else ("fp16 split (sp16 pairs)" + (", SplitMaps between the 3x3 layers" if backbone_mod.split_maps_active() else "")) if default_terms == 16 else f"bf16x{default_terms}",
-                       "parallelism": "single GPU" if world == 1 else (f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all" if mode == "ring" else
+                       "parallelism": "single GPU" if (not multi) else (f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all" if mode == "ring" else
                                                                                       f"{world} independent replicas, no collective (fall-back: see `rccl.fallbacks`)" if mode == "replicas" else
                                                                                       f"one frame over {world} ranks (agent blocks), {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-gather, ego tail on every rank") +
                                        (", one communicator per lane" if args.comm_per_lane else ", one communicator"),
@@ -945,15 +954,15 @@ def main():
             result["from_points"] = from_points
         if side is not None:
             result["other_modes"] = side
-        if world == 1 and not args.no_size_sweep:
+        if (not multi) and not args.no_size_sweep:
             pipe.close()
             del pipe
             torch.cuda.empty_cache()
             result["size_sweep"] = size_sweep(dev, streams=lane_streams, lanes=n_streams if use_graph else 3, result_lag=result_lag if use_graph else 1, queue_depth=queue_depth if use_graph else 1)
-        if world == 1 and not args.no_cpu_baseline:
+        if (not multi) and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(hypes, model, frames_cpu, anchors, args.cpu_frames, args.cpu_threads, args.cpu_budget_s)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -315,11 +315,15 @@ class BasicBlock(nn.Module):
         skip = ops.pointwise_conv_sparse(sc, pw, pd[1], wd.shape[0], False, out_channels_last=wino)
         return conv3x3_fused(y, p2, w2, b2, skip, out_channels_last=(wino or out_channels_last) and p2 is not None and p2.cout % 4 == 0)
 
-    def forward(self, x: torch.Tensor, out_channels_last: bool = False) -> torch.Tensor:
-        if self.takes_split_maps() and x.is_cuda:
+    def forward(self, x: torch.Tensor, out_channels_last: bool = False, out_split: bool = False) -> torch.Tensor:
+        """``out_split``: the caller (``ResNetStages``' per-block loop) reads ``ops.SplitMap``s and wants one back.  A plain ``block(x)`` / ``nn.Sequential`` call
+        always gets a tensor, and the SplitMap route is taken for float32 CUDA tensors and for this build's own map types only -- half / float64
+        inputs run the reference's module sequence below."""
+        if self.takes_split_maps() and (isinstance(x, (ops.SplitMap, ops.SparseCanvas)) or _fast_ok(self, x)):
             f = self._folded()
             if f[5] is not None and f[6] is not None and (self.stride == 1 or f[7] is not None):
-                return self._forward_split(x, out_channels_last)
+                y = self._forward_split(x, out_channels_last)
+                return y.dense() if isinstance(y, ops.SplitMap) and not out_split else y
         if isinstance(x, ops.SplitMap):
             x = x.dense()
         if isinstance(x, ops.SparseCanvas):
@@ -381,9 +385,12 @@ class ResNetStages(nn.Module):
             layer = getattr(self, f"layer{i}")
             if NHWC_STAGE_OUTPUTS and emu_active() and (isinstance(x, ops.SparseCanvas) or _fast_ok(self, x)):
                 for j, blk in enumerate(layer):
-                    x = blk(x, out_channels_last=(j == len(layer) - 1))
+                    last = j == len(layer) - 1
+                    x = blk(x, out_channels_last=last, out_split=not last)
             else:
                 x = layer(x)
+            if isinstance(x, ops.SplitMap):          # (a stage output is always a tensor: fusion, the exchange and the next stage read it)
+                x = x.dense()
             feats.append(x)
         return feats
 

@@ -64,6 +64,8 @@ struct EmuArgs {
     // (stamp & 0xffffffff) of x if stamps[(n * Hin + y) * Win + x] >> 32 equals *tag_ptr, else zero.  Channels-last input layouts only.
     const unsigned long long *__restrict__ stamps;
     const int *__restrict__ tag_ptr;
+    int *range_flag;                  // round 6 (may be NULL): bit 0 is set when an SP output value exceeds the pair's range (|y| > 65504), as in csrc/conv3x3_sp.hip
+    unsigned sparse_rows;             // round 6: rows behind x -- a stamp naming a row beyond them (a canvas object kept across a later encode through the same stamp map) reads as empty
     // round 5, fp16 split only: the per-output-channel power-of-two scale the weight image was multiplied with before it was split (its tail:
     // [Cout] 2^-k_c, then [Cout] 2^k_c).  bias + residual enter the accumulator times 2^k_c, the tile leaves it times 2^-k_c: both exact.
     const float *__restrict__ wscale;
@@ -249,7 +251,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                 if constexpr ((LAYOUT & LAYOUT_IN_NHWC) != 0) {
                     if (a.stamps) {                                 // sparse canvas: the pixel's feature row, or nothing
                         const unsigned long long st = a.stamps[(size_t)n0 * plane_in + (pl.off[j] < 0 ? 0 : pl.off[j])];
-                        pl.off[j] = (pl.off[j] >= 0 && (unsigned)(st >> 32) == sparse_tag) ? (int)(unsigned)st : -1;
+                        pl.off[j] = (pl.off[j] >= 0 && (unsigned)(st >> 32) == sparse_tag && (unsigned)st < a.sparse_rows) ? (int)(unsigned)st : -1;
                     }
                 }
             }
@@ -596,6 +598,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                 uint4 *ysp = reinterpret_cast<uint4 *>(a.y);
                 const size_t pix = live ? (size_t)gy * a.W + gx : 0;
                 const int on = live ? out_n : 0;
+                float vmax = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4 * G::NCO; ++r) {
                     float v[4];
@@ -605,6 +608,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                         v[j] = acc[r / 4][4 * (r % 4) + j] * winv[c] + bias[c];       // (SP outputs take no residual)
                         if (a.relu) v[j] = fmaxf(v[j], 0.f);
                     }
+                    vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                     unsigned h01, l01, h23, l23;
                     coalign::sp16_split2(v[0], v[1], h01, l01);
                     coalign::sp16_split2(v[2], v[3], h23, l23);
@@ -616,6 +620,7 @@ void conv3x3_emu_kernel(const EmuArgs a) {
                     const size_t idx = ((size_t)(on * (a.Cout / 16) + g8 / 2) * 4 + (g8 % 2) * 2 + half) * plane + pix;
                     if (live) ysp[idx] = uint4{a0, a1, b0, b1};
                 }
+                if (a.range_flag && live && vmax > 65504.f) atomicOr(a.range_flag, 1);      // (the pair clamps: finite, never NaN -- the host reads the word)
             } else if (live) {
                 if constexpr ((LAYOUT & LAYOUT_OUT_NHWC) != 0) {      // channels-last output: accumulators 4 r .. 4 r + 3 are 4 consecutive channels
                     float *yp = a.y + (((size_t)out_n * a.H + gy) * a.W + gx) * a.Cout + cur.cg * kCoutTile + cb + 4 * half;
@@ -1041,7 +1046,7 @@ extern "C" int coalign_conv3x3_emu_bias_act(const float *x, const void *w_split,
 }
 
 extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const float *bias, const float *residual, float *y, int N, int Cin,
-                                      int Cout, int Hin, int Win, int stride, int relu, int terms, int layout, void *workspace,
+                                      int Cout, int Hin, int Win, int stride, int relu, int terms, int layout, int32_t *range_flag, void *workspace,
                                       size_t workspace_bytes, void *stream) {
     using namespace coalign;
     if (stride == 1 && layout == LAYOUT_NCHW)
@@ -1061,6 +1066,7 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
         EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, Hin, Win, relu, 0, 0, 0, Hin, Win, nullptr, nullptr};
         a.prio_mode = emu_prio_mode();
         a.wscale = emu_wscale(w_split, Cin, Cout, terms, 1);
+        a.range_flag = range_flag;
 #ifdef EMU_TRACE
         a.trace = g_emu_trace;
         a.ablate = g_emu_ablate;
@@ -1083,6 +1089,7 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
     EmuArgs a{x, static_cast<const uint4 *>(w_split), bias, residual, y, N, Cin, Cout, H, W, relu, 0, 0, 0, Hin, Win, nullptr, nullptr};
     a.prio_mode = emu_prio_mode();
     a.wscale = emu_wscale(w_split, Cin, Cout, terms, 0);
+    a.range_flag = range_flag;
 #ifdef EMU_TRACE
     a.trace = g_emu_trace;
     a.ablate = g_emu_ablate;
@@ -1094,8 +1101,8 @@ extern "C" int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const
 
 // Round 4: the strided first convolution of the first ResNet stage reading a SPARSE canvas (csrc/pillar_sparse.hip) instead of the dense zero-filled one:
 // same kernel, the pixel -> row lookup happens once per tile in the patch plan.  Output channels-last (out_nhwc != 0) or NCHW.
-extern "C" int coalign_conv3x3_emu_sparse(const float *feats, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y, int N,
-                                          int Cin, int Cout, int Hin, int Win, int relu, int terms, int out_nhwc, void *stream) {
+extern "C" int coalign_conv3x3_emu_sparse(const float *feats, int M_rows, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y, int N,
+                                          int Cin, int Cout, int Hin, int Win, int relu, int terms, int out_nhwc, int32_t *range_flag, void *stream) {
     using namespace coalign;
     if (!feats || !stamps || !state || !w_split || !y || !bias) return COALIGN_ERR_NULL_POINTER;
     const int H = (Hin + 1) / 2, W = (Win + 1) / 2;
@@ -1109,6 +1116,9 @@ extern "C" int coalign_conv3x3_emu_sparse(const float *feats, const void *stamps
     a.wscale = emu_wscale(w_split, Cin, Cout, terms, 0);
     a.stamps = static_cast<const unsigned long long *>(stamps);
     a.tag_ptr = state;
+    if (M_rows < 0) return COALIGN_ERR_BAD_SHAPE;
+    a.sparse_rows = (unsigned)M_rows;
+    a.range_flag = range_flag;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (out_nhwc == 2 && terms != 16) return COALIGN_ERR_UNSUPPORTED;      // SP map output: fp16 split only
     const int layout = out_nhwc == 2 ? (LAYOUT_IN_NHWC | LAYOUT_OUT_SP) : out_nhwc ? LAYOUT_NHWC : LAYOUT_IN_NHWC;

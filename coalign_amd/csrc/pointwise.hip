@@ -33,6 +33,7 @@ struct PwArgs {
     // stamps[(n * Hin + y) * Win + x] >> 32 == *tag_ptr, else zero
     const unsigned long long *stamps;
     const int *tag_ptr;
+    unsigned sparse_rows;  // round 6: rows behind x; a stamp naming a row beyond them reads as empty
     // round 5: y is an SP map (csrc/conv3x3_sp.hip: [N][Ctot / 16][4 planes][Ho][Wo][8 x fp16]) -- the up-sampling heads write the input of the shrink header's
     // first convolution already split; range_flag as there (bit 0: a value beyond the pair's range)
     int out_sp;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwArgs a) {
         bool ok = ok0;
         if (a.stamps) {        // sparse canvas: the pixel's feature row, or nothing
             const unsigned long long st = a.stamps[(size_t)n * in_plane + off];
-            ok = ok0 && (unsigned)(st >> 32) == (unsigned)*a.tag_ptr;
+            ok = ok0 && (unsigned)(st >> 32) == (unsigned)*a.tag_ptr && (unsigned)st < a.sparse_rows;
             off = ok ? (size_t)(unsigned)st : 0;
         }
         if (a.in_nhwc) {       // a pixel's channels are contiguous: 16 B per lane, thread t takes channel quads c0, c0 + cstep, ...
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void pointwise_emu_kernel(const PwArgs a) {
         bool ok = ok0;
         if (a.stamps) {        // sparse canvas: the pixel's feature row, or nothing
             const unsigned long long st = a.stamps[(size_t)n * in_plane + off];
-            ok = ok0 && (unsigned)(st >> 32) == (unsigned)*a.tag_ptr;
+            ok = ok0 && (unsigned)(st >> 32) == (unsigned)*a.tag_ptr && (unsigned)st < a.sparse_rows;
             off = ok ? (size_t)(unsigned)st : 0;
         }
         for (int g = g0; g < G; g += gstep) {
@@ -340,7 +341,7 @@ extern "C" int coalign_pointwise_conv(const float *x, const float *w, const floa
 
 static int pointwise_impl(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
                           int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, bool emu,
-                          void *stream, const void *stamps = nullptr, const int32_t *state = nullptr, bool out_sp = false, int32_t *range_flag = nullptr) {
+                          void *stream, const void *stamps = nullptr, const int32_t *state = nullptr, bool out_sp = false, int32_t *range_flag = nullptr, int sparse_rows = 0) {
     using namespace coalign;
     if (!x || !w || !bias || !y) return COALIGN_ERR_NULL_POINTER;
     if (emu && ((Cin & 15) || (reinterpret_cast<uintptr_t>(w) & 15))) return COALIGN_ERR_UNSUPPORTED;
@@ -356,7 +357,7 @@ static int pointwise_impl(const float *x, const float *w, const float *bias, flo
     in_nhwc &= 1;
     if (out_nhwc && (up != 1 || (Ctot & 3) || (c_off & 3) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias)) & 15))) return COALIGN_ERR_UNSUPPORTED;
     PwArgs a{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu, in_nhwc != 0, 1, out_nhwc,
-             static_cast<const unsigned long long *>(stamps), state, out_sp ? 1 : 0, range_flag};
+             static_cast<const unsigned long long *>(stamps), state, (unsigned)(sparse_rows < 0 ? 0 : sparse_rows), out_sp ? 1 : 0, range_flag};
     if (out_sp && (!emu || out_nhwc || (Cout & 15) || (Ctot & 15) || (c_off & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15) ||
                    M_padded != Cout * up * up || (size_t)N * Ctot * a.Hp * up * a.Wp * up >= ((size_t)1 << 33)))
         return COALIGN_ERR_UNSUPPORTED;
@@ -421,11 +422,12 @@ extern "C" int coalign_pointwise_conv_emu(const float *x, const void *w_split, c
 
 // Round 4: the 1 x 1 / stride-2 skip convolution of the first ResNet stage reading the SPARSE canvas of csrc/pillar_sparse.hip (feature rows + cell stamps)
 // instead of the dense canvas.  out_nhwc: bit 0 = channels-last output.
-extern "C" int coalign_pointwise_conv_emu_sparse(const float *feats, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y,
+extern "C" int coalign_pointwise_conv_emu_sparse(const float *feats, int M_rows, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y,
                                                  int N, int Cin, int Hin, int Win, int Cout, int M_padded, int relu, int out_nhwc, void *stream) {
     if (!stamps || !state) return COALIGN_ERR_NULL_POINTER;
+    if (M_rows < 0) return COALIGN_ERR_BAD_SHAPE;
     return pointwise_impl(feats, static_cast<const float *>(w_split), bias, y, N, Cin, Hin, Win, 2, Cout, 1, M_padded, Cout, 0, relu, 1 | (out_nhwc ? 2 : 0), true, stream,
-                          stamps, state);
+                          stamps, state, false, nullptr, M_rows);
 }
 
 // Round 5: the up-sampling heads writing their channel slice of the concatenated map as an SP map (include/coalign_amd.h (9e)): the shrink header's first

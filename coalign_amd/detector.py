@@ -57,6 +57,20 @@ def _run_heads(model: nn.Module, x: torch.Tensor) -> dict:
     return out
 
 
+def _single_agent_batch(data_dict: dict) -> dict:
+    """``batch_dict`` of the single-agent models (point_pillar.py:52-60) plus the optional keys of this build's callers: ``record_len`` when the batch carries one
+    (saves PillarVFE its host read of the largest agent index), the device voxeliser's streaming keys and FramePipeline's frame record -- PillarVFE raises
+    ``FrameRecordUnsupported`` for a record on a route that reads the arrays directly, so a record can never be dropped silently."""
+    pl = data_dict["processed_lidar"]
+    batch_dict = {"voxel_features": pl["voxel_features"], "voxel_coords": pl["voxel_coords"], "voxel_num_points": pl["voxel_num_points"]}
+    if data_dict.get("record_len") is not None:
+        batch_dict["record_len"] = host_ints(data_dict["record_len"])
+    for k in ("voxel_count_dev", "voxel_cells_unique", "want_pillar_features", "pillar_frame"):
+        if k in pl:
+            batch_dict[k] = pl[k]
+    return batch_dict
+
+
 def x_is_cuda(maps) -> bool:
     return len(maps) > 0 and all(getattr(m, "is_cuda", False) for m in maps)
 
@@ -106,6 +120,7 @@ class PointPillarBaselineMultiscale(nn.Module):
 
     # -- stages, exposed separately so the sharded runner can place them on different ranks ----------------
     accepts_normalized_affine = True      # encode() takes data_dict['normalized_affine_matrix'] in place of normalising pairwise_t_matrix itself (FramePipeline)
+    accepts_pillar_frame = True           # encode() hands processed_lidar['pillar_frame'] (ops.PillarFrameRecord) to PillarVFE: FramePipeline may read frames in place
 
     def encode(self, data_dict: dict):
         """Per-agent part: pillars -> canvas -> multiscale features.  Returns (feature list, normalised affine)."""
@@ -212,10 +227,7 @@ class PointPillar(nn.Module):
             self.dir_head = nn.Conv2d(self.out_channel, args["dir_args"]["num_bins"] * args["anchor_number"], kernel_size=1)
 
     def forward(self, data_dict: dict) -> dict:
-        pl = data_dict["processed_lidar"]
-        batch_dict = {"voxel_features": pl["voxel_features"], "voxel_coords": pl["voxel_coords"],
-                      "voxel_num_points": pl["voxel_num_points"]}
-        batch_dict = self.backbone(self.scatter(self.pillar_vfe(batch_dict)))
+        batch_dict = self.backbone(self.scatter(self.pillar_vfe(_single_agent_batch(data_dict))))
         x = batch_dict["spatial_features_2d"]
         if self.shrink_flag:
             x = self.shrink_conv(x)
@@ -242,10 +254,7 @@ class PointPillarUncertainty(nn.Module):
             self.dir_head = nn.Conv2d(width, args["dir_args"]["num_bins"] * args["anchor_number"], kernel_size=1)
 
     def forward(self, data_dict: dict) -> dict:
-        pl = data_dict["processed_lidar"]
-        batch_dict = {"voxel_features": pl["voxel_features"], "voxel_coords": pl["voxel_coords"],
-                      "voxel_num_points": pl["voxel_num_points"]}
-        batch_dict = self.backbone(self.scatter(self.pillar_vfe(batch_dict)))
+        batch_dict = self.backbone(self.scatter(self.pillar_vfe(_single_agent_batch(data_dict))))
         return _run_heads(self, batch_dict["spatial_features_2d"])
 
 

@@ -35,8 +35,8 @@ SIGNATURES = {
     "coalign_pillar_encode_sparse": (c_int, [P, P, P, c_int, P, c_int, P, c_int, c_int, POINTER(c_double), POINTER(c_double),
                                              c_int, c_int, c_int, P, P, P, P]),
     "coalign_pillar_encode_sparse_frame": (c_int, [P, c_int, c_int, P, c_int, c_int, POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, P, P]),
-    "coalign_conv3x3_emu_sparse": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "coalign_pointwise_conv_emu_sparse": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "coalign_conv3x3_emu_sparse": (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "coalign_pointwise_conv_emu_sparse": (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_scatter_to_bev": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     "coalign_warp_fuse": (c_int, [P, c_int, c_int, c_int, c_int, P, POINTER(c_int32), c_int, c_int, P, c_int, c_int, P]),
     "coalign_normalize_pairwise": (c_int, [P, c_int, c_int, c_int, c_double, c_double, P, P]),
@@ -66,7 +66,7 @@ SIGNATURES = {
     "coalign_conv3x3_emu_weight_bytes_ex": (c_size_t, [c_int, c_int, c_int, c_int]),
     "coalign_conv3x3_emu_workspace_bytes_ex": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "coalign_conv3x3_emu_bias_act": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
-    "coalign_conv3x3_emu_ex": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "coalign_conv3x3_emu_ex": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     "coalign_sp_map_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "coalign_sp_pack": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P, P]),
     "coalign_sp_unpack": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -120,8 +120,8 @@ def lib() -> ctypes.CDLL:
         fn = getattr(handle, name)  # AttributeError here == header / library mismatch
         fn.restype = res
         fn.argtypes = args
-    if handle.coalign_abi_version() != 1:
-        raise CoalignHipError(f"ABI version mismatch: library reports {handle.coalign_abi_version()}, binding expects 1")
+    if handle.coalign_abi_version() != 2:
+        raise CoalignHipError(f"ABI version mismatch: library reports {handle.coalign_abi_version()}, binding expects 2")
     _LIB = handle
     return handle
 

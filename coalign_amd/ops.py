@@ -279,14 +279,23 @@ class SparseCanvas:
     ``PillarVFE`` + ``PointPillarScatter`` hand to the first ResNet stage on the fast path.  ``shape`` is the dense tensor's; ``dense()`` materialises it
     (the reference's ``spatial_features``) for anyone who needs the tensor."""
 
-    def __init__(self, feats, stamps, state, coords, n_agents, C, ny, nx, count_dev=None):
+    def __init__(self, feats, stamps, state, coords, n_agents, C, ny, nx, count_dev=None, owner: Optional[dict] = None):
         self.feats, self.stamps, self.state, self.coords = feats, stamps, state, coords
+        # every canvas of one (device, stream, grid) shares ONE stamp map, and only the LATEST encode through it is in the stamps: `owner` is that map's cache
+        # entry, `generation` the encode this object came from.  The consumers refuse a canvas that a later encode has overwritten (check_current) instead of
+        # reading the newer frame's rows out of this object's `feats`; on the device a stamp naming a row beyond `feats` reads as empty (M_rows, (9d) / (10b)).
+        self.owner, self.generation = owner, None if owner is None else owner.get("generation")
         if feats.numel() == 0 and feats.untyped_storage().nbytes() == 0:      # the consumers take a non-NULL row pointer even when every stamp is stale
             self.feats = torch.empty((1, C), dtype=torch.float32, device=feats.device)[:0]
         self.n_agents, self.C, self.ny, self.nx, self.count_dev = n_agents, C, ny, nx, count_dev
         self.shape = (n_agents, C, ny, nx)
         self.device, self.dtype = feats.device, feats.dtype
         self.is_cuda = True
+
+    def check_current(self) -> None:
+        if self.owner is not None and self.owner.get("generation") != self.generation:
+            raise hip.CoalignHipError("stale SparseCanvas: a later pillar_encode_sparse on the same device, stream and grid has overwritten the shared stamp map "
+                                      "(consume a canvas -- or .dense() it -- before the next encode, or encode on another stream / with another canvas_cache)")
 
     def dense(self) -> torch.Tensor:
         if self.coords is None:
@@ -311,6 +320,7 @@ def reset_sparse_canvases(canvas_cache: dict) -> int:
             entry["stamps"].zero_()
             entry["state"].zero_()
             entry["calls"] = 0
+            entry["generation"] = entry.get("generation", 0) + 1      # canvases encoded before the reset are gone
             n += 1
     return n
 
@@ -395,6 +405,7 @@ def pillar_encode_sparse(voxel_features: torch.Tensor, voxel_num_points: torch.T
     if entry is None:
         entry = canvas_cache[key] = {"stamps": torch.zeros(n_agents * ny * nx, dtype=torch.int64, device=dev), "state": torch.zeros(2, dtype=torch.int32, device=dev)}
     entry["calls"] = entry.get("calls", 0) + 1
+    entry["generation"] = entry.get("generation", 0) + 1      # (SparseCanvas.check_current)
     if entry["calls"] >= SPARSE_TAG_RESET_AFTER:             # (never inside a captured frame: a capture happens in a map's first calls)
         entry["stamps"].zero_()
         entry["state"].zero_()
@@ -404,12 +415,12 @@ def pillar_encode_sparse(voxel_features: torch.Tensor, voxel_num_points: torch.T
         with _Timed("pillar_encode_sparse"):
             hip.check(L.coalign_pillar_encode_sparse_frame(_ptr(frame.words), M, P, _ptr(folded), C, int(use_absolute_xyz), _dbl3(voxel_size), _dbl3(range_min), n_agents,
                                                            ny, nx, _ptr(feats), _ptr(entry["stamps"]), _ptr(entry["state"]), _stream()), "coalign_pillar_encode_sparse_frame")
-        return SparseCanvas(feats, entry["stamps"], entry["state"], None, n_agents, C, ny, nx, None)
+        return SparseCanvas(feats, entry["stamps"], entry["state"], None, n_agents, C, ny, nx, None, owner=entry)
     with _Timed("pillar_encode_sparse"):
         hip.check(L.coalign_pillar_encode_sparse(_ptr(vf), _ptr(npts), _ptr(coords), M, _ptr(count_dev), P, _ptr(folded), C, int(use_absolute_xyz), _dbl3(voxel_size),
                                                  _dbl3(range_min), n_agents, ny, nx, _ptr(feats), _ptr(entry["stamps"]), _ptr(entry["state"]), _stream()),
                   "coalign_pillar_encode_sparse")
-    return SparseCanvas(feats, entry["stamps"], entry["state"], coords, n_agents, C, ny, nx, count_dev)
+    return SparseCanvas(feats, entry["stamps"], entry["state"], coords, n_agents, C, ny, nx, count_dev, owner=entry)
 
 
 @_device_op
@@ -417,6 +428,7 @@ def conv3x3_emu_sparse(sc: SparseCanvas, w_split: torch.Tensor, bias: torch.Tens
     """The strided first convolution of the backbone reading a SparseCanvas (include/coalign_amd.h (9d)); tap-pair weight image.  ``out_split`` (terms 16):
     the result is a ``SplitMap`` (the input of ``conv3x3_sp``)."""
     L = hip.lib()
+    sc.check_current()
     N, Cin, H, W = sc.shape
     Ho, Wo = (H + 1) // 2, (W + 1) // 2
     if w_split.numel() != L.coalign_conv3x3_emu_weight_bytes(Cin, cout, terms):
@@ -429,8 +441,9 @@ def conv3x3_emu_sparse(sc: SparseCanvas, w_split: torch.Tensor, bias: torch.Tens
     else:
         out = y = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=sc.device, memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
     with _Timed("conv3x3_emu_sparse"):
-        hip.check(L.coalign_conv3x3_emu_sparse(_rows_ptr(sc.feats), _ptr(sc.stamps), _ptr(sc.state), _ptr(w_split), _ptr(_f32c(bias)), _ptr(y), N, Cin, cout, H, W,
-                                               int(relu), terms, 2 if out_split else int(out_channels_last), _stream()), "coalign_conv3x3_emu_sparse")
+        hip.check(L.coalign_conv3x3_emu_sparse(_rows_ptr(sc.feats), int(sc.feats.shape[0]), _ptr(sc.stamps), _ptr(sc.state), _ptr(w_split), _ptr(_f32c(bias)), _ptr(y), N, Cin, cout, H, W,
+                                               int(relu), terms, 2 if out_split else int(out_channels_last), _ptr(sp_range_flag(sc.device)) if out_split else None, _stream()),
+                  "coalign_conv3x3_emu_sparse")
     return out
 
 
@@ -438,13 +451,14 @@ def conv3x3_emu_sparse(sc: SparseCanvas, w_split: torch.Tensor, bias: torch.Tens
 def pointwise_conv_sparse(sc: SparseCanvas, w_emu: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool, out_channels_last: bool) -> torch.Tensor:
     """The 1 x 1 / stride-2 skip convolution reading a SparseCanvas (include/coalign_amd.h (10b)); ``w_emu``: ``pack_pointwise_emu_weight`` image."""
     L = hip.lib()
+    sc.check_current()
     N, Cin, H, W = sc.shape
     if w_emu.dtype != torch.int16 or w_emu.dim() != 5 or w_emu.shape[1] * 16 != Cin:
         raise ValueError("pointwise_conv_sparse needs the split-bf16 weight image of this Cin")
     Ho, Wo = (H + 1) // 2, (W + 1) // 2
     y = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=sc.device, memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
     with _Timed("pointwise_conv_sparse"):
-        hip.check(L.coalign_pointwise_conv_emu_sparse(_rows_ptr(sc.feats), _ptr(sc.stamps), _ptr(sc.state), _ptr(w_emu), _ptr(_f32c(bias)), _ptr(y), N, Cin, H, W, cout,
+        hip.check(L.coalign_pointwise_conv_emu_sparse(_rows_ptr(sc.feats), int(sc.feats.shape[0]), _ptr(sc.stamps), _ptr(sc.state), _ptr(w_emu), _ptr(_f32c(bias)), _ptr(y), N, Cin, H, W, cout,
                                                       w_emu.shape[0] * 32, int(relu), int(out_channels_last), _stream()), "coalign_pointwise_conv_emu_sparse")
     return y
 
@@ -906,7 +920,7 @@ def conv3x3_emu_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: torch.Ten
         ws = _conv_workspace(key, ws_bytes, xc.device)
     with _Timed("conv3x3_emu_bias_act"):
         hip.check(L.coalign_conv3x3_emu_ex(_ptr(xc), _ptr(w_split), _ptr(_f32c(bias)), _ptr(res), _ptr(y), N, Cin, cout, H, W, int(stride),
-                                           int(relu), terms, layout, _ptr(ws), 0 if ws is None else ws.numel(), _stream()),
+                                           int(relu), terms, layout, _ptr(sp_range_flag(xc.device)) if out_split else None, _ptr(ws), 0 if ws is None else ws.numel(), _stream()),
                   "coalign_conv3x3_emu_ex")
     return y if out is None else out
 

@@ -168,7 +168,9 @@ class FramePipeline:
         # form, cells not assumed unique), which then serves every other count of that bucket: ragged streams settle on <= 2 graphs per lane
         self._bucket_seen: List[Dict[tuple, tuple]] = [dict() for _ in range(self.n_lanes)]
         # frames read in place through a device record (no input copies); switched off for good when the model's route turns out not to take one
-        self._records_ok = FRAME_RECORDS and hasattr(model, "pillar_vfe") and hasattr(model, "scatter")
+        # (an explicit capability of the model class -- ADVICE r05: a model whose forward builds its own batch_dict would drop the record and the captured graph would keep
+        #  reading the FIRST frame's arrays; PillarVFE raises FrameRecordUnsupported when a record reaches a route that cannot take it, which switches this off as well)
+        self._records_ok = FRAME_RECORDS and bool(getattr(model, "accepts_pillar_frame", False)) and hasattr(model, "pillar_vfe") and hasattr(model, "scatter")
         self.frames_in_place = self.frames_copied = 0             # graph-mode frames read through a device record / copied into the graph's input buffers
         self._host_poses = self._records_ok and bool(getattr(model, "accepts_normalized_affine", False)) and hasattr(model, "voxel_size")
         self.graphs_captured = 0
@@ -293,15 +295,19 @@ class FramePipeline:
                    "pairwise_t_matrix": batch["pairwise_t_matrix"]}
         direct = offsets is None and self._records_ok and ops.PillarFrameRecord.admits(src["voxel_features"], src["voxel_num_points"], src["voxel_coords"], self.device)
         pose_host = batch.get("pairwise_t_matrix_host") if direct and self._host_poses else None
-        if pose_host is not None and (pose_host.is_cuda or pose_host.dtype != torch.float64 or tuple(pose_host.shape) != tuple(src["pairwise_t_matrix"].shape)):
+        # (the host copy stands in for the device matrix only when both are the dataset's float64 matrices of one shape: a float32 device matrix normalises to other bits)
+        if pose_host is not None and (pose_host.is_cuda or pose_host.dtype != torch.float64 or src["pairwise_t_matrix"].dtype != torch.float64
+                                      or tuple(pose_host.shape) != tuple(src["pairwise_t_matrix"].shape)):
             pose_host = None
-        key = (tuple(record), None if offsets is None else tuple(offsets), direct, pose_host is not None) + tuple((tuple(t.shape), str(t.dtype)) for t in src.values())
+        # (multi-rank frames: the tail graph bakes the agent grouping the ego sees -- another rank dropping an agent changes it while this rank's record stays the same)
+        tail_rec = tuple(host_ints(batch["tail_record_len"])) if (self.exchange is not None and "tail_record_len" in batch) else None
+        key = (tuple(record), tail_rec, None if offsets is None else tuple(offsets), direct, pose_host is not None) + tuple((tuple(t.shape), str(t.dtype)) for t in src.values())
         slot = self._slots[k].get(key)
         M = cap = None
         if offsets is None and slot is None and self.pillar_buckets:
             M = int(src["voxel_features"].shape[0])
             cap = max(4096, 1 << max(M - 1, 0).bit_length())
-            bkey = (tuple(record), "bucket", cap, direct, pose_host is not None, tuple(src["voxel_features"].shape[1:]), tuple(src["pairwise_t_matrix"].shape))
+            bkey = (tuple(record), tail_rec, "bucket", cap, direct, pose_host is not None, tuple(src["voxel_features"].shape[1:]), tuple(src["pairwise_t_matrix"].shape))
             first = self._bucket_seen[k].setdefault(bkey, key)
             if bkey in self._slots[k] or first != key:           # a second shape of this bucket: the capacity-sized graph from here on
                 key = bkey
@@ -359,6 +365,7 @@ class FramePipeline:
                 self._records_ok = self._host_poses = False
                 return self._graphed(k, batch, record)
             self.graphs_captured += 1
+            slot.proto = None                                   # (the capture-time arrays gave shapes and dtypes only: not kept alive for the slot's lifetime)
             self._slots[k][key] = slot                          # only a slot whose capture succeeded is ever looked up again
         self.frames_in_place += slot.record is not None
         self.frames_copied += slot.record is None
@@ -453,6 +460,10 @@ class FramePipeline:
         return done + self.submit(batch, _t_submit=t_sub)
 
     def submit(self, batch: dict, _t_submit: Optional[float] = None) -> List[FrameResult]:
+        """Enqueue one frame; -> the frames that completed.  LIFETIME OF THE INPUTS: in graph mode a float32 / int32 contiguous frame on the lane's device is read
+        IN PLACE by the pillar launch (no input copy), so ``batch['processed_lidar']`` must stay UNMODIFIED until this frame's result has come back -- up to
+        ``result_lag`` submits later (the pipeline keeps the tensors referenced; it cannot keep a caller from refilling a preallocated batch).  A caller that
+        reuses its input buffers passes ``COALIGN_FRAME_RECORDS=0`` (every frame is copied into the graph's own buffers, as in rounds 2-4) or waits for the result."""
         import time
         t0 = time.perf_counter()
         t_sub = t0 if _t_submit is None else _t_submit

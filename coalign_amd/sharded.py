@@ -77,11 +77,14 @@ class FrameRing:
     ``[n_agents, C, H, W]`` holding MY frame's agents source-rank major, and ``rows[i]`` = the row of logical agent i
     (agent 0 = ego)."""
 
-    def __init__(self, n_agents: int, group=None, wire_dtype: Optional[torch.dtype] = None):
+    def __init__(self, n_agents: int, group=None, wire_dtype: Optional[torch.dtype] = None, force_collective: bool = False):
         self.n = n_agents
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # round 6: a world of ONE still runs the collective (a self all-to-all on the backend's own stream and buffers) -- how the RCCL path is exercised on a
+        # 1-GPU box (tests/test_round6_gpu.py, bench.py --force-dist); without it a single rank hands its maps straight through
+        self.force_collective = bool(force_collective) and dist.is_available() and dist.is_initialized()
         self.send_order, self.send_counts = send_plan(self.rank, self.world, self.n)
         self.recv_agents, self.recv_counts = recv_plan(self.rank, self.world, self.n)
         self.rows = [0] * self.n
@@ -95,7 +98,7 @@ class FrameRing:
         return encode_assignments(self.rank, self.world, self.n)
 
     def exchange(self, feats: Sequence[torch.Tensor]) -> Tuple[List[torch.Tensor], List[int]]:
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return list(feats), list(range(self.n))
         out, sent = [], 0
         for i, f in enumerate(feats):
@@ -135,11 +138,12 @@ class AgentGather:
     """Latency mode: the agents of ONE frame are split over the ranks, ``gather(feats)`` all-gathers the per-scale maps
     (``[per, C, H, W]`` on every rank, unused rows arbitrary) into ``[n_agents, C, H, W]`` in agent order on every rank."""
 
-    def __init__(self, n_agents: int, group=None, wire_dtype: Optional[torch.dtype] = None):
+    def __init__(self, n_agents: int, group=None, wire_dtype: Optional[torch.dtype] = None, force_collective: bool = False):
         self.n = n_agents
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.force_collective = bool(force_collective) and dist.is_available() and dist.is_initialized()      # (see FrameRing)
         self.per, self.blocks = agent_blocks(self.world, self.n)
         self.wire_dtype = wire_dtype
         self._recv: Dict[tuple, torch.Tensor] = {}
@@ -149,7 +153,7 @@ class AgentGather:
         return self.blocks[self.rank]
 
     def gather(self, feats: Sequence[torch.Tensor]) -> List[torch.Tensor]:
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return [f[: self.n] for f in feats]
         out, sent = [], 0
         for i, f in enumerate(feats):

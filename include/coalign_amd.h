@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define COALIGN_ABI_VERSION 1
+#define COALIGN_ABI_VERSION 2      /* round 6: M_rows / range_flag parameters of (9b) _ex, (9d), (10b) */
 
 typedef enum coalign_status {
     COALIGN_OK = 0,
@@ -353,8 +353,8 @@ enum { COALIGN_LAYOUT_NCHW = 0, COALIGN_LAYOUT_OUT_NHWC = 1, COALIGN_LAYOUT_IN_N
 size_t coalign_conv3x3_emu_weight_bytes_ex(int Cin, int Cout, int terms, int tap_major);
 size_t coalign_conv3x3_emu_workspace_bytes_ex(int N, int Cin, int Cout, int H, int W, int terms, int layout);
 int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const float *bias, const float *residual, float *y, int N, int Cin,
-                           int Cout, int Hin, int Win, int stride, int relu, int terms, int layout, void *workspace,
-                           size_t workspace_bytes, void *stream);
+                           int Cout, int Hin, int Win, int stride, int relu, int terms, int layout, int32_t *range_flag, void *workspace,
+                           size_t workspace_bytes, void *stream);      /* range_flag (SP map outputs; may be NULL): as in (9e) */
 
 /* terms = 16 (round 4; scale free since round 5): the fp16 split.  Every operand is an "sp16 pair" (csrc/common.h): the value rounded to 22 significant bits,
  * h = its leading 11 bits as fp16, l = the following 11 bits times 2^10 (a normal fp16 number for every |value| >= 2^-14); products w_h x_h in one fp32
@@ -426,10 +426,11 @@ int coalign_pillar_encode_sparse_frame(const coalign_pillar_frame *frame, int M_
                                        const double *voxel_size, const double *range_min, int n_agents, int ny, int nx, float *pillar_features, void *stamps,
                                        int32_t *state, void *stream);
 /* (9d) The strided 3x3 convolution of (9b) (stride 2, pad 1, bias + ReLU; resblock.py:150-174) reading the sparse canvas of (1b): feats [M, Cin], pixel
- * (n, y, x) of the logical [N, Hin, Win, Cin] input = feats row (stamp & 0xffffffff) where the cell's stamp carries state[0], else zero.
+ * (n, y, x) of the logical [N, Hin, Win, Cin] input = feats row (stamp & 0xffffffff) where the cell's stamp carries state[0] and names a row < M_rows (the rows
+ * behind feats: a stamp map shared with a later, larger frame can never index past the caller's array), else zero.
  * y: [N, Cout, ceil(Hin/2), ceil(Win/2)] NCHW, channels-last if out_nhwc == 1, an SP map (9e) if out_nhwc == 2 (terms 16).  terms in {2, 3, 16} with the tap-pair weight image of (9b). */
-int coalign_conv3x3_emu_sparse(const float *feats, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y, int N, int Cin,
-                               int Cout, int Hin, int Win, int relu, int terms, int out_nhwc, void *stream);
+int coalign_conv3x3_emu_sparse(const float *feats, int M_rows, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y, int N, int Cin,
+                               int Cout, int Hin, int Win, int relu, int terms, int out_nhwc, int32_t *range_flag, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * (10) Pointwise layers of the BEV backbone as one GEMM launch each, bias (+ ReLU) fused, NCHW float32:
@@ -462,7 +463,7 @@ int coalign_pointwise_conv_emu(const float *x, const void *w_split, const float 
 
 /* (10b) The 1 x 1 / stride-2 skip convolution of (10) on the split-bf16 matrix cores reading the sparse canvas of (1b) (resblock.py:165-174).
  * y: [N, Cout, ceil(Hin/2), ceil(Win/2)] NCHW, or channels-last if out_nhwc != 0 (Cout % 4 == 0). */
-int coalign_pointwise_conv_emu_sparse(const float *feats, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y, int N,
+int coalign_pointwise_conv_emu_sparse(const float *feats, int M_rows, const void *stamps, const int32_t *state, const void *w_split, const float *bias, float *y, int N,
                                       int Cin, int Hin, int Win, int Cout, int M_padded, int relu, int out_nhwc, void *stream);
 
 /* (10c) Round 5: (10) on the split-bf16 matrix cores writing its channel slice [c_off, c_off + Cout) of an SP map (9e) of Ctot channels instead of float32 --

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/coalign_amd.h but not exported"
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
-    assert lib.coalign_abi_version() == 1
+    assert lib.coalign_abi_version() == 2
     assert b"UNSUPPORTED" in lib.coalign_status_string(-3)
 
 

@@ -30,7 +30,7 @@ stride = int(os.environ.get("STRIDE", "1"))      # STRIDE=2: the first convoluti
 if stride == 2:
     layout = 2 | 8
 L = ctypes.CDLL(lib)
-L.coalign_conv3x3_emu_ex.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 9 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+L.coalign_conv3x3_emu_ex.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 9 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
 L.coalign_conv3x3_emu_workspace_bytes_ex.restype = ctypes.c_size_t
 L.coalign_conv3x3_emu_workspace_bytes_ex.argtypes = [ctypes.c_int] * 7
 x = torch.randn(N, Ci, H, W, device="cuda")
@@ -46,7 +46,7 @@ L.coalign_conv3x3_emu_set_trace(ctypes.c_void_p(tr.data_ptr()))
 scratch = torch.empty(max(1, L.coalign_conv3x3_emu_workspace_bytes_ex(N, Ci, Co, H, W, terms, layout)), dtype=torch.uint8, device="cuda")
 for _ in range(3):
     tr.zero_()
-    rc = L.coalign_conv3x3_emu_ex(x.data_ptr(), ws.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(), N, Ci, Co, H, W, stride, 1, terms, layout,
+    rc = L.coalign_conv3x3_emu_ex(x.data_ptr(), ws.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(), N, Ci, Co, H, W, stride, 1, terms, layout, None,
                                   scratch.data_ptr(), scratch.numel(), None)
     torch.cuda.synchronize()
 assert rc == 0, rc
@@ -74,7 +74,7 @@ else:
 L.coalign_conv3x3_emu_set_ablate.argtypes = [ctypes.c_int]
 L.coalign_conv3x3_emu_set_trace(None)
 def run():
-    return L.coalign_conv3x3_emu_ex(x.data_ptr(), ws.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(), N, Ci, Co, H, W, stride, 1, terms, layout,
+    return L.coalign_conv3x3_emu_ex(x.data_ptr(), ws.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(), N, Ci, Co, H, W, stride, 1, terms, layout, None,
                                     scratch.data_ptr(), scratch.numel(), None)
 tr.zero_()
 L.coalign_conv3x3_emu_set_trace(ctypes.c_void_p(tr.data_ptr()))
