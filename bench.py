@@ -298,6 +298,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="~150 eager launches per frame (1.5 ms of host time) instead of one HIP graph replay per frame "
                     "(0.1 ms; single-GPU default: measured +1 ... +4 % frames/s on the channels-last route; multi-rank runs are always eager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-numerics", action="store_true", help="skip the float64 end-to-end error report (`numerics`: two float64 CPU forwards of the benchmarked frame, ~20-40 s)")
     ap.add_argument("--conv-emu", type=int, default=None, choices=(0, 2, 3, 16),
                     help="override the 3x3 convolution arithmetic: 0 = native fp32 MFMA / MIOpen, 3 / 2 = split-bf16 products (default: the package default)")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the extra timed passes of the other convolution modes")
@@ -523,7 +524,10 @@ def main():
         return time.perf_counter() - t0, t_issue, [(i - base, b, sc) for i, b, sc in results]
 
     pipe = make_pipe(use_graph)
-    warm = max(args.warmup, 2 * n_lanes if use_graph else args.warmup)     # every lane captures its graph during the warm-up
+    # `warmup` is what was asked for.  The lanes' HIP graphs are captured BEFORE the warm-up, in a separate untimed pass reported as
+    # `config.lane_capture_frames` (one capture + one replay per pipeline lane: rounds 2-5 folded them into a raised warm-up count)
+    warm = args.warmup
+    capture_frames = 2 * n_lanes if use_graph else 0
     if multi:
         # the chosen schedule's first exchanges, guarded: any error on any rank moves ALL ranks to the next schedule (ring -> gather -> replicas;
         # coalign_amd.sharded.negotiate_schedule, CPU-tested with gloo ranks in tests/test_sharded_cpu.py)
@@ -592,7 +596,7 @@ def main():
                 rccl["exchange_timing_error"] = f"{type(e).__name__}: {str(e)[:160]}"
     if use_graph and (not multi):       # a capture that fails here (driver / allocator state of this box) must not cost the bench line: fall back to eager
         try:
-            for s_ in range(n_lanes):
+            for s_ in range(capture_frames):
                 pipe.submit(step_batches[s_ % len(step_batches)])
             pipe.drain()
             torch.cuda.synchronize()
@@ -887,7 +891,13 @@ def main():
             roofline = {"kernel": f"coalign_conv3x3_sp (csrc/conv3x3_sp.hip: v_mfma_f32_32x32x16_f16 on sp16 pairs, operands by LDS-DMA from the producer's SplitMap; "
                                   f"256->256 channels at {ny // 8}x{nx // 8}, N={N}; {dom['launches_per_frame']} launches per frame)",
                         "bound": "mfma", "achieved": dom["executed_TFLOPs"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac_of_fp16_peak"],
-                        "avg_launch_ms": round(dom["us"] / 1e3, 5), "algorithmic_flops_per_launch": executed, "fp32_equivalent_flops_per_launch": executed // 3,
+                        "avg_launch_ms": round(dom["us"] / 1e3, 5),
+                        # ALGORITHMIC = the layer's fp32 multiply-adds; EXECUTED = the 16-bit products the kernel issues for them (3 per
+                        # fp32 product).  `achieved` / `frac` price the executed products against the fp16 peak (what the matrix pipe does); `frac_algorithmic` prices
+                        # the algorithmic flops against the same peak, `frac_algorithmic_of_fp32_mfma_peak` against the 157.3 TFLOP/s an fp32-MFMA kernel is bounded by
+                        "algorithmic_flops_per_launch": executed // 3, "executed_flops_per_launch": executed,
+                        "frac_algorithmic": round(executed / 3 / (dom["us"] * 1e-6) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                        "frac_algorithmic_of_fp32_mfma_peak": round(executed / 3 / (dom["us"] * 1e-6) / 1e12 / F32_MFMA_PEAK_TFLOPS, 3),
                         "fp32_equivalent_TFLOPs": dom["fp32_equivalent_TFLOPs"], "traffic": int(dom["pmc_hbm_MB"] * 1e6) if "pmc_hbm_MB" in dom else None,
                         "note": "executed 16-bit products = 3 per fp32 product (w_h x_h, w_h x_l, w_l x_h of 22-bit operands); peak = dense fp16 MFMA (MI355X_MICROARCH.md); "
                                 "192 tiles of 16 intervals on 256 CUs: alone on the GPU a quarter of the CUs idle (in the 3-lane pipeline other frames' kernels take them)"}
@@ -901,7 +911,8 @@ def main():
                                    f"conv3x3_emu_bias_act (v_mfma_f32_32x32x16_bf16, fp32 operands split {t}-way, 64->64 channels at {ny // 2}x{nx // 2}, N={N})"),
                         "bound": "mfma", "achieved": round(executed / ms / 1e9, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(executed / ms / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms, 5),
-                        "algorithmic_flops_per_launch": executed, "fp32_equivalent_flops_per_launch": conv_flops,
+                        "algorithmic_flops_per_launch": conv_flops, "executed_flops_per_launch": executed,
+                        "frac_algorithmic": round(conv_flops / ms / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4),
                         "fp32_equivalent_TFLOPs": round(conv_flops / ms / 1e9, 1), "traffic": traffic_of(f"conv_bf16x{t}_64ch"),
                         "note": f"executed 16-bit products = {6 if t == 3 else 3} per fp32 product; peak = dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)"}
         else:
@@ -929,7 +940,7 @@ def main():
                                    f"geometry): {N} agents/frame, {args.pillars} pillars/agent, canvas {nx}x{ny}, 70400 anchors, "
                                    f"full path incl. decode + rotated NMS, {pool_n} distinct frames in rotation",
                        "agents_per_frame": N, "pillars_per_agent": args.pillars, "frames_per_step": frames_per_step, "frames_in_flight": n_lanes, "streams": n_streams, "frames_queued_per_stream": n_lanes // n_streams,
-                       "result_lag_frames": pipe.result_lag, "hip_graph": use_graph,
+                       "result_lag_frames": pipe.result_lag, "hip_graph": use_graph, "lane_capture_frames": capture_frames,
                        "inputs": ("resident in HBM, read in place through a 32-byte device record; pose matrices normalised on the host; one small host-to-device transfer per frame"
                                   if pipe.frames_in_place and not pipe.frames_copied else "resident in HBM, copied into the captured graph's input buffers every frame" if use_graph else "resident in HBM"), "conv_arithmetic": "native fp32" if default_terms == 0 else ("fp16 split (sp16 pairs)" + (", SplitMaps between the 3x3 layers" if backbone_mod.split_maps_active() else "")) if default_terms == 16 else f"bf16x{default_terms}",
                        "parallelism": "single GPU" if (not multi) else (f"agent-sharded frame ring x{world}, {'RCCL' if backend == 'nccl' else backend + ' (functional test)'} all-to-all" if mode == "ring" else
@@ -961,6 +972,19 @@ def main():
             result["size_sweep"] = size_sweep(dev, streams=lane_streams, lanes=n_streams if use_graph else 3, result_lag=result_lag if use_graph else 1, queue_depth=queue_depth if use_graph else 1)
         if (not multi) and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(hypes, model, frames_cpu, anchors, args.cpu_frames, args.cpu_threads, args.cpu_budget_s)
+        if (not multi) and not args.no_numerics:
+            # checker leg (like cpu_baseline: rank 0, N = 1, outside every timed region): the benchmarked geometry end to end against a FLOAT64 evaluation of the
+            # reference's forward, in the default arithmetic, bf16 x 3 and native fp32, beside the reference's own fp32 (tests/numerics_table.py)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import numerics_table
+                torch.cuda.empty_cache()
+                rows = [numerics_table.measure("cfg3", prm, dev, threads=min(32, os.cpu_count() or 1)) for prm in ("random_init", "trained_like")]
+                result["numerics"] = {"against": "oracle.coalign_forward(dtype=float64) on the same float32 inputs and parameters; errors as a fraction of max |float64 tensor|, worst head",
+                                      "rows": numerics_table.summarize(rows)["rows"], "per_head": rows,
+                                      "full_table": "profiles/round6/numerics.json (cfg 2 / 3 / 4 x random-init / trained-like; tests/test_round6_gpu.py asserts it)"}
+            except Exception as e:      # noqa: BLE001  a side report must never cost the headline line
+                result["numerics"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         print(json.dumps(result), flush=True)
     if multi:
         dist.barrier()
@@ -984,11 +1008,15 @@ def cpu_baseline(hypes, model, frames_cpu, anchors, n_frames, threads, budget_s)
     (profiles/round2/cpu_baseline_sweep.json, tools/cpu_baseline_sweep.py) -- one torch thread per core is pathologically slow
     for the tiny batched matmuls of the attention fusion on a many-core host."""
     from oracle import coalign_oracle as oracle
+    sweep_src, sweep_tab = None, None
+    import glob as _glob
+    found = sorted(_glob.glob(os.path.join(ROOT, "profiles", "round*", "cpu_baseline_sweep.json")), key=lambda q: int("".join(c for c in os.path.basename(os.path.dirname(q)) if c.isdigit()) or 0))
+    if found:                                    # the NEWEST committed sweep (tools/cpu_baseline_sweep.py on the current oracle, re-run every round the oracle changes)
+        sweep_src = os.path.relpath(found[-1], ROOT)
+        sw = json.load(open(found[-1]))
+        sweep_tab = {k: v.get("frames_per_s") for k, v in sw.get("threads", {}).items()}
     if threads <= 0:
-        threads = 16
-        sweep = os.path.join(ROOT, "profiles", "round2", "cpu_baseline_sweep.json")
-        if os.path.exists(sweep):
-            threads = int(json.load(open(sweep)).get("best_threads", 16))
+        threads = int(sw.get("best_threads", 16)) if found else 16
     cores = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -1006,9 +1034,10 @@ def cpu_baseline(hypes, model, frames_cpu, anchors, n_frames, threads, budget_s)
         done += 1
     dt = time.perf_counter() - t0
     return {"value": round(done / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_string(),
-            "host_cores": os.cpu_count(),
+            "host_cores": os.cpu_count(), "thread_sweep_frames_per_s": sweep_tab, "thread_sweep_source": sweep_src,
             "sample": f"1 warm-up + {done} timed frame(s) of the same 5-agent synthetic pool ({dt:.1f} s, cap {budget_s:.0f} s), torch CPU threads = {cores} "
-                      f"of {os.cpu_count()} host cores; thread sweep in profiles/round2/cpu_baseline_sweep.json"}
+                      f"of {os.cpu_count()} host cores = the best count of the committed thread sweep ({sweep_src}: one torch thread per core is pathologically slow "
+                      f"for the oracle's per-pixel batched matmuls; the sweep includes os.cpu_count() threads)"}
 
 
 if __name__ == "__main__":

@@ -559,17 +559,24 @@ __device__ int edge_crossing(F2 e1, F2 e0, F2 f1, F2 f0, F2 &hit) {
     return 1;
 }
 
-__device__ int inside_with_margin(const float *box, F2 pt) {
-    const float ca = cosf(-box[6]), sa = sinf(-box[6]);
+// Round 6: the trigonometry of row N is DEFINED instead of left to the math library: cos / sin / atan2 evaluated in float64 and rounded once to float32 (a
+// correctly rounded float function up to ~2^-29 double-rounding cases) -- an admissible cosf / sinf / atan2f like the CUDA run time's or glibc's, and the same bits
+// on the device and in the gcc-built oracle (oracle/rotated_nms.c: trig_*), so the IoU MATRIX is bit-comparable, not only the keep lists.
+// cos(-a) = cos(a) and sin(-a) = -sin(a) hold exactly for these, so one evaluation per box serves iou3d_nms_kernel.cu's cos(-angle) / sin(-angle) too.
+__device__ __forceinline__ float trig_cos(float a) { return (float)cos((double)a); }
+__device__ __forceinline__ float trig_sin(float a) { return (float)sin((double)a); }
+__device__ __forceinline__ float trig_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+
+__device__ int inside_with_margin(const float *box, F2 pt, float cos_a, float sin_a) {
+    const float ca = cos_a, sa = -sin_a;                // cos(-angle), sin(-angle)
     const float lx = (pt.x - box[0]) * ca + (pt.y - box[1]) * (-sa);
     const float ly = (pt.x - box[0]) * sa + (pt.y - box[1]) * ca;
     return fabsf(lx) < box[3] / 2 + 1e-2f && fabsf(ly) < box[4] / 2 + 1e-2f;
 }
 
-__device__ void box_corners_f32(const float *box, F2 *c) {
+__device__ void box_corners_f32(const float *box, F2 *c, float ca, float sa) {
     const float hx = box[3] / 2, hy = box[4] / 2;
     const float x1 = box[0] - hx, y1 = box[1] - hy, x2 = box[0] + hx, y2 = box[1] + hy;
-    const float ca = cosf(box[6]), sa = sinf(box[6]);
     const F2 raw[4] = {{x1, y1}, {x2, y1}, {x2, y2}, {x1, y2}};
     for (int k = 0; k < 4; ++k) {
         c[k].x = (raw[k].x - box[0]) * ca + (raw[k].y - box[1]) * (-sa) + box[0];
@@ -583,20 +590,25 @@ template <bool AREA>
 __device__ float pcdet_iou(const float *A7, const float *B7) {
     F2 A[5], B[5], pts[16], ctr = {0.f, 0.f};
     int cnt = 0;
-    box_corners_f32(A7, A);
-    box_corners_f32(B7, B);
+    const float cos_a = trig_cos(A7[6]), sin_a = trig_sin(A7[6]), cos_b = trig_cos(B7[6]), sin_b = trig_sin(B7[6]);
+    box_corners_f32(A7, A, cos_a, sin_a);
+    box_corners_f32(B7, B, cos_b, sin_b);
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j)
             if (edge_crossing(A[i + 1], A[i], B[j + 1], B[j], pts[cnt])) { ctr.x += pts[cnt].x; ctr.y += pts[cnt].y; ++cnt; }
     for (int k = 0; k < 4; ++k) {
-        if (inside_with_margin(A7, B[k])) { ctr.x += B[k].x; ctr.y += B[k].y; pts[cnt++] = B[k]; }
-        if (inside_with_margin(B7, A[k])) { ctr.x += A[k].x; ctr.y += A[k].y; pts[cnt++] = A[k]; }
+        if (inside_with_margin(A7, B[k], cos_a, sin_a)) { ctr.x += B[k].x; ctr.y += B[k].y; pts[cnt++] = B[k]; }
+        if (inside_with_margin(B7, A[k], cos_b, sin_b)) { ctr.x += A[k].x; ctr.y += A[k].y; pts[cnt++] = A[k]; }
     }
     ctr.x /= cnt; ctr.y /= cnt;
+    // the reference's bubble sort by polar angle; the angle of a point is evaluated once (a pure function of the point: the same comparisons, the same order)
+    float ang[16];
+    for (int i = 0; i < cnt; ++i) ang[i] = trig_atan2(pts[i].y - ctr.y, pts[i].x - ctr.x);
     for (int j = 0; j < cnt - 1; ++j)
         for (int i = 0; i < cnt - j - 1; ++i)
-            if (atan2f(pts[i].y - ctr.y, pts[i].x - ctr.x) > atan2f(pts[i + 1].y - ctr.y, pts[i + 1].x - ctr.x)) {
+            if (ang[i] > ang[i + 1]) {
                 const F2 t = pts[i]; pts[i] = pts[i + 1]; pts[i + 1] = t;
+                const float ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
             }
     float area = 0.f;
     for (int k = 0; k < cnt - 1; ++k) {

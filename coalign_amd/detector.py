@@ -275,6 +275,50 @@ def build_model(hypes: dict) -> nn.Module:
     return MODEL_REGISTRY[name](hypes["model"]["args"])
 
 
+def load_saved_model(saved_path: str, model: nn.Module):
+    """``train_utils.load_saved_model`` (opencood/tools/train_utils.py:29-74): find the checkpoint of a training folder and load it into ``model``.
+
+    * ``net_epoch_bestval_at<E>.pth`` present (exactly one is allowed) -> that file, returns ``(E, model)``;
+    * else the highest ``net_epoch<E>.pth`` among ``*epoch*.pth`` -> that file, returns ``(E, model)``;
+    * else nothing is loaded and ``(0, model)`` comes back.
+
+    Like the reference: tensors are loaded onto the CPU (``map_location='cpu'``) and copied into whatever device the model lives on, ``strict=False`` (keys the
+    model does not have are ignored, keys the file lacks keep their initial values), a missing folder is an ``AssertionError``.  Unlike the reference the epoch is
+    parsed with a regular expression, never ``eval``-ed, and the file is read with ``weights_only=True`` (a ``state_dict`` holds tensors only)."""
+    import glob
+    import os
+    import re
+    assert os.path.exists(saved_path), "{} not found".format(saved_path)
+
+    def load(path):
+        try:
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+        except TypeError:                       # (a torch without the keyword)
+            sd = torch.load(path, map_location="cpu")
+        model.load_state_dict(sd, strict=False)
+
+    best = glob.glob(os.path.join(saved_path, "net_epoch_bestval_at*.pth"))
+    if best:
+        assert len(best) == 1
+        m = re.fullmatch(r"net_epoch_bestval_at(\d+)\.pth", os.path.basename(best[0]))
+        if m is None:
+            raise ValueError(f"cannot read the epoch out of '{os.path.basename(best[0])}'")
+        epoch = int(m.group(1))
+        print("resuming best validation model at epoch %d" % epoch)
+        load(best[0])
+        return epoch, model
+    epochs = []
+    for f in glob.glob(os.path.join(saved_path, "*epoch*.pth")):
+        m = re.search(r"epoch(\d+)\.pth", os.path.basename(f))
+        if m is not None:
+            epochs.append(int(m.group(1)))
+    initial_epoch = max(epochs) if epochs else 0
+    if initial_epoch > 0:
+        print("resuming by loading epoch %d" % initial_epoch)
+        load(os.path.join(saved_path, "net_epoch%d.pth" % initial_epoch))
+    return initial_epoch, model
+
+
 def to_device(inputs, device):
     """Recursive ``.to(device)`` over lists / dicts; non-tensors pass through (opencood/tools/train_utils.py:249-258)."""
     if isinstance(inputs, list):

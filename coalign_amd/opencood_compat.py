@@ -41,7 +41,7 @@ _EXPORTS: Dict[str, Dict[str, object]] = {
     "opencood.data_utils.post_processor": {"build_postprocessor": postprocess.build_postprocessor,
                                            "VoxelPostprocessor": postprocess.VoxelPostprocessor},
     "opencood.hypes_yaml.yaml_utils": {"load_yaml": config.load_yaml, "load_point_pillar_params": config.load_point_pillar_params},
-    "opencood.tools.train_utils": {"create_model": detector.build_model, "to_device": detector.to_device},
+    "opencood.tools.train_utils": {"create_model": detector.build_model, "to_device": detector.to_device, "load_saved_model": detector.load_saved_model},
     # rows N and the "next" rows of SURVEY section 8
     "opencood.pcdet_utils.iou3d_nms.iou3d_nms_utils": {"nms_gpu": pcdet.nms_gpu, "boxes_iou_bev": pcdet.boxes_iou_bev,
                                                        "boxes_iou3d_gpu": pcdet.boxes_iou3d_gpu, "nms_normal_gpu": pcdet.nms_normal_gpu},

@@ -52,7 +52,7 @@ def pillar_augment(voxel_features: torch.Tensor, voxel_num_points: torch.Tensor,
     (agent, z, y, x) (:123-131) with offsets ``voxel/2 + range_min`` (:84-89, python floats).
     Rows with index >= num_points are multiplied by 0 (:144-149).
     """
-    vf = voxel_features.float()
+    vf = voxel_features if voxel_features.dtype == torch.float64 else voxel_features.float()      # (float64: the yardstick form of coalign_forward(dtype=...))
     npts = voxel_num_points.to(vf.dtype).view(-1, 1, 1)
     xyz = vf[:, :, :3]
     mean = xyz.sum(dim=1, keepdim=True) / npts
@@ -180,6 +180,7 @@ def grid_sample_bilinear_zeros(src: torch.Tensor, grid: torch.Tensor) -> torch.T
     weights nw=(1-tx)(1-ty) ...; out-of-range taps contribute 0.
     """
     N, C, H, W = src.shape
+    grid = grid.to(src.dtype)                                    # (float32 in the reference; the float64 yardstick keeps the float32-ROUNDED sampling positions)
     gx, gy = grid[..., 0], grid[..., 1]
     ix = (gx + 1.0) * (W / 2.0) - 0.5
     iy = (gy + 1.0) * (H / 2.0) - 0.5
@@ -326,12 +327,18 @@ def naive_compressor(x: torch.Tensor, sd, prefix: str = "naive_compressor.") -> 
     return x
 
 
-def coalign_forward(sd, margs: dict, batch: dict, return_intermediate: bool = False):
-    """PointPillarBaselineMultiscale.forward, opencood/models/point_pillar_baseline_multiscale.py:93-135."""
+def coalign_forward(sd, margs: dict, batch: dict, return_intermediate: bool = False, dtype: torch.dtype = torch.float32):
+    """PointPillarBaselineMultiscale.forward, opencood/models/point_pillar_baseline_multiscale.py:93-135.
+
+    ``dtype=torch.float64`` (round 6): the SAME function of the same float32 inputs and float32 parameters evaluated in float64 -- the yardstick every float32
+    arithmetic (the reference's own op-by-op fp32, this build's convolution modes) is measured against.  What stays as the reference defines it: the sampling grid
+    is built in float64 and ROUNDED to float32 (torch_transformation_utils.py:328-330), i.e. the same sampling positions; everything else is exact to 2^-53."""
     pl = batch["processed_lidar"]
     rl = batch["record_len"]
     nx, ny, _ = [int(v) for v in margs["point_pillar_scatter"]["grid_size"]]
-    pf = pillar_vfe(pl["voxel_features"], pl["voxel_num_points"], pl["voxel_coords"], sd,
+    if dtype != torch.float32:
+        sd = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in sd.items()}
+    pf = pillar_vfe(pl["voxel_features"].to(dtype), pl["voxel_num_points"], pl["voxel_coords"], sd,
                     margs["voxel_size"], margs["lidar_range"])
     n_total = int(rl.sum())
     canvas = scatter(pf, pl["voxel_coords"], n_total, nx, ny)

@@ -164,10 +164,17 @@ static int seg_isect(F2 p1, F2 p0, F2 q1, F2 q0, F2 *ans) {
     return 1;
 }
 
+/* The float cos / sin / atan2 of row N, DEFINED (round 6): evaluated in float64 and rounded once to float32 -- an admissible cosf / sinf / atan2f (<= 0.5 ulp up to
+ * ~2^-29 double-rounding cases) like the CUDA run time's behind iou3d_nms_kernel.cu or glibc's behind iou3d_cpu.cpp, and the same bits here and in the device
+ * kernel (coalign_amd/csrc/nms.hip: trig_*), so the IoU matrices are compared bit for bit (tests/test_hip_parity.py::test_pcdet_iou_bev_vs_oracle). */
+static float trig_cos(float a) { return (float)cos((double)a); }
+static float trig_sin(float a) { return (float)sin((double)a); }
+static float trig_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+
 static int in_box_margin(const float *box, F2 p) {
     /* iou3d_cpu.cpp:76-87; cos/sin on a float argument resolve to the float overloads in C++. */
     const float cx = box[0], cy = box[1];
-    const float ca = cosf(-box[6]), sa = sinf(-box[6]);
+    const float ca = trig_cos(-box[6]), sa = trig_sin(-box[6]);
     const float rx = (p.x - cx) * ca + (p.y - cy) * (-sa);
     const float ry = (p.x - cx) * sa + (p.y - cy) * ca;
     return fabsf(rx) < box[3] / 2 + 1e-2f && fabsf(ry) < box[4] / 2 + 1e-2f;
@@ -176,7 +183,7 @@ static int in_box_margin(const float *box, F2 p) {
 static void box_corners_f32(const float *box, F2 *c /*[5]*/) {
     const float hx = box[3] / 2, hy = box[4] / 2;
     const float x1 = box[0] - hx, y1 = box[1] - hy, x2 = box[0] + hx, y2 = box[1] + hy;
-    const float ca = cosf(box[6]), sa = sinf(box[6]);
+    const float ca = trig_cos(box[6]), sa = trig_sin(box[6]);
     const F2 raw[4] = {{x1, y1}, {x2, y1}, {x2, y2}, {x1, y2}};
     for (int k = 0; k < 4; ++k) {
         c[k].x = (raw[k].x - box[0]) * ca + (raw[k].y - box[1]) * (-sa) + box[0];
@@ -202,7 +209,7 @@ float oracle_pcdet_overlap(const float *box_a, const float *box_b) {
     ctr.x /= cnt; ctr.y /= cnt;
     for (int j = 0; j < cnt - 1; ++j)           /* bubble sort by polar angle, as the reference does */
         for (int i = 0; i < cnt - j - 1; ++i)
-            if (atan2f(pts[i].y - ctr.y, pts[i].x - ctr.x) > atan2f(pts[i + 1].y - ctr.y, pts[i + 1].x - ctr.x)) {
+            if (trig_atan2(pts[i].y - ctr.y, pts[i].x - ctr.x) > trig_atan2(pts[i + 1].y - ctr.y, pts[i + 1].x - ctr.x)) {
                 F2 t = pts[i]; pts[i] = pts[i + 1]; pts[i + 1] = t;
             }
     float area = 0.f;

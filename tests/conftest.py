@@ -48,3 +48,16 @@ def conv_mode(request):
     backbone.CONV_EMU_TERMS = request.param
     yield request.param
     backbone.CONV_EMU_TERMS = saved
+
+
+def assert_elementwise(got, ref, what="", rtol=1e-4, floor=1e-5):
+    """End-to-end tensors are compared ELEMENT-WISE, not by one max-norm scalar: |got - ref| <= rtol * |ref| + floor * max |ref| for every element
+    (the bound of tests/test_hip_parity.py::feat_close: an order of magnitude inside the north star's 1e-3).  Returns max |diff| / max |ref| for the callers' printouts."""
+    import torch
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, tuple(got.shape), tuple(ref.shape))
+    scale = max(float(ref.abs().max()), 1e-30)
+    err = (got - ref).abs()
+    bad = err > rtol * ref.abs() + floor * scale
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())} of {bad.numel()} elements outside rtol {rtol} + {floor} of the scale; worst {float(err.max()) / scale:.3e} of the scale"
+    return float(err.max()) / scale

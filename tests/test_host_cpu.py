@@ -479,3 +479,61 @@ def test_product_library_reads_no_laboratory_switch():
         build.build(lab=True)
     lab = names(build.LAB_LIB_PATH)
     assert {b"COALIGN_EMU_STACK", b"COALIGN_EMU_TAPK_ROWS", b"COALIGN_PILLAR_DEBUG", b"COALIGN_WINO_ABL", b"COALIGN_PW_PB"} <= lab
+
+
+def test_load_saved_model_matches_reference(golden, tmp_path):
+    """``load_saved_model`` (opencood/tools/train_utils.py:29-74; SURVEY section 2 row 16, section 8b "Weights"): which checkpoint of a training folder is chosen, the
+    returned epoch, strict=False semantics and the failure cases equal what the REFERENCE'S OWN function did on the same folder layouts
+    (tests/golden/checkpoint.npz, written by tests/golden/make_checkpoint_golden.py); then a real detector round trip through a ``net_epoch_bestval_at*.pth`` file."""
+    from coalign_amd.detector import load_saved_model
+    g = golden("checkpoint.npz")
+    initial = float(g["initial"])
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.marker = torch.nn.Parameter(torch.full((1,), initial))
+            self.other = torch.nn.Parameter(torch.full((2,), initial))
+
+    for name in [str(n) for n in g["layouts"]]:
+        d = tmp_path / name
+        d.mkdir()
+        files = [str(f) for f in g[f"{name}.files"] if str(f)]
+        for i, n in enumerate(files):                                 # the generator's populate(): marker 100 + i per .pth file, an unknown key, `other` missing
+            if n.endswith(".pth"):
+                torch.save({"marker": torch.full((1,), float(100 + i)), "not_in_the_model": torch.zeros(3)}, str(d / n))
+            else:
+                (d / n).write_text("x")
+        m = Tiny()
+        raised = str(g[f"{name}.raised"])
+        if raised:
+            with pytest.raises(AssertionError):
+                load_saved_model(str(d), m)
+            assert float(m.marker.item()) == initial
+            continue
+        epoch, m2 = load_saved_model(str(d), m)
+        assert m2 is m
+        assert epoch == int(g[f"{name}.epoch"]), name
+        assert float(m.marker.item()) == float(g[f"{name}.marker"]), name
+        assert float(m.other[0].item()) == float(g[f"{name}.other"]), name
+    with pytest.raises(AssertionError, match=str(g["missing_folder.message"])):
+        load_saved_model("/nonexistent/coalign/folder", Tiny())
+    # ---- the detector itself: a checkpoint under the reference's best-validation name, loaded into a differently initialised model, through the opencood alias
+    from coalign_amd.synthetic import fill_parameters_
+    h = builtin_config("mini_coalign")
+    src, dst = build_model(h), build_model(h)
+    fill_parameters_(src, seed=5)
+    fill_parameters_(dst, seed=6)
+    ck = tmp_path / "trained"
+    ck.mkdir()
+    torch.save(src.state_dict(), str(ck / "net_epoch_bestval_at31.pth"))
+    torch.save(dst.state_dict(), str(ck / "net_epoch40.pth"))        # a later plain epoch must NOT win over the best-validation file
+    if not (os.path.isdir("/root/reference") and "/root/reference" in sys.path):
+        from coalign_amd import opencood_compat
+        opencood_compat.install()
+        from opencood.tools.train_utils import load_saved_model as aliased
+        assert aliased is load_saved_model
+    epoch, out = load_saved_model(str(ck), dst)
+    assert epoch == 31 and out is dst
+    a, b = src.state_dict(), dst.state_dict()
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)

@@ -167,7 +167,9 @@ def test_trained_like_parameters_vs_oracle_default_arithmetic(case):
         out = model(fd)
         ref = oracle.coalign_forward(sd, h["model"]["args"], frame)
     for k in ("cls_preds", "reg_preds", "dir_preds"):
-        e = rel_err(out[k], ref[k])
+        from conftest import assert_elementwise      # (round 6: element-wise; the floor for these parameter sets is set by the fp32 reference's own
+        # distance from float64 on them -- tests/test_round6_gpu.py::test_end_to_end_error_against_float64_by_arithmetic measures both sides)
+        e = assert_elementwise(out[k], ref[k], f"{config} trained-like {k}", rtol=1e-4, floor=1e-4)
         print(f"{config} trained-like {k}: max |diff| / max |ref| = {e:.2e}")
         assert e < 1e-4, k
     anchors = T(pp.generate_anchor_box())

@@ -67,7 +67,7 @@ else:
         mixed = {k: min((n for n in score if n.startswith("tapk")), key=lambda n: rows[n][k]["us"]) for k in weight}
         print("best tap-major setting per shape:", mixed)
     for name, env in runs + [("tapk_v3_r0", {"COALIGN_EMU_TAPK": "1", "COALIGN_EMU_TAPK_VAR": "3"})]:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-side-modes"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=400)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline --no-numerics", "--no-side-modes"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=400)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if line:
             d = json.loads(line[0])

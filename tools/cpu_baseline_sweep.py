@@ -20,8 +20,12 @@ for line in open("/proc/cpuinfo"):
     if line.startswith("model name"):
         cpu = line.split(":", 1)[1].strip(); break
 res = {"cpu_model": cpu, "host_cores": os.cpu_count(), "workload": "5 agents x 8000 pillars, OPV2V CoAlign, model + post-process", "threads": {}}
-budget = float(os.environ.get("SWEEP_BUDGET_S", "20"))
-for t in (4, 8, 16, 32, 64, 128):
+budget = float(os.environ.get("SWEEP_BUDGET_S", "15"))
+for t in sorted({1, 2, 4, 8, 16, 32, 64, os.cpu_count() or 1}):      # os.cpu_count() threads is one of the points (and the slowest on a many-core host)
+    prev = [v["frames_per_s"] for v in res["threads"].values() if v.get("frames_per_s")]
+    if prev and prev[-1] < 0.03 and t > 64:      # (round 6: 256 threads did not finish two frames in 10 minutes; the rate falls monotonically from 4 threads on)
+        res["threads"][str(t)] = {"frames": 0, "frames_per_s": None, "note": f"skipped: the previous point ran at {prev[-1]} frames/s and the rate falls with the thread count"}
+        continue
     torch.set_num_threads(t)
     with torch.no_grad():
         out = oracle.coalign_forward(sd, h["model"]["args"], frames[0]); oracle.post_process([out], anchors, h["postprocess"])      # warm-up
@@ -30,6 +34,6 @@ for t in (4, 8, 16, 32, 64, 128):
             out = oracle.coalign_forward(sd, h["model"]["args"], frames[n % 2]); oracle.post_process([out], anchors, h["postprocess"]); n += 1
     res["threads"][str(t)] = {"frames": n, "frames_per_s": round(n / (time.perf_counter() - t0), 4)}
     print(t, res["threads"][str(t)], file=sys.stderr, flush=True)
-best = max(res["threads"], key=lambda k: res["threads"][k]["frames_per_s"])
+best = max(res["threads"], key=lambda k: res["threads"][k]["frames_per_s"] or 0.0)
 res["best_threads"] = int(best)
 print(json.dumps(res))

@@ -3,23 +3,23 @@
 # per-frame detection digests as the 1-rank run: real frames are routed through the frame ring, not i.i.d. per rank.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/multirank; mkdir -p $OUT; cd $ROOT
-timeout 300 python bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-side-modes --no-from-points --no-latency --no-size-sweep > $OUT/n1.json 2> $OUT/n1.err
+timeout 300 python bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-numerics --no-side-modes --no-from-points --no-latency --no-size-sweep > $OUT/n1.json 2> $OUT/n1.err
 # round 5: the ranks are started by bench.py ITSELF (`python bench.py --gpus R`, no launcher) and every lane replays two HIP graphs per frame around its exchange
 for R in ${RING_RANKS:-2 4}; do
-COALIGN_BENCH_BACKEND=gloo COALIGN_BENCH_ONE_GPU=1 timeout 600 python bench.py --gpus $R --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes --no-size-sweep > $OUT/n$R.json 2> $OUT/n$R.err
+COALIGN_BENCH_BACKEND=gloo COALIGN_BENCH_ONE_GPU=1 timeout 600 python bench.py --gpus $R --steps 8 --warmup 2 --no-cpu-baseline --no-numerics --no-side-modes --no-size-sweep > $OUT/n$R.json 2> $OUT/n$R.err
 done
 # north_star's wording: ONE frame, agents split over the ranks, all-gather, ego tail (bench.py --mode gather); 2 and 5 ranks (5 = one agent per rank)
 # (6 ranks for 5 agents: one rank encodes an EMPTY agent block -- the sparse canvas of a frame without pillars)
 for R in ${GATHER_RANKS:-2 5 6}; do
 COALIGN_BENCH_BACKEND=gloo COALIGN_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $R --master-addr 127.0.0.1 --master-port $((29670 + R)) \
-    bench.py --gpus $R --mode gather --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes --no-size-sweep > $OUT/g$R.json 2> $OUT/g$R.err
+    bench.py --gpus $R --mode gather --steps 8 --warmup 2 --no-cpu-baseline --no-numerics --no-side-modes --no-size-sweep > $OUT/g$R.json 2> $OUT/g$R.err
 done
 # the fall-back chain with injected failures (raised on EVERY rank before the schedule's first collective: with host-blocking gloo collectives a failure on
 # one rank only would leave its peer inside the collective until the process-group timeout): ring fails -> gather; ring and gather fail -> independent replicas
 COALIGN_BENCH_INJECT_FAIL="ring:0,ring:1" COALIGN_BENCH_BACKEND=gloo COALIGN_BENCH_ONE_GPU=1 timeout 150 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29691 \
-    bench.py --gpus 2 --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes --no-size-sweep > $OUT/f1.json 2> $OUT/f1.err
+    bench.py --gpus 2 --steps 8 --warmup 2 --no-cpu-baseline --no-numerics --no-side-modes --no-size-sweep > $OUT/f1.json 2> $OUT/f1.err
 [ -n "${SKIP_F2:-}" ] || COALIGN_BENCH_INJECT_FAIL="ring:0,ring:1,gather:0,gather:1" COALIGN_BENCH_BACKEND=gloo COALIGN_BENCH_ONE_GPU=1 timeout 150 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29692 \
-    bench.py --gpus 2 --steps 8 --warmup 2 --no-cpu-baseline --no-side-modes --no-size-sweep > $OUT/f2.json 2> $OUT/f2.err
+    bench.py --gpus 2 --steps 8 --warmup 2 --no-cpu-baseline --no-numerics --no-side-modes --no-size-sweep > $OUT/f2.json 2> $OUT/f2.err
 python - $OUT <<'PY'
 import json,sys
 out=sys.argv[1]

@@ -6,7 +6,7 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/round; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
 cd $ROOT
 timeout 600 python bench.py 2> $OUT/bench.err | tee $OUT/bench_n1.json | cut -c1-300
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py --no-cpu-baseline --no-side-modes --no-size-sweep --no-from-points --no-latency > $OUT/stats.log 2>&1 )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py --no-cpu-baseline --no-numerics --no-side-modes --no-size-sweep --no-from-points --no-latency > $OUT/stats.log 2>&1 )
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cp $(find $OUT/stats -name "*domain_stats.csv" | head -1) $OUT/domain_stats.csv
 grep -h '"metric"' $OUT/stats.log > $OUT/bench_n1_under_rocprof.json
@@ -52,7 +52,7 @@ for op,d in res.items():
     print(op, {k: round(v) for k,v in d.items() if k.startswith("hbm")}, "L2 hit", round(d["per_op_call"].get("TCC_HIT_sum",0)/max(1,d["per_op_call"].get("TCC_HIT_sum",0)+d["per_op_call"].get("TCC_MISS_sum",0)),3))
 PY
 if [ -z "${SKIP_SWEEP:-}" ]; then
-  timeout 400 python tools/cpu_baseline_sweep.py > $OUT/cpu_baseline_sweep.json 2> $OUT/cpu_sweep.err
+  timeout 900 python tools/cpu_baseline_sweep.py > $OUT/cpu_baseline_sweep.json 2> $OUT/cpu_sweep.err
   cat $OUT/cpu_baseline_sweep.json | cut -c1-600
 fi
 python - $OUT/kernel_stats.csv <<'PY'

@@ -5,7 +5,7 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/steady; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
 A=${STEPS_A:-40}; B=${STEPS_B:-140}
 for S in $A $B; do
-  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s$S -- python $ROOT/bench.py --steps $S ${BENCH_ARGS:-} --no-cpu-baseline --no-side-modes --no-size-sweep --no-from-points --no-latency > $OUT/s$S.log 2>&1 )
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s$S -- python $ROOT/bench.py --steps $S ${BENCH_ARGS:-} --no-cpu-baseline --no-numerics --no-side-modes --no-size-sweep --no-from-points --no-latency > $OUT/s$S.log 2>&1 )
 done
 python - $OUT $A $B <<'PY'
 import csv, glob, sys, json
