@@ -77,8 +77,8 @@ struct Geo {
     static constexpr int WQ = 9 * 2 * 2 * kCoutTile;                           // 16-byte groups of one interval's weights
     static constexpr int WINS = WQ / 64;
     static constexpr int W_BYTES = WQ * 16, B_BYTES = 4 * PIXP * 16;
-    static constexpr size_t LDS_BYTES = 2 * (size_t)W_BYTES + 2 * (size_t)B_BYTES;
-    static_assert(LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
+    static constexpr size_t LDS_BYTES = 2 * (size_t)W_BYTES + 2 * (size_t)B_BYTES;      // both operands double buffered (Work::LDS_BYTES: what a mode really takes)
+    static_assert(W_BYTES + B_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS");
 };
 
 struct Tile {
@@ -107,27 +107,43 @@ enum { SP_RES_NONE = 0, SP_RES_SP = 1, SP_RES_NHWC = 2 };
 //   3  one EXTRA wavefront per workgroup that only issues the DMA (8-wavefront geometries: 9 wavefronts = three per SIMD within the register budget):
 //      the computing wavefronts' instruction streams are ds_read + matrix instructions only;
 //   4  as 1, the tap's DMA instructions IN FRONT of its matrix instructions;   5  as 1, front-loaded: two instructions behind each of the first taps.
+//   7  (round 6) as 3 with FOUR loader wavefronts, one per SIMD (8-wavefront geometries: 12 wavefronts = three per SIMD within the register budget): 17 DMA
+//      instructions per loader and interval instead of 68 on one -- the computing wavefronts' streams are ds_read + matrix instructions only;
+//   6  (round 6) TWO WORKGROUPS PER CU, out of phase: ONE weight buffer + ONE patch buffer (65-70 KB of LDS on the 8-wavefront geometries), registers capped at
+//      128 (four wavefronts per SIMD), every wavefront issues its share of the next interval's DMA at once behind the barrier that ends an interval and waits for it.
+//      A workgroup alone would expose the DMA latency every interval; its PARTNER on the CU runs matrix steps meanwhile (and through the other one's tile prologue,
+//      epilogue and barrier waits: profiles/round5/experiments/conv_sp_epilogue_phases.md named this remedy).  The workgroup in the CU's odd slot (HW_ID.TG_ID) issues
+//      at a higher priority, so that two workgroups that start in step fall out of step instead of sharing the pipe and then loading together.
 template <int BH, int BW, int NPB, int NBX, int MODE>
 struct Work {
     using G = Geo<BH, BW, NPB, NBX>;
-    static constexpr int LOADERS = MODE == 2 ? 4 : MODE == 3 ? 1 : G::WAVES;
+    static constexpr int EXTRA = MODE == 3 ? 1 : MODE == 7 ? 4 : 0;             // loader-only wavefronts on top of the computing ones (MODE 7, round 6: one per SIMD)
+    static constexpr int LOADERS = MODE == 2 ? 4 : EXTRA ? EXTRA : G::WAVES;
     static constexpr bool INTERLEAVED = MODE == 1 || MODE == 4 || MODE == 5;
-    static constexpr int THREADS = G::THREADS + (MODE == 3 ? 64 : 0);
+    static constexpr bool PAIRED = MODE == 6;                                   // two workgroups per CU, single buffers
+    static constexpr int NBUF = PAIRED ? 1 : 2;
+    static constexpr size_t LDS_BYTES = (size_t)NBUF * ((size_t)G::W_BYTES + (size_t)G::B_BYTES);
+    static constexpr int WAVES_PER_EU = PAIRED ? 4 : (NPB + 3) / 4;              // (the defaults the work-group size implies, except for the paired mode's cap)
+    static_assert(!PAIRED || NPB == 8, "two workgroups per CU: 8-wavefront geometries (16 wavefronts per CU = 4 per SIMD at 128 registers)");
+    static_assert(!PAIRED || 2 * LDS_BYTES <= 160 * 1024, "two workgroups of this geometry do not fit the 160 KB LDS");
+    static_assert(LDS_BYTES <= 160 * 1024, "geometry does not fit the 160 KB LDS in this mode");
+    static constexpr int THREADS = G::THREADS + 64 * EXTRA;
     static constexpr int WJ = (G::WINS + LOADERS - 1) / LOADERS, PJ = (G::PINS + LOADERS - 1) / LOADERS, OPS = WJ + 4 * PJ;
 };
 
 template <int BH, int BW, int NPB, int NBX, int OUT, int MODE, bool SPLIT>
-__global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_kernel(const SpArgs a) {
+__global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), (MODE == 6 ? 4 : MODE == 7 ? (NPB + 7) / 4 : (NPB + 3) / 4)) void conv3x3_sp_kernel(const SpArgs a) {
     using G = Geo<BH, BW, NPB, NBX>;
     using K = Work<BH, BW, NPB, NBX, MODE>;
+    static_assert(!(K::PAIRED && SPLIT), "the paired mode runs whole tiles");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;
     const int HW = a.H * a.W, CI16 = a.Cin / 16, CO16 = a.Cout / 16, groups = a.Cout / kCoutTile, chunks = CI16;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
-    // LDS map: weight buffers 0 | 1, patch buffers 0 | 1
+    // LDS map: weight buffers 0 | 1, patch buffers 0 | 1 (paired mode: one of each)
     int member_cg = 0;                                                        // (set below, before decode() is first called)
-    const bool loader = MODE == 3 ? wave == G::WAVES : wave < K::LOADERS, compute = wave < G::WAVES;
-    const int lw = MODE == 3 ? 0 : wave;                                      // index among the loaders
+    const bool loader = K::EXTRA ? wave >= G::WAVES : wave < K::LOADERS, compute = wave < G::WAVES;
+    const int lw = K::EXTRA ? (wave >= G::WAVES ? wave - G::WAVES : 0) : wave;      // index among the loaders
 
     const int blk_y = wave / NBX, blk_x = wave - blk_y * NBX;                 // this wavefront's pixel block inside the tile
     // Lane -> pixel inside the block.  2 x 16 blocks (PW = 18: a patch row is 288 bytes = 256 + 32): row 1's columns are rotated by two, so that the four lane
@@ -192,7 +208,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
         } else {
             const int j = (k - K::WJ) / 4, q = (k - K::WJ) % 4, ins = lw + K::LOADERS * j;
             if (ins < G::PINS && !SP_ABLATE(2))
-                dma16(pl.off[j] < 0 ? a.zero : a.x + (size_t)pl.off[j] + ((size_t)c * 4 + q) * HW, lds0 + 2 * G::W_BYTES + slot * G::B_BYTES + (q * G::PIXP + ins * 64) * 16);
+                dma16(pl.off[j] < 0 ? a.zero : a.x + (size_t)pl.off[j] + ((size_t)c * 4 + q) * HW, lds0 + K::NBUF * G::W_BYTES + slot * G::B_BYTES + (q * G::PIXP + ins * 64) * 16);
         }
     };
     auto issue_all = [&](const Plan &pl, int c, int slot) {
@@ -226,14 +242,17 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
     const int n_local = SPLIT ? range_start(gang + 1) - s0 : ((a.total_tiles - g + n_wg - 1) / n_wg) * chunks;
     if (n_local <= 0) return;
 #ifdef SP_TRACE
-    if (tid == 0) a.trace[2 * 16 * 64 * 8 + 2 * g] = wall_clock64();
+    if (tid == 0) {
+        a.trace[2 * 16 * 64 * 8 + 2 * g] = wall_clock64();
+        if (g < 4096) a.trace[2 * 16 * 64 * 8 + 2 * 4096 + g] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);      // HW_ID: where this workgroup runs (CU, SE, TG slot)
+    }
 #endif
     int tile = SPLIT ? s0 / chunks : g, chunk0 = SPLIT ? s0 - tile * chunks : 0;
     const int tile_step = SPLIT ? 1 : n_wg;
     Tile cur = decode(tile);
-    if constexpr (MODE == 3) {
-        static_assert(!SPLIT, "the loader wavefront mirrors the whole-tile schedule only (its barriers must match the computing wavefronts')");
-        if (wave == G::WAVES) {                                    // the loader wavefront: one barrier per interval like everybody else, nothing but DMA issue
+    if constexpr (K::EXTRA != 0) {
+        static_assert(!SPLIT, "the loader wavefronts mirror the whole-tile schedule only (their barriers must match the computing wavefronts')");
+        if (wave >= G::WAVES) {                                    // a loader wavefront: one barrier per interval like everybody else, nothing but DMA issue
             __builtin_amdgcn_s_setprio(3);
             Plan pl = make_plan(cur);
             issue_all(pl, 0, 0);
@@ -253,13 +272,17 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
             return;
         }
     }
-    const bool loader_here = MODE == 3 ? false : loader;           // (MODE 3: the computing wavefronts carry no plan and issue nothing)
+    const bool loader_here = K::EXTRA ? false : loader;            // (MODE 3 / 7: the computing wavefronts carry no plan and issue nothing)
     Plan plan{};
     if (loader_here) {
         plan = make_plan(cur);
         issue_all(plan, chunk0, 0);
     }
-    if (MODE != 2 && wave >= G::WAVES / 2) __builtin_amdgcn_s_setprio(1);      // (as conv3x3_emu.hip: the later-dispatched half of the wavefronts loses every arbitration otherwise)
+    if constexpr (K::PAIRED) {
+        // HW_REG_HW_ID (register 4) bits 16-19 = TG_ID: the workgroup's slot on its CU.  The odd slot outranks the even one at every issue arbitration.
+        const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);
+        if (tg & 1) __builtin_amdgcn_s_setprio(2);
+    } else if (MODE != 2 && wave >= G::WAVES / 2) __builtin_amdgcn_s_setprio(1);      // (as conv3x3_emu.hip: the later-dispatched half of the wavefronts loses every arbitration otherwise)
     int L = 0;
     while (L < n_local) {
         const int c_begin = SPLIT ? chunk0 : 0, c_end = SPLIT && (n_local - L) < (chunks - c_begin) ? c_begin + (n_local - L) : chunks;
@@ -315,11 +338,13 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
                 next = decode(ntile);
                 if (loader_here) nplan = make_plan(next);
             }
-            if (!K::INTERLEAVED && more && loader_here) issue_all(nplan, nc, (L + 1) & 1);
-            if (chunk == c_end - 1 && head && wave_live && !SP_ABLATE(8)) fetch_residual();
+            constexpr bool kPaired = K::PAIRED;
+            const int slot_cur = kPaired ? 0 : (L & 1), slot_next = kPaired ? 0 : ((L + 1) & 1);
+            if (!K::INTERLEAVED && !kPaired && more && loader_here) issue_all(nplan, nc, slot_next);
+            if (!kPaired && chunk == c_end - 1 && head && wave_live && !SP_ABLATE(8)) fetch_residual();
             SP_STAMP(3);
             if (wave_live && !SP_ABLATE(4)) {
-                const uint4 *bq = reinterpret_cast<const uint4 *>(lds + 2 * G::W_BYTES + (L & 1) * G::B_BYTES) + bshift, *wq = reinterpret_cast<const uint4 *>(lds + (L & 1) * G::W_BYTES) + wlane;
+                const uint4 *bq = reinterpret_cast<const uint4 *>(lds + K::NBUF * G::W_BYTES + slot_cur * G::B_BYTES) + bshift, *wq = reinterpret_cast<const uint4 *>(lds + slot_cur * G::W_BYTES) + wlane;
                 auto load_b = [&](int s, halfx8 (&b)[2]) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) b[t] = __builtin_bit_cast(halfx8, bq[t * G::PIXP + boff[s]]);
@@ -331,19 +356,24 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
                         for (int t = 0; t < 2; ++t) w[q][t] = __builtin_bit_cast(halfx8, wq[((s * 2 + t) * 2) * kCoutTile + q * 32]);
                 };
                 halfx8 bc[2], wc[2][2];
-                load_b(0, bc);
-                load_w(0, wc);
+                if constexpr (!kPaired) {
+                    load_b(0, bc);
+                    load_w(0, wc);
+                }
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
                     halfx8 bn[2], wn[2][2];
-                    if (s + 1 < 9) {                               // operands of the next tap are in flight while this tap's matrix instructions issue
+                    if constexpr (kPaired) {                       // four wavefronts per SIMD hide the LDS latency; no second operand set in the 128 registers
+                        load_b(s, bc);
+                        load_w(s, wc);
+                    } else if (s + 1 < 9) {                        // operands of the next tap are in flight while this tap's matrix instructions issue
                         load_b(s + 1, bn);
                         load_w(s + 1, wn);
                     }
                     if constexpr (MODE == 4) {
                         if (more) {
 #pragma unroll
-                            for (int k = s; k < K::OPS; k += 9) issue_op(nplan, nc, (L + 1) & 1, k);
+                            for (int k = s; k < K::OPS; k += 9) issue_op(nplan, nc, slot_next, k);
                         }
                     }
 #pragma unroll
@@ -355,17 +385,17 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
                     if constexpr (MODE == 1) {
                         if (more) {
 #pragma unroll
-                            for (int k = s; k < K::OPS; k += 9) issue_op(nplan, nc, (L + 1) & 1, k);
+                            for (int k = s; k < K::OPS; k += 9) issue_op(nplan, nc, slot_next, k);
                         }
                     }
                     if constexpr (MODE == 5) {
                         if (more) {
 #pragma unroll
                             for (int k = 2 * s; k < 2 * s + 2; ++k)
-                                if (k < K::OPS) issue_op(nplan, nc, (L + 1) & 1, k);
+                                if (k < K::OPS) issue_op(nplan, nc, slot_next, k);
                         }
                     }
-                    if (s + 1 < 9) {
+                    if (!kPaired && s + 1 < 9) {
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
                             bc[t] = bn[t];
@@ -375,9 +405,18 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
                     }
                 }
             } else if (K::INTERLEAVED && more) {
-                issue_all(nplan, nc, (L + 1) & 1);
+                issue_all(nplan, nc, slot_next);
+            }
+            if constexpr (kPaired) {                               // everyone has read the buffers: the next interval's operands take their place (the partner workgroup computes meanwhile)
+                SP_STAMP(5);
+                __syncthreads();
+                SP_STAMP(6);
+                if (more && loader_here) issue_all(nplan, nc, 0);
             }
             SP_STAMP(4);
+        }
+        if constexpr (K::PAIRED) {                                 // (no residual prefetch behind the last interval: its 32 registers do not fit beside the K loop's at 128)
+            if (head && wave_live && !SP_ABLATE(8)) fetch_residual();
         }
         chunk0 = 0;                                                // every later segment of this range opens its tile
         SP_STAMP_AT(5, L - 1);                                     // (epilogue stamps land in the record of the tile's last interval: 5 start, 6 residual in float, 7 stored)
@@ -428,7 +467,9 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
         // the range check one running maximum, the store address a running pointer, each group's bias / scale loads are issued one group ahead.
         const float4 *bias4 = reinterpret_cast<const float4 *>(a.bias + cur.cg * kCoutTile + 4 * half), *winv4 = reinterpret_cast<const float4 *>(a.wscale + cur.cg * kCoutTile + 4 * half);
         float rr[8][4];
-        if (a.res_kind == SP_RES_SP) {
+        if constexpr (K::PAIRED) {
+            // (converted per channel group below: a float copy of all 32 residual values beside the 64 accumulators does not fit the paired mode's 128 registers)
+        } else if (a.res_kind == SP_RES_SP) {
 #pragma unroll
             for (int g8 = 0; g8 < 8; ++g8) {
                 const halfx4 h = __builtin_bit_cast(halfx4, uint2{rraw[g8].x, rraw[g8].y}), l = __builtin_bit_cast(halfx4, uint2{rraw[g8].z, rraw[g8].w});
@@ -458,6 +499,16 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : 0)) void conv3x3_sp_ke
                 i4 = winv4[2 * (g8 + 1)];
             }
             float v[4];
+            if constexpr (K::PAIRED) {
+                if (a.res_kind == SP_RES_SP) {
+                    const halfx4 h = __builtin_bit_cast(halfx4, uint2{rraw[g8].x, rraw[g8].y}), l = __builtin_bit_cast(halfx4, uint2{rraw[g8].z, rraw[g8].w});
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rr[g8][j] = coalign::sp16_join(h[j], l[j]);
+                } else {
+                    rr[g8][0] = __builtin_bit_cast(float, rraw[g8].x); rr[g8][1] = __builtin_bit_cast(float, rraw[g8].y);
+                    rr[g8][2] = __builtin_bit_cast(float, rraw[g8].z); rr[g8][3] = __builtin_bit_cast(float, rraw[g8].w);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int q = g8 / 4, e = 4 * (g8 % 4) + j;
@@ -545,7 +596,8 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
     static int cus[kMaxDev] = {0};                                    // per device: the function attribute belongs to the device's code object
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
-    constexpr bool CAN_SPLIT = NPB == 8 && MODE != 3;                 // (the hand-over code needs the 8-wavefront geometries' register budget; the loader wavefront of MODE 3 mirrors whole tiles only)
+    using KW = Work<BH, BW, NPB, NBX, MODE>;
+    constexpr bool CAN_SPLIT = NPB == 8 && MODE != 3 && MODE != 6 && MODE != 7;    // (the hand-over code needs the 8-wavefront geometries' register budget; the loader wavefront of MODE 3 mirrors whole tiles only; the paired mode runs whole tiles)
     auto k_sp = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP, MODE, false>;
     auto k_cl = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC, MODE, false>;
     auto k_sp_s = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP, MODE, CAN_SPLIT>;
@@ -555,7 +607,7 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
         if (!query) {
             for (const void *fn : {reinterpret_cast<const void *>(k_sp), reinterpret_cast<const void *>(k_cl), reinterpret_cast<const void *>(k_sp_s), reinterpret_cast<const void *>(k_cl_s)}) {
-                const int rc = coalign::hip_call(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+                const int rc = coalign::hip_call(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KW::LDS_BYTES));
                 if (rc != COALIGN_OK) {
                     (void)hipGetLastError();
                     return rc;
@@ -575,7 +627,7 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
     a.tiles_y = (a.H + G::TH - 1) / G::TH;                            // per image (not stacked)
     const int row_tiles = a.stack ? (a.N * a.H + G::TH - 1) / G::TH : a.N * a.tiles_y;
     a.total_tiles = a.tiles_x * row_tiles * (a.Cout / kCoutTile);
-    const int slots = n_cu, chunks = a.Cin / 16;                      // 111-147 KB of LDS: one workgroup per CU
+    const int slots = n_cu * (KW::PAIRED ? 2 : 1), chunks = a.Cin / 16;      // 111-147 KB of LDS: one workgroup per CU (paired mode: 65-70 KB, two)
     // Stream-K pays where whole tiles leave the last round badly filled AND a workgroup's range spans whole tiles, i.e. at most one hand-over per workgroup
     // (the shrink header: 572 tiles of 16 intervals = three rounds at 74 %: 132 -> 125 us).  Measured where a tile is cut into several shares
     // (profiles/round5/conv_sp_layers.json): 5 x 256 x 25 x 88 (192 tiles on 256 CUs, 12 of 16 intervals each) 42.6 -> 49.7 us, 2 x 256 x 25 x 63 (56 tiles)
@@ -604,19 +656,28 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
         a.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + l.flag_bytes);
     }
     constexpr int kThreads = Work<BH, BW, NPB, NBX, MODE>::THREADS;
-    if (split) hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp_s : k_cl_s, dim3(l.grid), dim3(kThreads), G::LDS_BYTES, s, a);
-    else hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp : k_cl, dim3(l.grid), dim3(kThreads), G::LDS_BYTES, s, a);
+    if (split) hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp_s : k_cl_s, dim3(l.grid), dim3(kThreads), KW::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp : k_cl, dim3(l.grid), dim3(kThreads), KW::LDS_BYTES, s, a);
     return COALIGN_OK;
 }
 
 template <int MODE>
 int launch_mode(int geo, const SpArgs &a, int out_kind, int split_policy, void *ws, size_t ws_bytes, hipStream_t s, SpLaunch *query) {
-    switch (geo) {
-        case 81: return launch_geo<1, 32, 8, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);       // 8 rows x 32 columns
-        case 121: return launch_geo<1, 32, 12, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);     // 12 x 32
-        case 124: return launch_geo<2, 16, 12, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);     // 24 x 16 (2 x 16 blocks)
-        case 148: return launch_geo<4, 8, 8, 4, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);       // 8 x 32 in 4 x 8 blocks, four block columns
-        default: return COALIGN_ERR_UNSUPPORTED;
+    if constexpr (MODE == 6 || MODE == 7) {                           // two workgroups per CU / four loader wavefronts: the 8-wavefront geometries
+        switch (geo) {
+            case 81: return launch_geo<1, 32, 8, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);   // 8 rows x 32 columns
+            case 84: return launch_geo<2, 16, 8, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);   // 16 x 16 (2 x 16 blocks): maps 16 (mod 32) wide
+            case 148: return launch_geo<4, 8, 8, 4, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);   // 8 x 32 in 4 x 8 blocks
+            default: return COALIGN_ERR_UNSUPPORTED;
+        }
+    } else {
+        switch (geo) {
+            case 81: return launch_geo<1, 32, 8, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);       // 8 rows x 32 columns
+            case 121: return launch_geo<1, 32, 12, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);     // 12 x 32
+            case 124: return launch_geo<2, 16, 12, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);     // 24 x 16 (2 x 16 blocks)
+            case 148: return launch_geo<4, 8, 8, 4, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);       // 8 x 32 in 4 x 8 blocks, four block columns
+            default: return COALIGN_ERR_UNSUPPORTED;
+        }
     }
 }
 
@@ -634,14 +695,16 @@ int dispatch_sp(const SpArgs &a, int out_kind, int geometry, void *ws, size_t ws
         else if (a.H >= 8 && a.H <= 32 && a.W % 32 > 0 && a.W % 32 <= 24) geo = 148;
         else geo = 81;
     }
-#if defined(COALIGN_LAB) || defined(SP_TRACE)      // laboratory / trace builds carry all three issue modes
+#if defined(COALIGN_LAB) || defined(SP_TRACE)      // laboratory / trace builds carry every issue mode
     if (mode == 3 && (geo == 81 || geo == 148)) return launch_mode<3>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
+    if (mode == 6) return launch_mode<6>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
+    if (mode == 7) return launch_mode<7>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
     if (mode == 4) return launch_mode<4>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
     if (mode == 5) return launch_mode<5>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
     return mode == 0 ? launch_mode<0>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query) : mode == 2 ? launch_mode<2>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query)
                                                                                               : launch_mode<1>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
 #else
-    (void)mode;
+    if (mode != kDefaultMode && geometry >= 1000) return COALIGN_ERR_UNSUPPORTED;      // (issue modes 0, 2-7 are measured-and-not-adopted variants: laboratory library only)
     return launch_mode<kDefaultMode>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
 #endif
 }

@@ -286,3 +286,60 @@ def test_end_to_end_error_against_float64_by_arithmetic(case, params):
         assert viol == 0, (case, params, m)
     yard = max(worst["0"][0], ref_max)
     assert worst["16"][0] <= 2.0 * yard + 2e-6, (case, params, worst, ref_max)
+
+
+# ---------------------------------------------------------------------------------------------------- conv3x3_sp: the two issue modes measured in round 6 (laboratory library)
+def _sp_mode_check(geometry):
+    """Runs in a COALIGN_LAB=1 subprocess (the product library carries the adopted issue mode only)."""
+    r5 = _sibling("test_round5_gpu")
+    from coalign_amd import ops
+    dev = torch.device("cuda:0")
+    for shape in r5.SP_SHAPES + [(5, 256, 256, 25, 88), (5, 128, 128, 50, 176), (2, 64, 64, 100, 352)]:
+        N, Ci, Co, H, W = shape
+        g = torch.Generator(device=dev).manual_seed(sum(shape) + geometry)
+        x = r5.round22(torch.randn((N, Ci, H, W), generator=g, device=dev))
+        w = torch.randn((Co, Ci, 3, 3), generator=g, device=dev) / (9 * Ci) ** 0.5
+        b = torch.randn(Co, generator=g, device=dev)
+        rs = ops.SplitMap.pack(torch.randn((N, Co, H, W), generator=g, device=dev))
+        r = rs.dense()
+        w16 = ops.pack_conv3x3_emu_weight(w, 16, True)
+        xs = ops.SplitMap.pack(x)
+        for res_kind, relu in (("none", True), ("split", True), ("nhwc", False)):
+            res_old = None if res_kind == "none" else r
+            res_new = None if res_kind == "none" else rs if res_kind == "split" else r.contiguous(memory_format=torch.channels_last)
+            want = ops.conv3x3_emu_bias_act(x, w16, b, Co, res_old, relu, 16)
+            got_cl = ops.conv3x3_sp(xs, w16, b, Co, res_new, relu, out_split=False, geometry=geometry)
+            assert got_cl.shape == want.shape and torch.equal(got_cl, want), (shape, geometry, res_kind, float((got_cl - want).abs().max()))
+            got_sp = ops.conv3x3_sp(xs, w16, b, Co, res_new, relu, out_split=True, geometry=geometry)
+            r5.assert_split_map_holds(got_sp, want, (shape, geometry, res_kind))
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()      # launches of two streams side by side: paired workgroups of DIFFERENT launches share CUs
+        torch.cuda.synchronize()
+        outs = []
+        for i in range(6):
+            with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+                outs.append(ops.conv3x3_sp(xs, w16, b, Co, rs, True, out_split=False, geometry=geometry))
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, outs[0]) for o in outs[1:]), shape
+    assert not ops.sp_range_exceeded(dev)
+    print("sp mode ok", geometry)
+
+
+@pytest.mark.parametrize("geometry", [7081, 7084, 7148, 8081, 8084, 8148])
+def test_conv3x3_sp_round6_issue_modes_equal_the_product_kernel_bit_for_bit(geometry):
+    """csrc/conv3x3_sp.hip MODE 6 (single LDS buffers, 128 registers, two workgroups per CU out of phase; geometry 7000 + g) and MODE 7 (four loader-only wavefronts
+    beside the eight computing ones; 8000 + g) -- both measured SLOWER than the product's mode 1 (profiles/round6/experiments/conv_sp_*) and
+    kept in the laboratory library -- run the same matrix instructions on the same operands in the same order: identical bits against the consumer-split kernel
+    for every test shape, residual kind and output kind (resblock.py:53-69) on the three 8-wavefront geometries (81: 8 x 32 tiles, 84: 16 x 16, 148: 8 x 32 in 4 x 8
+    blocks).  The PRODUCT library refuses the codes."""
+    import subprocess
+    import sys
+    from coalign_amd import hip, ops
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    code = f"import sys; sys.path[:0] = [{root!r}, {here!r}]; import test_round6_gpu as t; t._sp_mode_check({geometry})"
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, COALIGN_LAB="1"), capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and f"sp mode ok {geometry}" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+    xs = ops.SplitMap.pack(torch.zeros((1, 16, 8, 32), device=DEV))
+    w16 = ops.pack_conv3x3_emu_weight(torch.zeros((64, 16, 3, 3), device=DEV), 16, True)
+    with pytest.raises(hip.CoalignHipError):
+        ops.conv3x3_sp(xs, w16, torch.zeros(64, device=DEV), 64, None, True, out_split=False, geometry=geometry)

@@ -39,7 +39,7 @@ w16 = ops.pack_conv3x3_emu_weight(w, 16, True)
 xs, rs = ops.SplitMap.pack(x), ops.SplitMap.pack(r)
 out = ops.SplitMap.empty(N, Co, H, W, "cuda")
 waves, S = 16, 8
-tr = torch.zeros(2 * waves * 64 * S + 2 * 4096, dtype=torch.int64, device="cuda")
+tr = torch.zeros(2 * waves * 64 * S + 3 * 4096, dtype=torch.int64, device="cuda")
 L.coalign_conv3x3_sp_set_trace(P(tr.data_ptr()))
 
 
@@ -59,8 +59,18 @@ for _ in range(3):
     tr.zero_()
     run()
     torch.cuda.synchronize()
-span = tr.cpu()[2 * waves * 64 * S:].view(-1, 2)
-span = span[span[:, 1] > 0]
+hwid = tr.cpu()[2 * waves * 64 * S + 2 * 4096:]
+span_all = tr.cpu()[2 * waves * 64 * S: 2 * waves * 64 * S + 2 * 4096].view(-1, 2)
+live = span_all[:, 1] > 0
+# round 6: where the workgroups ran (HW_ID: CU_ID bits 8-11, SH_ID 12, SE_ID 13-15, TG_ID 16-19; the XCD is not in HW_ID: workgroup g runs on XCD g % 8) and how
+# many of them shared a CU at the same time -- the paired mode (geometry 7000 + g) wants two per CU
+ids = [(int(g) % 8, (int(h) >> 13) & 7, (int(h) >> 12) & 1, (int(h) >> 8) & 15, (int(h) >> 16) & 15, int(a), int(b)) for g, (h, (a, b)) in enumerate(zip(hwid[: len(span_all)].tolist(), span_all.tolist())) if b > 0]
+cus = {}
+for xcd, se, sh, cu, tg, a0, b0 in ids:
+    cus.setdefault((xcd, se, sh, cu), []).append((a0, b0, tg))
+pairs = sum(1 for v in cus.values() for i in range(len(v)) for j in range(i) if min(v[i][1], v[j][1]) - max(v[i][0], v[j][0]) > 0.5 * min(v[i][1] - v[i][0], v[j][1] - v[j][0]))
+print(f"{len(ids)} workgroups on {len(cus)} distinct (XCD, SE, SH, CU); workgroups per CU: max {max(len(v) for v in cus.values())}; pairs overlapping in time for > half of the shorter one's life: {pairs}; TG slots seen: {sorted({t for v in cus.values() for _, _, t in v})}")
+span = span_all[live]
 t0 = int(span[:, 0].min())
 st, en = (span[:, 0] - t0).float() / 100.0, (span[:, 1] - t0).float() / 100.0
 print(f"conv3x3_sp {N}x{Ci}->{Co} {H}x{W} geometry {geo}: {len(span)} workgroups: start median {st.median():.1f} max {st.max():.1f} us; end min {en.min():.1f} median {en.median():.1f} max {en.max():.1f} us")
@@ -77,6 +87,10 @@ for wg in (0, 1):
                 break
             nxt = int(t[wg, wv, c + 1, 0]) if c + 1 < 64 and int(t[wg, wv, c + 1, 0]) else int(s[4])
             d = [int(s[1] - s[0]), int(s[2] - s[1]), int(s[3] - s[2]), int(s[4] - s[3]), nxt - int(s[4])]
+            if geo % 100000 // 1000 == 7 and int(s[5]) > int(s[3]) and int(s[6]) >= int(s[5]) and int(s[4]) >= int(s[6]):      # paired mode: steps | the barrier that ends the interval | DMA issue
+                d[3] = int(s[5] - s[3])
+                d.insert(4, int(s[6] - s[5]))
+                d.insert(5, int(s[4] - s[6]))
             epi = ""
             if int(s[5]) and int(s[7]):      # a tile's last interval: the gap in parts (accumulator join + hand-over | residual wait + conversion | the 8 channel groups: scale, split, stores | to the next top)
                 epi = f"   epilogue: join {int(s[5] - s[4])} residual {int(s[6] - s[5])} groups {int(s[7] - s[6])} rest {nxt - int(s[7])}"
