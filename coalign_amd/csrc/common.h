@@ -51,6 +51,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return base + slot;
 }
 
+// Streaming ("non-temporal") stores for outputs the NEXT launch reads (from any XCD, i.e. through memory anyway): the line leaves the XCD's write-back L2 as it is
+// produced instead of waiting dirty for the end-of-kernel release, which then has megabytes to write back before the launch can complete.  Round 6, measured
+// (profiles/round6/experiments/streaming_stores.txt): pillar rows 13.4-13.9 -> 12.9 us, fused maps 20.4-21.0 -> 18.7-19.4 us (adopted); the convolutions' SplitMap
+// output -4 % alone on the GPU but -1.7 % frames/s inside the two-stream pipeline, their channels-last output +16 % (16-byte pieces of lines): not adopted.
+__device__ __forceinline__ void store_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
+typedef float coalign_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned coalign_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(float4 *p, float4 v) { __builtin_nontemporal_store(coalign_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<coalign_f4 *>(p)); }
+__device__ __forceinline__ void store_stream(uint4 *p, uint4 v) { __builtin_nontemporal_store(coalign_u4{v.x, v.y, v.z, v.w}, reinterpret_cast<coalign_u4 *>(p)); }
+
 // Order a wavefront's own LDS traffic: write by some lanes, read by others of the SAME wave.  The LDS unit executes one
 // wave's DS instructions in issue order, so no hardware wait is needed -- only the compiler must not reorder across this
 // point.  (A __builtin_amdgcn_fence here can also drain vmcnt, i.e. wait for every prefetched global load.)

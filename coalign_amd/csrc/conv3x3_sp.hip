@@ -39,6 +39,7 @@ struct SpArgs {
     void *__restrict__ y;               // SP map or channels-last fp32, per the OUT template argument
     int *range_flag;                    // may be NULL: bit 0 is set when an SP output value exceeds the pair's range (|y| > 65504)
     int N, Cin, Cout, H, W, relu, res_kind, stack, tiles_x, tiles_y, total_tiles, xcd;
+    int stream_out;                     // laboratory switch (round 6): the SP output leaves with streaming (non-temporal) stores (common.h store_stream); measured, not adopted
     // stream-K (split != 0): the (tile, interval) steps are cut into gridDim.x equal contiguous ranges; a workgroup that starts in the middle of a tile
     // publishes the partial sums of its share (slot g of `partial`, then flags[g] = 1), the workgroup that OPENED the tile adds them and runs the epilogue.
     int split;
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
                 v[j] = fmaxf(acc[q][e] * ii[j] + (rr[g8][j] + bb[j]), floor_v);
             }
             if constexpr (OUT == SP_OUT_NHWC) {
-                if (live && !SP_ABLATE(16)) ycl[2 * g8] = float4{v[0], v[1], v[2], v[3]};
+                if (live && !SP_ABLATE(16)) ycl[2 * g8] = float4{v[0], v[1], v[2], v[3]};      // (16 bytes per pixel and instruction: streaming stores measured +16 % here -- partial lines; the SP map's 512-byte runs below gain 4 %)
             } else {
                 vmax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), vmax));
                 unsigned h01, l01, h23, l23;
@@ -523,7 +524,10 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
                 coalign::sp16_split2(v[2], v[3], h23, l23);
                 swap32(h01, l01);          // lanes 0-31: h of channels 0,1 | 4,5 of the 8-channel group; lanes 32-63: l of the same channels
                 swap32(h23, l23);
-                if (live && !SP_ABLATE(16)) *ysp = uint4{h01, h23, l01, l23};      // plane = 2 * channel half + term: lanes 32-63 hold term 1 (the `half` in ysp)
+                if (live && !SP_ABLATE(16)) {                              // plane = 2 * channel half + term: lanes 32-63 hold term 1 (the `half` in ysp)
+                    if (a.stream_out) coalign::store_stream(ysp, uint4{h01, h23, l01, l23});
+                    else *ysp = uint4{h01, h23, l01, l23};
+                }
                 ysp += sp_step;
             }
         }
@@ -781,6 +785,7 @@ extern "C" int coalign_conv3x3_sp(const void *x_sp, const void *w_split, const f
     a.range_flag = range_flag;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.relu = relu; a.res_kind = residual_kind;
     a.xcd = 1;
+    a.stream_out = coalign::lab_env("COALIGN_SP_STREAM", 0);      // (alone on the GPU the SP output gains 4 % from streaming stores; inside the two-stream frame pipeline it LOSES 1.7 %: laboratory switch)
 #ifdef SP_TRACE
     a.trace = g_sp_trace;
     a.ablate = g_sp_ablate;

@@ -7,7 +7,7 @@
 //   feats  [M, C]            the pillar feature rows (pillar_features of the reference; every pillar writes its own row: no write races)
 //   stamps [n_agents*ny*nx]  one 64-bit word per cell = (frame tag << 32) | pillar row, entered with a device-scope atomicMax: two pillars of one
 //                            cell resolve to the larger row index -- the reference's sequential-indexing rule -- without a pre-pass
-//   state  [2]               state[0] = tag of the last completed frame, state[1] = arrival counter of the launch in flight
+//   state  [528]             state[0] = tag of the last completed frame, state[1] and state[16 + 16 g] = arrival counters of the launch in flight (round 6: two levels)
 // A cell is occupied in the current frame iff its stamp carries the current tag: nothing is ever cleared (the previous frames' stamps are stale by
 // their tag), there is no cell-map pre-pass and no ordering problem between clearing and writing -- one launch.  The consumers
 // (coalign_conv3x3_emu_sparse, coalign_pointwise_conv_emu_sparse) look a pixel up as stamps[cell] -> row of feats, or zero.
@@ -39,7 +39,11 @@ typedef __attribute__((address_space(3))) void *lptr_sp_t;
 constexpr int kWaves = 4;                   // wavefronts per workgroup
 constexpr int kRunPairs = 32;               // pillar pairs per wavefront at most (one lane per pillar in the prologue)
 constexpr int kPointShift = 6;              // the point offsets enter the fp16 contraction times 2^6 (see the header)
-constexpr int kRound = 3;                   // pairs per LDS-DMA round (3 KB per buffer: 8 KB of LDS per wavefront, 32 KB per workgroup; the grid puts three workgroups on a CU)
+constexpr int kArriveGroups = 32, kArriveBase = 16, kArriveStride = 16;      // state[16 + 16 g]: the arrival counter of workgroups b % 32 == g (see the end of the kernel)
+constexpr int kRound = 4;                   // pairs per LDS-DMA round (4 KB per buffer: 10 KB of LDS per wavefront, 40 KB per workgroup; the grid puts three workgroups on a CU).
+                                            // Round 6: 3 -> 4 and the first TWO rounds are issued before anything waits, so that a wavefront of the benchmarked size (6-7 pairs)
+                                            // has all its points in flight at once instead of fetching its second half after the first has landed and been processed
+constexpr int kPairsPerWave = 6;            // pairs per wavefront the grid is sized for
 #ifdef COALIGN_LAB
 constexpr bool kLab = true;
 #else
@@ -293,8 +297,8 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
     const int npairs = (a.M + 1) / 2;
     // even shares (+-1 pair): with a grid that is a whole number of workgroups per CU every SIMD gets the same work.  The grid is sized for the CAPACITY of the
     // arrays; when the device-side count is far below it (the voxeliser's route: room for 5 x 70 000 pillars, ~36 000 present) only as many wavefronts as give
-    // each about 2 * kRound pairs take part -- a wavefront's prologue is not worth one or two pairs
-    const int active = max(1, min(nwave, (npairs + 2 * kRound - 1) / (2 * kRound)));
+    // each about kPairsPerWave pairs take part -- a wavefront's prologue is not worth one or two pairs
+    const int active = max(1, min(nwave, (npairs + kPairsPerWave - 1) / kPairsPerWave));
     const int p0 = gwave < active ? (int)((long long)gwave * npairs / active) : 0, p1 = gwave < active ? (int)((long long)(gwave + 1) * npairs / active) : 0;
     if (p0 < p1) {
         const int ncell = a.ny * a.nx;
@@ -315,6 +319,7 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
             }
         };
         issue_round(p0, 0);
+        if (p0 + kRound < p1) issue_round(p0 + kRound, 1);
         // counts, coordinates, cells of the whole run: once per wavefront (one lane per pillar); the channel parameters' loads go out before anything waits
         const bool pro = lane < 2 * (p1 - p0);
         const int m_j = 2 * p0 + lane, mj = min(m_j, a.M - 1);
@@ -342,11 +347,62 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
         int buf = 0;
         for (int r0 = p0; r0 < p1; r0 += kRound, buf ^= 1) {
             const int nr = min(kRound, p1 - r0);
-            __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): this round's points are in LDS
-            coalign::wave_lds_sync();
+            if (r0 != p0 + kRound) {                                 // (the second round landed under the first round's wait)
+                __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this round's points are in LDS
+                coalign::wave_lds_sync();
+            }
             if (kLab && (a.debug & 512)) ts[r0 == p0 ? 3 : 5] = (long long)__builtin_amdgcn_s_memtime();
-            if (r0 + kRound < p1) issue_round(r0 + kRound, buf ^ 1);
+            if (r0 != p0 && r0 + kRound < p1) issue_round(r0 + kRound, buf ^ 1);      // from the second round on: the next one goes into the buffer the previous round has left
             const char *pb = pbuf + buf * (kRound * 1024);
+            // Round 6: a FULL round runs as straight-line code, two pairs at a time, the stores behind them.  The kernel is latency bound, not issue bound (2.9 M
+            // wave instructions in 40 k cycles on 1024 SIMDs: one instruction per ~14 cycles and SIMD): a pair is one dependent chain -- record -> point reads ->
+            // DPP means -> operand split -> swaps -> matrix instruction -> max tree -> swaps -> epilogue -- of ~1100 cycles, and with one conditional block per pair
+            // the scheduler never sees two chains in one region.
+            if (!kLab) {
+#pragma unroll
+                for (int k2 = 0; k2 < kRound; k2 += 2) {
+                    if (k2 + 1 < nr) {                              // two pairs, one scheduling region
+                        float yy[2][2];
+                        bool hb[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int k = k2 + u, pair = r0 + k;
+                            hb[u] = 2 * pair + 1 < a.M;
+                            const float4 *rec = reinterpret_cast<const float4 *>(meta + (2 * (pair - p0) + half) * 32);
+                            const float4 rec0 = rec[0];
+                            const float ctr_z = rec[1].x;
+                            const int np_eff = __builtin_bit_cast(int, rec0.x);
+                            float4 q = *reinterpret_cast<const float4 *>(pb + k * 1024 + lane * 16);
+                            const float4 qs = *reinterpret_cast<const float4 *>(pb + k * 1024 + (col >= np_eff ? half * 512 : lane * 16));
+                            if (a.P < 32 && col >= a.P) q = make_float4(0.f, 0.f, 0.f, 0.f);
+                            f32_pair_half<ABS>(a, fc, q, qs, np_eff, rec0.y, rec0.z, rec0.w, ctr_z, yy[u]);
+                            swap32(yy[u][0], yy[u][1]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int pair = r0 + k2 + u;
+                            if (lane < a.C) coalign::store_stream(reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair) * (unsigned)a.C + (unsigned)lane) * 4u), yy[u][0]);
+                            if (hb[u] && lane < a.C) coalign::store_stream(reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair + 1) * (unsigned)a.C + (unsigned)lane) * 4u), yy[u][1]);
+                        }
+                    } else if (k2 < nr) {                           // the odd pair at the end of a run
+                        const int k = k2, pair = r0 + k;
+                        const bool hasB = 2 * pair + 1 < a.M;
+                        const float4 *rec = reinterpret_cast<const float4 *>(meta + (2 * (pair - p0) + half) * 32);
+                        const float4 rec0 = rec[0];
+                        const float ctr_z = rec[1].x;
+                        const int np_eff = __builtin_bit_cast(int, rec0.x);
+                        float4 q = *reinterpret_cast<const float4 *>(pb + k * 1024 + lane * 16);
+                        const float4 qs = *reinterpret_cast<const float4 *>(pb + k * 1024 + (col >= np_eff ? half * 512 : lane * 16));
+                        if (a.P < 32 && col >= a.P) q = make_float4(0.f, 0.f, 0.f, 0.f);
+                        float y[2];
+                        f32_pair_half<ABS>(a, fc, q, qs, np_eff, rec0.y, rec0.z, rec0.w, ctr_z, y);
+                        swap32(y[0], y[1]);
+                        if (lane < a.C) coalign::store_stream(reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair) * (unsigned)a.C + (unsigned)lane) * 4u), y[0]);
+                        if (hasB && lane < a.C) coalign::store_stream(reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair + 1) * (unsigned)a.C + (unsigned)lane) * 4u), y[1]);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < kRound; ++k) {
                 if (k < nr) {
@@ -365,8 +421,8 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
                     // half layout -> lane = channel: [A ch 0-31 | B ch 0-31], [A ch 32-63 | B ch 32-63] -> [A 0-63], [B 0-63]: 256-byte row stores
                     swap32(y[0], y[1]);
                     if (kLab && (a.debug & 8)) continue;
-                    if (lane < a.C) *reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair) * (unsigned)a.C + (unsigned)lane) * 4u) = y[0];      // (2 pair < M: p1 ends at the last pair)
-                    if (hasB && lane < a.C) *reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair + 1) * (unsigned)a.C + (unsigned)lane) * 4u) = y[1];
+                    if (lane < a.C) coalign::store_stream(reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair) * (unsigned)a.C + (unsigned)lane) * 4u), y[0]);      // (2 pair < M: p1 ends at the last pair)
+                    if (hasB && lane < a.C) coalign::store_stream(reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair + 1) * (unsigned)a.C + (unsigned)lane) * 4u), y[1]);
                 }
             }
         }
@@ -384,17 +440,29 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
     // (No fence: nobody reads the tag inside this launch -- the consumers are later launches on the stream, and a launch boundary publishes every store.  The
     //  counter only has to order "every workgroup has read state[0]" before "state[0] changes", which arrival itself does.  An agent-scope fence per workgroup
     //  here wrote back the XCD's dirty L2 lines -- the feature rows just stored -- 500 times: 55 us instead of 12.)
+    // Round 6: the arrival is counted in TWO levels.  One counter for all workgroups cost 3.8 of the launch's 18.3 us (768 returning device-scope atomics on one
+    // address are served one after the other, the last workgroups to finish queue behind each other: profiles/round6/experiments/pillar_sparse_ablations.txt).
+    // Now workgroup b arrives at group counter b % kArriveGroups (64 bytes apart: different channels), the last of a group at the top counter, the last of those
+    // publishes the tag: at most gridDim.x / 32 + 32 atomics per address.  Every counter is left at zero for the next launch.
     __syncthreads();
     if (threadIdx.x == 0 && !(kLab && (a.debug & 4))) {
-        const int arrived = __hip_atomic_fetch_add(a.state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == (int)gridDim.x - 1) {
-            __hip_atomic_store(a.state + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.state, (int)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int grp = (int)(blockIdx.x % kArriveGroups);
+        const int members = ((int)gridDim.x - grp + kArriveGroups - 1) / kArriveGroups;          // blocks b < gridDim.x with b % kArriveGroups == grp
+        const int live_groups = (int)gridDim.x < kArriveGroups ? (int)gridDim.x : kArriveGroups;
+        int *gc = a.state + kArriveBase + grp * kArriveStride;
+        if (__hip_atomic_fetch_add(gc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            __hip_atomic_store(gc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(a.state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == live_groups - 1) {
+                __hip_atomic_store(a.state + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.state, (int)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
 
 }  // namespace
+
+extern "C" size_t coalign_sparse_canvas_state_bytes(void) { return (size_t)(kArriveBase + kArriveGroups * kArriveStride) * sizeof(int32_t); }
 
 extern "C" size_t coalign_sparse_canvas_stamp_bytes(int n_agents, int ny, int nx) {
     if (n_agents <= 0 || ny <= 0 || nx <= 0) return 0;
@@ -455,7 +523,7 @@ int encode_sparse(const coalign_pillar_frame *frame, const float *voxel_features
     a.debug = coalign::lab_env("COALIGN_SPARSE_DEBUG", 0);
     // Grid = a WHOLE number of workgroups per CU (the dispatcher spreads resident workgroups evenly: measured 3 or 4 per CU for 834 workgroups, and the CUs with
     // 4 finish 3.5 us after those with 3 -- the kernel is bound by each SIMD's issue, so the launch ends with the busiest SIMD), pairs shared out evenly
-    // (+-1): k = 1..3 workgroups per CU (32 KB of LDS each), about 2 * kRound pairs per wavefront; larger inputs: runs of at most kRunPairs pairs, more rounds
+    // (+-1): k = 1..3 workgroups per CU (40 KB of LDS each), about kPairsPerWave pairs per wavefront; larger inputs: runs of at most kRunPairs pairs, more rounds
     // of workgroups.
     static int cus = 0;
     if (!cus) {
@@ -464,7 +532,7 @@ int encode_sparse(const coalign_pillar_frame *frame, const float *voxel_features
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     const int pairs = (M_capacity + 1) / 2;
-    const int per_wave_target = coalign::lab_env("COALIGN_SPARSE_PAIRS", 2 * kRound);      // laboratory build: pairs per wavefront the grid is sized for
+    const int per_wave_target = coalign::lab_env("COALIGN_SPARSE_PAIRS", kPairsPerWave);      // laboratory build: pairs per wavefront the grid is sized for
     const int unit = cus * kWaves * per_wave_target;
     int k = (pairs + unit / 2) / unit;
     k = k < 1 ? 1 : k > 3 ? 3 : k;       // (four per CU fit on paper -- 128 KB of LDS -- but a grid that needs EVERY slot waits a whole workgroup lifetime for a straggler: 31 vs 20 us)

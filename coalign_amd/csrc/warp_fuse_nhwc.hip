@@ -204,8 +204,8 @@ __device__ __forceinline__ void fuse_tile(const FuseArgs &f, const ScaleArgs &a,
                 for (int j = 0; j < 8; ++j) o[j] = fmaf(sn, X[n][j], o[j]);
             }
             if (pix_ok) {
-                *reinterpret_cast<float4 *>(a.out + opix) = make_float4(o[0], o[1], o[2], o[3]);
-                *reinterpret_cast<float4 *>(a.out + opix + a.C / 2) = make_float4(o[4], o[5], o[6], o[7]);
+                coalign::store_stream(reinterpret_cast<float4 *>(a.out + opix), make_float4(o[0], o[1], o[2], o[3]));
+                coalign::store_stream(reinterpret_cast<float4 *>(a.out + opix + a.C / 2), make_float4(o[4], o[5], o[6], o[7]));
             }
         } else if (f.mode == COALIGN_FUSE_MAX) {
             float o[8];
@@ -218,8 +218,8 @@ __device__ __forceinline__ void fuse_tile(const FuseArgs &f, const ScaleArgs &a,
                     for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], X[n][j]);
                 }
             if (pix_ok) {
-                *reinterpret_cast<float4 *>(a.out + opix) = make_float4(o[0], o[1], o[2], o[3]);
-                *reinterpret_cast<float4 *>(a.out + opix + a.C / 2) = make_float4(o[4], o[5], o[6], o[7]);
+                coalign::store_stream(reinterpret_cast<float4 *>(a.out + opix), make_float4(o[0], o[1], o[2], o[3]));
+                coalign::store_stream(reinterpret_cast<float4 *>(a.out + opix + a.C / 2), make_float4(o[4], o[5], o[6], o[7]));
             }
         } else {
             const size_t per_agent = (size_t)a.Ho * a.Wo * a.C;

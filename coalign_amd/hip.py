@@ -30,6 +30,7 @@ SIGNATURES = {
     "coalign_pillar_encode_stream": (c_int, [P, P, P, c_int, P, c_int, P, P, P, P, P, P, c_float, c_int, c_int, c_int,
                                              POINTER(c_double), POINTER(c_double), c_int, c_int, c_int, P, P, P, P, c_int, P]),
     "coalign_sparse_canvas_stamp_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "coalign_sparse_canvas_state_bytes": (c_size_t, []),
     "coalign_pillar_folded_param_bytes": (c_size_t, []),
     "coalign_pillar_fold_params": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, P, P]),
     "coalign_pillar_encode_sparse": (c_int, [P, P, P, c_int, P, c_int, P, c_int, c_int, POINTER(c_double), POINTER(c_double),

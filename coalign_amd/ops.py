@@ -403,7 +403,7 @@ def pillar_encode_sparse(voxel_features: torch.Tensor, voxel_num_points: torch.T
     key = ("sparse", str(dev), torch.cuda.current_stream(dev).cuda_stream, n_agents, ny, nx)
     entry = canvas_cache.get(key)
     if entry is None:
-        entry = canvas_cache[key] = {"stamps": torch.zeros(n_agents * ny * nx, dtype=torch.int64, device=dev), "state": torch.zeros(2, dtype=torch.int32, device=dev)}
+        entry = canvas_cache[key] = {"stamps": torch.zeros(n_agents * ny * nx, dtype=torch.int64, device=dev), "state": torch.zeros(L.coalign_sparse_canvas_state_bytes() // 4, dtype=torch.int32, device=dev)}
     entry["calls"] = entry.get("calls", 0) + 1
     entry["generation"] = entry.get("generation", 0) + 1      # (SparseCanvas.check_current)
     if entry["calls"] >= SPARSE_TAG_RESET_AFTER:             # (never inside a captured frame: a capture happens in a map's first calls)
@@ -943,6 +943,11 @@ def _sp_workspace(device, ws_bytes: int) -> torch.Tensor:
     return ws
 
 
+# Measurement switch (round 6): COALIGN_SP_GEO="25x88:121,50x176:81" overrides the tile geometry `coalign_conv3x3_sp` picks for maps of the listed H x W
+# (codes: include/coalign_amd.h (9e)); read once at import, the dict is read per call.
+import os as _os
+SP_GEO_OVERRIDE = {tuple(int(v) for v in k.split("x")): int(g) for k, g in (item.split(":") for item in _os.environ.get("COALIGN_SP_GEO", "").split(",") if item)}
+
 SP_RES_NONE, SP_RES_SP, SP_RES_NHWC = 0, 1, 2      # residual_kind of coalign_conv3x3_sp
 SP_OUT_SP, SP_OUT_NHWC = 1, 2                      # out_kind
 
@@ -958,6 +963,8 @@ def conv3x3_sp(x: "SplitMap", w_split: torch.Tensor, bias: torch.Tensor, cout: i
     _need_gpu(x.data, w_split, bias)
     L = hip.lib()
     N, Cin, H, W = x.shape
+    if geometry == 0 and SP_GEO_OVERRIDE:
+        geometry = SP_GEO_OVERRIDE.get((H, W), 0)
     if w_split.numel() != L.coalign_conv3x3_emu_weight_bytes_ex(Cin, cout, 16, 1):
         raise ValueError("conv3x3_sp needs the tap-major terms-16 weight image of (Cin, Cout)")
     res_kind, res_t = SP_RES_NONE, None

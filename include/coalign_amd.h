@@ -396,7 +396,8 @@ int coalign_fill_words(void *p, size_t n_words, uint32_t value, void *stream);
  *   pillar_features [M_capacity, C] out: the feature rows (C <= 64, P <= 32; the linearised PFN evaluated exactly in fp32 on v_mfma_f32_32x32x2_f32).
  *   stamps: coalign_sparse_canvas_stamp_bytes(n_agents, ny, nx) bytes, 8-byte aligned, ZERO-INITIALISED ONCE by the caller and then owned by this
  *     sequence of calls: 64-bit words (frame tag << 32) | pillar row per cell, entered by atomicMax -- the larger row of a cell wins, the reference's rule.
- *   state: int32[2], zero-initialised once: state[0] = tag of the last completed call, state[1] = arrival counter.  A cell holds pillar row
+ *   state: coalign_sparse_canvas_state_bytes() bytes (int32[528] since round 6; [2] before), zero-initialised once: state[0] = tag of the last completed call, the rest
+ *     the launch's arrival counters (two levels: one counter for every workgroup cost 3.8 of the launch's 18 us).  A cell holds pillar row
  *     (stamp & 0xffffffff) of THIS frame iff (stamp >> 32) == state[0] after the call; nothing is cleared between frames.  The tag is 32 bits and stamps are
  *     ordered by (tag, row): the caller re-zeroes stamps and state before 2^32 - 1 calls have gone through one stamp map (coalign_amd/ops.py does after 2^31).
  *   M_dev (may be NULL): the pillar count on the device (int32), M_capacity then sizes the arrays.  No distance feature (with_distance configs use (1)).
@@ -404,6 +405,7 @@ int coalign_fill_words(void *p, size_t n_words, uint32_t value, void *stream);
  *     Linear weight [C, 10 or 7] (+ bias when there is no BatchNorm) and its eval BatchNorm tensors: the channel parameters in the form the kernel's pair
  *     loop uses (the three weight groups summed, BatchNorm folded to scale / shift, signs folded) -- the counterpart of the convolutions' split weight images. */
 size_t coalign_sparse_canvas_stamp_bytes(int n_agents, int ny, int nx);
+size_t coalign_sparse_canvas_state_bytes(void);
 size_t coalign_pillar_folded_param_bytes(void);
 int coalign_pillar_fold_params(const float *pfn_weight, const float *pfn_bias, const float *bn_weight, const float *bn_bias, const float *bn_mean,
                                const float *bn_var, float bn_eps, int C, int use_absolute_xyz, float *folded, void *stream);
