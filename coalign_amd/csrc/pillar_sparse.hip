@@ -44,6 +44,10 @@ constexpr int kRound = 4;                   // pairs per LDS-DMA round (4 KB per
                                             // Round 6: 3 -> 4 and the first TWO rounds are issued before anything waits, so that a wavefront of the benchmarked size (6-7 pairs)
                                             // has all its points in flight at once instead of fetching its second half after the first has landed and been processed
 constexpr int kPairsPerWave = 6;            // pairs per wavefront the grid is sized for
+#ifndef COALIGN_PILLAR_GROUP
+#define COALIGN_PILLAR_GROUP 2
+#endif
+constexpr int kGroup = COALIGN_PILLAR_GROUP; // pairs per straight-line scheduling region (see the round loop)
 #ifdef COALIGN_LAB
 constexpr bool kLab = true;
 #else
@@ -360,12 +364,12 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
             // the scheduler never sees two chains in one region.
             if (!kLab) {
 #pragma unroll
-                for (int k2 = 0; k2 < kRound; k2 += 2) {
-                    if (k2 + 1 < nr) {                              // two pairs, one scheduling region
-                        float yy[2][2];
-                        bool hb[2];
+                for (int k2 = 0; k2 < kRound; k2 += kGroup) {
+                    if (k2 + kGroup - 1 < nr) {                     // kGroup pairs, one scheduling region
+                        float yy[kGroup][2];
+                        bool hb[kGroup];
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < kGroup; ++u) {
                             const int k = k2 + u, pair = r0 + k;
                             hb[u] = 2 * pair + 1 < a.M;
                             const float4 *rec = reinterpret_cast<const float4 *>(meta + (2 * (pair - p0) + half) * 32);
@@ -379,13 +383,16 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
                             swap32(yy[u][0], yy[u][1]);
                         }
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < kGroup; ++u) {
                             const int pair = r0 + k2 + u;
                             if (lane < a.C) coalign::store_stream(reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair) * (unsigned)a.C + (unsigned)lane) * 4u), yy[u][0]);
                             if (hb[u] && lane < a.C) coalign::store_stream(reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair + 1) * (unsigned)a.C + (unsigned)lane) * 4u), yy[u][1]);
                         }
-                    } else if (k2 < nr) {                           // the odd pair at the end of a run
-                        const int k = k2, pair = r0 + k;
+                    } else {                                        // what is left of a run: one pair at a time
+#pragma unroll
+                      for (int k = k2; k < k2 + kGroup - 1; ++k) {
+                        if (k >= nr) break;
+                        const int pair = r0 + k;
                         const bool hasB = 2 * pair + 1 < a.M;
                         const float4 *rec = reinterpret_cast<const float4 *>(meta + (2 * (pair - p0) + half) * 32);
                         const float4 rec0 = rec[0];
@@ -399,6 +406,7 @@ __global__ __launch_bounds__(kWaves * 64) void pillar_sparse_kernel(SparseArgs a
                         swap32(y[0], y[1]);
                         if (lane < a.C) coalign::store_stream(reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair) * (unsigned)a.C + (unsigned)lane) * 4u), y[0]);
                         if (hasB && lane < a.C) coalign::store_stream(reinterpret_cast<float *>(feat_b + ((unsigned)(2 * pair + 1) * (unsigned)a.C + (unsigned)lane) * 4u), y[1]);
+                      }
                     }
                 }
                 continue;

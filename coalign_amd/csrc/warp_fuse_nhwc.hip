@@ -188,18 +188,22 @@ __device__ __forceinline__ void fuse_tile(const FuseArgs &f, const ScaleArgs &a,
                 s[n] = (LPP == 16) ? group_sum<LPP>(p) / a.sqrt_dim : group_sum<LPP>(p) * a.inv_sqrt_dim;
                 if (n < f.n) smax = fmaxf(smax, s[n]);
             }
+            // Round 6: softmax with the hardware exponential (v_exp_f32 on (s - max) * log2 e: ~1 ulp, like the vectorised exp behind F.softmax on the CPU) and ONE
+            // division for the pixel instead of one per agent -- a fifth of the kernel's vector instructions were the library expf and the N divisions
+            // (weights within 2 ulp of exp(s - max) / sum: 2e-7 of a fused value, against the 1e-4 the parity tests hold).
             float den = 0.f;
 #pragma unroll
             for (int n = 0; n < NA; ++n) {
-                s[n] = (n < f.n) ? expf(s[n] - smax) : 0.f;
+                s[n] = (n < f.n) ? __builtin_amdgcn_exp2f((s[n] - smax) * 1.44269504088896341f) : 0.f;
                 den += s[n];
             }
+            const float inv_den = 1.0f / den;
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = 0.f;
 #pragma unroll
             for (int n = 0; n < NA; ++n) {
-                const float sn = s[n] / den;
+                const float sn = s[n] * inv_den;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = fmaf(sn, X[n][j], o[j]);
             }
