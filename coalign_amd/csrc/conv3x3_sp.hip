@@ -698,6 +698,22 @@ int dispatch_sp(const SpArgs &a, int out_kind, int geometry, void *ws, size_t ws
         else if (a.H >= 64) geo = (a.N == 1 && a.Cin >= 128) ? 81 : 121;      // (one image, long tiles -- the shrink header: the 8-wavefront geometry, which can split)
         else if (a.H >= 8 && a.H <= 32 && a.W % 32 > 0 && a.W % 32 <= 24) geo = 148;
         else geo = 81;
+        // Round 6: a 12-wavefront geometry that leaves more than a quarter of the CUs without a tile loses to the 8-wavefront one whose (smaller) tiles still fit one
+        // round: 2 x 64 -> 64 @ 100 x 252 (DAIR stage 1: 136 tiles of 12 x 32 against 200 of 8 x 32 on 256 CUs) 21.5 -> 17.0 us.  Same sums in the same order:
+        // the geometries are bit-equal (tests/test_round5_gpu.py).
+        if (geo == 121 || geo == 124) {
+            static int n_cu = 0;
+            if (!n_cu) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            }
+            const int th12 = geo == 121 ? 12 : 24, tw12 = geo == 121 ? 32 : 16, alt = (a.W % 32 == 0 || a.W % 32 > 24) ? 81 : 148;
+            const int rows = a.N * a.H, groups = a.Cout / kCoutTile;
+            const long long t12 = (long long)((rows + th12 - 1) / th12) * ((a.W + tw12 - 1) / tw12) * groups;
+            const long long t8 = (long long)((rows + 7) / 8) * ((a.W + 31) / 32) * groups;
+            if (t12 * 4 < 3LL * n_cu && t8 <= n_cu) geo = alt;
+        }
     }
 #if defined(COALIGN_LAB) || defined(SP_TRACE)      // laboratory / trace builds carry every issue mode
     if (mode == 3 && (geo == 81 || geo == 148)) return launch_mode<3>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);

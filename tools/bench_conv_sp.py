@@ -12,7 +12,9 @@ sys.path.insert(0, ROOT)
 from coalign_amd import ops  # noqa: E402
 
 SHAPES = ((5, 64, 64, 100, 352), (5, 128, 128, 50, 176), (5, 256, 256, 25, 88), (1, 256, 256, 100, 352), (2, 64, 64, 100, 252), (2, 256, 256, 25, 63))
-WEIGHT = (5, 9, 15, 1, 0, 0)            # stride-1 SplitMap-input 3x3 layers of each shape in one 5-agent OPV2V frame (layer_nums 3 / 5 / 8 + the shrink header's second)
+if os.environ.get("SHAPES"):          # e.g. SHAPES="2x64x64x100x352,2x128x128x50x176": other shapes (frame weights zero)
+    SHAPES = tuple(tuple(int(v) for v in item.split("x")) for item in os.environ["SHAPES"].split(","))
+WEIGHT = (5, 9, 15, 1, 0, 0) if not os.environ.get("SHAPES") else (0,) * len(SHAPES)            # stride-1 SplitMap-input 3x3 layers of each shape in one 5-agent OPV2V frame (layer_nums 3 / 5 / 8 + the shrink header's second)
 
 
 def timed(fn, n=20, reps=5):
