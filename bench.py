@@ -107,7 +107,7 @@ def kernel_trace_us():
     """Average kernel durations (us) of the pillar op and the fusion from the committed rocprofv3 --kernel-trace --stats summary of
     tools/kernels_only.py (same workload as the roofline figures): an independent clock beside the HIP events."""
     import csv
-    path = next((q for q in (os.path.join(ROOT, "profiles", r, "kernels_isolated_stats.csv") for r in ("round5", "round4", "round3")) if os.path.exists(q)), "")
+    path = next((q for q in (os.path.join(ROOT, "profiles", r, "kernels_isolated_stats.csv") for r in ("round6", "round5", "round4", "round3")) if os.path.exists(q)), "")
     if not path:
         return None
     out = {}
@@ -811,7 +811,7 @@ def main():
         # reads = 2 x FETCH_SIZE (gfx950 tallies the 128-B requests of 16 B/lane streaming loads at 64 B, MI355X_MICROARCH.md
         # "HBM"), writes = WRITE_SIZE; null when no summary is committed for this workload
         pmc, pmc_src = {}, None
-        path = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_summary.json") for r in ("round5", "round4", "round3", "round2")) if os.path.exists(q)), "")
+        path = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_summary.json") for r in ("round6", "round5", "round4", "round3", "round2")) if os.path.exists(q)), "")
         if path and N == 5 and args.pillars == 8000 and args.config == "opv2v_coalign":
             pmc, pmc_src = json.load(open(path)), os.path.relpath(path, ROOT)
 

@@ -24,6 +24,7 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -432,9 +433,14 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
         // workgroup, the partial sums are read by loads issued after it.  Guarded by tests/test_round5_gpu.py::test_conv3x3_sp_stream_k_*.
         if (SPLIT && !head) {
             if (wave_live) {
-                float *slot = a.partial + ((size_t)g * G::WAVES + wave) * (32 * 64) + lane;
+                // round 6: the share leaves as 8 agent-scope 16-byte stores per lane (global_store_dwordx4 sc1: the cache policy of the 4-byte relaxed atomic stores
+                // they replace -- write-through past the XCD's L2 -- at a quarter of the instructions; 1 KB per wavefront instruction)
+                floatx4 *slot4 = reinterpret_cast<floatx4 *>(a.partial + ((size_t)g * G::WAVES + wave) * (32 * 64)) + lane;
 #pragma unroll
-                for (int q = 0; q < 32; ++q) __hip_atomic_store(slot + q * 64, acc[q / 16][q % 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int q4 = 0; q4 < 8; ++q4) {
+                    const floatx4 v = {acc[q4 / 4][4 * (q4 % 4)], acc[q4 / 4][4 * (q4 % 4) + 1], acc[q4 / 4][4 * (q4 % 4) + 2], acc[q4 / 4][4 * (q4 % 4) + 3]};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slot4 + q4 * 64), "v"(v) : "memory");
+                }
             }
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
@@ -454,9 +460,15 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
                 }
                 __syncthreads();
                 if (wave_live) {
-                    const float *slot = a.partial + ((size_t)j * G::WAVES + wave) * (32 * 64) + lane;
+                    const floatx4 *slot4 = reinterpret_cast<const floatx4 *>(a.partial + ((size_t)j * G::WAVES + wave) * (32 * 64)) + lane;
+                    floatx4 sh[8];
 #pragma unroll
-                    for (int q = 0; q < 32; ++q) acc[q / 16][q % 16] += __hip_atomic_load(slot + q * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int q4 = 0; q4 < 8; ++q4) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(sh[q4]) : "v"(slot4 + q4 * 64) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int q4 = 0; q4 < 8; ++q4)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[q4 / 4][4 * (q4 % 4) + e] += sh[q4][e];
                 }
                 rem -= range_start(jg + 1) - range_start(jg);
             }
