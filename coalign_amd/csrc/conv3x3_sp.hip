@@ -25,6 +25,7 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
     using K = Work<BH, BW, NPB, NBX, MODE>;
     static_assert(!(K::PAIRED && SPLIT), "the paired mode runs whole tiles");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
+    __shared__ int s_share_ready;                                   // stream-K: "the next gang's share is there already" (decided by one lane, read by all behind a barrier)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;
     const int HW = a.H * a.W, CI16 = a.Cin / 16, CO16 = a.Cout / 16, groups = a.Cout / kCoutTile, chunks = CI16;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
         if (tg & 1) __builtin_amdgcn_s_setprio(2);
     } else if (MODE != 2 && wave >= G::WAVES / 2) __builtin_amdgcn_s_setprio(1);      // (as conv3x3_emu.hip: the later-dispatched half of the wavefronts loses every arbitration otherwise)
     int L = 0;
+    bool pending_pub = false;                                      // stream-K (round 6): this workgroup's share has left, its flag goes up behind the next interval's barrier
     while (L < n_local) {
         const int c_begin = SPLIT ? chunk0 : 0, c_end = SPLIT && (n_local - L) < (chunks - c_begin) ? c_begin + (n_local - L) : chunks;
         const bool head = !SPLIT || c_begin == 0, complete = !SPLIT || c_end == chunks;
@@ -302,12 +305,13 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
         acc[1] = floatx16{0};
         accl[0] = floatx16{0};
         accl[1] = floatx16{0};
-        uint4 rraw[8];                                             // the residual of this lane's 32 outputs, fetched behind the barrier of the owner's LAST interval
-#pragma unroll
-        for (int g8 = 0; g8 < 8; ++g8) rraw[g8] = uint4{0, 0, 0, 0};
+        uintx4 rraw[8];                                            // the residual of this lane's 32 outputs, fetched behind the barrier of the owner's LAST interval
+#pragma unroll                                                     // (stream-K owners: the same registers first carry the next gang's share, fetched beside that interval)
+        for (int g8 = 0; g8 < 8; ++g8) rraw[g8] = uintx4{0, 0, 0, 0};
         Tile next = cur;
         Plan nplan = plan;
         int ntile = tile;
+        bool share_early = false;
         // (The residual fetch steps a base pointer: two instructions per load instead of ten.  Moving it, or the next tile's plan, behind different taps per
         //  wavefront -- so that a SIMD's other wavefronts keep the matrix pipe fed -- was tried: behind a tap the 32 residual registers are live together with the
         //  prefetched operands, the 12-wavefront geometries spill, and the plan needs a third plan record; no gain measured, dropped.)
@@ -318,12 +322,15 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
 #pragma unroll
                 for (int g8 = 0; g8 < 8; ++g8) {
                     const uint2 h = rb[g8 * step], l = rb[g8 * step + lo];
-                    rraw[g8] = uint4{h.x, h.y, l.x, l.y};
+                    rraw[g8] = uintx4{h.x, h.y, l.x, l.y};
                 }
             } else if (a.res_kind == SP_RES_NHWC) {
                 const uint4 *rp = reinterpret_cast<const uint4 *>(static_cast<const float *>(a.residual) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half);
 #pragma unroll
-                for (int g8 = 0; g8 < 8; ++g8) rraw[g8] = rp[2 * g8];
+                for (int g8 = 0; g8 < 8; ++g8) {
+                    const uint4 t = rp[2 * g8];
+                    rraw[g8] = uintx4{t.x, t.y, t.z, t.w};
+                }
             }
         };
         for (int chunk = c_begin; chunk < c_end; ++chunk, ++L) {
@@ -332,6 +339,10 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
             SP_STAMP(1);
             __syncthreads();
             SP_STAMP(2);
+            if (SPLIT && pending_pub) {                            // every wavefront's share stores are acknowledged (its s_waitcnt above) and all have passed the barrier
+                if (tid == 0) __hip_atomic_store(a.flags + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pending_pub = false;
+            }
             const bool more = L + 1 < n_local;
             int nc = chunk + 1;
             if (more && nc == chunks) {                            // the next interval opens this workgroup's next tile
@@ -340,10 +351,29 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
                 next = decode(ntile);
                 if (loader_here) nplan = make_plan(next);
             }
+            if constexpr (SPLIT) {
+                // Round 6: the owner of a tile its range does not finish looks for the next gang's share BEFORE its own last interval: if the flag is up (the normal
+                // case: that share was computed first thing in the neighbour's range), the eight 16-byte loads fly beside this interval's matrix steps.
+                if (!complete && head && chunk == c_end - 1) {
+                    const int j = (gang + 1) * groups + member_cg;
+                    if (tid == 0) {
+                        const int up = __hip_atomic_load(a.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (up) __hip_atomic_store(a.flags + j, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_share_ready = up;
+                    }
+                    __syncthreads();
+                    share_early = s_share_ready != 0;
+                    if (share_early && wave_live) {
+                        const floatx4 *slot4 = reinterpret_cast<const floatx4 *>(a.partial + ((size_t)j * G::WAVES + wave) * (32 * 64)) + lane;
+#pragma unroll
+                        for (int q4 = 0; q4 < 8; ++q4) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(rraw[q4]) : "v"(slot4 + q4 * 64) : "memory");
+                    }
+                }
+            }
             constexpr bool kPaired = K::PAIRED;
             const int slot_cur = kPaired ? 0 : (L & 1), slot_next = kPaired ? 0 : ((L + 1) & 1);
             if (!K::INTERLEAVED && !kPaired && more && loader_here) issue_all(nplan, nc, slot_next);
-            if (!kPaired && chunk == c_end - 1 && head && wave_live && !SP_ABLATE(8)) fetch_residual();
+            if (!kPaired && chunk == c_end - 1 && head && complete && wave_live && !SP_ABLATE(8)) fetch_residual();      // (an owner that still has to take shares in fetches it behind them)
             SP_STAMP(3);
             if (wave_live && !SP_ABLATE(4)) {
                 const uint4 *bq = reinterpret_cast<const uint4 *>(lds + K::NBUF * G::W_BYTES + slot_cur * G::B_BYTES) + bshift, *wq = reinterpret_cast<const uint4 *>(lds + slot_cur * G::W_BYTES) + wlane;
@@ -442,17 +472,33 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
                     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slot4 + q4 * 64), "v"(v) : "memory");
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(a.flags + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (round 6: the flag is raised behind the NEXT interval's wait + barrier -- the stores' write-through latency, ~2 us, runs beside that interval's matrix
+            //  steps instead of in front of them; a range that ends with its share raises it after the loop)
+            pending_pub = true;
             cur = next;
             plan = nplan;
             tile = ntile;
             continue;
         }
         if (SPLIT && !complete) {                                  // owner of a tile this range does not finish: the following workgroups' shares
-            int rem = chunks - c_end;
-            for (int jg = gang + 1; rem > 0; ++jg) {
+            int rem = chunks - c_end, jg0 = gang + 1;
+            if (share_early) {                                     // fetched beside the last interval
+                if (wave_live) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int q4 = 0; q4 < 8; ++q4)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned u = rraw[q4][e];        // (through a local: see the epilogue)
+                            acc[q4 / 4][4 * (q4 % 4) + e] += __builtin_bit_cast(float, u);
+                        }
+#pragma unroll
+                    for (int g8 = 0; g8 < 8; ++g8) rraw[g8] = uintx4{0, 0, 0, 0};
+                }
+                rem -= range_start(jg0 + 1) - range_start(jg0);
+                ++jg0;
+            }
+            for (int jg = jg0; rem > 0; ++jg) {
                 const int j = jg * groups + member_cg;             // the same member of the next gang
                 if (tid == 0) {
                     while (__hip_atomic_load(a.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
@@ -472,6 +518,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
                 }
                 rem -= range_start(jg + 1) - range_start(jg);
             }
+            if (wave_live && !SP_ABLATE(8)) fetch_residual();      // (not prefetched behind the last interval: its 32 registers are the early share's there)
         }
         // ---- epilogue: y = (acc + 2^-10 accl) * 2^-k_c + (residual + bias), ReLU, stored as an SP map or as channels-last fp32.  It is VALU bound (two or
         // three wavefronts per SIMD all arrive here together, the matrix pipe idles): ~700 vector instructions per wavefront in the first version = 8400 cycles
@@ -492,8 +539,9 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
         } else {                                                   // channels-last float32, or none (rraw is zero)
 #pragma unroll
             for (int g8 = 0; g8 < 8; ++g8) {
-                rr[g8][0] = __builtin_bit_cast(float, rraw[g8].x); rr[g8][1] = __builtin_bit_cast(float, rraw[g8].y);
-                rr[g8][2] = __builtin_bit_cast(float, rraw[g8].z); rr[g8][3] = __builtin_bit_cast(float, rraw[g8].w);
+                const unsigned u0 = rraw[g8].x, u1 = rraw[g8].y, u2 = rraw[g8].z, u3 = rraw[g8].w;      // (bit-casting a vector ELEMENT directly is miscompiled by hipcc 7.2 -- pillar_sparse.hip swap32: go through locals)
+                rr[g8][0] = __builtin_bit_cast(float, u0); rr[g8][1] = __builtin_bit_cast(float, u1);
+                rr[g8][2] = __builtin_bit_cast(float, u2); rr[g8][3] = __builtin_bit_cast(float, u3);
             }
         }
         SP_STAMP_AT(6, L - 1);
@@ -518,8 +566,9 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) rr[g8][j] = coalign::sp16_join(h[j], l[j]);
                 } else {
-                    rr[g8][0] = __builtin_bit_cast(float, rraw[g8].x); rr[g8][1] = __builtin_bit_cast(float, rraw[g8].y);
-                    rr[g8][2] = __builtin_bit_cast(float, rraw[g8].z); rr[g8][3] = __builtin_bit_cast(float, rraw[g8].w);
+                    const unsigned u0 = rraw[g8].x, u1 = rraw[g8].y, u2 = rraw[g8].z, u3 = rraw[g8].w;      // (bit-casting a vector ELEMENT directly is miscompiled by hipcc 7.2 -- pillar_sparse.hip swap32: go through locals)
+                rr[g8][0] = __builtin_bit_cast(float, u0); rr[g8][1] = __builtin_bit_cast(float, u1);
+                    rr[g8][2] = __builtin_bit_cast(float, u2); rr[g8][3] = __builtin_bit_cast(float, u3);
                 }
             }
 #pragma unroll
@@ -550,6 +599,11 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
         cur = next;
         plan = nplan;
         tile = ntile;
+    }
+    if (SPLIT && pending_pub) {                                    // the range ended with a share: nothing left to hide the stores behind
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.flags + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #ifdef SP_TRACE
     if (tid == 0) a.trace[2 * 16 * 64 * 8 + 2 * g + 1] = wall_clock64();
@@ -651,6 +705,14 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
     const int rounds = (a.total_tiles + slots - 1) / slots;
     const long long steps = (long long)a.total_tiles * chunks;
     bool split = CAN_SPLIT && chunks >= 16 && a.total_tiles > slots && (long long)a.total_tiles * 100 < (long long)rounds * slots * 88;
+    // Round 6: the hand-over became cheap -- a share is eight agent-scope 16-byte stores per lane (32 four-byte ones before), its flag goes up behind the publisher's
+    // NEXT interval, the owner fetches it beside its own last interval -- and with it cutting an UNDER-FILLED single round pays alone on the GPU (5 x 256 x 25 x 88,
+    // 192 tiles: 43.4-44.4 -> 41.8-42.8 us; 2 x 256 x 25 x 63, 56 tiles: 39.2 -> 27 us; round 5's hand-over: 42.6 -> 49.7 and 38.6 -> 67.9).  It is NOT done:
+    // (1) inside the two-stream frame pipeline the cut stage-3 layers cost 4.5 % frames/s (594-596 against 621-624, same box, alternating: a launch that owns every
+    // CU leaves the other frame's kernels nothing, and its owners spin); (2) the cut depends on the tile count, i.e. on the BATCH -- an agent's maps would differ in
+    // the last bits between one rank encoding five agents and five ranks encoding one each, and the sharded runs are bit-identical to the single-rank run by
+    // construction (tests/test_sharded_gpu.py caught it).  The shrink header (always one image) keeps its cut and gains the cheaper hand-over: 124.8 -> 117-119 us.
+    // (profiles/round6/experiments/conv_sp_stream_k_handover.txt; split_policy 2 = the laboratory's forced cut)
     if (split_policy == 1) split = false;
     if (split_policy == 2) split = CAN_SPLIT && chunks >= 2 && steps >= slots;
     const int n_groups = a.Cout / kCoutTile;
