@@ -697,7 +697,12 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
     a.tiles_y = (a.H + G::TH - 1) / G::TH;                            // per image (not stacked)
     const int row_tiles = a.stack ? (a.N * a.H + G::TH - 1) / G::TH : a.N * a.tiles_y;
     a.total_tiles = a.tiles_x * row_tiles * (a.Cout / kCoutTile);
-    const int slots = n_cu * (KW::PAIRED ? 2 : 1), chunks = a.Cin / 16;      // 111-147 KB of LDS: one workgroup per CU (paired mode: 65-70 KB, two)
+    int slots = n_cu * (KW::PAIRED ? 2 : 1);                           // 111-147 KB of LDS: one workgroup per CU (paired mode: 65-70 KB, two)
+    {   // laboratory switch: fewer persistent workgroups than CUs (what a launch leaves free, the other frame's kernels take)
+        const int cap = coalign::lab_env("COALIGN_SP_SLOTS", 0);
+        if (cap > 0 && cap < slots) slots = cap;
+    }
+    const int chunks = a.Cin / 16;
     // Stream-K pays where whole tiles leave the last round badly filled AND a workgroup's range spans whole tiles, i.e. at most one hand-over per workgroup
     // (the shrink header: 572 tiles of 16 intervals = three rounds at 74 %: 132 -> 125 us).  Measured where a tile is cut into several shares
     // (profiles/round5/conv_sp_layers.json): 5 x 256 x 25 x 88 (192 tiles on 256 CUs, 12 of 16 intervals each) 42.6 -> 49.7 us, 2 x 256 x 25 x 63 (56 tiles)
