@@ -98,6 +98,12 @@ SPLIT_MAPS = os.environ.get("COALIGN_SPLIT_MAPS", "1") != "0"
 HEAD_SPLIT_MAPS = os.environ.get("COALIGN_HEAD_SPLIT_MAPS", "1") != "0"
 
 
+# Round 6: the STRIDED first convolution of a stage on split operands too (csrc/conv3x3_sp_s2.hip, include/coalign_amd.h (9f)): the sparse canvas's rows are
+# packed to sp16 rows and gathered by LDS-DMA; a dense stage output is packed to a SplitMap first.  "sparse": the first stage only, "all": every stage whose
+# first convolution has Cin % 16 == 0, "0": the consumer-split kernel of rounds 4-5 (csrc/conv3x3_emu.hip) everywhere.  Read at every call.
+S2_SPLIT = os.environ.get("COALIGN_S2_SP", "all")
+
+
 def split_maps_active() -> bool:
     return SPLIT_MAPS and CONV_EMU_TERMS == 16 and NHWC_STAGE_OUTPUTS and CONV_EMU_TAP_MAJOR and POINTWISE_EMU
 
@@ -287,22 +293,32 @@ class BasicBlock(nn.Module):
             return d is not None and c1.in_channels % 8 == 0 and d[0].stride[0] == 2 and d[0].in_channels % 16 == 0 and d[0].in_channels <= 256 and d[0].out_channels % 32 == 0
         return self.stride == 1 and self.downsample is None and c1.in_channels % 16 == 0
 
-    def _forward_split(self, x, out_channels_last: bool):
+    def _forward_split(self, x, out_channels_last: bool, out_both: bool = False, x_split=None):
         """conv1 -> SplitMap -> conv2 (+ skip) -> SplitMap, or channels-last float32 at the end of a stage (resblock.py:53-69)."""
         w1, b1, w2, b2, wd, p1, p2, pd = self._folded()
         if self.stride == 2:
+            s2 = S2_SPLIT if p1.cin % 16 == 0 else "0"
             if isinstance(x, ops.SparseCanvas):
-                y = ops.conv3x3_emu_sparse(x, p1.emu(16, False), b1, p1.cout, True, 16, out_channels_last=False, out_split=True)
+                if s2 in ("sparse", "all") and p1.cin >= 32:
+                    y = ops.conv3x3_sp_s2(x, p1.emu(16, True), b1, p1.cout, True)
+                else:
+                    y = ops.conv3x3_emu_sparse(x, p1.emu(16, False), b1, p1.cout, True, 16, out_channels_last=False, out_split=True)
                 skip = ops.pointwise_conv_sparse(x, pd[0].get(), pd[1], wd.shape[0], False, out_channels_last=True)
             else:
+                xs = x if isinstance(x, ops.SplitMap) else x_split
                 if isinstance(x, ops.SplitMap):
                     x = x.dense(channels_last=True)
-                y = ops.conv3x3_emu_bias_act(x, p1.emu(16, False), b1, p1.cout, None, True, 16, stride=2, out_split=True)
+                if s2 == "all":
+                    y = ops.conv3x3_sp_s2(xs if xs is not None else ops.SplitMap.pack(x), p1.emu(16, True), b1, p1.cout, True)
+                else:
+                    y = ops.conv3x3_emu_bias_act(x, p1.emu(16, False), b1, p1.cout, None, True, 16, stride=2, out_split=True)
                 skip = ops.pointwise_conv(x, pd[0].get(), pd[1], wd.shape[0], in_stride=2, relu=False, out_channels_last=True)
         else:
             xs = x if isinstance(x, ops.SplitMap) else ops.SplitMap.pack(x)
             y = ops.conv3x3_sp(xs, p1.emu(16, True), b1, p1.cout, None, True, out_split=True)
             skip = xs
+        if out_both:                                       # (channels-last float32 for the fusion kernel and the skip, SplitMap for the next stage's strided convolution)
+            return ops.conv3x3_sp(y, p2.emu(16, True), b2, p2.cout, skip, True, out_both=True)
         return ops.conv3x3_sp(y, p2.emu(16, True), b2, p2.cout, skip, True, out_split=not out_channels_last)
 
     def _forward_sparse(self, sc: "ops.SparseCanvas", out_channels_last: bool) -> torch.Tensor:
@@ -315,15 +331,19 @@ class BasicBlock(nn.Module):
         skip = ops.pointwise_conv_sparse(sc, pw, pd[1], wd.shape[0], False, out_channels_last=wino)
         return conv3x3_fused(y, p2, w2, b2, skip, out_channels_last=(wino or out_channels_last) and p2 is not None and p2.cout % 4 == 0)
 
-    def forward(self, x: torch.Tensor, out_channels_last: bool = False, out_split: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, out_channels_last: bool = False, out_split: bool = False, out_both: bool = False, x_split=None) -> torch.Tensor:
         """``out_split``: the caller (``ResNetStages``' per-block loop) reads ``ops.SplitMap``s and wants one back.  A plain ``block(x)`` / ``nn.Sequential`` call
         always gets a tensor, and the SplitMap route is taken for float32 CUDA tensors and for this build's own map types only -- half / float64
         inputs run the reference's module sequence below."""
         if self.takes_split_maps() and (isinstance(x, (ops.SplitMap, ops.SparseCanvas)) or _fast_ok(self, x)):
             f = self._folded()
             if f[5] is not None and f[6] is not None and (self.stride == 1 or f[7] is not None):
-                y = self._forward_split(x, out_channels_last)
+                y = self._forward_split(x, out_channels_last, out_both=out_both and out_channels_last, x_split=x_split)
+                if out_both:                               # (round 6: the stage's last block; the caller asked for the pair)
+                    return y if isinstance(y, tuple) else (y, None)
                 return y.dense() if isinstance(y, ops.SplitMap) and not out_split else y
+        if out_both:
+            return self.forward(x, out_channels_last, out_split), None
         if isinstance(x, ops.SplitMap):
             x = x.dense()
         if isinstance(x, ops.SparseCanvas):
@@ -379,14 +399,26 @@ class ResNetStages(nn.Module):
 
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
         feats = []
+        carry = None                                         # the SplitMap of the previous stage's output (round 6), when that stage wrote one
         if isinstance(x, ops.SparseCanvas) and not (NHWC_STAGE_OUTPUTS and emu_active() and FAST_INFERENCE and not self.training):
             x = x.dense()
         for i in range(self.layernum):
             layer = getattr(self, f"layer{i}")
             if NHWC_STAGE_OUTPUTS and emu_active() and (isinstance(x, ops.SparseCanvas) or _fast_ok(self, x)):
+                # round 6 (S2_SPLIT = all): the stage's last block also hands the next stage's strided convolution the SplitMap of its output
+                nxt = getattr(self, f"layer{i + 1}")[0] if i + 1 < self.layernum else None
+                both = (S2_SPLIT == "all" and nxt is not None and isinstance(nxt, BasicBlock) and nxt.stride == 2 and nxt.conv1.in_channels % 16 == 0 and nxt.takes_split_maps()
+                        and len(layer) > 1)
+                x_split = carry if not isinstance(x, (ops.SparseCanvas, ops.SplitMap)) else None
+                carry = None
                 for j, blk in enumerate(layer):
                     last = j == len(layer) - 1
-                    x = blk(x, out_channels_last=last, out_split=not last)
+                    if last and both:
+                        x, carry = blk(x, out_channels_last=True, out_split=False, out_both=True)
+                    elif j == 0 and x_split is not None:
+                        x = blk(x, out_channels_last=last, out_split=not last, x_split=x_split)
+                    else:
+                        x = blk(x, out_channels_last=last, out_split=not last)
             else:
                 x = layer(x)
             if isinstance(x, ops.SplitMap):          # (a stage output is always a tensor: fusion, the exchange and the next stage read it)

@@ -29,7 +29,7 @@ LAB_LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip_lab.so")
 # cause).  `python -m coalign_amd.build --labvec`; COALIGN_LAB=vec loads it.  tools/pk_f32_recheck.sh runs the experiment.
 LABVEC_LIB_PATH = os.path.join(LIB_DIR, "libcoalign_hip_labvec.so")
 INCLUDE = os.path.join(REPO, "include")
-SOURCES = ["status.cpp", "pillar_scatter.hip", "pillar_sparse.hip", "warp_fuse.hip", "warp_fuse_nhwc.hip", "decode.hip", "nms.hip", "epilogue.hip", "voxelize.hip", "pose_graph.hip", "conv3x3.hip", "conv3x3_emu.hip", "conv3x3_sp.hip", "pointwise.hip"]
+SOURCES = ["status.cpp", "pillar_scatter.hip", "pillar_sparse.hip", "warp_fuse.hip", "warp_fuse_nhwc.hip", "decode.hip", "nms.hip", "epilogue.hip", "voxelize.hip", "pose_graph.hip", "conv3x3.hip", "conv3x3_emu.hip", "conv3x3_sp.hip", "conv3x3_sp_s2.hip", "pointwise.hip"]
 # Kernels that were measured and NOT adopted live in the laboratory library only: the Winograd F(2x2, 3x3) convolution (1.14 x / 0.89 x / 1.05 x
 # against the direct kernel per stage) -- include/coalign_amd_lab.h, coalign_amd.hip.lab_lib(), tests/test_round4_gpu.py keep it testable.
 LAB_ONLY_SOURCES = ["conv3x3_wino.hip"]

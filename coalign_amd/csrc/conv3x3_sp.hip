@@ -39,6 +39,7 @@ struct SpArgs {
     const float *__restrict__ bias, *__restrict__ wscale;      // wscale: [Cout] 2^-k_c, [Cout] 2^k_c
     const void *__restrict__ residual;  // SP map or channels-last fp32, per res_kind
     void *__restrict__ y;               // SP map or channels-last fp32, per the OUT template argument
+    void *__restrict__ y2;              // OUT = SP_OUT_BOTH (round 6): the SP map beside the channels-last fp32 map in y (a stage's last layer: the fusion kernel reads y, the next stage's strided convolution y2)
     int *range_flag;                    // may be NULL: bit 0 is set when an SP output value exceeds the pair's range (|y| > 65504)
     int N, Cin, Cout, H, W, relu, res_kind, stack, tiles_x, tiles_y, total_tiles, xcd;
     int stream_out;                     // laboratory switch (round 6): the SP output leaves with streaming (non-temporal) stores (common.h store_stream); measured, not adopted
@@ -99,7 +100,7 @@ __device__ __forceinline__ void dma16(const uint4 *src, unsigned lds_byte) {    
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds_byte)), "v"(src) : "memory", "m0");
 }
 
-enum { SP_OUT_SP = 1, SP_OUT_NHWC = 2 };
+enum { SP_OUT_SP = 1, SP_OUT_NHWC = 2, SP_OUT_BOTH = 3 };
 enum { SP_RES_NONE = 0, SP_RES_SP = 1, SP_RES_NHWC = 2 };
 
 // MODE: who issues the LDS-DMA of the next interval, and when (measured: tools/trace_conv_sp.py)
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
         const float floor_v = a.relu ? 0.f : -__builtin_inff();   // (a NaN leaves as the floor: v_max returns the other operand, as fmaxf(v, 0) always did under ReLU)
         float vmax = 0.f;
         // first store position of this lane: group 0 of the tile's 64 channels; every further 8-channel group lies 2 planes (SP) / 8 floats (channels-last) on
-        uint4 *ysp = static_cast<uint4 *>(a.y) + ((size_t)(on * CO16 + cur.cg * 4) * 4 + half) * HW + pix;
+        uint4 *ysp = static_cast<uint4 *>(OUT == SP_OUT_BOTH ? a.y2 : a.y) + ((size_t)(on * CO16 + cur.cg * 4) * 4 + half) * HW + pix;
         float4 *ycl = reinterpret_cast<float4 *>(static_cast<float *>(a.y) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half);
         const size_t sp_step = 2 * (size_t)HW;
         float4 b4 = bias4[0], i4 = winv4[0];
@@ -576,9 +577,10 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
                 const int q = g8 / 4, e = 4 * (g8 % 4) + j;
                 v[j] = fmaxf(acc[q][e] * ii[j] + (rr[g8][j] + bb[j]), floor_v);
             }
-            if constexpr (OUT == SP_OUT_NHWC) {
+            if constexpr (OUT == SP_OUT_NHWC || OUT == SP_OUT_BOTH) {
                 if (live && !SP_ABLATE(16)) ycl[2 * g8] = float4{v[0], v[1], v[2], v[3]};      // (16 bytes per pixel and instruction: streaming stores measured +16 % here -- partial lines; the SP map's 512-byte runs below gain 4 %)
-            } else {
+            }
+            if constexpr (OUT == SP_OUT_SP || OUT == SP_OUT_BOTH) {
                 vmax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), vmax));
                 unsigned h01, l01, h23, l23;
                 coalign::sp16_split2(v[0], v[1], h01, l01);
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
                 ysp += sp_step;
             }
         }
-        if constexpr (OUT == SP_OUT_SP) {
+        if constexpr (OUT == SP_OUT_SP || OUT == SP_OUT_BOTH) {
             if (a.range_flag && live && vmax > 65504.f) atomicOr(a.range_flag, 1);
         }
         SP_STAMP_AT(7, L - 1);
@@ -672,11 +674,14 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
     auto k_cl = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC, MODE, false>;
     auto k_sp_s = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP, MODE, CAN_SPLIT>;
     auto k_cl_s = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC, MODE, CAN_SPLIT>;
+    auto k_both = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_BOTH, MODE, false>;
+    auto k_both_s = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_BOTH, MODE, CAN_SPLIT>;
     if (!cus[dev]) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
         if (!query) {
-            for (const void *fn : {reinterpret_cast<const void *>(k_sp), reinterpret_cast<const void *>(k_cl), reinterpret_cast<const void *>(k_sp_s), reinterpret_cast<const void *>(k_cl_s)}) {
+            for (const void *fn : {reinterpret_cast<const void *>(k_sp), reinterpret_cast<const void *>(k_cl), reinterpret_cast<const void *>(k_sp_s), reinterpret_cast<const void *>(k_cl_s),
+                                   reinterpret_cast<const void *>(k_both), reinterpret_cast<const void *>(k_both_s)}) {
                 const int rc = coalign::hip_call(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KW::LDS_BYTES));
                 if (rc != COALIGN_OK) {
                     (void)hipGetLastError();
@@ -739,8 +744,8 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
         a.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + l.flag_bytes);
     }
     constexpr int kThreads = Work<BH, BW, NPB, NBX, MODE>::THREADS;
-    if (split) hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp_s : k_cl_s, dim3(l.grid), dim3(kThreads), KW::LDS_BYTES, s, a);
-    else hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp : k_cl, dim3(l.grid), dim3(kThreads), KW::LDS_BYTES, s, a);
+    if (split) hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp_s : out_kind == SP_OUT_BOTH ? k_both_s : k_cl_s, dim3(l.grid), dim3(kThreads), KW::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp : out_kind == SP_OUT_BOTH ? k_both : k_cl, dim3(l.grid), dim3(kThreads), KW::LDS_BYTES, s, a);
     return COALIGN_OK;
 }
 
@@ -857,14 +862,33 @@ extern "C" size_t coalign_conv3x3_sp_workspace_bytes(int N, int Cin, int Cout, i
     return dispatch_sp(a, SP_OUT_SP, geometry, nullptr, 0, nullptr, &l) == COALIGN_OK ? l.ws_bytes : 0;
 }
 
+static int conv3x3_sp_impl(const void *x_sp, const void *w_split, const float *bias, const void *residual, int residual_kind, void *y, void *y2, int out_kind,
+                           int N, int Cin, int Cout, int H, int W, int relu, int geometry, int32_t *range_flag, void *workspace, size_t workspace_bytes, void *stream);
+
 extern "C" int coalign_conv3x3_sp(const void *x_sp, const void *w_split, const float *bias, const void *residual, int residual_kind, void *y, int out_kind,
                                   int N, int Cin, int Cout, int H, int W, int relu, int geometry, int32_t *range_flag, void *workspace, size_t workspace_bytes,
                                   void *stream) {
+    if (out_kind != SP_OUT_SP && out_kind != SP_OUT_NHWC) return y && x_sp && w_split && bias ? COALIGN_ERR_UNSUPPORTED : COALIGN_ERR_NULL_POINTER;
+    return conv3x3_sp_impl(x_sp, w_split, bias, residual, residual_kind, y, nullptr, out_kind, N, Cin, Cout, H, W, relu, geometry, range_flag, workspace, workspace_bytes, stream);
+}
+
+// Round 6: a stage's LAST layer writes its map twice -- channels-last float32 (fusion kernel, exchange, 1 x 1 skip) and SP map (the next stage's strided
+// convolution, coalign_conv3x3_sp_s2): the SP map holds coalign_sp_pack of the float32 map, bit for bit.
+extern "C" int coalign_conv3x3_sp_both(const void *x_sp, const void *w_split, const float *bias, const void *residual, int residual_kind, float *y_nhwc, void *y_sp,
+                                       int N, int Cin, int Cout, int H, int W, int relu, int geometry, int32_t *range_flag, void *workspace, size_t workspace_bytes,
+                                       void *stream) {
+    if (!y_sp) return COALIGN_ERR_NULL_POINTER;
+    if (reinterpret_cast<uintptr_t>(y_sp) & 15) return COALIGN_ERR_UNSUPPORTED;
+    return conv3x3_sp_impl(x_sp, w_split, bias, residual, residual_kind, y_nhwc, y_sp, SP_OUT_BOTH, N, Cin, Cout, H, W, relu, geometry, range_flag, workspace, workspace_bytes, stream);
+}
+
+static int conv3x3_sp_impl(const void *x_sp, const void *w_split, const float *bias, const void *residual, int residual_kind, void *y, void *y2, int out_kind,
+                           int N, int Cin, int Cout, int H, int W, int relu, int geometry, int32_t *range_flag, void *workspace, size_t workspace_bytes, void *stream) {
     using namespace coalign;
     if (!x_sp || !w_split || !bias || !y || (residual_kind != SP_RES_NONE && !residual)) return COALIGN_ERR_NULL_POINTER;
     int rc = sp_check(N, Cin, Cout, H, W);
     if (rc != COALIGN_OK) return rc;
-    if ((out_kind != SP_OUT_SP && out_kind != SP_OUT_NHWC) || residual_kind < 0 || residual_kind > SP_RES_NHWC) return COALIGN_ERR_UNSUPPORTED;
+    if ((out_kind != SP_OUT_SP && out_kind != SP_OUT_NHWC && out_kind != SP_OUT_BOTH) || residual_kind < 0 || residual_kind > SP_RES_NHWC) return COALIGN_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(x_sp) | reinterpret_cast<uintptr_t>(w_split) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) return COALIGN_ERR_UNSUPPORTED;
     if (N == 0) return COALIGN_OK;
     const size_t wbytes = coalign_conv3x3_emu_weight_bytes_ex(Cin, Cout, 16, 1), tail = (size_t)Cout * 8;
@@ -877,6 +901,7 @@ extern "C" int coalign_conv3x3_sp(const void *x_sp, const void *w_split, const f
     a.wscale = reinterpret_cast<const float *>(wb + wbytes - tail);
     a.residual = residual;
     a.y = y;
+    a.y2 = y2;
     a.range_flag = range_flag;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.relu = relu; a.res_kind = residual_kind;
     a.xcd = 1;

@@ -73,6 +73,11 @@ SIGNATURES = {
     "coalign_sp_unpack": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_conv3x3_sp_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "coalign_conv3x3_sp": (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "coalign_conv3x3_sp_both": (c_int, [P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "coalign_sp_rows_bytes": (c_size_t, [c_int, c_int]),
+    "coalign_sp_pack_rows": (c_int, [P, c_int, P, c_int, P, P, P]),
+    "coalign_conv3x3_sp_s2": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "coalign_conv3x3_sp_s2_sparse": (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "coalign_pointwise_conv": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_pointwise_conv_ex": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_pointwise_emu_weight_bytes": (c_size_t, [c_int, c_int]),

@@ -415,7 +415,9 @@ def pillar_encode_sparse(voxel_features: torch.Tensor, voxel_num_points: torch.T
         with _Timed("pillar_encode_sparse"):
             hip.check(L.coalign_pillar_encode_sparse_frame(_ptr(frame.words), M, P, _ptr(folded), C, int(use_absolute_xyz), _dbl3(voxel_size), _dbl3(range_min), n_agents,
                                                            ny, nx, _ptr(feats), _ptr(entry["stamps"]), _ptr(entry["state"]), _stream()), "coalign_pillar_encode_sparse_frame")
-        return SparseCanvas(feats, entry["stamps"], entry["state"], None, n_agents, C, ny, nx, None, owner=entry)
+        sc = SparseCanvas(feats, entry["stamps"], entry["state"], None, n_agents, C, ny, nx, None, owner=entry)
+        sc.count_word = frame.words[3:4].view(torch.int32)[0:1]      # the record's pillar count (little endian: the low half of word 3), for sp_pack_rows
+        return sc
     with _Timed("pillar_encode_sparse"):
         hip.check(L.coalign_pillar_encode_sparse(_ptr(vf), _ptr(npts), _ptr(coords), M, _ptr(count_dev), P, _ptr(folded), C, int(use_absolute_xyz), _dbl3(voxel_size),
                                                  _dbl3(range_min), n_agents, ny, nx, _ptr(feats), _ptr(entry["stamps"]), _ptr(entry["state"]), _stream()),
@@ -953,13 +955,16 @@ SP_OUT_SP, SP_OUT_NHWC = 1, 2                      # out_kind
 
 
 @_device_op
-def conv3x3_sp(x: "SplitMap", w_split: torch.Tensor, bias: torch.Tensor, cout: int, residual=None, relu: bool = True, out_split: bool = True, geometry: int = 0):
+def conv3x3_sp(x: "SplitMap", w_split: torch.Tensor, bias: torch.Tensor, cout: int, residual=None, relu: bool = True, out_split: bool = True, geometry: int = 0,
+               out_both: bool = False):
     """y = act(conv3x3(x, w, stride 1, padding 1) + bias (+ residual)) on a ``SplitMap`` input (include/coalign_amd.h (9e), csrc/conv3x3_sp.hip): the fp16
     mode's arithmetic with the operand split done by the producer.  ``w_split``: the tap-major terms-16 image of ``pack_conv3x3_emu_weight``; ``residual``: a
     SplitMap, a float32 tensor (converted to channels-last memory if it is not) or None; returns a SplitMap (``out_split``) or a float32 tensor of logical
-    shape [N, C, H, W] in channels-last memory."""
+    shape [N, C, H, W] in channels-last memory; ``out_both`` (round 6, ``coalign_conv3x3_sp_both``): the pair (channels-last float32 tensor, SplitMap of it)."""
     if not isinstance(x, SplitMap):
         raise TypeError("conv3x3_sp reads a SplitMap")
+    if out_both:
+        out_split = False
     _need_gpu(x.data, w_split, bias)
     L = hip.lib()
     N, Cin, H, W = x.shape
@@ -985,10 +990,54 @@ def conv3x3_sp(x: "SplitMap", w_split: torch.Tensor, bias: torch.Tensor, cout: i
             out = y = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
     ws_bytes = L.coalign_conv3x3_sp_workspace_bytes(N, Cin, cout, H, W, int(geometry))
     ws = _sp_workspace(x.device, ws_bytes) if ws_bytes else None
+    if out_both:
+        both = SplitMap.empty(N, cout, H, W, x.device)
+        with _Timed("conv3x3_sp"):
+            hip.check(L.coalign_conv3x3_sp_both(_ptr(x.data), _ptr(w_split), _ptr(_f32c(bias)), _ptr(res_t), res_kind, _ptr(y), _ptr(both.data), N, Cin, cout, H, W, int(relu), int(geometry),
+                                                _ptr(sp_range_flag(x.device)), _ptr(ws), 0 if ws is None else ws.numel(), _stream()), "coalign_conv3x3_sp_both")
+        return out, both
     with _Timed("conv3x3_sp"):
         hip.check(L.coalign_conv3x3_sp(_ptr(x.data), _ptr(w_split), _ptr(_f32c(bias)), _ptr(res_t), res_kind, _ptr(y), SP_OUT_SP if out_split else SP_OUT_NHWC,
                                        N, Cin, cout, H, W, int(relu), int(geometry), _ptr(sp_range_flag(x.device)) if out_split else None,
                                        _ptr(ws), 0 if ws is None else ws.numel(), _stream()), "coalign_conv3x3_sp")
+    return out
+
+
+@_device_op
+def sp_pack_rows(sc: "SparseCanvas") -> torch.Tensor:
+    """The feature rows of a ``SparseCanvas`` as sp16 rows [M, C / 16, 4, 8] float16 (``coalign_sp_pack_rows``, include/coalign_amd.h (9f)): what the LDS-DMA
+    gather of ``conv3x3_sp_s2`` reads.  Rows at and beyond the device-side count (if the canvas has one) are left untouched."""
+    L = hip.lib()
+    M, C = int(sc.feats.shape[0]), sc.C
+    out = torch.empty((max(M, 1), C // 16, 4, 8), dtype=torch.float16, device=sc.device)[:M]
+    with _Timed("sp_pack_rows"):
+        hip.check(L.coalign_sp_pack_rows(_rows_ptr(sc.feats), M, _ptr(sc.count_dev) if sc.count_dev is not None else _ptr(getattr(sc, "count_word", None)), C, _rows_ptr(out),
+                                         _ptr(sp_range_flag(sc.device)), _stream()), "coalign_sp_pack_rows")
+    return out
+
+
+@_device_op
+def conv3x3_sp_s2(x, w_split: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool = True) -> "SplitMap":
+    """y = act(conv3x3(x, w, stride 2, padding 1) + bias) on split operands (include/coalign_amd.h (9f), csrc/conv3x3_sp_s2.hip): ``x`` a ``SplitMap`` or a
+    ``SparseCanvas`` (its rows are packed to sp16 rows first); ``w_split``: the tap-major terms-16 image of ``pack_conv3x3_emu_weight``; returns a ``SplitMap``."""
+    L = hip.lib()
+    N, Cin, H, W = x.shape
+    if w_split.numel() != L.coalign_conv3x3_emu_weight_bytes_ex(Cin, cout, 16, 1):
+        raise ValueError("conv3x3_sp_s2 needs the tap-major terms-16 weight image of (Cin, Cout)")
+    out = SplitMap.empty(N, cout, (H + 1) // 2, (W + 1) // 2, x.device)
+    flag = _ptr(sp_range_flag(x.device))
+    if isinstance(x, SparseCanvas):
+        x.check_current()
+        rows = sp_pack_rows(x)
+        with _Timed("conv3x3_sp_s2_sparse"):
+            hip.check(L.coalign_conv3x3_sp_s2_sparse(_rows_ptr(rows), int(rows.shape[0]), _ptr(x.stamps), _ptr(x.state), _ptr(w_split), _ptr(_f32c(bias)), _ptr(out.data),
+                                                     N, Cin, cout, H, W, int(relu), flag, _stream()), "coalign_conv3x3_sp_s2_sparse")
+        return out
+    if not isinstance(x, SplitMap):
+        raise TypeError("conv3x3_sp_s2 reads a SplitMap or a SparseCanvas")
+    _need_gpu(x.data, w_split, bias)
+    with _Timed("conv3x3_sp_s2"):
+        hip.check(L.coalign_conv3x3_sp_s2(_ptr(x.data), _ptr(w_split), _ptr(_f32c(bias)), _ptr(out.data), N, Cin, cout, H, W, int(relu), flag, _stream()), "coalign_conv3x3_sp_s2")
     return out
 
 

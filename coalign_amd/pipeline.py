@@ -264,6 +264,22 @@ class FramePipeline:
             slot.buf = self.pp.decode_buffers({"ego": out})
         self.pp.enqueue(self.meta, {"ego": out}, slot.buf)
 
+    @staticmethod
+    def _quiesce_collectives(stream) -> None:
+        """Before a capture on a stream a collective has just run on: wait for the stream AND for the collective backend's watchdog to retire the finished work.
+        RCCL's process group records a collective's end event on the caller's stream and its watchdog thread polls that event every 100 ms until it has seen it
+        complete; ROCm's hipEventQuery refuses an event whose stream is capturing at that moment (hipErrorCapturedEvent), which ends the watchdog -- and with it the
+        process -- even under the thread-local capture mode (round 6: 1 run in 12 of tests/test_round6_gpu.py::test_rccl_world_of_one_*, whenever a poll fell into
+        the ~20 ms of a capture).  Three poll periods after the stream has drained no finished work is left to poll.  Captures happen once per (lane, shape)."""
+        stream.synchronize()
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+                import time
+                time.sleep(0.35)
+        except Exception:      # noqa: BLE001  (no process group: nothing polls)
+            pass
+
     def _capture_split(self, k: int, slot: _GraphSlot, record: List[int]) -> None:
         """Encoder graph | collective (eager, on the lane's stream) | tail graph.  Captured with thread-local error mode: a collective backend's watchdog
         thread polls events while we capture."""
@@ -271,13 +287,13 @@ class FramePipeline:
         self._encode_body(slot, record)                         # eager warm-up: weight folds, canvases, the exchange's receive buffers
         feats, rows = self.exchange[k](slot.feats)
         self._tail_body(slot, feats, rows)
-        stream.synchronize()
+        self._quiesce_collectives(stream)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
             self._encode_body(slot, record)
         feats, rows = self.exchange[k](slot.feats)              # on the capture's output maps: these are the send buffers of every replay
         slot.recv_ptrs, slot.rows = tuple(f.data_ptr() for f in feats), None if rows is None else list(rows)
-        stream.synchronize()
+        self._quiesce_collectives(stream)
         t = torch.cuda.CUDAGraph()
         with torch.cuda.graph(t, stream=stream, capture_error_mode="thread_local"):
             self._tail_body(slot, feats, rows)

@@ -385,6 +385,29 @@ size_t coalign_conv3x3_sp_workspace_bytes(int N, int Cin, int Cout, int H, int W
 int coalign_conv3x3_sp(const void *x_sp, const void *w_split, const float *bias, const void *residual, int residual_kind, void *y, int out_kind,
                        int N, int Cin, int Cout, int H, int W, int relu, int geometry, int32_t *range_flag, void *workspace, size_t workspace_bytes, void *stream);
 
+/* (9e') Round 6: coalign_conv3x3_sp writing its map TWICE -- channels-last float32 in y_nhwc (what the fusion kernel, the exchange and the 1 x 1 skip
+ * convolution read) and the SP map in y_sp (what the next stage's strided convolution (9f) reads): the last 3x3 convolution of a ResNet stage
+ * (resblock.py:53-69, base_bev_backbone_resnet.py:95-119).  y_sp holds coalign_sp_pack(y_nhwc), bit for bit; everything else as coalign_conv3x3_sp. */
+int coalign_conv3x3_sp_both(const void *x_sp, const void *w_split, const float *bias, const void *residual, int residual_kind, float *y_nhwc, void *y_sp,
+                            int N, int Cin, int Cout, int H, int W, int relu, int geometry, int32_t *range_flag, void *workspace, size_t workspace_bytes, void *stream);
+
+/* (9f) Round 6: the STRIDED 3x3 convolution (stride 2, pad 1, bias + ReLU: the first convolution of a ResNet stage, resblock.py:53-69 with stride 2 and
+ * :150-174, base_bev_backbone_resnet.py:59-119) in the form of (9e): input already split, K loop = LDS-DMA + matrix instructions (csrc/conv3x3_sp_s2.hip).
+ *   coalign_conv3x3_sp_s2: x_sp = SP map [N, Cin, H, W] -> y_sp = SP map [N, Cout, ceil(H/2), ceil(W/2)]; w_split = the TAP-MAJOR terms-16 image of (9b).
+ *   coalign_conv3x3_sp_s2_sparse: the same layer reading the sparse canvas of (1b): rows_sp = coalign_sp_pack_rows of the feature rows, stamps / state as (9d);
+ *     a stamp naming a row >= M_rows reads as empty.  Cin >= 32.
+ *   coalign_sp_pack_rows: float32 feature rows [M_capacity, C] (C % 16 == 0) -> sp16 rows [M][C / 16][4 planes][8] fp16 (coalign_sp_rows_bytes = M * C * 4
+ *     bytes, 16-byte aligned): a row's 16-byte group (c16, plane) = one matrix operand, fetched by one lane of an LDS-DMA instruction.  M_dev (may be NULL):
+ *     the row count on the device; rows at and beyond it are not touched.
+ *   Output (y, x) is bit-identical to output (2 y, 2 x) of coalign_conv3x3_sp on the same map (same operations in the same order); Cin % 16 == 0,
+ *   Cout % 64 == 0; range_flag as (9e); no workspace. */
+size_t coalign_sp_rows_bytes(int M, int C);
+int coalign_sp_pack_rows(const float *rows, int M_capacity, const int32_t *M_dev, int C, void *rows_sp, int32_t *range_flag, void *stream);
+int coalign_conv3x3_sp_s2(const void *x_sp, const void *w_split, const float *bias, void *y_sp, int N, int Cin, int Cout, int H, int W, int relu,
+                          int32_t *range_flag, void *stream);
+int coalign_conv3x3_sp_s2_sparse(const void *rows_sp, int M_rows, const void *stamps, const int32_t *state, const void *w_split, const float *bias, void *y_sp,
+                                 int N, int Cin, int Cout, int H, int W, int relu, int32_t *range_flag, void *stream);
+
 /* (9c) The Winograd F(2x2, 3x3) convolution of round 4 (measured, not adopted) is exported by the LABORATORY library only: include/coalign_amd_lab.h. */
 
 /* Fill `n_words` 32-bit words at `p` (4-byte aligned) with `value`, as a kernel on `stream` (the per-frame counters of the post-processing

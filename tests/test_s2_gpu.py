@@ -1,0 +1,139 @@
+"""GPU tests of the strided SplitMap convolution (round 6; csrc/conv3x3_sp_s2.hip, include/coalign_amd.h (9f)), all through the C ABI.
+
+The layer is the stride-2 first convolution of a ResNet stage (opencood/models/sub_modules/resblock.py:53-69 with stride 2, :150-174).  A stride-2 / pad-1 3x3
+convolution's output (y, x) is the stride-1 / pad-1 convolution's output (2 y, 2 x), and ``coalign_conv3x3_sp_s2`` runs the SAME operations in the SAME order as
+``coalign_conv3x3_sp``: the two must agree bit for bit on the same SplitMap -- and, through it, with the float64 yardstick of tests/test_round5_gpu.py.
+"""
+import pytest
+import torch
+
+from coalign_amd import backbone, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# (N, Cin, Cout, H, W): the three strided layers of the 5-agent OPV2V workload (the first reads the sparse canvas in the product), DAIR's, and ragged shapes
+S2_SHAPES = [(5, 64, 64, 200, 704), (5, 64, 128, 100, 352), (5, 128, 256, 50, 176), (2, 64, 128, 100, 252), (2, 32, 64, 37, 45), (1, 16, 64, 9, 70), (3, 48, 192, 8, 8), (1, 64, 64, 1, 1),
+             (2, 64, 64, 5, 131)]
+
+
+def conv64(x, w, b, stride):
+    """relu(conv3x3(x, w, stride, pad 1) + b) in float64 as nine matrix products."""
+    N, Ci, H, W = x.shape
+    xp = torch.nn.functional.pad(x.double(), (1, 1, 1, 1))
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    out = torch.zeros((N, w.shape[0], Ho, Wo), dtype=torch.float64, device=x.device)
+    for dy in range(3):
+        for dx in range(3):
+            out += torch.einsum("oc,nchw->nohw", w.double()[:, :, dy, dx], xp[:, :, dy:dy + stride * Ho:stride, dx:dx + stride * Wo:stride])
+    return torch.relu(out + b.double().view(1, -1, 1, 1))
+
+
+def _case(shape, seed, relu=True):
+    N, Ci, Co, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn((N, Ci, H, W), generator=g, device=DEV)
+    w = torch.randn((Co, Ci, 3, 3), generator=g, device=DEV) * (1.0 / (9 * Ci) ** 0.5)
+    b = torch.randn(Co, generator=g, device=DEV) * 0.1
+    return x, w, b
+
+
+@pytest.mark.parametrize("shape", S2_SHAPES)
+@pytest.mark.parametrize("relu", [True, False])
+def test_strided_split_convolution_equals_the_stride_one_kernel_at_even_pixels(shape, relu):
+    x, w, b = _case(shape, 7)
+    img = ops.pack_conv3x3_emu_weight(w, 16, tap_major=True)
+    xs = ops.SplitMap.pack(x)
+    want = ops.conv3x3_sp(xs, img, b, shape[2], None, relu, out_split=True).dense()[:, :, ::2, ::2]
+    got = ops.conv3x3_sp_s2(xs, img, b, shape[2], relu)
+    assert got.shape == tuple(want.shape)
+    assert torch.equal(got.dense(), want)
+    assert torch.equal(got.dense(), got.dense_reference())
+
+
+def test_strided_split_convolution_against_float64():
+    shape = (5, 64, 128, 100, 352)
+    x, w, b = _case(shape, 3)
+    img = ops.pack_conv3x3_emu_weight(w, 16, tap_major=True)
+    got = ops.conv3x3_sp_s2(ops.SplitMap.pack(x), img, b, shape[2], True).dense().double()
+    ref = conv64(x, w, b, 2)
+    err = float((got - ref).abs().max()) / float(ref.abs().max())
+    print(f"\nconv3x3_sp_s2 vs float64: {err:.2e} of the scale")
+    assert err <= 2e-6
+
+
+def _sparse_canvas(n_agents, ny, nx, pillars, seed, count_below_capacity=False):
+    """A SparseCanvas from the one-launch pillar op on random pillars (duplicate cells included: the larger row wins)."""
+    from coalign_amd.config import builtin_config
+    from coalign_amd.detector import build_model
+    from coalign_amd.synthetic import fill_parameters_, make_frame
+    h = builtin_config("opv2v_coalign")
+    model = build_model(h)
+    fill_parameters_(model, seed=seed)
+    model = model.to(DEV).eval()
+    margs = h["model"]["args"]
+    pl = make_frame(h, n_agents, pillars_per_agent=pillars, seed=seed)["processed_lidar"]
+    pfn = model.pillar_vfe.pfn_layers[0]
+    bn = (pfn.norm.weight, pfn.norm.bias, pfn.norm.running_mean, pfn.norm.running_var)
+    gx, gy, _ = [int(v) for v in margs["point_pillar_scatter"]["grid_size"]]
+    assert (gy, gx) == (ny, nx)
+    count_dev = None
+    vf, npts, coords = pl["voxel_features"].to(DEV), pl["voxel_num_points"].to(DEV), pl["voxel_coords"].to(DEV)
+    if count_below_capacity:
+        count_dev = torch.tensor([vf.shape[0] - 1234], dtype=torch.int32, device=DEV)
+    return ops.pillar_encode_sparse(vf, npts, coords, pfn.linear.weight, None, bn, 1e-3, True, margs["voxel_size"], margs["lidar_range"][:3], n_agents, ny, nx, canvas_cache={},
+                                    count_dev=count_dev)
+
+
+@pytest.mark.parametrize("pillars,below", [(8000, False), (3000, True), (40000, False)])
+def test_strided_split_convolution_reads_the_sparse_canvas(pillars, below):
+    """The LDS-DMA gather through the cell stamps: bit-equal to the dense route on the densified canvas (zeros where no pillar lives)."""
+    sc = _sparse_canvas(3, 200, 704, pillars, 11, below)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    w = torch.randn((64, 64, 3, 3), generator=g, device=DEV) * (1.0 / 24.0)
+    b = torch.randn(64, generator=g, device=DEV) * 0.1
+    img = ops.pack_conv3x3_emu_weight(w, 16, tap_major=True)
+    dense = ops.SplitMap.pack(sc.dense())
+    want = ops.conv3x3_sp_s2(dense, img, b, 64, True)
+    got = ops.conv3x3_sp_s2(sc, img, b, 64, True)
+    assert torch.equal(got.data, want.data)
+    ref = ops.conv3x3_sp(dense, img, b, 64, None, True, out_split=True).dense()[:, :, ::2, ::2]
+    assert torch.equal(got.dense(), ref)
+    assert float(got.dense().abs().max()) > 0
+
+
+def test_sp_pack_rows_is_the_split_of_the_rows():
+    sc = _sparse_canvas(2, 200, 704, 5000, 3)
+    rows = ops.sp_pack_rows(sc)
+    M, C = sc.feats.shape
+    d = rows.float()                                           # [M, C/16, 4, 8]
+    v = (d[:, :, 0::2] + d[:, :, 1::2] / 1024.0).reshape(M, C)  # planes (2 * half + term) -> [M, C/16, 2 halves, 8]
+    r = ((sc.feats.contiguous().view(torch.int32) + 2) & -4).view(torch.float32)      # 22 significant bits, ties away from zero
+    assert torch.equal(v, r)
+
+
+def test_model_on_the_strided_split_route_stays_within_the_suite_tolerance():
+    """Whole multiscale backbone, S2_SPLIT = all vs 0: the strided layers change their summation order (16-channel intervals of nine taps instead of tap pairs of
+    8 channels), nothing else: the stage outputs agree to float32 rounding."""
+    from coalign_amd.config import builtin_config
+    from coalign_amd.detector import build_model
+    from coalign_amd.synthetic import fill_parameters_
+    h = builtin_config("opv2v_coalign")
+    model = build_model(h)
+    fill_parameters_(model, seed=0)
+    model = model.to(DEV).eval()
+    sc = _sparse_canvas(3, 200, 704, 6000, 11)
+    saved = backbone.S2_SPLIT
+    try:
+        outs = {}
+        for mode in ("0", "sparse", "all"):
+            backbone.S2_SPLIT = mode
+            with torch.no_grad():
+                outs[mode] = [f.clone() for f in model.backbone.get_multiscale_feature(sc)]
+    finally:
+        backbone.S2_SPLIT = saved
+    for mode in ("sparse", "all"):
+        for a, b in zip(outs[mode], outs["0"]):
+            e = float((a - b).abs().max()) / float(b.abs().max())
+            print(f"\nS2_SPLIT={mode}: {tuple(a.shape)} {e:.2e} of the scale")
+            assert e <= 2e-6

@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""The three strided first convolutions of the 5-agent OPV2V backbone, each alone on the GPU (graph replays of 20 launches, HIP events): the consumer-split
+kernel of rounds 4-5 (csrc/conv3x3_emu.hip: float32 channels-last / sparse canvas in) against round 6's coalign_conv3x3_sp_s2 (SplitMap / sp16 rows in), plus what
+the new route adds in front (coalign_sp_pack / coalign_sp_pack_rows).  Prints one JSON line."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from coalign_amd import ops  # noqa: E402
+
+
+def timed(fn, n=20, reps=5):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    best = 1e9
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); g.replay(); e.record(); torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e) / n * 1e3)
+    return round(best, 2)
+
+
+out = {}
+for (N, Ci, Co, H, W) in ((5, 64, 128, 100, 352), (5, 128, 256, 50, 176), (2, 64, 128, 100, 252)):
+    g = torch.Generator(device="cuda").manual_seed(H + Co)
+    x = torch.relu(torch.randn((N, Ci, H, W), generator=g, device="cuda")).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn((Co, Ci, 3, 3), generator=g, device="cuda") / (9 * Ci) ** 0.5
+    w_pair, w_tap = ops.pack_conv3x3_emu_weight(wt, 16, False), ops.pack_conv3x3_emu_weight(wt, 16, True)
+    b = torch.randn(Co, generator=g, device="cuda")
+    xs = ops.SplitMap.pack(x)
+    key = f"{N}x{Ci}x{Co}x{H}x{W}"
+    out[key] = {"emu_us": timed(lambda: ops.conv3x3_emu_bias_act(x, w_pair, b, Co, None, True, 16, stride=2, out_split=True)),
+                "sp_s2_us": timed(lambda: ops.conv3x3_sp_s2(xs, w_tap, b, Co, True)),
+                "sp_pack_us": timed(lambda: ops.SplitMap.pack(x))}
+from test_s2_gpu import _sparse_canvas  # noqa: E402
+for pillars in (8000,):
+    sc = _sparse_canvas(5, 200, 704, pillars, 11)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    wt = torch.randn((64, 64, 3, 3), generator=g, device="cuda") / 24.0
+    w_pair, w_tap = ops.pack_conv3x3_emu_weight(wt, 16, False), ops.pack_conv3x3_emu_weight(wt, 16, True)
+    b = torch.randn(64, generator=g, device="cuda")
+    rows = ops.sp_pack_rows(sc)
+    L = ops.hip.lib()
+    y = ops.SplitMap.empty(5, 64, 100, 352, "cuda")
+
+    def s2_only():
+        ops.hip.check(L.coalign_conv3x3_sp_s2_sparse(rows.data_ptr(), rows.shape[0], sc.stamps.data_ptr(), sc.state.data_ptr(), w_tap.data_ptr(), b.data_ptr(), y.data.data_ptr(),
+                                                     5, 64, 64, 200, 704, 1, None, ops._stream()), "s2")
+    out[f"sparse_5x{pillars}"] = {"emu_us": timed(lambda: ops.conv3x3_emu_sparse(sc, w_pair, b, 64, True, 16, False, out_split=True)),
+                                 "sp_s2_us": timed(s2_only), "pack_rows_us": timed(lambda: ops.sp_pack_rows(sc)),
+                                 "sp_s2_with_pack_us": timed(lambda: ops.conv3x3_sp_s2(sc, w_tap, b, 64, True))}
+print(json.dumps(out))
