@@ -31,6 +31,7 @@ typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void *lptr_t;
 
 constexpr int kCoutTile = 64;
+constexpr int kMaxCoutLds = 1024;       // output channels whose bias and scale words fit the 8 KB of LDS behind the operand buffers
 
 struct SpArgs {
     const uint4 *__restrict__ x;        // SP map of the input
@@ -68,9 +69,13 @@ struct SpArgs {
 #define SP_ABLATE(bit) 0
 #endif
 
-template <int BH, int BW, int NPB, int NBX>
+// CT (round 6): output channels of a tile -- 64 (a wavefront owns two 32 x 32 accumulator tiles x two accumulators), or 32 (one tile: half the matrix work per
+// wavefront and interval, twice the tasks -- the 25 x 88 maps fill 256 CUs with 12-wavefront workgroups instead of 192 with 8-wavefront ones)
+template <int BH, int BW, int NPB, int NBX, int CT = 64>
 struct Geo {
     static_assert(BH * BW == 32 && NPB % NBX == 0, "a wavefront owns 32 pixels; whole block rows");
+    static_assert(CT == 64 || CT == 32, "output-channel tile");
+    static constexpr int NQ = CT / 32, NG8 = CT / 8;                           // 32 x 32 accumulator tiles per accumulator; 8-channel groups
     static constexpr int WAVES = NPB, THREADS = 64 * NPB;
     static constexpr int TH = BH * NPB / NBX, TW = BW * NBX;                   // output tile
     static constexpr int PWU = TW + 2;                                         // patch columns in use
@@ -78,7 +83,8 @@ struct Geo {
     static constexpr int PH = TH + 4;                                          // halo + the two zero rows of an image boundary inside the tile
     static constexpr int PIX = PH * PW, PIXP = (PIX + 63) / 64 * 64;           // groups per plane, padded to whole DMA instructions
     static constexpr int PINS = PIXP / 64;                                     // DMA instructions per plane
-    static constexpr int WQ = 9 * 2 * 2 * kCoutTile;                           // 16-byte groups of one interval's weights
+    static constexpr int WQ = 9 * 2 * 2 * CT;                                  // 16-byte groups of one interval's weights in LDS
+    static constexpr int WQ_SRC = 9 * 2 * 2 * kCoutTile;                       // ... in the weight image (64 output channels per block)
     static constexpr int WINS = WQ / 64;
     static constexpr int W_BYTES = WQ * 16, B_BYTES = 4 * PIXP * 16;
     static constexpr size_t LDS_BYTES = 2 * (size_t)W_BYTES + 2 * (size_t)B_BYTES;      // both operands double buffered (Work::LDS_BYTES: what a mode really takes)
@@ -118,15 +124,16 @@ enum { SP_RES_NONE = 0, SP_RES_SP = 1, SP_RES_NHWC = 2 };
 //      A workgroup alone would expose the DMA latency every interval; its PARTNER on the CU runs matrix steps meanwhile (and through the other one's tile prologue,
 //      epilogue and barrier waits: profiles/round5/experiments/conv_sp_epilogue_phases.md named this remedy).  The workgroup in the CU's odd slot (HW_ID.TG_ID) issues
 //      at a higher priority, so that two workgroups that start in step fall out of step instead of sharing the pipe and then loading together.
-template <int BH, int BW, int NPB, int NBX, int MODE>
+template <int BH, int BW, int NPB, int NBX, int MODE, int CT = 64>
 struct Work {
-    using G = Geo<BH, BW, NPB, NBX>;
+    using G = Geo<BH, BW, NPB, NBX, CT>;
     static constexpr int EXTRA = MODE == 3 ? 1 : MODE == 7 ? 4 : 0;             // loader-only wavefronts on top of the computing ones (MODE 7, round 6: one per SIMD)
     static constexpr int LOADERS = MODE == 2 ? 4 : EXTRA ? EXTRA : G::WAVES;
     static constexpr bool INTERLEAVED = MODE == 1 || MODE == 4 || MODE == 5;
     static constexpr bool PAIRED = MODE == 6;                                   // two workgroups per CU, single buffers
     static constexpr int NBUF = PAIRED ? 1 : 2;
-    static constexpr size_t LDS_BYTES = (size_t)NBUF * ((size_t)G::W_BYTES + (size_t)G::B_BYTES);
+    static constexpr size_t OPERAND_BYTES = (size_t)NBUF * ((size_t)G::W_BYTES + (size_t)G::B_BYTES);
+    static constexpr size_t LDS_BYTES = OPERAND_BYTES + 2 * kMaxCoutLds * sizeof(float);      // + the layer's bias | 2^-k_c words (round 6: the epilogue reads them from LDS)
     static constexpr int WAVES_PER_EU = PAIRED ? 4 : (NPB + 3) / 4;              // (the defaults the work-group size implies, except for the paired mode's cap)
     static_assert(!PAIRED || NPB == 8, "two workgroups per CU: 8-wavefront geometries (16 wavefronts per CU = 4 per SIMD at 128 registers)");
     static_assert(!PAIRED || 2 * LDS_BYTES <= 160 * 1024, "two workgroups of this geometry do not fit the 160 KB LDS");
@@ -135,16 +142,26 @@ struct Work {
     static constexpr int WJ = (G::WINS + LOADERS - 1) / LOADERS, PJ = (G::PINS + LOADERS - 1) / LOADERS, OPS = WJ + 4 * PJ;
 };
 
-template <int BH, int BW, int NPB, int NBX, int OUT, int MODE, bool SPLIT>
+template <int BH, int BW, int NPB, int NBX, int OUT, int MODE, bool SPLIT, int CT = 64>
 __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), (MODE == 6 ? 4 : MODE == 7 ? (NPB + 7) / 4 : (NPB + 3) / 4)) void conv3x3_sp_kernel(const SpArgs a) {
-    using G = Geo<BH, BW, NPB, NBX>;
-    using K = Work<BH, BW, NPB, NBX, MODE>;
+    using G = Geo<BH, BW, NPB, NBX, CT>;
+    using K = Work<BH, BW, NPB, NBX, MODE, CT>;
     static_assert(!(K::PAIRED && SPLIT), "the paired mode runs whole tiles");
+    static_assert(CT == 64 || !SPLIT, "stream-K hand-overs carry 64-channel tiles");
+    constexpr int NQ = G::NQ, NG8 = G::NG8;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     __shared__ int s_share_ready;                                   // stream-K: "the next gang's share is there already" (decided by one lane, read by all behind a barrier)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;
-    const int HW = a.H * a.W, CI16 = a.Cin / 16, CO16 = a.Cout / 16, groups = a.Cout / kCoutTile, chunks = CI16;
+    const int HW = a.H * a.W, CI16 = a.Cin / 16, CO16 = a.Cout / 16, groups = a.Cout / CT, chunks = CI16;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
+    // Round 6: bias | 2^-k_c of every output channel -> LDS, once per workgroup.  The epilogue used to load them from memory: ~800 clocks of exposed latency per
+    // tile, and the vmcnt wait the compiler puts in front of their first use also waits for the next tile's LDS-DMA (invisible to its counter model).  The first
+    // interval's s_waitcnt + barrier orders these stores before any epilogue.
+    float *lds_par = reinterpret_cast<float *>(lds + K::OPERAND_BYTES);
+    for (int i = tid; i < a.Cout / 4; i += K::THREADS) {
+        reinterpret_cast<float4 *>(lds_par)[i] = reinterpret_cast<const float4 *>(a.bias)[i];
+        reinterpret_cast<float4 *>(lds_par + a.Cout)[i] = reinterpret_cast<const float4 *>(a.wscale)[i];
+    }
     // LDS map: weight buffers 0 | 1, patch buffers 0 | 1 (paired mode: one of each)
     int member_cg = 0;                                                        // (set below, before decode() is first called)
     const bool loader = K::EXTRA ? wave >= G::WAVES : wave < K::LOADERS, compute = wave < G::WAVES;
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
     int boff[9];                                                              // group of this lane's pixel under tap s, inside plane (2 * half + term 0)
 #pragma unroll
     for (int s = 0; s < 9; ++s) boff[s] = 2 * half * G::PIXP + (py + s / 3) * G::PW + px + s % 3;
-    const int wlane = half * kCoutTile + p;                                   // this lane's group inside one (tap, term) weight block
+    const int wlane = half * CT + p;                                   // this lane's group inside one (tap, term) weight block
 
     // tile id t: whole-tile schedule = spatial tile * groups + output-channel group (the groups of one spatial tile are neighbours: they read the same patch);
     // stream-K = spatial tile only, the group is the workgroup's MEMBER index inside its gang (below)
@@ -189,7 +206,9 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
     };
     auto make_plan = [&](const Tile &t) {
         Plan pl;
-        pl.wsrc = a.wt + (size_t)t.cg * chunks * G::WQ + lane;
+        // (CT = 32: a 1 KB piece = the two channel halves of one (tap, term): lanes 0-31 / 32-63 fetch 32 of the image's 64 output channels each)
+        pl.wsrc = CT == 64 ? a.wt + (size_t)t.cg * chunks * G::WQ_SRC + lane
+                           : a.wt + (size_t)(t.cg >> 1) * chunks * G::WQ_SRC + (lane >> 5) * kCoutTile + (t.cg & 1) * 32 + (lane & 31);
 #pragma unroll
         for (int j = 0; j < K::PJ; ++j) {
             const int i = (lw + K::LOADERS * j) * 64 + lane;
@@ -209,7 +228,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
     auto issue_op = [&](const Plan &pl, int c, int slot, int k) {
         if (k < K::WJ) {
             const int ins = lw + K::LOADERS * k;
-            if (ins < G::WINS && !SP_ABLATE(1)) dma16(pl.wsrc + (size_t)c * G::WQ + ins * 64, lds0 + slot * G::W_BYTES + ins * 1024);
+            if (ins < G::WINS && !SP_ABLATE(1)) dma16(pl.wsrc + (size_t)c * G::WQ_SRC + ins * (64 * kCoutTile / CT), lds0 + slot * G::W_BYTES + ins * 1024);
         } else {
             const int j = (k - K::WJ) / 4, q = (k - K::WJ) % 4, ins = lw + K::LOADERS * j;
             if (ins < G::PINS && !SP_ABLATE(2))
@@ -301,11 +320,12 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
         const bool wave_live = compute && __builtin_amdgcn_readfirstlane((int)(cur.n0 * a.H + cur.yl0 + blk_y * BH < (a.stack ? a.N * a.H : cur.n0 * a.H + a.H) && cur.x0 + blk_x * BW < a.W)) != 0;
         const size_t pix = live ? (size_t)gy * a.W + gx : 0;
         const int on = live ? out_n : 0;
-        floatx16 acc[2], accl[2];
-        acc[0] = floatx16{0};
-        acc[1] = floatx16{0};
-        accl[0] = floatx16{0};
-        accl[1] = floatx16{0};
+        floatx16 acc[NQ], accl[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            acc[q] = floatx16{0};
+            accl[q] = floatx16{0};
+        }
         uintx4 rraw[8];                                            // the residual of this lane's 32 outputs, fetched behind the barrier of the owner's LAST interval
 #pragma unroll                                                     // (stream-K owners: the same registers first carry the next gang's share, fetched beside that interval)
         for (int g8 = 0; g8 < 8; ++g8) rraw[g8] = uintx4{0, 0, 0, 0};
@@ -318,17 +338,17 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
         //  prefetched operands, the 12-wavefront geometries spill, and the plan needs a third plan record; no gain measured, dropped.)
         auto fetch_residual = [&]() {
             if (a.res_kind == SP_RES_SP) {                         // h groups | l groups: 8 bytes each per (lane, 8-channel group); consecutive groups lie two planes apart
-                const uint2 *rb = reinterpret_cast<const uint2 *>(a.residual) + (((size_t)(on * CO16 + cur.cg * 4) * 4) * HW + pix) * 2 + half;
+                const uint2 *rb = reinterpret_cast<const uint2 *>(a.residual) + (((size_t)(on * CO16 + cur.cg * (CT / 16)) * 4) * HW + pix) * 2 + half;
                 const size_t step = 4 * (size_t)HW, lo = 2 * (size_t)HW;
 #pragma unroll
-                for (int g8 = 0; g8 < 8; ++g8) {
+                for (int g8 = 0; g8 < NG8; ++g8) {
                     const uint2 h = rb[g8 * step], l = rb[g8 * step + lo];
                     rraw[g8] = uintx4{h.x, h.y, l.x, l.y};
                 }
             } else if (a.res_kind == SP_RES_NHWC) {
-                const uint4 *rp = reinterpret_cast<const uint4 *>(static_cast<const float *>(a.residual) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half);
+                const uint4 *rp = reinterpret_cast<const uint4 *>(static_cast<const float *>(a.residual) + ((size_t)on * HW + pix) * a.Cout + cur.cg * CT + 4 * half);
 #pragma unroll
-                for (int g8 = 0; g8 < 8; ++g8) {
+                for (int g8 = 0; g8 < NG8; ++g8) {
                     const uint4 t = rp[2 * g8];
                     rraw[g8] = uintx4{t.x, t.y, t.z, t.w};
                 }
@@ -382,20 +402,20 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
 #pragma unroll
                     for (int t = 0; t < 2; ++t) b[t] = __builtin_bit_cast(halfx8, bq[t * G::PIXP + boff[s]]);
                 };
-                auto load_w = [&](int s, halfx8 (&w)[2][2]) {
+                auto load_w = [&](int s, halfx8 (&w)[NQ][2]) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+                    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) w[q][t] = __builtin_bit_cast(halfx8, wq[((s * 2 + t) * 2) * kCoutTile + q * 32]);
+                        for (int t = 0; t < 2; ++t) w[q][t] = __builtin_bit_cast(halfx8, wq[((s * 2 + t) * 2) * CT + q * 32]);
                 };
-                halfx8 bc[2], wc[2][2];
+                halfx8 bc[2], wc[NQ][2];
                 if constexpr (!kPaired) {
                     load_b(0, bc);
                     load_w(0, wc);
                 }
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
-                    halfx8 bn[2], wn[2][2];
+                    halfx8 bn[2], wn[NQ][2];
                     if constexpr (kPaired) {                       // four wavefronts per SIMD hide the LDS latency; no second operand set in the 128 registers
                         load_b(s, bc);
                         load_w(s, wc);
@@ -410,11 +430,11 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
                         }
                     }
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) accl[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[q][0], bc[1], accl[q], 0, 0, 0);      // w_h x_l'
+                    for (int q = 0; q < NQ; ++q) accl[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[q][0], bc[1], accl[q], 0, 0, 0);      // w_h x_l'
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) accl[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[q][1], bc[0], accl[q], 0, 0, 0);      // w_l' x_h
+                    for (int q = 0; q < NQ; ++q) accl[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[q][1], bc[0], accl[q], 0, 0, 0);      // w_l' x_h
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[q][0], bc[0], acc[q], 0, 0, 0);        // w_h x_h
+                    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[q][0], bc[0], acc[q], 0, 0, 0);        // w_h x_h
                     if constexpr (MODE == 1) {
                         if (more) {
 #pragma unroll
@@ -432,8 +452,8 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
                             bc[t] = bn[t];
-                            wc[0][t] = wn[0][t];
-                            wc[1][t] = wn[1][t];
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) wc[q][t] = wn[q][t];
                         }
                     }
                 }
@@ -455,14 +475,15 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
         SP_STAMP_AT(5, L - 1);                                     // (epilogue stamps land in the record of the tile's last interval: 5 start, 6 residual in float, 7 stored)
         // the segment's sums, both accumulators joined: t = acc + 2^-10 accl
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[q][e] = fmaf(accl[q][e], coalign::kSp16LowInv, acc[q][e]);
         // Stream-K hand-over, as conv3x3_emu.hip: agent-scope write-through stores / L2-bypassing loads (relaxed atomics), no fences.  Producer: partial
         // sums leave as write-through stores; s_waitcnt(0) = acknowledged; the barrier = true for every wavefront; only then the flag.  Consumer: one lane
         // spins on the flag (and clears it: exactly one consumer per flag and launch, launches on a stream are ordered), the barrier releases the
         // workgroup, the partial sums are read by loads issued after it.  Guarded by tests/test_round5_gpu.py::test_conv3x3_sp_stream_k_*.
-        if (SPLIT && !head) {
+        if constexpr (SPLIT) {
+        if (!head) {
             if (wave_live) {
                 // round 6: the share leaves as 8 agent-scope 16-byte stores per lane (global_store_dwordx4 sc1: the cache policy of the 4-byte relaxed atomic stores
                 // they replace -- write-through past the XCD's L2 -- at a quarter of the instructions; 1 KB per wavefront instruction)
@@ -481,7 +502,7 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
             tile = ntile;
             continue;
         }
-        if (SPLIT && !complete) {                                  // owner of a tile this range does not finish: the following workgroups' shares
+        if (!complete) {                                  // owner of a tile this range does not finish: the following workgroups' shares
             int rem = chunks - c_end, jg0 = gang + 1;
             if (share_early) {                                     // fetched beside the last interval
                 if (wave_live) {
@@ -521,25 +542,26 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
             }
             if (wave_live && !SP_ABLATE(8)) fetch_residual();      // (not prefetched behind the last interval: its 32 registers are the early share's there)
         }
+        }
         // ---- epilogue: y = (acc + 2^-10 accl) * 2^-k_c + (residual + bias), ReLU, stored as an SP map or as channels-last fp32.  It is VALU bound (two or
         // three wavefronts per SIMD all arrive here together, the matrix pipe idles): ~700 vector instructions per wavefront in the first version = 8400 cycles
         // per tile on the 12-wavefront geometries (profiles/round5/experiments/conv_sp_interval_timeline_stage1_stage2.txt, the "gap" of a tile's last interval).
         // Hence: the residual is converted to float ONCE, outside the channel-group loop (no per-group branches on its kind), ReLU is one v_max against a floor,
         // the range check one running maximum, the store address a running pointer, each group's bias / scale loads are issued one group ahead.
-        const float4 *bias4 = reinterpret_cast<const float4 *>(a.bias + cur.cg * kCoutTile + 4 * half), *winv4 = reinterpret_cast<const float4 *>(a.wscale + cur.cg * kCoutTile + 4 * half);
+        const float4 *bias4 = reinterpret_cast<const float4 *>(lds_par + cur.cg * CT + 4 * half), *winv4 = reinterpret_cast<const float4 *>(lds_par + a.Cout + cur.cg * CT + 4 * half);
         float rr[8][4];
         if constexpr (K::PAIRED) {
             // (converted per channel group below: a float copy of all 32 residual values beside the 64 accumulators does not fit the paired mode's 128 registers)
         } else if (a.res_kind == SP_RES_SP) {
 #pragma unroll
-            for (int g8 = 0; g8 < 8; ++g8) {
+            for (int g8 = 0; g8 < NG8; ++g8) {
                 const halfx4 h = __builtin_bit_cast(halfx4, uint2{rraw[g8].x, rraw[g8].y}), l = __builtin_bit_cast(halfx4, uint2{rraw[g8].z, rraw[g8].w});
 #pragma unroll
                 for (int j = 0; j < 4; ++j) rr[g8][j] = coalign::sp16_join(h[j], l[j]);
             }
         } else {                                                   // channels-last float32, or none (rraw is zero)
 #pragma unroll
-            for (int g8 = 0; g8 < 8; ++g8) {
+            for (int g8 = 0; g8 < NG8; ++g8) {
                 const unsigned u0 = rraw[g8].x, u1 = rraw[g8].y, u2 = rraw[g8].z, u3 = rraw[g8].w;      // (bit-casting a vector ELEMENT directly is miscompiled by hipcc 7.2 -- pillar_sparse.hip swap32: go through locals)
                 rr[g8][0] = __builtin_bit_cast(float, u0); rr[g8][1] = __builtin_bit_cast(float, u1);
                 rr[g8][2] = __builtin_bit_cast(float, u2); rr[g8][3] = __builtin_bit_cast(float, u3);
@@ -549,14 +571,14 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
         const float floor_v = a.relu ? 0.f : -__builtin_inff();   // (a NaN leaves as the floor: v_max returns the other operand, as fmaxf(v, 0) always did under ReLU)
         float vmax = 0.f;
         // first store position of this lane: group 0 of the tile's 64 channels; every further 8-channel group lies 2 planes (SP) / 8 floats (channels-last) on
-        uint4 *ysp = static_cast<uint4 *>(OUT == SP_OUT_BOTH ? a.y2 : a.y) + ((size_t)(on * CO16 + cur.cg * 4) * 4 + half) * HW + pix;
-        float4 *ycl = reinterpret_cast<float4 *>(static_cast<float *>(a.y) + ((size_t)on * HW + pix) * a.Cout + cur.cg * kCoutTile + 4 * half);
+        uint4 *ysp = static_cast<uint4 *>(OUT == SP_OUT_BOTH ? a.y2 : a.y) + ((size_t)(on * CO16 + cur.cg * (CT / 16)) * 4 + half) * HW + pix;
+        float4 *ycl = reinterpret_cast<float4 *>(static_cast<float *>(a.y) + ((size_t)on * HW + pix) * a.Cout + cur.cg * CT + 4 * half);
         const size_t sp_step = 2 * (size_t)HW;
         float4 b4 = bias4[0], i4 = winv4[0];
 #pragma unroll
-        for (int g8 = 0; g8 < 8; ++g8) {                           // 8 groups of 4 consecutive channels per lane: channel = 8 g8 + 4 half + j
+        for (int g8 = 0; g8 < NG8; ++g8) {                         // 8 (CT = 32: 4) groups of 4 consecutive channels per lane: channel = 8 g8 + 4 half + j
             const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
-            if (g8 + 1 < 8) {
+            if (g8 + 1 < NG8) {
                 b4 = bias4[2 * (g8 + 1)];
                 i4 = winv4[2 * (g8 + 1)];
             }
@@ -661,21 +683,21 @@ struct SpLaunch {          // what the host needs to know about one (shape, geom
 };
 
 // split_policy: 0 = by the rule below, 1 = never, 2 = whenever possible (laboratory)
-template <int BH, int BW, int NPB, int NBX, int MODE>
+template <int BH, int BW, int NPB, int NBX, int MODE, int CT = 64>
 int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t workspace_bytes, hipStream_t s, SpLaunch *query) {
-    using G = Geo<BH, BW, NPB, NBX>;
+    using G = Geo<BH, BW, NPB, NBX, CT>;
     constexpr int kMaxDev = 16;
     static int cus[kMaxDev] = {0};                                    // per device: the function attribute belongs to the device's code object
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
-    using KW = Work<BH, BW, NPB, NBX, MODE>;
-    constexpr bool CAN_SPLIT = NPB == 8 && MODE != 3 && MODE != 6 && MODE != 7;    // (the hand-over code needs the 8-wavefront geometries' register budget; the loader wavefront of MODE 3 mirrors whole tiles only; the paired mode runs whole tiles)
-    auto k_sp = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP, MODE, false>;
-    auto k_cl = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC, MODE, false>;
-    auto k_sp_s = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP, MODE, CAN_SPLIT>;
-    auto k_cl_s = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC, MODE, CAN_SPLIT>;
-    auto k_both = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_BOTH, MODE, false>;
-    auto k_both_s = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_BOTH, MODE, CAN_SPLIT>;
+    using KW = Work<BH, BW, NPB, NBX, MODE, CT>;
+    constexpr bool CAN_SPLIT = NPB == 8 && CT == 64 && MODE != 3 && MODE != 6 && MODE != 7;    // (the hand-over code needs the 8-wavefront geometries' register budget; the loader wavefront of MODE 3 mirrors whole tiles only; the paired mode runs whole tiles)
+    auto k_sp = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP, MODE, false, CT>;
+    auto k_cl = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC, MODE, false, CT>;
+    auto k_sp_s = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_SP, MODE, CAN_SPLIT, CT>;
+    auto k_cl_s = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_NHWC, MODE, CAN_SPLIT, CT>;
+    auto k_both = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_BOTH, MODE, false, CT>;
+    auto k_both_s = conv3x3_sp_kernel<BH, BW, NPB, NBX, SP_OUT_BOTH, MODE, CAN_SPLIT, CT>;
     if (!cus[dev]) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
@@ -701,7 +723,7 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
     a.tiles_x = (a.W + G::TW - 1) / G::TW;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;                            // per image (not stacked)
     const int row_tiles = a.stack ? (a.N * a.H + G::TH - 1) / G::TH : a.N * a.tiles_y;
-    a.total_tiles = a.tiles_x * row_tiles * (a.Cout / kCoutTile);
+    a.total_tiles = a.tiles_x * row_tiles * (a.Cout / CT);
     int slots = n_cu * (KW::PAIRED ? 2 : 1);                           // 111-147 KB of LDS: one workgroup per CU (paired mode: 65-70 KB, two)
     {   // laboratory switch: fewer persistent workgroups than CUs (what a launch leaves free, the other frame's kernels take)
         const int cap = coalign::lab_env("COALIGN_SP_SLOTS", 0);
@@ -725,7 +747,7 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
     // (profiles/round6/experiments/conv_sp_stream_k_handover.txt; split_policy 2 = the laboratory's forced cut)
     if (split_policy == 1) split = false;
     if (split_policy == 2) split = CAN_SPLIT && chunks >= 2 && steps >= slots;
-    const int n_groups = a.Cout / kCoutTile;
+    const int n_groups = a.Cout / CT;
     if (split && (slots < n_groups || steps / n_groups < slots / n_groups)) split = false;      // (every gang needs at least one step)
     SpLaunch l;
     l.split = split ? 1 : 0;
@@ -743,7 +765,7 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
         a.flags = static_cast<int *>(workspace);
         a.partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + l.flag_bytes);
     }
-    constexpr int kThreads = Work<BH, BW, NPB, NBX, MODE>::THREADS;
+    constexpr int kThreads = Work<BH, BW, NPB, NBX, MODE, CT>::THREADS;
     if (split) hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp_s : out_kind == SP_OUT_BOTH ? k_both_s : k_cl_s, dim3(l.grid), dim3(kThreads), KW::LDS_BYTES, s, a);
     else hipLaunchKernelGGL(out_kind == SP_OUT_SP ? k_sp : out_kind == SP_OUT_BOTH ? k_both : k_cl, dim3(l.grid), dim3(kThreads), KW::LDS_BYTES, s, a);
     return COALIGN_OK;
@@ -764,6 +786,7 @@ int launch_mode(int geo, const SpArgs &a, int out_kind, int split_policy, void *
             case 121: return launch_geo<1, 32, 12, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);     // 12 x 32
             case 124: return launch_geo<2, 16, 12, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);     // 24 x 16 (2 x 16 blocks)
             case 148: return launch_geo<4, 8, 8, 4, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);       // 8 x 32 in 4 x 8 blocks, four block columns
+            case 326: return launch_geo<4, 8, 12, 6, MODE, 32>(a, out_kind, split_policy, ws, ws_bytes, s, query);  // (round 6) 8 x 48 in 4 x 8 blocks x 32 output channels, 12 wavefronts
             default: return COALIGN_ERR_UNSUPPORTED;
         }
     }
@@ -785,18 +808,30 @@ int dispatch_sp(const SpArgs &a, int out_kind, int geometry, void *ws, size_t ws
         // Round 6: a 12-wavefront geometry that leaves more than a quarter of the CUs without a tile loses to the 8-wavefront one whose (smaller) tiles still fit one
         // round: 2 x 64 -> 64 @ 100 x 252 (DAIR stage 1: 136 tiles of 12 x 32 against 200 of 8 x 32 on 256 CUs) 21.5 -> 17.0 us.  Same sums in the same order:
         // the geometries are bit-equal (tests/test_round5_gpu.py).
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        const int rows = a.N * a.H, groups = a.Cout / kCoutTile;
         if (geo == 121 || geo == 124) {
-            static int n_cu = 0;
-            if (!n_cu) {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-            }
             const int th12 = geo == 121 ? 12 : 24, tw12 = geo == 121 ? 32 : 16, alt = (a.W % 32 == 0 || a.W % 32 > 24) ? 81 : 148;
-            const int rows = a.N * a.H, groups = a.Cout / kCoutTile;
             const long long t12 = (long long)((rows + th12 - 1) / th12) * ((a.W + tw12 - 1) / tw12) * groups;
             const long long t8 = (long long)((rows + 7) / 8) * ((a.W + 31) / 32) * groups;
             if (t12 * 4 < 3LL * n_cu && t8 <= n_cu) geo = alt;
+        }
+        // Round 6, measured and NOT made the rule: an 8-wavefront geometry whose 64-channel tiles leave a fifth of the CUs idle, where 8 x 48 tiles of 32 output
+        // channels still fit one round (geometry 326: twelve wavefronts of half the matrix work each; 5 x 256 x 25 x 88: 192 tiles of 8 wavefronts on 256 CUs ->
+        // 256 tiles of 12).  Alone on the GPU the layer goes 43.1 -> 39.4 us (2 x 256 x 25 x 63: 39.3 -> 31.4) and one frame in flight 1.99 -> 1.90 ms, but a
+        // wavefront that owns 32 x 32 outputs reads 1.33 LDS operands per matrix instruction instead of 1.0 -- an interval is ~4900 clocks for 2592 of matrix work
+        // (64-channel tiles: 4600 for 3456) -- and the launch holds every CU: the two-stream frame pipeline LOSES 1.6 % (646.6 against 657.2 frames/s, same box,
+        // alternating).  Same sums in the same order per output value: bit-equal to the other geometries (tests/test_s2_gpu.py).  A latency-bound caller selects
+        // it per map size (coalign_amd/ops.py: COALIGN_SP_GEO="25x88:326"); the laboratory build's COALIGN_SP_CT32=1 makes it the rule.
+        if ((geo == 81 || geo == 148) && a.H >= 8 && coalign::lab_env("COALIGN_SP_CT32", 0)) {
+            const long long t64 = (long long)((rows + 7) / 8) * ((a.W + 31) / 32) * groups;
+            const long long t32 = (long long)((rows + 7) / 8) * ((a.W + 47) / 48) * groups * 2;
+            if (t64 * 5 <= 4LL * n_cu && t32 <= n_cu) geo = 326;
         }
     }
 #if defined(COALIGN_LAB) || defined(SP_TRACE)      // laboratory / trace builds carry every issue mode
@@ -849,7 +884,7 @@ extern "C" int coalign_sp_unpack(const void *x_sp, float *y, int out_nhwc, int N
 
 static int sp_check(int N, int Cin, int Cout, int H, int W) {
     if (N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return COALIGN_ERR_BAD_SHAPE;
-    if (Cin % 16 || Cout % kCoutTile) return COALIGN_ERR_UNSUPPORTED;
+    if (Cin % 16 || Cout % kCoutTile || Cout > kMaxCoutLds) return COALIGN_ERR_UNSUPPORTED;
     if ((int64_t)N * (Cin > Cout ? Cin : Cout) * H * W > (int64_t)1 << 32) return COALIGN_ERR_UNSUPPORTED;      // group offsets are 32-bit
     return COALIGN_OK;
 }

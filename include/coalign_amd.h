@@ -372,7 +372,8 @@ int coalign_conv3x3_emu_ex(const float *x, const void *w_split, const float *bia
  *   coalign_sp_pack / coalign_sp_unpack: float32 (NCHW, or channels-last if *_nhwc != 0) <-> SP map (unpack(pack(x)) = x rounded to 22 significant bits).
  *   coalign_conv3x3_sp: y = relu?(conv3x3(x, w) + bias + residual);  w_split = the TAP-MAJOR terms-16 image of (9b);
  *     residual_kind 0 none | 1 SP map [N, Cout, H, W] | 2 channels-last float32;  out_kind 1 SP map | 2 channels-last float32;
- *     geometry 0 = chosen from the shape, 81 / 121 / 124 / 148 = a fixed tile geometry (8 x 32, 12 x 32, 24 x 16, 8 x 32 in 4 x 8 blocks);
+ *     geometry 0 = chosen from the shape, 81 / 121 / 124 / 148 = a fixed tile geometry (8 x 32, 12 x 32, 24 x 16, 8 x 32 in 4 x 8 blocks); 326 (round 6) = 8 x 48
+ *     tiles of 32 output channels on 12 wavefronts: never chosen by 0 (a layer's latency -9 ... -20 % on 25-row maps, the frame pipeline's throughput -1.6 %);
  *     range_flag (may be NULL): bit 0 is set when a value written to an SP map exceeded 65504 in magnitude.
  *     workspace: coalign_conv3x3_sp_workspace_bytes(...) bytes (0 = none needed for that shape), 16-byte aligned, ZERO-INITIALISED ONCE by the caller and
  *     then owned by the launches of ONE stream: the stream-K hand-over of tiles cut between workgroups (shapes whose whole tiles would leave the chip badly

@@ -220,7 +220,7 @@ SP_SHAPES = [(1, 16, 64, 4, 4), (2, 16, 64, 5, 6), (1, 32, 128, 6, 35), (3, 16, 
              (5, 32, 64, 7, 3), (3, 32, 64, 26, 40), (2, 32, 64, 50, 48)]
 
 
-@pytest.mark.parametrize("geometry", [81, 121, 124, 148])
+@pytest.mark.parametrize("geometry", [81, 121, 124, 148, 326])      # (326, round 6: 8 x 48 tiles of 32 output channels, 12 wavefronts)
 @pytest.mark.parametrize("shape", SP_SHAPES)
 def test_conv3x3_sp_equals_consumer_split_kernel_bit_for_bit(shape, geometry):
     """The producer-split kernel (csrc/conv3x3_sp.hip) against the fp16 mode of csrc/conv3x3_emu.hip on the same 22-bit inputs: identical bits, for every

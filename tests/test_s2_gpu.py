@@ -137,3 +137,25 @@ def test_model_on_the_strided_split_route_stays_within_the_suite_tolerance():
             e = float((a - b).abs().max()) / float(b.abs().max())
             print(f"\nS2_SPLIT={mode}: {tuple(a.shape)} {e:.2e} of the scale")
             assert e <= 2e-6
+
+
+@pytest.mark.parametrize("shape", [(5, 256, 256, 25, 88), (2, 256, 256, 25, 88), (2, 256, 256, 25, 63), (1, 64, 128, 19, 50)])
+def test_32_channel_tiles_are_bit_equal_to_the_64_channel_geometries_and_both_outputs_agree(shape):
+    """Round 6: ``coalign_conv3x3_sp`` with 8 x 48 tiles of 32 output channels (geometry 326: the 25 x 88 maps fill 256 CUs) -- same sums in the same order as
+    the 64-channel geometries; and ``coalign_conv3x3_sp_both``: the SplitMap beside the channels-last map is ``coalign_sp_pack`` of it, bit for bit."""
+    N, Ci, Co, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = ops.SplitMap.pack(torch.randn((N, Ci, H, W), generator=g, device=DEV))
+    w = ops.pack_conv3x3_emu_weight(torch.randn((Co, Ci, 3, 3), generator=g, device=DEV) / (9 * Ci) ** 0.5, 16, True)
+    b = torch.randn(Co, generator=g, device=DEV)
+    rs = ops.SplitMap.pack(torch.randn((N, Co, H, W), generator=g, device=DEV))
+    for res in (None, rs, rs.dense(channels_last=True)):
+        want = ops.conv3x3_sp(x, w, b, Co, res, True, out_split=True, geometry=100148)
+        want_cl = ops.conv3x3_sp(x, w, b, Co, res, True, out_split=False, geometry=100148)      # (float32: not rounded to the pairs' 22 bits)
+        for geo in (100326, 0):
+            got = ops.conv3x3_sp(x, w, b, Co, res, True, out_split=True, geometry=geo)
+            assert torch.equal(got.data, want.data), (shape, geo)
+            cl = ops.conv3x3_sp(x, w, b, Co, res, True, out_split=False, geometry=geo)
+            assert torch.equal(cl, want_cl), (shape, geo)
+            y, ysp = ops.conv3x3_sp(x, w, b, Co, res, True, geometry=geo, out_both=True)
+            assert torch.equal(y, cl) and torch.equal(ysp.data, ops.SplitMap.pack(y).data) and torch.equal(ysp.data, want.data), (shape, geo)
