@@ -104,6 +104,10 @@ HEAD_SPLIT_MAPS = os.environ.get("COALIGN_HEAD_SPLIT_MAPS", "1") != "0"
 S2_SPLIT = os.environ.get("COALIGN_S2_SP", "all")
 
 
+# Round 6: the up-sampling heads of the three scales as ONE launch (coalign_pointwise_conv_emu_sp_multi) when they write a SplitMap; "0": one launch per scale.
+HEADS_ONE_LAUNCH = os.environ.get("COALIGN_HEADS_ONE_LAUNCH", "1") != "0"
+
+
 def split_maps_active() -> bool:
     return SPLIT_MAPS and CONV_EMU_TERMS == 16 and NHWC_STAGE_OUTPUTS and CONV_EMU_TAP_MAJOR and POINTWISE_EMU
 
@@ -498,8 +502,11 @@ class _MultiscaleDecodeMixin:
                 x = ops.SplitMap.empty(f0.shape[0], c_tot, f0.shape[2] * s0, f0.shape[3] * s0, f0.device)
             else:
                 x = torch.empty((f0.shape[0], c_tot, f0.shape[2] * s0, f0.shape[3] * s0), dtype=torch.float32, device=f0.device)
-            for (f, w, b, cout, up, off), im in zip(ops_, images):
-                ops.pointwise_conv(f, im, b, cout, up=up, relu=True, out=x, c_off=off)
+            if isinstance(x, ops.SplitMap) and HEADS_ONE_LAUNCH and 1 < len(ops_) <= 4:      # round 6: the scales' heads side by side in one launch
+                ops.pointwise_heads_split([(f, im, b, cout, up, off) for (f, w, b, cout, up, off), im in zip(ops_, images)], x)
+            else:
+                for (f, w, b, cout, up, off), im in zip(ops_, images):
+                    ops.pointwise_conv(f, im, b, cout, up=up, relu=True, out=x, c_off=off)
             if len(self.deblocks) > self.num_levels:
                 x = self._deblock(len(self.deblocks) - 1, x)
             return x

@@ -247,13 +247,12 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&out)[3]) {
 }
 
 template <int UP>
-__global__ __launch_bounds__(256) void pointwise_emu_kernel(const PwArgs a) {
-    extern __shared__ uint4 xs[];                         // [3][Cin / 8][TP]
+__device__ __forceinline__ void pointwise_emu_body(const PwArgs &a, uint4 *xs, int bx, int by, int bz) {      // xs: [3][Cin / 8][TP] (dynamic LDS)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, p = lane & 31;
     const int pixels = a.Hp * a.Wp;
     const int PB = a.pb, WPB = 4 / PB, TP = 32 * PB;
-    const int p0 = blockIdx.x * TP, n = blockIdx.z;
-    const int m_base = blockIdx.y * (64 * WPB);
+    const int p0 = bx * TP, n = bz;
+    const int m_base = by * (64 * WPB);
     const size_t in_plane = (size_t)a.Hin * a.Win;
     const float *xin = a.stamps ? a.x : a.x + (size_t)n * a.Cin * in_plane;
     const int G = a.Cin >> 3;
@@ -332,6 +331,45 @@ __global__ __launch_bounds__(256) void pointwise_emu_kernel(const PwArgs a) {
     else pw_store<UP>(a, n, m0, second, p0 + pbk * 32 + p, half, acc0, acc1);
 }
 
+template <int UP>
+__global__ __launch_bounds__(256) void pointwise_emu_kernel(const PwArgs a) {
+    extern __shared__ uint4 xs[];
+    pointwise_emu_body<UP>(a, xs, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Round 6: SEVERAL pointwise layers in ONE launch -- the up-sampling heads of the three scales (base_bev_backbone_resnet.py:121-138) are independent GEMMs writing
+// disjoint channel slices of one concatenated map, each a few hundred workgroups of latency-bound work (2 200 ... 35 200 pixels of ONE fused map: 20 / 19 / 40 us
+// alone on the GPU for 4 us worth of matrix work).  Back to back on a stream they leave most of the chip idle three times; as one launch their workgroups run
+// side by side.  A block's layer comes from its index (the longest layer's blocks first).
+constexpr int kMultiMax = 4;
+struct PwMulti {
+    PwArgs l[kMultiMax];
+    int first[kMultiMax + 1], gx[kMultiMax], gy[kMultiMax];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void pointwise_emu_multi_kernel(const PwMulti m) {
+    extern __shared__ uint4 xs[];
+    const int bid = blockIdx.x;
+    // (a struct member selected by a runtime index would live in scratch: one branch per slot keeps the arguments in scalar registers; first[k] = the grid size
+    //  for every unused slot)
+#define COALIGN_PW_SLOT(K)                                                                  \
+    if (bid >= m.first[K] && bid < m.first[K + 1]) {                                        \
+        const PwArgs &a = m.l[K];                                                           \
+        const int local = bid - m.first[K], gx = m.gx[K], gy = m.gy[K];                     \
+        const int bx = local % gx, by = (local / gx) % gy, bz = local / (gx * gy);          \
+        if (a.up == 4) pointwise_emu_body<4>(a, xs, bx, by, bz);                            \
+        else if (a.up == 2) pointwise_emu_body<2>(a, xs, bx, by, bz);                       \
+        else pointwise_emu_body<1>(a, xs, bx, by, bz);                                      \
+        return;                                                                             \
+    }
+    COALIGN_PW_SLOT(0)
+    COALIGN_PW_SLOT(1)
+    COALIGN_PW_SLOT(2)
+    COALIGN_PW_SLOT(3)
+#undef COALIGN_PW_SLOT
+}
+
 }  // namespace
 
 extern "C" int coalign_pointwise_conv(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
@@ -339,9 +377,10 @@ extern "C" int coalign_pointwise_conv(const float *x, const float *w, const floa
     return coalign_pointwise_conv_ex(x, w, bias, y, N, Cin, Hin, Win, in_stride, Cout, up, M_padded, Ctot, c_off, relu, 0, stream);
 }
 
-static int pointwise_impl(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
-                          int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, bool emu,
-                          void *stream, const void *stamps = nullptr, const int32_t *state = nullptr, bool out_sp = false, int32_t *range_flag = nullptr, int sparse_rows = 0) {
+// argument checks + launch record of one layer; `grid` / `lds` as the single-layer launch would use them
+static int pointwise_prepare(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
+                             int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, bool emu,
+                             const void *stamps, const int32_t *state, bool out_sp, int32_t *range_flag, int sparse_rows, PwArgs &a, dim3 &grid, size_t &lds) {
     using namespace coalign;
     if (!x || !w || !bias || !y) return COALIGN_ERR_NULL_POINTER;
     if (emu && ((Cin & 15) || (reinterpret_cast<uintptr_t>(w) & 15))) return COALIGN_ERR_UNSUPPORTED;
@@ -351,13 +390,12 @@ static int pointwise_impl(const float *x, const float *w, const float *bias, flo
         return COALIGN_ERR_UNSUPPORTED;
     const int M = Cout * up * up;
     if (M_padded < M || M_padded % 32 || (up != 1 && M_padded != M)) return COALIGN_ERR_BAD_SHAPE;
-    if (N == 0) return COALIGN_OK;
     // in_nhwc: bit 0 = channels-last input, bit 1 = channels-last output (up = 1; Ctot, c_off multiples of 4, 16-byte aligned y and bias)
     const int out_nhwc = (in_nhwc >> 1) & 1;
     in_nhwc &= 1;
     if (out_nhwc && (up != 1 || (Ctot & 3) || (c_off & 3) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias)) & 15))) return COALIGN_ERR_UNSUPPORTED;
-    PwArgs a{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu, in_nhwc != 0, 1, out_nhwc,
-             static_cast<const unsigned long long *>(stamps), state, (unsigned)(sparse_rows < 0 ? 0 : sparse_rows), out_sp ? 1 : 0, range_flag};
+    a = PwArgs{x, w, bias, y, N, Cin, Hin, Win, in_stride, (Hin + in_stride - 1) / in_stride, (Win + in_stride - 1) / in_stride, M_padded, up, Cout, Ctot, c_off, relu, in_nhwc != 0, 1, out_nhwc,
+               static_cast<const unsigned long long *>(stamps), state, (unsigned)(sparse_rows < 0 ? 0 : sparse_rows), out_sp ? 1 : 0, range_flag};
     if (out_sp && (!emu || out_nhwc || (Cout & 15) || (Ctot & 15) || (c_off & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15) ||
                    M_padded != Cout * up * up || (size_t)N * Ctot * a.Hp * up * a.Wp * up >= ((size_t)1 << 33)))
         return COALIGN_ERR_UNSUPPORTED;
@@ -370,27 +408,50 @@ static int pointwise_impl(const float *x, const float *w, const float *bias, flo
     if (up == 4 && ((a.Wp * 4) % 4 || (reinterpret_cast<uintptr_t>(y) & 15))) return COALIGN_ERR_UNSUPPORTED;
     if (up == 2 && (reinterpret_cast<uintptr_t>(y) & 7)) return COALIGN_ERR_UNSUPPORTED;
     const int rows_per_wg = 64 * (4 / a.pb), px_per_wg = 32 * a.pb;
-    const dim3 grid((pixels + px_per_wg - 1) / px_per_wg, (M_padded + rows_per_wg - 1) / rows_per_wg, N);
+    grid = dim3((pixels + px_per_wg - 1) / px_per_wg, (M_padded + rows_per_wg - 1) / rows_per_wg, N);
+    lds = 0;
+    if (emu) {
+        lds = (size_t)Cin * px_per_wg * 6;                        // three bf16 terms of the pixel tile (<= 48 KB up to 256 input channels, 96 KB at 512)
+        if (out_sp && lds < (size_t)256 * 33 * 4) lds = (size_t)256 * 33 * 4;      // the SP epilogue parks the workgroup's 256 rows x 32 pixels of floats there
+    }
+    return COALIGN_OK;
+}
+
+static int pointwise_big_lds(size_t lds) {                       // beyond 64 KB of dynamic LDS the kernels need the attribute -- the merged heads of a 384-channel map -- and the
+    using namespace coalign;                                     // attribute belongs to the DEVICE's code object: one flag per device
+    static bool big_lds_dev[16] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    bool &big_lds = big_lds_dev[dev];
+    if (lds > 48 * 1024 && !big_lds) {
+        const void *fns[4] = {reinterpret_cast<const void *>(pointwise_emu_kernel<1>), reinterpret_cast<const void *>(pointwise_emu_kernel<2>),
+                              reinterpret_cast<const void *>(pointwise_emu_kernel<4>), reinterpret_cast<const void *>(pointwise_emu_multi_kernel)};
+        for (const void *fn : fns) {
+            const int rc = hip_call(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            if (rc != COALIGN_OK) {
+                (void)hipGetLastError();
+                return rc;
+            }
+        }
+        big_lds = true;
+    }
+    return COALIGN_OK;
+}
+
+static int pointwise_impl(const float *x, const float *w, const float *bias, float *y, int N, int Cin, int Hin, int Win,
+                          int in_stride, int Cout, int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, bool emu,
+                          void *stream, const void *stamps = nullptr, const int32_t *state = nullptr, bool out_sp = false, int32_t *range_flag = nullptr, int sparse_rows = 0) {
+    using namespace coalign;
+    PwArgs a;
+    dim3 grid;
+    size_t lds;
+    int rc = pointwise_prepare(x, w, bias, y, N, Cin, Hin, Win, in_stride, Cout, up, M_padded, Ctot, c_off, relu, in_nhwc, emu, stamps, state, out_sp, range_flag, sparse_rows, a, grid, lds);
+    if (rc != COALIGN_OK) return rc;
+    if (N == 0) return COALIGN_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (emu) {
-        size_t lds = (size_t)Cin * px_per_wg * 6;                 // three bf16 terms of the pixel tile (<= 48 KB up to 256 input channels, 96 KB at 512)
-        if (out_sp && lds < (size_t)256 * 33 * 4) lds = (size_t)256 * 33 * 4;      // the SP epilogue parks the workgroup's 256 rows x 32 pixels of floats there
-        static bool big_lds_dev[16] = {false};                    // (beyond 64 KB of dynamic LDS the kernels need the attribute -- the merged heads of a 384-channel
-        int dev = 0;                                              //  map -- and the attribute belongs to the DEVICE's code object: one flag per device)
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-        bool &big_lds = big_lds_dev[dev];
-        if (lds > 48 * 1024 && !big_lds) {
-            const void *fns[3] = {reinterpret_cast<const void *>(pointwise_emu_kernel<1>), reinterpret_cast<const void *>(pointwise_emu_kernel<2>),
-                                  reinterpret_cast<const void *>(pointwise_emu_kernel<4>)};
-            for (const void *fn : fns) {
-                const int rc = hip_call(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-                if (rc != COALIGN_OK) {
-                    (void)hipGetLastError();
-                    return rc;
-                }
-            }
-            big_lds = true;
-        }
+        rc = pointwise_big_lds(lds);
+        if (rc != COALIGN_OK) return rc;
         if (up == 4) hipLaunchKernelGGL(pointwise_emu_kernel<4>, grid, dim3(256), lds, s, a);
         else if (up == 2) hipLaunchKernelGGL(pointwise_emu_kernel<2>, grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL(pointwise_emu_kernel<1>, grid, dim3(256), lds, s, a);
@@ -437,4 +498,47 @@ extern "C" int coalign_pointwise_conv_emu_sp(const float *x, const void *w_split
     if (in_nhwc & ~1) return COALIGN_ERR_UNSUPPORTED;
     return pointwise_impl(x, static_cast<const float *>(w_split), bias, static_cast<float *>(y_sp), N, Cin, Hin, Win, in_stride, Cout, up, M_padded, Ctot, c_off, relu, in_nhwc,
                           true, stream, nullptr, nullptr, true, range_flag);
+}
+
+// Round 6: the up-sampling heads of ALL scales in one launch (10c, several layers): layer i reads x[i] ([N, Cin[i], Hin[i], Win[i]], channels-last if in_nhwc[i]) and
+// writes channels [c_off[i], c_off[i] + Cout[i]) of the SP map y_sp [N, Ctot, Hin[i] * up[i], Win[i] * up[i]] (the same output size for every layer).  Results
+// are those of n_layers calls of coalign_pointwise_conv_emu_sp, bit for bit.
+extern "C" int coalign_pointwise_conv_emu_sp_multi(int n_layers, const void *const *x, const void *const *w_split, const void *const *bias, const int32_t *Cin, const int32_t *Hin,
+                                                   const int32_t *Win, const int32_t *Cout, const int32_t *up, const int32_t *c_off, const int32_t *in_nhwc, void *y_sp, int N, int Ctot,
+                                                   int relu, int32_t *range_flag, void *stream) {
+    using namespace coalign;
+    if (!x || !w_split || !bias || !Cin || !Hin || !Win || !Cout || !up || !c_off || !in_nhwc || !y_sp) return COALIGN_ERR_NULL_POINTER;
+    if (n_layers < 1 || n_layers > kMultiMax) return COALIGN_ERR_UNSUPPORTED;
+    PwMulti m{};
+    m.n = n_layers;
+    size_t lds = 0;
+    int order[kMultiMax];
+    long long work[kMultiMax];
+    for (int i = 0; i < n_layers; ++i) {
+        if (in_nhwc[i] & ~1) return COALIGN_ERR_UNSUPPORTED;
+        if (Hin[i] * up[i] != Hin[0] * up[0] || Win[i] * up[i] != Win[0] * up[0]) return COALIGN_ERR_BAD_SHAPE;
+        order[i] = i;
+        work[i] = (long long)Cin[i] * Cout[i] * up[i] * up[i];                     // the longest workgroups first
+    }
+    for (int i = 0; i < n_layers; ++i)
+        for (int j = i + 1; j < n_layers; ++j)
+            if (work[order[j]] > work[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    for (int k = 0; k < n_layers; ++k) {
+        const int i = order[k];
+        dim3 grid;
+        size_t l;
+        const int rc = pointwise_prepare(static_cast<const float *>(x[i]), static_cast<const float *>(w_split[i]), static_cast<const float *>(bias[i]), static_cast<float *>(y_sp), N, Cin[i],
+                                         Hin[i], Win[i], 1, Cout[i], up[i], Cout[i] * up[i] * up[i], Ctot, c_off[i], relu, in_nhwc[i], true, nullptr, nullptr, true, range_flag, 0, m.l[k], grid, l);
+        if (rc != COALIGN_OK) return rc;
+        m.gx[k] = (int)grid.x;
+        m.gy[k] = (int)grid.y;
+        m.first[k + 1] = m.first[k] + (int)(grid.x * grid.y * grid.z);
+        if (l > lds) lds = l;
+    }
+    for (int k = n_layers; k < kMultiMax; ++k) m.first[k + 1] = m.first[n_layers];
+    if (N == 0) return COALIGN_OK;
+    const int rc = pointwise_big_lds(lds);
+    if (rc != COALIGN_OK) return rc;
+    hipLaunchKernelGGL(pointwise_emu_multi_kernel, dim3(m.first[n_layers]), dim3(256), lds, static_cast<hipStream_t>(stream), m);
+    return check_launch();
 }

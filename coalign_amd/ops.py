@@ -1176,6 +1176,33 @@ def pointwise_conv(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
 
 
 @_device_op
+@_device_op
+def pointwise_heads_split(layers, out: "SplitMap", relu: bool = True) -> "SplitMap":
+    """The up-sampling heads of all scales in ONE launch (``coalign_pointwise_conv_emu_sp_multi``, include/coalign_amd.h (10d)): ``layers`` = [(x, w_emu, bias, cout,
+    up, c_off), ...] (at most four), each writing its channel slice of the SplitMap ``out``.  Bit-identical to one ``pointwise_conv(..., out=out)`` per layer."""
+    L = hip.lib()
+    n = len(layers)
+    N = out.shape[0]
+    keep, xs, ws, bs = [], [], [], []
+    ci, hi, wi, co, ups, offs, nh = [], [], [], [], [], [], []
+    for (x, w_emu, bias, cout, up, c_off) in layers:
+        _need_gpu(x, w_emu, bias)
+        nhwc = x.dtype == torch.float32 and is_channels_last(x) and x.shape[1] % 4 == 0
+        xc = x if nhwc else _f32c(x)
+        b = _f32c(bias)
+        if w_emu.dtype != torch.int16 or w_emu.dim() != 5 or w_emu.shape[1] * 16 != xc.shape[1] or not w_emu.is_contiguous() or w_emu.shape[0] * 32 != cout * up * up or xc.shape[0] != N:
+            raise ValueError("pointwise_heads_split: split weight image of (Cin, Cout * up * up), one batch size")
+        keep += [xc, b]
+        xs.append(xc.data_ptr()); ws.append(w_emu.data_ptr()); bs.append(b.data_ptr())
+        ci.append(xc.shape[1]); hi.append(xc.shape[2]); wi.append(xc.shape[3]); co.append(cout); ups.append(up); offs.append(c_off); nh.append(int(nhwc))
+    arr_p = lambda v: (ctypes.c_void_p * n)(*v)
+    arr_i = lambda v: (ctypes.c_int32 * n)(*v)
+    with _Timed("pointwise_heads_split"):
+        hip.check(L.coalign_pointwise_conv_emu_sp_multi(n, arr_p(xs), arr_p(ws), arr_p(bs), arr_i(ci), arr_i(hi), arr_i(wi), arr_i(co), arr_i(ups), arr_i(offs), arr_i(nh), _ptr(out.data),
+                                                        N, out.shape[1], int(relu), _ptr(sp_range_flag(out.device)), _stream()), "coalign_pointwise_conv_emu_sp_multi")
+    return out
+
+
 def boxes_overlap_bev(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Tensor:
     """OpenPCDet-semantics fp32 BEV overlap AREA matrix [Na, Nb] of (x, y, z, dx, dy, dz, heading) boxes."""
     _need_gpu(boxes_a, boxes_b)

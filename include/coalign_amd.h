@@ -498,6 +498,13 @@ int coalign_pointwise_conv_emu_sparse(const float *feats, int M_rows, const void
  * Cout, Ctot, c_off multiples of 16; M_padded == Cout * up * up; in_nhwc: 0 / 1 (input layout); range_flag as in (9e), may be NULL. */
 int coalign_pointwise_conv_emu_sp(const float *x, const void *w_split, const float *bias, void *y_sp, int N, int Cin, int Hin, int Win, int in_stride, int Cout,
                                   int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, int32_t *range_flag, void *stream);
+/* (10d) Round 6: (10c) for SEVERAL layers in ONE launch: the up-sampling heads of the backbone's scales (base_bev_backbone_resnet.py:121-138) are independent GEMMs on
+ * one fused map each (2 200 ... 35 200 pixels), latency bound one after the other; as one launch their workgroups run side by side.  Layer i: x[i] float32
+ * [N, Cin[i], Hin[i], Win[i]] (channels-last if in_nhwc[i]), split weight image w_split[i], bias[i]; writes channels [c_off[i], c_off[i] + Cout[i]) of the SP map
+ * y_sp [N, Ctot, Hin[i] * up[i], Win[i] * up[i]] (one output size for all).  n_layers <= 4.  Bit-identical to n_layers calls of (10c). */
+int coalign_pointwise_conv_emu_sp_multi(int n_layers, const void *const *x, const void *const *w_split, const void *const *bias, const int32_t *Cin, const int32_t *Hin,
+                                        const int32_t *Win, const int32_t *Cout, const int32_t *up, const int32_t *c_off, const int32_t *in_nhwc, void *y_sp, int N, int Ctot,
+                                        int relu, int32_t *range_flag, void *stream);
 
 #ifdef __cplusplus
 }

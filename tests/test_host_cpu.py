@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(REPO, "include", "coalign_amd.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(coalign_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) == 62
+    assert len(declared) == 63
     lib = hip.lib()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/coalign_amd.h but not exported"
@@ -55,6 +55,20 @@ def test_argument_validation_without_a_gpu():
     assert lib.coalign_pointwise_conv_emu_sp(one, one, one, one, 1, 64, 8, 8, 1, 120, 1, 128, 384, 0, 1, 1, null, null) == -3          # Cout % 16
     assert lib.coalign_pointwise_conv_emu_sp(one, one, one, one, 1, 64, 8, 8, 1, 128, 1, 128, 384, 8, 1, 1, null, null) == -3          # c_off % 16
     assert lib.coalign_pointwise_conv_emu_sp(one, one, one, one, 1, 64, 8, 8, 1, 128, 2, 128, 384, 0, 1, 1, null, null) == -2          # M_padded != Cout * up * up
+    # round 6's entry points: the strided SplitMap convolution (dense / sparse canvas), the sp16 row packer, the two-output form of the stride-1 kernel
+    assert lib.coalign_conv3x3_sp_s2(null, one, one, one, 1, 64, 64, 8, 8, 1, null, null) == -1                                         # no input map
+    assert lib.coalign_conv3x3_sp_s2(one, one, one, one, 1, 24, 64, 8, 8, 1, null, null) == -3                                          # Cin % 16
+    assert lib.coalign_conv3x3_sp_s2(one, one, one, one, 1, 64, 96, 8, 8, 1, null, null) == -3                                          # Cout % 64
+    assert lib.coalign_conv3x3_sp_s2(one, one, one, one, 1, 64, 64, 0, 8, 1, null, null) == -2                                          # empty map
+    assert lib.coalign_conv3x3_sp_s2(one, one, one, one, 0, 64, 64, 8, 8, 1, null, null) == 0                                           # no images: nothing to do
+    assert lib.coalign_conv3x3_sp_s2_sparse(one, 10, null, one, one, one, one, 1, 64, 64, 8, 8, 1, null, null) == -1                    # no stamps
+    assert lib.coalign_conv3x3_sp_s2_sparse(one, -1, one, one, one, one, one, 1, 64, 64, 8, 8, 1, null, null) == -2                     # negative row count
+    assert lib.coalign_conv3x3_sp_s2_sparse(one, 10, one, one, one, one, one, 1, 16, 64, 8, 8, 1, null, null) == -3                     # Cin < 32 on the sparse route
+    assert lib.coalign_conv3x3_sp_s2_sparse(one, 10, ctypes.c_void_p(20), one, one, one, one, 1, 64, 64, 8, 8, 1, null, null) == -3     # stamps not 8-byte aligned
+    assert lib.coalign_sp_pack_rows(null, 10, null, 64, one, null, null) == -1 and lib.coalign_sp_pack_rows(one, 10, null, 24, one, null, null) == -3
+    assert lib.coalign_sp_pack_rows(one, 0, null, 64, one, null, null) == 0 and lib.coalign_sp_rows_bytes(100, 64) == 100 * 64 * 4 and lib.coalign_sp_rows_bytes(100, 24) == 0
+    assert lib.coalign_conv3x3_sp_both(one, one, one, null, 0, one, null, 1, 64, 64, 8, 8, 1, 0, null, null, 0, null) == -1            # no SplitMap output
+    assert lib.coalign_conv3x3_sp_both(one, one, one, null, 0, one, ctypes.c_void_p(24), 1, 64, 64, 8, 8, 1, 0, null, null, 0, null) == -3      # ... not 16-byte aligned
 
 
 def test_ops_have_no_cpu_fallback():

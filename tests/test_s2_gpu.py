@@ -159,3 +159,27 @@ def test_32_channel_tiles_are_bit_equal_to_the_64_channel_geometries_and_both_ou
             assert torch.equal(cl, want_cl), (shape, geo)
             y, ysp = ops.conv3x3_sp(x, w, b, Co, res, True, geometry=geo, out_both=True)
             assert torch.equal(y, cl) and torch.equal(ysp.data, ops.SplitMap.pack(y).data) and torch.equal(ysp.data, want.data), (shape, geo)
+
+
+@pytest.mark.parametrize("N,hw", [(1, (100, 352)), (2, (48, 72))])
+def test_heads_in_one_launch_equal_one_launch_per_scale(N, hw):
+    """Round 6: ``coalign_pointwise_conv_emu_sp_multi`` -- the three up-sampling heads (base_bev_backbone_resnet.py:121-138) as one launch write the same SplitMap,
+    bit for bit, as one ``coalign_pointwise_conv_emu_sp`` launch per scale."""
+    from coalign_amd.backbone import PointwisePack
+    H, W = hw
+    g = torch.Generator(device=DEV).manual_seed(N + H)
+    layers, c_off = [], 0
+    for cin, up in ((64, 1), (128, 2), (256, 4)):
+        x = torch.relu(torch.randn((N, cin, H // up, W // up), generator=g, device=DEV)).contiguous(memory_format=torch.channels_last)
+        wt = torch.randn((cin, 128, up, up), generator=g, device=DEV) / cin ** 0.5            # ConvTranspose2d weight [Cin, Cout, k, k]
+        b = torch.randn(128, generator=g, device=DEV) * 0.1
+        layers.append((x, PointwisePack(wt, True).get(), b, 128, up, c_off))
+        c_off += 128
+    want = ops.SplitMap.empty(N, c_off, H, W, DEV)
+    for (x, im, b, cout, up, off) in layers:
+        ops.pointwise_conv(x, im, b, cout, up=up, relu=True, out=want, c_off=off)
+    got = ops.SplitMap.empty(N, c_off, H, W, DEV)
+    got.data.fill_(float("nan"))
+    ops.pointwise_heads_split(layers, got)
+    assert torch.equal(got.data, want.data)
+    assert float(got.dense().abs().max()) > 0

@@ -60,3 +60,19 @@ for pillars in (8000,):
                                  "sp_s2_us": timed(s2_only), "pack_rows_us": timed(lambda: ops.sp_pack_rows(sc)),
                                  "sp_s2_with_pack_us": timed(lambda: ops.conv3x3_sp_s2(sc, w_tap, b, 64, True))}
 print(json.dumps(out))
+# the three up-sampling heads on ONE fused map: a launch per scale against one launch (round 6)
+from coalign_amd.backbone import PointwisePack  # noqa: E402
+g = torch.Generator(device="cuda").manual_seed(3)
+layers, c_off = [], 0
+for cin, up in ((64, 1), (128, 2), (256, 4)):
+    x = torch.relu(torch.randn((1, cin, 100 // up, 352 // up), generator=g, device="cuda")).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn((cin, 128, up, up), generator=g, device="cuda") / cin ** 0.5
+    layers.append((x, PointwisePack(wt, True).get(), torch.randn(128, generator=g, device="cuda"), 128, up, c_off))
+    c_off += 128
+cat = ops.SplitMap.empty(1, c_off, 100, 352, "cuda")
+
+
+def per_scale():
+    for (x, im, b, cout, up, off) in layers:
+        ops.pointwise_conv(x, im, b, cout, up=up, relu=True, out=cat, c_off=off)
+print(json.dumps({"heads_three_launches_us": timed(per_scale, n=10), "heads_one_launch_us": timed(lambda: ops.pointwise_heads_split(layers, cat), n=10)}))
