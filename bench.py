@@ -160,16 +160,17 @@ def conv_layer_rooflines(dev, N, ny, nx, pmc):
     """the six 3x3 layer shapes of the frame, each alone on the GPU (HIP events around graph replays of 8 launches): executed 16-bit
     TFLOP/s against the 2.5 PFLOP/s dense fp16 matrix peak, algorithmic HBM bytes (maps in + residual + out + weights once), launches per frame, and -- from the
     committed rocprofv3 --pmc passes where present -- the matrix-pipe busy share and the corrected HBM bytes.  Kernels: coalign_conv3x3_sp on SplitMaps (the
-    stride-1 layers inside a stage and both convolutions of the shrink header) and the consumer-split fp16 kernel of csrc/conv3x3_emu.hip (the strided layers
-    that start a stage's SplitMap chain from float32 input)."""
+    stride-1 layers inside a stage and both convolutions of the shrink header) and coalign_conv3x3_sp_s2 (round 6: the strided layers that open stages 2 and 3;
+    rounds 4-5 ran them on the consumer-split kernel of csrc/conv3x3_emu.hip)."""
     H1, W1 = ny // 2, nx // 2
     cases = [("stage 1: 64 -> 64 @ %dx%d x %d agents" % (H1, W1, N), "conv_sp_64ch", N, 64, 64, H1, W1, True, 5),
              ("stage 2: 128 -> 128 @ %dx%d x %d" % (H1 // 2, W1 // 2, N), "conv_sp_128ch", N, 128, 128, H1 // 2, W1 // 2, True, 9),
              ("stage 3: 256 -> 256 @ %dx%d x %d" % (H1 // 4, W1 // 4, N), "conv_sp_256ch", N, 256, 256, H1 // 4, W1 // 4, True, 15),
              ("shrink header 2nd: 256 -> 256 @ %dx%d x 1" % (H1, W1), "conv_sp_shrink2_256ch_100x352", 1, 256, 256, H1, W1, True, 1),
              ("shrink header 1st: 384 -> 256 @ %dx%d x 1 (SplitMap from the up-sampling heads in, SplitMap out)" % (H1, W1), "conv_sp_shrink1_384ch_100x352", 1, 384, 256, H1, W1, True, 1),
-             ("first of stage 2 (stride 2): 64 -> 128 @ %dx%d -> %dx%d x %d (consumer-split kernel, channels-last float32 in, SplitMap out)" % (H1, W1, H1 // 2, W1 // 2, N),
-              "conv_fp16x2_s2_64to128_nhwc_in_split_out", N, 64, 128, H1, W1, False, 2)]
+             ("first of stage 2 (stride 2): 64 -> 128 @ %dx%d -> %dx%d x %d (round 6: SplitMap in, SplitMap out)" % (H1, W1, H1 // 2, W1 // 2, N),
+              "conv_sp_s2_64to128", N, 64, 128, H1, W1, False, 1),
+             ("first of stage 3 (stride 2): 128 -> 256 @ %dx%d -> %dx%d x %d" % (H1 // 2, W1 // 2, H1 // 4, W1 // 4, N), "conv_sp_s2_128to256", N, 128, 256, H1 // 2, W1 // 2, False, 1)]
     rows = []
     for name, key, n, ci, co, H, W, sp, per_frame in cases:
         try:
@@ -182,12 +183,11 @@ def conv_layer_rooflines(dev, N, ny, nx, pmc):
                 xs_ = ops.SplitMap.pack(x)
                 fn = lambda: ops.conv3x3_sp(xs_, w16, b, co, res, True, out_split=n > 1 or ci != co)
                 kern = "conv3x3_sp_kernel (csrc/conv3x3_sp.hip)" + (", stream-K" if ops.conv3x3_sp_is_split(n, ci, co, H, W) else "")
-            else:                                         # the strided first convolution of a stage: tap-pair image, channels-last input
+            else:                                         # the strided first convolution of a stage (round 6: on split operands too; the first stage's reads the sparse canvas)
                 res = None
-                xcl = x.contiguous(memory_format=torch.channels_last)
-                w16 = ops.pack_conv3x3_emu_weight(torch.randn((co, ci, 3, 3), generator=g, device=dev) / (9 * ci) ** 0.5, 16, False)
-                fn = lambda: ops.conv3x3_emu_bias_act(xcl, w16, b, co, None, True, 16, stride=2, out_split=True)
-                kern = "conv3x3_emu_kernel, fp16 split, quad staging, two workgroups per CU (csrc/conv3x3_emu.hip)"
+                xs_ = ops.SplitMap.pack(x)
+                fn = lambda: ops.conv3x3_sp_s2(xs_, w16, b, co, True)
+                kern = "conv3x3_sp_s2_kernel (csrc/conv3x3_sp_s2.hip)"
             ms = graph_time(fn, dev)
             so = 1 if sp else 4                           # output pixels per input pixel: 1, or 1/4 for the strided layer
             executed = 3 * 2 * 9 * ci * co * H * W * n // so

@@ -43,6 +43,7 @@ struct SpArgs {
     void *__restrict__ y2;              // OUT = SP_OUT_BOTH (round 6): the SP map beside the channels-last fp32 map in y (a stage's last layer: the fusion kernel reads y, the next stage's strided convolution y2)
     int *range_flag;                    // may be NULL: bit 0 is set when an SP output value exceeds the pair's range (|y| > 65504)
     int N, Cin, Cout, H, W, relu, res_kind, stack, tiles_x, tiles_y, total_tiles, xcd;
+    int prio_mode;                      // round 6: 1 = progress-based issue priority (see the K loop); laboratory switch COALIGN_SP_PRIO
     int stream_out;                     // laboratory switch (round 6): the SP output leaves with streaming (non-temporal) stores (common.h store_stream); measured, not adopted
     // stream-K (split != 0): the (tile, interval) steps are cut into gridDim.x equal contiguous ranges; a workgroup that starts in the middle of a tile
     // publishes the partial sums of its share (slot g of `partial`, then flags[g] = 1), the workgroup that OPENED the tile adds them and runs the epilogue.
@@ -415,6 +416,23 @@ __global__ __launch_bounds__(64 * NPB + (MODE == 3 ? 64 : MODE == 7 ? 256 : 0), 
                 }
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
+                    // Round 6: PROGRESS-BASED issue priority.  A SIMD's two or three wavefronts share one matrix pipe; with fixed priorities the favoured one runs
+                    // through its nine taps first and the last one finishes alone, at the pace of its own operand reads (12-wavefront geometries: the three
+                    // wavefronts of a SIMD end their steps 3100 / 5300 / 6400 clocks after the barrier for 5184 clocks of matrix work; tools/trace_conv_sp.py
+                    // ALLWAVES=1).  A wavefront now lowers its own priority as it advances (taps 0-2: 2, 3-5: 1, 6-8: 0): whoever is behind wins the arbitration.
+                    if (a.prio_mode == 1) {
+                        if (s == 0) __builtin_amdgcn_s_setprio(2);
+                        if (s == 3) __builtin_amdgcn_s_setprio(1);
+                        if (s == 6) __builtin_amdgcn_s_setprio(0);
+                    } else if (a.prio_mode == 2) {                 // ... and the later-dispatched wavefronts (they lose every tie) step down one tap later
+                        const int late = wave >= (2 * G::WAVES + 2) / 3 ? 2 : wave >= G::WAVES / 3 ? 1 : 0;      // thirds of the workgroup = the wavefronts of one SIMD, oldest first
+                        if (s == 0) __builtin_amdgcn_s_setprio(2);
+                        if (s == 3 && late == 0) __builtin_amdgcn_s_setprio(1);
+                        if (s == 4 && late != 0) __builtin_amdgcn_s_setprio(1);
+                        if (s == 6 && late == 0) __builtin_amdgcn_s_setprio(0);
+                        if (s == 7 && late == 1) __builtin_amdgcn_s_setprio(0);
+                        if (s == 8 && late == 2) __builtin_amdgcn_s_setprio(0);
+                    }
                     halfx8 bn[2], wn[NQ][2];
                     if constexpr (kPaired) {                       // four wavefronts per SIMD hide the LDS latency; no second operand set in the 128 registers
                         load_b(s, bc);
@@ -940,10 +958,12 @@ static int conv3x3_sp_impl(const void *x_sp, const void *w_split, const float *b
     a.range_flag = range_flag;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.relu = relu; a.res_kind = residual_kind;
     a.xcd = 1;
+    a.prio_mode = coalign::lab_env("COALIGN_SP_PRIO", 1);      // (0: the fixed priorities of round 5; 2: + the later-dispatched wavefronts step down a tap later -- inside the noise)
     a.stream_out = coalign::lab_env("COALIGN_SP_STREAM", 0);      // (alone on the GPU the SP output gains 4 % from streaming stores; inside the two-stream frame pipeline it LOSES 1.7 %: laboratory switch)
 #ifdef SP_TRACE
     a.trace = g_sp_trace;
-    a.ablate = g_sp_ablate;
+    a.ablate = g_sp_ablate & 31;
+    if (g_sp_ablate & 32) a.prio_mode = 1;      // (trace build: bit 5 of the ablation word switches the progress-based priority on)
 #endif
     rc = dispatch_sp(a, out_kind, geometry, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr);
     return rc != COALIGN_OK ? rc : check_launch();

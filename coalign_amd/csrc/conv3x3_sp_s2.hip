@@ -254,6 +254,11 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_sp_s2_kernel(const S2Args 
                 load_w(0, wc);
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
+                    if (!(a.ablate & 16)) {                        // progress-based issue priority (conv3x3_sp.hip): whoever is behind wins the SIMD's matrix pipe
+                        if (s == 0) __builtin_amdgcn_s_setprio(2);
+                        if (s == 3) __builtin_amdgcn_s_setprio(1);
+                        if (s == 6) __builtin_amdgcn_s_setprio(0);
+                    }
                     halfx8 bn[2], wn[2];
                     if (s + 1 < 9) {                               // operands of the next tap are in flight while this tap's matrix instructions issue (two taps ahead: no gain measured)
                         load_b(s + 1, bn);
@@ -388,7 +393,7 @@ int fill_common(S2Args &a, const void *w_split, const float *bias, void *y_sp, i
 #ifdef COALIGN_LAB
     a.trace = g_s2_trace;
 #endif
-    a.ablate = coalign::lab_env("COALIGN_S2_ABLATE", 0);      // laboratory build: 1 no weight DMA, 2 no patch DMA, 4 no matrix steps, 8 no stores
+    a.ablate = coalign::lab_env("COALIGN_S2_ABLATE", 0);      // laboratory build: 1 no weight DMA, 2 no patch DMA, 4 no matrix steps, 8 no stores, 16 fixed issue priorities
     return COALIGN_OK;
 }
 

@@ -13,7 +13,7 @@ grep -h '"metric"' $OUT/stats.log > $OUT/bench_n1_under_rocprof.json
 ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/iso -- python $ROOT/tools/kernels_only.py 20 > $OUT/iso.log 2>&1 )
 cp $(find $OUT/iso -name "*kernel_stats.csv" | head -1) $OUT/kernels_isolated_stats.csv
 grep -h '^{' $OUT/iso.log > $OUT/kernels_isolated_events.json
-for op in ${PMC_OPS:-pillar_sparse fuse_nhwc_3scales conv_sp_64ch conv_sp_128ch conv_sp_256ch conv_sp_shrink2_256ch_100x352 conv_sp_shrink1_384ch_100x352 conv_fp16x2_s2_64to128_nhwc_in_split_out}; do
+for op in ${PMC_OPS:-pillar_sparse fuse_nhwc_3scales conv_sp_64ch conv_sp_128ch conv_sp_256ch conv_sp_shrink2_256ch_100x352 conv_sp_shrink1_384ch_100x352 conv_sp_s2_64to128 conv_sp_s2_128to256 conv_sp_s2_sparse_canvas_with_row_pack}; do
   i=0
   for ctrs in "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA"; do
     i=$((i+1))

@@ -47,8 +47,11 @@ wsb = L.coalign_conv3x3_sp_workspace_bytes(N, Ci, Co, H, W, geo)
 ws = torch.zeros(max(wsb, 16), dtype=torch.uint8, device="cuda")
 
 
+PRIO = 32 if os.environ.get("PRIO") else 0      # round 6: progress-based issue priority on (bit 5 of the trace build's ablation word)
+
+
 def run(ablate=0, n=1):
-    L.coalign_conv3x3_sp_set_ablate(ablate)
+    L.coalign_conv3x3_sp_set_ablate(ablate | PRIO)
     for _ in range(n):
         rc = L.coalign_conv3x3_sp(xs.data.data_ptr(), w16.data_ptr(), b.data_ptr(), rs.data.data_ptr(), 1, out.data.data_ptr(), 1, N, Ci, Co, H, W, 1, geo, None,
                                   ws.data_ptr() if wsb else None, wsb, None)
@@ -95,6 +98,15 @@ for wg in (0, 1):
             if int(s[5]) and int(s[7]):      # a tile's last interval: the gap in parts (accumulator join + hand-over | residual wait + conversion | the 8 channel groups: scale, split, stores | to the next top)
                 epi = f"   epilogue: join {int(s[5] - s[4])} residual {int(s[6] - s[5])} groups {int(s[7] - s[6])} rest {nxt - int(s[7])}"
             print(f"   {c:3d} " + " ".join(f"{v:7d}" for v in d) + f" | {nxt - int(s[0]):7d}" + epi)
+
+
+if os.environ.get("ALLWAVES"):      # round 6: who arrives last at an interval's barrier -- every wavefront's stamps of intervals 2..4 of workgroup 0, relative to the barrier's release
+    for c in (2, 3, 4):
+        rel = int(t[0, :nw, c, 2].max())
+        print(f"interval {c} of workgroup 0, clocks relative to the barrier's release: wavefront: top-of-interval  own-DMA-landed  released | issue-done steps-done (of this interval)")
+        for wv in range(nw):
+            s = t[0, wv, c]
+            print(f"   wave {wv:2d} (SIMD slot {wv % 4}): {int(s[0]) - rel:7d} {int(s[1]) - rel:7d} {int(s[2]) - rel:7d} | {int(s[3]) - rel:7d} {int(s[4]) - rel:7d}")
 
 
 def timed(ablate):
