@@ -290,7 +290,7 @@ class BasicBlock(nn.Module):
         if self.training or not FAST_INFERENCE or not split_maps_active():
             return False
         c1, c2 = self.conv1, self.conv2
-        if c1.out_channels % 64 or c2.out_channels % 64 or c2.in_channels % 16 or tuple(c1.kernel_size) != (3, 3) or tuple(c2.kernel_size) != (3, 3):
+        if c1.out_channels % 64 or c2.out_channels % 64 or c2.in_channels % 16 or tuple(c1.kernel_size) != (3, 3) or tuple(c2.kernel_size) != (3, 3) or max(c1.out_channels, c2.out_channels) > 1024:      # (the kernels keep a layer's bias / scale words in 8 KB of LDS)
             return False
         if self.stride == 2:
             d = self.downsample
@@ -425,6 +425,7 @@ class ResNetStages(nn.Module):
                         x = blk(x, out_channels_last=last, out_split=not last)
             else:
                 x = layer(x)
+                carry = None                         # (a SplitMap handed on by an earlier stage does not describe this stage's output)
             if isinstance(x, ops.SplitMap):          # (a stage output is always a tensor: fusion, the exchange and the next stage read it)
                 x = x.dense()
             feats.append(x)
