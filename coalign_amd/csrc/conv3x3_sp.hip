@@ -770,6 +770,10 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
     SpLaunch l;
     l.split = split ? 1 : 0;
     l.grid = split ? slots / n_groups * n_groups : (a.total_tiles < slots ? a.total_tiles : slots);      // stream-K: whole gangs (one workgroup per output-channel group)
+    if (!split && a.total_tiles > slots && coalign::lab_env("COALIGN_SP_BALANCE", 0)) {      // laboratory: as many workgroups as give every one the same number of tiles (462 tiles: 231 x 2 instead of 206 x 2 + 50 x 1)
+        const int r = (a.total_tiles + slots - 1) / slots;
+        l.grid = (a.total_tiles + r - 1) / r;
+    }
     l.flag_bytes = split ? coalign::align_up((size_t)(l.grid + 4) * sizeof(int), 256) : 0;
     l.ws_bytes = split ? l.flag_bytes + (size_t)(l.grid + 4) * G::WAVES * 32 * 64 * sizeof(float) : 0;
     if (query) {
