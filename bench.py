@@ -186,11 +186,12 @@ def conv_layer_rooflines(dev, N, ny, nx, pmc):
             else:                                         # the strided first convolution of a stage (round 6: on split operands too; the first stage's reads the sparse canvas)
                 res = None
                 xs_ = ops.SplitMap.pack(x)
-                fn = lambda: ops.conv3x3_sp_s2(xs_, w16, b, co, True)
-                kern = "conv3x3_sp_s2_kernel (csrc/conv3x3_sp_s2.hip)"
+                wsk = ops.pack_conv1x1_sp_weight(torch.randn((co, ci, 1, 1), generator=g, device=dev) / ci ** 0.5)
+                fn = lambda: ops.conv3x3_sp_s2(xs_, w16, b, co, True, w_skip=wsk)
+                kern = "conv3x3_sp_s2_kernel with the block's 1x1 skip convolution as a tenth tap (csrc/conv3x3_sp_s2.hip)"
             ms = graph_time(fn, dev)
             so = 1 if sp else 4                           # output pixels per input pixel: 1, or 1/4 for the strided layer
-            executed = 3 * 2 * 9 * ci * co * H * W * n // so
+            executed = 3 * 2 * (9 if sp else 10) * ci * co * H * W * n // so      # (the strided layers carry the skip convolution as a tenth tap)
             hbm = 4 * n * H * W * ci + 4 * n * H * W * (co + (co if res is not None else 0)) // so + w16.numel()
             row = {"layer": name, "kernel": kern, "launches_per_frame": per_frame, "us": round(ms * 1e3, 2), "executed_TFLOPs": round(executed / ms / 1e9, 1),
                    "frac_of_fp16_peak": round(executed / ms / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4), "fp32_equivalent_TFLOPs": round(executed / 3 / ms / 1e9, 1),

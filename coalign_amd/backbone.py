@@ -102,6 +102,8 @@ HEAD_SPLIT_MAPS = os.environ.get("COALIGN_HEAD_SPLIT_MAPS", "1") != "0"
 # packed to sp16 rows and gathered by LDS-DMA; a dense stage output is packed to a SplitMap first.  "sparse": the first stage only, "all": every stage whose
 # first convolution has Cin % 16 == 0, "0": the consumer-split kernel of rounds 4-5 (csrc/conv3x3_emu.hip) everywhere.  Read at every call.
 S2_SPLIT = os.environ.get("COALIGN_S2_SP", "all")
+# ... and the block's 1 x 1 / stride-2 skip convolution as a tenth tap of that launch (coalign_conv3x3_sp_s2_skip, (9g)); "0": a pointwise launch of its own.
+S2_SKIP = os.environ.get("COALIGN_S2_SKIP", "1") != "0"
 
 
 # Round 6: the up-sampling heads of the three scales as ONE launch (coalign_pointwise_conv_emu_sp_multi) when they write a SplitMap; "0": one launch per scale.
@@ -159,6 +161,15 @@ class PointwisePack:
     def __init__(self, weight: torch.Tensor, transposed: bool):
         self.f32 = ops.pack_pointwise_weight(weight, transposed)
         self._emu = None
+        self._weight, self._transposed, self._sp = weight, transposed, None
+
+    def sp(self) -> torch.Tensor:
+        """Round 6: the sp16 image of a 1 x 1 convolution that rides in ``conv3x3_sp_s2`` as a tenth tap (``ops.pack_conv1x1_sp_weight``)."""
+        if self._sp is None:
+            if self._transposed or self._weight.dim() != 4 or tuple(self._weight.shape[2:]) != (1, 1):
+                raise ValueError("the fused skip is a 1 x 1 convolution")
+            self._sp = ops.pack_conv1x1_sp_weight(self._weight)
+        return self._sp
 
     def get(self) -> torch.Tensor:
         """The image for the arithmetic in force: 3-way split when the 3x3 layers use it and Cin is a multiple of 16, else fp32."""
@@ -302,21 +313,33 @@ class BasicBlock(nn.Module):
         w1, b1, w2, b2, wd, p1, p2, pd = self._folded()
         if self.stride == 2:
             s2 = S2_SPLIT if p1.cin % 16 == 0 else "0"
+            fused = S2_SKIP and wd.shape[0] == p1.cout and p1.cout <= 512 and tuple(wd.shape[2:]) == (1, 1)      # the skip as a tenth tap of the strided launch
             if isinstance(x, ops.SparseCanvas):
+                skip = None
                 if s2 in ("sparse", "all") and p1.cin >= 32:
-                    y = ops.conv3x3_sp_s2(x, p1.emu(16, True), b1, p1.cout, True)
+                    if fused:
+                        y, skip = ops.conv3x3_sp_s2(x, p1.emu(16, True), b1, p1.cout, True, w_skip=pd[0].sp())
+                    else:
+                        y = ops.conv3x3_sp_s2(x, p1.emu(16, True), b1, p1.cout, True)
                 else:
                     y = ops.conv3x3_emu_sparse(x, p1.emu(16, False), b1, p1.cout, True, 16, out_channels_last=False, out_split=True)
-                skip = ops.pointwise_conv_sparse(x, pd[0].get(), pd[1], wd.shape[0], False, out_channels_last=True)
+                if skip is None:
+                    skip = ops.pointwise_conv_sparse(x, pd[0].get(), pd[1], wd.shape[0], False, out_channels_last=True)
             else:
                 xs = x if isinstance(x, ops.SplitMap) else x_split
                 if isinstance(x, ops.SplitMap):
                     x = x.dense(channels_last=True)
+                skip = None
                 if s2 == "all":
-                    y = ops.conv3x3_sp_s2(xs if xs is not None else ops.SplitMap.pack(x), p1.emu(16, True), b1, p1.cout, True)
+                    xs = xs if xs is not None else ops.SplitMap.pack(x)
+                    if fused:
+                        y, skip = ops.conv3x3_sp_s2(xs, p1.emu(16, True), b1, p1.cout, True, w_skip=pd[0].sp())
+                    else:
+                        y = ops.conv3x3_sp_s2(xs, p1.emu(16, True), b1, p1.cout, True)
                 else:
                     y = ops.conv3x3_emu_bias_act(x, p1.emu(16, False), b1, p1.cout, None, True, 16, stride=2, out_split=True)
-                skip = ops.pointwise_conv(x, pd[0].get(), pd[1], wd.shape[0], in_stride=2, relu=False, out_channels_last=True)
+                if skip is None:
+                    skip = ops.pointwise_conv(x, pd[0].get(), pd[1], wd.shape[0], in_stride=2, relu=False, out_channels_last=True)
         else:
             xs = x if isinstance(x, ops.SplitMap) else ops.SplitMap.pack(x)
             y = ops.conv3x3_sp(xs, p1.emu(16, True), b1, p1.cout, None, True, out_split=True)

@@ -11,6 +11,10 @@
 //     takes its 16 bytes from its own address, so the gather costs no instruction more than the dense form; the stamps of a tile (two per lane) are loaded one
 //     interval before the tile's first DMA is issued.
 // Output: an SP map [N][Cout / 16][4][Ho][Wo][8], Ho = ceil(H / 2), Wo = ceil(W / 2); bias, ReLU, range word as conv3x3_sp.hip.
+// SKIP (round 6): the block's 1 x 1 / stride-2 down-sampling convolution (resblock.py:165-174, `downsample`) rides along as a TENTH TAP -- its input pixel (2 y, 2 x) is the
+// centre tap's operand, already in registers: three more matrix instructions per interval into a second accumulator pair (weights: two 16-byte loads per lane and interval
+// straight from L2, one interval ahead), a second epilogue that writes the skip map channels-last float32 (no bias: its BatchNorm shift sits in the block's second
+// convolution, no ReLU).  One launch instead of two for the first block of a stage; the pointwise launch it replaces took 20-30 us for 0.5 us of matrix work.
 // Weight image: the tap-major terms-16 image (coalign_conv3x3_emu_weight_bytes_ex(Cin, Cout, 16, 1)), as conv3x3_sp.hip.
 //
 // Arithmetic: per output value the SAME operations in the SAME order as conv3x3_sp.hip (intervals ascending, taps 0..8, w_h x_h -> acc, w_h x_l' then w_l' x_h
@@ -36,7 +40,7 @@ constexpr int CPP = 34, ROWP = 2 * CPP;            // groups per column phase, p
 constexpr int PIX = PR * ROWP, PIXP = (PIX + 63) / 64 * 64, PINS = PIXP / 64;      // 612 -> 640 groups per plane, 10 DMA instructions
 constexpr int WQ = 9 * 2 * 2 * kCoutTile, WINS = WQ / 64;                          // 2304 groups = 36 DMA instructions per interval
 constexpr int W_BYTES = WQ * 16, B_BYTES = 4 * PIXP * 16;
-constexpr int kMaxCout = 1024;                     // the layer's bias and 2^-k_c words live in LDS behind the operand buffers (8 KB)
+constexpr int kMaxCout = 1024, kMaxCoutSkip = 512; // the layer's bias and 2^-k_c words (+ the skip's 2^-k_c words) live in LDS behind the operand buffers (8 KB)
 constexpr size_t OPERAND_BYTES = 2 * (size_t)W_BYTES + 2 * (size_t)B_BYTES, LDS_BYTES = OPERAND_BYTES + 2 * kMaxCout * sizeof(float);
 constexpr int WAVES = 8, THREADS = 64 * WAVES;
 constexpr int WJ = 5, PJ = 2, OPS = WJ + 4 * PJ;   // DMA operations of a wavefront and interval (some empty): wavefronts 0-1 carry 3 weight pieces + 2 patch instructions x 4 planes, 2-7 5 + 1 x 4
@@ -51,6 +55,9 @@ struct S2Args {
     const uint4 *__restrict__ wt, *__restrict__ zero;
     const float *__restrict__ bias, *__restrict__ wscale;
     uint4 *__restrict__ y;
+    const uint4 *__restrict__ ws;        // SKIP: the 1 x 1 weight image [Cout / 64][Cin / 16][2 terms][2 channel halves][64 cout][8 cin] fp16
+    const float *__restrict__ ws_scale;  // SKIP: [Cout] 2^-k_c of the skip weights
+    float *__restrict__ yskip;           // SKIP: [N, Ho, Wo, Cout] channels-last float32
     int *range_flag;
     int N, Cin, Cout, H, W, Ho, Wo, relu, tiles_x, tiles_y, total_tasks;
     int ablate;                         // laboratory switch (tools/_abl_s2.sh)
@@ -85,7 +92,7 @@ struct Plan {
     const uint4 *wsrc;
 };
 
-template <bool SPARSE>
+template <bool SPARSE, bool SKIP>
 __global__ __launch_bounds__(THREADS, 2) void conv3x3_sp_s2_kernel(const S2Args a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, p = lane & 31;
@@ -107,7 +114,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_sp_s2_kernel(const S2Args 
     for (int i = tid; i < a.Cout / 4; i += THREADS) {
         reinterpret_cast<float4 *>(lds_par)[i] = reinterpret_cast<const float4 *>(a.bias)[i];
         reinterpret_cast<float4 *>(lds_par + a.Cout)[i] = reinterpret_cast<const float4 *>(a.wscale)[i];
+        if constexpr (SKIP) reinterpret_cast<float4 *>(lds_par + 2 * a.Cout)[i] = reinterpret_cast<const float4 *>(a.ws_scale)[i];
     }
+    // SKIP: this lane's two weight groups (term 0 / 1) of interval c of channel group cg: the A operand of the tenth tap
+    auto skip_w = [&](int cg, int c, uint4 (&w)[2]) {
+        const uint4 *base = a.ws + ((size_t)(cg * chunks + c) * 4 + half) * kCoutTile + cq * 32 + p;
+        w[0] = base[0];
+        w[1] = base[2 * kCoutTile];
+    };
 
     auto decode = [&](int t) {
         Task c;
@@ -200,13 +214,15 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_sp_s2_kernel(const S2Args 
     // (Round 6, measured and dropped: the epilogue DEFERRED into the first interval of the workgroup's next task, its four steps behind taps 1, 3, 5, 7 -- the
     //  interval's body grew by the epilogue's ~2000 clocks (3330 -> 5180: a wavefront's instruction stream, not the matrix pipe, bounds an interval) and the three
     //  layers got 1.5-2 us slower: profiles/round6/experiments/conv_sp_s2.md.)
+    uint4 sw_cur[2] = {}, sw_nxt[2] = {};                          // SKIP: the tenth tap's weight operands of this / the next interval
+    if constexpr (SKIP) skip_w(cur.cg, 0, sw_nxt);
     int L = 0;
     while (L < n_local) {
         const int oy = cur.oy0 + oyl, ox = cur.ox0 + oxl;
         const bool live = oy < a.Ho && ox < a.Wo;
         const bool wave_live = __builtin_amdgcn_readfirstlane((int)(cur.ox0 + bx * 8 < a.Wo)) != 0;
         const size_t pix = live ? (size_t)oy * a.Wo + ox : 0;
-        floatx16 acc = {0}, accl = {0};
+        floatx16 acc = {0}, accl = {0}, sacc = {0}, saccl = {0};
         Task next = cur;
         Plan nplan = plan;
         int ntask = task;
@@ -219,6 +235,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_sp_s2_kernel(const S2Args 
             S2_STAMP(1);
             __syncthreads();
             S2_STAMP(2);
+            if constexpr (SKIP) {                                  // first touch of the words loaded an interval ago: nothing of this wavefront is in flight here
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    asm volatile("" : "+v"(sw_nxt[t].x), "+v"(sw_nxt[t].y), "+v"(sw_nxt[t].z), "+v"(sw_nxt[t].w));
+                    sw_cur[t] = sw_nxt[t];
+                }
+            }
             const bool more = L + 1 < n_local;
             int nc = chunk + 1;
             if constexpr (SPARSE) {                                 // the next task's stamps: one interval ahead of its first DMA
@@ -237,6 +260,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_sp_s2_kernel(const S2Args 
                     next = decode(ntask);
                     nplan = make_plan_dense(next);
                 }
+            }
+            if constexpr (SKIP) {                                  // ... and the next interval's, ahead of this interval's DMA
+                if (more) skip_w(nc == 0 ? next.cg : cur.cg, nc, sw_nxt);
             }
             const int slot_cur = L & 1, slot_next = (L + 1) & 1;
             if (wave_live && !(a.ablate & 4)) {
@@ -267,6 +293,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_sp_s2_kernel(const S2Args 
                     accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[0], bc[1], accl, 0, 0, 0);      // w_h x_l'
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[0], bc[0], acc, 0, 0, 0);        // w_h x_h
                     accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[1], bc[0], accl, 0, 0, 0);      // w_l' x_h
+                    if constexpr (SKIP) {
+                        if (s == 4) {                              // the centre tap's pixel is the 1 x 1 / stride-2 convolution's input pixel
+                            const halfx8 sh = __builtin_bit_cast(halfx8, sw_cur[0]), sl = __builtin_bit_cast(halfx8, sw_cur[1]);
+                            saccl = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh, bc[1], saccl, 0, 0, 0);
+                            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh, bc[0], sacc, 0, 0, 0);
+                            saccl = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl, bc[0], saccl, 0, 0, 0);
+                        }
+                    }
                     if (more) {
 #pragma unroll
                         for (int k = s; k < OPS; k += 9) issue_op(nplan, nc, slot_next, k);
@@ -310,6 +344,20 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_sp_s2_kernel(const S2Args 
             ysp += sp_step;
         }
         if (a.range_flag && live && wave_live && vmax > 65504.f) atomicOr(a.range_flag, 1);
+        if constexpr (SKIP) {                                       // the skip map: sums * 2^-k_c, channels-last float32 (16 bytes per pixel and store)
+            const float4 *sinv4 = reinterpret_cast<const float4 *>(lds_par + 2 * a.Cout + ch0);
+            float4 *ys = reinterpret_cast<float4 *>(a.yskip + ((size_t)cur.n * HWo + pix) * a.Cout + ch0);
+#pragma unroll
+            for (int g8 = 0; g8 < 4; ++g8) {
+                const float4 i4 = sinv4[2 * g8];
+                float4 o;
+                o.x = fmaf(saccl[4 * g8], coalign::kSp16LowInv, sacc[4 * g8]) * i4.x;
+                o.y = fmaf(saccl[4 * g8 + 1], coalign::kSp16LowInv, sacc[4 * g8 + 1]) * i4.y;
+                o.z = fmaf(saccl[4 * g8 + 2], coalign::kSp16LowInv, sacc[4 * g8 + 2]) * i4.z;
+                o.w = fmaf(saccl[4 * g8 + 3], coalign::kSp16LowInv, sacc[4 * g8 + 3]) * i4.w;
+                if (live && wave_live && !(a.ablate & 8)) ys[2 * g8] = o;
+            }
+        }
         cur = next;
         plan = nplan;
         task = ntask;
@@ -351,13 +399,13 @@ int s2_check(int N, int Cin, int Cout, int H, int W) {
     return COALIGN_OK;
 }
 
-template <bool SPARSE>
+template <bool SPARSE, bool SKIP>
 int launch_s2(S2Args a, hipStream_t s) {
     constexpr int kMaxDev = 16;
     static int cus[kMaxDev] = {0};                                    // per device: the function attribute belongs to the device's code object
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
-    auto kern = conv3x3_sp_s2_kernel<SPARSE>;
+    auto kern = conv3x3_sp_s2_kernel<SPARSE, SKIP>;
     if (!cus[dev]) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) prop.multiProcessorCount = 256;
@@ -429,7 +477,7 @@ extern "C" int coalign_conv3x3_sp_s2(const void *x_sp, const void *w_split, cons
     S2Args a{};
     a.x = static_cast<const uint4 *>(x_sp);
     fill_common(a, w_split, bias, y_sp, N, Cin, Cout, H, W, relu, range_flag);
-    return launch_s2<false>(a, static_cast<hipStream_t>(stream));
+    return launch_s2<false, false>(a, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int coalign_conv3x3_sp_s2_sparse(const void *rows_sp, int M_rows, const void *stamps, const int32_t *state, const void *w_split, const float *bias, void *y_sp,
@@ -449,5 +497,57 @@ extern "C" int coalign_conv3x3_sp_s2_sparse(const void *rows_sp, int M_rows, con
     a.tag_ptr = state;
     a.sparse_rows = (unsigned)M_rows;
     fill_common(a, w_split, bias, y_sp, N, Cin, Cout, H, W, relu, range_flag);
-    return launch_s2<true>(a, static_cast<hipStream_t>(stream));
+    return launch_s2<true, false>(a, static_cast<hipStream_t>(stream));
+}
+
+// ---- the same launches with the block's 1 x 1 / stride-2 skip convolution as a tenth tap (SKIP) ----------------------------------------------------------------
+extern "C" size_t coalign_conv1x1_sp_weight_bytes(int Cin, int Cout) {
+    if (Cin < 16 || Cin % 16 || Cout < kCoutTile || Cout % kCoutTile) return 0;
+    return (size_t)Cout * Cin * 4 + 16 + (size_t)Cout * 8;      // two fp16 terms per weight, 16 zero bytes, [Cout] 2^-k_c, [Cout] 2^k_c
+}
+
+static int fill_skip(S2Args &a, const void *w_skip, float *y_skip, int Cin, int Cout) {
+    if (!w_skip || !y_skip) return COALIGN_ERR_NULL_POINTER;
+    if (Cout > kMaxCoutSkip || ((reinterpret_cast<uintptr_t>(w_skip) | reinterpret_cast<uintptr_t>(y_skip)) & 15)) return COALIGN_ERR_UNSUPPORTED;
+    a.ws = static_cast<const uint4 *>(w_skip);
+    a.ws_scale = reinterpret_cast<const float *>(static_cast<const char *>(w_skip) + (size_t)Cout * Cin * 4 + 16);
+    a.yskip = y_skip;
+    return COALIGN_OK;
+}
+
+extern "C" int coalign_conv3x3_sp_s2_skip(const void *x_sp, const void *w_split, const float *bias, const void *w_skip, void *y_sp, float *y_skip, int N, int Cin, int Cout, int H, int W,
+                                          int relu, int32_t *range_flag, void *stream) {
+    if (!x_sp || !w_split || !bias || !y_sp) return COALIGN_ERR_NULL_POINTER;
+    int rc = s2_check(N, Cin, Cout, H, W);
+    if (rc != COALIGN_OK) return rc;
+    if ((reinterpret_cast<uintptr_t>(x_sp) | reinterpret_cast<uintptr_t>(w_split) | reinterpret_cast<uintptr_t>(y_sp) | reinterpret_cast<uintptr_t>(bias)) & 15) return COALIGN_ERR_UNSUPPORTED;
+    S2Args a{};
+    rc = fill_skip(a, w_skip, y_skip, Cin, Cout);
+    if (rc != COALIGN_OK) return rc;
+    if (N == 0) return COALIGN_OK;
+    a.x = static_cast<const uint4 *>(x_sp);
+    fill_common(a, w_split, bias, y_sp, N, Cin, Cout, H, W, relu, range_flag);
+    return launch_s2<false, true>(a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int coalign_conv3x3_sp_s2_skip_sparse(const void *rows_sp, int M_rows, const void *stamps, const int32_t *state, const void *w_split, const float *bias, const void *w_skip,
+                                                 void *y_sp, float *y_skip, int N, int Cin, int Cout, int H, int W, int relu, int32_t *range_flag, void *stream) {
+    if (!rows_sp || !stamps || !state || !w_split || !bias || !y_sp) return COALIGN_ERR_NULL_POINTER;
+    if (M_rows < 0) return COALIGN_ERR_BAD_SHAPE;
+    int rc = s2_check(N, Cin, Cout, H, W);
+    if (rc != COALIGN_OK) return rc;
+    if (Cin < 32) return COALIGN_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(rows_sp) | reinterpret_cast<uintptr_t>(w_split) | reinterpret_cast<uintptr_t>(y_sp) | reinterpret_cast<uintptr_t>(bias)) & 15) return COALIGN_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(stamps) & 7) return COALIGN_ERR_UNSUPPORTED;
+    if ((int64_t)M_rows * Cin / 4 >= (int64_t)1 << 31) return COALIGN_ERR_UNSUPPORTED;
+    S2Args a{};
+    rc = fill_skip(a, w_skip, y_skip, Cin, Cout);
+    if (rc != COALIGN_OK) return rc;
+    if (N == 0) return COALIGN_OK;
+    a.x = static_cast<const uint4 *>(rows_sp);
+    a.stamps = static_cast<const unsigned long long *>(stamps);
+    a.tag_ptr = state;
+    a.sparse_rows = (unsigned)M_rows;
+    fill_common(a, w_split, bias, y_sp, N, Cin, Cout, H, W, relu, range_flag);
+    return launch_s2<true, true>(a, static_cast<hipStream_t>(stream));
 }

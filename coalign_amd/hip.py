@@ -78,6 +78,9 @@ SIGNATURES = {
     "coalign_sp_pack_rows": (c_int, [P, c_int, P, c_int, P, P, P]),
     "coalign_conv3x3_sp_s2": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "coalign_conv3x3_sp_s2_sparse": (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "coalign_conv1x1_sp_weight_bytes": (c_size_t, [c_int, c_int]),
+    "coalign_conv3x3_sp_s2_skip": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "coalign_conv3x3_sp_s2_skip_sparse": (c_int, [P, c_int, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "coalign_pointwise_conv": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_pointwise_conv_ex": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_pointwise_emu_weight_bytes": (c_size_t, [c_int, c_int]),

@@ -1016,29 +1016,59 @@ def sp_pack_rows(sc: "SparseCanvas") -> torch.Tensor:
     return out
 
 
+def pack_conv1x1_sp_weight(weight: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin] (or [Cout, Cin, 1, 1]) fp32 -> the sp16 image of the 1 x 1 skip convolution that rides in ``conv3x3_sp_s2`` (include/coalign_amd.h (9g)): the
+    centre-tap slice of the tap-major terms-16 image of ``pack_conv3x3_emu_weight`` (same per-output-channel scale rule), as uint8."""
+    w = weight.detach().float().reshape(weight.shape[0], weight.shape[1])
+    co, ci = w.shape
+    w3 = torch.zeros((co, ci, 3, 3), dtype=torch.float32, device=w.device)
+    w3[:, :, 1, 1] = w
+    img = pack_conv3x3_emu_weight(w3, 16, True)
+    body = co * ci * 9 * 4                                    # two fp16 terms per weight
+    taps = img[:body].view(torch.float16).reshape(co // 64, ci // 16, 9, 2 * 2 * 64 * 8)
+    out = torch.cat([taps[:, :, 4].contiguous().view(torch.uint8).reshape(-1), img[body:]])
+    assert out.numel() == hip.lib().coalign_conv1x1_sp_weight_bytes(ci, co)
+    return out
+
+
 @_device_op
-def conv3x3_sp_s2(x, w_split: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool = True) -> "SplitMap":
+def conv3x3_sp_s2(x, w_split: torch.Tensor, bias: torch.Tensor, cout: int, relu: bool = True, w_skip: Optional[torch.Tensor] = None):
     """y = act(conv3x3(x, w, stride 2, padding 1) + bias) on split operands (include/coalign_amd.h (9f), csrc/conv3x3_sp_s2.hip): ``x`` a ``SplitMap`` or a
-    ``SparseCanvas`` (its rows are packed to sp16 rows first); ``w_split``: the tap-major terms-16 image of ``pack_conv3x3_emu_weight``; returns a ``SplitMap``."""
+    ``SparseCanvas`` (its rows are packed to sp16 rows first); ``w_split``: the tap-major terms-16 image of ``pack_conv3x3_emu_weight``; returns a ``SplitMap``.
+    ``w_skip`` (``pack_conv1x1_sp_weight``; (9g)): the block's 1 x 1 / stride-2 skip convolution rides along as a tenth tap -- returns (SplitMap, skip map: float32
+    of logical shape [N, Cout, Ho, Wo] in channels-last memory, no bias, no ReLU)."""
     L = hip.lib()
     N, Cin, H, W = x.shape
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
     if w_split.numel() != L.coalign_conv3x3_emu_weight_bytes_ex(Cin, cout, 16, 1):
         raise ValueError("conv3x3_sp_s2 needs the tap-major terms-16 weight image of (Cin, Cout)")
-    out = SplitMap.empty(N, cout, (H + 1) // 2, (W + 1) // 2, x.device)
+    if w_skip is not None and w_skip.numel() != L.coalign_conv1x1_sp_weight_bytes(Cin, cout):
+        raise ValueError("conv3x3_sp_s2: the skip image does not match (Cin, Cout)")
+    out = SplitMap.empty(N, cout, Ho, Wo, x.device)
+    skip = None if w_skip is None else torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
     flag = _ptr(sp_range_flag(x.device))
+    b = _f32c(bias)
     if isinstance(x, SparseCanvas):
         x.check_current()
         rows = sp_pack_rows(x)
         with _Timed("conv3x3_sp_s2_sparse"):
-            hip.check(L.coalign_conv3x3_sp_s2_sparse(_rows_ptr(rows), int(rows.shape[0]), _ptr(x.stamps), _ptr(x.state), _ptr(w_split), _ptr(_f32c(bias)), _ptr(out.data),
-                                                     N, Cin, cout, H, W, int(relu), flag, _stream()), "coalign_conv3x3_sp_s2_sparse")
-        return out
+            if w_skip is None:
+                hip.check(L.coalign_conv3x3_sp_s2_sparse(_rows_ptr(rows), int(rows.shape[0]), _ptr(x.stamps), _ptr(x.state), _ptr(w_split), _ptr(b), _ptr(out.data),
+                                                         N, Cin, cout, H, W, int(relu), flag, _stream()), "coalign_conv3x3_sp_s2_sparse")
+            else:
+                hip.check(L.coalign_conv3x3_sp_s2_skip_sparse(_rows_ptr(rows), int(rows.shape[0]), _ptr(x.stamps), _ptr(x.state), _ptr(w_split), _ptr(b), _ptr(w_skip), _ptr(out.data),
+                                                              _ptr(skip), N, Cin, cout, H, W, int(relu), flag, _stream()), "coalign_conv3x3_sp_s2_skip_sparse")
+        return out if w_skip is None else (out, skip)
     if not isinstance(x, SplitMap):
         raise TypeError("conv3x3_sp_s2 reads a SplitMap or a SparseCanvas")
     _need_gpu(x.data, w_split, bias)
     with _Timed("conv3x3_sp_s2"):
-        hip.check(L.coalign_conv3x3_sp_s2(_ptr(x.data), _ptr(w_split), _ptr(_f32c(bias)), _ptr(out.data), N, Cin, cout, H, W, int(relu), flag, _stream()), "coalign_conv3x3_sp_s2")
-    return out
+        if w_skip is None:
+            hip.check(L.coalign_conv3x3_sp_s2(_ptr(x.data), _ptr(w_split), _ptr(b), _ptr(out.data), N, Cin, cout, H, W, int(relu), flag, _stream()), "coalign_conv3x3_sp_s2")
+        else:
+            hip.check(L.coalign_conv3x3_sp_s2_skip(_ptr(x.data), _ptr(w_split), _ptr(b), _ptr(w_skip), _ptr(out.data), _ptr(skip), N, Cin, cout, H, W, int(relu), flag, _stream()),
+                      "coalign_conv3x3_sp_s2_skip")
+    return out if w_skip is None else (out, skip)
 
 
 def conv3x3_sp_is_split(N: int, Cin: int, cout: int, H: int, W: int, geometry: int = 0) -> bool:

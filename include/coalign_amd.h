@@ -409,6 +409,18 @@ int coalign_conv3x3_sp_s2(const void *x_sp, const void *w_split, const float *bi
 int coalign_conv3x3_sp_s2_sparse(const void *rows_sp, int M_rows, const void *stamps, const int32_t *state, const void *w_split, const float *bias, void *y_sp,
                                  int N, int Cin, int Cout, int H, int W, int relu, int32_t *range_flag, void *stream);
 
+/* (9g) Round 6: (9f) carrying the block's 1 x 1 / stride-2 DOWN-SAMPLING convolution (resblock.py:165-174: `downsample`, BatchNorm folded, no ReLU; its input pixel (2y, 2x)
+ * is the centre tap of the strided 3x3 convolution) as a tenth tap: ONE launch computes conv1 (SP map out) and the skip map y_skip [N, ceil(H/2), ceil(W/2), Cout]
+ * channels-last float32 -- what (10) / (10b) computed in a launch of their own (20-30 us for 0.5 us of matrix work).
+ *   w_skip: coalign_conv1x1_sp_weight_bytes(Cin, Cout) bytes, 16-byte aligned: [Cout / 64][Cin / 16][2 terms][2 channel halves][64 cout][8 cin] fp16 sp16 pairs of the
+ *   per-output-channel scaled 1 x 1 weights, 16 zero bytes, [Cout] float32 2^-k_c, [Cout] float32 2^k_c (the centre-tap slice of the image of (9b): terms 16, tap-major).
+ *   No bias on the skip (the caller adds its BatchNorm shift to the second convolution's bias, as (10) does); Cout <= 512.  conv1's output is that of (9f), bit for bit. */
+size_t coalign_conv1x1_sp_weight_bytes(int Cin, int Cout);
+int coalign_conv3x3_sp_s2_skip(const void *x_sp, const void *w_split, const float *bias, const void *w_skip, void *y_sp, float *y_skip, int N, int Cin, int Cout, int H, int W,
+                               int relu, int32_t *range_flag, void *stream);
+int coalign_conv3x3_sp_s2_skip_sparse(const void *rows_sp, int M_rows, const void *stamps, const int32_t *state, const void *w_split, const float *bias, const void *w_skip,
+                                      void *y_sp, float *y_skip, int N, int Cin, int Cout, int H, int W, int relu, int32_t *range_flag, void *stream);
+
 /* (9c) The Winograd F(2x2, 3x3) convolution of round 4 (measured, not adopted) is exported by the LABORATORY library only: include/coalign_amd_lab.h. */
 
 /* Fill `n_words` 32-bit words at `p` (4-byte aligned) with `value`, as a kernel on `stream` (the per-frame counters of the post-processing

@@ -183,3 +183,56 @@ def test_heads_in_one_launch_equal_one_launch_per_scale(N, hw):
     ops.pointwise_heads_split(layers, got)
     assert torch.equal(got.data, want.data)
     assert float(got.dense().abs().max()) > 0
+
+
+@pytest.mark.parametrize("shape", [(5, 64, 128, 100, 352), (5, 128, 256, 50, 176), (2, 32, 64, 37, 45), (1, 64, 64, 9, 70)])
+def test_skip_convolution_as_a_tenth_tap(shape):
+    """Round 6 (9g): ``coalign_conv3x3_sp_s2_skip`` -- conv1's SplitMap is that of the plain launch bit for bit; the skip map equals a float64 1 x 1 / stride-2
+    convolution of the 22-bit input to 2e-6 of its scale (resblock.py:165-174: ``downsample``, no bias here, no ReLU)."""
+    N, Ci, Co, H, W = shape
+    x, w, b = _case(shape, 11)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    wd = torch.randn((Co, Ci, 1, 1), generator=g, device=DEV) / Ci ** 0.5
+    img = ops.pack_conv3x3_emu_weight(w, 16, tap_major=True)
+    xs = ops.SplitMap.pack(x)
+    want = ops.conv3x3_sp_s2(xs, img, b, Co, True)
+    got, skip = ops.conv3x3_sp_s2(xs, img, b, Co, True, w_skip=ops.pack_conv1x1_sp_weight(wd))
+    assert torch.equal(got.data, want.data)
+    ref = torch.einsum("oc,nchw->nohw", wd[:, :, 0, 0].double(), xs.dense().double()[:, :, ::2, ::2])
+    assert skip.shape == ref.shape and skip.permute(0, 2, 3, 1).is_contiguous()
+    err = float((skip.double() - ref).abs().max()) / float(ref.abs().max())
+    print(f"\nskip as a tenth tap vs float64: {err:.2e} of the scale")
+    assert err <= 2e-6
+
+
+def test_skip_as_a_tenth_tap_on_the_sparse_canvas_and_in_the_model():
+    sc = _sparse_canvas(3, 200, 704, 6000, 11)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    w = torch.randn((64, 64, 3, 3), generator=g, device=DEV) / 24.0
+    wd = torch.randn((64, 64, 1, 1), generator=g, device=DEV) / 8.0
+    b = torch.randn(64, generator=g, device=DEV) * 0.1
+    img, simg = ops.pack_conv3x3_emu_weight(w, 16, tap_major=True), ops.pack_conv1x1_sp_weight(wd)
+    dense = ops.SplitMap.pack(sc.dense())
+    want, want_skip = ops.conv3x3_sp_s2(dense, img, b, 64, True, w_skip=simg)
+    got, got_skip = ops.conv3x3_sp_s2(sc, img, b, 64, True, w_skip=simg)
+    assert torch.equal(got.data, want.data) and torch.equal(got_skip, want_skip) and float(got_skip.abs().max()) > 0
+    # the whole backbone with the skip fused against a pointwise launch of its own: the skip changes its arithmetic (22-bit pairs instead of three bf16 terms)
+    from coalign_amd.config import builtin_config
+    from coalign_amd.detector import build_model
+    from coalign_amd.synthetic import fill_parameters_
+    h = builtin_config("opv2v_coalign")
+    model = build_model(h)
+    fill_parameters_(model, seed=0)
+    model = model.to(DEV).eval()
+    saved, outs = backbone.S2_SKIP, {}
+    try:
+        for mode in (False, True):
+            backbone.S2_SKIP = mode
+            with torch.no_grad():
+                outs[mode] = [f.clone() for f in model.backbone.get_multiscale_feature(sc)]
+    finally:
+        backbone.S2_SKIP = saved
+    for a, c in zip(outs[True], outs[False]):
+        e = float((a - c).abs().max()) / float(c.abs().max())
+        print(f"\nS2_SKIP on / off: {tuple(a.shape)} {e:.2e} of the scale")
+        assert e <= 2e-6

@@ -39,8 +39,14 @@ for (N, Ci, Co, H, W) in ((5, 64, 128, 100, 352), (5, 128, 256, 50, 176), (2, 64
     b = torch.randn(Co, generator=g, device="cuda")
     xs = ops.SplitMap.pack(x)
     key = f"{N}x{Ci}x{Co}x{H}x{W}"
+    wd = torch.randn((Co, Ci, 1, 1), generator=g, device="cuda") / Ci ** 0.5
+    w_skip = ops.pack_conv1x1_sp_weight(wd)
+    from coalign_amd.backbone import PointwisePack
+    pw, zb = PointwisePack(wd, False).get(), torch.zeros(Co, device="cuda")
     out[key] = {"emu_us": timed(lambda: ops.conv3x3_emu_bias_act(x, w_pair, b, Co, None, True, 16, stride=2, out_split=True)),
                 "sp_s2_us": timed(lambda: ops.conv3x3_sp_s2(xs, w_tap, b, Co, True)),
+                "sp_s2_with_skip_tap_us": timed(lambda: ops.conv3x3_sp_s2(xs, w_tap, b, Co, True, w_skip=w_skip)),
+                "skip_pointwise_launch_us": timed(lambda: ops.pointwise_conv(x, pw, zb, Co, in_stride=2, relu=False, out_channels_last=True)),
                 "sp_pack_us": timed(lambda: ops.SplitMap.pack(x))}
 from test_s2_gpu import _sparse_canvas  # noqa: E402
 for pillars in (8000,):

@@ -62,3 +62,5 @@ tot=sum(int(r['TotalDurationNs']) for r in rows); print("total kernel ms", tot/1
 for r in rows[:22]:
     print(f"{r['Name'][:100]:100s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:8.1f} pct={r['Percentage']}")
 PY
+# the raw traces and counter dumps are bulky (gpurun merges at most 64 MiB back): the summaries above are what is kept
+rm -rf $OUT/stats $OUT/iso; for d in $OUT/pmc_*; do [ -d "$d" ] && rm -rf "$d"; done

@@ -29,3 +29,4 @@ for r in rows[:40]: print(f"  {r[1]:7.2f} x {r[2]:8.1f} us = {r[3]:8.1f} us/fram
 print("library kernels (at::native / rocBLAS / rocPRIM / MIOpen) per steady-state frame:", [(r[0][:90], round(r[1], 2)) for r in lib] or "none")
 json.dump({"steps": [A, B], "library_kernels_per_frame": [(r[0], r[1]) for r in lib], "launches_per_frame": sum(r[1] for r in rows)}, open(out + "/steady_state_summary.json", "w"), indent=1)
 PY
+rm -rf $OUT/s$A $OUT/s$B      # (the raw traces are bulky; the per-frame table is what is kept)

@@ -141,6 +141,9 @@ _b_s2a = torch.randn(128, generator=g).to(dev)
 _xs_s2b = ops.SplitMap.pack(torch.relu(torch.randn(5, 128, 50, 176, generator=g).to(dev)))
 _w16_s2b = ops.pack_conv3x3_emu_weight(torch.randn(256, 128, 3, 3, generator=g).to(dev) / 34.0, 16, True)
 _b_s2b = torch.randn(256, generator=g).to(dev)
+_ws_64 = ops.pack_conv1x1_sp_weight(torch.randn(64, 64, 1, 1, generator=g).to(dev) / 8.0)          # the blocks' 1 x 1 / stride-2 skip convolutions ride as a tenth tap (9g)
+_ws_s2a = ops.pack_conv1x1_sp_weight(torch.randn(128, 64, 1, 1, generator=g).to(dev) / 8.0)
+_ws_s2b = ops.pack_conv1x1_sp_weight(torch.randn(256, 128, 1, 1, generator=g).to(dev) / 11.0)
 
 OPS = {
     "conv_sp_64ch": lambda: ops.conv3x3_sp(_spx(0)[0], _w16, bconv, 64, _spx(0)[1], True, out_split=True),
@@ -156,9 +159,10 @@ OPS = {
     "pointwise_up4_split_out": lambda: ops.pointwise_conv(xs[2][:1], wtp_emu, bconv.repeat(2), 128, up=4, out=_headmap(), c_off=256),
     "conv_fp16x2_shrink1_384ch_split_out": lambda: ops.conv3x3_emu_bias_act(_x384, _w384, _b256, 256, None, True, 16, out_split=True),
     "conv_fp16x2_s2_64to128_nhwc_in_split_out": lambda: ops.conv3x3_emu_bias_act(xcl[0], _w16_s2_128, _b128, 128, None, True, 16, stride=2, out_split=True),
-    "conv_sp_s2_sparse_canvas_with_row_pack": lambda: ops.conv3x3_sp_s2(_sc(), _w16_tap64, bconv, 64, True),
-    "conv_sp_s2_64to128": lambda: ops.conv3x3_sp_s2(_xs_s2a, _w16_s2a, _b_s2a, 128, True),
-    "conv_sp_s2_128to256": lambda: ops.conv3x3_sp_s2(_xs_s2b, _w16_s2b, _b_s2b, 256, True),
+    "conv_sp_s2_sparse_canvas_with_row_pack": lambda: ops.conv3x3_sp_s2(_sc(), _w16_tap64, bconv, 64, True, w_skip=_ws_64),
+    "conv_sp_s2_64to128": lambda: ops.conv3x3_sp_s2(_xs_s2a, _w16_s2a, _b_s2a, 128, True, w_skip=_ws_s2a),
+    "conv_sp_s2_128to256": lambda: ops.conv3x3_sp_s2(_xs_s2b, _w16_s2b, _b_s2b, 256, True, w_skip=_ws_s2b),
+    "conv_sp_s2_64to128_without_skip_tap": lambda: ops.conv3x3_sp_s2(_xs_s2a, _w16_s2a, _b_s2a, 128, True),
     "conv_fp16x2_s2_sparse_canvas_split_out": lambda: ops.conv3x3_emu_sparse(_sc(), _w16_s2, bconv, 64, True, 16, out_channels_last=False, out_split=True),
     "nms_gather_K600": _nms_fused,
     "nms_then_gather_K600": _nms_two_calls,
