@@ -19,7 +19,7 @@
 //
 // Arithmetic: per output value the SAME operations in the SAME order as conv3x3_sp.hip (intervals ascending, taps 0..8, w_h x_h -> acc, w_h x_l' then w_l' x_h
 // -> accl, tile = (acc + 2^-10 accl) * 2^-k_c + bias): output (y, x) equals, bit for bit, output (2 y, 2 x) of coalign_conv3x3_sp on the same (dense) map
-// (tests/test_round6_gpu.py).
+// (tests/test_s2_gpu.py).
 //
 // Tiles: 4 x 32 output pixels x 64 output channels per workgroup of 8 wavefronts; a wavefront owns a 4 x 8 pixel block x 32 channels (one 32 x 32 accumulator
 // tile x two accumulators).  The halo patch is 9 x 65 input pixels; in LDS its columns are DE-INTERLEAVED (even columns | odd columns of a row, 34 groups each):
@@ -60,7 +60,7 @@ struct S2Args {
     float *__restrict__ yskip;           // SKIP: [N, Ho, Wo, Cout] channels-last float32
     int *range_flag;
     int N, Cin, Cout, H, W, Ho, Wo, relu, tiles_x, tiles_y, total_tasks;
-    int ablate;                         // laboratory switch (tools/_abl_s2.sh)
+    int ablate;                         // laboratory switch COALIGN_S2_ABLATE (tools/trace_conv_s2.py, tools/README.md)
 #ifdef COALIGN_LAB
     long long *trace;                   // laboratory: [2 workgroups][8 waves][64 intervals][4 stamps] (tools/trace_conv_s2.py)
 #endif
