@@ -555,3 +555,27 @@ def test_load_saved_model_matches_reference(golden, tmp_path):
     assert epoch == 31 and out is dst
     a, b = src.state_dict(), dst.state_dict()
     assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_skip_weight_image_layout_and_values():
+    """Round 6 (include/coalign_amd.h (9g)): ``ops.pack_conv1x1_sp_weight`` -- [Cout / 64][Cin / 16][2 terms][2 channel halves][64 cout][8 cin] fp16 sp16 pairs of the
+    per-output-channel scaled weights, 16 zero bytes, [Cout] 2^-k_c, [Cout] 2^k_c: the pairs decode to the weights rounded to 22 significant bits."""
+    torch.manual_seed(3)
+    co, ci = 128, 48
+    w = torch.randn(co, ci, 1, 1) * torch.logspace(-4, 1, co).reshape(co, 1, 1, 1)      # channel scales over five decades: the per-channel power of two matters
+    w[5] = 0.0                                                                            # a dead channel
+    img = ops.pack_conv1x1_sp_weight(w)
+    assert img.dtype == torch.uint8 and img.numel() == hip.lib().coalign_conv1x1_sp_weight_bytes(ci, co) == co * ci * 4 + 16 + co * 8
+    body = img[: co * ci * 4].view(torch.float16).reshape(co // 64, ci // 16, 2, 2, 64, 8).float()
+    assert int(img[co * ci * 4: co * ci * 4 + 16].sum()) == 0
+    inv = img[co * ci * 4 + 16: co * ci * 4 + 16 + co * 4].view(torch.float32)
+    scale = img[co * ci * 4 + 16 + co * 4:].view(torch.float32)
+    assert torch.equal(inv * scale, torch.ones(co)) and bool((torch.frexp(scale)[0] == 0.5).all())          # exact powers of two
+    val = body[:, :, 0] + body[:, :, 1] / 1024.0                                          # [g, interval, half, cout, cin]
+    got = val.permute(0, 3, 1, 2, 4).reshape(co, ci) * inv.reshape(co, 1)                 # channel = 16 * interval + 8 * half + cin
+    ws = w.reshape(co, ci) * scale.reshape(co, 1)
+    want = ((ws.contiguous().view(torch.int32) + 2) & -4).view(torch.float32) * inv.reshape(co, 1)
+    assert torch.equal(got, want)
+    amax = (w.reshape(co, ci).abs() * scale.reshape(co, 1)).amax(dim=1)
+    live = w.reshape(co, ci).abs().amax(dim=1) > 0
+    assert bool(((amax[live] >= 2.0 ** 13) & (amax[live] < 2.0 ** 14)).all())             # every channel's largest weight in [2^13, 2^14): both terms normal fp16 numbers
