@@ -26,6 +26,8 @@ struct DecodeArgs {
     uint8_t *cand_keep;
     uint32_t *status;
     int *block_counts;
+    uint32_t *clear;          // round 6: the frame's counters / status words, zeroed by the FIRST decode launch of a frame (no fill launch of their own)
+    int n_clear;
 };
 
 // Correctly rounded float32 sigmoid (evaluated in float64): the value every faithful float32 implementation
@@ -116,6 +118,7 @@ __device__ void decode_and_store(const DecodeArgs &a, int i, float prob, int pos
 __global__ __launch_bounds__(kBlock) void count_kernel(DecodeArgs a) {
     __shared__ int wave_cnt[kBlock / 64];
     const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (blockIdx.x == 0 && (int)threadIdx.x < a.n_clear) a.clear[threadIdx.x] = 0u;      // (nothing of this launch reads them; emit_kernel, the next launch, does)
     float p;
     const bool ok = i < a.total && passes(a, i, p);
     const unsigned long long m = __ballot(ok);
@@ -179,11 +182,39 @@ size_t coalign_anchor_decode_workspace_bytes(int A, int H, int W) {
     return coalign::align_up(((total + kBlock - 1) / kBlock) * sizeof(int), 256);
 }
 
+static int anchor_decode_impl(const float *cls, const float *reg, const float *dir, const float *anchors, int A, int H, int W,
+                              int num_bins, float score_thr, float dir_offset, int order_hwl, const float *transform,
+                              int capacity, const int32_t *count_in, int32_t *count_out, int32_t *cand_index,
+                              float *cand_score, float *cand_box7, float *cand_corners, uint8_t *cand_keep, uint32_t *status,
+                              void *workspace, size_t workspace_bytes, uint32_t *clear_words, int n_clear, void *stream_);
+
 int coalign_anchor_decode(const float *cls, const float *reg, const float *dir, const float *anchors, int A, int H, int W,
                           int num_bins, float score_thr, float dir_offset, int order_hwl, const float *transform,
                           int capacity, const int32_t *count_in, int32_t *count_out, int32_t *cand_index,
                           float *cand_score, float *cand_box7, float *cand_corners, uint8_t *cand_keep, uint32_t *status,
                           void *workspace, size_t workspace_bytes, void *stream_) {
+    return anchor_decode_impl(cls, reg, dir, anchors, A, H, W, num_bins, score_thr, dir_offset, order_hwl, transform, capacity, count_in, count_out, cand_index, cand_score, cand_box7,
+                              cand_corners, cand_keep, status, workspace, workspace_bytes, nullptr, 0, stream_);
+}
+
+// Round 6: the FIRST decode call of a frame also zeroes the frame's counter / status words (n_clear <= 256 32-bit words at clear_words: count_in, count_out and status
+// normally point into them) -- the fill launch in front of the post-processing chain is gone.
+int coalign_anchor_decode_first(const float *cls, const float *reg, const float *dir, const float *anchors, int A, int H, int W,
+                                int num_bins, float score_thr, float dir_offset, int order_hwl, const float *transform,
+                                int capacity, const int32_t *count_in, int32_t *count_out, int32_t *cand_index,
+                                float *cand_score, float *cand_box7, float *cand_corners, uint8_t *cand_keep, uint32_t *status,
+                                void *workspace, size_t workspace_bytes, uint32_t *clear_words, int n_clear, void *stream_) {
+    if (!clear_words) return COALIGN_ERR_NULL_POINTER;
+    if (n_clear < 1 || n_clear > kBlock) return COALIGN_ERR_BAD_SHAPE;
+    return anchor_decode_impl(cls, reg, dir, anchors, A, H, W, num_bins, score_thr, dir_offset, order_hwl, transform, capacity, count_in, count_out, cand_index, cand_score, cand_box7,
+                              cand_corners, cand_keep, status, workspace, workspace_bytes, clear_words, n_clear, stream_);
+}
+
+static int anchor_decode_impl(const float *cls, const float *reg, const float *dir, const float *anchors, int A, int H, int W,
+                              int num_bins, float score_thr, float dir_offset, int order_hwl, const float *transform,
+                              int capacity, const int32_t *count_in, int32_t *count_out, int32_t *cand_index,
+                              float *cand_score, float *cand_box7, float *cand_corners, uint8_t *cand_keep, uint32_t *status,
+                              void *workspace, size_t workspace_bytes, uint32_t *clear_words, int n_clear, void *stream_) {
     using namespace coalign;
     hipStream_t stream = (hipStream_t)stream_;
     if (A <= 0 || H <= 0 || W <= 0 || capacity < 0 || (dir && num_bins <= 0)) return COALIGN_ERR_BAD_SHAPE;
@@ -198,6 +229,8 @@ int coalign_anchor_decode(const float *cls, const float *reg, const float *dir, 
     a.count_in = count_in; a.count_out = count_out; a.cand_index = cand_index; a.cand_score = cand_score;
     a.cand_box7 = cand_box7; a.cand_corners = cand_corners; a.cand_keep = cand_keep; a.status = status;
     a.block_counts = (int *)workspace;
+    a.clear = clear_words;
+    a.n_clear = clear_words ? n_clear : 0;
     const int blocks = (a.total + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(kBlock), 0, stream, a);
     int rc = check_launch();

@@ -47,6 +47,8 @@ SIGNATURES = {
     "coalign_anchor_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "coalign_anchor_decode": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P, c_int, P, P, P,
                                       P, P, P, P, P, P, c_size_t, P]),
+    "coalign_anchor_decode_first": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P, c_int, P, P, P,
+                                            P, P, P, P, P, P, c_size_t, P, c_int, P]),
     "coalign_nms_rotated_workspace_bytes": (c_size_t, [c_int, c_int]),
     "coalign_nms_rotated": (c_int, [P, c_int, c_int, P, P, c_int, P, c_float, c_int, P, P, P, c_size_t, P]),
     "coalign_nms_rotated_gather": (c_int, [P, P, P, c_int, P, c_float, c_int, P, P, POINTER(c_double), P, P, P, P, c_size_t, P]),

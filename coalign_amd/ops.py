@@ -593,8 +593,9 @@ class DecodeBuffers:
 @_device_op
 def anchor_decode(buf: DecodeBuffers, slot: int, cls: torch.Tensor, reg: torch.Tensor, dir_: Optional[torch.Tensor],
                   anchors_f32: torch.Tensor, score_thr: float, dir_offset: float, num_bins: int, order: str,
-                  transform: Optional[torch.Tensor]) -> None:
-    """Append one agent's candidates after slot ``slot`` of ``buf.counts`` (slot 0 must hold 0)."""
+                  transform: Optional[torch.Tensor], clear_frame: bool = False) -> None:
+    """Append one agent's candidates after slot ``slot`` of ``buf.counts`` (slot 0 must hold 0).  ``clear_frame`` (round 6, ``coalign_anchor_decode_first``): this
+    is the frame's first decode call -- its first launch zeroes ``buf.frame_words`` (what ``reset_frame`` did with a launch of its own)."""
     _need_gpu(cls, reg, anchors_f32)
     L = hip.lib()
     cls_c, reg_c = _f32c(cls), _f32c(reg)
@@ -606,13 +607,21 @@ def anchor_decode(buf: DecodeBuffers, slot: int, cls: torch.Tensor, reg: torch.T
         dir_c = None if dir_c is None else dir_c[0]
     A, H, W = cls_c.shape
     T = None if transform is None else _f32c(transform)
-    hip.check(L.coalign_anchor_decode(_ptr(cls_c), _ptr(reg_c), _ptr(dir_c), _ptr(anchors_f32), A, H, W, int(num_bins),
-                                      float(score_thr), float(dir_offset), int(order == "hwl"), _ptr(T), buf.capacity,
-                                      ctypes.c_void_p(buf.counts.data_ptr() + 4 * slot),
-                                      ctypes.c_void_p(buf.counts.data_ptr() + 4 * (slot + 1)),
-                                      _ptr(buf.cand_index), _ptr(buf.cand_score), _ptr(buf.cand_box7), _ptr(buf.cand_corners),
-                                      _ptr(buf.cand_keep), _ptr(buf.status), _ptr(buf.dec_ws), buf.dec_ws_bytes, _stream()),
-              "coalign_anchor_decode")
+    args = (_ptr(cls_c), _ptr(reg_c), _ptr(dir_c), _ptr(anchors_f32), A, H, W, int(num_bins),
+            float(score_thr), float(dir_offset), int(order == "hwl"), _ptr(T), buf.capacity,
+            ctypes.c_void_p(buf.counts.data_ptr() + 4 * slot),
+            ctypes.c_void_p(buf.counts.data_ptr() + 4 * (slot + 1)),
+            _ptr(buf.cand_index), _ptr(buf.cand_score), _ptr(buf.cand_box7), _ptr(buf.cand_corners),
+            _ptr(buf.cand_keep), _ptr(buf.status), _ptr(buf.dec_ws), buf.dec_ws_bytes)
+    if clear_frame and _os.environ.get("COALIGN_PP_FILL") == "1":      # (measurement switch: the separate fill launch of rounds 2-5)
+        buf.reset_frame()
+        clear_frame = False
+    if clear_frame:
+        if slot != 0:
+            raise ValueError("the frame's words are cleared by its FIRST decode call (slot 0)")
+        hip.check(L.coalign_anchor_decode_first(*args, _ptr(buf.frame_words), buf.frame_words.numel(), _stream()), "coalign_anchor_decode_first")
+    else:
+        hip.check(L.coalign_anchor_decode(*args, _stream()), "coalign_anchor_decode")
 
 
 @_device_op

@@ -95,7 +95,8 @@ class VoxelPostprocessor:
             raise ValueError("too many cavs for one post_process call")
         thr = self.params["target_args"]["score_threshold"]
         da = self.params.get("dir_args", {})
-        buf.reset_frame()
+        if not cavs:
+            buf.reset_frame()                             # (nothing to decode: the fill launch still opens the frame; otherwise the first decode call clears the words)
         for slot, cav_id in enumerate(cavs):
             assert cav_id in output_dict
             out = output_dict[cav_id]
@@ -113,7 +114,7 @@ class VoxelPostprocessor:
                     if t is not None:
                         t.record_stream(record_on)
             ops.anchor_decode(buf, slot, cls, reg, dirp, anchors, thr, da.get("dir_offset", 0.0), da.get("num_bins", 2),
-                              self.params["order"], T)
+                              self.params["order"], T, clear_frame=slot == 0)
             if "iou_preds" in out:
                 # IoU-head rescoring (voxel_postprocessor.py:335-339): scores *= ((clamp(sigmoid(iou), 0, 1) + 1) / 2) ** 4 on the candidates
                 # this cav just appended (rows counts[slot] .. counts[slot + 1], flat anchor index in cand_index); element-wise torch ops on
@@ -261,9 +262,8 @@ class UncertaintyVoxelPostprocessor(VoxelPostprocessor):
         da = self.params.get("dir_args", {})
         corners, boxes, uncertainty, any_box = [], [], [], False
         for i in range(n_agents):
-            buf.reset_frame()
             ops.anchor_decode(buf, 0, cls[i], reg[i], None if dirp is None else dirp[i], anchors, thr, da.get("dir_offset", 0.0),
-                              da.get("num_bins", 2), self.params["order"], None)
+                              da.get("num_bins", 2), self.params["order"], None, clear_frame=True)
             k_dev = buf.counts[1:2]
             ops.nms_rotated_device(buf.cand_corners, buf.cand_score, self.params["nms_thresh"], NMS_TOP, valid=None, k_dev=k_dev,
                                    keep=buf.keep, keep_count=buf.keep_count, ws=buf.nms_ws)

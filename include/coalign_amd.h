@@ -167,6 +167,13 @@ int coalign_anchor_decode(const float *cls, const float *reg, const float *dir, 
                           int capacity, const int32_t *count_in, int32_t *count_out, int32_t *cand_index,
                           float *cand_score, float *cand_box7, float *cand_corners, uint8_t *cand_keep, uint32_t *status,
                           void *workspace, size_t workspace_bytes, void *stream);
+/* Round 6: the FIRST decode call of a frame also zeroes the frame's counter / status words (n_clear <= 256 32-bit words at clear_words; count_in, count_out and
+ * status normally point into them: the per-frame state of voxel_postprocessor.py:243-402) -- one launch less in front of the post-processing chain. */
+int coalign_anchor_decode_first(const float *cls, const float *reg, const float *dir, const float *anchors, int A, int H, int W,
+                                int num_bins, float score_thr, float dir_offset, int order_hwl, const float *transform,
+                                int capacity, const int32_t *count_in, int32_t *count_out, int32_t *cand_index,
+                                float *cand_score, float *cand_box7, float *cand_corners, uint8_t *cand_keep, uint32_t *status,
+                                void *workspace, size_t workspace_bytes, uint32_t *clear_words, int n_clear, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * (4) Rotated NMS.  Replaces nms_rotated opencood/utils/box_utils.py:693-738 (+ compute_iou / convert_format
