@@ -108,6 +108,8 @@ S2_SKIP = os.environ.get("COALIGN_S2_SKIP", "1") != "0"
 
 # Round 6: the up-sampling heads of the three scales as ONE launch (coalign_pointwise_conv_emu_sp_multi) when they write a SplitMap; "0": one launch per scale.
 HEADS_ONE_LAUNCH = os.environ.get("COALIGN_HEADS_ONE_LAUNCH", "1") != "0"
+# Round 6: the merged cls / reg / dir 1 x 1 heads read the shrink header's map as a SplitMap (coalign_heads_sp); "0": channels-last float32 + the pointwise kernel.
+HEADS_SPLIT_IN = os.environ.get("COALIGN_HEADS_SP", "1") != "0"
 
 
 def split_maps_active() -> bool:
@@ -647,7 +649,8 @@ class DoubleConv(nn.Module):
         ok = lambda c: c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.out_channels % 64 == 0 and c.in_channels % 16 == 0
         return bool(HEAD_SPLIT_MAPS and split_maps_active() and not self.training and ok(c1) and ok(c2) and c1.weight.is_cuda)
 
-    def forward(self, x):
+    def forward(self, x, out_split: bool = False):
+        """``out_split`` (round 6): the caller's next layer reads a SplitMap (the merged heads, ``ops.heads_sp``) -- granted on the SplitMap route only."""
         if isinstance(x, ops.SplitMap):
             if not self.takes_split_maps():
                 x = x.dense()
@@ -655,7 +658,7 @@ class DoubleConv(nn.Module):
                 c1, c2 = self.double_conv[0], self.double_conv[2]
                 p1, p2 = _cache_of(self).get([c1.weight, c2.weight], lambda: (Conv3x3Pack(c1.weight.detach()), Conv3x3Pack(c2.weight.detach())))
                 y = ops.conv3x3_sp(x, p1.emu(16, True), c1.bias, p1.cout, None, True, out_split=True)
-                return ops.conv3x3_sp(y, p2.emu(16, True), c2.bias, p2.cout, None, True, out_split=False)
+                return ops.conv3x3_sp(y, p2.emu(16, True), c2.bias, p2.cout, None, True, out_split=out_split)
         if _fast_ok(self, x):
             c1, c2 = self.double_conv[0], self.double_conv[2]
 
@@ -692,9 +695,10 @@ class DownsampleConv(nn.Module):
     def takes_split_maps(self) -> bool:
         return len(self.layers) > 0 and self.layers[0].takes_split_maps()
 
-    def forward(self, x):
-        for layer in self.layers:
-            x = layer(x)
+    def forward(self, x, out_split: bool = False):
+        """``out_split`` (round 6): hand the caller the last layer's SplitMap when the layers run on the SplitMap route (else the float32 tensor, as always)."""
+        for i, layer in enumerate(self.layers):
+            x = layer(x, out_split=True) if (out_split and i == len(self.layers) - 1 and isinstance(x, ops.SplitMap)) else layer(x)
         return x
 
 

@@ -542,3 +542,80 @@ extern "C" int coalign_pointwise_conv_emu_sp_multi(int n_layers, const void *con
     hipLaunchKernelGGL(pointwise_emu_multi_kernel, dim3(m.first[n_layers]), dim3(256), lds, static_cast<hipStream_t>(stream), m);
     return check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the merged cls / reg / dir 1 x 1 heads (point_pillar_baseline_multiscale.py:123-133: three nn.Conv2d(C, k, 1) on the shrink header's map) reading that map AS
+// AN SP MAP (csrc/conv3x3_sp.hip) -- the shrink header's last convolution writes sp16 pairs in matrix-operand order, so a B operand is ONE 16-byte global load per lane
+// (32 consecutive pixels of a plane = 512 contiguous bytes): no pixel staging through LDS, no split on the VALU, and the sp16 arithmetic of the 3 x 3 layers (three fp16
+// products) instead of the six bf16 ones.  The pointwise kernel above took 25 us for this layer (32 pixels per workgroup, three of four wavefronts idle behind the
+// staging); here a wavefront owns 32 pixels x the (<= 32) head channels and streams 2 x 2 x 16 bytes per lane and 16 input channels, four steps ahead.
+// Weight image: ops.pack_conv1x1_sp_weight of the head weights padded to 64 rows ((9g): [Cin / 16][2 terms][2 channel halves][64 rows][8 cin] + zero group + 2^-k / 2^k words).
+namespace {
+
+typedef _Float16 hd_halfx8 __attribute__((ext_vector_type(8)));
+
+struct HeadsArgs {
+    const uint4 *__restrict__ x, *__restrict__ w;
+    const float *__restrict__ winv, *__restrict__ bias;
+    float *__restrict__ y;
+    int N, Cin, HW, M;
+};
+
+constexpr int kHeadsAhead = 4;      // steps (of 16 input channels) whose operands are in flight
+
+__global__ __launch_bounds__(256) void heads_sp_kernel(const HeadsArgs a) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, p = lane & 31;
+    const int n = blockIdx.y, px0 = (blockIdx.x * 4 + wave) * 32;
+    if (px0 >= a.HW) return;                                          // wave-uniform
+    const int px = px0 + p, pix = px < a.HW ? px : a.HW - 1;
+    const int CI16 = a.Cin / 16;
+    const uint4 *xb = a.x + ((size_t)n * CI16 * 4 + 2 * half) * a.HW + pix;      // plane (2 * half + term) of interval c: + (4 c + term) * HW
+    const uint4 *wb = a.w + half * 64 + p;                                       // term t of interval c: + (4 c + 2 t) * 64
+    floatx16 acc = {0}, accl = {0};
+    uint4 xh[kHeadsAhead], xl[kHeadsAhead], wh[kHeadsAhead], wl[kHeadsAhead];
+    auto load = [&](int c, int slot) {
+        xh[slot] = xb[(size_t)(4 * c) * a.HW];
+        xl[slot] = xb[(size_t)(4 * c + 1) * a.HW];
+        wh[slot] = wb[(4 * c) * 64];
+        wl[slot] = wb[(4 * c + 2) * 64];
+    };
+#pragma unroll
+    for (int k = 0; k < kHeadsAhead; ++k) load(k < CI16 ? k : CI16 - 1, k);
+    for (int c0 = 0; c0 < CI16; c0 += kHeadsAhead) {
+#pragma unroll
+        for (int k = 0; k < kHeadsAhead; ++k) {
+            const int c = c0 + k;
+            if (c < CI16) {
+                const hd_halfx8 bh = __builtin_bit_cast(hd_halfx8, xh[k]), bl = __builtin_bit_cast(hd_halfx8, xl[k]);
+                const hd_halfx8 ah = __builtin_bit_cast(hd_halfx8, wh[k]), al = __builtin_bit_cast(hd_halfx8, wl[k]);
+                const int cn = c + kHeadsAhead;
+                load(cn < CI16 ? cn : CI16 - 1, k);                   // (the tail reloads the last step: no branch in the stream)
+                accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accl, 0, 0, 0);      // w_h x_l'
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);        // w_h x_h
+                accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accl, 0, 0, 0);      // w_l' x_h
+            }
+        }
+    }
+    if (px >= a.HW) return;
+    float *yo = a.y + (size_t)n * a.M * a.HW + px;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = 8 * (e / 4) + 4 * half + (e % 4);               // accumulator e of lane (half, p): GEMM row m, pixel p
+        if (m < a.M) yo[(size_t)m * a.HW] = fmaf(accl[e], coalign::kSp16LowInv, acc[e]) * a.winv[m] + a.bias[m];
+    }
+}
+
+}  // namespace
+
+extern "C" int coalign_heads_sp(const void *x_sp, const void *w_sp, const float *bias, float *y, int N, int Cin, int M, int H, int W, void *stream) {
+    using namespace coalign;
+    if (!x_sp || !w_sp || !bias || !y) return COALIGN_ERR_NULL_POINTER;
+    if (N < 0 || Cin < 16 || M < 1 || H < 1 || W < 1) return COALIGN_ERR_BAD_SHAPE;
+    if ((Cin & 15) || M > 32 || N > 65535 || ((reinterpret_cast<uintptr_t>(x_sp) | reinterpret_cast<uintptr_t>(w_sp)) & 15)) return COALIGN_ERR_UNSUPPORTED;
+    if ((int64_t)N * Cin * H * W > (int64_t)1 << 32) return COALIGN_ERR_UNSUPPORTED;
+    if (N == 0) return COALIGN_OK;
+    HeadsArgs a{static_cast<const uint4 *>(x_sp), static_cast<const uint4 *>(w_sp),
+                reinterpret_cast<const float *>(static_cast<const char *>(w_sp) + (size_t)64 * Cin * 4 + 16), bias, y, N, Cin, H * W, M};
+    hipLaunchKernelGGL(heads_sp_kernel, dim3((unsigned)((H * W + 127) / 128), (unsigned)N), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch();
+}

@@ -36,14 +36,20 @@ def _run_heads(model: nn.Module, x: torch.Tensor) -> dict:
         heads.append(("unc_preds", model.unc_head))
     if model.use_dir:
         heads.append(("dir_preds", model.dir_head))
-    if not _fast_ok(model, x):
+    if isinstance(x, ops.SplitMap) and not heads_take_split_map(model, x):
+        x = x.dense()
+    if not isinstance(x, ops.SplitMap) and not _fast_ok(model, x):
         return {k: h(x) for k, h in heads}
 
     def build():
         return (torch.cat([h.weight for _, h in heads]).contiguous(), torch.cat([h.bias for _, h in heads]).contiguous())
     w, b = _cache_of(model.cls_head).get([t for _, h in heads for t in (h.weight, h.bias)], build)
     from . import backbone as _bb
-    if _bb.CONV_EMU_TERMS in (3, 16) and _bb.POINTWISE_EMU and w.shape[1] % 16 == 0 and w.shape[1] <= 512:
+    if isinstance(x, ops.SplitMap):
+        # round 6: the shrink header's last convolution handed its map over as a SplitMap: the merged heads read it with one 16-byte load per lane and operand
+        img = _bb._pw_cache_of(model.reg_head).get([t for _, h in heads for t in (h.weight, h.bias)], lambda: ops.pack_heads_sp_weight(w))      # (a cache slot of its own: reg_head's fold cache holds the pointwise image)
+        y = ops.heads_sp(x, img, b, w.shape[0])
+    elif _bb.CONV_EMU_TERMS in (3, 16) and _bb.POINTWISE_EMU and w.shape[1] % 16 == 0 and w.shape[1] <= 512:
         # round 4: the merged 1x1 heads on the hand-written pointwise kernel (split-bf16 matrix cores; GEMM rows padded to 32), reading the shrink
         # header's map in whatever layout it has and writing the NCHW maps the decode kernel reads -- no rocBLAS / bias pass in the frame
         pk = _cache_of(model.reg_head).get([t for _, h in heads for t in (h.weight, h.bias)], lambda: _bb.PointwisePack(w, False))
@@ -55,6 +61,16 @@ def _run_heads(model: nn.Module, x: torch.Tensor) -> dict:
         out[k] = y[:, c0:c0 + h.out_channels]
         c0 += h.out_channels
     return out
+
+
+def heads_take_split_map(model: nn.Module, x=None) -> bool:
+    """The merged heads can read the shrink header's map as a SplitMap (``ops.heads_sp``): <= 32 head channels in all, Cin % 16 == 0, eval mode, the switch on."""
+    from . import backbone as _bb
+    if not _bb.HEADS_SPLIT_IN or model.training or not _bb.split_maps_active():
+        return False
+    heads = [model.cls_head, model.reg_head] + ([model.unc_head] if getattr(model, "unc_head", None) is not None else []) + ([model.dir_head] if model.use_dir else [])
+    rows = sum(h.out_channels for h in heads)
+    return rows <= 32 and model.cls_head.in_channels % 16 == 0 and all(tuple(h.kernel_size) == (1, 1) for h in heads) and model.cls_head.weight.is_cuda
 
 
 def _single_agent_batch(data_dict: dict) -> dict:
@@ -190,7 +206,7 @@ class PointPillarBaselineMultiscale(nn.Module):
         want_split = bool(self.shrink_flag and x_is_cuda(fused) and self.shrink_conv.takes_split_maps())
         x = self.backbone.decode_multiscale_feature(fused, out_split=True) if want_split else self.backbone.decode_multiscale_feature(fused)
         if self.shrink_flag:
-            x = self.shrink_conv(x)
+            x = self.shrink_conv(x, out_split=isinstance(x, ops.SplitMap) and heads_take_split_map(self))
         elif isinstance(x, ops.SplitMap):
             x = x.dense()
         return _run_heads(self, x)

@@ -90,6 +90,7 @@ SIGNATURES = {
     "coalign_pointwise_conv_emu_sp": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "coalign_pointwise_conv_emu_sp_multi": (c_int, [c_int, POINTER(P), POINTER(P), POINTER(P), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                             POINTER(c_int32), POINTER(c_int32), P, c_int, c_int, c_int, P, P]),
+    "coalign_heads_sp": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "coalign_pose_graph_workspace_bytes": (c_size_t, [c_int]),
     "coalign_pose_graph_optimize": (c_int, [c_int, P, P, P, c_int, P, P, P, P, P, P, c_int, P, P, c_size_t, P]),
     "coalign_voxelize": (c_int, [P, POINTER(c_int64), c_int, POINTER(c_double), POINTER(c_double), c_int, c_int, c_int,

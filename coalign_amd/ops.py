@@ -1242,6 +1242,32 @@ def pointwise_heads_split(layers, out: "SplitMap", relu: bool = True) -> "SplitM
     return out
 
 
+def pack_heads_sp_weight(weight: torch.Tensor) -> torch.Tensor:
+    """[M <= 32, Cin(, 1, 1)] merged head weights -> the image ``heads_sp`` reads (include/coalign_amd.h (10e)): ``pack_conv1x1_sp_weight`` of the weights padded to 64 rows."""
+    w = weight.detach().float().reshape(weight.shape[0], weight.shape[1])
+    if w.shape[0] > 32:
+        raise ValueError("heads_sp serves at most 32 head channels")
+    pad = torch.zeros((64, w.shape[1]), dtype=torch.float32, device=w.device)
+    pad[: w.shape[0]] = w
+    return pack_conv1x1_sp_weight(pad)
+
+
+@_device_op
+def heads_sp(x: "SplitMap", w_sp: torch.Tensor, bias: torch.Tensor, M: int) -> torch.Tensor:
+    """The merged 1 x 1 heads on a SplitMap (``coalign_heads_sp``, (10e)): -> [N, M, H, W] float32, no activation."""
+    if not isinstance(x, SplitMap):
+        raise TypeError("heads_sp reads a SplitMap")
+    _need_gpu(x.data, w_sp, bias)
+    L = hip.lib()
+    N, Cin, H, W = x.shape
+    if w_sp.numel() != L.coalign_conv1x1_sp_weight_bytes(Cin, 64):
+        raise ValueError("heads_sp: the weight image does not match Cin")
+    y = torch.empty((N, M, H, W), dtype=torch.float32, device=x.device)
+    with _Timed("heads_sp"):
+        hip.check(L.coalign_heads_sp(_ptr(x.data), _ptr(w_sp), _ptr(_f32c(bias)), _ptr(y), N, Cin, M, H, W, _stream()), "coalign_heads_sp")
+    return y
+
+
 def boxes_overlap_bev(boxes_a: torch.Tensor, boxes_b: torch.Tensor) -> torch.Tensor:
     """OpenPCDet-semantics fp32 BEV overlap AREA matrix [Na, Nb] of (x, y, z, dx, dy, dz, heading) boxes."""
     _need_gpu(boxes_a, boxes_b)

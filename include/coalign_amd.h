@@ -517,6 +517,10 @@ int coalign_pointwise_conv_emu_sparse(const float *feats, int M_rows, const void
  * Cout, Ctot, c_off multiples of 16; M_padded == Cout * up * up; in_nhwc: 0 / 1 (input layout); range_flag as in (9e), may be NULL. */
 int coalign_pointwise_conv_emu_sp(const float *x, const void *w_split, const float *bias, void *y_sp, int N, int Cin, int Hin, int Win, int in_stride, int Cout,
                                   int up, int M_padded, int Ctot, int c_off, int relu, int in_nhwc, int32_t *range_flag, void *stream);
+/* (10e) Round 6: the merged cls / reg / dir 1 x 1 heads (point_pillar_baseline_multiscale.py:123-133, point_pillar.py: three nn.Conv2d(C, k, 1) on the shrink header's map,
+ * their weights concatenated to M <= 32 rows) reading that map as an SP MAP (9e): y [N, M, H, W] float32 NCHW = W x + bias, no activation.  w_sp: the image of (9g) built from
+ * the weights padded to 64 rows (coalign_conv1x1_sp_weight_bytes(Cin, 64) bytes).  One 16-byte load per lane and operand, no LDS, the sp16 arithmetic of the 3x3 layers. */
+int coalign_heads_sp(const void *x_sp, const void *w_sp, const float *bias, float *y, int N, int Cin, int M, int H, int W, void *stream);
 /* (10d) Round 6: (10c) for SEVERAL layers in ONE launch: the up-sampling heads of the backbone's scales (base_bev_backbone_resnet.py:121-138) are independent GEMMs on
  * one fused map each (2 200 ... 35 200 pixels), latency bound one after the other; as one launch their workgroups run side by side.  Layer i: x[i] float32
  * [N, Cin[i], Hin[i], Win[i]] (channels-last if in_nhwc[i]), split weight image w_split[i], bias[i]; writes channels [c_off[i], c_off[i] + Cout[i]) of the SP map

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(REPO, "include", "coalign_amd.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(coalign_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) == 67
+    assert len(declared) == 68
     lib = hip.lib()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/coalign_amd.h but not exported"
@@ -72,6 +72,8 @@ def test_argument_validation_without_a_gpu():
     assert lib.coalign_conv3x3_sp_s2_skip(one, one, one, one, one, one, 1, 64, 576, 8, 8, 1, null, null) == -3                         # Cout > 512 on the fused form
     assert lib.coalign_conv3x3_sp_s2_skip_sparse(one, 10, one, one, one, one, one, one, null, 1, 64, 64, 8, 8, 1, null, null) == -1     # no skip map
     assert lib.coalign_conv1x1_sp_weight_bytes(64, 128) == 128 * 64 * 4 + 16 + 128 * 8 and lib.coalign_conv1x1_sp_weight_bytes(24, 128) == 0
+    assert lib.coalign_heads_sp(null, one, one, one, 1, 256, 20, 8, 8, null) == -1 and lib.coalign_heads_sp(one, one, one, one, 1, 256, 40, 8, 8, null) == -3      # no map; more than 32 head channels
+    assert lib.coalign_heads_sp(one, one, one, one, 1, 250, 20, 8, 8, null) == -3 and lib.coalign_heads_sp(one, one, one, one, 0, 256, 20, 8, 8, null) == 0
     assert lib.coalign_conv3x3_sp_both(one, one, one, null, 0, one, ctypes.c_void_p(24), 1, 64, 64, 8, 8, 1, 0, null, null, 0, null) == -3      # ... not 16-byte aligned
 
 

@@ -236,3 +236,45 @@ def test_skip_as_a_tenth_tap_on_the_sparse_canvas_and_in_the_model():
         e = float((a - c).abs().max()) / float(c.abs().max())
         print(f"\nS2_SKIP on / off: {tuple(a.shape)} {e:.2e} of the scale")
         assert e <= 2e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 256, 20, 100, 352), (2, 64, 32, 37, 45), (1, 128, 6, 9, 70)])
+def test_merged_heads_on_a_split_map(shape):
+    """Round 6 (10e): ``coalign_heads_sp`` -- the merged 1 x 1 heads (point_pillar_baseline_multiscale.py:123-133) on the shrink header's SplitMap against a float64
+    product of the same 22-bit values: within 2e-6 of the scale."""
+    N, Ci, M, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = ops.SplitMap.pack(torch.relu(torch.randn((N, Ci, H, W), generator=g, device=DEV)))
+    w = torch.randn((M, Ci, 1, 1), generator=g, device=DEV) / Ci ** 0.5
+    w[M // 2] *= 1e-3                                            # a head channel three decades below the others: the per-row power-of-two scale
+    b = torch.randn(M, generator=g, device=DEV)
+    got = ops.heads_sp(x, ops.pack_heads_sp_weight(w), b, M)
+    ref = torch.einsum("oc,nchw->nohw", w[:, :, 0, 0].double(), x.dense().double()) + b.double().view(1, -1, 1, 1)
+    assert got.shape == ref.shape and got.is_contiguous()
+    for m in range(M):
+        err = float((got[:, m].double() - ref[:, m]).abs().max()) / float(ref[:, m].abs().max())
+        assert err <= 2e-6, (m, err)
+
+
+def test_model_with_heads_on_a_split_map_matches_the_pointwise_heads():
+    """Whole detector, ``HEADS_SPLIT_IN`` on / off: the head outputs agree to 2e-6 of their scale (22-bit pairs against three bf16 terms on the float32 map)."""
+    from coalign_amd.config import builtin_config
+    from coalign_amd.detector import build_model, to_device
+    from coalign_amd.synthetic import fill_parameters_, make_frame
+    h = builtin_config("opv2v_coalign")
+    model = build_model(h)
+    fill_parameters_(model, seed=0)
+    model = model.to(DEV).eval()
+    fr = to_device(make_frame(h, 3, pillars_per_agent=5000, seed=5, noise=(0.2, 0.2)), DEV)
+    saved, outs = backbone.HEADS_SPLIT_IN, {}
+    try:
+        for mode in (False, True):
+            backbone.HEADS_SPLIT_IN = mode
+            with torch.no_grad():
+                outs[mode] = {k: v.clone() for k, v in model(fr).items()}
+    finally:
+        backbone.HEADS_SPLIT_IN = saved
+    for k in ("cls_preds", "reg_preds", "dir_preds"):
+        e = float((outs[True][k] - outs[False][k]).abs().max()) / float(outs[False][k].abs().max())
+        print(f"\n{k}: heads on a SplitMap vs pointwise heads {e:.2e} of the scale")
+        assert outs[True][k].shape == outs[False][k].shape and e <= 2e-6, k

@@ -82,3 +82,11 @@ def per_scale():
     for (x, im, b, cout, up, off) in layers:
         ops.pointwise_conv(x, im, b, cout, up=up, relu=True, out=cat, c_off=off)
 print(json.dumps({"heads_three_launches_us": timed(per_scale, n=10), "heads_one_launch_us": timed(lambda: ops.pointwise_heads_split(layers, cat), n=10)}))
+# the merged 1 x 1 heads on the shrink header's map: pointwise kernel on channels-last float32 against coalign_heads_sp on the SplitMap (round 6)
+g = torch.Generator(device="cuda").manual_seed(9)
+xm = torch.relu(torch.randn((1, 256, 100, 352), generator=g, device="cuda"))
+wh = torch.randn((20, 256, 1, 1), generator=g, device="cuda") / 16.0
+bh = torch.randn(20, generator=g, device="cuda")
+xcl, xsp = xm.contiguous(memory_format=torch.channels_last), ops.SplitMap.pack(xm)
+pk, img = PointwisePack(wh, False).get(), ops.pack_heads_sp_weight(wh)
+print(json.dumps({"heads_1x1_pointwise_us": timed(lambda: ops.pointwise_conv(xcl, pk, bh, 20, relu=False), n=10), "heads_1x1_on_split_map_us": timed(lambda: ops.heads_sp(xsp, img, bh, 20), n=10)}))
