@@ -795,7 +795,17 @@ int launch_geo(SpArgs a, int out_kind, int split_policy, void *workspace, size_t
 
 template <int MODE>
 int launch_mode(int geo, const SpArgs &a, int out_kind, int split_policy, void *ws, size_t ws_bytes, hipStream_t s, SpLaunch *query) {
-    if constexpr (MODE == 6 || MODE == 7) {                           // two workgroups per CU / four loader wavefronts: the 8-wavefront geometries
+    if constexpr (MODE == 5) {                                        // front-loaded DMA issue: the product carries it for the 8-wavefront geometries only (dispatch_sp)
+        switch (geo) {
+            case 81: return launch_geo<1, 32, 8, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);
+            case 148: return launch_geo<4, 8, 8, 4, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);
+#if defined(COALIGN_LAB) || defined(SP_TRACE)
+            case 121: return launch_geo<1, 32, 12, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);
+            case 124: return launch_geo<2, 16, 12, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);
+#endif
+            default: return COALIGN_ERR_UNSUPPORTED;
+        }
+    } else if constexpr (MODE == 6 || MODE == 7) {                    // two workgroups per CU / four loader wavefronts: the 8-wavefront geometries
         switch (geo) {
             case 81: return launch_geo<1, 32, 8, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);   // 8 rows x 32 columns
             case 84: return launch_geo<2, 16, 8, 1, MODE>(a, out_kind, split_policy, ws, ws_bytes, s, query);   // 16 x 16 (2 x 16 blocks): maps 16 (mod 32) wide
@@ -856,6 +866,11 @@ int dispatch_sp(const SpArgs &a, int out_kind, int geometry, void *ws, size_t ws
             if (t64 * 5 <= 4LL * n_cu && t32 <= n_cu) geo = 326;
         }
     }
+    // Round 6: the 8-wavefront geometries issue their LDS-DMA FRONT-LOADED (mode 5: two instructions behind each of the first taps instead of one behind every tap):
+    // with the progress-based priority the wavefronts of a SIMD finish together, and the interval's closing s_waitcnt no longer waits ~300 clocks for a piece issued
+    // behind the last tap -- stage 3 44.6-45.4 -> 43.4-43.8 us, shrink header 2nd 120.0-120.3 -> 116.7-117.0 (profiles/round6/experiments/conv_sp_geometry_modes.txt);
+    // the 12-wavefront geometries gain nothing from it (47.2-47.9 -> 47.7-48.3, 41.1-41.3 -> 41.6-41.7).  Same arithmetic, same bits.
+    if (geometry < 1000 && (geo == 81 || geo == 148) && coalign::lab_env("COALIGN_SP_FRONT", 1)) mode = 5;
 #if defined(COALIGN_LAB) || defined(SP_TRACE)      // laboratory / trace builds carry every issue mode
     if (mode == 3 && (geo == 81 || geo == 148)) return launch_mode<3>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
     if (mode == 6) return launch_mode<6>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
@@ -865,7 +880,8 @@ int dispatch_sp(const SpArgs &a, int out_kind, int geometry, void *ws, size_t ws
     return mode == 0 ? launch_mode<0>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query) : mode == 2 ? launch_mode<2>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query)
                                                                                               : launch_mode<1>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
 #else
-    if (mode != kDefaultMode && geometry >= 1000) return COALIGN_ERR_UNSUPPORTED;      // (issue modes 0, 2-7 are measured-and-not-adopted variants: laboratory library only)
+    if (mode != kDefaultMode && geometry >= 1000) return COALIGN_ERR_UNSUPPORTED;      // (issue modes 0, 2-4, 6, 7 are measured-and-not-adopted variants: laboratory library only)
+    if (mode == 5) return launch_mode<5>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
     return launch_mode<kDefaultMode>(geo, a, out_kind, split_policy, ws, ws_bytes, s, query);
 #endif
 }
