@@ -302,8 +302,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_sp_s2_kernel(const S2Args 
                         }
                     }
                     if (more) {
+                        if (a.ablate & 32) {                       // laboratory: one operation behind every tap (the first version) instead of front-loaded
 #pragma unroll
-                        for (int k = s; k < OPS; k += 9) issue_op(nplan, nc, slot_next, k);
+                            for (int k = s; k < OPS; k += 9) issue_op(nplan, nc, slot_next, k);
+                        } else {                                   // front-loaded: two operations behind each of the first taps (as conv3x3_sp.hip's 8-wavefront geometries)
+#pragma unroll
+                            for (int k = 2 * s; k < 2 * s + 2; ++k)
+                                if (k < OPS) issue_op(nplan, nc, slot_next, k);
+                        }
                     }
                     if (s + 1 < 9) {
 #pragma unroll
@@ -441,7 +447,7 @@ int fill_common(S2Args &a, const void *w_split, const float *bias, void *y_sp, i
 #ifdef COALIGN_LAB
     a.trace = g_s2_trace;
 #endif
-    a.ablate = coalign::lab_env("COALIGN_S2_ABLATE", 0);      // laboratory build: 1 no weight DMA, 2 no patch DMA, 4 no matrix steps, 8 no stores, 16 fixed issue priorities
+    a.ablate = coalign::lab_env("COALIGN_S2_ABLATE", 0);      // laboratory build: 1 no weight DMA, 2 no patch DMA, 4 no matrix steps, 8 no stores, 16 fixed issue priorities, 32 DMA one piece per tap
     return COALIGN_OK;
 }
 
